@@ -1,0 +1,106 @@
+/* oracle/oracle.h -- C API of the CPU restatement.  TEST INFRASTRUCTURE ONLY (see gl.h header).
+ * "parity unpinned" by the reference: plonky_block_proof_gen has no tests; the
+ * arithmetic follows the published plonky2 algorithms reached from proof_gen.rs:44-52.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include "gl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------- K1/K2: field + NTT (plonky2_field fft conventions, natural order in and out) ---------- */
+void orc_dft_naive(const gl_t* in, gl_t* out, unsigned log_n, int inverse);
+void orc_ntt(gl_t* a, unsigned log_n);                 /* values[i] = sum_j a[j] w^(ij) */
+void orc_intt(gl_t* a, unsigned log_n);                /* inverse, includes 1/n */
+void orc_coset_ntt(gl_t* a, unsigned log_n, gl_t shift);   /* evaluate on shift*<w> */
+void orc_coset_intt(gl_t* a, unsigned log_n, gl_t shift);
+/* column-major batch: col c at cols + c*stride; uses OpenMP over columns */
+void orc_ntt_batch(gl_t* cols, unsigned log_n, size_t n_cols, size_t stride, int inverse);
+/* values (n) -> coeffs (n) -> LDE evaluations on 7*<w_{n*2^r}> (natural order), column-major.
+ * PolynomialBatch::from_values equivalent.  coeffs_out may be NULL. */
+void orc_lde_batch(const gl_t* values, gl_t* coeffs_out, gl_t* lde_out, unsigned log_n,
+                   unsigned rate_bits, size_t n_cols, int from_coeffs);
+
+/* ---------- K3/K4: Poseidon + Merkle ---------- */
+void orc_poseidon(gl_t state[12]);
+void orc_poseidon_batch(gl_t* states, size_t n);
+void orc_hash_no_pad(const gl_t* in, size_t len, gl_t out[4]);
+void orc_hash_or_noop(const gl_t* in, size_t len, gl_t out[4]);
+void orc_two_to_one(const gl_t l[4], const gl_t r[4], gl_t out[4]);
+/* Merkle tree over n_leaves = 2^log_leaves leaves.  Leaf k is the row bitrev(k) of the column-major
+ * matrix (n_cols columns, stride elements apart) when bitrev_rows != 0, else row k.
+ * digests_out: all levels, level 0 (leaves) first, down to the cap level: (2*n_leaves - 2^cap_h)*4
+ * words; the last 2^cap_h*4 words are the cap. */
+size_t orc_merkle_digest_words(unsigned log_leaves, unsigned cap_h);
+void orc_merkle_commit(const gl_t* cols, size_t stride, size_t n_cols, unsigned log_leaves,
+                       unsigned cap_h, int bitrev_rows, gl_t* digests_out);
+/* row-major leaves (leaf k = leaf_len consecutive words) -- used for FRI layers */
+void orc_merkle_commit_rows(const gl_t* leaves, size_t leaf_len, unsigned log_leaves, unsigned cap_h,
+                            gl_t* digests_out);
+void orc_merkle_path(const gl_t* digests, unsigned log_leaves, unsigned cap_h, size_t leaf,
+                     gl_t* path_out /* (log_leaves-cap_h)*4 */);
+int orc_merkle_verify(const gl_t* leaf_data, size_t leaf_len, size_t leaf, const gl_t* path,
+                      unsigned log_leaves, unsigned cap_h, const gl_t* cap);
+
+/* ---------- K7: challenger (plonky2::iop::challenger duplex sponge) ---------- */
+typedef struct {
+  gl_t state[12];
+  gl_t in[8]; unsigned n_in;
+  gl_t out[8]; unsigned n_out;
+} orc_challenger;
+void orc_ch_init(orc_challenger* c);
+void orc_ch_observe(orc_challenger* c, gl_t e);
+void orc_ch_observe_many(orc_challenger* c, const gl_t* e, size_t n);
+gl_t orc_ch_challenge(orc_challenger* c);
+gl2_t orc_ch_challenge_ext(orc_challenger* c);
+
+/* ---------- K6: FRI fold of one layer (evaluation domain, bit-reversed order) ---------- */
+/* in: m ext values in bit-reversed order of the coset shift*<w_m>; out: m/arity values of the folded
+ * polynomial on shift^arity*<w_{m/arity}>, bit-reversed.  Equals plonky2's coefficient-space fold. */
+void orc_fri_fold(const gl2_t* in, gl2_t* out, unsigned log_m, unsigned arity_bits, gl_t shift,
+                  gl2_t beta);
+
+/* ---------- synthetic STARK ---------- */
+typedef struct {
+  uint32_t log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits,
+      arity_bits, final_poly_bits;
+} orc_stark_cfg;
+
+uint32_t orc_cfg_n_aux(const orc_stark_cfg* c);
+uint32_t orc_cfg_n_quot(const orc_stark_cfg* c);
+uint32_t orc_cfg_n_layers(const orc_stark_cfg* c);
+size_t orc_proof_words(const orc_stark_cfg* c);
+
+/* deterministic witness: fills n_cols columns of 2^log_n rows (column-major) satisfying the AIR.
+ * consts: n_const columns (NULL when n_const == 0). */
+void orc_synth_constants(uint64_t seed, unsigned log_n, size_t n_const, gl_t* consts);
+void orc_synth_trace(uint64_t seed, const orc_stark_cfg* c, const gl_t* consts, gl_t* trace);
+
+/* preprocessed constants commitment (ProverState analog, prover_state.rs:80-100) */
+typedef struct orc_committed orc_committed;
+orc_committed* orc_commit_values(const gl_t* values, unsigned log_n, size_t n_cols, unsigned rate_bits,
+                                 unsigned cap_h);
+orc_committed* orc_commit_coeffs(const gl_t* coeffs, unsigned log_n, size_t n_cols, unsigned rate_bits,
+                                 unsigned cap_h);
+const gl_t* orc_committed_cap(const orc_committed* c);
+const gl_t* orc_committed_lde(const orc_committed* c);
+const gl_t* orc_committed_coeffs(const orc_committed* c);
+const gl_t* orc_committed_digests(const orc_committed* c);
+void orc_committed_free(orc_committed* c);
+
+/* Prove one table.  `ch` is the running transcript (trace cap NOT yet observed by this call: the
+ * caller observes caps first, plonky2_evm prover order).  ctl[4] = beta0,gamma0,beta1,gamma1.
+ * Returns 0 on success. proof_out has orc_proof_words(cfg) words. */
+int orc_stark_prove(const orc_stark_cfg* cfg, const orc_committed* consts, const orc_committed* trace,
+                    const gl_t* trace_values, const gl_t ctl[4], orc_challenger* ch, gl_t* proof_out);
+/* Verify; the caller must have driven `ch` identically (caps observed etc.). 0 = accept. */
+int orc_stark_verify(const orc_stark_cfg* cfg, const gl_t* const_cap, const gl_t ctl[4],
+                     orc_challenger* ch, const gl_t* proof);
+void orc_proof_digest(const orc_stark_cfg* cfg, const gl_t* proof, gl_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

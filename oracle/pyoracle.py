@@ -1,0 +1,269 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(the product package must never do so).  "parity unpinned" by the reference: see oracle/gl.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("core.c", "stark.c", "proofgen.c", "gl.h", "oracle.h",
+                                              "poseidon_rc.inc", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+class StarkCfg(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("log_n", "n_cols", "n_const", "deg_pow", "rate_bits", "cap_height",
+                                           "num_queries", "pow_bits", "arity_bits", "final_poly_bits")]
+
+
+class Challenger(C.Structure):
+    _fields_ = [("state", C.c_uint64 * 12), ("inb", C.c_uint64 * 8), ("n_in", C.c_uint),
+                ("outb", C.c_uint64 * 8), ("n_out", C.c_uint)]
+
+
+class Gl2(C.Structure):
+    _fields_ = [("c0", C.c_uint64), ("c1", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    vp, u, sz, i, u6 = C.c_void_p, C.c_uint, C.c_size_t, C.c_int, C.c_uint64
+    L.orc_dft_naive.argtypes = [u64p, u64p, u, i]
+    L.orc_ntt.argtypes = [u64p, u]
+    L.orc_intt.argtypes = [u64p, u]
+    L.orc_coset_ntt.argtypes = [u64p, u, u6]
+    L.orc_coset_intt.argtypes = [u64p, u, u6]
+    L.orc_ntt_batch.argtypes = [u64p, u, sz, sz, i]
+    L.orc_lde_batch.argtypes = [u64p, vp, u64p, u, u, sz, i]
+    L.orc_poseidon_batch.argtypes = [u64p, sz]
+    L.orc_hash_no_pad.argtypes = [u64p, sz, u64p]
+    L.orc_hash_or_noop.argtypes = [u64p, sz, u64p]
+    L.orc_merkle_digest_words.argtypes = [u, u]
+    L.orc_merkle_digest_words.restype = sz
+    L.orc_merkle_commit.argtypes = [u64p, sz, sz, u, u, i, u64p]
+    L.orc_merkle_commit_rows.argtypes = [u64p, sz, u, u, u64p]
+    L.orc_merkle_path.argtypes = [u64p, u, u, sz, u64p]
+    L.orc_merkle_verify.argtypes = [u64p, sz, sz, u64p, u, u, u64p]
+    L.orc_ch_init.argtypes = [C.POINTER(Challenger)]
+    L.orc_ch_observe.argtypes = [C.POINTER(Challenger), u6]
+    L.orc_ch_observe_many.argtypes = [C.POINTER(Challenger), u64p, sz]
+    L.orc_ch_challenge.argtypes = [C.POINTER(Challenger)]
+    L.orc_ch_challenge.restype = u6
+    L.orc_fri_fold.argtypes = [u64p, u64p, u, u, u6, Gl2]
+    cfgp = C.POINTER(StarkCfg)
+    for name in ("orc_cfg_n_aux", "orc_cfg_n_quot", "orc_cfg_n_layers"):
+        getattr(L, name).argtypes = [cfgp]
+        getattr(L, name).restype = C.c_uint32
+    L.orc_proof_words.argtypes = [cfgp]
+    L.orc_proof_words.restype = sz
+    L.orc_synth_constants.argtypes = [u6, u, sz, u64p]
+    L.orc_synth_trace.argtypes = [u6, cfgp, vp, u64p]
+    L.orc_commit_values.argtypes = [u64p, u, sz, u, u]
+    L.orc_commit_values.restype = vp
+    L.orc_commit_coeffs.argtypes = [u64p, u, sz, u, u]
+    L.orc_commit_coeffs.restype = vp
+    for name in ("orc_committed_cap", "orc_committed_lde", "orc_committed_coeffs", "orc_committed_digests"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.POINTER(C.c_uint64)
+    L.orc_committed_free.argtypes = [vp]
+    L.orc_stark_prove.argtypes = [cfgp, vp, vp, u64p, u64p, C.POINTER(Challenger), u64p]
+    L.orc_stark_verify.argtypes = [cfgp, vp, u64p, C.POINTER(Challenger), u64p]
+    L.orc_proof_digest.argtypes = [cfgp, u64p, u64p]
+    _lib = L
+    return L
+
+
+P = 0xFFFFFFFF00000001
+
+
+def arr(x):
+    return np.ascontiguousarray(x, dtype=np.uint64)
+
+
+def ntt(a, inverse=False):
+    a = arr(a).copy()
+    log_n = int(a.shape[-1]).bit_length() - 1
+    (lib().orc_intt if inverse else lib().orc_ntt)(a, log_n)
+    return a
+
+
+def dft_naive(a, inverse=False):
+    a = arr(a)
+    out = np.empty_like(a)
+    lib().orc_dft_naive(a, out, int(a.size).bit_length() - 1, int(inverse))
+    return out
+
+
+def ntt_batch(cols, inverse=False):
+    cols = arr(cols).copy()
+    n_cols, n = cols.shape
+    lib().orc_ntt_batch(cols, n.bit_length() - 1, n_cols, n, int(inverse))
+    return cols
+
+
+def lde_batch(values, rate_bits, from_coeffs=False):
+    values = arr(values)
+    n_cols, n = values.shape
+    coeffs = np.empty_like(values)
+    lde = np.empty((n_cols, n << rate_bits), dtype=np.uint64)
+    lib().orc_lde_batch(values, coeffs.ctypes.data, lde, n.bit_length() - 1, rate_bits, n_cols, int(from_coeffs))
+    return coeffs, lde
+
+
+def poseidon(states):
+    s = arr(states).copy().reshape(-1, 12)
+    lib().orc_poseidon_batch(s, s.shape[0])
+    return s
+
+
+def hash_no_pad(x):
+    x = arr(x)
+    out = np.empty(4, dtype=np.uint64)
+    lib().orc_hash_no_pad(x, x.size, out)
+    return out
+
+
+def hash_or_noop(x):
+    x = arr(x)
+    out = np.empty(4, dtype=np.uint64)
+    lib().orc_hash_or_noop(x, x.size, out)
+    return out
+
+
+def merkle_commit(cols, cap_h, bitrev_rows=True):
+    """cols: [n_cols, n_leaves] column-major.  Returns (digests[levels...,4], cap[2^cap_h,4])."""
+    cols = arr(cols)
+    n_cols, n = cols.shape
+    log_l = n.bit_length() - 1
+    words = lib().orc_merkle_digest_words(log_l, cap_h)
+    dig = np.empty(words, dtype=np.uint64)
+    lib().orc_merkle_commit(cols, n, n_cols, log_l, cap_h, int(bitrev_rows), dig)
+    return dig.reshape(-1, 4), dig[-(4 << cap_h):].reshape(-1, 4).copy()
+
+
+def merkle_commit_rows(leaves, cap_h):
+    leaves = arr(leaves)
+    n, leaf_len = leaves.shape
+    log_l = n.bit_length() - 1
+    dig = np.empty(lib().orc_merkle_digest_words(log_l, cap_h), dtype=np.uint64)
+    lib().orc_merkle_commit_rows(leaves, leaf_len, log_l, cap_h, dig)
+    return dig.reshape(-1, 4), dig[-(4 << cap_h):].reshape(-1, 4).copy()
+
+
+def fri_fold(values, arity_bits, shift, beta):
+    """values: [m, 2] ext elements, bit-reversed order."""
+    v = arr(values)
+    m = v.shape[0]
+    out = np.empty((m >> arity_bits, 2), dtype=np.uint64)
+    lib().orc_fri_fold(v, out, m.bit_length() - 1, arity_bits, shift, Gl2(int(beta[0]), int(beta[1])))
+    return out
+
+
+class PyChallenger:
+    def __init__(self):
+        self.c = Challenger()
+        lib().orc_ch_init(C.byref(self.c))
+
+    def observe(self, xs):
+        xs = arr(np.atleast_1d(xs)).ravel()
+        lib().orc_ch_observe_many(C.byref(self.c), xs, xs.size)
+
+    def challenge(self):
+        return int(lib().orc_ch_challenge(C.byref(self.c)))
+
+    def clone(self):
+        o = PyChallenger()
+        C.memmove(C.byref(o.c), C.byref(self.c), C.sizeof(Challenger))
+        return o
+
+
+def make_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, num_queries=84, pow_bits=16,
+             arity_bits=4, final_poly_bits=5):
+    return StarkCfg(log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits, arity_bits,
+                    final_poly_bits)
+
+
+class Committed:
+    def __init__(self, handle, n_cols, log_n, rate_bits, cap_h):
+        self.h, self.n_cols, self.log_n, self.rate_bits, self.cap_h = handle, n_cols, log_n, rate_bits, cap_h
+
+    @classmethod
+    def from_values(cls, values, rate_bits, cap_h, from_coeffs=False):
+        values = arr(values)
+        n_cols, n = values.shape
+        f = lib().orc_commit_coeffs if from_coeffs else lib().orc_commit_values
+        return cls(f(values, n.bit_length() - 1, n_cols, rate_bits, cap_h), n_cols, n.bit_length() - 1, rate_bits,
+                   cap_h)
+
+    def cap(self):
+        p = lib().orc_committed_cap(self.h)
+        return np.ctypeslib.as_array(p, shape=(1 << self.cap_h, 4)).copy()
+
+    def lde(self):
+        p = lib().orc_committed_lde(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.n_cols, 1 << (self.log_n + self.rate_bits))).copy()
+
+    def coeffs(self):
+        p = lib().orc_committed_coeffs(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.n_cols, 1 << self.log_n)).copy()
+
+    def __del__(self):
+        if self.h:
+            lib().orc_committed_free(self.h)
+            self.h = None
+
+
+def synth_constants(seed, log_n, n_const):
+    out = np.empty((n_const, 1 << log_n), dtype=np.uint64)
+    lib().orc_synth_constants(seed, log_n, n_const, out)
+    return out
+
+
+def synth_trace(seed, cfg, consts=None):
+    out = np.empty((cfg.n_cols, 1 << cfg.log_n), dtype=np.uint64)
+    lib().orc_synth_trace(seed, C.byref(cfg), consts.ctypes.data if consts is not None else None, out)
+    return out
+
+
+def stark_prove(cfg, trace_values, ctl, challenger, consts_committed=None, trace_committed=None):
+    """Runs the per-table prover.  The caller owns transcript setup (observe caps, draw ctl)."""
+    tc = trace_committed or Committed.from_values(trace_values, cfg.rate_bits, cfg.cap_height)
+    proof = np.zeros(lib().orc_proof_words(C.byref(cfg)), dtype=np.uint64)
+    rc = lib().orc_stark_prove(C.byref(cfg), consts_committed.h if consts_committed else None, tc.h,
+                               arr(trace_values), arr(ctl), C.byref(challenger.c), proof)
+    if rc != 0:
+        raise RuntimeError("orc_stark_prove failed: %d" % rc)
+    return proof
+
+
+def stark_verify(cfg, proof, ctl, challenger, const_cap=None):
+    cc = arr(const_cap).ctypes.data if const_cap is not None else None
+    return lib().orc_stark_verify(C.byref(cfg), cc, arr(ctl), C.byref(challenger.c), arr(proof))
+
+
+def proof_digest(cfg, proof):
+    out = np.empty(4, dtype=np.uint64)
+    lib().orc_proof_digest(C.byref(cfg), arr(proof), out)
+    return out
