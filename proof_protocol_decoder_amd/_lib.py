@@ -1,0 +1,54 @@
+"""ctypes loader for libbpg.so (C ABI: include/bpg.h).  Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "lib", "libbpg.so")
+
+BP_OK = 0
+STATUS_NAMES = {0: "BP_OK", -1: "BP_ERR_ABORTED", -2: "BP_ERR_INVALID_INPUT", -3: "BP_ERR_RANGE",
+                -4: "BP_ERR_DEVICE", -5: "BP_ERR_VERIFY", -6: "BP_ERR_UNSUPPORTED"}
+
+
+class BpgError(RuntimeError):
+    """Mirror of the reference's ProofGenError(String) (proof_gen.rs:22-36) with the status code."""
+
+    def __init__(self, code, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(code, str(code)), message))
+        self.code = code
+        self.message = message
+
+
+def lib_path():
+    return _PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_PATH):
+        raise ImportError(
+            "libbpg.so not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path." % _PATH)
+    L = C.CDLL(_PATH)
+    vp, u32, u64, i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.bp_last_error.restype = C.c_char_p
+    L.bp_version.restype = C.c_char_p
+    L.bp_device_count.restype = i
+    L.bp_ntt_batch.argtypes = [vp, u32, u32, u64, i, vp]
+    L.bp_lde_batch.argtypes = [vp, u64, vp, u64, vp, u64, u32, u32, u32, i, vp]
+    L.bp_poseidon_perm_batch.argtypes = [vp, u64, vp]
+    L.bp_merkle_digest_words.argtypes = [u32, u32]
+    L.bp_merkle_digest_words.restype = u64
+    L.bp_merkle_commit.argtypes = [vp, u64, u32, u32, u32, u32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != BP_OK:
+        raise BpgError(rc, lib().bp_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,155 @@
+// hash_kernels.hip -- K3/K4: Poseidon permutation batch, Merkle leaf hashing and tree build.
+//
+// Restates plonky2::hash::{poseidon, hashing::hash_n_to_m_no_pad, merkle_tree::MerkleTree::new}
+// as reached from plonky_block_proof_gen/src/proof_gen.rs:44-52 (PolynomialBatch::from_values).
+// Leaf hashing streams the LDE matrix once (8*L*C bytes, coalesced 8-byte column loads: lane =
+// row, so a wave reads 512 contiguous bytes per column) but is integer-ALU bound: ceil(C/8)
+// permutations per row.
+#include "common.hpp"
+#include "poseidon.cuh"
+
+namespace {
+
+__global__ void __launch_bounds__(256) perm_batch_kernel(uint64_t* __restrict__ states, uint64_t n) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = states[i * 12 + k];
+  poseidon::permute(s);
+#pragma unroll
+  for (int k = 0; k < 12; k++) states[i * 12 + k] = gl::canon(s[k]);
+}
+
+// One lane per LDE row.  Row `pos` = t*n + m (coset-major) is Merkle leaf bitrev_r(t)*n +
+// bitrev_n(m) (upstream reverse_index_bits order); the 32-byte digest is scattered there.
+__global__ void __launch_bounds__(256)
+leaf_hash_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
+                 uint32_t rate_bits, uint64_t* __restrict__ digests) {
+  const uint64_t rows = (uint64_t)1 << (log_n + rate_bits);
+  uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (pos >= rows) return;
+  const uint32_t t = (uint32_t)(pos >> log_n), m = (uint32_t)(pos & ((1u << log_n) - 1));
+  const uint64_t leaf = ((uint64_t)gl::bitrev(t, rate_bits) << log_n) | gl::bitrev(m, log_n);
+  uint64_t s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = 0;
+  const uint64_t* p = lde + pos;
+  if (n_cols <= 4) {  // hash_or_noop: short rows are the digest
+    for (uint32_t c = 0; c < n_cols; c++) s[c] = p[(uint64_t)c * stride];
+  } else {
+    uint32_t c = 0;
+    for (; c + 8 <= n_cols; c += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = p[(uint64_t)(c + k) * stride];
+      poseidon::permute(s);
+    }
+    if (c < n_cols) {  // ragged tail: overwrite only the first (n_cols - c) rate words
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (c + k < n_cols) s[k] = p[(uint64_t)(c + k) * stride];
+      poseidon::permute(s);
+    }
+  }
+  uint64_t* d = digests + leaf * 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++) d[k] = gl::canon(s[k]);
+}
+
+// Row-major leaves (FRI layers): leaf k = leaf_len consecutive words.
+__global__ void __launch_bounds__(256)
+leaf_hash_rows_kernel(const uint64_t* __restrict__ leaves, uint32_t leaf_len, uint64_t n_leaves,
+                      uint64_t* __restrict__ digests) {
+  uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (k >= n_leaves) return;
+  const uint64_t* p = leaves + k * leaf_len;
+  uint64_t s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = 0;
+  if (leaf_len <= 4) {
+    for (uint32_t c = 0; c < leaf_len; c++) s[c] = p[c];
+  } else {
+    for (uint32_t c = 0; c < leaf_len; c += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (c + i < leaf_len) s[i] = p[c + i];
+      poseidon::permute(s);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) digests[k * 4 + i] = gl::canon(s[i]);
+}
+
+// One lane per parent node of one level.
+__global__ void __launch_bounds__(256)
+merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= n_parents) return;
+  uint64_t l[4], r[4], o[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    l[k] = child[i * 8 + k];
+    r[k] = child[i * 8 + 4 + k];
+  }
+  poseidon::two_to_one(l, r, o);
+#pragma unroll
+  for (int k = 0; k < 4; k++) parent[i * 4 + k] = o[k];
+}
+
+}  // namespace
+
+namespace bpg {
+
+int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st) {
+  uint64_t* lvl = d_digests;
+  for (uint32_t l = log_leaves; l > cap_height; l--) {
+    uint64_t cnt = (uint64_t)1 << l;
+    uint64_t* nxt = lvl + cnt * 4;
+    merkle_level_kernel<<<ceil_div(cnt / 2, 256), 256, 0, st>>>(lvl, nxt, cnt / 2);
+    BPG_LAUNCH_CHECK();
+    lvl = nxt;
+  }
+  return BP_OK;
+}
+
+int merkle_commit_rows(const uint64_t* d_leaves, uint32_t leaf_len, uint32_t log_leaves, uint32_t cap_height,
+                       uint64_t* d_digests, hipStream_t st) {
+  uint64_t n = (uint64_t)1 << log_leaves;
+  leaf_hash_rows_kernel<<<ceil_div(n, 256), 256, 0, st>>>(d_leaves, leaf_len, n, d_digests);
+  BPG_LAUNCH_CHECK();
+  return merkle_upper_levels(d_digests, log_leaves, cap_height, st);
+}
+
+}  // namespace bpg
+
+extern "C" {
+
+uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {
+  return (((uint64_t)2 << log_leaves) - ((uint64_t)1 << cap_height)) * 4;
+}
+
+int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream) {
+  if (!n) return BP_OK;
+  if (!d_states) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_poseidon_perm_batch: null buffer");
+  perm_batch_kernel<<<bpg::ceil_div(n, 256), 256, 0, bpg::as_stream(stream)>>>(d_states, n);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+
+int bp_merkle_commit(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n,
+                     uint32_t rate_bits, uint32_t cap_height, uint64_t* d_digests, void* stream) {
+  const uint32_t log_leaves = log_n + rate_bits;
+  if (!d_lde || !d_digests) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_merkle_commit: null buffer");
+  if (log_leaves > 30 || cap_height > log_leaves || n_cols == 0 || lde_stride < ((uint64_t)1 << log_leaves))
+    return bpg::fail(BP_ERR_INVALID_INPUT,
+                     "bp_merkle_commit: bad shape (log_n=%u rate_bits=%u cap_height=%u n_cols=%u stride=%llu)",
+                     log_n, rate_bits, cap_height, n_cols, (unsigned long long)lde_stride);
+  hipStream_t st = bpg::as_stream(stream);
+  uint64_t rows = (uint64_t)1 << log_leaves;
+  leaf_hash_kernel<<<bpg::ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
+                                                            d_digests);
+  BPG_LAUNCH_CHECK();
+  return bpg::merkle_upper_levels(d_digests, log_leaves, cap_height, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+// ntt.hip -- K2: batched Goldilocks NTT / iNTT / coset LDE over trace columns.
+//
+// Restates plonky2_field::fft (fft, ifft, coset_fft) and PolynomialBatch::from_values/from_coeffs
+// (ifft -> zero-pad -> coset_fft(shift = 7)), reached from plonky_block_proof_gen/src/
+// proof_gen.rs:44-52.  MI355X design (not upstream's recursive CPU FFT):
+//   * values are natural order, coefficients are stored BIT-REVERSED, so the inverse transform is
+//     a decimation-in-frequency pass (natural -> bit-reversed) and the forward one a
+//     decimation-in-time pass (bit-reversed -> natural): no permutation pass ever touches HBM;
+//   * the LDE on 7*<w_{n 2^r}> is 2^r independent n-point coset NTTs (the zero padding makes the
+//     first r DIT stages trivial); coset t is written as one contiguous block ("coset-major");
+//   * a column block of up to 2^14 elements (128 KiB) lives in LDS: one coalesced 8-byte-per-lane
+//     read, log2(n) radix-2 butterfly stages done as radix-8 register passes (3 stages per LDS
+//     round trip), one coalesced write: HBM traffic == algorithmic bytes (16*n per column);
+//   * n > 2^14 adds strided global radix passes (each lane owns 2^k elements n/2^k apart, so every
+//     wave access is a contiguous 512-byte run of one column).
+// Roofline: HBM (8 TB/s peak).  Algorithmic bytes: NTT/iNTT 16*n*C; iNTT+LDE 8*n*C*(2+2^r).
+#include <map>
+#include <mutex>
+#include <tuple>
+#include "common.hpp"
+#include "gl.hpp"
+
+namespace {
+
+constexpr uint32_t LOG_BLK_MAX = 14;  // 2^14 * 8 B = 128 KiB of the 160 KiB LDS
+
+// ---- radix-2^LOGR register passes.  x[m] sits at position base + m*sub of a block of size
+// S = sub << LOGR; j = base mod sub.  `tw` is the table w_N^e, e < N/2, tw_shift = log2(N/S).
+template <int LOGR, bool CANON = true>
+__device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const uint64_t* __restrict__ tw,
+                                                uint32_t j, uint32_t log_sub, uint32_t tw_shift) {
+  constexpr int R = 1 << LOGR;
+#pragma unroll
+  for (int s = 0; s < LOGR; s++) {
+    const int half = R >> (s + 1);
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if (m & half) continue;
+      const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);  // position in block of size S>>s
+      const uint64_t w = tw[(uint64_t)p << (tw_shift + s)];
+      const uint64_t a = x[m], b = x[m + half];
+      x[m] = gl::addc(a, b);
+      x[m + half] = gl::mulc(gl::subc(a, b), w);
+    }
+  }
+}
+template <int LOGR>
+__device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const uint64_t* __restrict__ tw,
+                                                uint32_t j, uint32_t log_sub, uint32_t tw_shift) {
+  constexpr int R = 1 << LOGR;
+#pragma unroll
+  for (int s = 0; s < LOGR; s++) {
+    const int step = 1 << s;  // stage block size = sub << (s+1); tw_shift is for S = sub << LOGR
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+      if (m & step) continue;
+      const uint32_t p = j + ((uint32_t)(m & (step - 1)) << log_sub);
+      const uint64_t w = tw[(uint64_t)p << (tw_shift + (LOGR - 1 - s))];
+      const uint64_t a = x[m], t = gl::mulc(x[m + step], w);
+      x[m] = gl::addc(a, t);
+      x[m + step] = gl::subc(a, t);
+    }
+  }
+}
+
+// One pass over a block of 2^log_blk elements held in `buf` (LDS).  span_log = log2(S).
+template <int LOGR, bool DIF>
+__device__ __forceinline__ void lds_pass(uint64_t* buf, uint32_t log_blk, uint32_t span_log,
+                                         const uint64_t* __restrict__ tw) {
+  constexpr int R = 1 << LOGR;
+  const uint32_t log_sub = span_log - LOGR, sub_mask = (1u << log_sub) - 1;
+  const uint32_t n_q = 1u << (log_blk - LOGR);
+  for (uint32_t q = threadIdx.x; q < n_q; q += blockDim.x) {
+    const uint32_t j = q & sub_mask, blk = q >> log_sub;
+    const uint32_t base = (blk << span_log) + j;
+    uint64_t x[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) x[m] = buf[base + ((uint32_t)m << log_sub)];
+    if (DIF) dif_butterflies<LOGR>(x, tw, j, log_sub, log_blk - span_log);
+    else dit_butterflies<LOGR>(x, tw, j, log_sub, log_blk - span_log);
+#pragma unroll
+    for (int m = 0; m < R; m++) buf[base + ((uint32_t)m << log_sub)] = x[m];
+  }
+}
+
+struct LdsNttArgs {
+  const uint64_t* in;
+  uint64_t in_stride;        // elements between columns
+  uint64_t* out;
+  uint64_t out_stride;       // elements between columns
+  uint64_t out_coset_stride; // elements between cosets (DIT LDE); 0 otherwise
+  const uint64_t* tw;        // w_B^e (or inverse), e < B/2, B = 2^log_blk
+  const uint64_t* scale;     // DIT: per-position input scale, [coset][n_total]; nullptr = none
+  uint64_t out_scalar;       // DIF: multiply outputs (1/n); 1 = none
+  uint32_t log_blk;          // block resident in LDS
+  uint32_t log_n_total;      // whole column (>= log_blk)
+};
+
+// grid = (blocks per column, columns, cosets)
+template <bool DIF>
+__global__ void __launch_bounds__(1024) ntt_lds_kernel(LdsNttArgs a) {
+  extern __shared__ uint64_t buf[];
+  const uint32_t n = 1u << a.log_blk;
+  const uint64_t off = (uint64_t)blockIdx.x << a.log_blk;
+  const uint64_t* src = a.in + blockIdx.y * a.in_stride + off;
+  uint64_t* dst = a.out + blockIdx.y * a.out_stride + blockIdx.z * a.out_coset_stride + off;
+  if (!DIF && a.scale) {
+    const uint64_t* sc = a.scale + ((uint64_t)blockIdx.z << a.log_n_total) + off;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) buf[i] = gl::mulc(src[i], sc[i]);
+  } else {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) buf[i] = src[i];
+  }
+  __syncthreads();
+  const uint32_t rem = a.log_blk % 3;
+  if (DIF) {
+    uint32_t span = a.log_blk;
+    for (; span >= 3 && span > rem; span -= 3) {
+      lds_pass<3, true>(buf, a.log_blk, span, a.tw);
+      __syncthreads();
+    }
+    if (rem == 1) lds_pass<1, true>(buf, a.log_blk, 1, a.tw);
+    else if (rem == 2) lds_pass<2, true>(buf, a.log_blk, 2, a.tw);
+    if (rem) __syncthreads();
+  } else {
+    if (rem == 1) lds_pass<1, false>(buf, a.log_blk, 1, a.tw);
+    else if (rem == 2) lds_pass<2, false>(buf, a.log_blk, 2, a.tw);
+    if (rem) __syncthreads();
+    for (uint32_t span = rem + 3; span <= a.log_blk; span += 3) {
+      lds_pass<3, false>(buf, a.log_blk, span, a.tw);
+      __syncthreads();
+    }
+  }
+  if (DIF && a.out_scalar != 1) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = gl::mulc(buf[i], a.out_scalar);
+  } else {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = buf[i];
+  }
+}
+
+// Strided global pass for columns taller than one LDS block: the top LOGR stages (DIF) or the
+// last LOGR stages (DIT) of the n-point transform.  Lane q owns elements q + m*(S>>LOGR).
+// grid = (ceil(n >> LOGR / 256), columns, cosets).  `tw` is the n-point table.
+template <int LOGR, bool DIF>
+__global__ void __launch_bounds__(256)
+ntt_global_pass_kernel(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride,
+                       uint64_t coset_stride, uint32_t log_n, uint32_t span_log,
+                       const uint64_t* __restrict__ tw) {
+  constexpr int R = 1 << LOGR;
+  const uint32_t log_sub = span_log - LOGR;
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (1u << (log_n - LOGR))) return;
+  const uint32_t j = q & ((1u << log_sub) - 1), blk = q >> log_sub;
+  const uint64_t base = ((uint64_t)blk << span_log) + j;
+  const uint64_t* src = in + blockIdx.y * in_stride + blockIdx.z * coset_stride + base;
+  uint64_t* dst = out + blockIdx.y * out_stride + blockIdx.z * coset_stride + base;
+  uint64_t x[R];
+#pragma unroll
+  for (int m = 0; m < R; m++) x[m] = src[(uint64_t)m << log_sub];
+  if (DIF) dif_butterflies<LOGR>(x, tw, j, log_sub, log_n - span_log);
+  else dit_butterflies<LOGR>(x, tw, j, log_sub, log_n - span_log);
+#pragma unroll
+  for (int m = 0; m < R; m++) dst[(uint64_t)m << log_sub] = x[m];
+}
+
+// table builders ------------------------------------------------------------------------------
+__global__ void twiddle_table_kernel(uint64_t* out, uint32_t count, uint64_t w) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < count) out[e] = gl::pow(w, e);
+}
+// scale[t][pos] = (7 * w_M^t)^(bitrev_n(pos)),  M = n << rate_bits
+__global__ void coset_scale_table_kernel(uint64_t* out, uint32_t log_n, uint32_t rate_bits, uint64_t w_m) {
+  uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= (1u << log_n)) return;
+  uint32_t t = blockIdx.y;
+  uint64_t g = gl::mulc(gl::GENERATOR, gl::pow(w_m, t));
+  out[((uint64_t)t << log_n) + pos] = gl::pow(g, gl::bitrev(pos, log_n));
+}
+__global__ void bitrev_permute_kernel(uint64_t* cols, uint64_t stride, uint32_t log_n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log_n)) return;
+  uint32_t j = gl::bitrev(i, log_n);
+  if (i < j) {
+    uint64_t* c = cols + blockIdx.y * stride;
+    uint64_t a = c[i], b = c[j];
+    c[i] = b;
+    c[j] = a;
+  }
+}
+
+// ---- per-device table cache ----------------------------------------------------------------
+struct TableKey {
+  int dev, kind;  // kind 0: fwd twiddles, 1: inv twiddles, 2: coset scales
+  uint32_t log_n, rate_bits;
+  bool operator<(const TableKey& o) const {
+    return std::tie(dev, kind, log_n, rate_bits) < std::tie(o.dev, o.kind, o.log_n, o.rate_bits);
+  }
+};
+std::mutex g_table_mu;
+std::map<TableKey, uint64_t*> g_tables;
+
+}  // namespace
+
+namespace bpg {
+
+// Tables are built once per (device, size) on the null stream and kept for the process lifetime.
+int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out) {
+  int dev = 0;
+  BPG_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_table_mu);
+  TableKey key{dev, kind, log_n, kind == 2 ? rate_bits : 0};
+  auto it = g_tables.find(key);
+  if (it != g_tables.end()) {
+    *out = it->second;
+    return BP_OK;
+  }
+  uint64_t* d = nullptr;
+  if (kind == 2) {
+    uint64_t count = (uint64_t)1 << (log_n + rate_bits);
+    BPG_HIP(hipMalloc(&d, count * 8));
+    dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 1u << rate_bits);
+    coset_scale_table_kernel<<<grid, 256, 0, 0>>>(d, log_n, rate_bits, gl::root(log_n + rate_bits));
+  } else {
+    uint32_t count = log_n ? (1u << (log_n - 1)) : 1;
+    BPG_HIP(hipMalloc(&d, (uint64_t)count * 8));
+    uint64_t w = gl::root(log_n);
+    if (kind == 1) w = gl::inv(w);
+    twiddle_table_kernel<<<ceil_div(count, 256), 256, 0, 0>>>(d, count, w);
+  }
+  BPG_LAUNCH_CHECK();
+  BPG_HIP(hipStreamSynchronize(0));
+  g_tables[key] = d;
+  *out = d;
+  return BP_OK;
+}
+
+static uint32_t lds_threads(uint32_t log_blk) {
+  uint32_t t = log_blk >= 3 ? (1u << (log_blk - 3)) : 1;
+  return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+}
+
+template <bool DIF>
+static int launch_global_passes(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride,
+                                uint64_t coset_stride, uint32_t n_cols, uint32_t n_cosets, uint32_t log_n,
+                                const uint64_t* tw, hipStream_t st) {
+  // DIF: spans log_n, log_n-k1, ... down to > LOG_BLK_MAX;  DIT: the same spans in reverse order.
+  uint32_t spans[8], radix[8], cnt = 0;
+  for (uint32_t span = log_n; span > LOG_BLK_MAX;) {
+    uint32_t k = span - LOG_BLK_MAX > 4 ? 4 : span - LOG_BLK_MAX;
+    spans[cnt] = span; radix[cnt] = k; cnt++;
+    span -= k;
+  }
+  for (uint32_t idx = 0; idx < cnt; idx++) {
+    uint32_t i = DIF ? idx : cnt - 1 - idx;
+    const uint64_t* src = (idx == 0) ? in : out;
+    uint64_t src_stride = (idx == 0) ? in_stride : out_stride;
+    dim3 grid(ceil_div((uint64_t)1 << (log_n - radix[i]), 256), n_cols, n_cosets);
+    switch (radix[i]) {
+      case 1: ntt_global_pass_kernel<1, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+      case 2: ntt_global_pass_kernel<2, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+      case 3: ntt_global_pass_kernel<3, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+      default: ntt_global_pass_kernel<4, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+    }
+    BPG_LAUNCH_CHECK();
+  }
+  return BP_OK;
+}
+
+// values (natural) -> coefficients (bit-reversed), scaled by 1/n.  in may equal out.
+int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride, uint32_t log_n,
+                uint32_t n_cols, bool inverse, hipStream_t st) {
+  if (n_cols == 0) return BP_OK;
+  const uint32_t log_blk = log_n < LOG_BLK_MAX ? log_n : LOG_BLK_MAX;
+  const uint64_t *tw_n = nullptr, *tw_b = nullptr;
+  int rc;
+  if ((rc = get_table(inverse ? 1 : 0, log_blk, 0, &tw_b))) return rc;
+  const uint64_t* src = in;
+  uint64_t src_stride = in_stride;
+  if (log_n > LOG_BLK_MAX) {
+    if ((rc = get_table(inverse ? 1 : 0, log_n, 0, &tw_n))) return rc;
+    if ((rc = launch_global_passes<true>(in, in_stride, out, out_stride, 0, n_cols, 1, log_n, tw_n, st))) return rc;
+    src = out;
+    src_stride = out_stride;
+  }
+  LdsNttArgs a{};
+  a.in = src; a.in_stride = src_stride; a.out = out; a.out_stride = out_stride; a.out_coset_stride = 0;
+  a.tw = tw_b; a.scale = nullptr;
+  a.out_scalar = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
+  a.log_blk = log_blk; a.log_n_total = log_n;
+  dim3 grid(1u << (log_n - log_blk), n_cols, 1);
+  size_t lds = (size_t)8 << log_blk;
+  ntt_lds_kernel<true><<<grid, lds_threads(log_blk), lds, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+
+// coefficients (bit-reversed) -> values (natural) on n_cosets cosets; scale (nullable) is the
+// [coset][n] input scale table.  Coset t goes to out + t*coset_stride.
+int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride, uint64_t coset_stride,
+               uint32_t log_n, uint32_t n_cols, uint32_t n_cosets, const uint64_t* scale, bool inverse,
+               hipStream_t st) {
+  if (n_cols == 0) return BP_OK;
+  const uint32_t log_blk = log_n < LOG_BLK_MAX ? log_n : LOG_BLK_MAX;
+  const uint64_t *tw_n = nullptr, *tw_b = nullptr;
+  int rc;
+  if ((rc = get_table(inverse ? 1 : 0, log_blk, 0, &tw_b))) return rc;
+  LdsNttArgs a{};
+  a.in = in; a.in_stride = in_stride; a.out = out; a.out_stride = out_stride; a.out_coset_stride = coset_stride;
+  a.tw = tw_b; a.scale = scale; a.out_scalar = 1; a.log_blk = log_blk; a.log_n_total = log_n;
+  dim3 grid(1u << (log_n - log_blk), n_cols, n_cosets);
+  size_t lds = (size_t)8 << log_blk;
+  ntt_lds_kernel<false><<<grid, lds_threads(log_blk), lds, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  if (log_n > LOG_BLK_MAX) {
+    if ((rc = get_table(inverse ? 1 : 0, log_n, 0, &tw_n))) return rc;
+    if ((rc = launch_global_passes<false>(out, out_stride, out, out_stride, coset_stride, n_cols, n_cosets, log_n,
+                                          tw_n, st)))
+      return rc;
+  }
+  return BP_OK;
+}
+
+int bitrev_permute(uint64_t* cols, uint64_t stride, uint32_t log_n, uint32_t n_cols, hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), n_cols);
+  bitrev_permute_kernel<<<grid, 256, 0, st>>>(cols, stride, log_n);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+
+int init_ntt_kernels() {
+  // allow the full 128 KiB dynamic LDS block
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_lds_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << LOG_BLK_MAX));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_lds_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << LOG_BLK_MAX));
+  return BP_OK;
+}
+
+}  // namespace bpg
+
+extern "C" {
+
+int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir, void* stream) {
+  if (n_cols == 0) return BP_OK;
+  if (!d_cols) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_ntt_batch: null buffer");
+  if (log_n > 30 || col_stride < ((uint64_t)1 << log_n))
+    return bpg::fail(BP_ERR_INVALID_INPUT, "bp_ntt_batch: bad shape (log_n=%u stride=%llu)", log_n,
+                     (unsigned long long)col_stride);
+  hipStream_t st = bpg::as_stream(stream);
+  int rc;
+  if ((rc = bpg::init_ntt_kernels())) return rc;
+  switch (dir) {
+    case BP_NTT_FWD_BR2NAT:
+      return bpg::ntt_br2nat(d_cols, col_stride, d_cols, col_stride, 0, log_n, n_cols, 1, nullptr, false, st);
+    case BP_NTT_INV_NAT2BR:
+      return bpg::intt_nat2br(d_cols, col_stride, d_cols, col_stride, log_n, n_cols, true, st);
+    case BP_NTT_FWD_NAT:
+      if ((rc = bpg::bitrev_permute(d_cols, col_stride, log_n, n_cols, st))) return rc;
+      return bpg::ntt_br2nat(d_cols, col_stride, d_cols, col_stride, 0, log_n, n_cols, 1, nullptr, false, st);
+    case BP_NTT_INV_NAT:
+      if ((rc = bpg::intt_nat2br(d_cols, col_stride, d_cols, col_stride, log_n, n_cols, true, st))) return rc;
+      return bpg::bitrev_permute(d_cols, col_stride, log_n, n_cols, st);
+    default:
+      return bpg::fail(BP_ERR_INVALID_INPUT, "bp_ntt_batch: unknown dir %d", dir);
+  }
+}
+
+int bp_lde_batch(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_coeffs_out, uint64_t coeffs_stride,
+                 uint64_t* d_lde_out, uint64_t lde_stride, uint32_t log_n, uint32_t rate_bits, uint32_t n_cols,
+                 int from_coeffs, void* stream) {
+  if (n_cols == 0) return BP_OK;
+  const uint64_t n = (uint64_t)1 << log_n;
+  if (!d_in || !d_lde_out || (!from_coeffs && !d_coeffs_out))
+    return bpg::fail(BP_ERR_INVALID_INPUT, "bp_lde_batch: null buffer");
+  if (log_n + rate_bits > 30 || rate_bits > 4 || in_stride < n || lde_stride < (n << rate_bits) ||
+      (d_coeffs_out && coeffs_stride < n))
+    return bpg::fail(BP_ERR_INVALID_INPUT, "bp_lde_batch: bad shape (log_n=%u rate_bits=%u)", log_n, rate_bits);
+  hipStream_t st = bpg::as_stream(stream);
+  int rc;
+  if ((rc = bpg::init_ntt_kernels())) return rc;
+  const uint64_t* coeffs = d_in;
+  uint64_t cstride = in_stride;
+  if (!from_coeffs) {
+    if ((rc = bpg::intt_nat2br(d_in, in_stride, d_coeffs_out, coeffs_stride, log_n, n_cols, true, st))) return rc;
+    coeffs = d_coeffs_out;
+    cstride = coeffs_stride;
+  } else if (d_coeffs_out && d_coeffs_out != d_in) {
+    BPG_HIP(hipMemcpy2DAsync(d_coeffs_out, coeffs_stride * 8, d_in, in_stride * 8, n * 8, n_cols,
+                             hipMemcpyDeviceToDevice, st));
+  }
+  const uint64_t* scale = nullptr;
+  if ((rc = bpg::get_table(2, log_n, rate_bits, &scale))) return rc;
+  return bpg::ntt_br2nat(coeffs, cstride, d_lde_out, lde_stride, n, log_n, n_cols, 1u << rate_bits, scale, false,
+                         st);
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+"""L0 kernel-shaped operations on torch device buffers (thin wrappers over the C ABI).
+
+torch is used only for device memory and streams (int64 tensors carry the u64 bit patterns).
+Layouts are the ones documented in include/bpg.h: column-major matrices, natural-order values,
+bit-reversed coefficients, coset-major LDE.
+"""
+import torch
+
+from ._lib import check, lib
+
+NTT_FWD_BR2NAT, NTT_INV_NAT2BR, NTT_FWD_NAT, NTT_INV_NAT = 0, 1, 2, 3
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise ValueError("bpg ops need device tensors (there is no CPU fallback)")
+    if t.dtype != torch.int64 or not t.is_contiguous():
+        raise ValueError("bpg ops need contiguous int64 tensors holding u64 bit patterns")
+
+
+def ntt_batch_(cols, direction):
+    """In-place NTT of a [n_cols, n] column-major batch."""
+    _require_cuda(cols)
+    n_cols, n = cols.shape
+    check(lib().bp_ntt_batch(cols.data_ptr(), n.bit_length() - 1, n_cols, n, direction, _stream()))
+    return cols
+
+
+def lde_batch(inp, rate_bits, from_coeffs=False):
+    """values/coeffs [n_cols, n] -> (coeffs [n_cols, n] bit-reversed, lde [n_cols, n << rate_bits] coset-major)."""
+    _require_cuda(inp)
+    n_cols, n = inp.shape
+    coeffs = torch.empty_like(inp)
+    lde = torch.empty((n_cols, n << rate_bits), dtype=torch.int64, device=inp.device)
+    check(lib().bp_lde_batch(inp.data_ptr(), n, coeffs.data_ptr(), n, lde.data_ptr(), n << rate_bits,
+                             n.bit_length() - 1, rate_bits, n_cols, int(from_coeffs), _stream()))
+    return coeffs, lde
+
+
+def poseidon_perm_batch_(states):
+    _require_cuda(states)
+    check(lib().bp_poseidon_perm_batch(states.data_ptr(), states.numel() // 12, _stream()))
+    return states
+
+
+def merkle_commit(lde, log_n, rate_bits, cap_height):
+    """Returns the level-order digest buffer [words/4, 4]; the last 2^cap_height rows are the cap."""
+    _require_cuda(lde)
+    n_cols, rows = lde.shape
+    assert rows == 1 << (log_n + rate_bits)
+    words = lib().bp_merkle_digest_words(log_n + rate_bits, cap_height)
+    dig = torch.empty((words // 4, 4), dtype=torch.int64, device=lde.device)
+    check(lib().bp_merkle_commit(lde.data_ptr(), rows, n_cols, log_n, rate_bits, cap_height, dig.data_ptr(),
+                                 _stream()))
+    return dig

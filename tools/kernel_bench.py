@@ -1,0 +1,32 @@
+"""Times the L0 kernels at the synthetic-txn table shapes."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import proof_protocol_decoder_amd as bpg
+
+def timeit(f, reps=5):
+    f(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+        a.record(); f(); b.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    return best
+
+P = 0xFFFFFFFF00000001
+def rnd(shape):
+    return torch.randint(0, 2**62, shape, dtype=torch.int64, device="cuda")
+
+shapes = [("arith", 16, 128, 1), ("bytepack", 9, 128, 1), ("cpu", 12, 192, 1), ("keccak", 14, 2432, 1),
+          ("ksponge", 9, 512, 1), ("logic", 12, 320, 1), ("memory", 17, 16, 1), ("recursion", 13, 135, 3),
+          ("sweep12", 12, 2048, 1), ("sweep14", 14, 2048, 1), ("sweep16", 16, 256, 1), ("sweep18", 18, 256, 1), ("sweep20", 20, 64, 1)]
+for name, log_n, C, r in shapes:
+    n = 1 << log_n
+    v = rnd((C, n))
+    t_intt = timeit(lambda: bpg.ops.ntt_batch_(v, bpg.ops.NTT_INV_NAT2BR))
+    t_lde = timeit(lambda: bpg.ops.lde_batch(v, r))
+    coeffs, lde = bpg.ops.lde_batch(v, r)
+    t_mk = timeit(lambda: bpg.ops.merkle_commit(lde, log_n, r, 4))
+    perms = (n << r) * ((C + 7) // 8) + (n << r)
+    print("%-10s logn=%2d C=%4d r=%d | intt %7.3f ms %6.0f GB/s | intt+lde %7.3f ms %6.0f GB/s(alg) | merkle %8.3f ms %6.3f Gperm/s" % (
+        name, log_n, C, r, t_intt, 16 * n * C / t_intt / 1e6, t_lde, 8 * n * C * (2 + (1 << r)) / t_lde / 1e6, t_mk, perms / t_mk / 1e6), flush=True)
