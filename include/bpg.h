@@ -85,6 +85,22 @@ uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height);
 int bp_merkle_commit(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n,
                      uint32_t rate_bits, uint32_t cap_height, uint64_t* d_digests, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * L0.5 -- one table proof on the synthetic AIR: K2-K9 end to end.
+ * This is what plonky2_evm's prove_single_table does for one STARK table (reached from
+ * proof_gen.rs:44-52); it exists in the ABI so the whole per-table path can be parity-tested
+ * against the oracle.  Transcript prologue: observe constants cap (if n_const), observe trace cap,
+ * draw 4 CTL challenges.  The witness is generated on the device from (seed, const_seed).
+ * *out receives orc-identical proof words (little-endian u64), *out_len their byte length.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bp_stark_cfg {
+  uint32_t log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits, arity_bits,
+      final_poly_bits;
+} bp_stark_cfg;
+int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
+                             uint8_t** out, size_t* out_len);
+void bp_free_buffer(uint8_t* buf);
+
 #ifdef __cplusplus
 }
 #endif

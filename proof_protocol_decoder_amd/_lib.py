@@ -19,6 +19,20 @@ class BpgError(RuntimeError):
         self.message = message
 
 
+class StarkCfg(C.Structure):
+    """bp_stark_cfg (include/bpg.h)."""
+    _fields_ = [(n, C.c_uint32) for n in ("log_n", "n_cols", "n_const", "deg_pow", "rate_bits", "cap_height",
+                                           "num_queries", "pow_bits", "arity_bits", "final_poly_bits")]
+
+
+def take_buffer(ptr, length):
+    """Copy a library-allocated buffer into bytes and release it with bp_free_buffer."""
+    try:
+        return C.string_at(ptr, length.value)
+    finally:
+        lib().bp_free_buffer(ptr)
+
+
 def lib_path():
     return _PATH
 
@@ -45,6 +59,10 @@ def lib():
     L.bp_merkle_digest_words.argtypes = [u32, u32]
     L.bp_merkle_digest_words.restype = u64
     L.bp_merkle_commit.argtypes = [vp, u64, u32, u32, u32, u32, vp, vp]
+    L.bp_stark_prove_synthetic.argtypes = [C.POINTER(StarkCfg), u64, u64, i, C.POINTER(C.POINTER(C.c_uint8)),
+                                           C.POINTER(C.c_size_t)]
+    L.bp_free_buffer.argtypes = [C.POINTER(C.c_uint8)]
+    L.bp_free_buffer.restype = None
     _lib = L
     return L
 

@@ -167,12 +167,14 @@ __global__ void twiddle_table_kernel(uint64_t* out, uint32_t count, uint64_t w) 
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < count) out[e] = gl::pow(w, e);
 }
-// scale[t][pos] = (7 * w_M^t)^(bitrev_n(pos)),  M = n << rate_bits
-__global__ void coset_scale_table_kernel(uint64_t* out, uint32_t log_n, uint32_t rate_bits, uint64_t w_m) {
+// scale[t][pos] = (7 * w_M^t)^(+-bitrev_n(pos)),  M = n << rate_bits
+__global__ void coset_scale_table_kernel(uint64_t* out, uint32_t log_n, uint32_t rate_bits, uint64_t w_m,
+                                         int inverse) {
   uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= (1u << log_n)) return;
   uint32_t t = blockIdx.y;
   uint64_t g = gl::mulc(gl::GENERATOR, gl::pow(w_m, t));
+  if (inverse) g = gl::inv(g);
   out[((uint64_t)t << log_n) + pos] = gl::pow(g, gl::bitrev(pos, log_n));
 }
 __global__ void bitrev_permute_kernel(uint64_t* cols, uint64_t stride, uint32_t log_n) {
@@ -189,7 +191,7 @@ __global__ void bitrev_permute_kernel(uint64_t* cols, uint64_t stride, uint32_t 
 
 // ---- per-device table cache ----------------------------------------------------------------
 struct TableKey {
-  int dev, kind;  // kind 0: fwd twiddles, 1: inv twiddles, 2: coset scales
+  int dev, kind;  // kind 0: fwd twiddles, 1: inv twiddles, 2: coset scales, 3: inverse coset scales
   uint32_t log_n, rate_bits;
   bool operator<(const TableKey& o) const {
     return std::tie(dev, kind, log_n, rate_bits) < std::tie(o.dev, o.kind, o.log_n, o.rate_bits);
@@ -207,18 +209,18 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
   int dev = 0;
   BPG_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_table_mu);
-  TableKey key{dev, kind, log_n, kind == 2 ? rate_bits : 0};
+  TableKey key{dev, kind, log_n, kind >= 2 ? rate_bits : 0};
   auto it = g_tables.find(key);
   if (it != g_tables.end()) {
     *out = it->second;
     return BP_OK;
   }
   uint64_t* d = nullptr;
-  if (kind == 2) {
+  if (kind >= 2) {
     uint64_t count = (uint64_t)1 << (log_n + rate_bits);
     BPG_HIP(hipMalloc(&d, count * 8));
     dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 1u << rate_bits);
-    coset_scale_table_kernel<<<grid, 256, 0, 0>>>(d, log_n, rate_bits, gl::root(log_n + rate_bits));
+    coset_scale_table_kernel<<<grid, 256, 0, 0>>>(d, log_n, rate_bits, gl::root(log_n + rate_bits), kind == 3);
   } else {
     uint32_t count = log_n ? (1u << (log_n - 1)) : 1;
     BPG_HIP(hipMalloc(&d, (uint64_t)count * 8));
@@ -326,13 +328,19 @@ int bitrev_permute(uint64_t* cols, uint64_t stride, uint32_t log_n, uint32_t n_c
   return BP_OK;
 }
 
-int init_ntt_kernels() {
+static int init_ntt_kernels_once() {
   // allow the full 128 KiB dynamic LDS block
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_lds_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << LOG_BLK_MAX));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_lds_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << LOG_BLK_MAX));
   return BP_OK;
+}
+int init_ntt_kernels() {
+  static std::once_flag once;
+  static int rc = BP_OK;
+  std::call_once(once, [] { rc = init_ntt_kernels_once(); });
+  return rc;
 }
 
 }  // namespace bpg

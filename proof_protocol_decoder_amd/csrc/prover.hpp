@@ -1,0 +1,125 @@
+// prover.hpp -- host side of the per-table STARK prover: transcript, device arena, commitments.
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "common.hpp"
+#include "gl.hpp"
+#include "stark_kernels.hpp"
+
+namespace bpg {
+
+// ---- host Poseidon (transcript only: K7 stays on the host) ----
+void poseidon_host(uint64_t s[12]);
+void hash_no_pad_host(const uint64_t* in, size_t len, uint64_t out[4]);
+
+// plonky2::iop::challenger::Challenger: overwrite-mode duplex sponge, outputs popped from the back.
+class Challenger {
+ public:
+  Challenger() { std::memset(this, 0, sizeof(*this)); }
+  void observe(uint64_t e) {
+    n_out_ = 0;
+    in_[n_in_++] = e;
+    if (n_in_ == 8) duplex();
+  }
+  void observe(const uint64_t* e, size_t n) {
+    for (size_t i = 0; i < n; i++) observe(e[i]);
+  }
+  void observe(gl::Ext e) {
+    observe(e.c0);
+    observe(e.c1);
+  }
+  uint64_t challenge() {
+    if (n_in_ || !n_out_) duplex();
+    return out_[--n_out_];
+  }
+  gl::Ext challenge_ext() {
+    uint64_t a = challenge(), b = challenge();
+    return gl::Ext{a, b};
+  }
+  // state a PoW candidate is spliced into (fri_proof_of_work's duplex_intermediate_state)
+  void pow_state(uint64_t st[12], uint32_t* pos) const {
+    std::memcpy(st, state_, sizeof(state_));
+    for (unsigned i = 0; i < n_in_; i++) st[i] = in_[i];
+    *pos = n_in_;
+  }
+
+ private:
+  void duplex() {
+    for (unsigned i = 0; i < n_in_; i++) state_[i] = in_[i];
+    n_in_ = 0;
+    poseidon_host(state_);
+    std::memcpy(out_, state_, 8 * sizeof(uint64_t));
+    n_out_ = 8;
+  }
+  uint64_t state_[12], in_[8], out_[8];
+  unsigned n_in_, n_out_;
+};
+
+// ---- shapes ----
+struct StarkCfg {
+  uint32_t log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits, arity_bits,
+      final_poly_bits;
+};
+struct ProofLayout {
+  size_t cap_words, trace_cap, aux_cap, quot_cap, open_zeta, open_next, open_first, fri_caps, final_poly, pow,
+      queries, query_words, total;
+  uint32_t n_aux, n_quot, n_layers, final_len, n_zeta, n_next, depth0;
+};
+constexpr uint64_t PROOF_MAGIC = 0x4B52415453475042ULL;  // "BPGSTARK"
+constexpr size_t PROOF_HDR_WORDS = 16;
+int check_cfg(const StarkCfg& c);
+ProofLayout proof_layout(const StarkCfg& c);
+void proof_digest(const StarkCfg& c, const uint64_t* proof, uint64_t out[4]);
+
+// ---- device memory: one bump arena per worker, no hipMalloc/hipFree on the proving path ----
+class DeviceArena {
+ public:
+  int init(size_t bytes);
+  void destroy();
+  // returns nullptr when exhausted (caller reports BP_ERR_DEVICE)
+  uint64_t* alloc_words(size_t words);
+  size_t mark() const { return off_; }
+  void release(size_t m) { off_ = m; }
+  size_t capacity() const { return cap_; }
+  size_t high_water() const { return high_; }
+
+ private:
+  char* base_ = nullptr;
+  size_t cap_ = 0, off_ = 0, high_ = 0;
+};
+
+struct Committed {
+  uint64_t *coeffs = nullptr, *lde = nullptr, *digests = nullptr;
+  uint32_t log_n = 0, n_cols = 0, rate_bits = 0, cap_height = 0;
+  std::vector<uint64_t> cap;  // host copy, 2^cap_height * 4 words
+};
+
+// One per host thread that proves: its own stream, arena and pinned staging buffer.
+struct Worker {
+  hipStream_t stream = nullptr;
+  DeviceArena arena;
+  uint64_t* pinned = nullptr;
+  size_t pinned_words = 0;
+  unsigned long long* d_pow_result = nullptr;
+  const volatile int32_t* abort_flag = nullptr;
+  int device = 0;
+
+  int init(int device, size_t arena_bytes);
+  void destroy();
+  int d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words);  // async copy + stream sync
+  bool aborted() const { return abort_flag && *abort_flag; }
+};
+
+// PolynomialBatch::from_values / from_coeffs: LDE + Merkle.  d_in is n_cols x n (values natural, or
+// bit-reversed coefficients when from_coeffs; then the commitment aliases d_in as its coefficients).
+int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
+           uint32_t cap_height, bool from_coeffs, Committed* out);
+
+// prove_single_table on the synthetic AIR.  The caller has already observed the trace cap(s) and
+// drawn ctl (plonky2_evm prover order).  Fills `proof` (proof_layout(cfg).total words).
+int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
+                const uint64_t* d_trace_values, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof);
+
+}  // namespace bpg

@@ -1,0 +1,533 @@
+// stark_kernels.hip -- K5/K6/K8/K9 and the glue kernels of the per-table STARK prover.
+//
+// Device side of prove_single_table / PolynomialBatch::prove_openings / fri_proof (upstream
+// plonky2_evm / plonky2 @ 265d46a9, reached from plonky_block_proof_gen/src/proof_gen.rs:44-52).
+// The AIR is the synthetic one of DESIGN.md section 4.  Layouts: include/bpg.h.
+// MI355X-first choices that differ from upstream's CPU code but give identical field values:
+//   * quotient: one lane per LDE row, constraints split into column chunks (Horner partials
+//     recombined with alpha powers) so short-but-wide tables still fill 256 CUs;
+//   * openings: dot product of each bit-reversed coefficient column with a power vector
+//     zeta^bitrev(pos) (no Horner dependency chain, coalesced);
+//   * FRI: alpha-combination in coefficient space (one pass over all coefficients), division by
+//     (X - z) pointwise on the coset, folding in the EVALUATION domain (upstream folds
+//     coefficients and re-FFTs every layer).
+#include "common.hpp"
+#include "gl.hpp"
+#include "poseidon.cuh"
+#include "stark_kernels.hpp"
+
+namespace {
+
+using gl::Ext;
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t rnd(uint64_t seed, uint64_t col, uint64_t row) {
+  return gl::canon(splitmix64(seed ^ (col << 32) ^ row));
+}
+__device__ __forceinline__ uint64_t pow_e(uint64_t t, uint32_t e) {
+  return e == 3 ? gl::mulc(gl::mulc(t, t), t) : t;
+}
+// w_n^m from the half-size table tw[e] = w_n^e, e < n/2
+__device__ __forceinline__ uint64_t root_pow(const uint64_t* __restrict__ tw, uint32_t log_n, uint32_t m) {
+  if (log_n == 0) return 1;
+  const uint32_t half = 1u << (log_n - 1);
+  uint64_t w = tw[m & (half - 1)];
+  return (m & half) ? gl::negc(w) : w;
+}
+
+// ---------------------------------------------------------------- synthetic witness
+__global__ void __launch_bounds__(256)
+synth_const_kernel(uint64_t* out, uint32_t log_n, uint32_t n_const, uint64_t seed) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i >= ((uint64_t)n_const << log_n)) return;
+  out[i] = rnd(seed ^ 0xC0115700C0115700ULL, i >> log_n, i & ((1ull << log_n) - 1));
+}
+// grid = (rows/256, groups + 1): group g < G fills columns 4g..4g+3; blockIdx.y == G fills the tail.
+__global__ void __launch_bounds__(256)
+synth_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ consts, uint32_t log_n, uint32_t n_cols,
+                   uint32_t n_const, uint32_t deg_pow, uint64_t seed) {
+  const uint32_t n = 1u << log_n, G = n_cols / 4;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t g = blockIdx.y;
+  if (g == G) {
+    for (uint32_t c = 4 * G; c < n_cols; c++) t[(uint64_t)c * n + i] = rnd(seed, c, i);
+    return;
+  }
+  uint64_t* a = t + (uint64_t)(4 * g) * n;
+  const uint64_t av = rnd(seed, 4 * g, i), bv = rnd(seed, 4 * g + 1, i);
+  const uint64_t q = n_const ? consts[(uint64_t)(g % n_const) * n + i] : 1;
+  const uint64_t ab = gl::mulc(av, bv);
+  const uint64_t cv = gl::addc(ab, gl::mulc(q, av));
+  a[i] = av;
+  a[n + i] = bv;
+  a[2 * (uint64_t)n + i] = cv;
+  if (i == 0) a[3 * (uint64_t)n] = gl::addc(av, bv);
+  if (i + 1 < n) a[3 * (uint64_t)n + i + 1] = gl::addc(pow_e(gl::mulc(ab, cv), deg_pow), bv);
+}
+
+// ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
+// z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
+// One workgroup per aux column: per-lane chunk products, LDS suffix scan, then the chunk itself.
+__global__ void __launch_bounds__(1024)
+aux_suffix_product_kernel(const uint64_t* __restrict__ trace, uint64_t* __restrict__ aux, uint32_t log_n,
+                          bpg::Ctl ctl) {
+  __shared__ uint64_t part[1024];
+  const uint32_t n = 1u << log_n, k = blockIdx.x, T = blockDim.x;
+  const uint64_t *a = trace + (uint64_t)(8 * k) * n, *b = a + n;
+  const uint64_t beta = ctl.v[2 * (k & 1)], gamma = ctl.v[2 * (k & 1) + 1];
+  uint64_t* z = aux + (uint64_t)k * n;
+  const uint32_t chunk = (n + T - 1) / T, lo = threadIdx.x * chunk, hi = min(lo + chunk, n);
+  uint64_t p = 1;
+  for (uint32_t i = lo; i < hi; i++) p = gl::mulc(p, gl::addc(gl::addc(gamma, a[i]), gl::mulc(beta, b[i])));
+  part[threadIdx.x] = p;
+  __syncthreads();
+  // inclusive suffix scan over the per-lane products (Hillis-Steele)
+  for (uint32_t d = 1; d < T; d <<= 1) {
+    uint64_t v = part[threadIdx.x];
+    uint64_t o = threadIdx.x + d < T ? part[threadIdx.x + d] : 1;
+    __syncthreads();
+    part[threadIdx.x] = gl::mulc(v, o);
+    __syncthreads();
+  }
+  uint64_t carry = threadIdx.x + 1 < T ? part[threadIdx.x + 1] : 1;  // product of everything after my chunk
+  for (uint32_t i = hi; i-- > lo;) {
+    carry = gl::mulc(carry, gl::addc(gl::addc(gamma, a[i]), gl::mulc(beta, b[i])));
+    z[i] = carry;
+  }
+}
+
+// ---------------------------------------------------------------- K5 quotient
+// Constraint order: per group g: all-rows, transition, first-row; then per
+// aux column: transition, last-row.  acc_j = acc_j*alpha_j + c (starky ConstraintConsumer).
+struct Acc {
+  uint64_t a0, a1, al0, al1;
+  __device__ __forceinline__ void push(uint64_t c) {
+    a0 = gl::addc(gl::mulc(a0, al0), c);
+    a1 = gl::addc(gl::mulc(a1, al1), c);
+  }
+};
+struct RowPoint {
+  uint64_t z_last, l_first, l_last;
+};
+__device__ __forceinline__ RowPoint row_point(const bpg::QuotArgs& q, uint32_t t, uint32_t m) {
+  const uint64_t x = gl::mulc(q.g_t[t], root_pow(q.tw_n, q.log_n, m));
+  const uint64_t zh = q.zh_t[t];
+  RowPoint p;
+  p.z_last = gl::subc(x, q.g_inv);
+  const uint64_t zn = gl::mulc(zh, q.n_inv);
+  p.l_first = gl::mulc(zn, gl::inv(gl::subc(x, 1)));
+  p.l_last = gl::mulc(zn, gl::inv(gl::subc(gl::mulc(q.g, x), 1)));
+  return p;
+}
+// grid = (rows/256, n_chunks).  Chunk y < n_group_chunks covers groups [y*GC, ...); the remaining
+// chunks cover aux columns.  partial[(chunk*2 + j)*rows + pos] = Horner partial of that chunk.
+__global__ void __launch_bounds__(256) quotient_partial_kernel(bpg::QuotArgs q) {
+  const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
+  const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (pos >= rows) return;
+  const uint32_t n = 1u << q.log_n;
+  const uint32_t t = (uint32_t)(pos >> q.log_n), m = (uint32_t)(pos & (n - 1));
+  const uint64_t pos_next = ((uint64_t)t << q.log_n) | ((m + 1) & (n - 1));
+  const RowPoint rp = row_point(q, t, m);
+  Acc acc{0, 0, q.alpha0, q.alpha1};
+  const uint32_t chunk = blockIdx.y;
+  if (chunk < q.n_group_chunks) {
+    const uint32_t g0 = chunk * q.groups_per_chunk, g1 = min(g0 + q.groups_per_chunk, q.n_cols / 4);
+    for (uint32_t g = g0; g < g1; g++) {
+      const uint64_t* col = q.trace_lde + (uint64_t)(4 * g) * q.trace_stride;
+      const uint64_t a = col[pos], b = col[q.trace_stride + pos], c = col[2 * q.trace_stride + pos],
+                     d = col[3 * q.trace_stride + pos], dn = col[3 * q.trace_stride + pos_next];
+      const uint64_t qc = q.n_const ? q.const_lde[(uint64_t)(g % q.n_const) * q.const_stride + pos] : 1;
+      const uint64_t ab = gl::mulc(a, b);
+      acc.push(gl::subc(gl::subc(c, ab), gl::mulc(qc, a)));
+      const uint64_t tt = pow_e(gl::mulc(ab, c), q.deg_pow);
+      acc.push(gl::mulc(gl::subc(gl::subc(dn, tt), b), rp.z_last));
+      acc.push(gl::mulc(gl::subc(gl::subc(d, a), b), rp.l_first));
+    }
+  } else {
+    const uint32_t k0 = (chunk - q.n_group_chunks) * q.aux_per_chunk, k1 = min(k0 + q.aux_per_chunk, q.n_aux);
+    for (uint32_t k = k0; k < k1; k++) {
+      const uint64_t beta = q.ctl.v[2 * (k & 1)], gamma = q.ctl.v[2 * (k & 1) + 1];
+      const uint64_t a = q.trace_lde[(uint64_t)(8 * k) * q.trace_stride + pos],
+                     b = q.trace_lde[(uint64_t)(8 * k + 1) * q.trace_stride + pos];
+      const uint64_t z = q.aux_lde[(uint64_t)k * q.aux_stride + pos],
+                     zn = q.aux_lde[(uint64_t)k * q.aux_stride + pos_next];
+      const uint64_t term = gl::addc(gl::addc(gamma, a), gl::mulc(beta, b));
+      acc.push(gl::mulc(gl::subc(z, gl::mulc(zn, term)), rp.z_last));
+      acc.push(gl::mulc(gl::subc(z, term), rp.l_last));
+    }
+  }
+  q.partial[((uint64_t)chunk * 2) * rows + pos] = acc.a0;
+  q.partial[((uint64_t)chunk * 2 + 1) * rows + pos] = acc.a1;
+}
+// acc = sum over chunks in order: acc*alpha^(#constraints in chunk) + partial; then / Z_H.
+__global__ void __launch_bounds__(256) quotient_combine_kernel(bpg::QuotArgs q, bpg::ChunkPows cp) {
+  const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
+  const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (pos >= rows) return;
+  const uint32_t j = blockIdx.y, t = (uint32_t)(pos >> q.log_n);
+  const uint32_t n_chunks = q.n_group_chunks + q.n_aux_chunks;
+  uint64_t acc = 0;
+  for (uint32_t c = 0; c < n_chunks; c++) {
+    const uint64_t ap = cp.d_pows[c * 2 + j];
+    acc = gl::addc(gl::mulc(acc, ap), q.partial[((uint64_t)c * 2 + j) * rows + pos]);
+  }
+  q.qvals[(uint64_t)j * rows + pos] = gl::mulc(acc, q.zh_inv_t[t]);
+}
+// After the per-coset inverse NTT: E_t[pos] (bit-reversed n0).  c_{n0 + n*n1} =
+// (s^n)^(-n1) / 2^r * sum_t w_{2^r}^(-t n1) * E_t[pos] * g_t^(-n0).   grid = (n/256, 2 challenges)
+__global__ void __launch_bounds__(256) quotient_chunks_kernel(bpg::ChunkArgs c) {
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << c.log_n;
+  if (pos >= n) return;
+  const uint32_t j = blockIdx.y, R = 1u << c.rate_bits;
+  const uint64_t* e = c.e + (uint64_t)j * ((uint64_t)n << c.rate_bits);
+  uint64_t d[16];
+  for (uint32_t t = 0; t < R; t++) d[t] = gl::mulc(e[(uint64_t)t * n + pos], c.inv_scale[(uint64_t)t * n + pos]);
+  for (uint32_t n1 = 0; n1 < R; n1++) {
+    uint64_t acc = 0;
+    for (uint32_t t = 0; t < R; t++) acc = gl::addc(acc, gl::mulc(d[t], c.wr_inv_pow[(t * n1) & (R - 1)]));
+    c.out[((uint64_t)j * R + n1) * c.out_stride + pos] = gl::mulc(acc, c.chunk_scale[n1]);
+  }
+}
+
+// ---------------------------------------------------------------- K8 openings
+// pw[0..n) = zeta^bitrev(pos) (c0 plane), pw[n..2n) c1 plane; same for the second point at 2n.
+__global__ void __launch_bounds__(256)
+power_vector_kernel(uint64_t* __restrict__ out, uint32_t log_n, Ext z0, Ext z1) {
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << log_n;
+  if (pos >= n) return;
+  const uint32_t e = gl::bitrev(pos, log_n);
+  const Ext z = blockIdx.y ? z1 : z0;
+  const Ext r = gl::pow(z, e);
+  uint64_t* o = out + (uint64_t)blockIdx.y * 2 * n;
+  o[pos] = r.c0;
+  o[n + pos] = r.c1;
+}
+__global__ void __launch_bounds__(256) alpha_pows_kernel(uint64_t* __restrict__ out, uint32_t count, Ext alpha) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  const Ext r = gl::pow(alpha, j);
+  out[2 * j] = r.c0;
+  out[2 * j + 1] = r.c1;
+}
+// One workgroup per coefficient column: out[col] = (sum c*p0.c0, sum c*p0.c1, sum c*p1.c0, sum c*p1.c1)
+__global__ void __launch_bounds__(256)
+openings_kernel(const uint64_t* __restrict__ coeffs, uint64_t stride, uint32_t log_n,
+                const uint64_t* __restrict__ pw, uint32_t n_points, uint64_t* __restrict__ out) {
+  __shared__ uint64_t red[4][256];
+  const uint32_t n = 1u << log_n;
+  const uint64_t* c = coeffs + blockIdx.x * stride;
+  uint64_t acc[4] = {0, 0, 0, 0};
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint64_t v = c[i];
+    acc[0] = gl::addc(acc[0], gl::mulc(v, pw[i]));
+    acc[1] = gl::addc(acc[1], gl::mulc(v, pw[n + i]));
+    if (n_points > 1) {
+      acc[2] = gl::addc(acc[2], gl::mulc(v, pw[2 * n + i]));
+      acc[3] = gl::addc(acc[3], gl::mulc(v, pw[3 * n + i]));
+    }
+  }
+  for (int k = 0; k < 4; k++) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      for (int k = 0; k < 4; k++) red[k][threadIdx.x] = gl::addc(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// ---------------------------------------------------------------- K6a FRI combine
+// Coefficient-space alpha reduction.  For a block of columns of ONE oracle, accumulates into up to
+// three batch polynomials:  G_b[pos] += sum_col alpha^(e_b + col) * coeff[col][pos].
+// grid = (n/256, column chunks).  partial layout: [chunk][b][2][n]
+__global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineArgs a) {
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << a.log_n;
+  if (pos >= n) return;
+  const uint32_t c0 = blockIdx.y * a.cols_per_chunk, c1 = min(c0 + a.cols_per_chunk, a.n_cols);
+  Ext acc[3] = {gl::ext(0), gl::ext(0), gl::ext(0)};
+  for (uint32_t c = c0; c < c1; c++) {
+    const uint64_t v = a.coeffs[(uint64_t)c * a.stride + pos];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      if (a.exp_base[b] < 0) continue;
+      const uint64_t* ap = a.alpha_pows + 2 * ((uint64_t)a.exp_base[b] + c);
+      acc[b] = Ext{gl::addc(acc[b].c0, gl::mulc(v, ap[0])), gl::addc(acc[b].c1, gl::mulc(v, ap[1]))};
+    }
+  }
+  uint64_t* out = a.partial + (uint64_t)(a.chunk_base + blockIdx.y) * 6 * n;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    out[(2 * b) * (uint64_t)n + pos] = acc[b].c0;
+    out[(2 * b + 1) * (uint64_t)n + pos] = acc[b].c1;
+  }
+}
+// g[6][n] = sum over chunks.  grid = (n/256, 6)
+__global__ void __launch_bounds__(256)
+fri_combine_reduce_kernel(const uint64_t* __restrict__ partial, uint32_t n_chunks, uint32_t log_n,
+                          uint64_t* __restrict__ g) {
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << log_n;
+  if (pos >= n) return;
+  uint64_t acc = 0;
+  for (uint32_t c = 0; c < n_chunks; c++) acc = gl::addc(acc, partial[((uint64_t)c * 6 + blockIdx.y) * n + pos]);
+  g[(uint64_t)blockIdx.y * n + pos] = acc;
+}
+// Layer-0 FRI values: V(x) = sum_b alpha^(e_b) * (G_b(x) - y_b) / (x - z_b), x on the LDE coset.
+// glde: [6][rows] coset-major; out: AoS ext [rows].
+__global__ void __launch_bounds__(256) fri_quotient_values_kernel(bpg::FriInitArgs a) {
+  const uint64_t rows = (uint64_t)1 << (a.log_n + a.rate_bits);
+  const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (pos >= rows) return;
+  const uint32_t t = (uint32_t)(pos >> a.log_n), m = (uint32_t)(pos & ((1u << a.log_n) - 1));
+  const uint64_t x = gl::mulc(a.g_t[t], root_pow(a.tw_n, a.log_n, m));
+  Ext sum = gl::ext(0);
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    const Ext gv{a.glde[(2 * b) * rows + pos], a.glde[(2 * b + 1) * rows + pos]};
+    const Ext num = gl::sub(gv, a.y[b]);
+    const Ext den = gl::sub(gl::ext(x), a.z[b]);
+    sum = gl::add(sum, gl::mul(a.alpha_shift[b], gl::mul(num, gl::inv(den))));
+  }
+  a.out[2 * pos] = sum.c0;
+  a.out[2 * pos + 1] = sum.c1;
+}
+
+// ---------------------------------------------------------------- K6b FRI layer: leaves + fold
+// Layer of m = n_l << r ext values, coset-major.  Lane (t, m0), m0 < n_l/a, owns the a points
+// x0 * w_a^j', j' = 0..a-1 at positions t*n_l + m0 + j'*(n_l/a).  Its Merkle leaf (upstream:
+// bit-reversed values chunked by arity) is those values in bitrev_a(j) order, leaf index
+// bitrev(t + 2^r*m0).
+__global__ void __launch_bounds__(256) fri_layer_leaf_kernel(bpg::FriLayerArgs a) {
+  const uint32_t log_q = a.log_nl - a.arity_bits;  // log2(n_l / arity)
+  const uint64_t n_leaves = (uint64_t)1 << (log_q + a.rate_bits);
+  const uint64_t id = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (id >= n_leaves) return;
+  const uint32_t t = (uint32_t)(id >> log_q), m0 = (uint32_t)(id & ((1u << log_q) - 1));
+  const uint64_t base = ((uint64_t)t << a.log_nl) + m0;
+  const uint32_t arity = 1u << a.arity_bits;
+  uint64_t s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = 0;
+  for (uint32_t j = 0; j < arity; j += 4) {  // 4 ext elements = 8 words per absorb
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t jj = gl::bitrev(j + u, a.arity_bits);
+      const uint64_t p = base + ((uint64_t)jj << log_q);
+      s[2 * u] = a.values[2 * p];
+      s[2 * u + 1] = a.values[2 * p + 1];
+    }
+    poseidon::permute(s);
+  }
+  const uint64_t leaf = gl::bitrev((uint32_t)(t + ((uint64_t)m0 << a.rate_bits)), log_q + a.rate_bits);
+#pragma unroll
+  for (int k = 0; k < 4; k++) a.digests[leaf * 4 + k] = gl::canon(s[k]);
+}
+// P'(x0^a) = sum_i (beta/x0)^i u_i,  u_i = 1/a * sum_j' w_a^(-i j') P(x0 w_a^j')
+__global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
+  const uint32_t log_q = a.log_nl - a.arity_bits;
+  const uint64_t n_out = (uint64_t)1 << (log_q + a.rate_bits);
+  const uint64_t id = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (id >= n_out) return;
+  const uint32_t t = (uint32_t)(id >> log_q), m0 = (uint32_t)(id & ((1u << log_q) - 1));
+  const uint64_t base = ((uint64_t)t << a.log_nl) + m0;
+  const uint32_t arity = 1u << a.arity_bits;
+  // 1/x0 = g_t^-1 * w_{n_l}^(-m0)
+  const uint64_t x_inv = gl::mulc(a.g_t_inv[t], root_pow(a.tw_nl_inv, a.log_nl, m0));
+  Ext v[16];
+  for (uint32_t j = 0; j < arity; j++) {
+    const uint64_t p = base + ((uint64_t)j << log_q);
+    v[j] = Ext{a.values[2 * p], a.values[2 * p + 1]};
+  }
+  const Ext bx = gl::scale(a.beta, x_inv);
+  Ext bxi = gl::ext(1), acc = gl::ext(0);
+  for (uint32_t i = 0; i < arity; i++) {
+    Ext u = gl::ext(0);
+    for (uint32_t j = 0; j < arity; j++) u = gl::add(u, gl::scale(v[j], a.wa_inv_pow[(i * j) & (arity - 1)]));
+    acc = gl::add(acc, gl::mul(gl::scale(u, a.arity_inv), bxi));
+    bxi = gl::mul(bxi, bx);
+  }
+  a.out[2 * id] = acc.c0;
+  a.out[2 * id + 1] = acc.c1;
+}
+
+// ---------------------------------------------------------------- K9 proof of work
+// Smallest witness w >= base with leading pow_bits zero in state[7] after the duplex
+// (fri_proof_of_work; upstream takes any winner, we take the minimum so results are reproducible).
+__global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned long long* result) {
+  const uint64_t cand = a.base + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = a.state[k];
+  s[a.pos] = cand;
+  poseidon::permute(s);
+  if ((gl::canon(s[7]) >> (64 - a.bits)) == 0) atomicMin(result, (unsigned long long)cand);
+}
+
+// ---------------------------------------------------------------- query openings
+// grid = (num_queries, n_oracles).  Writes row values and the Merkle path of leaf x into the
+// query record (layout: DESIGN.md section 6).
+__global__ void __launch_bounds__(256) query_initial_kernel(bpg::QueryArgs a) {
+  const uint32_t q = blockIdx.x, o = blockIdx.y;
+  const uint64_t x = a.x_index[q];
+  const bpg::QueryOracle& orc = a.oracle[o];
+  const uint32_t log_rows = a.log_n + a.rate_bits;
+  // leaf x = row bitrev: natural i = bitrev(x) = t + 2^r*m  ->  coset-major t*n + m
+  const uint32_t i = gl::bitrev((uint32_t)x, log_rows);
+  const uint64_t pos = ((uint64_t)(i & ((1u << a.rate_bits) - 1)) << a.log_n) + (i >> a.rate_bits);
+  if (o == 0 && threadIdx.x == 0) a.out[(uint64_t)q * a.query_words] = x;
+  uint64_t* w = a.out + (uint64_t)q * a.query_words + orc.out_offset;
+  for (uint32_t c = threadIdx.x; c < orc.n_cols; c += blockDim.x) w[c] = orc.lde[(uint64_t)c * orc.stride + pos];
+  w += orc.n_cols;
+  const uint32_t depth = log_rows - a.cap_height;
+  for (uint32_t k = threadIdx.x; k < depth * 4; k += blockDim.x) {
+    const uint32_t lvl = k >> 2;
+    // level offset in digests: sum_{l<lvl} 2^(log_rows-l) = 2^(log_rows+1) - 2^(log_rows-lvl+1)
+    const uint64_t off = ((uint64_t)2 << log_rows) - ((uint64_t)2 << (log_rows - lvl));
+    w[k] = orc.digests[(off + ((x >> lvl) ^ 1)) * 4 + (k & 3)];
+  }
+}
+// grid = (num_queries, n_layers)
+__global__ void __launch_bounds__(64) query_layers_kernel(bpg::QueryLayerArgs a) {
+  const uint32_t q = blockIdx.x, l = blockIdx.y;
+  const bpg::QueryLayer& L = a.layer[l];
+  const uint32_t arity = 1u << a.arity_bits;
+  const uint64_t leaf = a.x_index[q] >> (a.arity_bits * (l + 1));
+  const uint32_t log_q = L.log_nl - a.arity_bits, log_leaves = log_q + a.rate_bits;
+  const uint32_t c = gl::bitrev((uint32_t)leaf, log_leaves);  // = t + 2^r * m0
+  const uint32_t t = c & ((1u << a.rate_bits) - 1), m0 = c >> a.rate_bits;
+  const uint64_t base = ((uint64_t)t << L.log_nl) + m0;
+  uint64_t* w = a.out + (uint64_t)q * a.query_words + L.out_offset;
+  for (uint32_t k = threadIdx.x; k < 2 * arity; k += blockDim.x) {
+    const uint32_t jj = gl::bitrev(k >> 1, a.arity_bits);
+    w[k] = L.values[2 * (base + ((uint64_t)jj << log_q)) + (k & 1)];
+  }
+  w += 2 * arity;
+  const uint32_t depth = log_leaves - a.cap_height;
+  for (uint32_t k = threadIdx.x; k < depth * 4; k += blockDim.x) {
+    const uint32_t lvl = k >> 2;
+    const uint64_t off = ((uint64_t)2 << log_leaves) - ((uint64_t)2 << (log_leaves - lvl));
+    w[k] = L.digests[(off + ((leaf >> lvl) ^ 1)) * 4 + (k & 3)];
+  }
+}
+
+}  // namespace
+
+// ================================================================= host-side launchers
+namespace bpg {
+
+int launch_synth_constants(uint64_t* d_out, uint32_t log_n, uint32_t n_const, uint64_t seed, hipStream_t st) {
+  uint64_t total = (uint64_t)n_const << log_n;
+  if (!total) return BP_OK;
+  synth_const_kernel<<<ceil_div(total, 256), 256, 0, st>>>(d_out, log_n, n_const, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_synth_trace(uint64_t* d_trace, const uint64_t* d_consts, uint32_t log_n, uint32_t n_cols,
+                       uint32_t n_const, uint32_t deg_pow, uint64_t seed, hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), n_cols / 4 + 1);
+  synth_trace_kernel<<<grid, 256, 0, st>>>(d_trace, d_consts, log_n, n_cols, n_const, deg_pow, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
+               hipStream_t st) {
+  if (!n_aux) return BP_OK;
+  uint32_t threads = (1u << log_n) < 1024 ? (1u << log_n) : 1024;
+  if (threads < 64) threads = 64;
+  aux_suffix_product_kernel<<<n_aux, threads, 0, st>>>(d_trace, d_aux, log_n, ctl);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_quotient(const QuotArgs& q, const ChunkPows& cp, hipStream_t st) {
+  uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
+  dim3 g1(ceil_div(rows, 256), q.n_group_chunks + q.n_aux_chunks);
+  quotient_partial_kernel<<<g1, 256, 0, st>>>(q);
+  BPG_LAUNCH_CHECK();
+  dim3 g2(ceil_div(rows, 256), 2);
+  quotient_combine_kernel<<<g2, 256, 0, st>>>(q, cp);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_quotient_chunks(const ChunkArgs& c, hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)1 << c.log_n, 256), 2);
+  quotient_chunks_kernel<<<grid, 256, 0, st>>>(c);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_power_vectors(uint64_t* d_out, uint32_t log_n, gl::Ext z0, gl::Ext z1, uint32_t n_points,
+                         hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), n_points);
+  power_vector_kernel<<<grid, 256, 0, st>>>(d_out, log_n, z0, z1);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_alpha_pows(uint64_t* d_out, uint32_t count, gl::Ext alpha, hipStream_t st) {
+  alpha_pows_kernel<<<ceil_div(count, 256), 256, 0, st>>>(d_out, count, alpha);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, uint32_t n_cols,
+                    const uint64_t* d_pw, uint32_t n_points, uint64_t* d_out, hipStream_t st) {
+  if (!n_cols) return BP_OK;
+  openings_kernel<<<n_cols, 256, 0, st>>>(d_coeffs, stride, log_n, d_pw, n_points, d_out);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_combine_partial(const CombineArgs& a, uint32_t n_chunks, hipStream_t st) {
+  if (!a.n_cols) return BP_OK;
+  dim3 grid(ceil_div((uint64_t)1 << a.log_n, 256), n_chunks);
+  fri_combine_partial_kernel<<<grid, 256, 0, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_combine_reduce(const uint64_t* d_partial, uint32_t n_chunks, uint32_t log_n, uint64_t* d_g,
+                          hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 6);
+  fri_combine_reduce_kernel<<<grid, 256, 0, st>>>(d_partial, n_chunks, log_n, d_g);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_fri_init(const FriInitArgs& a, hipStream_t st) {
+  uint64_t rows = (uint64_t)1 << (a.log_n + a.rate_bits);
+  fri_quotient_values_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_fri_layer_leaves(const FriLayerArgs& a, hipStream_t st) {
+  uint64_t n = (uint64_t)1 << (a.log_nl - a.arity_bits + a.rate_bits);
+  fri_layer_leaf_kernel<<<ceil_div(n, 256), 256, 0, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_fri_fold(const FriLayerArgs& a, hipStream_t st) {
+  uint64_t n = (uint64_t)1 << (a.log_nl - a.arity_bits + a.rate_bits);
+  fri_fold_kernel<<<ceil_div(n, 256), 256, 0, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_pow(const PowArgs& a, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st) {
+  pow_grind_kernel<<<n_candidates / 256, 256, 0, st>>>(a, d_result);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_query_initial(const QueryArgs& a, uint32_t n_queries, uint32_t n_oracles, hipStream_t st) {
+  dim3 grid(n_queries, n_oracles);
+  query_initial_kernel<<<grid, 256, 0, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_query_layers(const QueryLayerArgs& a, uint32_t n_queries, uint32_t n_layers, hipStream_t st) {
+  if (!n_layers) return BP_OK;
+  dim3 grid(n_queries, n_layers);
+  query_layers_kernel<<<grid, 64, 0, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+
+}  // namespace bpg

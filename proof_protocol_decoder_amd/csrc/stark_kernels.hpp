@@ -1,0 +1,127 @@
+// stark_kernels.hpp -- argument blocks and launchers of the per-table STARK kernels
+// (stark_kernels.hip) plus the NTT / Merkle entry points used by the host prover.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "gl.hpp"
+
+namespace bpg {
+
+struct Ctl {
+  uint64_t v[4];  // beta0, gamma0, beta1, gamma1 (grand-product challenge sets)
+};
+
+struct QuotArgs {
+  const uint64_t *trace_lde, *aux_lde, *const_lde;
+  uint64_t trace_stride, aux_stride, const_stride;
+  uint64_t *partial, *qvals;
+  const uint64_t* tw_n;  // w_n^e, e < n/2
+  uint32_t log_n, rate_bits, n_cols, n_const, n_aux, deg_pow;
+  uint32_t n_group_chunks, groups_per_chunk, n_aux_chunks, aux_per_chunk;
+  uint64_t alpha0, alpha1, g, g_inv, n_inv;
+  uint64_t g_t[16], zh_t[16], zh_inv_t[16];  // per coset: 7*w_M^t, g_t^n - 1 and its inverse
+  Ctl ctl;
+};
+struct ChunkPows {
+  uint64_t d_pows[128];  // [chunk][challenge]: alpha_j^(#constraints in the chunk)
+};
+struct ChunkArgs {
+  const uint64_t* e;          // [2][2^r][n] per-coset inverse NTT output (bit-reversed)
+  const uint64_t* inv_scale;  // [2^r][n]: g_t^(-bitrev(pos))
+  uint64_t* out;              // [2*2^r] chunk coefficient columns
+  uint64_t out_stride;
+  uint32_t log_n, rate_bits;
+  uint64_t wr_inv_pow[16];    // w_{2^r}^(-k)
+  uint64_t chunk_scale[16];   // (7^n)^(-n1) / 2^r
+};
+struct CombineArgs {
+  const uint64_t* coeffs;
+  uint64_t stride;
+  uint32_t log_n, n_cols, cols_per_chunk, chunk_base;
+  int32_t exp_base[3];         // alpha exponent of this oracle's first column per batch; <0: not in batch
+  const uint64_t* alpha_pows;  // ext pairs alpha^j
+  uint64_t* partial;           // [chunks][6][n]
+};
+struct FriInitArgs {
+  const uint64_t* glde;  // [6][rows]
+  uint64_t* out;         // ext AoS [rows]
+  const uint64_t* tw_n;
+  uint32_t log_n, rate_bits;
+  uint64_t g_t[16];
+  gl::Ext y[3], z[3], alpha_shift[3];
+};
+struct FriLayerArgs {
+  const uint64_t* values;  // ext AoS, coset-major [2^r][n_l]
+  uint64_t* out;           // folded layer, ext AoS [2^r][n_l/arity]
+  uint64_t* digests;       // leaf digests in leaf order
+  const uint64_t* tw_nl_inv;
+  uint32_t log_nl, rate_bits, arity_bits;
+  uint64_t g_t_inv[16];
+  uint64_t wa_inv_pow[16];
+  uint64_t arity_inv;
+  gl::Ext beta;
+};
+struct PowArgs {
+  uint64_t state[12];
+  uint64_t base;
+  uint32_t pos, bits;
+};
+struct QueryOracle {
+  const uint64_t *lde, *digests;
+  uint64_t stride;
+  uint32_t n_cols, out_offset;
+};
+struct QueryArgs {
+  uint64_t x_index[128];
+  uint64_t* out;
+  uint64_t query_words;
+  uint32_t log_n, rate_bits, cap_height;
+  QueryOracle oracle[4];
+};
+struct QueryLayer {
+  const uint64_t *values, *digests;
+  uint32_t log_nl, out_offset;
+};
+struct QueryLayerArgs {
+  uint64_t x_index[128];
+  uint64_t* out;
+  uint64_t query_words;
+  uint32_t rate_bits, cap_height, arity_bits;
+  QueryLayer layer[8];
+};
+
+// stark_kernels.hip
+int launch_synth_constants(uint64_t* d_out, uint32_t log_n, uint32_t n_const, uint64_t seed, hipStream_t st);
+int launch_synth_trace(uint64_t* d_trace, const uint64_t* d_consts, uint32_t log_n, uint32_t n_cols,
+                       uint32_t n_const, uint32_t deg_pow, uint64_t seed, hipStream_t st);
+int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
+               hipStream_t st);
+int launch_quotient(const QuotArgs& q, const ChunkPows& cp, hipStream_t st);
+int launch_quotient_chunks(const ChunkArgs& c, hipStream_t st);
+int launch_power_vectors(uint64_t* d_out, uint32_t log_n, gl::Ext z0, gl::Ext z1, uint32_t n_points,
+                         hipStream_t st);
+int launch_alpha_pows(uint64_t* d_out, uint32_t count, gl::Ext alpha, hipStream_t st);
+int launch_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, uint32_t n_cols,
+                    const uint64_t* d_pw, uint32_t n_points, uint64_t* d_out, hipStream_t st);
+int launch_combine_partial(const CombineArgs& a, uint32_t n_chunks, hipStream_t st);
+int launch_combine_reduce(const uint64_t* d_partial, uint32_t n_chunks, uint32_t log_n, uint64_t* d_g,
+                          hipStream_t st);
+int launch_fri_init(const FriInitArgs& a, hipStream_t st);
+int launch_fri_layer_leaves(const FriLayerArgs& a, hipStream_t st);
+int launch_fri_fold(const FriLayerArgs& a, hipStream_t st);
+int launch_pow(const PowArgs& a, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st);
+int launch_query_initial(const QueryArgs& a, uint32_t n_queries, uint32_t n_oracles, hipStream_t st);
+int launch_query_layers(const QueryLayerArgs& a, uint32_t n_queries, uint32_t n_layers, hipStream_t st);
+
+// ntt.hip
+int init_ntt_kernels();
+int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out);  // 0 fwd, 1 inv, 2 coset, 3 inv coset
+int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride, uint32_t log_n,
+                uint32_t n_cols, bool inverse, hipStream_t st);
+int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride, uint64_t coset_stride,
+               uint32_t log_n, uint32_t n_cols, uint32_t n_cosets, const uint64_t* scale, bool inverse,
+               hipStream_t st);
+// hash_kernels.hip
+int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st);
+
+}  // namespace bpg

@@ -4,9 +4,12 @@ torch is used only for device memory and streams (int64 tensors carry the u64 bi
 Layouts are the ones documented in include/bpg.h: column-major matrices, natural-order values,
 bit-reversed coefficients, coset-major LDE.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 
-from ._lib import check, lib
+from ._lib import StarkCfg, check, lib, take_buffer
 
 NTT_FWD_BR2NAT, NTT_INV_NAT2BR, NTT_FWD_NAT, NTT_INV_NAT = 0, 1, 2, 3
 
@@ -57,3 +60,17 @@ def merkle_commit(lde, log_n, rate_bits, cap_height):
     check(lib().bp_merkle_commit(lde.data_ptr(), rows, n_cols, log_n, rate_bits, cap_height, dig.data_ptr(),
                                  _stream()))
     return dig
+
+
+def stark_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, num_queries=84, pow_bits=16,
+              arity_bits=4, final_poly_bits=5):
+    return StarkCfg(log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits, arity_bits,
+                    final_poly_bits)
+
+
+def stark_prove_synthetic(cfg, seed, const_seed=0, device=0):
+    """One table proof on the synthetic AIR, witness generated on the device.  Returns proof words (u64)."""
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    check(lib().bp_stark_prove_synthetic(C.byref(cfg), seed, const_seed, device, C.byref(out), C.byref(n)))
+    return np.frombuffer(take_buffer(out, n), dtype=np.uint64).copy()

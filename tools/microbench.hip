@@ -65,7 +65,7 @@ int main() {
   printf("device: %s, CUs %d, clock %d MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
   uint64_t* out;
   const int blocks = prop.multiProcessorCount * 8, threads = 256;
-  CK(hipMalloc(&out, (size_t)blocks * threads * 8));
+  CK(hipMalloc(&out, (size_t)prop.multiProcessorCount * 16 * threads * 8));  // largest launch below: 16 blocks/CU
   const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32+add", "v_mul_hi_u32+shl_add", "add_u64", "gl::mul",
                          "gl::addc", "v_lshl_add_u64", "v_dot4_u32_u8", "v_mad_u32_u24"};
   double ops = (double)blocks * threads * ITERS * 4;
@@ -85,5 +85,6 @@ int main() {
   CK(hipMemset(a, 1, bytes));
   ms = time_ms([&] { copy_kernel<<<prop.multiProcessorCount * 16, 256>>>(a, b, bytes / 16); });
   printf("copy 2 GiB: %.3f ms  %.2f TB/s (read+write)\n", ms, 2.0 * bytes / ms / 1e9);
+  CK(hipDeviceSynchronize());
   return 0;
 }
