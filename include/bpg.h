@@ -101,6 +101,82 @@ int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t co
                              uint8_t** out, size_t* out_len);
 void bp_free_buffer(uint8_t* buf);
 
+/* ------------------------------------------------------------------------------------------
+ * L1 -- the reference's public API for this path, byte-for-byte shaped.
+ *
+ *   reference (Rust)                                              this ABI
+ *   ProverStateBuilder::default() / set_<t>_circuit_size / build   bp_config_default, bp_state_build
+ *     (prover_state.rs:34-53, 55-75, 80-100; constants.rs:6-18)
+ *   generate_txn_proof(&ProverState, TxnProofGenIR, abort)         bp_generate_txn_proof
+ *     (proof_gen.rs:39-56)
+ *   generate_agg_proof(&ProverState, &lhs, &rhs)                   bp_generate_agg_proof
+ *     (proof_gen.rs:61-79; is_agg()/intern()/public_values(): proof_types.rs:55-74)
+ *   generate_block_proof(&ProverState, Option<&parent>, &agg)      bp_generate_block_proof
+ *     (proof_gen.rs:85-110)
+ *   VerifierState::from(&ProverState) / build_verifier / verify    bp_verifier_state_*, bp_verify_block_proof
+ *     (verifier_state.rs:34-42, 46-52, 56-71)
+ *
+ * The zkEVM tables and recursion circuits behind those calls are upstream-only, so
+ * the work performed is the synthetic txn proof of SURVEY.md section 8(d): 7 table STARKs (one per
+ * AllStark table, positional order arithmetic, byte_packing, cpu, keccak, keccak_sponge, logic,
+ * memory -- prover_state.rs:85-93), a 3-deep recursion-shaped chain per table and a root proof;
+ * an aggregation / block proof is one recursion-shaped proof bound to its children's digests.
+ * Byte formats (the reference fixes none: proof_types.rs:12,25,35,46 only derive serde) are defined
+ * in DESIGN.md section 6: little-endian u64 words throughout.
+ * ------------------------------------------------------------------------------------------ */
+#define BP_NUM_TABLES 7
+
+typedef struct bp_config {
+  /* per-table supported log2 trace heights, Range<usize> lo..hi, hi exclusive (constants.rs:6-18) */
+  uint32_t table_log_lo[BP_NUM_TABLES], table_log_hi[BP_NUM_TABLES];
+  /* StarkConfig::standard_fast_config(): rate_bits 1, cap_height 4, 84 queries, 16 PoW bits,
+   * ConstantArityBits(4, 5)  [UPSTREAM-UNVERIFIED values, runtime parameters here] */
+  uint32_t stark_rate_bits, stark_cap_height, stark_num_queries, stark_pow_bits, arity_bits, final_poly_bits;
+  /* CircuitConfig::standard_recursion_config() shaped proofs: 2^13 rows x 135 wires, 82 constant
+   * columns, rate_bits 3, 28 queries */
+  uint32_t rec_log_n, rec_n_cols, rec_n_const, rec_rate_bits, rec_num_queries, rec_pow_bits;
+  uint32_t shrink_depth; /* recursion-shaped proofs per table before the root (3) */
+  int32_t device;        /* HIP device index */
+  uint32_t n_workers;    /* concurrent provers (one HIP stream + arena each) */
+  uint64_t arena_bytes;  /* device arena per worker */
+} bp_config;
+
+typedef struct bp_state bp_state;                   /* ProverState (prover_state.rs:17-20) */
+typedef struct bp_verifier_state bp_verifier_state; /* VerifierState (verifier_state.rs:19-23) */
+
+void bp_config_default(bp_config* cfg);
+int bp_state_build(const bp_config* cfg, bp_state** out); /* "very expensive call" in the reference */
+void bp_state_free(bp_state* s);
+uint64_t bp_state_device_bytes(const bp_state* s);
+
+/* abort_flag: nullable; polled between kernel stages (Option<Arc<AtomicBool>>, proof_gen.rs:42). */
+int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
+                          uint8_t** out, size_t* out_len);
+int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
+                          const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len);
+/* parent may be NULL (checkpoint heights, proof_gen.rs:83-84). *b_height = block number of the proof. */
+int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t parent_len, const uint8_t* agg,
+                            size_t agg_len, uint8_t** out, size_t* out_len, uint64_t* b_height);
+
+int bp_verifier_state_from_prover(const bp_state* s, bp_verifier_state** out);
+int bp_verifier_state_build(const bp_config* cfg, bp_verifier_state** out);
+void bp_verifier_state_free(bp_verifier_state* v);
+/* CPU only.  BP_ERR_VERIFY with a reason in bp_last_error() when rejected. */
+int bp_verify_block_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len);
+/* same check for txn / agg containers (not in the reference API; used by tests and the block driver) */
+int bp_verify_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len);
+
+/* Serialise a TxnProofGenIR for the synthetic workload; out: BP_IR_WORDS u64. */
+#define BP_IR_WORDS 25
+#define BP_PV_WORDS 13
+int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas_used_before,
+                 uint64_t gas_used_after, const uint64_t state_root_before[4], uint64_t seed,
+                 const uint32_t table_log_n[BP_NUM_TABLES], const uint32_t table_width[BP_NUM_TABLES],
+                 uint64_t out_words[BP_IR_WORDS]);
+/* public values of a proof container: txn_before, txn_after, gas_before, gas_after, root_before[4],
+ * root_after[4], block_number */
+int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out);
+
 #ifdef __cplusplus
 }
 #endif

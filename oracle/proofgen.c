@@ -1,5 +1,254 @@
-/* oracle/proofgen.c -- txn / agg / block proof composition (CPU restatement).
+/* oracle/proofgen.c -- txn / agg / block proof composition (CPU restatement of the synthetic
+ * workload behind plonky_block_proof_gen/src/proof_gen.rs:39-110).
  * TEST INFRASTRUCTURE ONLY; "parity unpinned" by the reference (see gl.h).
- * Filled in with the L1 layer (proof_gen.rs:39-110 shapes); see DESIGN.md section 5.
+ * Produces byte-identical containers to libbpg's bp_generate_{txn,agg,block}_proof.
  */
 #include "oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NUM_TABLES 7
+#define IR_WORDS 25
+#define PV_WORDS 13
+#define BOX_HDR 4
+#define IR_MAGIC 0x52494E5854475042ULL
+#define BOX_MAGIC 0x464F4F5250475042ULL
+#define CIRCUIT_ROOT 7
+
+typedef struct {
+  uint32_t table_log_lo[NUM_TABLES], table_log_hi[NUM_TABLES];
+  uint32_t stark_rate_bits, stark_cap_height, stark_num_queries, stark_pow_bits, arity_bits, final_poly_bits;
+  uint32_t rec_log_n, rec_n_cols, rec_n_const, rec_rate_bits, rec_num_queries, rec_pow_bits;
+  uint32_t shrink_depth;
+} orc_pg_config;
+
+typedef struct {
+  int built;
+  gl_t* const_values;
+  orc_committed* consts;
+  gl_t digest[4];
+} circuit_t;
+
+typedef struct orc_pg_state {
+  orc_pg_config cfg;
+  orc_stark_cfg rec;
+  circuit_t table[NUM_TABLES][32];
+  circuit_t special[3];
+} orc_pg_state;
+
+static uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static uint64_t circuit_seed(uint32_t kind, uint32_t degree) {
+  return splitmix64(0xC12C0175EEDULL + ((uint64_t)kind << 8) + degree);
+}
+static orc_stark_cfg rec_cfg_of(const orc_pg_config* c) {
+  orc_stark_cfg r = {c->rec_log_n, c->rec_n_cols, c->rec_n_const, 3, c->rec_rate_bits, c->stark_cap_height,
+                     c->rec_num_queries, c->rec_pow_bits, c->arity_bits, c->final_poly_bits};
+  return r;
+}
+static orc_stark_cfg table_cfg_of(const orc_pg_config* c, uint32_t log_n, uint32_t width) {
+  orc_stark_cfg r = {log_n, width, 0, 1, c->stark_rate_bits, c->stark_cap_height, c->stark_num_queries,
+                     c->stark_pow_bits, c->arity_bits, c->final_poly_bits};
+  return r;
+}
+
+orc_pg_state* orc_pg_state_build(const orc_pg_config* cfg) {
+  orc_pg_state* s = (orc_pg_state*)calloc(1, sizeof(*s));
+  s->cfg = *cfg;
+  s->rec = rec_cfg_of(cfg);
+  return s;
+}
+static void circuit_free(circuit_t* c) {
+  if (c->built) { free(c->const_values); orc_committed_free(c->consts); }
+}
+void orc_pg_state_free(orc_pg_state* s) {
+  if (!s) return;
+  for (int t = 0; t < NUM_TABLES; t++) for (int d = 0; d < 32; d++) circuit_free(&s->table[t][d]);
+  for (int k = 0; k < 3; k++) circuit_free(&s->special[k]);
+  free(s);
+}
+/* circuits are preprocessed lazily (same data as libbpg's eager bp_state_build) */
+static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed) {
+  if (!c->built) {
+    size_t n = (size_t)1 << s->rec.log_n;
+    c->const_values = (gl_t*)malloc(s->rec.n_const * n * sizeof(gl_t));
+    orc_synth_constants(seed, s->rec.log_n, s->rec.n_const, c->const_values);
+    c->consts = orc_commit_values(c->const_values, s->rec.log_n, s->rec.n_const, s->rec.rate_bits, s->rec.cap_height);
+    orc_hash_no_pad(orc_committed_cap(c->consts), (size_t)4 << s->rec.cap_height, c->digest);
+    c->built = 1;
+  }
+  return c;
+}
+static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) { return get_circuit(s, &s->table[t][d], circuit_seed(t, d)); }
+static circuit_t* special_circuit(orc_pg_state* s, int k) { return get_circuit(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0)); }
+
+static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_pi, gl_t* proof) {
+  gl_t pi_hash[4];
+  orc_hash_no_pad(pi, n_pi, pi_hash);
+  orc_challenger ch;
+  orc_ch_init(&ch);
+  orc_ch_observe_many(&ch, circ->digest, 4);
+  orc_ch_observe_many(&ch, pi_hash, 4);
+  size_t n = (size_t)1 << s->rec.log_n;
+  gl_t* trace = (gl_t*)malloc(s->rec.n_cols * n * sizeof(gl_t));
+  orc_synth_trace(pi_hash[0], &s->rec, circ->const_values, trace);
+  orc_committed* tc = orc_commit_values(trace, s->rec.log_n, s->rec.n_cols, s->rec.rate_bits, s->rec.cap_height);
+  orc_ch_observe_many(&ch, orc_committed_cap(tc), (size_t)4 << s->rec.cap_height);
+  gl_t ctl[4];
+  for (int i = 0; i < 4; i++) ctl[i] = orc_ch_challenge(&ch);
+  int rc = orc_stark_prove(&s->rec, circ->consts, tc, trace, ctl, &ch, proof);
+  orc_committed_free(tc);
+  free(trace);
+  return rc;
+}
+
+static gl_t* emit_box(uint64_t kind, const gl_t* pi, size_t n_pi, const gl_t* stark, size_t sw, size_t* out_words) {
+  gl_t* o = (gl_t*)malloc((BOX_HDR + n_pi + sw) * sizeof(gl_t));
+  o[0] = BOX_MAGIC; o[1] = kind; o[2] = n_pi; o[3] = CIRCUIT_ROOT + kind;
+  memcpy(o + BOX_HDR, pi, n_pi * 8);
+  memcpy(o + BOX_HDR + n_pi, stark, sw * 8);
+  *out_words = BOX_HDR + n_pi + sw;
+  return o;
+}
+
+/* generate_txn_proof (proof_gen.rs:39-56) on the synthetic workload */
+int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) {
+  const orc_pg_config* cfg = &s->cfg;
+  if (I[0] != IR_MAGIC || I[1] != 1) return -2;
+  orc_stark_cfg tcfg[NUM_TABLES];
+  for (int t = 0; t < NUM_TABLES; t++) {
+    if (I[11 + t] < cfg->table_log_lo[t] || I[11 + t] >= cfg->table_log_hi[t]) return -3;
+    tcfg[t] = table_cfg_of(cfg, (uint32_t)I[11 + t], (uint32_t)I[18 + t]);
+  }
+  gl_t pv[PV_WORDS];
+  pv[0] = I[3]; pv[1] = I[3] + 1; pv[2] = I[4]; pv[3] = I[5];
+  memcpy(pv + 4, I + 6, 32);
+  gl_t in6[6] = {I[6], I[7], I[8], I[9], gl_canon(I[10]), gl_canon(I[3])};
+  orc_hash_no_pad(in6, 6, pv + 8);
+  pv[12] = I[2];
+  for (int i = 0; i < PV_WORDS; i++) pv[i] = gl_canon(pv[i]);
+
+  gl_t* trace[NUM_TABLES];
+  orc_committed* tc[NUM_TABLES];
+  orc_challenger ch;
+  orc_ch_init(&ch);
+  for (int t = 0; t < NUM_TABLES; t++) {
+    size_t n = (size_t)1 << tcfg[t].log_n;
+    trace[t] = (gl_t*)malloc(tcfg[t].n_cols * n * sizeof(gl_t));
+    orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
+    tc[t] = orc_commit_values(trace[t], tcfg[t].log_n, tcfg[t].n_cols, tcfg[t].rate_bits, tcfg[t].cap_height);
+    orc_ch_observe_many(&ch, orc_committed_cap(tc[t]), (size_t)4 << tcfg[t].cap_height);
+  }
+  orc_ch_observe_many(&ch, pv, PV_WORDS);
+  gl_t ctl[4];
+  for (int i = 0; i < 4; i++) ctl[i] = orc_ch_challenge(&ch);
+  gl_t digest[NUM_TABLES][4];
+  int rc = 0;
+  for (int t = 0; t < NUM_TABLES && !rc; t++) {
+    gl_t* proof = (gl_t*)malloc(orc_proof_words(&tcfg[t]) * sizeof(gl_t));
+    rc = orc_stark_prove(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proof);
+    if (!rc) orc_proof_digest(&tcfg[t], proof, digest[t]);
+    free(proof);
+  }
+  for (int t = 0; t < NUM_TABLES; t++) { orc_committed_free(tc[t]); free(trace[t]); }
+  if (rc) return rc;
+  size_t sw = orc_proof_words(&s->rec);
+  gl_t* proof = (gl_t*)malloc(sw * sizeof(gl_t));
+  for (int t = 0; t < NUM_TABLES && !rc; t++) {
+    circuit_t* circ = table_circuit(s, t, tcfg[t].log_n);
+    for (uint32_t depth = 0; depth < cfg->shrink_depth && !rc; depth++) {
+      gl_t pi[6] = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (gl_t)t, depth};
+      rc = rec_prove(s, circ, pi, 6, proof);
+      if (!rc) orc_proof_digest(&s->rec, proof, digest[t]);
+    }
+  }
+  if (!rc) {
+    gl_t pi[4 * NUM_TABLES + PV_WORDS];
+    for (int t = 0; t < NUM_TABLES; t++) memcpy(pi + 4 * t, digest[t], 32);
+    memcpy(pi + 4 * NUM_TABLES, pv, sizeof(pv));
+    rc = rec_prove(s, special_circuit(s, 0), pi, 4 * NUM_TABLES + PV_WORDS, proof);
+    if (!rc) *out = emit_box(0, pi, 4 * NUM_TABLES + PV_WORDS, proof, sw, out_words);
+  }
+  free(proof);
+  return rc;
+}
+
+typedef struct { uint64_t kind, n_pi; const gl_t *pi, *pv, *stark; } box_t;
+static int parse_box(orc_pg_state* s, const gl_t* w, size_t words, box_t* b) {
+  if (words < BOX_HDR + PV_WORDS || w[0] != BOX_MAGIC || w[1] > 2 || w[2] < PV_WORDS || w[2] > 64) return -2;
+  b->kind = w[1]; b->n_pi = w[2];
+  if (words != BOX_HDR + b->n_pi + orc_proof_words(&s->rec)) return -2;
+  b->pi = w + BOX_HDR; b->pv = b->pi + b->n_pi - PV_WORDS; b->stark = b->pi + b->n_pi;
+  return 0;
+}
+
+/* generate_agg_proof (proof_gen.rs:61-79) */
+int orc_pg_agg(orc_pg_state* s, const gl_t* lhs, size_t lw, int lhs_is_agg, const gl_t* rhs, size_t rw,
+               int rhs_is_agg, gl_t** out, size_t* out_words) {
+  box_t L, R;
+  if (parse_box(s, lhs, lw, &L) || parse_box(s, rhs, rw, &R)) return -2;
+  if ((L.kind == 1) != (lhs_is_agg != 0) || (R.kind == 1) != (rhs_is_agg != 0) || L.kind > 1 || R.kind > 1) return -2;
+  if (L.pv[1] != R.pv[0] || L.pv[3] != R.pv[2] || memcmp(L.pv + 8, R.pv + 4, 32) || L.pv[12] != R.pv[12]) return -2;
+  gl_t pi[10 + PV_WORDS];
+  orc_proof_digest(&s->rec, L.stark, pi);
+  orc_proof_digest(&s->rec, R.stark, pi + 4);
+  pi[8] = lhs_is_agg != 0; pi[9] = rhs_is_agg != 0;
+  gl_t* pv = pi + 10;
+  pv[0] = L.pv[0]; pv[1] = R.pv[1]; pv[2] = L.pv[2]; pv[3] = R.pv[3];
+  memcpy(pv + 4, L.pv + 4, 32); memcpy(pv + 8, R.pv + 8, 32);
+  pv[12] = L.pv[12];
+  size_t sw = orc_proof_words(&s->rec);
+  gl_t* proof = (gl_t*)malloc(sw * sizeof(gl_t));
+  int rc = rec_prove(s, special_circuit(s, 1), pi, 10 + PV_WORDS, proof);
+  if (!rc) *out = emit_box(1, pi, 10 + PV_WORDS, proof, sw, out_words);
+  free(proof);
+  return rc;
+}
+
+/* generate_block_proof (proof_gen.rs:85-110) */
+int orc_pg_block(orc_pg_state* s, const gl_t* parent, size_t pw, const gl_t* agg, size_t aw, gl_t** out,
+                 size_t* out_words) {
+  box_t A, Pb;
+  if (parse_box(s, agg, aw, &A) || A.kind != 1) return -2;
+  gl_t pi[9 + PV_WORDS];
+  memset(pi, 0, sizeof(pi));
+  if (parent) {
+    if (parse_box(s, parent, pw, &Pb) || Pb.kind != 2 || Pb.pv[12] + 1 != A.pv[12]) return -2;
+    orc_proof_digest(&s->rec, Pb.stark, pi);
+    pi[8] = 1;
+  }
+  orc_proof_digest(&s->rec, A.stark, pi + 4);
+  memcpy(pi + 9, A.pv, PV_WORDS * 8);
+  size_t sw = orc_proof_words(&s->rec);
+  gl_t* proof = (gl_t*)malloc(sw * sizeof(gl_t));
+  int rc = rec_prove(s, special_circuit(s, 2), pi, 9 + PV_WORDS, proof);
+  if (!rc) *out = emit_box(2, pi, 9 + PV_WORDS, proof, sw, out_words);
+  free(proof);
+  return rc;
+}
+
+/* VerifierState::verify (verifier_state.rs:56-71) */
+int orc_pg_verify(orc_pg_state* s, const gl_t* w, size_t words) {
+  box_t b;
+  if (parse_box(s, w, words, &b)) return -2;
+  if (w[3] != CIRCUIT_ROOT + b.kind) return -5;
+  circuit_t* circ = special_circuit(s, (int)b.kind);
+  gl_t pi_hash[4];
+  orc_hash_no_pad(b.pi, b.n_pi, pi_hash);
+  orc_challenger ch;
+  orc_ch_init(&ch);
+  orc_ch_observe_many(&ch, circ->digest, 4);
+  orc_ch_observe_many(&ch, pi_hash, 4);
+  size_t cap_words = (size_t)4 << s->rec.cap_height;
+  orc_ch_observe_many(&ch, b.stark + 16, cap_words); /* trace cap follows the 16-word header */
+  gl_t ctl[4];
+  for (int i = 0; i < 4; i++) ctl[i] = orc_ch_challenge(&ch);
+  return orc_stark_verify(&s->rec, orc_committed_cap(circ->consts), ctl, &ch, b.stark);
+}
+
+void orc_free(void* p) { free(p); }

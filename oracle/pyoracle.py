@@ -35,6 +35,15 @@ class Challenger(C.Structure):
                 ("outb", C.c_uint64 * 8), ("n_out", C.c_uint)]
 
 
+class PgConfig(C.Structure):
+    """orc_pg_config: the proving parameters of bp_config without the device/worker fields."""
+    _fields_ = ([("table_log_lo", C.c_uint32 * 7), ("table_log_hi", C.c_uint32 * 7)]
+                + [(n, C.c_uint32) for n in ("stark_rate_bits", "stark_cap_height", "stark_num_queries",
+                                             "stark_pow_bits", "arity_bits", "final_poly_bits", "rec_log_n",
+                                             "rec_n_cols", "rec_n_const", "rec_rate_bits", "rec_num_queries",
+                                             "rec_pow_bits", "shrink_depth")])
+
+
 class Gl2(C.Structure):
     _fields_ = [("c0", C.c_uint64), ("c1", C.c_uint64)]
 
@@ -91,6 +100,14 @@ def lib():
     L.orc_stark_prove.argtypes = [cfgp, vp, vp, u64p, u64p, C.POINTER(Challenger), u64p]
     L.orc_stark_verify.argtypes = [cfgp, vp, u64p, C.POINTER(Challenger), u64p]
     L.orc_proof_digest.argtypes = [cfgp, u64p, u64p]
+    L.orc_pg_state_build.argtypes = [C.POINTER(PgConfig)]
+    L.orc_pg_state_build.restype = vp
+    L.orc_pg_state_free.argtypes = [vp]
+    L.orc_pg_txn.argtypes = [vp, u64p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_pg_agg.argtypes = [vp, u64p, sz, i, u64p, sz, i, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_pg_block.argtypes = [vp, vp, sz, u64p, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_pg_verify.argtypes = [vp, u64p, sz]
+    L.orc_free.argtypes = [vp]
     _lib = L
     return L
 
@@ -267,3 +284,58 @@ def proof_digest(cfg, proof):
     out = np.empty(4, dtype=np.uint64)
     lib().orc_proof_digest(C.byref(cfg), arr(proof), out)
     return out
+
+
+class PgState:
+    """CPU restatement of ProverState + generate_{txn,agg,block}_proof (oracle/proofgen.c)."""
+
+    def __init__(self, **kw):
+        cfg = PgConfig()
+        for k, v in kw.items():
+            if k in ("table_log_lo", "table_log_hi"):
+                for t in range(7):
+                    getattr(cfg, k)[t] = v[t]
+            else:
+                setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = lib().orc_pg_state_build(C.byref(cfg))
+
+    def _take(self, ptr, n):
+        out = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+        lib().orc_free(ptr)
+        return out
+
+    def txn(self, ir_words):
+        ptr, n = C.POINTER(C.c_uint64)(), C.c_size_t()
+        rc = lib().orc_pg_txn(self.h, arr(ir_words), C.byref(ptr), C.byref(n))
+        if rc:
+            raise RuntimeError("orc_pg_txn failed: %d" % rc)
+        return self._take(ptr, n)
+
+    def agg(self, lhs, lhs_is_agg, rhs, rhs_is_agg):
+        ptr, n = C.POINTER(C.c_uint64)(), C.c_size_t()
+        lhs, rhs = arr(lhs), arr(rhs)
+        rc = lib().orc_pg_agg(self.h, lhs, lhs.size, int(lhs_is_agg), rhs, rhs.size, int(rhs_is_agg), C.byref(ptr),
+                              C.byref(n))
+        if rc:
+            raise RuntimeError("orc_pg_agg failed: %d" % rc)
+        return self._take(ptr, n)
+
+    def block(self, parent, agg):
+        ptr, n = C.POINTER(C.c_uint64)(), C.c_size_t()
+        agg = arr(agg)
+        par = arr(parent) if parent is not None else None
+        rc = lib().orc_pg_block(self.h, par.ctypes.data if par is not None else None, par.size if par is not None else 0,
+                                agg, agg.size, C.byref(ptr), C.byref(n))
+        if rc:
+            raise RuntimeError("orc_pg_block failed: %d" % rc)
+        return self._take(ptr, n)
+
+    def verify(self, proof):
+        proof = arr(proof)
+        return lib().orc_pg_verify(self.h, proof, proof.size)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_pg_state_free(self.h)
+            self.h = None

@@ -1,0 +1,456 @@
+// proofgen.cpp -- L1 of the C ABI: prover/verifier state and the txn / agg / block entry points,
+// mirroring plonky_block_proof_gen/src/{prover_state.rs, proof_gen.rs, verifier_state.rs,
+// proof_types.rs}.  What each call computes is the synthetic workload of SURVEY.md section 8(d)
+// (DESIGN.md section 5); the control flow, ownership, threading and error behaviour follow the
+// reference (see include/bpg.h).
+#include <condition_variable>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include "prover.hpp"
+
+using namespace bpg;
+
+namespace {
+
+constexpr uint64_t IR_MAGIC = 0x52494E5854475042ULL;     // "BPGTXNIR"
+constexpr uint64_t PROOF_BOX_MAGIC = 0x464F4F5250475042ULL;  // "BPGPROOF"
+constexpr uint32_t CIRCUIT_ROOT = 7, CIRCUIT_AGG = 8, CIRCUIT_BLOCK = 9;
+constexpr size_t BOX_HDR = 4;
+const char* TABLE_NAMES[BP_NUM_TABLES] = {"arithmetic", "byte_packing", "cpu", "keccak", "keccak_sponge", "logic", "memory"};
+
+uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+uint64_t circuit_seed(uint32_t table_or_kind, uint32_t degree) {
+  return splitmix64(0xC12C0175EEDULL + ((uint64_t)table_or_kind << 8) + degree);
+}
+
+struct Circuit {  // one preprocessed recursion circuit: constants commitment + its digest
+  uint64_t* d_const_values = nullptr;
+  Committed consts;
+  uint64_t digest[4];
+};
+struct LightCircuit {
+  std::vector<uint64_t> cap;
+  uint64_t digest[4];
+};
+
+}  // namespace
+
+struct bp_state {
+  bp_config cfg;
+  StarkCfg rec_cfg;
+  Worker builder;                       // owns the persistent (preprocessed) device memory
+  std::vector<Circuit> table_circuits;  // [table][degree - lo] flattened
+  uint32_t table_offset[BP_NUM_TABLES];
+  Circuit special[3];                   // root, agg, block
+  // worker pool: `&ProverState` is shared by many threads in the reference (proof_gen.rs:40)
+  mutable std::mutex mu;
+  mutable std::condition_variable cv;
+  mutable std::vector<std::unique_ptr<Worker>> workers;
+  mutable std::vector<Worker*> idle;
+};
+struct bp_verifier_state {
+  StarkCfg rec_cfg;
+  LightCircuit special[3];
+};
+
+namespace {
+
+struct WorkerLease {
+  const bp_state* s;
+  Worker* w;
+  size_t mark;
+  explicit WorkerLease(const bp_state* st) : s(st) {
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv.wait(lk, [&] { return !s->idle.empty(); });
+    w = s->idle.back();
+    s->idle.pop_back();
+    mark = w->arena.mark();
+  }
+  ~WorkerLease() {
+    (void)hipStreamSynchronize(w->stream);
+    w->arena.release(mark);
+    w->abort_flag = nullptr;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->idle.push_back(w);
+    s->cv.notify_one();
+  }
+};
+
+StarkCfg rec_cfg_of(const bp_config& c) {
+  return StarkCfg{c.rec_log_n, c.rec_n_cols, c.rec_n_const, 3, c.rec_rate_bits, c.stark_cap_height,
+                  c.rec_num_queries, c.rec_pow_bits, c.arity_bits, c.final_poly_bits};
+}
+StarkCfg table_cfg_of(const bp_config& c, uint32_t log_n, uint32_t width) {
+  return StarkCfg{log_n, width, 0, 1, c.stark_rate_bits, c.stark_cap_height, c.stark_num_queries,
+                  c.stark_pow_bits, c.arity_bits, c.final_poly_bits};
+}
+
+int build_circuit(Worker& w, const StarkCfg& rc, uint64_t seed, Circuit* out) {
+  const uint64_t N = (uint64_t)1 << rc.log_n;
+  out->d_const_values = w.arena.alloc_words((size_t)rc.n_const * N);
+  if (!out->d_const_values) return fail(BP_ERR_DEVICE, "state arena exhausted");
+  int rc2 = launch_synth_constants(out->d_const_values, rc.log_n, rc.n_const, seed, w.stream);
+  if (rc2) return rc2;
+  if ((rc2 = commit(w, out->d_const_values, rc.n_const, rc.log_n, rc.rate_bits, rc.cap_height, false, &out->consts)))
+    return rc2;
+  hash_no_pad_host(out->consts.cap.data(), out->consts.cap.size(), out->digest);
+  return BP_OK;
+}
+
+struct Box {  // parsed proof container
+  uint64_t kind, n_pi, circuit;
+  const uint64_t *pi, *pv, *stark;
+  size_t stark_words;
+};
+int parse_box(const uint8_t* bytes, size_t len, const StarkCfg& rc, Box* b) {
+  if (!bytes || len % 8 || len < (BOX_HDR + BP_PV_WORDS) * 8) return fail(BP_ERR_INVALID_INPUT, "proof: truncated");
+  const uint64_t* wds = reinterpret_cast<const uint64_t*>(bytes);
+  if (wds[0] != PROOF_BOX_MAGIC) return fail(BP_ERR_INVALID_INPUT, "proof: bad magic");
+  b->kind = wds[1]; b->n_pi = wds[2]; b->circuit = wds[3];
+  if (b->kind > 2 || b->n_pi < BP_PV_WORDS || b->n_pi > 64) return fail(BP_ERR_INVALID_INPUT, "proof: bad header");
+  const size_t sw = proof_layout(rc).total;
+  if (len / 8 != BOX_HDR + b->n_pi + sw) return fail(BP_ERR_INVALID_INPUT, "proof: wrong length for this circuit");
+  b->pi = wds + BOX_HDR;
+  b->pv = b->pi + b->n_pi - BP_PV_WORDS;
+  b->stark = b->pi + b->n_pi;
+  b->stark_words = sw;
+  return BP_OK;
+}
+int emit_box(uint64_t kind, uint64_t circuit, const std::vector<uint64_t>& pi, const std::vector<uint64_t>& stark,
+             uint8_t** out, size_t* out_len) {
+  const size_t words = BOX_HDR + pi.size() + stark.size();
+  uint64_t* o = static_cast<uint64_t*>(std::malloc(words * 8));
+  if (!o) return fail(BP_ERR_DEVICE, "host allocation failed");
+  o[0] = PROOF_BOX_MAGIC; o[1] = kind; o[2] = pi.size(); o[3] = circuit;
+  std::memcpy(o + BOX_HDR, pi.data(), pi.size() * 8);
+  std::memcpy(o + BOX_HDR + pi.size(), stark.data(), stark.size() * 8);
+  *out = reinterpret_cast<uint8_t*>(o);
+  *out_len = words * 8;
+  return BP_OK;
+}
+
+// One recursion-shaped proof: transcript = circuit digest, hash of the public inputs, trace cap.
+int rec_prove(Worker& w, const StarkCfg& rc, const Circuit& circ, const std::vector<uint64_t>& pi,
+              std::vector<uint64_t>& proof) {
+  const size_t mark = w.arena.mark();
+  uint64_t pi_hash[4];
+  hash_no_pad_host(pi.data(), pi.size(), pi_hash);
+  Challenger ch;
+  ch.observe(circ.digest, 4);
+  ch.observe(pi_hash, 4);
+  const uint64_t N = (uint64_t)1 << rc.log_n;
+  uint64_t* d_trace = w.arena.alloc_words((size_t)rc.n_cols * N);
+  if (!d_trace) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB)", w.arena.capacity() >> 20);
+  int r = launch_synth_trace(d_trace, circ.d_const_values, rc.log_n, rc.n_cols, rc.n_const, rc.deg_pow, pi_hash[0],
+                             w.stream);
+  if (r) return r;
+  Committed trace;
+  if ((r = commit(w, d_trace, rc.n_cols, rc.log_n, rc.rate_bits, rc.cap_height, false, &trace))) return r;
+  ch.observe(trace.cap.data(), trace.cap.size());
+  Ctl ctl;
+  for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
+  r = stark_prove(w, rc, &circ.consts, trace, d_trace, ctl, ch, proof);
+  w.arena.release(mark);
+  return r;
+}
+int rec_verify(const StarkCfg& rc, const LightCircuit& circ, const Box& b) {
+  uint64_t pi_hash[4];
+  hash_no_pad_host(b.pi, b.n_pi, pi_hash);
+  Challenger ch;
+  ch.observe(circ.digest, 4);
+  ch.observe(pi_hash, 4);
+  const ProofLayout L = proof_layout(rc);
+  ch.observe(b.stark + L.trace_cap, L.cap_words);
+  Ctl ctl;
+  for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
+  return stark_verify(rc, circ.cap.data(), ctl, ch, b.stark, b.stark_words);
+}
+
+void root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]) {
+  uint64_t in[6] = {root_before[0], root_before[1], root_before[2], root_before[3], gl::canon(seed), gl::canon(txn_number)};
+  hash_no_pad_host(in, 6, out);
+}
+
+}  // namespace
+
+extern "C" {
+
+void bp_config_default(bp_config* c) {
+  // constants.rs:6-18, positional order of prover_state.rs:85-93
+  static const uint32_t lo[BP_NUM_TABLES] = {16, 9, 12, 14, 9, 12, 17}, hi[BP_NUM_TABLES] = {28, 28, 28, 25, 25, 28, 30};
+  std::memset(c, 0, sizeof(*c));
+  for (int t = 0; t < BP_NUM_TABLES; t++) { c->table_log_lo[t] = lo[t]; c->table_log_hi[t] = hi[t]; }
+  c->stark_rate_bits = 1; c->stark_cap_height = 4; c->stark_num_queries = 84; c->stark_pow_bits = 16;
+  c->arity_bits = 4; c->final_poly_bits = 5;
+  c->rec_log_n = 13; c->rec_n_cols = 135; c->rec_n_const = 82; c->rec_rate_bits = 3; c->rec_num_queries = 28;
+  c->rec_pow_bits = 16;
+  c->shrink_depth = 3;
+  c->device = 0; c->n_workers = 4; c->arena_bytes = (uint64_t)6 << 30;
+}
+
+int bp_state_build(const bp_config* cfg, bp_state** out) {
+  if (!cfg || !out) return fail(BP_ERR_INVALID_INPUT, "bp_state_build: null argument");
+  *out = nullptr;
+  const StarkCfg rc = rec_cfg_of(*cfg);
+  int r = check_cfg(rc);
+  if (r) return r;
+  uint32_t n_circ = 0;
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    if (cfg->table_log_lo[t] >= cfg->table_log_hi[t] || cfg->table_log_hi[t] > 31)
+      return fail(BP_ERR_INVALID_INPUT, "empty or invalid range for table %s", TABLE_NAMES[t]);
+    StarkCfg tc = table_cfg_of(*cfg, cfg->table_log_lo[t], 8);
+    if ((r = check_cfg(tc))) return r;
+    n_circ += cfg->table_log_hi[t] - cfg->table_log_lo[t];
+  }
+  if (cfg->n_workers == 0 || cfg->n_workers > 64) return fail(BP_ERR_INVALID_INPUT, "n_workers out of range");
+  int n_dev = bp_device_count();
+  if (n_dev <= 0) return fail(BP_ERR_DEVICE, "no HIP device visible: the hot path has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= n_dev) return fail(BP_ERR_DEVICE, "device %d not present", cfg->device);
+  std::unique_ptr<bp_state> s(new bp_state());
+  s->cfg = *cfg;
+  s->rec_cfg = rc;
+  // persistent memory: per circuit K*n values + K*n coeffs + K*m LDE + digests
+  const uint64_t N = (uint64_t)1 << rc.log_n, M = N << rc.rate_bits;
+  const size_t per = ((size_t)rc.n_const * (2 * N + M) + 2 * M * 4 + 4096) * 8;
+  if ((r = s->builder.init(cfg->device, per * (n_circ + 3) + (64u << 20)))) return r;
+  s->table_circuits.resize(n_circ);
+  uint32_t idx = 0;
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    s->table_offset[t] = idx;
+    for (uint32_t d = cfg->table_log_lo[t]; d < cfg->table_log_hi[t]; d++, idx++)
+      if ((r = build_circuit(s->builder, rc, circuit_seed(t, d), &s->table_circuits[idx]))) return r;
+  }
+  for (uint32_t k = 0; k < 3; k++)
+    if ((r = build_circuit(s->builder, rc, circuit_seed(CIRCUIT_ROOT + k, 0), &s->special[k]))) return r;
+  BPG_HIP(hipStreamSynchronize(s->builder.stream));
+  for (uint32_t i = 0; i < cfg->n_workers; i++) {
+    std::unique_ptr<Worker> w(new Worker());
+    if ((r = w->init(cfg->device, cfg->arena_bytes))) { w->destroy(); return r; }
+    s->idle.push_back(w.get());
+    s->workers.push_back(std::move(w));
+  }
+  *out = s.release();
+  return BP_OK;
+}
+
+void bp_state_free(bp_state* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->cfg.device);
+  for (auto& w : s->workers) w->destroy();
+  s->builder.destroy();
+  delete s;
+}
+
+uint64_t bp_state_device_bytes(const bp_state* s) {
+  if (!s) return 0;
+  return s->builder.arena.capacity() + (uint64_t)s->workers.size() * s->cfg.arena_bytes;
+}
+
+int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas_used_before,
+                 uint64_t gas_used_after, const uint64_t state_root_before[4], uint64_t seed,
+                 const uint32_t table_log_n[BP_NUM_TABLES], const uint32_t table_width[BP_NUM_TABLES],
+                 uint64_t o[BP_IR_WORDS]) {
+  if (!state_root_before || !table_log_n || !table_width || !o) return fail(BP_ERR_INVALID_INPUT, "bp_ir_encode: null argument");
+  o[0] = IR_MAGIC; o[1] = 1; o[2] = block_number; o[3] = txn_number_before; o[4] = gas_used_before; o[5] = gas_used_after;
+  for (int i = 0; i < 4; i++) {
+    if (state_root_before[i] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "state root word is not a canonical field element");
+    o[6 + i] = state_root_before[i];
+  }
+  o[10] = seed;
+  for (int t = 0; t < BP_NUM_TABLES; t++) { o[11 + t] = table_log_n[t]; o[18 + t] = table_width[t]; }
+  return BP_OK;
+}
+
+int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out) {
+  if (!proof || len % 8 || len < (BOX_HDR + BP_PV_WORDS) * 8) return fail(BP_ERR_INVALID_INPUT, "proof: truncated");
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(proof);
+  if (w[0] != PROOF_BOX_MAGIC || w[1] > 2 || w[2] < BP_PV_WORDS || w[2] > 64 || len / 8 < BOX_HDR + w[2])
+    return fail(BP_ERR_INVALID_INPUT, "proof: bad header");
+  if (pv_out) std::memcpy(pv_out, w + BOX_HDR + w[2] - BP_PV_WORDS, BP_PV_WORDS * 8);
+  if (kind_out) *kind_out = (int)w[1];
+  return BP_OK;
+}
+
+int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
+                          uint8_t** out, size_t* out_len) {
+  if (!s || !ir || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof: null argument");
+  if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
+  const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
+  if (I[0] != IR_MAGIC || I[1] != 1) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
+  if (I[5] < I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: gas_used_after < gas_used_before");
+  const bp_config& cfg = s->cfg;
+  StarkCfg tcfg[BP_NUM_TABLES];
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    const uint64_t ln = I[11 + t], wd = I[18 + t];
+    if (ln < cfg.table_log_lo[t] || ln >= cfg.table_log_hi[t])
+      return fail(BP_ERR_RANGE, "table %s needs 2^%llu rows, outside the configured range %u..%u", TABLE_NAMES[t],
+                  (unsigned long long)ln, cfg.table_log_lo[t], cfg.table_log_hi[t]);
+    if (wd > 65536) return fail(BP_ERR_INVALID_INPUT, "table %s: width out of range", TABLE_NAMES[t]);
+    tcfg[t] = table_cfg_of(cfg, (uint32_t)ln, (uint32_t)wd);
+    int r = check_cfg(tcfg[t]);
+    if (r) return r;
+  }
+  for (int i = 0; i < 4; i++) if (I[6 + i] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "IR: non-canonical state root");
+  // PublicValues
+  std::vector<uint64_t> pv(BP_PV_WORDS);
+  pv[0] = I[3]; pv[1] = I[3] + 1; pv[2] = I[4]; pv[3] = I[5];
+  std::memcpy(&pv[4], I + 6, 32);
+  root_after(I + 6, I[10], I[3], &pv[8]);
+  pv[12] = I[2];
+  for (auto& v : pv) v = gl::canon(v);
+
+  (void)hipSetDevice(cfg.device);
+  WorkerLease lease(s);
+  Worker& w = *lease.w;
+  w.abort_flag = abort_flag;
+  if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before start");
+  int r;
+  // generate_traces + trace commitments for all tables, then the shared transcript prologue
+  uint64_t* d_trace[BP_NUM_TABLES];
+  Committed trace[BP_NUM_TABLES];
+  Challenger ch;
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    const uint64_t N = (uint64_t)1 << tcfg[t].log_n;
+    d_trace[t] = w.arena.alloc_words((size_t)tcfg[t].n_cols * N);
+    if (!d_trace[t]) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) for table %s", w.arena.capacity() >> 20, TABLE_NAMES[t]);
+    if ((r = launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, I[10] ^ splitmix64(t + 1), w.stream))) return r;
+    if ((r = commit(w, d_trace[t], tcfg[t].n_cols, tcfg[t].log_n, tcfg[t].rate_bits, tcfg[t].cap_height, false, &trace[t]))) return r;
+    ch.observe(trace[t].cap.data(), trace[t].cap.size());
+  }
+  ch.observe(pv.data(), pv.size());
+  Ctl ctl;
+  for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
+  // table proofs: sequential, one transcript threaded through all of them (plonky2_evm prover)
+  uint64_t digest[BP_NUM_TABLES][4];
+  std::vector<uint64_t> proof;
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before table %s", TABLE_NAMES[t]);
+    const size_t mark = w.arena.mark();
+    if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, proof))) return r;
+    proof_digest(tcfg[t], proof.data(), digest[t]);
+    w.arena.release(mark);
+  }
+  BPG_HIP(hipStreamSynchronize(w.stream));
+  w.arena.release(lease.mark);  // traces are dead; the chains below only need digests
+  // per-table recursion-shaped chain (wrap + shrinks)
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    const Circuit& circ = s->table_circuits[s->table_offset[t] + (tcfg[t].log_n - cfg.table_log_lo[t])];
+    for (uint32_t depth = 0; depth < cfg.shrink_depth; depth++) {
+      if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted in recursion chain of table %s", TABLE_NAMES[t]);
+      std::vector<uint64_t> pi = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (uint64_t)t, depth};
+      if ((r = rec_prove(w, s->rec_cfg, circ, pi, proof))) return r;
+      proof_digest(s->rec_cfg, proof.data(), digest[t]);
+    }
+  }
+  // root proof
+  std::vector<uint64_t> pi;
+  for (int t = 0; t < BP_NUM_TABLES; t++) pi.insert(pi.end(), digest[t], digest[t] + 4);
+  pi.insert(pi.end(), pv.begin(), pv.end());
+  if ((r = rec_prove(w, s->rec_cfg, s->special[0], pi, proof))) return r;
+  return emit_box(0, CIRCUIT_ROOT, pi, proof, out, out_len);
+}
+
+int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
+                          const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len) {
+  if (!s || !lhs || !rhs || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_agg_proof: null argument");
+  Box L, R;
+  int r;
+  if ((r = parse_box(lhs, lhs_len, s->rec_cfg, &L)) || (r = parse_box(rhs, rhs_len, s->rec_cfg, &R))) return r;
+  if ((L.kind == 1) != (lhs_is_agg != 0) || (R.kind == 1) != (rhs_is_agg != 0) || L.kind > 1 || R.kind > 1)
+    return fail(BP_ERR_INVALID_INPUT, "is_agg flags do not match the child proofs");
+  // children must cover contiguous txn ranges (proof_types.rs:23-24)
+  if (L.pv[1] != R.pv[0]) return fail(BP_ERR_INVALID_INPUT, "children are not contiguous: lhs ends at txn %llu, rhs starts at %llu",
+                                      (unsigned long long)L.pv[1], (unsigned long long)R.pv[0]);
+  if (L.pv[3] != R.pv[2] || std::memcmp(L.pv + 8, R.pv + 4, 32) != 0 || L.pv[12] != R.pv[12])
+    return fail(BP_ERR_INVALID_INPUT, "children public values do not chain (gas / state root / block number)");
+  std::vector<uint64_t> pi(10 + BP_PV_WORDS);
+  proof_digest(s->rec_cfg, L.stark, &pi[0]);
+  proof_digest(s->rec_cfg, R.stark, &pi[4]);
+  pi[8] = lhs_is_agg != 0; pi[9] = rhs_is_agg != 0;
+  uint64_t* pv = &pi[10];
+  pv[0] = L.pv[0]; pv[1] = R.pv[1]; pv[2] = L.pv[2]; pv[3] = R.pv[3];
+  std::memcpy(pv + 4, L.pv + 4, 32); std::memcpy(pv + 8, R.pv + 8, 32);
+  pv[12] = L.pv[12];
+  (void)hipSetDevice(s->cfg.device);
+  WorkerLease lease(s);
+  std::vector<uint64_t> proof;
+  if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[1], pi, proof))) return r;
+  return emit_box(1, CIRCUIT_AGG, pi, proof, out, out_len);
+}
+
+int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t parent_len, const uint8_t* agg,
+                            size_t agg_len, uint8_t** out, size_t* out_len, uint64_t* b_height) {
+  if (!s || !agg || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_block_proof: null argument");
+  Box A, Pb;
+  int r;
+  if ((r = parse_box(agg, agg_len, s->rec_cfg, &A))) return r;
+  if (A.kind != 1) return fail(BP_ERR_INVALID_INPUT, "curr_block_agg_proof is not an aggregation proof");
+  std::vector<uint64_t> pi(9 + BP_PV_WORDS, 0);
+  if (parent) {
+    if ((r = parse_box(parent, parent_len, s->rec_cfg, &Pb))) return r;
+    if (Pb.kind != 2) return fail(BP_ERR_INVALID_INPUT, "parent is not a block proof");
+    if (Pb.pv[12] + 1 != A.pv[12]) return fail(BP_ERR_INVALID_INPUT, "parent block height %llu does not precede %llu",
+                                                (unsigned long long)Pb.pv[12], (unsigned long long)A.pv[12]);
+    proof_digest(s->rec_cfg, Pb.stark, &pi[0]);
+    pi[8] = 1;
+  }
+  proof_digest(s->rec_cfg, A.stark, &pi[4]);
+  std::memcpy(&pi[9], A.pv, BP_PV_WORDS * 8);
+  (void)hipSetDevice(s->cfg.device);
+  WorkerLease lease(s);
+  std::vector<uint64_t> proof;
+  if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[2], pi, proof))) return r;
+  if (b_height) *b_height = A.pv[12];  // block_metadata.block_number.low_u64(), proof_gen.rs:90-94
+  return emit_box(2, CIRCUIT_BLOCK, pi, proof, out, out_len);
+}
+
+int bp_verifier_state_from_prover(const bp_state* s, bp_verifier_state** out) {
+  if (!s || !out) return fail(BP_ERR_INVALID_INPUT, "bp_verifier_state_from_prover: null argument");
+  bp_verifier_state* v = new bp_verifier_state();
+  v->rec_cfg = s->rec_cfg;
+  for (int k = 0; k < 3; k++) {
+    v->special[k].cap = s->special[k].consts.cap;
+    std::memcpy(v->special[k].digest, s->special[k].digest, 32);
+  }
+  *out = v;
+  return BP_OK;
+}
+// ProverStateBuilder::build_verifier (verifier_state.rs:34-42): build the circuits, keep the light part.
+int bp_verifier_state_build(const bp_config* cfg, bp_verifier_state** out) {
+  bp_state* s = nullptr;
+  bp_config c = *cfg;
+  c.n_workers = 1;
+  int r = bp_state_build(&c, &s);
+  if (r) return r;
+  r = bp_verifier_state_from_prover(s, out);
+  bp_state_free(s);
+  return r;
+}
+void bp_verifier_state_free(bp_verifier_state* v) { delete v; }
+
+int bp_verify_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len) {
+  if (!v || !proof) return fail(BP_ERR_INVALID_INPUT, "bp_verify_proof: null argument");
+  Box b;
+  int r = parse_box(proof, len, v->rec_cfg, &b);
+  if (r) return r;
+  if (b.circuit != CIRCUIT_ROOT + b.kind) return fail(BP_ERR_VERIFY, "proof was made by circuit %llu, expected %u",
+                                                      (unsigned long long)b.circuit, CIRCUIT_ROOT + (uint32_t)b.kind);
+  for (size_t i = 0; i < b.n_pi; i++) if (b.pi[i] >= gl::P) return fail(BP_ERR_VERIFY, "non-canonical public input");
+  return rec_verify(v->rec_cfg, v->special[b.kind], b);
+}
+int bp_verify_block_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len) {
+  if (!v || !proof) return fail(BP_ERR_INVALID_INPUT, "bp_verify_block_proof: null argument");
+  Box b;
+  int r = parse_box(proof, len, v->rec_cfg, &b);
+  if (r) return r;
+  if (b.kind != 2) return fail(BP_ERR_VERIFY, "not a block proof");
+  return bp_verify_proof(v, proof, len);
+}
+
+}  // extern "C"

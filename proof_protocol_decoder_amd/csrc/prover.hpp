@@ -122,4 +122,8 @@ int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uin
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
                 const uint64_t* d_trace_values, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof);
 
+// CPU verifier (verifier.cpp).  The caller has driven `ch` through the same prologue as the prover.
+int stark_verify(const StarkCfg& cfg, const uint64_t* const_cap, const Ctl& ctl, Challenger& ch,
+                 const uint64_t* proof, size_t n_words);
+
 }  // namespace bpg

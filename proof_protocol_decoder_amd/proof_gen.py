@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's plonky_block_proof_gen API over the C ABI (include/bpg.h).
+
+Same names, argument meaning and error behaviour as the Rust crate:
+  ProverStateBuilder / ProverState      plonky_block_proof_gen/src/prover_state.rs:17-100
+  generate_txn_proof / agg / block      plonky_block_proof_gen/src/proof_gen.rs:39-110
+  GeneratedTxnProof / AggProof / BlockProof / AggregatableProof
+                                        plonky_block_proof_gen/src/proof_types.rs:12-87
+  VerifierState                         plonky_block_proof_gen/src/verifier_state.rs:19-71
+  ProofGenError                         plonky_block_proof_gen/src/proof_gen.rs:16-36
+There is no CPU fallback: everything below calls libbpg.so.
+"""
+import ctypes as C
+import struct
+from dataclasses import dataclass
+
+from ._lib import BpgError, check, lib, take_buffer
+
+NUM_TABLES = 7
+TABLES = ("arithmetic", "byte_packing", "cpu", "keccak", "keccak_sponge", "logic", "memory")
+IR_WORDS, PV_WORDS = 25, 13
+
+ProofGenError = BpgError  # Result<T, ProofGenError(String)> -> exception carrying the message
+
+
+class BpConfig(C.Structure):
+    """bp_config (include/bpg.h)."""
+    _fields_ = ([("table_log_lo", C.c_uint32 * NUM_TABLES), ("table_log_hi", C.c_uint32 * NUM_TABLES)]
+                + [(n, C.c_uint32) for n in ("stark_rate_bits", "stark_cap_height", "stark_num_queries",
+                                             "stark_pow_bits", "arity_bits", "final_poly_bits", "rec_log_n",
+                                             "rec_n_cols", "rec_n_const", "rec_rate_bits", "rec_num_queries",
+                                             "rec_pow_bits", "shrink_depth")]
+                + [("device", C.c_int32), ("n_workers", C.c_uint32), ("arena_bytes", C.c_uint64)])
+
+
+def _bind():
+    L = lib()
+    if getattr(L, "_pg_bound", False):
+        return L
+    vp, u8p, szp = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)
+    L.bp_config_default.argtypes = [C.POINTER(BpConfig)]
+    L.bp_config_default.restype = None
+    L.bp_state_build.argtypes = [C.POINTER(BpConfig), C.POINTER(vp)]
+    L.bp_state_free.argtypes = [vp]
+    L.bp_state_free.restype = None
+    L.bp_state_device_bytes.argtypes = [vp]
+    L.bp_state_device_bytes.restype = C.c_uint64
+    L.bp_generate_txn_proof.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(u8p), szp]
+    L.bp_generate_agg_proof.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int,
+                                        C.POINTER(u8p), szp]
+    L.bp_generate_block_proof.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(u8p), szp,
+                                          C.POINTER(C.c_uint64)]
+    L.bp_verifier_state_from_prover.argtypes = [vp, C.POINTER(vp)]
+    L.bp_verifier_state_build.argtypes = [C.POINTER(BpConfig), C.POINTER(vp)]
+    L.bp_verifier_state_free.argtypes = [vp]
+    L.bp_verifier_state_free.restype = None
+    L.bp_verify_block_proof.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.bp_verify_proof.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.bp_ir_encode.argtypes = [C.c_uint64] * 4 + [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32),
+                                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.bp_proof_public_values.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    L._pg_bound = True
+    return L
+
+
+@dataclass(frozen=True)
+class PublicValues:
+    """Subset of plonky2_evm PublicValues carried by the synthetic workload."""
+    txn_number_before: int
+    txn_number_after: int
+    gas_used_before: int
+    gas_used_after: int
+    state_root_before: tuple
+    state_root_after: tuple
+    block_number: int
+
+    @classmethod
+    def from_words(cls, w):
+        return cls(w[0], w[1], w[2], w[3], tuple(w[4:8]), tuple(w[8:12]), w[12])
+
+
+def public_values_of(proof_bytes):
+    L = _bind()
+    pv = (C.c_uint64 * PV_WORDS)()
+    kind = C.c_int()
+    check(L.bp_proof_public_values(proof_bytes, len(proof_bytes), pv, C.byref(kind)))
+    return PublicValues.from_words(list(pv)), kind.value
+
+
+@dataclass(frozen=True)
+class TxnProofGenIR:
+    """Synthetic stand-in for protocol_decoder::types::TxnProofGenIR (= GenerationInputs,
+    protocol_decoder/src/types.rs:48): what one txn proof is generated from."""
+    block_number: int
+    txn_number_before: int
+    gas_used_before: int
+    gas_used_after: int
+    state_root_before: tuple
+    seed: int
+    table_log_n: tuple
+    table_width: tuple
+
+    def to_bytes(self):
+        L = _bind()
+        out = (C.c_uint64 * IR_WORDS)()
+        check(L.bp_ir_encode(self.block_number, self.txn_number_before, self.gas_used_before, self.gas_used_after,
+                             (C.c_uint64 * 4)(*self.state_root_before), self.seed,
+                             (C.c_uint32 * NUM_TABLES)(*self.table_log_n),
+                             (C.c_uint32 * NUM_TABLES)(*self.table_width), out))
+        return struct.pack("<%dQ" % IR_WORDS, *out)
+
+
+@dataclass(frozen=True)
+class GeneratedTxnProof:
+    p_vals: PublicValues
+    intern: bytes
+
+
+@dataclass(frozen=True)
+class GeneratedAggProof:
+    p_vals: PublicValues
+    intern: bytes
+
+
+@dataclass(frozen=True)
+class GeneratedBlockProof:
+    b_height: int
+    intern: bytes
+
+
+class AggregatableProof:
+    """Sum type Txn | Agg (proof_types.rs:46-87)."""
+
+    def __init__(self, proof):
+        if not isinstance(proof, (GeneratedTxnProof, GeneratedAggProof)):
+            raise TypeError("AggregatableProof wraps a txn or an agg proof")
+        self._p = proof
+
+    def public_values(self):
+        return self._p.p_vals
+
+    def is_agg(self):
+        return isinstance(self._p, GeneratedAggProof)
+
+    def intern(self):
+        return self._p.intern
+
+
+def _as_aggregatable(p):
+    return p if isinstance(p, AggregatableProof) else AggregatableProof(p)
+
+
+class ProverState:
+    """Pre-processed circuits resident in HBM (prover_state.rs:17-20).  Immutable; share freely
+    between threads."""
+
+    def __init__(self, handle, cfg):
+        self._h, self.cfg = handle, cfg
+
+    @property
+    def device_bytes(self):
+        return _bind().bp_state_device_bytes(self._h)
+
+    def close(self):
+        if self._h:
+            _bind().bp_state_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class ProverStateBuilder:
+    """Builder with the reference's default ranges (constants.rs:6-18) and
+    set_<table>_circuit_size(range) setters (prover_state.rs:55-75)."""
+
+    def __init__(self):
+        self.cfg = BpConfig()
+        _bind().bp_config_default(C.byref(self.cfg))
+
+    def _set(self, idx, size):
+        self.cfg.table_log_lo[idx], self.cfg.table_log_hi[idx] = size.start, size.stop
+        return self
+
+    def set_arithmetic_circuit_size(self, size): return self._set(0, size)
+    def set_byte_packing_circuit_size(self, size): return self._set(1, size)
+    def set_cpu_circuit_size(self, size): return self._set(2, size)
+    def set_keccak_circuit_size(self, size): return self._set(3, size)
+    def set_keccak_sponge_circuit_size(self, size): return self._set(4, size)
+    def set_logic_circuit_size(self, size): return self._set(5, size)
+    def set_memory_circuit_size(self, size): return self._set(6, size)
+
+    def set(self, **kw):
+        """Non-reference knobs: device, n_workers, arena_bytes, recursion/STARK shape parameters."""
+        for k, v in kw.items():
+            if not hasattr(self.cfg, k):
+                raise AttributeError(k)
+            setattr(self.cfg, k, v)
+        return self
+
+    def build(self):
+        h = C.c_void_p()
+        check(_bind().bp_state_build(C.byref(self.cfg), C.byref(h)))
+        return ProverState(h, self.cfg)
+
+    def build_verifier(self):
+        h = C.c_void_p()
+        check(_bind().bp_verifier_state_build(C.byref(self.cfg), C.byref(h)))
+        return VerifierState(h)
+
+
+def _out():
+    return C.POINTER(C.c_uint8)(), C.c_size_t()
+
+
+def generate_txn_proof(p_state, gen_inputs, abort_signal=None):
+    """proof_gen.rs:39-56.  abort_signal: optional ctypes.c_int32 shared flag (Arc<AtomicBool>)."""
+    L = _bind()
+    ir = gen_inputs.to_bytes() if isinstance(gen_inputs, TxnProofGenIR) else bytes(gen_inputs)
+    out, n = _out()
+    flag = C.byref(abort_signal) if abort_signal is not None else None
+    check(L.bp_generate_txn_proof(p_state._h, ir, len(ir), flag, C.byref(out), C.byref(n)))
+    intern = take_buffer(out, n)
+    return GeneratedTxnProof(public_values_of(intern)[0], intern)
+
+
+def generate_agg_proof(p_state, lhs_child, rhs_child):
+    """proof_gen.rs:61-79."""
+    L = _bind()
+    lhs, rhs = _as_aggregatable(lhs_child), _as_aggregatable(rhs_child)
+    out, n = _out()
+    check(L.bp_generate_agg_proof(p_state._h, lhs.intern(), len(lhs.intern()), int(lhs.is_agg()), rhs.intern(),
+                                  len(rhs.intern()), int(rhs.is_agg()), C.byref(out), C.byref(n)))
+    intern = take_buffer(out, n)
+    return GeneratedAggProof(public_values_of(intern)[0], intern)
+
+
+def generate_block_proof(p_state, prev_opt_parent_b_proof, curr_block_agg_proof):
+    """proof_gen.rs:85-110."""
+    L = _bind()
+    parent = prev_opt_parent_b_proof.intern if prev_opt_parent_b_proof is not None else None
+    out, n = _out()
+    h = C.c_uint64()
+    check(L.bp_generate_block_proof(p_state._h, parent, len(parent) if parent else 0, curr_block_agg_proof.intern,
+                                    len(curr_block_agg_proof.intern), C.byref(out), C.byref(n), C.byref(h)))
+    return GeneratedBlockProof(h.value, take_buffer(out, n))
+
+
+class VerifierState:
+    """verifier_state.rs:19-23; built from a ProverState (:46-52) or a builder (:34-42)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_prover_state(cls, p_state):
+        h = C.c_void_p()
+        check(_bind().bp_verifier_state_from_prover(p_state._h, C.byref(h)))
+        return cls(h)
+
+    def verify(self, block_proof):
+        """verifier_state.rs:56-71.  Raises ProofGenError when the proof is rejected."""
+        b = block_proof.intern if isinstance(block_proof, GeneratedBlockProof) else bytes(block_proof)
+        check(_bind().bp_verify_block_proof(self._h, b, len(b)))
+
+    def verify_any(self, proof):
+        b = proof.intern if hasattr(proof, "intern") and not callable(proof.intern) else bytes(proof)
+        check(_bind().bp_verify_proof(self._h, b, len(b)))
+
+    def close(self):
+        if self._h:
+            _bind().bp_verifier_state_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,157 @@
+"""GPU parity of the reference-shaped API (generate_txn_proof / agg / block, VerifierState) against
+the oracle: byte-identical proofs, both verifiers accept, error behaviour of proof_gen.rs."""
+import ctypes
+import struct
+
+import numpy as np
+import pytest
+
+from pg_common import LOG_N, SMALL, WIDTH, ir_words
+
+pytestmark = pytest.mark.gpu
+
+
+def words(b):
+    return np.frombuffer(b, dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def pg(bpg):
+    return bpg.proof_gen
+
+
+@pytest.fixture(scope="module")
+def p_state(pg):
+    b = pg.ProverStateBuilder()
+    for t, name in enumerate(pg.TABLES):
+        getattr(b, "set_%s_circuit_size" % name)(range(SMALL["table_log_lo"][t], SMALL["table_log_hi"][t]))
+    b.set(**{k: v for k, v in SMALL.items() if not k.startswith("table_")}, n_workers=2, arena_bytes=256 << 20)
+    st = b.build()
+    yield st
+    st.close()
+
+
+@pytest.fixture(scope="module")
+def o_state(oracle):
+    return oracle.PgState(**SMALL)
+
+
+def make_ir(pg, block, txn_before, seed, root=(1, 2, 3, 4), gas=(100, 121), log_n=LOG_N):
+    return pg.TxnProofGenIR(block, txn_before, gas[0], gas[1], tuple(root), seed, tuple(log_n), tuple(WIDTH))
+
+
+@pytest.fixture(scope="module")
+def chain(pg, p_state):
+    t0 = pg.generate_txn_proof(p_state, make_ir(pg, 7, 0, 0x5EED0001))
+    t1 = pg.generate_txn_proof(p_state, make_ir(pg, 7, 1, 0x5EED0002, root=t0.p_vals.state_root_after, gas=(121, 150)))
+    t2 = pg.generate_txn_proof(p_state, make_ir(pg, 7, 2, 0x5EED0003, root=t1.p_vals.state_root_after, gas=(150, 150)))
+    a01 = pg.generate_agg_proof(p_state, t0, t1)
+    a012 = pg.generate_agg_proof(p_state, a01, t2)
+    blk = pg.generate_block_proof(p_state, None, a012)
+    return t0, t1, t2, a01, a012, blk
+
+
+def test_txn_agg_block_bytes_match_oracle(pg, p_state, o_state, chain):
+    t0, t1, t2, a01, a012, blk = chain
+    o0 = o_state.txn(ir_words(7, 0, 0x5EED0001))
+    assert (words(t0.intern) == o0).all()
+    o1 = o_state.txn(ir_words(7, 1, 0x5EED0002, root_before=t0.p_vals.state_root_after, gas=(121, 150)))
+    assert (words(t1.intern) == o1).all()
+    oa = o_state.agg(o0, False, o1, False)
+    assert (words(a01.intern) == oa).all()
+    oa2 = o_state.agg(oa, True, words(t2.intern), False)
+    assert (words(a012.intern) == oa2).all()
+    ob = o_state.block(None, oa2)
+    assert (words(blk.intern) == ob).all()
+    assert blk.b_height == 7
+    # each side's verifier accepts the other side's proofs
+    for p in (t0, a01, a012, blk):
+        assert o_state.verify(words(p.intern)) == 0
+    v = pg.VerifierState.from_prover_state(p_state)
+    v.verify(blk)
+    v.verify(ob.tobytes())
+    v.verify_any(oa.tobytes())
+
+
+def test_public_values_chain(chain):
+    t0, t1, t2, a01, a012, blk = chain
+    assert (t0.p_vals.txn_number_before, t0.p_vals.txn_number_after) == (0, 1)
+    assert a012.p_vals.txn_number_before == 0 and a012.p_vals.txn_number_after == 3
+    assert a012.p_vals.state_root_before == (1, 2, 3, 4)
+    assert a012.p_vals.state_root_after == t2.p_vals.state_root_after
+    assert a012.p_vals.gas_used_after == 150 and a012.p_vals.block_number == 7
+
+
+def test_block_proof_chains_to_parent(pg, p_state, chain, o_state):
+    *_, a012, blk = chain
+    nxt0 = pg.generate_txn_proof(p_state, make_ir(pg, 8, 0, 0x5EED0101))
+    nxt1 = pg.generate_txn_proof(p_state, make_ir(pg, 8, 1, 0x5EED0102, root=nxt0.p_vals.state_root_after,
+                                                  gas=(121, 130)))
+    agg = pg.generate_agg_proof(p_state, nxt0, nxt1)
+    b2 = pg.generate_block_proof(p_state, blk, agg)
+    assert b2.b_height == 8
+    pg.VerifierState.from_prover_state(p_state).verify(b2)
+    assert o_state.verify(words(b2.intern)) == 0
+    with pytest.raises(pg.ProofGenError) as e:   # height must follow the parent
+        pg.generate_block_proof(p_state, b2, agg)
+    assert e.value.code == -2
+
+
+def test_verifier_rejects_corruption(pg, p_state, chain):
+    *_, blk = chain
+    v = pg.VerifierState.from_prover_state(p_state)
+    w = words(blk.intern).copy()
+    rng = np.random.default_rng(5)
+    for i in list(rng.integers(4, w.size, size=10)) + [4 + 9, 4 + 22 + 16]:  # a public value, the trace cap
+        bad = w.copy()
+        bad[i] ^= np.uint64(1 << int(rng.integers(0, 60)))
+        with pytest.raises(pg.ProofGenError) as e:
+            v.verify(bad.tobytes())
+        assert e.value.code in (-5, -2)
+    with pytest.raises(pg.ProofGenError):        # an agg proof is not a block proof
+        v.verify(chain[3].intern)
+    with pytest.raises(pg.ProofGenError):
+        v.verify(blk.intern[:-8])
+
+
+def test_agg_requires_contiguous_children(pg, p_state, chain):
+    t0, t1, t2, a01, *_ = chain
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_agg_proof(p_state, t1, t0)
+    assert e.value.code == -2 and "contiguous" in e.value.message
+    with pytest.raises(pg.ProofGenError):
+        pg.generate_agg_proof(p_state, t0, t2)
+    with pytest.raises(pg.ProofGenError):        # rhs must follow the whole lhs range
+        pg.generate_agg_proof(p_state, a01, t1)
+
+
+def test_range_and_input_errors(pg, p_state):
+    log_n = list(LOG_N)
+    log_n[3] = SMALL["table_log_hi"][3]            # one past the configured keccak range
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_txn_proof(p_state, make_ir(pg, 7, 0, 1, log_n=log_n))
+    assert e.value.code == -3 and "keccak" in e.value.message
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_txn_proof(p_state, b"\x00" * 200)
+    assert e.value.code == -2
+    with pytest.raises(pg.ProofGenError):
+        pg.generate_txn_proof(p_state, b"short")
+
+
+def test_abort_signal(pg, p_state):
+    flag = ctypes.c_int32(1)
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_txn_proof(p_state, make_ir(pg, 7, 0, 5), abort_signal=flag)
+    assert e.value.code == -1
+    flag.value = 0
+    pg.generate_txn_proof(p_state, make_ir(pg, 7, 0, 5), abort_signal=flag)   # the worker is reusable afterwards
+
+
+def test_concurrent_callers_share_the_state(pg, p_state, o_state):
+    from concurrent.futures import ThreadPoolExecutor
+    irs = [make_ir(pg, 9, i, 0xABC000 + i) for i in range(6)]
+    with ThreadPoolExecutor(4) as ex:
+        proofs = list(ex.map(lambda ir: pg.generate_txn_proof(p_state, ir), irs))
+    again = pg.generate_txn_proof(p_state, irs[3])
+    assert proofs[3].intern == again.intern                  # deterministic, independent of scheduling
+    assert (words(proofs[5].intern) == o_state.txn(ir_words(9, 5, 0xABC005))).all()
