@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- txn-proofs/sec on the 256-txn synthetic block (BASELINE.json metric), one process
+per GPU.
+
+A step = one whole 256-txn block: every rank proves its contiguous slice of the block's txns and
+its local aggregation subtree; the N sub-block proofs are gathered to rank 0 over RCCL, which
+finishes the tree and makes the block proof (strong scaling: the block is fixed, the slice shrinks
+with N).  value = 256 * steps / wall time, inputs (the IRs) resident before the clock starts; the
+witness of each txn is generated on the GPU inside generate_txn_proof, as generate_traces runs
+inside the reference's call (proof_gen.rs:44-52).
+
+Extra objects on the JSON line:
+  roofline      -- the LDE coset-NTT kernel (the HBM-roofline kernel the metric names), measured
+                   with HIP events on the kernel's own stream over the timed region;
+  roofline_isolated -- the same kernel alone on the chip at the widest table shape;
+  cpu_baseline  -- the oracle (CPU restatement, OpenMP) proving ONE txn of the same block.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# SURVEY.md section 8(d) S1 "transfer-txn": range minima of constants.rs:6-18, placeholder widths
+S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
+S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--txns", type=int, default=256, help="transactions per block")
+    ap.add_argument("--threads", type=int, default=8, help="concurrent provers (HIP streams) per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import proof_protocol_decoder_amd as pkg
+    from proof_protocol_decoder_amd import proof_gen as pg
+    from proof_protocol_decoder_amd.block_driver import BlockDriver, TorchGather, shard_bounds, synthetic_block_irs
+    L = pkg.lib()
+    L.bp_profile_read.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+
+    t_build = time.time()
+    # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
+    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads, arena_bytes=5 << 30).build()
+    t_build = time.time() - t_build
+    driver = BlockDriver(state, n_threads=args.threads)
+    gather = TorchGather(torch.device("cuda", local_rank)) if world > 1 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    blocks = [synthetic_block_irs(b, args.txns, S1_LOG_N, S1_WIDTH) for b in range(args.warmup + args.steps)]
+    last = None
+    for b in range(args.warmup):
+        last = driver.prove_block_distributed(blocks[b], rank, world, gather)
+    if not args.no_profile:
+        L.bp_profile_reset()
+        L.bp_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for b in range(args.warmup, args.warmup + args.steps):
+        last = driver.prove_block_distributed(blocks[b], rank, world, gather)
+    barrier()
+    dt = time.perf_counter() - t0
+    L.bp_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    if not args.no_profile:
+        n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
+        pkg._lib.check(L.bp_profile_read(0, C.byref(n), C.byref(ms), C.byref(by)))
+        if n.value:
+            ach = by.value / (ms.value * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "ntt_lds_kernel<DIT> (coset LDE)", "achieved": round(ach, 1),
+                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                        "alg_bytes_per_launch": round(by.value / n.value),
+                        "note": "in situ: %d prover streams share the chip, mostly with integer-ALU-bound Poseidon "
+                                "kernels" % args.threads}
+
+    if rank == 0:
+        # acceptance: the block proof verifies (VerifierState::verify, verifier_state.rs:56-71)
+        pg.VerifierState.from_prover_state(state).verify(last)
+        out = {
+            "metric": "txn-proofs/sec (whole node), 256-txn synthetic block",
+            "value": round(args.txns * args.steps / dt, 3), "unit": "txn-proofs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64 (Goldilocks field)",
+            "data": "synthetic",
+            "config": {"workload": "%d-txn synthetic block, S1 transfer-txn tables logN=%s widths=%s, 7 table STARKs "
+                                   "+ 22 recursion-shaped proofs per txn, %d agg proofs + 1 block proof per block"
+                                   % (args.txns, list(S1_LOG_N), list(S1_WIDTH), args.txns - 1),
+                       "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
+                       "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
+                       "state_build_s": round(t_build, 2), "state_device_gib": round(state.device_bytes / 2**30, 2)},
+            "roofline": roofline,
+        }
+        if world == 1:
+            out["roofline_isolated"] = isolated_roofline(pkg, torch)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0])
+        print(json.dumps(out), flush=True)
+    driver.close()
+    state.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def isolated_roofline(pkg, torch):
+    """The LDE kernel alone on the chip at the widest table shape (2^14 x 2432, rate 2)."""
+    log_n, C_, r = 14, 2432, 1
+    n = 1 << log_n
+    coeffs = torch.randint(0, 2**62, (C_, n), dtype=torch.int64, device="cuda")
+    pkg.ops.lde_batch(coeffs, r, from_coeffs=True)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        pkg.ops.lde_batch(coeffs, r, from_coeffs=True)   # launches on torch's current stream
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    alg = 8.0 * n * C_ * (1 + (1 << r))
+    ach = alg / (best * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "ntt_lds_kernel<DIT> (coset LDE), 2^14 x 2432, rate 2, alone", "achieved": round(ach, 1),
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "launch_ms": round(best, 4)}
+
+
+def cpu_baseline(ir):
+    """Oracle (CPU restatement, OpenMP over the host cores) proving one txn of the block."""
+    from oracle import pyoracle  # checker / baseline only
+    pyoracle.build()
+    cores = os.cpu_count() or 1
+    lo, hi = list(S1_LOG_N), [x + 1 for x in S1_LOG_N]
+    st = pyoracle.PgState(table_log_lo=lo, table_log_hi=hi, stark_rate_bits=1, stark_cap_height=4,
+                          stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5, rec_log_n=13,
+                          rec_n_cols=135, rec_n_const=82, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
+                          shrink_depth=3)
+    import struct
+    words = list(struct.unpack("<25Q", ir.to_bytes()))
+    t0 = time.perf_counter()
+    st.txn(words)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "txn-proofs/s", "cores": cores, "kind": "port",
+            "sample": "1 txn proof of the same block (7 tables + 22 recursion-shaped proofs), incl. lazy "
+                      "preprocessing of the 8 circuits it touches; %.1f s" % dt}
+
+
+if __name__ == "__main__":
+    main()

@@ -177,6 +177,16 @@ int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas
  * root_after[4], block_number */
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out);
 
+/* state root after one synthetic txn (host-side helper for building a chain of IRs) */
+int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]);
+
+/* Optional HIP-event timing of the NTT kernel families on their own streams (bench.py roofline leg).
+ * family 0: LDE coset NTT (LDS-resident DIT), 1: inverse NTT (DIF).  total_alg_bytes uses the
+ * algorithmic byte counts of SURVEY.md section 8(d). */
+void bp_profile_enable(int on);
+void bp_profile_reset(void);
+int bp_profile_read(int family, uint64_t* launches, double* total_ms, double* total_alg_bytes);
+
 #ifdef __cplusplus
 }
 #endif

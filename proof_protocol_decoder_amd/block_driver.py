@@ -1,0 +1,129 @@
+"""Block-level driver: what the reference leaves to an external scheduler ("Paladin",
+docs/usage_seq_diagrams.md:8-20) -- fan the txns of a block out, aggregate, make the block proof.
+
+One process per GPU.  Transactions are independent (trace_protocol.rs:18-22), so rank r proves the
+CONTIGUOUS slice [r*n/N, (r+1)*n/N) (aggregation needs contiguous ranges, proof_types.rs:23-24) and
+folds it into one proof with a local balanced tree: no communication.  The only exchange step of
+the whole path is the gather of the N sub-block proofs (a few hundred KB each) to rank 0, which
+finishes the tree (N-1 aggregation proofs) and makes the block proof.  No field data ever crosses
+GPUs, so there is no all-reduce here by construction.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+from . import proof_gen as pg
+
+
+def shard_bounds(n_items, rank, world_size):
+    """Contiguous, balanced split: the first (n_items % world_size) ranks get one extra item."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def tree_reduce(proofs, agg_fn, pool=None):
+    """Fold a contiguous list of aggregatable proofs left-to-right into one, level by level.
+    Every level's aggregations are independent and run concurrently on `pool`."""
+    level = list(proofs)
+    if not level:
+        raise ValueError("nothing to aggregate")
+    while len(level) > 1:
+        pairs = [(level[i], level[i + 1]) for i in range(0, len(level) - 1, 2)]
+        if pool is not None and len(pairs) > 1:
+            nxt = list(pool.map(lambda p: agg_fn(p[0], p[1]), pairs))
+        else:
+            nxt = [agg_fn(a, b) for a, b in pairs]
+        if len(level) % 2:
+            nxt.append(level[-1])
+        level = nxt
+    return level[0]
+
+
+class TorchGather:
+    """Gather variable-length proof bytes to rank 0 with torch.distributed (backend nccl = RCCL over
+    xGMI on the GPU box, gloo in the CPU tests).  Lengths first, then one padded uint8 gather."""
+
+    def __init__(self, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.device = torch, dist, device
+
+    def gather_bytes(self, payload):
+        torch, dist = self.torch, self.dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+        n = torch.tensor([len(payload)], dtype=torch.int64, device=self.device)
+        lens = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(lens, n)
+        max_len = max(int(x.item()) for x in lens)
+        buf = torch.zeros(max_len, dtype=torch.uint8, device=self.device)
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self.device)
+        out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, out, dst=0)
+        if rank != 0:
+            return None
+        return [bytes(out[r][:int(lens[r].item())].cpu().numpy().tobytes()) for r in range(world)]
+
+
+class BlockDriver:
+    """prove_txn(ir) -> GeneratedTxnProof, prove_agg(lhs, rhs) -> GeneratedAggProof,
+    prove_block(parent_or_None, agg) -> GeneratedBlockProof.  The defaults bind the HIP library."""
+
+    def __init__(self, p_state=None, n_threads=4, prove_txn=None, prove_agg=None, prove_block=None,
+                 decode_proof=None):
+        self.pool = ThreadPoolExecutor(n_threads) if n_threads > 1 else None
+        self.prove_txn = prove_txn or (lambda ir: pg.generate_txn_proof(p_state, ir))
+        self.prove_agg = prove_agg or (lambda a, b: pg.generate_agg_proof(p_state, a, b))
+        self.prove_block = prove_block or (lambda parent, agg: pg.generate_block_proof(p_state, parent, agg))
+        self.decode_proof = decode_proof or self._decode
+
+    @staticmethod
+    def _decode(raw):
+        pv, kind = pg.public_values_of(raw)
+        return (pg.GeneratedAggProof if kind == 1 else pg.GeneratedTxnProof)(pv, raw)
+
+    def prove_shard(self, irs):
+        """All txn proofs of a contiguous slice, then its local aggregation tree."""
+        if self.pool is not None:
+            txn_proofs = list(self.pool.map(self.prove_txn, irs))
+        else:
+            txn_proofs = [self.prove_txn(ir) for ir in irs]
+        return tree_reduce(txn_proofs, self.prove_agg, self.pool), txn_proofs
+
+    def prove_block_distributed(self, irs, rank=0, world_size=1, gather=None, parent=None):
+        """Returns the GeneratedBlockProof on rank 0, None elsewhere."""
+        lo, hi = shard_bounds(len(irs), rank, world_size)
+        if hi <= lo:
+            raise ValueError("rank %d has no transactions (block of %d over %d ranks)" % (rank, len(irs), world_size))
+        sub, _ = self.prove_shard(irs[lo:hi])
+        if world_size > 1:
+            raws = gather.gather_bytes(sub.intern)
+            if rank != 0:
+                return None
+            subs = [self.decode_proof(r) for r in raws]
+        else:
+            subs = [sub]
+        top = tree_reduce(subs, self.prove_agg, self.pool)
+        if not isinstance(top, pg.GeneratedAggProof):
+            raise ValueError("a block needs at least two transactions (decoding.rs:304-347 pads to >= 2)")
+        return self.prove_block(parent, top)
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown()
+
+
+def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_base=0x5EED000000000000,
+                        root0=(1, 2, 3, 4)):
+    """The synthetic block of SURVEY.md section 8(d): n_txns txns with distinct seeds whose public
+    values chain (state root, txn number, gas) like decoding.rs:106-154 chains GenerationInputs."""
+    import ctypes as C
+    L = pg._bind()
+    L.bp_state_root_after.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    irs, root, gas = [], tuple(root0), 0
+    for i in range(n_txns):
+        seed = seed_base + (block_number << 20) + i
+        irs.append(pg.TxnProofGenIR(block_number, i, gas, gas + 21000, root, seed, tuple(table_log_n),
+                                    tuple(table_width)))
+        out = (C.c_uint64 * 4)()
+        pg.check(L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out))
+        root, gas = tuple(out), gas + 21000
+    return irs

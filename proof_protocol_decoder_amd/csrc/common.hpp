@@ -21,6 +21,19 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
 #define BPG_LAUNCH_CHECK() BPG_HIP(hipGetLastError())
 
+// Optional per-kernel-family HIP-event timing (bench.py's roofline leg).  Off by default: when off the
+// guard is two branches.  Families: 0 = LDE coset NTT (DIT, LDS-resident), 1 = inverse NTT (DIF).
+enum { PROF_LDE_DIT = 0, PROF_INTT_DIF = 1, PROF_FAMILIES = 2 };
+bool profile_on();
+struct KernelTimer {
+  KernelTimer(int family, hipStream_t st, double alg_bytes);
+  ~KernelTimer();
+  int family;
+  hipStream_t st;
+  double bytes;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline unsigned ceil_div(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 

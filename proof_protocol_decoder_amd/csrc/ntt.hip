@@ -290,7 +290,10 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
   a.log_blk = log_blk; a.log_n_total = log_n;
   dim3 grid(1u << (log_n - log_blk), n_cols, 1);
   size_t lds = (size_t)8 << log_blk;
-  ntt_lds_kernel<true><<<grid, lds_threads(log_blk), lds, st>>>(a);
+  {
+    KernelTimer kt(PROF_INTT_DIF, st, 16.0 * (double)n_cols * (double)((uint64_t)1 << log_n));
+    ntt_lds_kernel<true><<<grid, lds_threads(log_blk), lds, st>>>(a);
+  }
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -310,7 +313,11 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
   a.tw = tw_b; a.scale = scale; a.out_scalar = 1; a.log_blk = log_blk; a.log_n_total = log_n;
   dim3 grid(1u << (log_n - log_blk), n_cols, n_cosets);
   size_t lds = (size_t)8 << log_blk;
-  ntt_lds_kernel<false><<<grid, lds_threads(log_blk), lds, st>>>(a);
+  {
+    // algorithmic bytes: coefficients read once, every coset written once
+    KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
+    ntt_lds_kernel<false><<<grid, lds_threads(log_blk), lds, st>>>(a);
+  }
   BPG_LAUNCH_CHECK();
   if (log_n > LOG_BLK_MAX) {
     if ((rc = get_table(inverse ? 1 : 0, log_n, 0, &tw_n))) return rc;

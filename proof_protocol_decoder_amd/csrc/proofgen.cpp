@@ -267,6 +267,15 @@ int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas
   return BP_OK;
 }
 
+// root_after of one txn (the synthetic "state transition"): hash_no_pad(root_before, seed, txn_number).
+// Host-side, like the decoder that chains GenerationInputs in the reference (decoding.rs:106-154).
+int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]) {
+  if (!root_before || !out) return fail(BP_ERR_INVALID_INPUT, "bp_state_root_after: null argument");
+  for (int i = 0; i < 4; i++) if (root_before[i] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "non-canonical state root");
+  root_after(root_before, seed, txn_number, out);
+  return BP_OK;
+}
+
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out) {
   if (!proof || len % 8 || len < (BOX_HDR + BP_PV_WORDS) * 8) return fail(BP_ERR_INVALID_INPUT, "proof: truncated");
   const uint64_t* w = reinterpret_cast<const uint64_t*>(proof);
