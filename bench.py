@@ -24,6 +24,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One HIP stream per concurrent prover: let the runtime map them onto distinct hardware queues
+# (ROCm multiplexes streams onto GPU_MAX_HW_QUEUES = 4 queues by default).  Must be set before
+# the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 # SURVEY.md section 8(d) S1 "transfer-txn": range minima of constants.rs:6-18, placeholder widths
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
@@ -37,7 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--txns", type=int, default=256, help="transactions per block")
-    ap.add_argument("--threads", type=int, default=8, help="concurrent provers (HIP streams) per GPU")
+    ap.add_argument("--threads", type=int, default=16, help="concurrent provers (HIP streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
     args = ap.parse_args()

@@ -63,6 +63,8 @@ def lib():
                                            C.POINTER(C.c_size_t)]
     L.bp_free_buffer.argtypes = [C.POINTER(C.c_uint8)]
     L.bp_free_buffer.restype = None
+    L.bp_tune_quad_threshold.argtypes = [u64]
+    L.bp_tune_quad_threshold.restype = None
     _lib = L
     return L
 

@@ -5,6 +5,7 @@
 // Leaf hashing streams the LDE matrix once (8*L*C bytes, coalesced 8-byte column loads: lane =
 // row, so a wave reads 512 contiguous bytes per column) but is integer-ALU bound: ceil(C/8)
 // permutations per row.
+#include <atomic>
 #include "common.hpp"
 #include "poseidon.cuh"
 
@@ -56,6 +57,46 @@ leaf_hash_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_c
   for (int k = 0; k < 4; k++) d[k] = gl::canon(s[k]);
 }
 
+// Quad-cooperative variants (poseidon.cuh): four lanes per row / node.  blockDim = 256 = 64 quads.
+__global__ void __launch_bounds__(256)
+leaf_hash_quad_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
+                      uint32_t rate_bits, uint64_t* __restrict__ digests) {
+  __shared__ uint64_t rc[360];
+  for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
+  __syncthreads();
+  const uint64_t rows = (uint64_t)1 << (log_n + rate_bits);
+  const uint64_t pos = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 2;
+  if (pos >= rows) return;  // whole quads leave together (rows is a power of two >= 1, 64 quads per block)
+  const poseidon::QuadCtx qc = poseidon::quad_ctx();
+  const uint32_t q = qc.q;
+  const uint32_t t = (uint32_t)(pos >> log_n), m = (uint32_t)(pos & ((1u << log_n) - 1));
+  const uint64_t leaf = ((uint64_t)gl::bitrev(t, rate_bits) << log_n) | gl::bitrev(m, log_n);
+  const uint64_t* p = lde + pos;
+  uint64_t e[3] = {0, 0, 0};
+  if (n_cols <= 4) {
+    if (q < n_cols) e[0] = p[(uint64_t)q * stride];
+  } else {
+    for (uint32_t c = 0; c < n_cols; c += 8) {
+      if (c + q < n_cols) e[0] = p[(uint64_t)(c + q) * stride];
+      if (c + 4 + q < n_cols) e[1] = p[(uint64_t)(c + 4 + q) * stride];
+      poseidon::permute_quad(e, qc, rc);
+    }
+  }
+  digests[leaf * 4 + q] = gl::canon(e[0]);
+}
+__global__ void __launch_bounds__(256)
+merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents) {
+  __shared__ uint64_t rc[360];
+  for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
+  __syncthreads();
+  const uint64_t i = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 2;
+  if (i >= n_parents) return;
+  const poseidon::QuadCtx qc = poseidon::quad_ctx();
+  uint64_t e[3] = {child[i * 8 + qc.q], child[i * 8 + 4 + qc.q], 0};
+  poseidon::permute_quad(e, qc, rc);
+  parent[i * 4 + qc.q] = gl::canon(e[0]);
+}
+
 // Row-major leaves (FRI layers): leaf k = leaf_len consecutive words.
 __global__ void __launch_bounds__(256)
 leaf_hash_rows_kernel(const uint64_t* __restrict__ leaves, uint32_t leaf_len, uint64_t n_leaves,
@@ -100,12 +141,19 @@ merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ p
 
 namespace bpg {
 
+// launches with fewer permutations than this use the quad-cooperative kernels (4x the waves)
+static std::atomic<uint64_t> g_quad_threshold{(uint64_t)1 << 17};
+uint64_t quad_threshold() { return g_quad_threshold.load(std::memory_order_relaxed); }
+
 int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st) {
   uint64_t* lvl = d_digests;
   for (uint32_t l = log_leaves; l > cap_height; l--) {
     uint64_t cnt = (uint64_t)1 << l;
     uint64_t* nxt = lvl + cnt * 4;
-    merkle_level_kernel<<<ceil_div(cnt / 2, 256), 256, 0, st>>>(lvl, nxt, cnt / 2);
+    if (cnt / 2 < quad_threshold())
+      merkle_level_quad_kernel<<<ceil_div(cnt * 2, 256), 256, 0, st>>>(lvl, nxt, cnt / 2);
+    else
+      merkle_level_kernel<<<ceil_div(cnt / 2, 256), 256, 0, st>>>(lvl, nxt, cnt / 2);
     BPG_LAUNCH_CHECK();
     lvl = nxt;
   }
@@ -123,6 +171,8 @@ int merkle_commit_rows(const uint64_t* d_leaves, uint32_t leaf_len, uint32_t log
 }  // namespace bpg
 
 extern "C" {
+
+void bp_tune_quad_threshold(uint64_t n_perms) { bpg::g_quad_threshold.store(n_perms); }
 
 uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {
   return (((uint64_t)2 << log_leaves) - ((uint64_t)1 << cap_height)) * 4;
@@ -146,8 +196,12 @@ int bp_merkle_commit(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols
                      log_n, rate_bits, cap_height, n_cols, (unsigned long long)lde_stride);
   hipStream_t st = bpg::as_stream(stream);
   uint64_t rows = (uint64_t)1 << log_leaves;
-  leaf_hash_kernel<<<bpg::ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
-                                                            d_digests);
+  if (rows < bpg::quad_threshold())
+    leaf_hash_quad_kernel<<<bpg::ceil_div(rows * 4, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
+                                                                      d_digests);
+  else
+    leaf_hash_kernel<<<bpg::ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
+                                                              d_digests);
   BPG_LAUNCH_CHECK();
   return bpg::merkle_upper_levels(d_digests, log_leaves, cap_height, st);
 }

@@ -456,10 +456,11 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
     pa.bits = cfg.pow_bits;
     uint64_t nonce = 0;
     if (cfg.pow_bits) {
-      const uint32_t batch = 1u << 20;
+      // expected 2^pow_bits candidates: first batch 2x that (86% hit), then grow to 2^20
+      uint32_t batch = std::min<uint32_t>(1u << 20, std::max<uint32_t>(1u << 12, 2u << cfg.pow_bits));
       unsigned long long res = ~0ULL;
       BPG_HIP(hipMemsetAsync(w.d_pow_result, 0xFF, 8, st));
-      for (uint64_t base = 0;; base += batch) {
+      for (uint64_t base = 0;; base += batch, batch = std::min<uint32_t>(1u << 20, batch * 2)) {
         pa.base = base;
         TRY(launch_pow(pa, batch, w.d_pow_result, st));
         TRY(w.d2h(reinterpret_cast<uint64_t*>(&res), reinterpret_cast<uint64_t*>(w.d_pow_result), 1));

@@ -328,6 +328,31 @@ __global__ void __launch_bounds__(256) fri_layer_leaf_kernel(bpg::FriLayerArgs a
 #pragma unroll
   for (int k = 0; k < 4; k++) a.digests[leaf * 4 + k] = gl::canon(s[k]);
 }
+// Quad-cooperative form of the same leaf hash: lane q of a quad carries state words q and q+4, i.e.
+// component (q & 1) of ext elements (q >> 1) and 2 + (q >> 1) of every 4-element absorb.
+__global__ void __launch_bounds__(256) fri_layer_leaf_quad_kernel(bpg::FriLayerArgs a) {
+  __shared__ uint64_t rc[360];
+  for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
+  __syncthreads();
+  const uint32_t log_q = a.log_nl - a.arity_bits;
+  const uint64_t n_leaves = (uint64_t)1 << (log_q + a.rate_bits);
+  const uint64_t id = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 2;
+  if (id >= n_leaves) return;
+  const poseidon::QuadCtx qc = poseidon::quad_ctx();
+  const uint32_t t = (uint32_t)(id >> log_q), m0 = (uint32_t)(id & ((1u << log_q) - 1));
+  const uint64_t base = ((uint64_t)t << a.log_nl) + m0;
+  const uint32_t arity = 1u << a.arity_bits, u = qc.q >> 1, comp = qc.q & 1;
+  uint64_t e[3] = {0, 0, 0};
+  for (uint32_t j = 0; j < arity; j += 4) {
+    const uint64_t p0 = base + ((uint64_t)gl::bitrev(j + u, a.arity_bits) << log_q);
+    const uint64_t p1 = base + ((uint64_t)gl::bitrev(j + 2 + u, a.arity_bits) << log_q);
+    e[0] = a.values[2 * p0 + comp];
+    e[1] = a.values[2 * p1 + comp];
+    poseidon::permute_quad(e, qc, rc);
+  }
+  const uint64_t leaf = gl::bitrev((uint32_t)(t + ((uint64_t)m0 << a.rate_bits)), log_q + a.rate_bits);
+  a.digests[leaf * 4 + qc.q] = gl::canon(e[0]);
+}
 // P'(x0^a) = sum_i (beta/x0)^i u_i,  u_i = 1/a * sum_j' w_a^(-i j') P(x0 w_a^j')
 __global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
   const uint32_t log_q = a.log_nl - a.arity_bits;
@@ -499,9 +524,11 @@ int launch_fri_init(const FriInitArgs& a, hipStream_t st) {
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+uint64_t quad_threshold();  // hash_kernels.hip
 int launch_fri_layer_leaves(const FriLayerArgs& a, hipStream_t st) {
   uint64_t n = (uint64_t)1 << (a.log_nl - a.arity_bits + a.rate_bits);
-  fri_layer_leaf_kernel<<<ceil_div(n, 256), 256, 0, st>>>(a);
+  if (n < quad_threshold()) fri_layer_leaf_quad_kernel<<<ceil_div(n * 4, 256), 256, 0, st>>>(a);
+  else fri_layer_leaf_kernel<<<ceil_div(n, 256), 256, 0, st>>>(a);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }

@@ -67,9 +67,13 @@ def test_poseidon_noncanonical_inputs(bpg, oracle):
     assert (got == oracle.poseidon(s % np.uint64(P))).all()
 
 
+@pytest.mark.parametrize("quad", [True, False], ids=["quad", "lane"])
 @pytest.mark.parametrize("log_n,rate_bits,n_cols,cap_h", [(3, 1, 3, 4), (4, 1, 4, 0), (6, 1, 8, 4), (7, 3, 19, 4),
-                                                          (10, 1, 135, 4), (12, 1, 33, 2), (9, 3, 2, 4)])
-def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap_h):
+                                                          (10, 1, 135, 4), (12, 1, 33, 2), (9, 3, 2, 4), (5, 1, 9, 1),
+                                                          (6, 1, 13, 3)])
+def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap_h, quad):
+    # both Poseidon kernel families (4 lanes per state with DPP exchange / one lane per state)
+    bpg.lib().bp_tune_quad_threshold((1 << 40) if quad else 0)
     rng = np.random.default_rng(300 + log_n)
     rows = 1 << (log_n + rate_bits)
     lde_cm = rand_field(rng, (n_cols, rows))          # coset-major, as the LDE kernel writes it
@@ -77,5 +81,6 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     lde_nat = np.ascontiguousarray(lde_cm[:, idx])    # natural order for the oracle
     want_dig, want_cap = oracle.merkle_commit(lde_nat, cap_h, bitrev_rows=True)
     dig = to_host(bpg.ops.merkle_commit(to_dev(lde_cm), log_n, rate_bits, cap_h))
+    bpg.lib().bp_tune_quad_threshold(1 << 17)
     assert (dig == want_dig).all()
     assert (dig[-(1 << cap_h):] == want_cap).all()
