@@ -95,18 +95,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    roofline = None
-    if not args.no_profile:
+    def read_family(note):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
         pkg._lib.check(L.bp_profile_read(0, C.byref(n), C.byref(ms), C.byref(by)))
-        if n.value:
-            ach = by.value / (ms.value * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "ntt_lds_kernel<DIT> (coset LDE)", "achieved": round(ach, 1),
-                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
-                        "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
-                        "alg_bytes_per_launch": round(by.value / n.value),
-                        "note": "in situ: %d prover streams share the chip, mostly with integer-ALU-bound Poseidon "
-                                "kernels" % args.threads}
+        if not n.value:
+            return None
+        ach = by.value / (ms.value * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "ntt_lds_kernel<DIT> (coset LDE, LDS-resident)", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                "alg_bytes_per_launch": round(by.value / n.value), "note": note}
+
+    roofline_in_situ = roofline = None
+    if not args.no_profile:
+        roofline_in_situ = read_family("HIP events around every launch in the timed region; %d prover streams share "
+                                       "the chip, mostly with integer-ALU-bound Poseidon kernels, so a launch's "
+                                       "duration is not the kernel's own cost" % args.threads)
+        if rank == 0:
+            # the same workload with ONE prover stream: every launch of the kernel has the chip to itself, so
+            # event time == kernel time (this is what the rocprof summary in profiles/ is taken from)
+            solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=5 << 30).build()
+            solo_driver = BlockDriver(solo, n_threads=1)
+            irs = synthetic_block_irs(1000, 2, S1_LOG_N, S1_WIDTH)
+            solo_driver.prove_shard(irs[:1])
+            L.bp_profile_reset()
+            L.bp_profile_enable(1)
+            solo_driver.prove_shard(irs)
+            torch.cuda.synchronize()
+            L.bp_profile_enable(0)
+            roofline = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one "
+                                   "stream (no co-running kernels); all 29 proofs x 3 commitments x tables per txn")
+            solo_driver.close()
+            solo.close()
 
     if rank == 0:
         # acceptance: the block proof verifies (VerifierState::verify, verifier_state.rs:56-71)
@@ -123,7 +143,7 @@ def main():
                        "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
                        "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
                        "state_build_s": round(t_build, 2), "state_device_gib": round(state.device_bytes / 2**30, 2)},
-            "roofline": roofline,
+            "roofline": roofline, "roofline_in_situ": roofline_in_situ,
         }
         if world == 1:
             out["roofline_isolated"] = isolated_roofline(pkg, torch)
@@ -161,7 +181,11 @@ def cpu_baseline(ir):
     """Oracle (CPU restatement, OpenMP over the host cores) proving one txn of the block."""
     from oracle import pyoracle  # checker / baseline only
     pyoracle.build()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # OpenMP would otherwise start one thread per host core, not per core we may run on
+        C.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     lo, hi = list(S1_LOG_N), [x + 1 for x in S1_LOG_N]
     st = pyoracle.PgState(table_log_lo=lo, table_log_hi=hi, stark_rate_bits=1, stark_cap_height=4,
                           stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5, rec_log_n=13,

@@ -165,6 +165,8 @@ int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t par
 
 int bp_verifier_state_from_prover(const bp_state* s, bp_verifier_state** out);
 int bp_verifier_state_build(const bp_config* cfg, bp_verifier_state** out);
+/* verifier-only deployment: the three circuit caps (root, agg, block), 4 << stark_cap_height words each */
+int bp_verifier_state_from_caps(const bp_config* cfg, const uint64_t* caps, bp_verifier_state** out);
 void bp_verifier_state_free(bp_verifier_state* v);
 /* CPU only.  BP_ERR_VERIFY with a reason in bp_last_error() when rejected. */
 int bp_verify_block_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len);

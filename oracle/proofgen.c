@@ -251,4 +251,10 @@ int orc_pg_verify(orc_pg_state* s, const gl_t* w, size_t words) {
   return orc_stark_verify(&s->rec, orc_committed_cap(circ->consts), ctl, &ch, b.stark);
 }
 
+/* cap of special circuit k (0 root, 1 agg, 2 block): what a light verifier keeps */
+void orc_pg_circuit_cap(orc_pg_state* s, int k, gl_t* out) {
+  circuit_t* c = special_circuit(s, k);
+  memcpy(out, orc_committed_cap(c->consts), ((size_t)4 << s->rec.cap_height) * sizeof(gl_t));
+}
+
 void orc_free(void* p) { free(p); }

@@ -108,6 +108,7 @@ def lib():
     L.orc_pg_block.argtypes = [vp, vp, sz, u64p, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_verify.argtypes = [vp, u64p, sz]
     L.orc_free.argtypes = [vp]
+    L.orc_pg_circuit_cap.argtypes = [vp, i, u64p]
     _lib = L
     return L
 
@@ -334,6 +335,14 @@ class PgState:
     def verify(self, proof):
         proof = arr(proof)
         return lib().orc_pg_verify(self.h, proof, proof.size)
+
+    def circuit_caps(self):
+        """[3, 2^cap_height, 4]: root, agg, block circuit caps."""
+        cw = 4 << self.cfg.stark_cap_height
+        out = np.empty((3, cw), dtype=np.uint64)
+        for k in range(3):
+            lib().orc_pg_circuit_cap(self.h, k, out[k])
+        return out
 
     def __del__(self):
         if getattr(self, "h", None):

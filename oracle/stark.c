@@ -374,14 +374,14 @@ int orc_stark_prove(const orc_stark_cfg* cf, const orc_committed* consts, const 
   for (int b = 0; b < 3; b++) {
     /* composition = sum_j alpha^j f_j  (ReducingFactor::reduce_polys_base: Horner from the back) */
     gl2_t* comp = (gl2_t*)xmalloc(N * sizeof(gl2_t));
-    for (size_t i = 0; i < N; i++) comp[i] = gl2_from(0);
-    for (int ri = B[b].n_r - 1; ri >= 0; ri--) {
-      const orc_committed* o = B[b].r[ri].o;
-      for (size_t c = B[b].r[ri].count; c-- > 0;) {
-        const gl_t* f = o->coeffs + c * N;
-#pragma omp parallel for
-        for (size_t i = 0; i < N; i++) comp[i] = gl2_add(gl2_mul(comp[i], alpha), gl2_from(f[i]));
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < N; i++) {
+      gl2_t acc = gl2_from(0);
+      for (int ri = B[b].n_r - 1; ri >= 0; ri--) {
+        const orc_committed* o = B[b].r[ri].o;
+        for (size_t c = B[b].r[ri].count; c-- > 0;) acc = gl2_add(gl2_mul(acc, alpha), gl2_from(o->coeffs[c * N + i]));
       }
+      comp[i] = acc;
     }
     /* quotient = (comp - comp(z)) / (X - z): synthetic division; padded back with a zero */
     gl2_t* quo = (gl2_t*)xmalloc(N * sizeof(gl2_t));

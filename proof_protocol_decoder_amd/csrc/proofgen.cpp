@@ -441,6 +441,24 @@ int bp_verifier_state_build(const bp_config* cfg, bp_verifier_state** out) {
   bp_state_free(s);
   return r;
 }
+// Light verifier data from raw caps (what a verifier-only deployment would load from disk):
+// caps = root, agg, block constants caps, each 4 << stark_cap_height words.  CPU only.
+int bp_verifier_state_from_caps(const bp_config* cfg, const uint64_t* caps, bp_verifier_state** out) {
+  if (!cfg || !caps || !out) return fail(BP_ERR_INVALID_INPUT, "bp_verifier_state_from_caps: null argument");
+  const StarkCfg rc = rec_cfg_of(*cfg);
+  int r = check_cfg(rc);
+  if (r) return r;
+  const size_t cw = (size_t)4 << rc.cap_height;
+  for (size_t i = 0; i < 3 * cw; i++) if (caps[i] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "non-canonical cap word");
+  bp_verifier_state* v = new bp_verifier_state();
+  v->rec_cfg = rc;
+  for (int k = 0; k < 3; k++) {
+    v->special[k].cap.assign(caps + k * cw, caps + (k + 1) * cw);
+    hash_no_pad_host(v->special[k].cap.data(), cw, v->special[k].digest);
+  }
+  *out = v;
+  return BP_OK;
+}
 void bp_verifier_state_free(bp_verifier_state* v) { delete v; }
 
 int bp_verify_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len) {

@@ -51,6 +51,7 @@ def _bind():
                                           C.POINTER(C.c_uint64)]
     L.bp_verifier_state_from_prover.argtypes = [vp, C.POINTER(vp)]
     L.bp_verifier_state_build.argtypes = [C.POINTER(BpConfig), C.POINTER(vp)]
+    L.bp_verifier_state_from_caps.argtypes = [C.POINTER(BpConfig), C.POINTER(C.c_uint64), C.POINTER(vp)]
     L.bp_verifier_state_free.argtypes = [vp]
     L.bp_verifier_state_free.restype = None
     L.bp_verify_block_proof.argtypes = [vp, C.c_char_p, C.c_size_t]
@@ -255,6 +256,14 @@ class VerifierState:
     def from_prover_state(cls, p_state):
         h = C.c_void_p()
         check(_bind().bp_verifier_state_from_prover(p_state._h, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_caps(cls, cfg, caps_words):
+        """Verifier-only deployment (no GPU): cfg is a BpConfig, caps_words the 3 circuit caps."""
+        h = C.c_void_p()
+        arr = (C.c_uint64 * len(caps_words))(*[int(x) for x in caps_words])
+        check(_bind().bp_verifier_state_from_caps(C.byref(cfg), arr, C.byref(h)))
         return cls(h)
 
     def verify(self, block_proof):
