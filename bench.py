@@ -177,11 +177,29 @@ def isolated_roofline(pkg, torch):
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "launch_ms": round(best, 4)}
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return min(n, 64)
+
+
 def cpu_baseline(ir):
     """Oracle (CPU restatement, OpenMP over the host cores) proving one txn of the block."""
     from oracle import pyoracle  # checker / baseline only
     pyoracle.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     try:  # OpenMP would otherwise start one thread per host core, not per core we may run on
         C.CDLL("libgomp.so.1").omp_set_num_threads(cores)
     except OSError:

@@ -74,6 +74,9 @@ int bp_lde_batch(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_coeffs_ou
                  uint64_t* d_lde_out, uint64_t lde_stride, uint32_t log_n, uint32_t rate_bits,
                  uint32_t n_cols, int from_coeffs, void* stream);
 
+/* Measurement aid: plain 8-byte-per-lane streaming copy of n words (calibrates PMC byte counters). */
+int bp_debug_copy_u64(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream);
+
 /* Tuning knob: hashing launches with fewer rows/nodes than this use the quad-cooperative Poseidon
  * kernels (4 lanes per state, DPP exchange); larger ones use one lane per state.  Results are
  * identical either way.  Default 2^17 (measured crossover). */

@@ -97,12 +97,14 @@ static inline gl_t sbox7(gl_t x) {
   return gl_mul(x3, x4);
 }
 static inline void mds_layer(gl_t s[12]) {
-  gl_t o[12];
+  /* entries < 2^6: accumulate the 32-bit halves separately in 64 bits (no overflow), recombine once */
+  uint64_t lo[24], hi[24], o[12];
+  for (int i = 0; i < 12; i++) { lo[i] = lo[i + 12] = (uint32_t)s[i]; hi[i] = hi[i + 12] = s[i] >> 32; }
   for (int r = 0; r < 12; r++) {
-    u128 acc = 0;
-    for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * MDS_CIRC[i];
-    if (r == 0) acc += (u128)s[0] * MDS_DIAG0;
-    o[r] = gl_reduce128(acc);
+    uint64_t L = 0, H = 0;
+    for (int i = 0; i < 12; i++) { L += lo[i + r] * MDS_CIRC[i]; H += hi[i + r] * MDS_CIRC[i]; }
+    if (r == 0) { L += lo[0] * MDS_DIAG0; H += hi[0] * MDS_DIAG0; }
+    o[r] = gl_reduce128((u128)L + ((u128)H << 32));
   }
   memcpy(s, o, sizeof(o));
 }

@@ -33,10 +33,8 @@ static inline gl_t gl_add(gl_t a, gl_t b) { /* a,b canonical */
 }
 static inline gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a + (GL_P - b); }
 static inline gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
-static inline gl_t gl_reduce128(u128 x) { return (gl_t)(x % GL_P); }
-static inline gl_t gl_mul(gl_t a, gl_t b) {
+static inline gl_t gl_reduce128(u128 x) {
   /* x = lo + 2^64*(hh*2^32 + hl);  2^64 = 2^32-1, 2^96 = -1 (mod p) */
-  u128 x = (u128)a * b;
   uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
   uint64_t hh = hi >> 32, hl = hi & GL_EPS;
   uint64_t t0 = lo - hh;
@@ -46,6 +44,7 @@ static inline gl_t gl_mul(gl_t a, gl_t b) {
   if (r < t1) r += GL_EPS;             /* carry */
   return gl_canon(r);
 }
+static inline gl_t gl_mul(gl_t a, gl_t b) { return gl_reduce128((u128)a * b); }
 static inline gl_t gl_sqr(gl_t a) { return gl_mul(a, a); }
 static inline gl_t gl_pow(gl_t a, uint64_t e) {
   gl_t r = 1;

@@ -172,6 +172,13 @@ int merkle_commit_rows(const uint64_t* d_leaves, uint32_t leaf_len, uint32_t log
 
 extern "C" {
 
+int bp_debug_copy_u64(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream) {
+  if (!d_in || !d_out) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_debug_copy_u64: null buffer");
+  calib_copy_u64_kernel<<<4096, 256, 0, bpg::as_stream(stream)>>>(d_in, d_out, n);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+
 void bp_tune_quad_threshold(uint64_t n_perms) { bpg::g_quad_threshold.store(n_perms); }
 
 uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {
