@@ -137,6 +137,15 @@ merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ p
   for (int k = 0; k < 4; k++) parent[i * 4 + k] = o[k];
 }
 
+// 8-byte-per-lane streaming copy: calibrates the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the
+// access width every field kernel here uses (MI355X_MICROARCH.md, HBM section).
+__global__ void __launch_bounds__(256)
+calib_copy_u64_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = in[i];
+}
+
 }  // namespace
 
 namespace bpg {
