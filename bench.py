@@ -33,6 +33,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
 S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
+TRAFFIC_OVER_ALGORITHMIC = 1.37  # measured, see profiles/README.md
 
 
 def main():
@@ -102,7 +103,10 @@ def main():
             return None
         ach = by.value / (ms.value * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "ntt_lds_kernel<DIT> (coset LDE, LDS-resident)", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                # PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/r1_pmc_*.csv): 1.37x algorithmic on
+                # the 2^14 x 2432 launch (each coset re-reads the coefficients); applied to the average launch
+                "traffic": round(by.value / n.value * TRAFFIC_OVER_ALGORITHMIC),
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "alg_bytes_per_launch": round(by.value / n.value), "note": note}
 
