@@ -24,9 +24,12 @@ __device__ __forceinline__ uint64_t sbox(uint64_t x) {
 }
 
 // MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...).  Entries are < 2^6, so the
-// 32-bit halves of the state are accumulated separately in 64 bits (no overflow: 12*41*2^32) and
-// recombined with one small reduction per row.
-__device__ __forceinline__ void mds(uint64_t (&s)[12]) {
+// 32-bit halves of the state are accumulated separately in 64 bits (no overflow: 12*41*2^32 plus a
+// 32-bit constant) and recombined with one small reduction per row.  `rc_next` (nullable) points at
+// the NEXT round's 12 constants: they are added inside the accumulators (the multiply-add's addend),
+// so a round never pays a separate modular addition for them.
+template <bool ADD_RC>
+__device__ __forceinline__ void mds(uint64_t (&s)[12], const uint64_t* __restrict__ rc_next) {
   constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   uint32_t lo[12], hi[12];
 #pragma unroll
@@ -37,6 +40,11 @@ __device__ __forceinline__ void mds(uint64_t (&s)[12]) {
 #pragma unroll
   for (int r = 0; r < 12; r++) {
     uint64_t L = 0, H = 0;
+    if (ADD_RC) {
+      const uint64_t k = rc_next[r];
+      L = (uint32_t)k;
+      H = k >> 32;
+    }
 #pragma unroll
     for (int i = 0; i < 12; i++) {
       L += (uint64_t)lo[(i + r) % 12] * C[i];
@@ -57,26 +65,30 @@ __device__ __forceinline__ void mds(uint64_t (&s)[12]) {
 }
 
 __device__ __forceinline__ void permute(uint64_t (&s)[12]) {
+  // round r: (state + RC[r]) -> S-box -> MDS; RC[r+1] rides in round r's MDS accumulators
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], RC[i]);
   int rnd = 0;
 #pragma unroll 1
   for (int k = 0; k < 4; k++, rnd++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox(gl::add(s[i], RC[rnd * 12 + i]));
-    mds(s);
+    for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+    mds<true>(s, RC + (rnd + 1) * 12);
   }
 #pragma unroll 1
   for (int k = 0; k < 22; k++, rnd++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], RC[rnd * 12 + i]);
     s[0] = sbox(s[0]);
-    mds(s);
+    mds<true>(s, RC + (rnd + 1) * 12);
   }
 #pragma unroll 1
-  for (int k = 0; k < 4; k++, rnd++) {
+  for (int k = 0; k < 3; k++, rnd++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox(gl::add(s[i], RC[rnd * 12 + i]));
-    mds(s);
+    for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+    mds<true>(s, RC + (rnd + 1) * 12);
   }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+  mds<false>(s, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -118,12 +130,18 @@ __device__ __forceinline__ QuadCtx quad_ctx() {
 
 // e[a] = state word q + 4a.  rc: the 360 round constants in LDS or global memory.
 __device__ __forceinline__ void permute_quad(uint64_t (&e)[3], const QuadCtx& c, const uint64_t* __restrict__ rc) {
+  {
+    const uint64_t* r0 = rc + c.q;
+#pragma unroll
+    for (int a = 0; a < 3; a++) e[a] = gl::add(e[a], r0[4 * a]);
+  }
 #pragma unroll 1
   for (int rnd = 0; rnd < 30; rnd++) {
     const bool full = rnd < 4 || rnd >= 26;
-    const uint64_t* r = rc + rnd * 12 + c.q;
-#pragma unroll
-    for (int a = 0; a < 3; a++) e[a] = gl::add(e[a], r[4 * a]);
+    // next round's constants for this lane's three rows (zero after the last round); they are added
+    // inside the MDS accumulators
+    const uint64_t* r = rc + (rnd < 29 ? rnd + 1 : 0) * 12 + c.q;
+    const uint64_t kmask = rnd < 29 ? ~0ULL : 0ULL;
     if (full) {
 #pragma unroll
       for (int a = 0; a < 3; a++) e[a] = sbox(e[a]);
@@ -144,12 +162,13 @@ __device__ __forceinline__ void permute_quad(uint64_t (&e)[3], const QuadCtx& c,
     }
 #pragma unroll
     for (int a = 0; a < 3; a++) {  // output row q + 4a
-      uint64_t L = 0, H = 0;
+      const uint64_t k = r[4 * a] & kmask;
+      uint64_t L = (uint32_t)k, H = k >> 32;
 #pragma unroll
-      for (int k = 0; k < 12; k++) {
-        const uint32_t cf = c.cf[(k - 4 * a + 12) % 12];
-        L += (uint64_t)lo[k] * cf;
-        H += (uint64_t)hi[k] * cf;
+      for (int kk = 0; kk < 12; kk++) {
+        const uint32_t cf = c.cf[(kk - 4 * a + 12) % 12];
+        L += (uint64_t)lo[kk] * cf;
+        H += (uint64_t)hi[kk] * cf;
       }
       if (a == 0) {
         L += (uint64_t)lo[0] * c.diag;

@@ -54,3 +54,39 @@ def test_bad_shapes_are_rejected(bpg):
     assert e.value.code == -2
     with pytest.raises(BpgError):
         bpg.ops.stark_prove_synthetic(bpg.ops.stark_cfg(8, 4), 1)
+
+
+FULL_SIZE = [
+    # the S1 "transfer-txn" table shapes of the bench and the recursion shape
+    (16, 128, 0, 1, 1), (9, 128, 0, 1, 1), (12, 192, 0, 1, 1), (14, 2432, 0, 1, 1), (9, 512, 0, 1, 1),
+    (12, 320, 0, 1, 1), (17, 16, 0, 1, 1), (13, 135, 82, 3, 3),
+]
+
+
+@pytest.mark.parametrize("shape", FULL_SIZE, ids=lambda c: "logn%d_C%d" % c[:2])
+def test_full_size_table_proofs_are_accepted_by_the_oracle_verifier(bpg, oracle, shape):
+    """At BASELINE sizes the oracle prover is too slow to run per test, but its verifier is not:
+    a full-size GPU proof must verify (all queries, Merkle paths, FRI consistency, constraint check
+    at zeta), and stop verifying after a single bit flip."""
+    log_n, C, K, e, r = shape
+    nq = 84 if K == 0 else 28
+    seed, const_seed = 0x5EED000000000000 + C, 99
+    got = bpg.ops.stark_prove_synthetic(
+        bpg.ops.stark_cfg(log_n, C, n_const=K, deg_pow=e, rate_bits=r, num_queries=nq, pow_bits=16), seed, const_seed)
+    cfg = oracle.make_cfg(log_n, C, n_const=K, deg_pow=e, rate_bits=r, num_queries=nq, pow_bits=16)
+    const_cap = None
+    if K:
+        const_cap = oracle.Committed.from_values(oracle.synth_constants(const_seed, log_n, K), r, 4).cap()
+
+    def prologue(proof):
+        ch = oracle.PyChallenger()
+        if K:
+            ch.observe(const_cap)
+        ch.observe(proof[16:16 + 64])
+        return ch, np.array([ch.challenge() for _ in range(4)], dtype=np.uint64)
+    ch, ctl = prologue(got)
+    assert oracle.stark_verify(cfg, got, ctl, ch, const_cap) == 0
+    bad = got.copy()
+    bad[got.size // 2] ^= np.uint64(2)
+    ch, ctl = prologue(bad)
+    assert oracle.stark_verify(cfg, bad, ctl, ch, const_cap) != 0
