@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16, help="concurrent provers (HIP streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
+    ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
     args = ap.parse_args()
 
     import torch
@@ -54,9 +55,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    # BPG_SHARE_GPU=1 is a rehearsal mode for a 1-GPU box: all ranks use device 0 and the gather runs
+    # over gloo (RCCL needs one device per rank).  The driver's real runs never set it.
+    share = os.environ.get("BPG_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import proof_protocol_decoder_amd as pkg
     from proof_protocol_decoder_amd import proof_gen as pg
@@ -66,10 +75,11 @@ def main():
 
     t_build = time.time()
     # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
-    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads, arena_bytes=5 << 30).build()
+    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads,
+                                         arena_bytes=int(args.arena_gib * 2**30)).build()
     t_build = time.time() - t_build
     driver = BlockDriver(state, n_threads=args.threads)
-    gather = TorchGather(torch.device("cuda", local_rank)) if world > 1 else None
+    gather = TorchGather(torch.device("cpu") if share else torch.device("cuda", local_rank)) if world > 1 else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -92,7 +102,7 @@ def main():
     dt = time.perf_counter() - t0
     L.bp_profile_enable(0)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -137,6 +137,163 @@ __global__ void __launch_bounds__(1024) ntt_lds_kernel(LdsNttArgs a) {
   }
 }
 
+// ================================================================================================
+// v2 LDS kernels for 2^12..2^14-point blocks: 16 elements per lane, four radix-2 stages per register
+// pass, XOR-swizzled LDS image so every exchange is bank-conflict free (checked exhaustively, see
+// DESIGN.md section 7), outer pass straight from/to global memory in coalesced 8-byte lanes, and
+// for the LDE all 2^r cosets are produced from ONE read of the coefficients.
+//   element index i (L bits).  Pass with register field [b+3:b]:  i = insert(t, m, b)
+//   outermost field [L-1:L-4]:  i = m*T + t  (T = 2^L/16 lanes)  -> global position, coalesced
+//   innermost field [3:0]:      i = bitrev(t)*16 + m             -> bit-reversed side, coalesced
+// ================================================================================================
+template <int L>
+__device__ __forceinline__ uint32_t swz(uint32_t i) {
+  uint32_t x;
+  if (L == 14) x = (((i >> 6) & 7u) << 2) ^ ((i >> 9) & 31u);
+  else if (L == 13) x = (((i >> 5) & 15u) << 1) ^ ((i >> 9) & 15u);
+  else x = (((i >> 8) & 1u) << 4) ^ ((i >> 7) & 1u) ^ (((i >> 9) & 7u) << 1);
+  return i ^ x;
+}
+__device__ __forceinline__ uint32_t insert4(uint32_t t, uint32_t m, uint32_t b) {
+  return ((t >> b) << (b + 4)) | (m << b) | (t & ((1u << b) - 1));
+}
+// R-stage butterflies on the sub-arrays x[g + (u << SH)] (u = 0..2^R-1) for every g < 2^SH,
+// or on x[(g << R) + u] when CONTIG.
+template <int R, int SH, bool CONTIG, bool DIF>
+__device__ __forceinline__ void sub_butterflies(uint64_t (&x)[16], const uint64_t* __restrict__ tw, uint32_t j,
+                                                uint32_t j_step_log, uint32_t log_sub, uint32_t tw_shift) {
+  constexpr int G = 16 >> R;
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    uint64_t y[1 << R];
+#pragma unroll
+    for (int u = 0; u < (1 << R); u++) y[u] = CONTIG ? x[(g << R) + u] : x[g + (u << SH)];
+    const uint32_t jj = CONTIG ? 0u : j + ((uint32_t)g << j_step_log);
+    if (DIF) dif_butterflies<R>(y, tw, jj, log_sub, tw_shift);
+    else dit_butterflies<R>(y, tw, jj, log_sub, tw_shift);
+#pragma unroll
+    for (int u = 0; u < (1 << R); u++) {
+      if (CONTIG) x[(g << R) + u] = y[u];
+      else x[g + (u << SH)] = y[u];
+    }
+  }
+}
+
+struct Ntt16Args {
+  const uint64_t* in;
+  uint64_t in_stride;
+  uint64_t* out;
+  uint64_t out_stride, out_coset_stride;
+  const uint64_t* tw;     // w_B^e, e < B/2, B = 2^L
+  const uint64_t* scale;  // DIT: [coset][n_total] input scale, nullable
+  uint64_t out_scalar;    // DIF: 1/n (1 = none)
+  uint32_t log_n_total, n_cosets, cosets_per_wg;
+};
+
+// natural -> bit-reversed.  grid = (blocks per column, columns)
+template <int L>
+__global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
+  extern __shared__ uint64_t buf[];
+  constexpr uint32_t T = (1u << L) / 16;
+  constexpr int RT = (L % 4 == 0) ? 4 : (L % 4);  // stages of the innermost pass
+  const uint32_t t = threadIdx.x;
+  const uint64_t off = (uint64_t)blockIdx.x << L;
+  const uint64_t* src = a.in + blockIdx.y * a.in_stride + off;
+  uint64_t* dst = a.out + blockIdx.y * a.out_stride + off;
+  uint64_t x[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) x[m] = src[m * T + t];
+  dif_butterflies<4>(x, a.tw, t, L - 4, 0);
+#pragma unroll
+  for (int m = 0; m < 16; m++) buf[swz<L>(m * T + t)] = x[m];
+  __syncthreads();
+#pragma unroll
+  for (int b = L - 8; b > 0; b -= 4) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(insert4(t, m, b))];
+    dif_butterflies<4>(x, a.tw, t & ((1u << b) - 1), b, L - (b + 4));
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[swz<L>(insert4(t, m, b))] = x[m];
+    __syncthreads();
+  }
+  const uint32_t base = gl::bitrev(t, L - 4) << 4;
+#pragma unroll
+  for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(base | m)];
+  sub_butterflies<RT, 0, true, true>(x, a.tw, 0, 0, 0, L - RT);
+  // In-place DIF leaves position i holding coefficient bitrev(i): exactly the bit-reversed storage
+  // order.  One more (conflict-free) LDS exchange turns "16 consecutive words per lane" into
+  // coalesced 8-byte lanes for the global store.
+#pragma unroll
+  for (int m = 0; m < 16; m++) buf[swz<L>(base | m)] = x[m];
+  __syncthreads();
+  if (a.out_scalar != 1) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) dst[m * T + t] = gl::mulc(buf[swz<L>(m * T + t)], a.out_scalar);
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; m++) dst[m * T + t] = buf[swz<L>(m * T + t)];
+  }
+}
+
+// bit-reversed -> natural, optional per-coset input scale; one workgroup makes all cosets of its block.
+template <int L>
+__global__ void __launch_bounds__((1 << L) / 16) ntt16_dit_kernel(Ntt16Args a) {
+  extern __shared__ uint64_t buf[];
+  constexpr uint32_t T = (1u << L) / 16;
+  constexpr int RT = (L % 4 == 0) ? 4 : (L % 4);  // stages of the outermost pass
+  const uint32_t t0 = threadIdx.x;
+  const uint64_t off = (uint64_t)blockIdx.x << L;
+  const uint64_t* src = a.in + blockIdx.y * a.in_stride + off;
+  // Coefficients are re-read per coset (the re-read is served on-die: this workgroup touched the
+  // same 8*2^L bytes microseconds earlier); keeping them in 32 more VGPRs spills at 1024 lanes.
+  uint64_t x[16];
+  const uint32_t coset0 = blockIdx.z * a.cosets_per_wg;
+#pragma unroll 1
+  for (uint32_t coset = coset0; coset < coset0 + a.cosets_per_wg; coset++) {
+    // the twiddles do not depend on the coset; keep the compiler from hoisting ~60 of them (120 VGPRs)
+    // out of this loop: re-reading them from L1 is cheaper than losing occupancy / spilling
+    const uint64_t* tw = a.tw;
+    asm volatile("" : "+s"(tw));
+    // same for the ~100 loop-invariant LDS/global addresses: recompute them per coset
+    uint32_t t = t0;
+    asm volatile("" : "+v"(t));
+    const uint32_t base = gl::bitrev(t, L - 4) << 4;
+    if (a.scale) {
+      const uint64_t* sc = a.scale + ((uint64_t)coset << a.log_n_total) + off;
+#pragma unroll
+      for (int m = 0; m < 16; m++) buf[swz<L>(m * T + t)] = gl::mulc(src[m * T + t], sc[m * T + t]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; m++) buf[swz<L>(m * T + t)] = src[m * T + t];
+    }
+    __syncthreads();
+    // innermost field [3:0]
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(base | m)];
+    dit_butterflies<4>(x, tw, 0, 0, L - 4);
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[swz<L>(base | m)] = x[m];
+    __syncthreads();
+#pragma unroll
+    for (int b = 4; b + 4 <= L - RT; b += 4) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(insert4(t, m, b))];
+      dit_butterflies<4>(x, tw, t & ((1u << b) - 1), b, L - (b + 4));
+#pragma unroll
+      for (int m = 0; m < 16; m++) buf[swz<L>(insert4(t, m, b))] = x[m];
+      __syncthreads();
+    }
+    // outermost field [L-1:L-4]: the top RT bits are still to do; lanes = low bits -> coalesced store
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(m * T + t)];
+    sub_butterflies<RT, 4 - RT, false, false>(x, tw, t, L - 4, L - RT, 0);
+    uint64_t* dst = a.out + blockIdx.y * a.out_stride + coset * a.out_coset_stride + off;
+#pragma unroll
+    for (int m = 0; m < 16; m++) dst[m * T + t] = x[m];
+    __syncthreads();  // everyone has read buf before the next coset overwrites it
+  }
+}
+
 // Strided global pass for columns taller than one LDS block: the top LOGR stages (DIF) or the
 // last LOGR stages (DIT) of the n-point transform.  Lane q owns elements q + m*(S>>LOGR).
 // grid = (ceil(n >> LOGR / 256), columns, cosets).  `tw` is the n-point table.
@@ -283,6 +440,19 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
     src = out;
     src_stride = out_stride;
   }
+  if (log_blk >= 12) {
+    Ntt16Args b{};
+    b.in = src; b.in_stride = src_stride; b.out = out; b.out_stride = out_stride; b.out_coset_stride = 0;
+    b.tw = tw_b; b.scale = nullptr; b.out_scalar = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
+    b.log_n_total = log_n; b.n_cosets = 1; b.cosets_per_wg = 1;
+    dim3 grid16(1u << (log_n - log_blk), n_cols);
+    KernelTimer kt(PROF_INTT_DIF, st, 16.0 * (double)n_cols * (double)((uint64_t)1 << log_n));
+    if (log_blk == 12) ntt16_dif_kernel<12><<<grid16, 256, 8u << 12, st>>>(b);
+    else if (log_blk == 13) ntt16_dif_kernel<13><<<grid16, 512, 8u << 13, st>>>(b);
+    else ntt16_dif_kernel<14><<<grid16, 1024, 8u << 14, st>>>(b);
+    BPG_LAUNCH_CHECK();
+    return BP_OK;
+  }
   LdsNttArgs a{};
   a.in = src; a.in_stride = src_stride; a.out = out; a.out_stride = out_stride; a.out_coset_stride = 0;
   a.tw = tw_b; a.scale = nullptr;
@@ -308,6 +478,23 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
   const uint64_t *tw_n = nullptr, *tw_b = nullptr;
   int rc;
   if ((rc = get_table(inverse ? 1 : 0, log_blk, 0, &tw_b))) return rc;
+  if (log_blk >= 12) {
+    Ntt16Args b{};
+    b.in = in; b.in_stride = in_stride; b.out = out; b.out_stride = out_stride; b.out_coset_stride = coset_stride;
+    b.tw = tw_b; b.scale = scale; b.out_scalar = 1; b.log_n_total = log_n; b.n_cosets = n_cosets;
+    // one workgroup makes every coset of its block (coefficients re-read on-die) unless that would
+    // leave the chip underfilled: then the cosets spread over grid.z
+    const uint64_t wgs = (uint64_t)n_cols << (log_n - log_blk);
+    b.cosets_per_wg = wgs >= 1024 ? n_cosets : 1;
+    dim3 grid16(1u << (log_n - log_blk), n_cols, n_cosets / b.cosets_per_wg);
+    {
+      KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
+      if (log_blk == 12) ntt16_dit_kernel<12><<<grid16, 256, 8u << 12, st>>>(b);
+      else if (log_blk == 13) ntt16_dit_kernel<13><<<grid16, 512, 8u << 13, st>>>(b);
+      else ntt16_dit_kernel<14><<<grid16, 1024, 8u << 14, st>>>(b);
+    }
+    BPG_LAUNCH_CHECK();
+  } else {
   LdsNttArgs a{};
   a.in = in; a.in_stride = in_stride; a.out = out; a.out_stride = out_stride; a.out_coset_stride = coset_stride;
   a.tw = tw_b; a.scale = scale; a.out_scalar = 1; a.log_blk = log_blk; a.log_n_total = log_n;
@@ -319,6 +506,7 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
     ntt_lds_kernel<false><<<grid, lds_threads(log_blk), lds, st>>>(a);
   }
   BPG_LAUNCH_CHECK();
+  }
   if (log_n > LOG_BLK_MAX) {
     if ((rc = get_table(inverse ? 1 : 0, log_n, 0, &tw_n))) return rc;
     if ((rc = launch_global_passes<false>(out, out_stride, out, out_stride, coset_stride, n_cols, n_cosets, log_n,
@@ -341,6 +529,14 @@ static int init_ntt_kernels_once() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << LOG_BLK_MAX));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_lds_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << LOG_BLK_MAX));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<14>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<14>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<13>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
   return BP_OK;
 }
 int init_ntt_kernels() {
