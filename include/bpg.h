@@ -187,6 +187,22 @@ int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas
  * root_after[4], block_number */
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out);
 
+/* ------------------------------------------------------------------------------------------
+ * Next row: Erigon compact block-witness decoder + state-trie root
+ * (protocol_decoder/src/compact/compact_prestate_processing.rs:1240-1281 process_compact_prestate,
+ * compact_to_partial_trie.rs:37-165).  Host-only (it is CPU parsing in the reference too).
+ * Pinned by the reference's own golden vectors (complex_test_payloads.rs:14-30 and
+ * compact_prestate_processing.rs:1439,1483-1492).  Any out-pointer may be NULL.
+ * n_accounts_missing_storage counts account leaves whose non-empty storage root has no extracted
+ * storage trie (the invariant the reference's test harness asserts, complex_test_payloads.rs:73-90).
+ * ------------------------------------------------------------------------------------------ */
+int bp_compact_decode(const uint8_t* witness, size_t len, uint8_t* header_version, uint8_t state_root[32],
+                      uint32_t* n_accounts, uint32_t* n_storage_tries, uint32_t* n_code,
+                      uint32_t* n_accounts_missing_storage);
+/* one instruction per text line; release with bp_free_buffer */
+int bp_compact_instructions(const uint8_t* witness, size_t len, uint8_t** text_out, size_t* text_len);
+void bp_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
+
 /* state root after one synthetic txn (host-side helper for building a chain of IRs) */
 int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]);
 

@@ -7,3 +7,4 @@ gfx950 device is present.
 from ._lib import BpgError, lib, lib_path  # noqa: F401
 from . import ops  # noqa: F401
 from . import proof_gen  # noqa: F401
+from . import compact  # noqa: F401
