@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
     ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
+    ap.add_argument("--quad-threshold-log2", type=int, default=None,
+                    help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
     args = ap.parse_args()
 
     import torch
@@ -72,6 +74,8 @@ def main():
     from proof_protocol_decoder_amd.block_driver import BlockDriver, TorchGather, shard_bounds, synthetic_block_irs
     L = pkg.lib()
     L.bp_profile_read.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if args.quad_threshold_log2 is not None:
+        L.bp_tune_quad_threshold(1 << args.quad_threshold_log2)
 
     t_build = time.time()
     # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them

@@ -79,7 +79,7 @@ int bp_debug_copy_u64(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* s
 
 /* Tuning knob: hashing launches with fewer rows/nodes than this use the quad-cooperative Poseidon
  * kernels (4 lanes per state, DPP exchange); larger ones use one lane per state.  Results are
- * identical either way.  Default 2^17 (measured crossover). */
+ * identical either way.  Default 2^15 (best on the saturated 16-stream bench; alone, the crossover is near 2^17). */
 void bp_tune_quad_threshold(uint64_t n_perms);
 
 /* K3.  Poseidon-Goldilocks permutation (width 12) on n states of 12 words, in place. */

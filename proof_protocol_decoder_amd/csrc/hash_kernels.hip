@@ -151,7 +151,7 @@ calib_copy_u64_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ ou
 namespace bpg {
 
 // launches with fewer permutations than this use the quad-cooperative kernels (4x the waves)
-static std::atomic<uint64_t> g_quad_threshold{(uint64_t)1 << 17};
+static std::atomic<uint64_t> g_quad_threshold{(uint64_t)1 << 15};
 uint64_t quad_threshold() { return g_quad_threshold.load(std::memory_order_relaxed); }
 
 int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st) {

@@ -140,6 +140,9 @@ int Worker::init(int dev, size_t arena_bytes) {
   pinned_words = (size_t)1 << 22;  // 32 MiB staging
   BPG_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), pinned_words * 8, hipHostMallocDefault));
   BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_pow_result), 8));
+  // many prover threads share few host cores: wait on a blocking event (the thread sleeps) rather
+  // than spin in hipStreamSynchronize
+  BPG_HIP(hipEventCreateWithFlags(&sync_event, hipEventBlockingSync | hipEventDisableTiming));
   return init_ntt_kernels();
 }
 void Worker::destroy() {
@@ -147,7 +150,9 @@ void Worker::destroy() {
   arena.destroy();
   if (pinned) (void)hipHostFree(pinned);
   if (d_pow_result) (void)hipFree(d_pow_result);
+  if (sync_event) (void)hipEventDestroy(sync_event);
   if (stream) (void)hipStreamDestroy(stream);
+  sync_event = nullptr;
   pinned = nullptr;
   d_pow_result = nullptr;
   stream = nullptr;
@@ -156,7 +161,8 @@ int Worker::d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words) {
   for (size_t off = 0; off < words; off += pinned_words) {
     size_t k = std::min(pinned_words, words - off);
     BPG_HIP(hipMemcpyAsync(pinned, dev_src + off, k * 8, hipMemcpyDeviceToHost, stream));
-    BPG_HIP(hipStreamSynchronize(stream));
+    BPG_HIP(hipEventRecord(sync_event, stream));
+    BPG_HIP(hipEventSynchronize(sync_event));
     std::memcpy(host_dst + off, pinned, k * 8);
   }
   return BP_OK;

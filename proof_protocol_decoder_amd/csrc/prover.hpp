@@ -103,6 +103,7 @@ struct Worker {
   uint64_t* pinned = nullptr;
   size_t pinned_words = 0;
   unsigned long long* d_pow_result = nullptr;
+  hipEvent_t sync_event = nullptr;  // blocking-sync event: waiting threads sleep instead of spinning
   const volatile int32_t* abort_flag = nullptr;
   int device = 0;
 

@@ -81,6 +81,6 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     lde_nat = np.ascontiguousarray(lde_cm[:, idx])    # natural order for the oracle
     want_dig, want_cap = oracle.merkle_commit(lde_nat, cap_h, bitrev_rows=True)
     dig = to_host(bpg.ops.merkle_commit(to_dev(lde_cm), log_n, rate_bits, cap_h))
-    bpg.lib().bp_tune_quad_threshold(1 << 17)
+    bpg.lib().bp_tune_quad_threshold(1 << 15)
     assert (dig == want_dig).all()
     assert (dig[-(1 << cap_h):] == want_cap).all()
