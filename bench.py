@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
     ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
+    ap.add_argument("--merkle-fused", type=int, default=None, help="0: one launch per Merkle level")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
                     help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
     args = ap.parse_args()
@@ -74,6 +75,8 @@ def main():
     from proof_protocol_decoder_amd.block_driver import BlockDriver, TorchGather, shard_bounds, synthetic_block_irs
     L = pkg.lib()
     L.bp_profile_read.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if args.merkle_fused is not None:
+        L.bp_tune_merkle_fused(args.merkle_fused)
     if args.quad_threshold_log2 is not None:
         L.bp_tune_quad_threshold(1 << args.quad_threshold_log2)
 

@@ -81,6 +81,9 @@ int bp_debug_copy_u64(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* s
  * kernels (4 lanes per state, DPP exchange); larger ones use one lane per state.  Results are
  * identical either way.  Default 2^15 (best on the saturated 16-stream bench; alone, the crossover is near 2^17). */
 void bp_tune_quad_threshold(uint64_t n_perms);
+/* 1: Merkle levels below the quad threshold are fused, up to 7 per launch; 0 (default, ~3% faster under
+ * multi-stream load): one launch per level.  Results are identical. */
+void bp_tune_merkle_fused(int on);
 
 /* K3.  Poseidon-Goldilocks permutation (width 12) on n states of 12 words, in place. */
 int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream);

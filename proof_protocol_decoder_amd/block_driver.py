@@ -81,12 +81,61 @@ class BlockDriver:
         return (pg.GeneratedAggProof if kind == 1 else pg.GeneratedTxnProof)(pv, raw)
 
     def prove_shard(self, irs):
-        """All txn proofs of a contiguous slice, then its local aggregation tree."""
-        if self.pool is not None:
-            txn_proofs = list(self.pool.map(self.prove_txn, irs))
-        else:
+        """All txn proofs of a contiguous slice and its local aggregation tree.  The tree has the
+        same shape as tree_reduce (adjacent pairs per level, an odd tail is carried up), but every
+        aggregation is submitted the moment both of its children exist, so the tree overlaps with
+        the remaining txn proofs instead of running after them."""
+        n = len(irs)
+        if self.pool is None or n < 2:
             txn_proofs = [self.prove_txn(ir) for ir in irs]
-        return tree_reduce(txn_proofs, self.prove_agg, self.pool), txn_proofs
+            return tree_reduce(txn_proofs, self.prove_agg, None), txn_proofs
+        import threading
+        lock = threading.Lock()
+        done = threading.Event()
+        # plan: levels[l] = list of node ids; a node is ("txn", i) or ("agg", left, right)
+        nodes = [("txn", i) for i in range(n)]
+        level = list(range(n))
+        parent_of = {}
+        while len(level) > 1:
+            nxt = []
+            for k in range(0, len(level) - 1, 2):
+                nodes.append(("agg", level[k], level[k + 1]))
+                nid = len(nodes) - 1
+                parent_of[level[k]] = parent_of[level[k + 1]] = nid
+                nxt.append(nid)
+            if len(level) % 2:
+                nxt.append(level[-1])
+            level = nxt
+        root = level[0]
+        results, errors = {}, []
+
+        def finish(nid, value):
+            with lock:
+                results[nid] = value
+                par = parent_of.get(nid)
+                ready = par is not None and nodes[par][1] in results and nodes[par][2] in results
+            if nid == root:
+                done.set()
+            elif ready:
+                self.pool.submit(run, par)
+
+        def run(nid):
+            try:
+                node = nodes[nid]
+                if node[0] == "txn":
+                    finish(nid, self.prove_txn(irs[node[1]]))
+                else:
+                    finish(nid, self.prove_agg(results[node[1]], results[node[2]]))
+            except BaseException as e:  # surface the first failure to the caller
+                errors.append(e)
+                done.set()
+
+        for i in range(n):
+            self.pool.submit(run, i)
+        done.wait()
+        if errors:
+            raise errors[0]
+        return results[root], [results[i] for i in range(n)]
 
     def prove_block_distributed(self, irs, rank=0, world_size=1, gather=None, parent=None):
         """Returns the GeneratedBlockProof on rank 0, None elsewhere."""

@@ -86,6 +86,7 @@ leaf_hash_quad_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_
 }
 __global__ void __launch_bounds__(256)
 merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   __shared__ uint64_t rc[360];
   for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
   __syncthreads();
@@ -97,10 +98,54 @@ merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restric
   parent[i * 4 + qc.q] = gl::canon(e[0]);
 }
 
+// Several Merkle levels in one launch: each 256-lane workgroup (64 quads) owns 64 consecutive parents
+// of the first level and everything above them, handing digests down through LDS.  Every level is
+// still written to the level-order digest buffer (Merkle paths need all of them).  Replaces up to
+// seven single-level launches on a proof's critical path.
+__global__ void __launch_bounds__(256)
+merkle_subtree_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ out, uint64_t n_parents,
+                           uint32_t levels) {
+  __shared__ uint64_t rc[360];
+  __shared__ uint64_t sm[2][64 * 4];
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+  for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
+  __syncthreads();
+  const poseidon::QuadCtx qc = poseidon::quad_ctx();
+  const uint32_t quad = threadIdx.x >> 2;
+  uint64_t level_parents = n_parents;                    // parents of the level being produced (whole tree)
+  uint32_t wg_parents = n_parents < 64 ? (uint32_t)n_parents : 64u;  // ... and in this workgroup
+  uint64_t wg_first = (uint64_t)blockIdx.x * 64;         // index of this workgroup's first parent in that level
+  uint64_t* dst = out;
+  for (uint32_t l = 0; l < levels; l++) {
+    if (quad < wg_parents) {
+      uint64_t e[3];
+      if (l == 0) {
+        const uint64_t p = wg_first + quad;
+        e[0] = child[p * 8 + qc.q];
+        e[1] = child[p * 8 + 4 + qc.q];
+      } else {
+        e[0] = sm[(l - 1) & 1][(2 * quad) * 4 + qc.q];
+        e[1] = sm[(l - 1) & 1][(2 * quad + 1) * 4 + qc.q];
+      }
+      e[2] = 0;
+      poseidon::permute_quad(e, qc, rc);
+      const uint64_t d = gl::canon(e[0]);
+      dst[(wg_first + quad) * 4 + qc.q] = d;
+      sm[l & 1][quad * 4 + qc.q] = d;
+    }
+    __syncthreads();
+    dst += level_parents * 4;
+    level_parents >>= 1;
+    wg_parents >>= 1;
+    wg_first >>= 1;
+  }
+}
+
 // Row-major leaves (FRI layers): leaf k = leaf_len consecutive words.
 __global__ void __launch_bounds__(256)
 leaf_hash_rows_kernel(const uint64_t* __restrict__ leaves, uint32_t leaf_len, uint64_t n_leaves,
                       uint64_t* __restrict__ digests) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (k >= n_leaves) return;
   const uint64_t* p = leaves + k * leaf_len;
@@ -124,6 +169,7 @@ leaf_hash_rows_kernel(const uint64_t* __restrict__ leaves, uint32_t leaf_len, ui
 // One lane per parent node of one level.
 __global__ void __launch_bounds__(256)
 merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= n_parents) return;
   uint64_t l[4], r[4], o[4];
@@ -153,18 +199,41 @@ namespace bpg {
 // launches with fewer permutations than this use the quad-cooperative kernels (4x the waves)
 static std::atomic<uint64_t> g_quad_threshold{(uint64_t)1 << 15};
 uint64_t quad_threshold() { return g_quad_threshold.load(std::memory_order_relaxed); }
+static std::atomic<int> g_merkle_fused{0};  // measured: per-level launches are ~3% faster under 16-stream load
 
 int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st) {
   uint64_t* lvl = d_digests;
-  for (uint32_t l = log_leaves; l > cap_height; l--) {
-    uint64_t cnt = (uint64_t)1 << l;
+  uint32_t l = log_leaves;
+  while (l > cap_height) {
+    const uint64_t cnt = (uint64_t)1 << l, parents = cnt / 2;
     uint64_t* nxt = lvl + cnt * 4;
-    if (cnt / 2 < quad_threshold())
-      merkle_level_quad_kernel<<<ceil_div(cnt * 2, 256), 256, 0, st>>>(lvl, nxt, cnt / 2);
-    else
-      merkle_level_kernel<<<ceil_div(cnt / 2, 256), 256, 0, st>>>(lvl, nxt, cnt / 2);
+    if (parents >= quad_threshold()) {  // big level: one lane per node is the most instruction-efficient
+      merkle_level_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents);
+      BPG_LAUNCH_CHECK();
+      lvl = nxt;
+      l--;
+      continue;
+    }
+    if (!g_merkle_fused.load(std::memory_order_relaxed)) {
+      merkle_level_quad_kernel<<<ceil_div(cnt * 2, 256), 256, 0, st>>>(lvl, nxt, parents);
+      BPG_LAUNCH_CHECK();
+      lvl = nxt;
+      l--;
+      continue;
+    }
+    // fused: a workgroup's 64 parents can be reduced 7 levels (64 -> 1); fewer if the cap comes first
+    // or the level is smaller than one workgroup
+    uint32_t levels = l - cap_height;
+    const uint32_t wgs = parents >= 64 ? (uint32_t)(parents / 64) : 1;
+    uint32_t max_levels = 1;
+    for (uint64_t p = parents >= 64 ? 64 : parents; p > 1; p >>= 1) max_levels++;
+    if (levels > max_levels) levels = max_levels;
+    merkle_subtree_quad_kernel<<<wgs, 256, 0, st>>>(lvl, nxt, parents, levels);
     BPG_LAUNCH_CHECK();
-    lvl = nxt;
+    for (uint32_t k = 0; k < levels; k++) {
+      lvl += ((uint64_t)1 << l) * 4;
+      l--;
+    }
   }
   return BP_OK;
 }
@@ -188,6 +257,7 @@ int bp_debug_copy_u64(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* s
   return BP_OK;
 }
 
+void bp_tune_merkle_fused(int on) { bpg::g_merkle_fused.store(on != 0); }
 void bp_tune_quad_threshold(uint64_t n_perms) { bpg::g_quad_threshold.store(n_perms); }
 
 uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {

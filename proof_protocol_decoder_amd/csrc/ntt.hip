@@ -99,6 +99,7 @@ struct LdsNttArgs {
 // grid = (blocks per column, columns, cosets)
 template <bool DIF>
 __global__ void __launch_bounds__(1024) ntt_lds_kernel(LdsNttArgs a) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   const uint32_t n = 1u << a.log_blk;
   const uint64_t off = (uint64_t)blockIdx.x << a.log_blk;
@@ -193,6 +194,7 @@ struct Ntt16Args {
 // natural -> bit-reversed.  grid = (blocks per column, columns)
 template <int L>
 __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr uint32_t T = (1u << L) / 16;
   constexpr int RT = (L % 4 == 0) ? 4 : (L % 4);  // stages of the innermost pass
@@ -238,6 +240,7 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
 // bit-reversed -> natural, optional per-coset input scale; one workgroup makes all cosets of its block.
 template <int L>
 __global__ void __launch_bounds__((1 << L) / 16) ntt16_dit_kernel(Ntt16Args a) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr uint32_t T = (1u << L) / 16;
   constexpr int RT = (L % 4 == 0) ? 4 : (L % 4);  // stages of the outermost pass

@@ -51,6 +51,7 @@ synth_const_kernel(uint64_t* out, uint32_t log_n, uint32_t n_const, uint64_t see
 __global__ void __launch_bounds__(256)
 synth_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ consts, uint32_t log_n, uint32_t n_cols,
                    uint32_t n_const, uint32_t deg_pow, uint64_t seed) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t n = 1u << log_n, G = n_cols / 4;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -77,6 +78,7 @@ synth_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ consts
 __global__ void __launch_bounds__(1024)
 aux_suffix_product_kernel(const uint64_t* __restrict__ trace, uint64_t* __restrict__ aux, uint32_t log_n,
                           bpg::Ctl ctl) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   __shared__ uint64_t part[1024];
   const uint32_t n = 1u << log_n, k = blockIdx.x, T = blockDim.x;
   const uint64_t *a = trace + (uint64_t)(8 * k) * n, *b = a + n;
@@ -128,6 +130,7 @@ __device__ __forceinline__ RowPoint row_point(const bpg::QuotArgs& q, uint32_t t
 // grid = (rows/256, n_chunks).  Chunk y < n_group_chunks covers groups [y*GC, ...); the remaining
 // chunks cover aux columns.  partial[(chunk*2 + j)*rows + pos] = Horner partial of that chunk.
 __global__ void __launch_bounds__(256) quotient_partial_kernel(bpg::QuotArgs q) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
   const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
@@ -168,6 +171,7 @@ __global__ void __launch_bounds__(256) quotient_partial_kernel(bpg::QuotArgs q) 
 }
 // acc = sum over chunks in order: acc*alpha^(#constraints in chunk) + partial; then / Z_H.
 __global__ void __launch_bounds__(256) quotient_combine_kernel(bpg::QuotArgs q, bpg::ChunkPows cp) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
   const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
@@ -183,6 +187,7 @@ __global__ void __launch_bounds__(256) quotient_combine_kernel(bpg::QuotArgs q, 
 // After the per-coset inverse NTT: E_t[pos] (bit-reversed n0).  c_{n0 + n*n1} =
 // (s^n)^(-n1) / 2^r * sum_t w_{2^r}^(-t n1) * E_t[pos] * g_t^(-n0).   grid = (n/256, 2 challenges)
 __global__ void __launch_bounds__(256) quotient_chunks_kernel(bpg::ChunkArgs c) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << c.log_n;
   if (pos >= n) return;
   const uint32_t j = blockIdx.y, R = 1u << c.rate_bits;
@@ -200,6 +205,7 @@ __global__ void __launch_bounds__(256) quotient_chunks_kernel(bpg::ChunkArgs c) 
 // pw[0..n) = zeta^bitrev(pos) (c0 plane), pw[n..2n) c1 plane; same for the second point at 2n.
 __global__ void __launch_bounds__(256)
 power_vector_kernel(uint64_t* __restrict__ out, uint32_t log_n, Ext z0, Ext z1) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << log_n;
   if (pos >= n) return;
   const uint32_t e = gl::bitrev(pos, log_n);
@@ -210,6 +216,7 @@ power_vector_kernel(uint64_t* __restrict__ out, uint32_t log_n, Ext z0, Ext z1) 
   o[n + pos] = r.c1;
 }
 __global__ void __launch_bounds__(256) alpha_pows_kernel(uint64_t* __restrict__ out, uint32_t count, Ext alpha) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
   const Ext r = gl::pow(alpha, j);
@@ -220,6 +227,7 @@ __global__ void __launch_bounds__(256) alpha_pows_kernel(uint64_t* __restrict__ 
 __global__ void __launch_bounds__(256)
 openings_kernel(const uint64_t* __restrict__ coeffs, uint64_t stride, uint32_t log_n,
                 const uint64_t* __restrict__ pw, uint32_t n_points, uint64_t* __restrict__ out) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   __shared__ uint64_t red[4][256];
   const uint32_t n = 1u << log_n;
   const uint64_t* c = coeffs + blockIdx.x * stride;
@@ -248,6 +256,7 @@ openings_kernel(const uint64_t* __restrict__ coeffs, uint64_t stride, uint32_t l
 // three batch polynomials:  G_b[pos] += sum_col alpha^(e_b + col) * coeff[col][pos].
 // grid = (n/256, column chunks).  partial layout: [chunk][b][2][n]
 __global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineArgs a) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << a.log_n;
   if (pos >= n) return;
   const uint32_t c0 = blockIdx.y * a.cols_per_chunk, c1 = min(c0 + a.cols_per_chunk, a.n_cols);
@@ -272,6 +281,7 @@ __global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineAr
 __global__ void __launch_bounds__(256)
 fri_combine_reduce_kernel(const uint64_t* __restrict__ partial, uint32_t n_chunks, uint32_t log_n,
                           uint64_t* __restrict__ g) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << log_n;
   if (pos >= n) return;
   uint64_t acc = 0;
@@ -281,6 +291,7 @@ fri_combine_reduce_kernel(const uint64_t* __restrict__ partial, uint32_t n_chunk
 // Layer-0 FRI values: V(x) = sum_b alpha^(e_b) * (G_b(x) - y_b) / (x - z_b), x on the LDE coset.
 // glde: [6][rows] coset-major; out: AoS ext [rows].
 __global__ void __launch_bounds__(256) fri_quotient_values_kernel(bpg::FriInitArgs a) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint64_t rows = (uint64_t)1 << (a.log_n + a.rate_bits);
   const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
@@ -304,6 +315,7 @@ __global__ void __launch_bounds__(256) fri_quotient_values_kernel(bpg::FriInitAr
 // bit-reversed values chunked by arity) is those values in bitrev_a(j) order, leaf index
 // bitrev(t + 2^r*m0).
 __global__ void __launch_bounds__(256) fri_layer_leaf_kernel(bpg::FriLayerArgs a) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t log_q = a.log_nl - a.arity_bits;  // log2(n_l / arity)
   const uint64_t n_leaves = (uint64_t)1 << (log_q + a.rate_bits);
   const uint64_t id = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -331,6 +343,7 @@ __global__ void __launch_bounds__(256) fri_layer_leaf_kernel(bpg::FriLayerArgs a
 // Quad-cooperative form of the same leaf hash: lane q of a quad carries state words q and q+4, i.e.
 // component (q & 1) of ext elements (q >> 1) and 2 + (q >> 1) of every 4-element absorb.
 __global__ void __launch_bounds__(256) fri_layer_leaf_quad_kernel(bpg::FriLayerArgs a) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   __shared__ uint64_t rc[360];
   for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
   __syncthreads();
@@ -355,6 +368,7 @@ __global__ void __launch_bounds__(256) fri_layer_leaf_quad_kernel(bpg::FriLayerA
 }
 // P'(x0^a) = sum_i (beta/x0)^i u_i,  u_i = 1/a * sum_j' w_a^(-i j') P(x0 w_a^j')
 __global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t log_q = a.log_nl - a.arity_bits;
   const uint64_t n_out = (uint64_t)1 << (log_q + a.rate_bits);
   const uint64_t id = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -398,6 +412,7 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned
 // grid = (num_queries, n_oracles).  Writes row values and the Merkle path of leaf x into the
 // query record (layout: DESIGN.md section 6).
 __global__ void __launch_bounds__(256) query_initial_kernel(bpg::QueryArgs a) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t q = blockIdx.x, o = blockIdx.y;
   const uint64_t x = a.x_index[q];
   const bpg::QueryOracle& orc = a.oracle[o];
@@ -419,6 +434,7 @@ __global__ void __launch_bounds__(256) query_initial_kernel(bpg::QueryArgs a) {
 }
 // grid = (num_queries, n_layers)
 __global__ void __launch_bounds__(64) query_layers_kernel(bpg::QueryLayerArgs a) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t q = blockIdx.x, l = blockIdx.y;
   const bpg::QueryLayer& L = a.layer[l];
   const uint32_t arity = 1u << a.arity_bits;
