@@ -119,7 +119,7 @@ def main():
         if not n.value:
             return None
         ach = by.value / (ms.value * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "ntt_lds_kernel<DIT> (coset LDE, LDS-resident)", "achieved": round(ach, 1),
+        return {"bound": "hbm", "kernel": "coset-LDE NTT family: ntt16_dit_kernel<12|13|14> + ntt_lds_kernel<DIT>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 # PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/r1_pmc_*.csv): 1.37x algorithmic on
                 # the 2^14 x 2432 launch (each coset re-reads the coefficients); applied to the average launch
@@ -194,7 +194,7 @@ def isolated_roofline(pkg, torch):
         best = min(best, a.elapsed_time(b))
     alg = 8.0 * n * C_ * (1 + (1 << r))
     ach = alg / (best * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "ntt_lds_kernel<DIT> (coset LDE), 2^14 x 2432, rate 2, alone", "achieved": round(ach, 1),
+    return {"bound": "hbm", "kernel": "ntt16_dit_kernel<14> (coset LDE), 2^14 x 2432, rate 2, alone", "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "launch_ms": round(best, 4)}
 
 
