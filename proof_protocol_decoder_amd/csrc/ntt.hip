@@ -405,11 +405,18 @@ static int launch_global_passes(const uint64_t* in, uint64_t in_stride, uint64_t
                                 uint64_t coset_stride, uint32_t n_cols, uint32_t n_cosets, uint32_t log_n,
                                 const uint64_t* tw, hipStream_t st) {
   // DIF: spans log_n, log_n-k1, ... down to > LOG_BLK_MAX;  DIT: the same spans in reverse order.
+  // As few passes as possible (each one streams the whole column through HBM): up to 5 bits (32
+  // elements per lane; 64 spill to scratch) per pass, split evenly.
   uint32_t spans[8], radix[8], cnt = 0;
-  for (uint32_t span = log_n; span > LOG_BLK_MAX;) {
-    uint32_t k = span - LOG_BLK_MAX > 4 ? 4 : span - LOG_BLK_MAX;
-    spans[cnt] = span; radix[cnt] = k; cnt++;
-    span -= k;
+  {
+    const uint32_t extra = log_n - LOG_BLK_MAX, n_pass = (extra + 4) / 5;
+    uint32_t span = log_n, left = extra;
+    for (uint32_t i = 0; i < n_pass; i++) {
+      const uint32_t k = (left + (n_pass - i) - 1) / (n_pass - i);
+      spans[cnt] = span; radix[cnt] = k; cnt++;
+      span -= k;
+      left -= k;
+    }
   }
   for (uint32_t idx = 0; idx < cnt; idx++) {
     uint32_t i = DIF ? idx : cnt - 1 - idx;
@@ -420,7 +427,8 @@ static int launch_global_passes(const uint64_t* in, uint64_t in_stride, uint64_t
       case 1: ntt_global_pass_kernel<1, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
       case 2: ntt_global_pass_kernel<2, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
       case 3: ntt_global_pass_kernel<3, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
-      default: ntt_global_pass_kernel<4, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+      case 4: ntt_global_pass_kernel<4, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+      default: ntt_global_pass_kernel<5, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
     }
     BPG_LAUNCH_CHECK();
   }
