@@ -85,7 +85,8 @@ leaf_hash_quad_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_
   digests[leaf * 4 + q] = gl::canon(e[0]);
 }
 __global__ void __launch_bounds__(256)
-merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents) {
+merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
+                         uint64_t* __restrict__ mirror) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   __shared__ uint64_t rc[360];
   for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
@@ -95,7 +96,9 @@ merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restric
   const poseidon::QuadCtx qc = poseidon::quad_ctx();
   uint64_t e[3] = {child[i * 8 + qc.q], child[i * 8 + 4 + qc.q], 0};
   poseidon::permute_quad(e, qc, rc);
-  parent[i * 4 + qc.q] = gl::canon(e[0]);
+  const uint64_t d = gl::canon(e[0]);
+  parent[i * 4 + qc.q] = d;
+  if (mirror) mirror[i * 4 + qc.q] = d;  // cap level: also straight into the host-visible mailbox
 }
 
 // Several Merkle levels in one launch: each 256-lane workgroup (64 quads) owns 64 consecutive parents
@@ -104,7 +107,7 @@ merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restric
 // seven single-level launches on a proof's critical path.
 __global__ void __launch_bounds__(256)
 merkle_subtree_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ out, uint64_t n_parents,
-                           uint32_t levels) {
+                           uint32_t levels, uint64_t* __restrict__ mirror) {
   __shared__ uint64_t rc[360];
   __shared__ uint64_t sm[2][64 * 4];
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
@@ -131,6 +134,7 @@ merkle_subtree_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restr
       poseidon::permute_quad(e, qc, rc);
       const uint64_t d = gl::canon(e[0]);
       dst[(wg_first + quad) * 4 + qc.q] = d;
+      if (mirror && l + 1 == levels) mirror[(wg_first + quad) * 4 + qc.q] = d;
       sm[l & 1][quad * 4 + qc.q] = d;
     }
     __syncthreads();
@@ -168,7 +172,8 @@ leaf_hash_rows_kernel(const uint64_t* __restrict__ leaves, uint32_t leaf_len, ui
 
 // One lane per parent node of one level.
 __global__ void __launch_bounds__(256)
-merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents) {
+merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
+                    uint64_t* __restrict__ mirror) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= n_parents) return;
@@ -181,6 +186,10 @@ merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ p
   poseidon::two_to_one(l, r, o);
 #pragma unroll
   for (int k = 0; k < 4; k++) parent[i * 4 + k] = o[k];
+  if (mirror) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) mirror[i * 4 + k] = o[k];
+  }
 }
 
 // 8-byte-per-lane streaming copy: calibrates the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the
@@ -196,27 +205,33 @@ calib_copy_u64_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ ou
 
 namespace bpg {
 
+int merkle_commit_cols(const uint64_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t*, hipStream_t, uint64_t*, bool*);
+
 // launches with fewer permutations than this use the quad-cooperative kernels (4x the waves)
 static std::atomic<uint64_t> g_quad_threshold{(uint64_t)1 << 15};
 uint64_t quad_threshold() { return g_quad_threshold.load(std::memory_order_relaxed); }
 static std::atomic<int> g_merkle_fused{0};  // measured: per-level launches are ~3% faster under 16-stream load
 
-int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st) {
+// `mirror` (nullable): host-visible buffer that receives the 2^cap_height cap digests directly from
+// the kernel that produces them, so the caller needs no device->host copy, only a stream wait.
+// Returns with *mirrored = false when there was no level to run (the cap is the leaf level).
+int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st,
+                        uint64_t* mirror, bool* mirrored) {
   uint64_t* lvl = d_digests;
   uint32_t l = log_leaves;
+  if (mirrored) *mirrored = false;
   while (l > cap_height) {
     const uint64_t cnt = (uint64_t)1 << l, parents = cnt / 2;
     uint64_t* nxt = lvl + cnt * 4;
-    if (parents >= quad_threshold()) {  // big level: one lane per node is the most instruction-efficient
-      merkle_level_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents);
+    const bool fused = parents < quad_threshold() && g_merkle_fused.load(std::memory_order_relaxed);
+    if (!fused) {
+      uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;
+      if (parents >= quad_threshold())  // big level: one lane per node is the most instruction-efficient
+        merkle_level_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
+      else
+        merkle_level_quad_kernel<<<ceil_div(cnt * 2, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
       BPG_LAUNCH_CHECK();
-      lvl = nxt;
-      l--;
-      continue;
-    }
-    if (!g_merkle_fused.load(std::memory_order_relaxed)) {
-      merkle_level_quad_kernel<<<ceil_div(cnt * 2, 256), 256, 0, st>>>(lvl, nxt, parents);
-      BPG_LAUNCH_CHECK();
+      if (mir && mirrored) *mirrored = true;
       lvl = nxt;
       l--;
       continue;
@@ -228,8 +243,10 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     uint32_t max_levels = 1;
     for (uint64_t p = parents >= 64 ? 64 : parents; p > 1; p >>= 1) max_levels++;
     if (levels > max_levels) levels = max_levels;
-    merkle_subtree_quad_kernel<<<wgs, 256, 0, st>>>(lvl, nxt, parents, levels);
+    uint64_t* mir = (l - levels == cap_height) ? mirror : nullptr;
+    merkle_subtree_quad_kernel<<<wgs, 256, 0, st>>>(lvl, nxt, parents, levels, mir);
     BPG_LAUNCH_CHECK();
+    if (mir && mirrored) *mirrored = true;
     for (uint32_t k = 0; k < levels; k++) {
       lvl += ((uint64_t)1 << l) * 4;
       l--;
@@ -243,7 +260,7 @@ int merkle_commit_rows(const uint64_t* d_leaves, uint32_t leaf_len, uint32_t log
   uint64_t n = (uint64_t)1 << log_leaves;
   leaf_hash_rows_kernel<<<ceil_div(n, 256), 256, 0, st>>>(d_leaves, leaf_len, n, d_digests);
   BPG_LAUNCH_CHECK();
-  return merkle_upper_levels(d_digests, log_leaves, cap_height, st);
+  return merkle_upper_levels(d_digests, log_leaves, cap_height, st, nullptr, nullptr);
 }
 
 }  // namespace bpg
@@ -274,22 +291,30 @@ int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream) {
 
 int bp_merkle_commit(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n,
                      uint32_t rate_bits, uint32_t cap_height, uint64_t* d_digests, void* stream) {
-  const uint32_t log_leaves = log_n + rate_bits;
-  if (!d_lde || !d_digests) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_merkle_commit: null buffer");
-  if (log_leaves > 30 || cap_height > log_leaves || n_cols == 0 || lde_stride < ((uint64_t)1 << log_leaves))
-    return bpg::fail(BP_ERR_INVALID_INPUT,
-                     "bp_merkle_commit: bad shape (log_n=%u rate_bits=%u cap_height=%u n_cols=%u stride=%llu)",
-                     log_n, rate_bits, cap_height, n_cols, (unsigned long long)lde_stride);
-  hipStream_t st = bpg::as_stream(stream);
-  uint64_t rows = (uint64_t)1 << log_leaves;
-  if (rows < bpg::quad_threshold())
-    leaf_hash_quad_kernel<<<bpg::ceil_div(rows * 4, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
-                                                                      d_digests);
-  else
-    leaf_hash_kernel<<<bpg::ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
-                                                              d_digests);
-  BPG_LAUNCH_CHECK();
-  return bpg::merkle_upper_levels(d_digests, log_leaves, cap_height, st);
+  return bpg::merkle_commit_cols(d_lde, lde_stride, n_cols, log_n, rate_bits, cap_height, d_digests,
+                                 bpg::as_stream(stream), nullptr, nullptr);
 }
 
 }  // extern "C"
+
+namespace bpg {
+
+int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                       uint32_t cap_height, uint64_t* d_digests, hipStream_t st, uint64_t* mirror, bool* mirrored) {
+  const uint32_t log_leaves = log_n + rate_bits;
+  if (!d_lde || !d_digests) return fail(BP_ERR_INVALID_INPUT, "bp_merkle_commit: null buffer");
+  if (log_leaves > 30 || cap_height > log_leaves || n_cols == 0 || lde_stride < ((uint64_t)1 << log_leaves))
+    return fail(BP_ERR_INVALID_INPUT,
+                "bp_merkle_commit: bad shape (log_n=%u rate_bits=%u cap_height=%u n_cols=%u stride=%llu)", log_n,
+                rate_bits, cap_height, n_cols, (unsigned long long)lde_stride);
+  uint64_t rows = (uint64_t)1 << log_leaves;
+  if (rows < quad_threshold())
+    leaf_hash_quad_kernel<<<ceil_div(rows * 4, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
+                                                                 d_digests);
+  else
+    leaf_hash_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests);
+  BPG_LAUNCH_CHECK();
+  return merkle_upper_levels(d_digests, log_leaves, cap_height, st, mirror, mirrored);
+}
+
+}  // namespace bpg

@@ -139,6 +139,7 @@ int Worker::init(int dev, size_t arena_bytes) {
   if (rc) return rc;
   pinned_words = (size_t)1 << 22;  // 32 MiB staging
   BPG_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), pinned_words * 8, hipHostMallocDefault));
+  BPG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&pinned_dev), pinned, 0));
   BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_pow_result), 8));
   // many prover threads share few host cores: wait on a blocking event (the thread sleeps) rather
   // than spin in hipStreamSynchronize
@@ -156,6 +157,11 @@ void Worker::destroy() {
   pinned = nullptr;
   d_pow_result = nullptr;
   stream = nullptr;
+}
+int Worker::wait() {
+  BPG_HIP(hipEventRecord(sync_event, stream));
+  BPG_HIP(hipEventSynchronize(sync_event));
+  return BP_OK;
 }
 int Worker::d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words) {
   for (size_t off = 0; off < words; off += pinned_words) {
@@ -181,7 +187,6 @@ int Worker::d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words) {
 
 extern "C" int bp_lde_batch(const uint64_t*, uint64_t, uint64_t*, uint64_t, uint64_t*, uint64_t, uint32_t, uint32_t,
                             uint32_t, int, void*);
-extern "C" int bp_merkle_commit(const uint64_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t*, void*);
 extern "C" uint64_t bp_merkle_digest_words(uint32_t, uint32_t);
 
 int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
@@ -198,11 +203,16 @@ int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uin
   }
   TRY(bp_lde_batch(d_in, n, from_coeffs ? nullptr : coeffs, n, lde, m, log_n, rate_bits, n_cols, from_coeffs,
                    w.stream));
-  TRY(bp_merkle_commit(lde, m, n_cols, log_n, rate_bits, cap_height, digests, w.stream));
+  // the kernel that makes the cap level writes it into the pinned mailbox as well: no copy launch
+  bool mirrored = false;
+  TRY(merkle_commit_cols(lde, m, n_cols, log_n, rate_bits, cap_height, digests, w.stream, w.pinned_dev, &mirrored));
   out->coeffs = coeffs; out->lde = lde; out->digests = digests;
   const size_t cw = (size_t)4 << cap_height;
   out->cap.resize(cw);
-  return w.d2h(out->cap.data(), digests + dw - cw, cw);
+  if (!mirrored) return w.d2h(out->cap.data(), digests + dw - cw, cw);
+  TRY(w.wait());
+  std::memcpy(out->cap.data(), w.pinned, cw * 8);
+  return BP_OK;
 }
 
 // ------------------------------------------------------------------ one table
@@ -313,7 +323,8 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
   TRY(launch_power_vectors(d_pw, log_n, zeta, zeta_next, 2, st));
   TRY(launch_power_vectors(d_pw1, log_n, gl::ext(1), gl::ext(1), 1, st));
   const size_t open_cols = (size_t)K + C + A + Q + A;
-  ARENA_ALLOC(d_open, open_cols * 4);
+  if (open_cols * 4 > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "too many columns for the opening mailbox");
+  uint64_t* d_open = w.pinned_dev;  // kernels write the openings straight into host-visible memory
   uint64_t* d_o = d_open;
   if (K) TRY(launch_openings(consts->coeffs, N, log_n, K, d_pw, 1, d_o, st));
   d_o += (size_t)K * 4;
@@ -324,8 +335,8 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
   TRY(launch_openings(quot.coeffs, N, log_n, Q, d_pw, 1, d_o, st));
   d_o += (size_t)Q * 4;
   TRY(launch_openings(aux.coeffs, N, log_n, A, d_pw1, 1, d_o, st));
-  std::vector<uint64_t> ho(open_cols * 4);
-  TRY(w.d2h(ho.data(), d_open, ho.size()));
+  TRY(w.wait());
+  std::vector<uint64_t> ho(w.pinned, w.pinned + open_cols * 4);
   {
     uint64_t* oz = P + L.open_zeta;
     for (size_t c = 0; c < (size_t)K + C + A + Q; c++) { oz[2 * c] = ho[4 * c]; oz[2 * c + 1] = ho[4 * c + 1]; }
@@ -411,9 +422,15 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
     for (uint32_t k = 0; k < arity; k++) fa.wa_inv_pow[k] = gl::pow(wa_inv, k);
     fa.arity_inv = gl::inv(arity);
     TRY(launch_fri_layer_leaves(fa, st));
-    TRY(merkle_upper_levels(d_dig, log_leaves, h, st));
+    bool mirrored = false;
+    TRY(merkle_upper_levels(d_dig, log_leaves, h, st, w.pinned_dev, &mirrored));
     uint64_t* cap = P + L.fri_caps + l * L.cap_words;
-    TRY(w.d2h(cap, d_dig + dw - L.cap_words, L.cap_words));
+    if (mirrored) {
+      TRY(w.wait());
+      std::memcpy(cap, w.pinned, L.cap_words * 8);
+    } else {
+      TRY(w.d2h(cap, d_dig + dw - L.cap_words, L.cap_words));
+    }
     ch.observe(cap, L.cap_words);
     fa.beta = ch.challenge_ext();
     TRY(launch_fri_fold(fa, st));
@@ -488,7 +505,10 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
     QueryArgs qa2{};
     QueryLayerArgs ql{};
     for (uint32_t q = 0; q < cfg.num_queries; q++) qa2.x_index[q] = ql.x_index[q] = ch.challenge() & (M - 1);
-    ARENA_ALLOC(d_q, (size_t)cfg.num_queries * L.query_words);
+    const size_t q_words = (size_t)cfg.num_queries * L.query_words;
+    const bool q_direct = q_words <= w.pinned_words;  // gather straight into host-visible memory when it fits
+    uint64_t* d_q = q_direct ? w.pinned_dev : w.arena.alloc_words(q_words);
+    if (!d_q) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) allocating the query buffer", w.arena.capacity() >> 20);
     qa2.out = ql.out = d_q;
     qa2.query_words = ql.query_words = L.query_words;
     qa2.log_n = log_n; qa2.rate_bits = r; qa2.cap_height = h;
@@ -505,7 +525,12 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
       off += 2 * arity + (layer_log_nl[l] - ab + r - h) * 4;
     }
     TRY(launch_query_layers(ql, cfg.num_queries, L.n_layers, st));
-    TRY(w.d2h(P + L.queries, d_q, (size_t)cfg.num_queries * L.query_words));
+    if (q_direct) {
+      TRY(w.wait());
+      std::memcpy(P + L.queries, w.pinned, q_words * 8);
+    } else {
+      TRY(w.d2h(P + L.queries, d_q, q_words));
+    }
   }
   return BP_OK;
 }

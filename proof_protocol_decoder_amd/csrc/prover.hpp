@@ -100,7 +100,8 @@ struct Committed {
 struct Worker {
   hipStream_t stream = nullptr;
   DeviceArena arena;
-  uint64_t* pinned = nullptr;
+  uint64_t* pinned = nullptr;      // host staging / mailbox (kernels may write it directly)
+  uint64_t* pinned_dev = nullptr;  // the same memory as seen from the device
   size_t pinned_words = 0;
   unsigned long long* d_pow_result = nullptr;
   hipEvent_t sync_event = nullptr;  // blocking-sync event: waiting threads sleep instead of spinning
@@ -110,6 +111,7 @@ struct Worker {
   int init(int device, size_t arena_bytes);
   void destroy();
   int d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words);  // async copy + stream sync
+  int wait();  // everything queued on the stream has completed (blocking event)
   bool aborted() const { return abort_flag && *abort_flag; }
 };
 

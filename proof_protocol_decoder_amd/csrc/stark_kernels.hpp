@@ -122,6 +122,9 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
                uint32_t log_n, uint32_t n_cols, uint32_t n_cosets, const uint64_t* scale, bool inverse,
                hipStream_t st);
 // hash_kernels.hip
-int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st);
+int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st,
+                        uint64_t* mirror, bool* mirrored);
+int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
+                       uint32_t cap_height, uint64_t* d_digests, hipStream_t st, uint64_t* mirror, bool* mirrored);
 
 }  // namespace bpg
