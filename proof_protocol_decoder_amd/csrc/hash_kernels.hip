@@ -223,7 +223,8 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
   while (l > cap_height) {
     const uint64_t cnt = (uint64_t)1 << l, parents = cnt / 2;
     uint64_t* nxt = lvl + cnt * 4;
-    const bool fused = parents < quad_threshold() && g_merkle_fused.load(std::memory_order_relaxed);
+    // fuse only what fits in <= 64 workgroups: those launches are latency-critical and run at raised priority
+    const bool fused = parents <= 4096 && parents < quad_threshold() && g_merkle_fused.load(std::memory_order_relaxed);
     if (!fused) {
       uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;
       if (parents >= quad_threshold())  // big level: one lane per node is the most instruction-efficient
