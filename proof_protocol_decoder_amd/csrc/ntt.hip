@@ -38,9 +38,10 @@ __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const 
       if (m & half) continue;
       const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);  // position in block of size S>>s
       const uint64_t w = tw[(uint64_t)p << (tw_shift + s)];
-      const uint64_t a = x[m], b = x[m + half];
-      x[m] = gl::addc(a, b);
-      x[m + half] = gl::mulc(gl::subc(a, b), w);
+      // lazily reduced values: only the operand that must be canonical is canonicalised
+      const uint64_t a = x[m], b = gl::canon(x[m + half]);
+      x[m] = gl::add(a, b);
+      x[m + half] = gl::mul(gl::sub(a, b), w);
     }
   }
 }
@@ -57,8 +58,8 @@ __device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const 
       const uint32_t p = j + ((uint32_t)(m & (step - 1)) << log_sub);
       const uint64_t w = tw[(uint64_t)p << (tw_shift + (LOGR - 1 - s))];
       const uint64_t a = x[m], t = gl::mulc(x[m + step], w);
-      x[m] = gl::addc(a, t);
-      x[m + step] = gl::subc(a, t);
+      x[m] = gl::add(a, t);   // a: any u64, t: canonical -> lazily reduced result
+      x[m + step] = gl::sub(a, t);
     }
   }
 }
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(1024) ntt_lds_kernel(LdsNttArgs a) {
   if (DIF && a.out_scalar != 1) {
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = gl::mulc(buf[i], a.out_scalar);
   } else {
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = buf[i];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = gl::canon(buf[i]);
   }
 }
 
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
     for (int m = 0; m < 16; m++) dst[m * T + t] = gl::mulc(buf[swz<L>(m * T + t)], a.out_scalar);
   } else {
 #pragma unroll
-    for (int m = 0; m < 16; m++) dst[m * T + t] = buf[swz<L>(m * T + t)];
+    for (int m = 0; m < 16; m++) dst[m * T + t] = gl::canon(buf[swz<L>(m * T + t)]);
   }
 }
 
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dit_kernel(Ntt16Args a) {
     sub_butterflies<RT, 4 - RT, false, false>(x, tw, t, L - 4, L - RT, 0);
     uint64_t* dst = a.out + blockIdx.y * a.out_stride + coset * a.out_coset_stride + off;
 #pragma unroll
-    for (int m = 0; m < 16; m++) dst[m * T + t] = x[m];
+    for (int m = 0; m < 16; m++) dst[m * T + t] = gl::canon(x[m]);
     __syncthreads();  // everyone has read buf before the next coset overwrites it
   }
 }
@@ -319,7 +320,7 @@ ntt_global_pass_kernel(const uint64_t* in, uint64_t in_stride, uint64_t* out, ui
   if (DIF) dif_butterflies<LOGR>(x, tw, j, log_sub, log_n - span_log);
   else dit_butterflies<LOGR>(x, tw, j, log_sub, log_n - span_log);
 #pragma unroll
-  for (int m = 0; m < R; m++) dst[(uint64_t)m << log_sub] = x[m];
+  for (int m = 0; m < R; m++) dst[(uint64_t)m << log_sub] = gl::canon(x[m]);
 }
 
 // table builders ------------------------------------------------------------------------------
