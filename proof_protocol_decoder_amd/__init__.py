@@ -8,3 +8,4 @@ from ._lib import BpgError, lib, lib_path  # noqa: F401
 from . import ops  # noqa: F401
 from . import proof_gen  # noqa: F401
 from . import compact  # noqa: F401
+from . import trace_protocol  # noqa: F401
