@@ -68,12 +68,147 @@ GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
   hi = (uint64_t)(x >> 64);
 #endif
 }
+#if defined(__HIP__)  // both passes of a HIP compilation parse these; only the device pass emits them
+// ---- carry-chain primitives (device only).  The compiler never uses the carry-out of
+// v_mad_u64_u32 and forms (x, 0) register pairs with v_mov for every 32->64-bit addend (64-bit VGPR
+// operands must be even-aligned), which makes its modular multiply 25 VALU instructions.  With the
+// carries kept as explicit wave masks in SGPR pairs the same product + reduction is 17.  Each
+// one-instruction asm statement that CONSUMES a carry carries its own `s_nop 1`: on gfx940+ a VALU
+// write of an SGPR needs 2 wait states before a VALU read of it, and the compiler's hazard
+// recogniser does not look inside inline asm.  (Other waves of the SIMD issue during the nop.)
+namespace cc {
+typedef uint64_t mask;  // wave-wide carry mask, lives in an SGPR pair
+__device__ __forceinline__ uint64_t mad_co(uint32_t a, uint32_t b, uint64_t c, mask& co) {
+  uint64_t d;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint64_t mad_eps_co(uint32_t a, uint64_t c, mask& co) {  // a*(2^32-1) + c
+  uint64_t d;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(d), "=s"(co) : "v"(a), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t add_co(uint32_t a, uint32_t b, mask& co) {
+  uint32_t d;
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(d), "=s"(co) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t addc_co(uint32_t a, uint32_t b, mask ci, mask& co) {  // a + b + ci
+  uint32_t d;
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(a), "v"(b), "s"(ci));
+  return d;
+}
+__device__ __forceinline__ uint32_t addc0_co(uint32_t a, mask ci, mask& co) {  // a + ci
+  uint32_t d;
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(d), "=s"(co) : "v"(a), "s"(ci));
+  return d;
+}
+__device__ __forceinline__ uint32_t sub_co(uint32_t a, uint32_t b, mask& co) {
+  uint32_t d;
+  asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(d), "=s"(co) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t subb_co(uint32_t a, uint32_t b, mask ci, mask& co) {  // a - b - ci
+  uint32_t d;
+  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(a), "v"(b), "s"(ci));
+  return d;
+}
+__device__ __forceinline__ uint32_t subb0_co(uint32_t a, mask ci, mask& co) {  // a - ci
+  uint32_t d;
+  asm("s_nop 1\n\tv_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(d), "=s"(co) : "v"(a), "s"(ci));
+  return d;
+}
+__device__ __forceinline__ uint32_t sel_eps(mask m) {  // m ? 2^32-1 : 0
+  uint32_t d;
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d) : "s"(m));
+  return d;
+}
+__device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+// t (true value t + c*2^64) -> t + c*EPS; the sum cannot wrap again when t is the low word of a sum
+// of a 64-bit value and a product below 2^64 - 2^33.
+__device__ __forceinline__ uint64_t fold_carry(uint64_t t, mask c) {
+  mask c4, c5;
+  const uint32_t e = sel_eps(c);
+  const uint32_t lo = add_co((uint32_t)t, e, c4);
+  const uint32_t hi = addc0_co((uint32_t)(t >> 32), c4, c5);
+  return mk64(lo, hi);
+}
+#include "gl_cc.inc"  // the same instructions in groups of N = 3, 4 independent elements (no s_nop needed)
+}  // namespace cc
+#endif
+
 // any x any -> reduced
 GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // a*b = P + M*2^32 + C*2^96 + Q*2^64 with P = a0*b0, M + C*2^64 = a0*b1 + a1*b0, Q = a1*b1.
+  // In 32-bit limbs and with 2^64 = EPS, 2^96 = -1 (mod p):
+  //   a*b = U + S*EPS - (Q1 + C + c2),  U = (P0, P1 + M0 mod 2^32),  S + c2*2^32 = M1 + Q0 + carry(P1 + M0)
+  const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+  cc::mask C, c1, c2, c3, cx, bw, bw2, b3;
+  const uint64_t P = (uint64_t)a0 * b0;
+  const uint64_t M = cc::mad_co(a1, b0, (uint64_t)a0 * b1, C);
+  const uint64_t Q = (uint64_t)a1 * b1;  // Q1 <= 2^32 - 2, so Q1 + C fits
+  const uint32_t p1 = cc::add_co((uint32_t)(P >> 32), (uint32_t)M, c1);
+  const uint32_t S = cc::addc_co((uint32_t)(M >> 32), (uint32_t)Q, c1, c2);
+  const uint32_t K = cc::addc0_co((uint32_t)(Q >> 32), C, cx);
+  const uint64_t T = cc::fold_carry(cc::mad_eps_co(S, cc::mk64((uint32_t)P, p1), c3), c3);
+  // T - K - c2; on borrow the true value is 2^64 less: subtract EPS (the wrapped value is > EPS)
+  const uint32_t u0 = cc::subb_co((uint32_t)T, K, c2, bw);
+  const uint32_t u1 = cc::subb0_co((uint32_t)(T >> 32), bw, bw2);
+  const uint32_t r0 = cc::sub_co(u0, cc::sel_eps(bw2), b3);
+  const uint32_t r1 = cc::subb0_co(u1, b3, cx);
+  return cc::mk64(r0, r1);
+#else
   uint64_t lo, hi;
   mul_wide(a, b, lo, hi);
   return reduce128(lo, hi);
+#endif
 }
+#if defined(__HIP__)
+// N (= 3 or 4) independent products at once, instruction-interleaved: same arithmetic as mul(), but
+// every carry consumer sits N-1 >= 2 instructions behind its producer, so no s_nop is spent.  This is
+// the form the throughput kernels use (12 S-boxes of a Poseidon round, 8 butterflies of an NTT stage).
+template <int N>
+__device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
+  static_assert(N == 3 || N == 4, "groups of 3 or 4");
+  uint32_t a0[N], a1[N], b0[N], P0[N], P1[N], M0[N], M1[N], Q0[N], Q1[N];
+  uint64_t P[N], Mi[N], M[N], Q[N], U[N], T[N];
+  cc::mask C[N], c1[N], c2[N], c3[N], c4[N], cx[N], bw[N], bw2[N], b3[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    a0[i] = (uint32_t)a[i]; a1[i] = (uint32_t)(a[i] >> 32); b0[i] = (uint32_t)b[i];
+    const uint32_t b1 = (uint32_t)(b[i] >> 32);
+    P[i] = (uint64_t)a0[i] * b0[i];
+    Mi[i] = (uint64_t)a0[i] * b1;
+    Q[i] = (uint64_t)a1[i] * b1;
+  }
+  cc::mad_co(M, C, a1, b0, Mi);
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    P0[i] = (uint32_t)P[i]; P1[i] = (uint32_t)(P[i] >> 32); M0[i] = (uint32_t)M[i]; M1[i] = (uint32_t)(M[i] >> 32);
+    Q0[i] = (uint32_t)Q[i]; Q1[i] = (uint32_t)(Q[i] >> 32);
+  }
+  uint32_t p1[N], S[N], K[N], e[N], lo[N], hi[N], u0[N], u1[N], e2[N], r0[N], r1[N], T0[N], T1[N];
+  cc::add_co(p1, c1, P1, M0);
+  cc::addc_co(S, c2, M1, Q0, c1);
+  cc::addc0_co(K, cx, Q1, C);
+#pragma unroll
+  for (int i = 0; i < N; i++) U[i] = cc::mk64(P0[i], p1[i]);
+  cc::mad_eps_co(T, c3, S, U);
+  cc::sel_eps(e, c3);
+#pragma unroll
+  for (int i = 0; i < N; i++) { T0[i] = (uint32_t)T[i]; T1[i] = (uint32_t)(T[i] >> 32); }
+  cc::add_co(lo, c4, T0, e);
+  cc::addc0_co(hi, cx, T1, c4);
+  cc::subb_co(u0, bw, lo, K, c2);
+  cc::subb0_co(u1, bw2, hi, bw);
+  cc::sel_eps(e2, bw2);
+  cc::sub_co(r0, b3, u0, e2);
+  cc::subb0_co(r1, cx, u1, b3);
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = cc::mk64(r0[i], r1[i]);
+}
+#endif
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 GL_HD uint64_t mulc(uint64_t a, uint64_t b) { return canon(mul(a, b)); }
 

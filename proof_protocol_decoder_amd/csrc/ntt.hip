@@ -26,40 +26,87 @@ constexpr uint32_t LOG_BLK_MAX = 14;  // 2^14 * 8 B = 128 KiB of the 160 KiB LDS
 
 // ---- radix-2^LOGR register passes.  x[m] sits at position base + m*sub of a block of size
 // S = sub << LOGR; j = base mod sub.  `tw` is the table w_N^e, e < N/2, tw_shift = log2(N/S).
-template <int LOGR, bool CANON = true>
+// The R/2 twiddle multiplies of a stage are independent: they go through gl::mul_n in groups of four
+// (instruction-interleaved carry chains, gl.hpp), falling back to the one-at-a-time form for R < 8.
+template <int LOGR>
 __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const uint64_t* __restrict__ tw,
                                                 uint32_t j, uint32_t log_sub, uint32_t tw_shift) {
-  constexpr int R = 1 << LOGR;
+  constexpr int R = 1 << LOGR, NB = R / 2;
 #pragma unroll
   for (int s = 0; s < LOGR; s++) {
     const int half = R >> (s + 1);
+    // butterfly k of the stage pairs x[m], x[m + half], m = (k / half) * 2 * half + k % half
+    if constexpr (NB % 4 == 0) {
 #pragma unroll
-    for (int m = 0; m < R; m++) {
-      if (m & half) continue;
-      const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);  // position in block of size S>>s
-      const uint64_t w = tw[(uint64_t)p << (tw_shift + s)];
-      // lazily reduced values: only the operand that must be canonical is canonicalised
-      const uint64_t a = x[m], b = gl::canon(x[m + half]);
-      x[m] = gl::add(a, b);
-      x[m + half] = gl::mul(gl::sub(a, b), w);
+      for (int k0 = 0; k0 < NB; k0 += 4) {
+        uint64_t d[4], w[4], r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
+          const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);  // position in block of size S>>s
+          w[i] = tw[(uint64_t)p << (tw_shift + s)];
+          // lazily reduced values: only the operand that must be canonical is canonicalised
+          const uint64_t a = x[m], b = gl::canon(x[m + half]);
+          x[m] = gl::add(a, b);
+          d[i] = gl::sub(a, b);
+        }
+        gl::mul_n<4>(d, w, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
+          x[m + half] = r[i];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < R; m++) {
+        if (m & half) continue;
+        const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);
+        const uint64_t w = tw[(uint64_t)p << (tw_shift + s)];
+        const uint64_t a = x[m], b = gl::canon(x[m + half]);
+        x[m] = gl::add(a, b);
+        x[m + half] = gl::mul(gl::sub(a, b), w);
+      }
     }
   }
 }
 template <int LOGR>
 __device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const uint64_t* __restrict__ tw,
                                                 uint32_t j, uint32_t log_sub, uint32_t tw_shift) {
-  constexpr int R = 1 << LOGR;
+  constexpr int R = 1 << LOGR, NB = R / 2;
 #pragma unroll
   for (int s = 0; s < LOGR; s++) {
     const int step = 1 << s;  // stage block size = sub << (s+1); tw_shift is for S = sub << LOGR
+    if constexpr (NB % 4 == 0) {
 #pragma unroll
-    for (int m = 0; m < R; m++) {
-      if (m & step) continue;
-      const uint32_t p = j + ((uint32_t)(m & (step - 1)) << log_sub);
-      const uint64_t w = tw[(uint64_t)p << (tw_shift + (LOGR - 1 - s))];
-      const uint64_t a = x[m], t = gl::mulc(x[m + step], w);
-      x[m] = gl::add(a, t);   // a: any u64, t: canonical -> lazily reduced result
-      x[m + step] = gl::sub(a, t);
+      for (int k0 = 0; k0 < NB; k0 += 4) {
+        uint64_t v[4], w[4], r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / step) * 2 * step + (k % step);
+          const uint32_t p = j + ((uint32_t)(m & (step - 1)) << log_sub);
+          w[i] = tw[(uint64_t)p << (tw_shift + (LOGR - 1 - s))];
+          v[i] = x[m + step];
+        }
+        gl::mul_n<4>(v, w, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / step) * 2 * step + (k % step);
+          const uint64_t a = x[m], t = gl::canon(r[i]);
+          x[m] = gl::add(a, t);   // a: any u64, t: canonical -> lazily reduced result
+          x[m + step] = gl::sub(a, t);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < R; m++) {
+        if (m & step) continue;
+        const uint32_t p = j + ((uint32_t)(m & (step - 1)) << log_sub);
+        const uint64_t w = tw[(uint64_t)p << (tw_shift + (LOGR - 1 - s))];
+        const uint64_t a = x[m], t = gl::mulc(x[m + step], w);
+        x[m] = gl::add(a, t);
+        x[m + step] = gl::sub(a, t);
+      }
     }
   }
 }
@@ -231,7 +278,17 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
   __syncthreads();
   if (a.out_scalar != 1) {
 #pragma unroll
-    for (int m = 0; m < 16; m++) dst[m * T + t] = gl::mulc(buf[swz<L>(m * T + t)], a.out_scalar);
+    for (int m0 = 0; m0 < 16; m0 += 4) {
+      uint64_t v[4], w[4], r[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        v[i] = buf[swz<L>((m0 + i) * T + t)];
+        w[i] = a.out_scalar;
+      }
+      gl::mul_n<4>(v, w, r);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[(m0 + i) * T + t] = gl::canon(r[i]);
+    }
   } else {
 #pragma unroll
     for (int m = 0; m < 16; m++) dst[m * T + t] = gl::canon(buf[swz<L>(m * T + t)]);
@@ -240,7 +297,7 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
 
 // bit-reversed -> natural, optional per-coset input scale; one workgroup makes all cosets of its block.
 template <int L>
-__global__ void __launch_bounds__((1 << L) / 16) ntt16_dit_kernel(Ntt16Args a) {
+__global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per_eu(4, 8))) ntt16_dit_kernel(Ntt16Args a) {
   if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr uint32_t T = (1u << L) / 16;
@@ -265,7 +322,17 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dit_kernel(Ntt16Args a) {
     if (a.scale) {
       const uint64_t* sc = a.scale + ((uint64_t)coset << a.log_n_total) + off;
 #pragma unroll
-      for (int m = 0; m < 16; m++) buf[swz<L>(m * T + t)] = gl::mulc(src[m * T + t], sc[m * T + t]);
+      for (int m0 = 0; m0 < 16; m0 += 4) {
+        uint64_t v[4], w[4], r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          v[i] = src[(m0 + i) * T + t];
+          w[i] = sc[(m0 + i) * T + t];
+        }
+        gl::mul_n<4>(v, w, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++) buf[swz<L>((m0 + i) * T + t)] = r[i];  // reduced, not canonical: fine as a butterfly input
+      }
     } else {
 #pragma unroll
       for (int m = 0; m < 16; m++) buf[swz<L>(m * T + t)] = src[m * T + t];

@@ -23,6 +23,50 @@ __device__ __forceinline__ uint64_t sbox(uint64_t x) {
   return gl::mul(x3, x4);
 }
 
+// x^7 on N (3 or 4) independent words with the interleaved multiply (gl::mul_n)
+template <int N>
+__device__ __forceinline__ void sbox_n(uint64_t (&x)[N]) {
+  uint64_t x2[N], x4[N], x3[N];
+  gl::mul_n<N>(x, x, x2);
+  gl::mul_n<N>(x2, x2, x4);
+  gl::mul_n<N>(x2, x, x3);
+  gl::mul_n<N>(x3, x4, x);
+}
+__device__ __forceinline__ void sbox_all(uint64_t (&s)[12]) {
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    uint64_t y[4] = {s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+    sbox_n<4>(y);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[4 * g + i] = y[i];
+  }
+}
+
+// N accumulator pairs (L + H*2^32 < 2^74, L and H below 2^42) -> reduced words, carry-chain form:
+// (L0, L1 + H0) + (H1 + carry)*EPS, then fold the multiply-add's carry-out.
+template <int N>
+__device__ __forceinline__ void reduce_rows(const uint64_t (&L)[N], const uint64_t (&H)[N], uint64_t (&out)[N]) {
+  uint32_t L0[N], L1[N], H0[N], H1[N], rh[N], top[N], e[N], T0[N], T1[N], lo[N], hi[N];
+  uint64_t U[N], T[N];
+  gl::cc::mask c1[N], c3[N], c4[N], cx[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    L0[i] = (uint32_t)L[i]; L1[i] = (uint32_t)(L[i] >> 32); H0[i] = (uint32_t)H[i]; H1[i] = (uint32_t)(H[i] >> 32);
+  }
+  gl::cc::add_co(rh, c1, L1, H0);
+  gl::cc::addc0_co(top, cx, H1, c1);  // < 2^11
+#pragma unroll
+  for (int i = 0; i < N; i++) U[i] = gl::cc::mk64(L0[i], rh[i]);
+  gl::cc::mad_eps_co(T, c3, top, U);  // carry => T < 2^43, so folding it cannot wrap
+  gl::cc::sel_eps(e, c3);
+#pragma unroll
+  for (int i = 0; i < N; i++) { T0[i] = (uint32_t)T[i]; T1[i] = (uint32_t)(T[i] >> 32); }
+  gl::cc::add_co(lo, c4, T0, e);
+  gl::cc::addc0_co(hi, cx, T1, c4);
+#pragma unroll
+  for (int i = 0; i < N; i++) out[i] = gl::cc::mk64(lo[i], hi[i]);
+}
+
 // MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...).  Entries are < 2^6, so the
 // 32-bit halves of the state are accumulated separately in 64 bits (no overflow: 12*41*2^32 plus a
 // 32-bit constant) and recombined with one small reduction per row.  `rc_next` (nullable) points at
@@ -38,29 +82,32 @@ __device__ __forceinline__ void mds(uint64_t (&s)[12], const uint64_t* __restric
     hi[i] = (uint32_t)(s[i] >> 32);
   }
 #pragma unroll
-  for (int r = 0; r < 12; r++) {
-    uint64_t L = 0, H = 0;
-    if (ADD_RC) {
-      const uint64_t k = rc_next[r];
-      L = (uint32_t)k;
-      H = k >> 32;
-    }
+  for (int g = 0; g < 3; g++) {
+    uint64_t L[4], H[4];
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-      L += (uint64_t)lo[(i + r) % 12] * C[i];
-      H += (uint64_t)hi[(i + r) % 12] * C[i];
+    for (int rr = 0; rr < 4; rr++) {
+      const int r = 4 * g + rr;
+      L[rr] = 0;
+      H[rr] = 0;
+      if (ADD_RC) {
+        const uint64_t k = rc_next[r];
+        L[rr] = (uint32_t)k;
+        H[rr] = k >> 32;
+      }
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        L[rr] += (uint64_t)lo[(i + r) % 12] * C[i];
+        H[rr] += (uint64_t)hi[(i + r) % 12] * C[i];
+      }
+      if (r == 0) {
+        L[rr] += (uint64_t)lo[0] * 8;
+        H[rr] += (uint64_t)hi[0] * 8;
+      }
     }
-    if (r == 0) {
-      L += (uint64_t)lo[0] * 8;
-      H += (uint64_t)hi[0] * 8;
-    }
-    // value = L + H*2^32 < 2^74:  lo64 = L + (H<<32), top = (H>>32) + carry  (top < 2^11)
-    uint64_t hs = H << 32;
-    uint64_t lo64 = L + hs;
-    uint64_t top = (H >> 32) + (lo64 < hs ? 1 : 0);
-    uint64_t t1 = (top << 32) - top;  // top * (2^32-1), canonical
-    uint64_t res = lo64 + t1;
-    s[r] = res < t1 ? res + gl::EPS : res;
+    uint64_t out[4];
+    reduce_rows<4>(L, H, out);
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) s[4 * g + rr] = out[rr];
   }
 }
 
@@ -71,8 +118,7 @@ __device__ __forceinline__ void permute(uint64_t (&s)[12]) {
   int rnd = 0;
 #pragma unroll 1
   for (int k = 0; k < 4; k++, rnd++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+    sbox_all(s);
     mds<true>(s, RC + (rnd + 1) * 12);
   }
 #pragma unroll 1
@@ -82,12 +128,10 @@ __device__ __forceinline__ void permute(uint64_t (&s)[12]) {
   }
 #pragma unroll 1
   for (int k = 0; k < 3; k++, rnd++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+    sbox_all(s);
     mds<true>(s, RC + (rnd + 1) * 12);
   }
-#pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+  sbox_all(s);
   mds<false>(s, nullptr);
 }
 
@@ -143,8 +187,7 @@ __device__ __forceinline__ void permute_quad(uint64_t (&e)[3], const QuadCtx& c,
     const uint64_t* r = rc + (rnd < 29 ? rnd + 1 : 0) * 12 + c.q;
     const uint64_t kmask = rnd < 29 ? ~0ULL : 0ULL;
     if (full) {
-#pragma unroll
-      for (int a = 0; a < 3; a++) e[a] = sbox(e[a]);
+      sbox_n<3>(e);
     } else {
       const uint64_t sb = sbox(e[0]);  // only state word 0 (lane q == 0, slot 0) takes it
       e[0] = c.q == 0 ? sb : e[0];
@@ -160,27 +203,24 @@ __device__ __forceinline__ void permute_quad(uint64_t (&e)[3], const QuadCtx& c,
       lo[4 * a + 2] = (uint32_t)b2; hi[4 * a + 2] = (uint32_t)(b2 >> 32);
       lo[4 * a + 3] = (uint32_t)b3; hi[4 * a + 3] = (uint32_t)(b3 >> 32);
     }
+    uint64_t L[3], H[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {  // output row q + 4a
       const uint64_t k = r[4 * a] & kmask;
-      uint64_t L = (uint32_t)k, H = k >> 32;
+      L[a] = (uint32_t)k;
+      H[a] = k >> 32;
 #pragma unroll
       for (int kk = 0; kk < 12; kk++) {
         const uint32_t cf = c.cf[(kk - 4 * a + 12) % 12];
-        L += (uint64_t)lo[kk] * cf;
-        H += (uint64_t)hi[kk] * cf;
+        L[a] += (uint64_t)lo[kk] * cf;
+        H[a] += (uint64_t)hi[kk] * cf;
       }
       if (a == 0) {
-        L += (uint64_t)lo[0] * c.diag;
-        H += (uint64_t)hi[0] * c.diag;
+        L[a] += (uint64_t)lo[0] * c.diag;
+        H[a] += (uint64_t)hi[0] * c.diag;
       }
-      const uint64_t hs = H << 32;
-      const uint64_t lo64 = L + hs;
-      const uint64_t top = (H >> 32) + (lo64 < hs ? 1 : 0);
-      const uint64_t t1 = (top << 32) - top;
-      const uint64_t res = lo64 + t1;
-      e[a] = res < t1 ? res + gl::EPS : res;
     }
+    reduce_rows<3>(L, H, e);
   }
 }
 
