@@ -209,6 +209,48 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
   for (int i = 0; i < N; i++) r[i] = cc::mk64(r0[i], r1[i]);
 }
 #endif
+#if defined(__HIP__)
+// Unreduced dot-product accumulator: sum of 64x64-bit products kept as three 64-bit columns
+// (a0*b0 | a0*b1 + a1*b0 | a1*b1) plus a wrap counter per column; 4 multiply-adds and 4 carry counts
+// per term, one reduction at the end (instead of multiply + reduce + canonical add = 28 per term).
+struct DotAcc {
+  uint64_t p, m, q;        // column sums modulo 2^64
+  uint32_t cp, cm, cq;     // how often each wrapped
+};
+__device__ __forceinline__ DotAcc dot_zero() { return DotAcc{0, 0, 0, 0, 0, 0}; }
+// acc[i] += a[i] * b[i] for four independent accumulators (instruction-interleaved, no s_nop)
+__device__ __forceinline__ void dot_mad4(DotAcc (&acc)[4], const uint64_t (&a)[4], const uint64_t (&b)[4]) {
+  uint32_t a0[4], a1[4], b0[4], b1[4], cnt[4], cn2[4];
+  uint64_t in[4], out[4];
+  cc::mask c[4], cx[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    a0[i] = (uint32_t)a[i]; a1[i] = (uint32_t)(a[i] >> 32); b0[i] = (uint32_t)b[i]; b1[i] = (uint32_t)(b[i] >> 32);
+  }
+#define BPG_DOT_COL(COL, CNT, X, Y)                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; i++) { in[i] = acc[i].COL; cnt[i] = acc[i].CNT; } \
+  cc::mad_co(out, c, X, Y, in);                                       \
+  cc::addc0_co(cn2, cx, cnt, c);                                      \
+  _Pragma("unroll") for (int i = 0; i < 4; i++) { acc[i].COL = out[i]; acc[i].CNT = cn2[i]; }
+  BPG_DOT_COL(p, cp, a0, b0)
+  BPG_DOT_COL(m, cm, a0, b1)
+  BPG_DOT_COL(m, cm, a1, b0)
+  BPG_DOT_COL(q, cq, a1, b1)
+#undef BPG_DOT_COL
+}
+GL_HD uint64_t mulc(uint64_t a, uint64_t b);
+GL_HD uint64_t addc(uint64_t a, uint64_t b);
+// value = p + (m << 32) + (q << 64) + cp*2^64 + cm*2^96 + cq*2^128  (mod p), canonical
+__device__ __forceinline__ uint64_t dot_reduce(const DotAcc& d) {
+  uint64_t r = canon(d.p);
+  r = addc(r, mulc(d.m, (uint64_t)1 << 32));
+  r = addc(r, mulc(d.q, EPS));                       // 2^64 = EPS
+  r = addc(r, mulc(d.cp, EPS));
+  r = subc(r, canon((uint64_t)d.cm));                // 2^96 = -1
+  r = subc(r, mulc(d.cq, (uint64_t)1 << 32));        // 2^128 = -2^32
+  return r;
+}
+#endif
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 GL_HD uint64_t mulc(uint64_t a, uint64_t b) { return canon(mul(a, b)); }
 
@@ -221,7 +263,26 @@ GL_HD uint64_t pow(uint64_t a, uint64_t e) {
   }
   return r;
 }
-GL_HD uint64_t inv(uint64_t a) { return pow(a, P - 2); }
+// a^(p-2) with p - 2 = (2^32 - 2) * 2^32 + (2^32 - 1): 63 squarings and 9 multiplies instead of the
+// 64 + 62 of the generic ladder (same canonical value; inv(0) = 0 as before).
+GL_HD uint64_t inv(uint64_t a) {
+  // e_k = a^(2^k - 1): e_{j+k} = e_j^(2^k) * e_k
+  auto sq_n = [](uint64_t x, int n) {
+    for (int i = 0; i < n; i++) x = mul(x, x);
+    return x;
+  };
+  const uint64_t e1 = a;
+  const uint64_t e2 = mul(sq_n(e1, 1), e1);
+  const uint64_t e3 = mul(sq_n(e2, 1), e1);
+  const uint64_t e6 = mul(sq_n(e3, 3), e3);
+  const uint64_t e12 = mul(sq_n(e6, 6), e6);
+  const uint64_t e24 = mul(sq_n(e12, 12), e12);
+  const uint64_t e30 = mul(sq_n(e24, 6), e6);
+  const uint64_t e31 = mul(sq_n(e30, 1), e1);
+  const uint64_t hi = sq_n(e31, 1);   // a^(2^32 - 2)
+  const uint64_t lo = mul(hi, a);     // a^(2^32 - 1)
+  return mulc(sq_n(hi, 32), lo);
+}
 // primitive 2^k-th root of unity (plonky2_field convention)
 GL_HD uint64_t root(unsigned k) {
   uint64_t r = TWO_ADIC_ROOT;
@@ -237,10 +298,25 @@ GL_HD Ext ext(uint64_t a, uint64_t b = 0) { return Ext{a, b}; }
 GL_HD bool eq(Ext a, Ext b) { return a.c0 == b.c0 && a.c1 == b.c1; }
 GL_HD Ext add(Ext a, Ext b) { return Ext{addc(a.c0, b.c0), addc(a.c1, b.c1)}; }
 GL_HD Ext sub(Ext a, Ext b) { return Ext{subc(a.c0, b.c0), subc(a.c1, b.c1)}; }
+// 7 * x for any u64 x -> reduced: x*7 = (P0, M0) + M1*2^64 with M1 < 8
+GL_HD uint64_t mul7(uint64_t x) {
+  const uint64_t p = (uint64_t)(uint32_t)x * 7u;
+  const uint64_t m = (x >> 32) * 7u + (p >> 32);
+  const uint64_t u = (m << 32) | (uint32_t)p;
+  const uint64_t t = u + (m >> 32) * EPS;
+  return t < u ? t + EPS : t;
+}
 GL_HD Ext mul(Ext a, Ext b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint64_t x[4] = {a.c0, a.c1, a.c0, a.c1}, y[4] = {b.c0, b.c1, b.c1, b.c0};
+  uint64_t r[4];
+  mul_n<4>(x, y, r);
+  return Ext{addc(canon(r[0]), canon(mul7(r[1]))), addc(canon(r[2]), canon(r[3]))};
+#else
   uint64_t c0 = addc(mulc(a.c0, b.c0), mulc(W, mulc(a.c1, b.c1)));
   uint64_t c1 = addc(mulc(a.c0, b.c1), mulc(a.c1, b.c0));
   return Ext{c0, c1};
+#endif
 }
 GL_HD Ext scale(Ext a, uint64_t s) { return Ext{mulc(a.c0, s), mulc(a.c1, s)}; }
 GL_HD Ext pow(Ext a, uint64_t e) {

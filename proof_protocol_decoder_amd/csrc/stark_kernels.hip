@@ -123,8 +123,11 @@ __device__ __forceinline__ RowPoint row_point(const bpg::QuotArgs& q, uint32_t t
   RowPoint p;
   p.z_last = gl::subc(x, q.g_inv);
   const uint64_t zn = gl::mulc(zh, q.n_inv);
-  p.l_first = gl::mulc(zn, gl::inv(gl::subc(x, 1)));
-  p.l_last = gl::mulc(zn, gl::inv(gl::subc(gl::mulc(q.g, x), 1)));
+  // both Lagrange denominators with one inversion (x is off the subgroup: neither is zero)
+  const uint64_t df = gl::subc(x, 1), dl = gl::subc(gl::mulc(q.g, x), 1);
+  const uint64_t both = gl::mulc(zn, gl::inv(gl::mulc(df, dl)));
+  p.l_first = gl::mulc(both, dl);
+  p.l_last = gl::mulc(both, df);
   return p;
 }
 // grid = (rows/256, n_chunks).  Chunk y < n_group_chunks covers groups [y*GC, ...); the remaining
@@ -231,16 +234,21 @@ openings_kernel(const uint64_t* __restrict__ coeffs, uint64_t stride, uint32_t l
   __shared__ uint64_t red[4][256];
   const uint32_t n = 1u << log_n;
   const uint64_t* c = coeffs + blockIdx.x * stride;
-  uint64_t acc[4] = {0, 0, 0, 0};
+  // unreduced accumulation (gl::DotAcc): 8 VALU per product, one reduction per lane at the end
+  gl::DotAcc dacc[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint64_t v = c[i];
-    acc[0] = gl::addc(acc[0], gl::mulc(v, pw[i]));
-    acc[1] = gl::addc(acc[1], gl::mulc(v, pw[n + i]));
+    const uint64_t vv[4] = {v, v, v, v};
+    uint64_t w[4] = {pw[i], pw[n + i], 0, 0};
     if (n_points > 1) {
-      acc[2] = gl::addc(acc[2], gl::mulc(v, pw[2 * n + i]));
-      acc[3] = gl::addc(acc[3], gl::mulc(v, pw[3 * n + i]));
+      w[2] = pw[2 * n + i];
+      w[3] = pw[3 * n + i];
     }
+    gl::dot_mad4(dacc, vv, w);
   }
+  uint64_t acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) acc[k] = gl::dot_reduce(dacc[k]);
   for (int k = 0; k < 4; k++) red[k][threadIdx.x] = acc[k];
   __syncthreads();
   for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
@@ -260,16 +268,35 @@ __global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineAr
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << a.log_n;
   if (pos >= n) return;
   const uint32_t c0 = blockIdx.y * a.cols_per_chunk, c1 = min(c0 + a.cols_per_chunk, a.n_cols);
-  Ext acc[3] = {gl::ext(0), gl::ext(0), gl::ext(0)};
+  // six unreduced accumulators (3 batches x 2 extension components) in two groups of four
+  gl::DotAcc d01[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
+  gl::DotAcc d2[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
+  const bool on0 = a.exp_base[0] >= 0, on1 = a.exp_base[1] >= 0, on2 = a.exp_base[2] >= 0;
   for (uint32_t c = c0; c < c1; c++) {
     const uint64_t v = a.coeffs[(uint64_t)c * a.stride + pos];
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-      if (a.exp_base[b] < 0) continue;
-      const uint64_t* ap = a.alpha_pows + 2 * ((uint64_t)a.exp_base[b] + c);
-      acc[b] = Ext{gl::addc(acc[b].c0, gl::mulc(v, ap[0])), gl::addc(acc[b].c1, gl::mulc(v, ap[1]))};
+    const uint64_t vv[4] = {v, v, v, v};
+    if (on0 || on1) {
+      uint64_t w[4] = {0, 0, 0, 0};
+      if (on0) {
+        const uint64_t* ap = a.alpha_pows + 2 * ((uint64_t)a.exp_base[0] + c);
+        w[0] = ap[0];
+        w[1] = ap[1];
+      }
+      if (on1) {
+        const uint64_t* ap = a.alpha_pows + 2 * ((uint64_t)a.exp_base[1] + c);
+        w[2] = ap[0];
+        w[3] = ap[1];
+      }
+      gl::dot_mad4(d01, vv, w);
+    }
+    if (on2) {
+      const uint64_t* ap = a.alpha_pows + 2 * ((uint64_t)a.exp_base[2] + c);
+      const uint64_t w[4] = {ap[0], ap[1], 0, 0};
+      gl::dot_mad4(d2, vv, w);
     }
   }
+  const Ext acc[3] = {Ext{gl::dot_reduce(d01[0]), gl::dot_reduce(d01[1])}, Ext{gl::dot_reduce(d01[2]), gl::dot_reduce(d01[3])},
+                      Ext{gl::dot_reduce(d2[0]), gl::dot_reduce(d2[1])}};
   uint64_t* out = a.partial + (uint64_t)(a.chunk_base + blockIdx.y) * 6 * n;
 #pragma unroll
   for (int b = 0; b < 3; b++) {
@@ -297,13 +324,19 @@ __global__ void __launch_bounds__(256) fri_quotient_values_kernel(bpg::FriInitAr
   if (pos >= rows) return;
   const uint32_t t = (uint32_t)(pos >> a.log_n), m = (uint32_t)(pos & ((1u << a.log_n) - 1));
   const uint64_t x = gl::mulc(a.g_t[t], root_pow(a.tw_n, a.log_n, m));
+  // 1/(x - z_b) for the three points with ONE inversion (x is on the coset, z_b is a transcript
+  // challenge in the extension: the denominators are nonzero)
+  const Ext d0 = gl::sub(gl::ext(x), a.z[0]), d1 = gl::sub(gl::ext(x), a.z[1]), d2 = gl::sub(gl::ext(x), a.z[2]);
+  const Ext d01 = gl::mul(d0, d1);
+  const Ext all_inv = gl::inv(gl::mul(d01, d2));
+  const Ext i2 = gl::mul(all_inv, d01), i01 = gl::mul(all_inv, d2);
+  const Ext den_inv[3] = {gl::mul(i01, d1), gl::mul(i01, d0), i2};
   Ext sum = gl::ext(0);
 #pragma unroll
   for (int b = 0; b < 3; b++) {
     const Ext gv{a.glde[(2 * b) * rows + pos], a.glde[(2 * b + 1) * rows + pos]};
     const Ext num = gl::sub(gv, a.y[b]);
-    const Ext den = gl::sub(gl::ext(x), a.z[b]);
-    sum = gl::add(sum, gl::mul(a.alpha_shift[b], gl::mul(num, gl::inv(den))));
+    sum = gl::add(sum, gl::mul(a.alpha_shift[b], gl::mul(num, den_inv[b])));
   }
   a.out[2 * pos] = sum.c0;
   a.out[2 * pos + 1] = sum.c1;
@@ -375,22 +408,61 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
   if (id >= n_out) return;
   const uint32_t t = (uint32_t)(id >> log_q), m0 = (uint32_t)(id & ((1u << log_q) - 1));
   const uint64_t base = ((uint64_t)t << a.log_nl) + m0;
-  const uint32_t arity = 1u << a.arity_bits;
   // 1/x0 = g_t^-1 * w_{n_l}^(-m0)
   const uint64_t x_inv = gl::mulc(a.g_t_inv[t], root_pow(a.tw_nl_inv, a.log_nl, m0));
-  Ext v[16];
-  for (uint32_t j = 0; j < arity; j++) {
+  // u_i = sum_j w_a^(-i j) v_j by four radix-2 decimation-in-frequency stages (arity = 16 is the only
+  // built size, prover.cpp); u lands in bit-reversed slots.  The 1/a factor is applied once at the end.
+  uint64_t c0[16], c1[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
     const uint64_t p = base + ((uint64_t)j << log_q);
-    v[j] = Ext{a.values[2 * p], a.values[2 * p + 1]};
+    c0[j] = a.values[2 * p];
+    c1[j] = a.values[2 * p + 1];
   }
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int half = 8 >> s;
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += 2) {  // two butterflies = four base-field multiplies
+      uint64_t d[4], w[4], r[4];
+      int mm[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
+        mm[i] = m;
+        const uint64_t wv = a.wa_inv_pow[(m & (half - 1)) << s];
+        const uint64_t x0 = c0[m], x1 = c1[m], y0 = c0[m + half], y1 = c1[m + half];  // canonical
+        c0[m] = gl::addc(x0, y0);
+        c1[m] = gl::addc(x1, y1);
+        d[2 * i] = gl::subc(x0, y0);
+        d[2 * i + 1] = gl::subc(x1, y1);
+        w[2 * i] = wv;
+        w[2 * i + 1] = wv;
+      }
+      if (half == 1) {  // last stage: every twiddle is 1
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = d[i];
+      } else {
+        gl::mul_n<4>(d, w, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = gl::canon(r[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        c0[mm[i] + half] = r[2 * i];
+        c1[mm[i] + half] = r[2 * i + 1];
+      }
+    }
+  }
+  // P'(x0^a) = 1/a * sum_i (beta/x0)^i u_i, Horner from the top; u_i sits in slot bitrev4(i)
   const Ext bx = gl::scale(a.beta, x_inv);
-  Ext bxi = gl::ext(1), acc = gl::ext(0);
-  for (uint32_t i = 0; i < arity; i++) {
-    Ext u = gl::ext(0);
-    for (uint32_t j = 0; j < arity; j++) u = gl::add(u, gl::scale(v[j], a.wa_inv_pow[(i * j) & (arity - 1)]));
-    acc = gl::add(acc, gl::mul(gl::scale(u, a.arity_inv), bxi));
-    bxi = gl::mul(bxi, bx);
+  Ext acc = gl::ext(0);
+#pragma unroll
+  for (int i = 15; i >= 0; i--) {
+    const int slot = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+    acc = gl::add(gl::mul(acc, bx), Ext{c0[slot], c1[slot]});
   }
+  acc = gl::scale(acc, a.arity_inv);
   a.out[2 * id] = acc.c0;
   a.out[2 * id + 1] = acc.c1;
 }
