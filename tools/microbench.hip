@@ -27,6 +27,33 @@ __global__ void __launch_bounds__(256) alu_kernel(uint64_t* out, uint64_t seed) 
       if (OP == 6) a[k] = (a[k] << 3) + b;                                           // v_lshl_add_u64
       if (OP == 7) a[k] = __builtin_amdgcn_udot4((uint32_t)a[k], (uint32_t)b, (uint32_t)(a[k] >> 32), false);
       if (OP == 8) a[k] = __umul24((uint32_t)a[k], (uint32_t)b) + (uint32_t)(a[k] >> 32); // v_mad_u32_u24
+      if (OP == 9) a[k] = (uint32_t)((uint32_t)a[k] + (uint32_t)b) ^ 0x5bd1e995u;             // v_add_u32 + v_xor_b32 (2 ops)
+      if (OP == 10) {                                                                         // compiler-only modmul
+        uint64_t lo, hi;
+        gl::mul_wide(a[k], b, lo, hi);
+        a[k] = gl::reduce128(lo, hi);
+      }
+    }
+    if (OP == 12) {  // 64-bit add as two VOP3B carry ops with SGPR-pair carries (4 interleaved)
+      uint32_t lo[4], hi[4], bl[4], rl[4], rh[4];
+      gl::cc::mask c[4], cx[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { lo[k] = (uint32_t)a[k]; hi[k] = (uint32_t)(a[k] >> 32); bl[k] = (uint32_t)b; }
+      gl::cc::add_co(rl, c, lo, bl);
+      gl::cc::addc0_co(rh, cx, hi, c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) a[k] = gl::cc::mk64(rl[k], rh[k]);
+    }
+    if (OP == 13) {  // v_cndmask_b32 x2 + v_cmp (compiler): select on a 64-bit compare
+#pragma unroll
+      for (int k = 0; k < 4; k++) a[k] = a[k] < b ? a[k] ^ 0x9E3779B97F4A7C15ULL : a[k] + 1;
+    }
+    if (OP == 11) {  // four interleaved carry-chain multiplies
+      const uint64_t bb[4] = {b, b, b, b};
+      uint64_t r[4];
+      gl::mul_n<4>(a, bb, r);
+#pragma unroll
+      for (int k = 0; k < 4; k++) a[k] = r[k];
     }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a[0] ^ a[1] ^ a[2] ^ a[3];
@@ -66,14 +93,16 @@ int main() {
   uint64_t* out;
   const int blocks = prop.multiProcessorCount * 8, threads = 256;
   CK(hipMalloc(&out, (size_t)prop.multiProcessorCount * 16 * threads * 8));  // largest launch below: 16 blocks/CU
-  const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32+add", "v_mul_hi_u32+shl_add", "add_u64", "gl::mul",
-                         "gl::addc", "v_lshl_add_u64", "v_dot4_u32_u8", "v_mad_u32_u24"};
+  const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32+add", "v_mul_hi_u32+shl_add", "add_u64", "gl::mul (asm, 17 VALU+nop)",
+                         "gl::addc", "v_lshl_add_u64", "v_dot4_u32_u8", "v_mad_u32_u24", "v_add_u32+v_xor_b32",
+                         "modmul (compiler, 25 VALU)", "gl::mul_n<4> (17 VALU)", "add_co+addc_co (VOP3B, 2 ops)",
+                         "cmp_u64+2 xor+2 cndmask+add64"};
   double ops = (double)blocks * threads * ITERS * 4;
   float ms;
 #define RUN(OP) ms = time_ms([&] { alu_kernel<OP><<<blocks, threads>>>(out, 12345); }); \
-  printf("%-22s %8.3f ms  %8.2f Gop/s  (%.1f lane-cycles/op at 2.4GHz x 256CU x 128 lanes)\n", names[OP], ms, ops / ms / 1e6, \
+  printf("%-28s %8.3f ms  %8.2f Gop/s  (%.1f lane-cycles/op at 2.4GHz x 256CU x 128 lanes)\n", names[OP], ms, ops / ms / 1e6, \
          (2.4e9 * prop.multiProcessorCount * 128) / (ops / ms * 1e3));
-  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8)
+  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13)
   for (int occ_blocks : {4, 8, 16}) {
     int pb = prop.multiProcessorCount * occ_blocks, reps = 64;
     ms = time_ms([&] { poseidon_kernel<<<pb, 256>>>(out, 99, reps); });
