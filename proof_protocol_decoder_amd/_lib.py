@@ -56,6 +56,7 @@ def lib():
     L.bp_ntt_batch.argtypes = [vp, u32, u32, u64, i, vp]
     L.bp_lde_batch.argtypes = [vp, u64, vp, u64, vp, u64, u32, u32, u32, i, vp]
     L.bp_poseidon_perm_batch.argtypes = [vp, u64, vp]
+    L.bp_debug_field_ops.argtypes = [vp, vp, vp, u64, vp]
     L.bp_merkle_digest_words.argtypes = [u32, u32]
     L.bp_merkle_digest_words.restype = u64
     L.bp_merkle_commit.argtypes = [vp, u64, u32, u32, u32, u32, vp, vp]

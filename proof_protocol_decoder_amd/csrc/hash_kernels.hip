@@ -203,6 +203,51 @@ calib_copy_u64_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ ou
   for (; i < n; i += stride) out[i] = in[i];
 }
 
+// K1 check kernel: every device form of the field arithmetic on caller-supplied operand pairs.
+// out[op][i]; a is ANY u64 (also non-canonical), b likewise for the multiplies; the add/sub forms get
+// canon(b) as the contract of gl::add / gl::sub demands.
+__global__ void __launch_bounds__(256) field_ops_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
+                                                        uint64_t* __restrict__ out, uint64_t n) {
+  const uint64_t i0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  uint64_t x[4], y[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint64_t i = i0 + k < n ? i0 + k : n - 1;
+    x[k] = a[i];
+    y[k] = b[i];
+  }
+  uint64_t r4[4], r3[3];
+  gl::mul_n<4>(x, y, r4);
+  const uint64_t x3[3] = {x[1], x[2], x[3]}, y3[3] = {y[1], y[2], y[3]};
+  gl::mul_n<3>(x3, y3, r3);
+  gl::DotAcc d[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
+  gl::dot_mad4(d, x, y);
+  gl::dot_mad4(d, y, x);           // 2*a*b, through the wrap counters when the operands are large
+  const uint64_t yy[4] = {y[0], y[0], y[0], y[0]};
+  gl::dot_mad4(d, x, yy);          // + a_k * b_0
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint64_t i = i0 + k;
+    if (i >= n) break;
+    const uint64_t cb = gl::canon(y[k]);
+    out[0 * n + i] = gl::canon(gl::mul(x[k], y[k]));                 // one-element carry chain
+    out[1 * n + i] = gl::canon(r4[k]);                               // groups of four
+    out[2 * n + i] = k ? gl::canon(r3[k - 1]) : gl::canon(r4[0]);    // groups of three
+    uint64_t lo, hi;
+    gl::mul_wide(x[k], y[k], lo, hi);
+    out[3 * n + i] = gl::canon(gl::reduce128(lo, hi));               // compiler form
+    out[4 * n + i] = gl::canon(gl::add(x[k], cb));
+    out[5 * n + i] = gl::canon(gl::sub(x[k], cb));
+    out[6 * n + i] = gl::dot_reduce(d[k]);                           // 2*a*b + a*b_0 of the group
+    out[7 * n + i] = gl::canon(gl::mul7(x[k]));
+    out[8 * n + i] = gl::inv(gl::canon(x[k]));
+    const gl::Ext e = gl::mul(gl::Ext{gl::canon(x[k]), cb}, gl::Ext{cb, gl::canon(x[k] ^ y[k])});
+    out[9 * n + i] = e.c0;
+    out[10 * n + i] = e.c1;
+  }
+}
+
 }  // namespace
 
 namespace bpg {
@@ -273,6 +318,14 @@ extern "C" {
 int bp_debug_copy_u64(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream) {
   if (!d_in || !d_out) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_debug_copy_u64: null buffer");
   calib_copy_u64_kernel<<<4096, 256, 0, bpg::as_stream(stream)>>>(d_in, d_out, n);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+
+int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream) {
+  if (!n) return BP_OK;
+  if (!d_a || !d_b || !d_out) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_debug_field_ops: null buffer");
+  field_ops_kernel<<<bpg::ceil_div(bpg::ceil_div(n, 4), 256), 256, 0, bpg::as_stream(stream)>>>(d_a, d_b, d_out, n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }

@@ -45,6 +45,37 @@ def test_lde_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols):
     assert (to_host(lde2) == to_host(lde)).all() and (to_host(c2) == to_host(coeffs)).all()
 
 
+def test_field_ops_against_big_integers(bpg):
+    """K1 (SURVEY.md section 8(c) self-consistency item 2): every device form of the modular multiply
+    (one-element carry chain, groups of three and four, the compiler form), lazy add/sub, the
+    unreduced dot-product accumulator, 7*x, the inverse and the extension product, against Python
+    integers -- on random operands and on the edges, including NON-canonical u64 inputs."""
+    rng = np.random.default_rng(11)
+    edge = [0, 1, 2, 7, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, P - 1, P, P + 1, (1 << 63), (1 << 64) - 1,
+            (1 << 64) - (1 << 32), (1 << 64) - (1 << 32) - 1, 0xFFFFFFFF00000000, 0x00000000FFFFFFFF,
+            0xFFFFFFFEFFFFFFFF, 0x8000000080000000, P - (1 << 32), (1 << 48) + 12345]
+    a = [x for x in edge for _ in edge] + [int(v) for v in rng.integers(0, 1 << 64, 4096, dtype=np.uint64)]
+    b = [y for _ in edge for y in edge] + [int(v) for v in rng.integers(0, 1 << 64, 4096, dtype=np.uint64)]
+    # a block of all-ones operands drives the accumulator's wrap counters
+    a += [(1 << 64) - 1] * 8
+    b += [(1 << 64) - 1] * 8
+    n = len(a)
+    av, bv = np.array(a, dtype=np.uint64), np.array(b, dtype=np.uint64)
+    out = to_host(bpg.ops.field_ops(to_dev(av), to_dev(bv)))
+    got = [[int(v) for v in row] for row in out]
+    for i in range(n):
+        x, y = a[i], b[i]
+        prod = x * y % P
+        assert got[0][i] == prod and got[1][i] == prod and got[2][i] == prod and got[3][i] == prod, (i, hex(x), hex(y))
+        assert got[4][i] == (x + y) % P and got[5][i] == (x - y) % P, (i, hex(x), hex(y))
+        y0 = b[i - i % 4]
+        assert got[6][i] == (2 * x * y + x * y0) % P, (i, hex(x), hex(y), hex(y0))
+        assert got[7][i] == 7 * x % P
+        assert got[8][i] == (pow(x % P, P - 2, P) if x % P else 0)
+        e0, e1, f0, f1 = x % P, y % P, y % P, (x ^ y) % P
+        assert got[9][i] == (e0 * f0 + 7 * e1 * f1) % P and got[10][i] == (e0 * f1 + e1 * f0) % P
+
+
 def test_poseidon_kat_and_random(bpg, oracle):
     rng = np.random.default_rng(7)
     states = rand_field(rng, (4099, 12))
