@@ -33,7 +33,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
 S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
-TRAFFIC_OVER_ALGORITHMIC = 1.37  # measured, see profiles/README.md
+TRAFFIC_OVER_ALGORITHMIC = 1.138  # PMC over this very leg: profiles/r1b_pmc_lde_family.txt
 
 
 def main():
@@ -121,8 +121,9 @@ def main():
         ach = by.value / (ms.value * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": "coset-LDE NTT family: ntt16_dit_kernel<12|13|14> + ntt_lds_kernel<DIT>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                # PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes, profiles/r1_pmc_*.csv): 1.37x algorithmic on
-                # the 2^14 x 2432 launch (each coset re-reads the coefficients); applied to the average launch
+                # HBM bytes per launch = algorithmic x the ratio that two rocprofv3 --pmc passes (FETCH_SIZE x2,
+                # WRITE_SIZE) of this same command measured over the launches of the single-stream leg
+                # (tools/pmc_family_traffic.py; the leg is bracketed by marker dispatches): 36.38 / 31.98 MB
                 "traffic": round(by.value / n.value * TRAFFIC_OVER_ALGORITHMIC),
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "alg_bytes_per_launch": round(by.value / n.value), "note": note}
@@ -139,11 +140,19 @@ def main():
             solo_driver = BlockDriver(solo, n_threads=1)
             irs = synthetic_block_irs(1000, 2, S1_LOG_N, S1_WIDTH)
             solo_driver.prove_shard(irs[:1])
+            # marker dispatches (one-word copies) bracket the leg so that a `rocprofv3 --pmc` pass of this
+            # same command can pick out exactly these launches (tools/pmc_family_traffic.py)
+            mark = torch.zeros(2, dtype=torch.int64, device="cuda")
+            L.bp_debug_copy_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+            L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
+            torch.cuda.synchronize()
             L.bp_profile_reset()
             L.bp_profile_enable(1)
             solo_driver.prove_shard(irs)
             torch.cuda.synchronize()
             L.bp_profile_enable(0)
+            L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
+            torch.cuda.synchronize()
             roofline = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one "
                                    "stream (no co-running kernels); all 29 proofs x 3 commitments x tables per txn")
             solo_driver.close()

@@ -171,42 +171,43 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
 template <int N>
 __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
   static_assert(N == 3 || N == 4, "groups of 3 or 4");
-  uint32_t a0[N], a1[N], b0[N], P0[N], P1[N], M0[N], M1[N], Q0[N], Q1[N];
-  uint64_t P[N], Mi[N], M[N], Q[N], U[N], T[N];
+  // every step overwrites one of its operands (gl_cc.inc): per element P, M, Q and one scratch word
+  uint32_t a1[N], b0[N], t0[N], t1[N], m0[N], m1[N], q0[N], q1[N], e[N];
+  uint64_t P[N], M[N], Q[N];
   cc::mask C[N], c1[N], c2[N], c3[N], c4[N], cx[N], bw[N], bw2[N], b3[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    a0[i] = (uint32_t)a[i]; a1[i] = (uint32_t)(a[i] >> 32); b0[i] = (uint32_t)b[i];
-    const uint32_t b1 = (uint32_t)(b[i] >> 32);
-    P[i] = (uint64_t)a0[i] * b0[i];
-    Mi[i] = (uint64_t)a0[i] * b1;
-    Q[i] = (uint64_t)a1[i] * b1;
+    const uint32_t a0 = (uint32_t)a[i], b1 = (uint32_t)(b[i] >> 32);
+    a1[i] = (uint32_t)(a[i] >> 32);
+    b0[i] = (uint32_t)b[i];
+    P[i] = (uint64_t)a0 * b0[i];
+    M[i] = (uint64_t)a0 * b1;
+    Q[i] = (uint64_t)a1[i] * b1;  // Q1 <= 2^32 - 2, so Q1 + C fits
   }
-  cc::mad_co(M, C, a1, b0, Mi);
+  cc::mad_co(M, C, a1, b0);  // M += a1*b0, carry C (weight 2^96 = -1)
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    P0[i] = (uint32_t)P[i]; P1[i] = (uint32_t)(P[i] >> 32); M0[i] = (uint32_t)M[i]; M1[i] = (uint32_t)(M[i] >> 32);
-    Q0[i] = (uint32_t)Q[i]; Q1[i] = (uint32_t)(Q[i] >> 32);
+    t0[i] = (uint32_t)P[i]; t1[i] = (uint32_t)(P[i] >> 32); m0[i] = (uint32_t)M[i]; m1[i] = (uint32_t)(M[i] >> 32);
+    q0[i] = (uint32_t)Q[i]; q1[i] = (uint32_t)(Q[i] >> 32);
   }
-  uint32_t p1[N], S[N], K[N], e[N], lo[N], hi[N], u0[N], u1[N], e2[N], r0[N], r1[N], T0[N], T1[N];
-  cc::add_co(p1, c1, P1, M0);
-  cc::addc_co(S, c2, M1, Q0, c1);
-  cc::addc0_co(K, cx, Q1, C);
+  cc::add_co(t1, c1, m0);        // U = (P0, P1 + M0)
+  cc::addc_co(m1, c2, q0, c1);   // S = M1 + Q0 + c1 (mod 2^32), carry c2
+  cc::addc0_co(q1, cx, C);       // K = Q1 + C
 #pragma unroll
-  for (int i = 0; i < N; i++) U[i] = cc::mk64(P0[i], p1[i]);
-  cc::mad_eps_co(T, c3, S, U);
+  for (int i = 0; i < N; i++) P[i] = cc::mk64(t0[i], t1[i]);
+  cc::mad_eps_co(P, c3, m1);     // T = U + S*EPS, carry c3 (weight 2^64 = EPS)
   cc::sel_eps(e, c3);
 #pragma unroll
-  for (int i = 0; i < N; i++) { T0[i] = (uint32_t)T[i]; T1[i] = (uint32_t)(T[i] >> 32); }
-  cc::add_co(lo, c4, T0, e);
-  cc::addc0_co(hi, cx, T1, c4);
-  cc::subb_co(u0, bw, lo, K, c2);
-  cc::subb0_co(u1, bw2, hi, bw);
-  cc::sel_eps(e2, bw2);
-  cc::sub_co(r0, b3, u0, e2);
-  cc::subb0_co(r1, cx, u1, b3);
+  for (int i = 0; i < N; i++) { t0[i] = (uint32_t)P[i]; t1[i] = (uint32_t)(P[i] >> 32); }
+  cc::add_co(t0, c4, e);         // T += c3 ? EPS : 0 (cannot wrap again)
+  cc::addc0_co(t1, cx, c4);
+  cc::subb_co(t0, bw, q1, c2);   // T -= K + c2
+  cc::subb0_co(t1, bw2, bw);
+  cc::sel_eps(e, bw2);           // on borrow the true value is 2^64 less: subtract EPS
+  cc::sub_co(t0, b3, e);
+  cc::subb0_co(t1, cx, b3);
 #pragma unroll
-  for (int i = 0; i < N; i++) r[i] = cc::mk64(r0[i], r1[i]);
+  for (int i = 0; i < N; i++) r[i] = cc::mk64(t0[i], t1[i]);
 }
 #endif
 #if defined(__HIP__)
@@ -220,18 +221,18 @@ struct DotAcc {
 __device__ __forceinline__ DotAcc dot_zero() { return DotAcc{0, 0, 0, 0, 0, 0}; }
 // acc[i] += a[i] * b[i] for four independent accumulators (instruction-interleaved, no s_nop)
 __device__ __forceinline__ void dot_mad4(DotAcc (&acc)[4], const uint64_t (&a)[4], const uint64_t (&b)[4]) {
-  uint32_t a0[4], a1[4], b0[4], b1[4], cnt[4], cn2[4];
-  uint64_t in[4], out[4];
+  uint32_t a0[4], a1[4], b0[4], b1[4], cnt[4];
+  uint64_t col[4];
   cc::mask c[4], cx[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     a0[i] = (uint32_t)a[i]; a1[i] = (uint32_t)(a[i] >> 32); b0[i] = (uint32_t)b[i]; b1[i] = (uint32_t)(b[i] >> 32);
   }
 #define BPG_DOT_COL(COL, CNT, X, Y)                                  \
-  _Pragma("unroll") for (int i = 0; i < 4; i++) { in[i] = acc[i].COL; cnt[i] = acc[i].CNT; } \
-  cc::mad_co(out, c, X, Y, in);                                       \
-  cc::addc0_co(cn2, cx, cnt, c);                                      \
-  _Pragma("unroll") for (int i = 0; i < 4; i++) { acc[i].COL = out[i]; acc[i].CNT = cn2[i]; }
+  _Pragma("unroll") for (int i = 0; i < 4; i++) { col[i] = acc[i].COL; cnt[i] = acc[i].CNT; } \
+  cc::mad_co(col, c, X, Y);                                           \
+  cc::addc0_co(cnt, cx, c);                                           \
+  _Pragma("unroll") for (int i = 0; i < 4; i++) { acc[i].COL = col[i]; acc[i].CNT = cnt[i]; }
   BPG_DOT_COL(p, cp, a0, b0)
   BPG_DOT_COL(m, cm, a0, b1)
   BPG_DOT_COL(m, cm, a1, b0)

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) perm_batch_kernel(uint64_t* __restrict__ 
 // One lane per LDE row.  Row `pos` = t*n + m (coset-major) is Merkle leaf bitrev_r(t)*n +
 // bitrev_n(m) (upstream reverse_index_bits order); the 32-byte digest is scattered there.
 // >= 5 waves per SIMD: the interleaved S-boxes otherwise balloon to ~190 VGPRs (2 waves), which exposes latency
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 leaf_hash_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
                  uint32_t rate_bits, uint64_t* __restrict__ digests) {
   const uint64_t rows = (uint64_t)1 << (log_n + rate_bits);
@@ -148,7 +148,7 @@ merkle_subtree_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restr
 
 // Row-major leaves (FRI layers): leaf k = leaf_len consecutive words.
 // >= 5 waves per SIMD: the interleaved S-boxes otherwise balloon to ~190 VGPRs (2 waves), which exposes latency
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 leaf_hash_rows_kernel(const uint64_t* __restrict__ leaves, uint32_t leaf_len, uint64_t n_leaves,
                       uint64_t* __restrict__ digests) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first

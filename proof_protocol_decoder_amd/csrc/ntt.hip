@@ -236,7 +236,7 @@ struct Ntt16Args {
   const uint64_t* tw;     // w_B^e, e < B/2, B = 2^L
   const uint64_t* scale;  // DIT: [coset][n_total] input scale, nullable
   uint64_t out_scalar;    // DIF: 1/n (1 = none)
-  uint32_t log_n_total, n_cosets, cosets_per_wg;
+  uint32_t log_n_total, n_cosets, n_units;  // n_units = columns * blocks per column (DIT grid mapping)
 };
 
 // natural -> bit-reversed.  grid = (blocks per column, columns)
@@ -295,74 +295,76 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
   }
 }
 
-// bit-reversed -> natural, optional per-coset input scale; one workgroup makes all cosets of its block.
+// bit-reversed -> natural, optional per-coset input scale.  One workgroup = one (column block, coset).
+// XCD-aware 1-D grid: the 2^r coset workgroups of a block all re-read the same 8*2^L coefficient
+// bytes, so they are given ids that agree modulo 8 and are adjacent in dispatch order: blocks are
+// dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, workgroup dispatch), which puts them on ONE
+// XCD at about the same time and lets its L2 serve all but the first read (PMC: fetched bytes drop
+// from 2^r x to ~1 x the coefficients).  id -> xcd = id % 8, k = id / 8, coset = k % n_cosets,
+// unit = (k / n_cosets) * 8 + xcd, unit = column * blocks_per_column + block.  A speed choice only.
 template <int L>
 __global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per_eu(4, 8))) ntt16_dit_kernel(Ntt16Args a) {
-  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr uint32_t T = (1u << L) / 16;
   constexpr int RT = (L % 4 == 0) ? 4 : (L % 4);  // stages of the outermost pass
-  const uint32_t t0 = threadIdx.x;
-  const uint64_t off = (uint64_t)blockIdx.x << L;
-  const uint64_t* src = a.in + blockIdx.y * a.in_stride + off;
-  // Coefficients are re-read per coset (the re-read is served on-die: this workgroup touched the
-  // same 8*2^L bytes microseconds earlier); keeping them in 32 more VGPRs spills at 1024 lanes.
+  const uint32_t id = blockIdx.x, k = id >> 3;
+  const uint32_t coset = k % a.n_cosets, unit = (k / a.n_cosets) * 8 + (id & 7);
+  if (unit >= a.n_units) return;  // padding of the last group of eight (whole workgroup leaves together)
+  const uint32_t log_bpc = a.log_n_total - L;  // blocks per column
+  const uint32_t col = unit >> log_bpc, blk = unit & ((1u << log_bpc) - 1);
+  const uint32_t t = threadIdx.x;
+  const uint64_t off = (uint64_t)blk << L;
+  const uint64_t* src = a.in + col * a.in_stride + off;
+  const uint64_t* tw = a.tw;
   uint64_t x[16];
-  const uint32_t coset0 = blockIdx.z * a.cosets_per_wg;
-#pragma unroll 1
-  for (uint32_t coset = coset0; coset < coset0 + a.cosets_per_wg; coset++) {
-    // the twiddles do not depend on the coset; keep the compiler from hoisting ~60 of them (120 VGPRs)
-    // out of this loop: re-reading them from L1 is cheaper than losing occupancy / spilling
-    const uint64_t* tw = a.tw;
-    asm volatile("" : "+s"(tw));
-    // same for the ~100 loop-invariant LDS/global addresses: recompute them per coset
-    uint32_t t = t0;
-    asm volatile("" : "+v"(t));
-    const uint32_t base = gl::bitrev(t, L - 4) << 4;
-    if (a.scale) {
-      const uint64_t* sc = a.scale + ((uint64_t)coset << a.log_n_total) + off;
+  const uint32_t base = gl::bitrev(t, L - 4) << 4;
+  if (a.scale) {
+    const uint64_t* sc = a.scale + ((uint64_t)coset << a.log_n_total) + off;
 #pragma unroll
-      for (int m0 = 0; m0 < 16; m0 += 4) {
-        uint64_t v[4], w[4], r[4];
+    for (int m0 = 0; m0 < 16; m0 += 4) {
+      uint64_t v[4], w[4], r[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          v[i] = src[(m0 + i) * T + t];
-          w[i] = sc[(m0 + i) * T + t];
-        }
-        gl::mul_n<4>(v, w, r);
-#pragma unroll
-        for (int i = 0; i < 4; i++) buf[swz<L>((m0 + i) * T + t)] = r[i];  // reduced, not canonical: fine as a butterfly input
+      for (int i = 0; i < 4; i++) {
+        v[i] = src[(m0 + i) * T + t];
+        w[i] = sc[(m0 + i) * T + t];
       }
-    } else {
+      gl::mul_n<4>(v, w, r);
 #pragma unroll
-      for (int m = 0; m < 16; m++) buf[swz<L>(m * T + t)] = src[m * T + t];
+      for (int i = 0; i < 4; i++) buf[swz<L>((m0 + i) * T + t)] = r[i];  // reduced, not canonical: fine as a butterfly input
     }
-    __syncthreads();
-    // innermost field [3:0]
+  } else {
 #pragma unroll
-    for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(base | m)];
-    dit_butterflies<4>(x, tw, 0, 0, L - 4);
-#pragma unroll
-    for (int m = 0; m < 16; m++) buf[swz<L>(base | m)] = x[m];
-    __syncthreads();
-#pragma unroll
-    for (int b = 4; b + 4 <= L - RT; b += 4) {
-#pragma unroll
-      for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(insert4(t, m, b))];
-      dit_butterflies<4>(x, tw, t & ((1u << b) - 1), b, L - (b + 4));
-#pragma unroll
-      for (int m = 0; m < 16; m++) buf[swz<L>(insert4(t, m, b))] = x[m];
-      __syncthreads();
-    }
-    // outermost field [L-1:L-4]: the top RT bits are still to do; lanes = low bits -> coalesced store
-#pragma unroll
-    for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(m * T + t)];
-    sub_butterflies<RT, 4 - RT, false, false>(x, tw, t, L - 4, L - RT, 0);
-    uint64_t* dst = a.out + blockIdx.y * a.out_stride + coset * a.out_coset_stride + off;
-#pragma unroll
-    for (int m = 0; m < 16; m++) dst[m * T + t] = gl::canon(x[m]);
-    __syncthreads();  // everyone has read buf before the next coset overwrites it
+    for (int m = 0; m < 16; m++) buf[swz<L>(m * T + t)] = src[m * T + t];
   }
+  __syncthreads();
+  // innermost field [3:0]
+#pragma unroll
+  for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(base | m)];
+  dit_butterflies<4>(x, tw, 0, 0, L - 4);
+#pragma unroll
+  for (int m = 0; m < 16; m++) buf[swz<L>(base | m)] = x[m];
+  __syncthreads();
+#pragma unroll
+  for (int b = 4; b + 4 <= L - RT; b += 4) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(insert4(t, m, b))];
+    dit_butterflies<4>(x, tw, t & ((1u << b) - 1), b, L - (b + 4));
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[swz<L>(insert4(t, m, b))] = x[m];
+    __syncthreads();
+  }
+  // outermost field [L-1:L-4]: the top RT bits are still to do; lanes = low bits -> coalesced store.
+  // These LDS addresses equal the ones of the first store; an opaque copy of t keeps the compiler from
+  // carrying them across the whole body (it spills them to scratch = extra HBM writes).
+  uint32_t t2 = t;
+  asm volatile("" : "+v"(t2));
+#pragma unroll
+  for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(m * T + t2)];
+  sub_butterflies<RT, 4 - RT, false, false>(x, tw, t2, L - 4, L - RT, 0);
+  uint64_t* dst = a.out + col * a.out_stride + coset * a.out_coset_stride + off;
+#pragma unroll
+  for (int m = 0; m < 16; m++) dst[m * T + t2] = gl::canon(x[m]);
 }
 
 // Strided global pass for columns taller than one LDS block: the top LOGR stages (DIF) or the
@@ -523,7 +525,7 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
     Ntt16Args b{};
     b.in = src; b.in_stride = src_stride; b.out = out; b.out_stride = out_stride; b.out_coset_stride = 0;
     b.tw = tw_b; b.scale = nullptr; b.out_scalar = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
-    b.log_n_total = log_n; b.n_cosets = 1; b.cosets_per_wg = 1;
+    b.log_n_total = log_n; b.n_cosets = 1; b.n_units = 0;
     dim3 grid16(1u << (log_n - log_blk), n_cols);
     KernelTimer kt(PROF_INTT_DIF, st, 16.0 * (double)n_cols * (double)((uint64_t)1 << log_n));
     if (log_blk == 12) ntt16_dif_kernel<12><<<grid16, 256, 8u << 12, st>>>(b);
@@ -561,11 +563,8 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
     Ntt16Args b{};
     b.in = in; b.in_stride = in_stride; b.out = out; b.out_stride = out_stride; b.out_coset_stride = coset_stride;
     b.tw = tw_b; b.scale = scale; b.out_scalar = 1; b.log_n_total = log_n; b.n_cosets = n_cosets;
-    // one workgroup makes every coset of its block (coefficients re-read on-die) unless that would
-    // leave the chip underfilled: then the cosets spread over grid.z
-    const uint64_t wgs = (uint64_t)n_cols << (log_n - log_blk);
-    b.cosets_per_wg = wgs >= 1024 ? n_cosets : 1;
-    dim3 grid16(1u << (log_n - log_blk), n_cols, n_cosets / b.cosets_per_wg);
+    b.n_units = n_cols << (log_n - log_blk);
+    const dim3 grid16((b.n_units + 7) / 8 * 8 * n_cosets);
     {
       KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
       if (log_blk == 12) ntt16_dit_kernel<12><<<grid16, 256, 8u << 12, st>>>(b);

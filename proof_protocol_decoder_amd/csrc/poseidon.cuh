@@ -46,25 +46,25 @@ __device__ __forceinline__ void sbox_all(uint64_t (&s)[12]) {
 // (L0, L1 + H0) + (H1 + carry)*EPS, then fold the multiply-add's carry-out.
 template <int N>
 __device__ __forceinline__ void reduce_rows(const uint64_t (&L)[N], const uint64_t (&H)[N], uint64_t (&out)[N]) {
-  uint32_t L0[N], L1[N], H0[N], H1[N], rh[N], top[N], e[N], T0[N], T1[N], lo[N], hi[N];
-  uint64_t U[N], T[N];
+  uint32_t l0[N], l1[N], h0[N], h1[N], e[N];
+  uint64_t T[N];
   gl::cc::mask c1[N], c3[N], c4[N], cx[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    L0[i] = (uint32_t)L[i]; L1[i] = (uint32_t)(L[i] >> 32); H0[i] = (uint32_t)H[i]; H1[i] = (uint32_t)(H[i] >> 32);
+    l0[i] = (uint32_t)L[i]; l1[i] = (uint32_t)(L[i] >> 32); h0[i] = (uint32_t)H[i]; h1[i] = (uint32_t)(H[i] >> 32);
   }
-  gl::cc::add_co(rh, c1, L1, H0);
-  gl::cc::addc0_co(top, cx, H1, c1);  // < 2^11
+  gl::cc::add_co(l1, c1, h0);
+  gl::cc::addc0_co(h1, cx, c1);  // top < 2^11
 #pragma unroll
-  for (int i = 0; i < N; i++) U[i] = gl::cc::mk64(L0[i], rh[i]);
-  gl::cc::mad_eps_co(T, c3, top, U);  // carry => T < 2^43, so folding it cannot wrap
+  for (int i = 0; i < N; i++) T[i] = gl::cc::mk64(l0[i], l1[i]);
+  gl::cc::mad_eps_co(T, c3, h1);  // carry => T < 2^43, so folding it cannot wrap
   gl::cc::sel_eps(e, c3);
 #pragma unroll
-  for (int i = 0; i < N; i++) { T0[i] = (uint32_t)T[i]; T1[i] = (uint32_t)(T[i] >> 32); }
-  gl::cc::add_co(lo, c4, T0, e);
-  gl::cc::addc0_co(hi, cx, T1, c4);
+  for (int i = 0; i < N; i++) { l0[i] = (uint32_t)T[i]; l1[i] = (uint32_t)(T[i] >> 32); }
+  gl::cc::add_co(l0, c4, e);
+  gl::cc::addc0_co(l1, cx, c4);
 #pragma unroll
-  for (int i = 0; i < N; i++) out[i] = gl::cc::mk64(lo[i], hi[i]);
+  for (int i = 0; i < N; i++) out[i] = gl::cc::mk64(l0[i], l1[i]);
 }
 
 // MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...).  Entries are < 2^6, so the
