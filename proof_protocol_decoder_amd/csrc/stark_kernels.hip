@@ -74,33 +74,62 @@ synth_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ consts
 
 // ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
 // z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
-// One workgroup per aux column: per-lane chunk products, LDS suffix scan, then the chunk itself.
+// One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
+// tile lane t owns the 8 consecutive elements [8t, 8t+8) (one 64-byte piece: a wave covers 4 KiB of
+// each input per tile, read and written once with 16-byte accesses), the per-lane products are
+// suffix-scanned through LDS and multiplied by the product of the tiles already done.
+// (The first version gave each lane one n/T-element chunk: lanes n/T*8 bytes apart, every access a
+// different cache line, 16x the algorithmic HBM reads on the 2^14..2^17-row tables by PMC.)
 __global__ void __launch_bounds__(1024)
 aux_suffix_product_kernel(const uint64_t* __restrict__ trace, uint64_t* __restrict__ aux, uint32_t log_n,
                           bpg::Ctl ctl) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   __shared__ uint64_t part[1024];
-  const uint32_t n = 1u << log_n, k = blockIdx.x, T = blockDim.x;
+  const uint32_t n = 1u << log_n, k = blockIdx.x, T = blockDim.x, t = threadIdx.x;
   const uint64_t *a = trace + (uint64_t)(8 * k) * n, *b = a + n;
   const uint64_t beta = ctl.v[2 * (k & 1)], gamma = ctl.v[2 * (k & 1) + 1];
   uint64_t* z = aux + (uint64_t)k * n;
-  const uint32_t chunk = (n + T - 1) / T, lo = threadIdx.x * chunk, hi = min(lo + chunk, n);
-  uint64_t p = 1;
-  for (uint32_t i = lo; i < hi; i++) p = gl::mulc(p, gl::addc(gl::addc(gamma, a[i]), gl::mulc(beta, b[i])));
-  part[threadIdx.x] = p;
-  __syncthreads();
-  // inclusive suffix scan over the per-lane products (Hillis-Steele)
-  for (uint32_t d = 1; d < T; d <<= 1) {
-    uint64_t v = part[threadIdx.x];
-    uint64_t o = threadIdx.x + d < T ? part[threadIdx.x + d] : 1;
+  // elements per lane per tile (n and T are powers of two; the launcher never uses fewer than 64
+  // lanes, so T may exceed n: the surplus lanes then hold the neutral element)
+  const uint32_t per0 = n >= 8 * T ? 8 : (n >= T ? n / T : 1);
+  const uint32_t tile = n >= T ? per0 * T : n;
+  const uint32_t per = t * per0 < tile ? per0 : 0;       // 0: this lane has no elements
+  uint64_t done = 1;                                     // product of every tile after the current one
+  for (uint32_t base = n; base > 0;) {
+    base -= tile;
+    const uint32_t lo = base + t * per0;
+    uint64_t f[8], p = 1;
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+      if ((uint32_t)j < per) {
+        f[j] = gl::addc(gl::addc(gamma, a[lo + j]), gl::mulc(beta, b[lo + j]));
+        p = gl::mulc(p, f[j]);
+      }
+    }
+    part[t] = p;
     __syncthreads();
-    part[threadIdx.x] = gl::mulc(v, o);
-    __syncthreads();
-  }
-  uint64_t carry = threadIdx.x + 1 < T ? part[threadIdx.x + 1] : 1;  // product of everything after my chunk
-  for (uint32_t i = hi; i-- > lo;) {
-    carry = gl::mulc(carry, gl::addc(gl::addc(gamma, a[i]), gl::mulc(beta, b[i])));
-    z[i] = carry;
+    // inclusive suffix scan over the per-lane products (Hillis-Steele)
+    for (uint32_t d = 1; d < T; d <<= 1) {
+      const uint64_t v = part[t];
+      const uint64_t o = t + d < T ? part[t + d] : 1;
+      __syncthreads();
+      part[t] = gl::mulc(v, o);
+      __syncthreads();
+    }
+    uint64_t carry = gl::mulc(t + 1 < T ? part[t + 1] : 1, done);  // everything after my piece
+    const uint64_t whole = part[0];
+    __syncthreads();  // part is rewritten by the next tile
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+      if ((uint32_t)j < per) {
+        carry = gl::mulc(carry, f[j]);
+        f[j] = carry;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if ((uint32_t)j < per) z[lo + j] = f[j];
+    done = gl::mulc(done, whole);
   }
 }
 
