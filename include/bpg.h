@@ -118,6 +118,10 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
+/* bp_stark_prove_synthetic keeps one worker (stream + device arena, up to ~100 GB for a 2^20 x 2432
+ * table) parked per device between calls, because re-allocating it costs more than the proof.
+ * This frees the parked workers. */
+void bp_release_cached_memory(void);
 void bp_free_buffer(uint8_t* buf);
 
 /* ------------------------------------------------------------------------------------------
