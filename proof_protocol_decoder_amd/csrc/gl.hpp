@@ -6,9 +6,11 @@
 // Representation: every value stored to memory is canonical (< p).  In registers a value is any
 // u64 congruent to the element ("reduced"), and each helper states what it needs and returns.
 //
-// CDNA4 notes: there is no 64x64 multiplier; a 64x64->128 product is four v_mad_u64_u32 (quarter
-// rate) and the Goldilocks reduction (2^64 = 2^32 - 1, 2^96 = -1) is ~10 full-rate VALU ops, so a
-// modular multiply is ~25-30 VALU issue slots.  No MFMA anywhere (integer field work).
+// CDNA4 notes: there is no 64x64 multiplier; a 64x64->128 product is four v_mad_u64_u32 (~1.25
+// issue slots each) and the Goldilocks reduction uses 2^64 = 2^32 - 1, 2^96 = -1.  The compiler's
+// rendering of mul_wide + reduce128 is 25 VALU instructions; the device forms below (namespace cc,
+// mul, mul_n, DotAcc) keep the carries as explicit SGPR masks and need 17.
+// No MFMA anywhere (integer field work).
 #pragma once
 #include <cstdint>
 #include <hip/hip_runtime.h>
