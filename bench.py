@@ -128,7 +128,22 @@ def main():
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "alg_bytes_per_launch": round(by.value / n.value), "note": note}
 
-    roofline_in_situ = roofline = None
+    def read_leaf_hash():
+        # the integer-ALU-bound family (report Gperm/s, claim no HBM fraction)
+        n, ms, perms = C.c_uint64(), C.c_double(), C.c_double()
+        pkg._lib.check(L.bp_profile_read(2, C.byref(n), C.byref(ms), C.byref(perms)))
+        if not n.value:
+            return None
+        rate = perms.value / (ms.value * 1e-3) / 1e9
+        return {"kernel": "Merkle leaf hashing: leaf_hash_kernel + leaf_hash_quad_kernel (Poseidon, width 12)",
+                "bound": "int-ALU (VALU issue)", "achieved": round(rate, 3), "unit": "Gperm/s",
+                # 21.2 k VALU instructions per permutation (static count) against
+                # 256 CUs x 4 SIMD16 x 2.4 GHz: the fraction of the chip's VALU issue slots this family used
+                "valu_issue_frac": round(rate * 1e9 * 21.2e3 / (256 * 64 * 2.4e9), 3),
+                "peak_measured": 1.88, "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                "perms_per_launch": round(perms.value / n.value)}
+
+    roofline_in_situ = roofline = alu_kernel = None
     if not args.no_profile:
         roofline_in_situ = read_family("HIP events around every launch in the timed region; %d prover streams share "
                                        "the chip, mostly with integer-ALU-bound Poseidon kernels, so a launch's "
@@ -155,6 +170,7 @@ def main():
             torch.cuda.synchronize()
             roofline = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one "
                                    "stream (no co-running kernels); all 29 proofs x 3 commitments x tables per txn")
+            alu_kernel = read_leaf_hash()
             solo_driver.close()
             solo.close()
 
@@ -173,7 +189,7 @@ def main():
                        "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
                        "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
                        "state_build_s": round(t_build, 2), "state_device_gib": round(state.device_bytes / 2**30, 2)},
-            "roofline": roofline, "roofline_in_situ": roofline_in_situ,
+            "roofline": roofline, "roofline_in_situ": roofline_in_situ, "alu_kernel": alu_kernel,
         }
         if world == 1:
             out["roofline_isolated"] = isolated_roofline(pkg, torch)

@@ -221,9 +221,10 @@ void bp_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
 /* state root after one synthetic txn (host-side helper for building a chain of IRs) */
 int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]);
 
-/* Optional HIP-event timing of the NTT kernel families on their own streams (bench.py roofline leg).
- * family 0: LDE coset NTT (LDS-resident DIT), 1: inverse NTT (DIF).  total_alg_bytes uses the
- * algorithmic byte counts of SURVEY.md section 8(d). */
+/* Optional HIP-event timing of kernel families on their own streams (bench.py roofline leg).
+ * family 0: LDE coset NTT (LDS-resident DIT), 1: inverse NTT (DIF); total_alg_bytes uses the
+ * algorithmic byte counts of SURVEY.md section 8(d).  family 2: Merkle leaf hashing (integer-ALU
+ * bound): the third output counts Poseidon PERMUTATIONS instead of bytes. */
 void bp_profile_enable(int on);
 void bp_profile_reset(void);
 int bp_profile_read(int family, uint64_t* launches, double* total_ms, double* total_alg_bytes);

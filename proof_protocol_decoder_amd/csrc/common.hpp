@@ -23,7 +23,7 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
 // Optional per-kernel-family HIP-event timing (bench.py's roofline leg).  Off by default: when off the
 // guard is two branches.  Families: 0 = LDE coset NTT (DIT, LDS-resident), 1 = inverse NTT (DIF).
-enum { PROF_LDE_DIT = 0, PROF_INTT_DIF = 1, PROF_FAMILIES = 2 };
+enum { PROF_LDE_DIT = 0, PROF_INTT_DIF = 1, PROF_LEAF_HASH = 2, PROF_FAMILIES = 3 };  // family 2 counts permutations, not bytes
 bool profile_on();
 struct KernelTimer {
   KernelTimer(int family, hipStream_t st, double alg_bytes);

@@ -364,11 +364,15 @@ int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_co
                 "bp_merkle_commit: bad shape (log_n=%u rate_bits=%u cap_height=%u n_cols=%u stride=%llu)", log_n,
                 rate_bits, cap_height, n_cols, (unsigned long long)lde_stride);
   uint64_t rows = (uint64_t)1 << log_leaves;
-  if (rows < quad_threshold())
-    leaf_hash_quad_kernel<<<ceil_div(rows * 4, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
-                                                                 d_digests);
-  else
-    leaf_hash_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests);
+  {
+    // integer-ALU-bound family: the "bytes" slot of the profiler carries permutations
+    KernelTimer kt(PROF_LEAF_HASH, st, n_cols > 4 ? (double)rows * (double)((n_cols + 7) / 8) : 0.0);
+    if (rows < quad_threshold())
+      leaf_hash_quad_kernel<<<ceil_div(rows * 4, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
+                                                                   d_digests);
+    else
+      leaf_hash_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests);
+  }
   BPG_LAUNCH_CHECK();
   return merkle_upper_levels(d_digests, log_leaves, cap_height, st, mirror, mirrored);
 }
