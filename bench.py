@@ -42,9 +42,14 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--txns", type=int, default=256, help="transactions per block")
-    ap.add_argument("--threads", type=int, default=16, help="concurrent provers (HIP streams) per GPU")
+    ap.add_argument("--threads", type=int, default=0,
+                    help="concurrent provers (HIP streams) per GPU; 0 = min(24, half this rank's txns): measured "
+                         "optimum (profiles/README.md), the waits sleep so the count is not tied to host cores")
+    ap.add_argument("--spin-wait", action="store_true", help="leave HIP's default spinning host waits (for comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline leg)")
+    ap.add_argument("--no-in-situ-profile", action="store_true",
+                    help="do not time the LDE launches inside the timed region (pooled HIP events: no measurable cost)")
     ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
     ap.add_argument("--merkle-fused", type=int, default=None, help="0: one launch per Merkle level")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
@@ -60,9 +65,16 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     # BPG_SHARE_GPU=1 is a rehearsal mode for a 1-GPU box: all ranks use device 0 and the gather runs
     # over gloo (RCCL needs one device per rank).  The driver's real runs never set it.
+    if args.threads <= 0:
+        shard = (args.txns + world - 1) // world
+        args.threads = max(4, min(24, (shard + 1) // 2))
     share = os.environ.get("BPG_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    # host waits must sleep, not spin (tools/wait_probe.hip): set before torch creates the device context
+    import proof_protocol_decoder_amd as _pkg0
+    if not args.spin_wait:
+        _pkg0.lib().bp_use_blocking_sync(local_rank)
     torch.cuda.set_device(local_rank)
     if world > 1:
         if share:
@@ -79,39 +91,6 @@ def main():
         L.bp_tune_merkle_fused(args.merkle_fused)
     if args.quad_threshold_log2 is not None:
         L.bp_tune_quad_threshold(1 << args.quad_threshold_log2)
-
-    t_build = time.time()
-    # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
-    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads,
-                                         arena_bytes=int(args.arena_gib * 2**30)).build()
-    t_build = time.time() - t_build
-    driver = BlockDriver(state, n_threads=args.threads)
-    gather = TorchGather(torch.device("cpu") if share else torch.device("cuda", local_rank)) if world > 1 else None
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    blocks = [synthetic_block_irs(b, args.txns, S1_LOG_N, S1_WIDTH) for b in range(args.warmup + args.steps)]
-    last = None
-    for b in range(args.warmup):
-        last = driver.prove_block_distributed(blocks[b], rank, world, gather)
-    if not args.no_profile:
-        L.bp_profile_reset()
-        L.bp_profile_enable(1)
-    barrier()
-    t0 = time.perf_counter()
-    for b in range(args.warmup, args.warmup + args.steps):
-        last = driver.prove_block_distributed(blocks[b], rank, world, gather)
-    barrier()
-    dt = time.perf_counter() - t0
-    L.bp_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     def read_family(note):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
@@ -143,36 +122,73 @@ def main():
                 "peak_measured": 1.88, "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "perms_per_launch": round(perms.value / n.value)}
 
-    roofline_in_situ = roofline = alu_kernel = None
-    if not args.no_profile:
+    # ---- roofline leg (rank 0), BEFORE the block run: the same workload with ONE prover stream on a fresh
+    # device, so every launch of the kernel has the chip to itself and event time == kernel time (this is what
+    # the rocprof summary in profiles/ is taken from).  Measured after the 24-stream region the same leg read
+    # anything from 1x to 0.5x of this figure.
+    roofline = alu_kernel = None
+    if not args.no_profile and rank == 0:
+        solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=5 << 30).build()
+        solo_driver = BlockDriver(solo, n_threads=1)
+        irs = synthetic_block_irs(1000, 2, S1_LOG_N, S1_WIDTH)
+        solo_driver.prove_shard(irs[:1])
+        # marker dispatches (one-word copies) bracket the leg so that a `rocprofv3 --pmc` pass of this
+        # same command can pick out exactly these launches (tools/pmc_family_traffic.py)
+        mark = torch.zeros(2, dtype=torch.int64, device="cuda")
+        L.bp_debug_copy_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
+        torch.cuda.synchronize()
+        L.bp_profile_reset()
+        L.bp_profile_enable(1)
+        solo_driver.prove_shard(irs)
+        torch.cuda.synchronize()
+        L.bp_profile_enable(0)
+        L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
+        torch.cuda.synchronize()
+        roofline = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one "
+                               "stream (no co-running kernels); all 29 proofs x 3 commitments x tables per txn")
+        alu_kernel = read_leaf_hash()
+        solo_driver.close()
+        solo.close()
+
+    t_build = time.time()
+    # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
+    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads,
+                                         arena_bytes=int(args.arena_gib * 2**30)).build()
+    t_build = time.time() - t_build
+    driver = BlockDriver(state, n_threads=args.threads)
+    gather = TorchGather(torch.device("cpu") if share else torch.device("cuda", local_rank)) if world > 1 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    blocks = [synthetic_block_irs(b, args.txns, S1_LOG_N, S1_WIDTH) for b in range(args.warmup + args.steps)]
+    last = None
+    for b in range(args.warmup):
+        last = driver.prove_block_distributed(blocks[b], rank, world, gather)
+    if not args.no_profile and not args.no_in_situ_profile:
+        L.bp_profile_reset()
+        L.bp_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for b in range(args.warmup, args.warmup + args.steps):
+        last = driver.prove_block_distributed(blocks[b], rank, world, gather)
+    barrier()
+    dt = time.perf_counter() - t0
+    L.bp_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline_in_situ = None
+    if not args.no_profile and not args.no_in_situ_profile:
         roofline_in_situ = read_family("HIP events around every launch in the timed region; %d prover streams share "
                                        "the chip, mostly with integer-ALU-bound Poseidon kernels, so a launch's "
                                        "duration is not the kernel's own cost" % args.threads)
-        if rank == 0:
-            # the same workload with ONE prover stream: every launch of the kernel has the chip to itself, so
-            # event time == kernel time (this is what the rocprof summary in profiles/ is taken from)
-            solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=5 << 30).build()
-            solo_driver = BlockDriver(solo, n_threads=1)
-            irs = synthetic_block_irs(1000, 2, S1_LOG_N, S1_WIDTH)
-            solo_driver.prove_shard(irs[:1])
-            # marker dispatches (one-word copies) bracket the leg so that a `rocprofv3 --pmc` pass of this
-            # same command can pick out exactly these launches (tools/pmc_family_traffic.py)
-            mark = torch.zeros(2, dtype=torch.int64, device="cuda")
-            L.bp_debug_copy_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-            L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
-            torch.cuda.synchronize()
-            L.bp_profile_reset()
-            L.bp_profile_enable(1)
-            solo_driver.prove_shard(irs)
-            torch.cuda.synchronize()
-            L.bp_profile_enable(0)
-            L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
-            torch.cuda.synchronize()
-            roofline = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one "
-                                   "stream (no co-running kernels); all 29 proofs x 3 commitments x tables per txn")
-            alu_kernel = read_leaf_hash()
-            solo_driver.close()
-            solo.close()
 
     if rank == 0:
         # acceptance: the block proof verifies (VerifierState::verify, verifier_state.rs:56-71)

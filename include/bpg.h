@@ -46,6 +46,11 @@ const char* bp_last_error(void);
 const char* bp_version(void);
 /* number of visible HIP devices; negative on error.  Does not initialise a context. */
 int bp_device_count(void);
+/* Makes host threads SLEEP while they wait for this device (hipDeviceScheduleBlockingSync) instead of
+ * spinning; call it once per process before proving (bp_state_build does, but a process that has
+ * already created the device context through another library should call it first thing).  A prover
+ * stream per host thread needs this to use more streams than the host has cores. */
+int bp_use_blocking_sync(int device);
 
 /* ------------------------------------------------------------------------------------------
  * L0 -- kernel-shaped operations on device buffers.

@@ -2,6 +2,7 @@
 // Error convention mirrors the reference's ProofGenError(String)
 // (plonky_block_proof_gen/src/proof_gen.rs:16-36): a status code plus a thread-local message.
 #include <atomic>
+#include <deque>
 #include <mutex>
 #include <vector>
 #include "common.hpp"
@@ -24,38 +25,90 @@ int fail(int code, const char* fmt, ...) {
 }
 
 // ---- kernel-family timing ----
+// HIP events around a launch, on the launch's own stream.  Events are pooled per host thread and
+// retired as soon as they have completed: creating two events per launch and keeping tens of
+// thousands outstanding until the read-out made the runtime crawl at 24 prover streams.
 namespace {
 struct Pending { hipEvent_t e0, e1; int family; double bytes; };
+struct FamilyStats { uint64_t launches = 0; double ms = 0, bytes = 0; };
+struct ThreadProf {
+  std::mutex mu;
+  std::deque<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  FamilyStats stats[PROF_FAMILIES];
+  // retire finished pairs from the front; with `wait` every pair
+  void retire(bool wait) {
+    while (!pending.empty()) {
+      Pending& p = pending.front();
+      if (wait ? hipEventSynchronize(p.e1) != hipSuccess : hipEventQuery(p.e1) != hipSuccess) {
+        if (!wait) return;
+      } else {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+          stats[p.family].launches++;
+          stats[p.family].ms += ms;
+          stats[p.family].bytes += p.bytes;
+        }
+      }
+      free_events.push_back(p.e0);
+      free_events.push_back(p.e1);
+      pending.pop_front();
+    }
+  }
+  hipEvent_t get() {
+    if (!free_events.empty()) {
+      hipEvent_t e = free_events.back();
+      free_events.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+  }
+};
 std::mutex g_prof_mu;
-std::vector<Pending> g_pending;
+std::vector<ThreadProf*> g_threads;  // never shrinks: prover threads are pooled for the life of a state
 std::atomic<bool> g_prof_on{false};
-struct FamilyStats { uint64_t launches = 0; double ms = 0, bytes = 0; } g_stats[PROF_FAMILIES];
+ThreadProf& thread_prof() {
+  thread_local ThreadProf* tp = nullptr;
+  if (!tp) {
+    tp = new ThreadProf();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_threads.push_back(tp);
+  }
+  return *tp;
+}
 }  // namespace
 bool profile_on() { return g_prof_on.load(std::memory_order_relaxed); }
 KernelTimer::KernelTimer(int f, hipStream_t s, double b) : family(f), st(s), bytes(b) {
   if (!profile_on()) return;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+  ThreadProf& tp = thread_prof();
+  std::lock_guard<std::mutex> lk(tp.mu);
+  e0 = tp.get();
+  e1 = tp.get();
+  if (!e0 || !e1) { e0 = e1 = nullptr; return; }
   (void)hipEventRecord(e0, st);
 }
 KernelTimer::~KernelTimer() {
   if (!e0) return;
   (void)hipEventRecord(e1, st);
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_pending.push_back(Pending{e0, e1, family, bytes});
+  ThreadProf& tp = thread_prof();
+  std::lock_guard<std::mutex> lk(tp.mu);
+  tp.pending.push_back(Pending{e0, e1, family, bytes});
+  if (tp.pending.size() >= 64) tp.retire(false);
 }
-static void profile_drain() {
+// everything recorded so far, summed over threads; `reset` also clears the sums
+static void profile_collect(FamilyStats (&out)[PROF_FAMILIES], bool reset) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (auto& p : g_pending) {
-    float ms = 0;
-    if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
-      g_stats[p.family].launches++;
-      g_stats[p.family].ms += ms;
-      g_stats[p.family].bytes += p.bytes;
+  for (ThreadProf* tp : g_threads) {
+    std::lock_guard<std::mutex> lk2(tp->mu);
+    tp->retire(true);
+    for (int f = 0; f < PROF_FAMILIES; f++) {
+      out[f].launches += tp->stats[f].launches;
+      out[f].ms += tp->stats[f].ms;
+      out[f].bytes += tp->stats[f].bytes;
+      if (reset) tp->stats[f] = FamilyStats();
     }
-    (void)hipEventDestroy(p.e0);
-    (void)hipEventDestroy(p.e1);
   }
-  g_pending.clear();
 }
 
 }  // namespace bpg
@@ -64,15 +117,16 @@ extern "C" {
 
 void bp_profile_enable(int on) { bpg::g_prof_on.store(on != 0); }
 void bp_profile_reset(void) {
-  bpg::profile_drain();
-  for (auto& s : bpg::g_stats) s = bpg::FamilyStats();
+  bpg::FamilyStats scratch[bpg::PROF_FAMILIES];
+  bpg::profile_collect(scratch, true);
 }
 int bp_profile_read(int family, uint64_t* launches, double* total_ms, double* total_alg_bytes) {
   if (family < 0 || family >= bpg::PROF_FAMILIES) return bpg::fail(BP_ERR_INVALID_INPUT, "unknown kernel family %d", family);
-  bpg::profile_drain();
-  if (launches) *launches = bpg::g_stats[family].launches;
-  if (total_ms) *total_ms = bpg::g_stats[family].ms;
-  if (total_alg_bytes) *total_alg_bytes = bpg::g_stats[family].bytes;
+  bpg::FamilyStats all[bpg::PROF_FAMILIES];
+  bpg::profile_collect(all, false);
+  if (launches) *launches = all[family].launches;
+  if (total_ms) *total_ms = all[family].ms;
+  if (total_alg_bytes) *total_alg_bytes = all[family].bytes;
   return BP_OK;
 }
 
@@ -87,6 +141,20 @@ int bp_device_count(void) {
     return bpg::fail(BP_ERR_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
   }
   return n;
+}
+
+int bp_use_blocking_sync(int device) {
+  // On this ROCm every host wait (hipStreamSynchronize, hipEventSynchronize -- even on an event made
+  // with hipEventBlockingSync) spins at 100 % of a core unless the device was given
+  // hipDeviceScheduleBlockingSync (tools/wait_probe.hip: 100 % -> 1 %).  With one prover thread per
+  // stream the spinning threads fill the box's cores and more streams than cores lose throughput.
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) return bpg::fail(BP_ERR_DEVICE, "hipSetDeviceFlags(blocking sync) on device %d: %s", device, hipGetErrorString(e));
+  return BP_OK;
 }
 
 }  // extern "C"

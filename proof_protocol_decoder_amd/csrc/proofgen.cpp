@@ -10,6 +10,7 @@
 #include "prover.hpp"
 
 using namespace bpg;
+extern "C" int bp_use_blocking_sync(int device);
 
 namespace {
 
@@ -212,6 +213,9 @@ int bp_state_build(const bp_config* cfg, bp_state** out) {
   int n_dev = bp_device_count();
   if (n_dev <= 0) return fail(BP_ERR_DEVICE, "no HIP device visible: the hot path has no CPU fallback");
   if (cfg->device < 0 || cfg->device >= n_dev) return fail(BP_ERR_DEVICE, "device %d not present", cfg->device);
+  // prover threads must sleep, not spin, while they wait (capi.cpp); a refusal (context configured by
+  // another library already) is not an error: the prover then works with spinning waits
+  (void)bp_use_blocking_sync(cfg->device);
   std::unique_ptr<bp_state> s(new bp_state());
   s->cfg = *cfg;
   s->rec_cfg = rc;
