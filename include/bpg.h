@@ -109,6 +109,34 @@ uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height);
 int bp_merkle_commit(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n,
                      uint32_t rate_bits, uint32_t cap_height, uint64_t* d_digests, void* stream);
 
+struct bp_stark_cfg;
+/* K5.  Constraint / quotient evaluation on the extended domain for the synthetic AIR:
+ * what plonky2_evm's compute_quotient_polys does for one table (reached from proof_gen.rs:44-52).
+ * shape: log_n, n_cols, n_const, deg_pow, rate_bits of the table (the other fields must make a valid
+ * configuration: use the values of the proof the quotient belongs to).  The three LDE matrices are
+ * column-major and coset-major with column stride n << rate_bits (d_aux_lde: n_cols/8 columns; d_const_lde may
+ * be NULL when n_const == 0).  ctl = beta0, gamma0, beta1, gamma1; alphas = the two constraint challenges.
+ * d_scratch: bp_quotient_scratch_words(shape) words.  d_qvals_out: [2][n << rate_bits], coset-major:
+ * position t*n + m = quotient value at 7 * w_{n 2^r}^(t + 2^r m), already divided by Z_H. */
+uint64_t bp_quotient_scratch_words(const struct bp_stark_cfg* shape);
+int bp_quotient_eval(const struct bp_stark_cfg* shape, const uint64_t* d_trace_lde, const uint64_t* d_aux_lde,
+                     const uint64_t* d_const_lde, const uint64_t ctl[4], const uint64_t alphas[2],
+                     uint64_t* d_scratch, uint64_t* d_qvals_out, void* stream);
+
+/* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
+ * folded domain), done in the evaluation domain.  d_values: the layer's n_l << rate_bits extension values
+ * (c0, c1 interleaved) on shift * <w_{n_l 2^r}>, coset-major (position t*n_l + m = point index t + 2^r m).
+ * d_out: the next layer, (n_l / 2^arity_bits) << rate_bits values on shift^(2^arity_bits) * <...>, same
+ * layout.  arity_bits must be 4 (ConstantArityBits(4, 5)). */
+int bp_fri_fold(const uint64_t* d_values, uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uint64_t shift,
+                const uint64_t beta[2], uint64_t* d_out, void* stream);
+
+/* K9.  Proof-of-work grind (plonky2 fri::prover::fri_proof_of_work): the SMALLEST nonce w such that the
+ * Poseidon permutation of `state` with word `pos` (a rate word, < 8) replaced by w has `bits` leading
+ * zero bits in output word 7.  Upstream accepts any witness; the minimum makes results reproducible.
+ * Synchronous: *nonce_out is valid on return. */
+int bp_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * L0.5 -- one table proof on the synthetic AIR: K2-K9 end to end.
  * This is what plonky2_evm's prove_single_table does for one STARK table (reached from

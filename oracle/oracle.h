@@ -79,6 +79,11 @@ void orc_synth_constants(uint64_t seed, unsigned log_n, size_t n_const, gl_t* co
 void orc_synth_trace(uint64_t seed, const orc_stark_cfg* c, const gl_t* consts, gl_t* trace);
 
 /* preprocessed constants commitment (ProverState analog, prover_state.rs:80-100) */
+/* K5: quotient values on the LDE coset in natural order; LDE matrices column-major with stride n << rate_bits
+ * (const_lde may be NULL when n_const == 0).  qv: [2][n << rate_bits]. */
+void orc_quotient_values(const orc_stark_cfg* c, const gl_t* const_lde, const gl_t* trace_lde, const gl_t* aux_lde,
+                         const gl_t ctl[4], gl_t alpha0, gl_t alpha1, gl_t* qv);
+
 typedef struct orc_committed orc_committed;
 orc_committed* orc_commit_values(const gl_t* values, unsigned log_n, size_t n_cols, unsigned rate_bits,
                                  unsigned cap_h);

@@ -98,6 +98,7 @@ def lib():
         getattr(L, name).restype = C.POINTER(C.c_uint64)
     L.orc_committed_free.argtypes = [vp]
     L.orc_stark_prove.argtypes = [cfgp, vp, vp, u64p, u64p, C.POINTER(Challenger), u64p]
+    L.orc_quotient_values.argtypes = [cfgp, vp, u64p, u64p, u64p, u6, u6, u64p]
     L.orc_stark_verify.argtypes = [cfgp, vp, u64p, C.POINTER(Challenger), u64p]
     L.orc_proof_digest.argtypes = [cfgp, u64p, u64p]
     L.orc_pg_state_build.argtypes = [C.POINTER(PgConfig)]
@@ -262,6 +263,16 @@ def synth_constants(seed, log_n, n_const):
 def synth_trace(seed, cfg, consts=None):
     out = np.empty((cfg.n_cols, 1 << cfg.log_n), dtype=np.uint64)
     lib().orc_synth_trace(seed, C.byref(cfg), consts.ctypes.data if consts is not None else None, out)
+    return out
+
+
+def quotient_values(cfg, const_lde, trace_lde, aux_lde, ctl, alpha0, alpha1):
+    """orc_quotient_values: natural-order LDE matrices [cols, n << rate_bits] -> [2, n << rate_bits]."""
+    t, a = arr(trace_lde), arr(aux_lde)
+    c = arr(const_lde) if const_lde is not None else None
+    out = np.empty((2, t.shape[1]), dtype=np.uint64)
+    lib().orc_quotient_values(C.byref(cfg), c.ctypes.data if c is not None else None, t, a,
+                              np.ascontiguousarray(ctl, dtype=np.uint64), int(alpha0), int(alpha1), out)
     return out
 
 

@@ -264,6 +264,44 @@ static gl_t pow_grind(const orc_challenger* ch, unsigned bits) {
 }
 
 /* ------------------------------------------------------------------ prover */
+/* Quotient values on the LDE coset (prover::compute_quotient_polys): for natural index i of the domain
+ * 7*<w_M>, row i of the three LDE matrices (column stride M = n << rate_bits) and row i + 2^rate_bits
+ * ("next"), all constraints folded with alpha0 / alpha1 and divided by Z_H.  qv: [2][M]. */
+void orc_quotient_values(const orc_stark_cfg* cf, const gl_t* const_lde, const gl_t* trace_lde, const gl_t* aux_lde,
+                         const gl_t ctl[4], gl_t alpha0, gl_t alpha1, gl_t* qv) {
+  const unsigned log_n = cf->log_n, r = cf->rate_bits, log_m = log_n + r;
+  const size_t N = (size_t)1 << log_n, M = N << r, C = cf->n_cols, K = cf->n_const, A = orc_cfg_n_aux(cf),
+               qdf = (size_t)1 << r;
+  {
+    gl_t wM = gl_root(log_m), g = gl_root(log_n), ginv = gl_inv(g), ninv = gl_inv((gl_t)N);
+    gl_t sN = gl_pow(GL_GENERATOR, N), wq = gl_root(r); /* x^N = 7^N * w_{2^r}^(i mod 2^r) */
+#pragma omp parallel
+    {
+      gl_t* row = (gl_t*)xmalloc((K + 2 * C + 2 * A + 1) * sizeof(gl_t));
+      gl_t *cst = row, *loc = cst + K, *nxt = loc + C, *ax = nxt + C, *axn = ax + A;
+#pragma omp for schedule(static)
+      for (size_t i = 0; i < M; i++) {
+        size_t in = (i + qdf) & (M - 1);
+        for (size_t c = 0; c < K; c++) cst[c] = const_lde[c * M + i];
+        for (size_t c = 0; c < C; c++) { loc[c] = trace_lde[c * M + i]; nxt[c] = trace_lde[c * M + in]; }
+        for (size_t c = 0; c < A; c++) { ax[c] = aux_lde[c * M + i]; axn[c] = aux_lde[c * M + in]; }
+        gl_t x = gl_mul(GL_GENERATOR, gl_pow(wM, i));
+        gl_t zh = gl_sub(gl_mul(sN, gl_pow(wq, i & (qdf - 1))), 1); /* x^N - 1, never 0 on the coset */
+        consumer_t k;
+        k.alpha[0] = alpha0; k.alpha[1] = alpha1; k.acc[0] = k.acc[1] = 0;
+        k.z_last = gl_sub(x, ginv);
+        k.l_first = gl_mul(gl_mul(zh, ninv), gl_inv(gl_sub(x, 1)));
+        k.l_last = gl_mul(gl_mul(zh, ninv), gl_inv(gl_sub(gl_mul(g, x), 1)));
+        eval_constraints_base(cf, cst, loc, nxt, ax, axn, ctl, &k);
+        gl_t zhi = gl_inv(zh);
+        qv[i] = gl_mul(k.acc[0], zhi);
+        qv[M + i] = gl_mul(k.acc[1], zhi);
+      }
+      free(row);
+    }
+  }
+}
+
 int orc_stark_prove(const orc_stark_cfg* cf, const orc_committed* consts, const orc_committed* trace,
                     const gl_t* tv, const gl_t ctl[4], orc_challenger* ch, gl_t* proof) {
   layout_t L = layout(cf);
@@ -299,34 +337,7 @@ int orc_stark_prove(const orc_stark_cfg* cf, const orc_committed* consts, const 
 
   /* 3. quotient values on the LDE coset, prover::compute_quotient_polys */
   gl_t* qv = (gl_t*)xmalloc(2 * M * sizeof(gl_t));
-  {
-    gl_t wM = gl_root(log_m), g = gl_root(log_n), ginv = gl_inv(g), ninv = gl_inv((gl_t)N);
-    gl_t sN = gl_pow(GL_GENERATOR, N), wq = gl_root(r); /* x^N = 7^N * w_{2^r}^(i mod 2^r) */
-#pragma omp parallel
-    {
-      gl_t* row = (gl_t*)xmalloc((K + 2 * C + 2 * A + 1) * sizeof(gl_t));
-      gl_t *cst = row, *loc = cst + K, *nxt = loc + C, *ax = nxt + C, *axn = ax + A;
-#pragma omp for schedule(static)
-      for (size_t i = 0; i < M; i++) {
-        size_t in = (i + qdf) & (M - 1);
-        for (size_t c = 0; c < K; c++) cst[c] = consts->lde[c * M + i];
-        for (size_t c = 0; c < C; c++) { loc[c] = trace->lde[c * M + i]; nxt[c] = trace->lde[c * M + in]; }
-        for (size_t c = 0; c < A; c++) { ax[c] = aux->lde[c * M + i]; axn[c] = aux->lde[c * M + in]; }
-        gl_t x = gl_mul(GL_GENERATOR, gl_pow(wM, i));
-        gl_t zh = gl_sub(gl_mul(sN, gl_pow(wq, i & (qdf - 1))), 1); /* x^N - 1, never 0 on the coset */
-        consumer_t k;
-        k.alpha[0] = alpha0; k.alpha[1] = alpha1; k.acc[0] = k.acc[1] = 0;
-        k.z_last = gl_sub(x, ginv);
-        k.l_first = gl_mul(gl_mul(zh, ninv), gl_inv(gl_sub(x, 1)));
-        k.l_last = gl_mul(gl_mul(zh, ninv), gl_inv(gl_sub(gl_mul(g, x), 1)));
-        eval_constraints_base(cf, cst, loc, nxt, ax, axn, ctl, &k);
-        gl_t zhi = gl_inv(zh);
-        qv[i] = gl_mul(k.acc[0], zhi);
-        qv[M + i] = gl_mul(k.acc[1], zhi);
-      }
-      free(row);
-    }
-  }
+  orc_quotient_values(cf, K ? consts->lde : NULL, trace->lde, aux->lde, ctl, alpha0, alpha1, qv);
   /* values on the coset -> coefficients (degree < qdf*N) -> qdf chunks of N per challenge */
   orc_coset_intt(qv, log_m, GL_GENERATOR);
   orc_coset_intt(qv + M, log_m, GL_GENERATOR);

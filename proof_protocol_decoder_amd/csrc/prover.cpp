@@ -215,6 +215,60 @@ int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uin
   return BP_OK;
 }
 
+// Everything of the quotient launch that follows from the table shape and the challenges (the caller
+// sets the three LDE pointers and the two output buffers).  Used by stark_prove and bp_quotient_eval.
+int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out, ChunkPows* cp) {
+  QuotArgs& qa = *out;
+  const uint32_t log_n = cfg.log_n, r = cfg.rate_bits, R = 1u << r, C = cfg.n_cols, K = cfg.n_const, A = C / 8;
+  const uint64_t N = (uint64_t)1 << log_n, M = N << r;
+  const uint64_t wM = gl::root(log_n + r), wN = gl::root(log_n);
+  qa.trace_stride = qa.aux_stride = qa.const_stride = M;
+  TRY(get_table(0, log_n, 0, &qa.tw_n));
+  qa.log_n = log_n; qa.rate_bits = r; qa.n_cols = C; qa.n_const = K; qa.n_aux = A; qa.deg_pow = cfg.deg_pow;
+  const uint32_t G = C / 4;
+  qa.groups_per_chunk = std::max<uint32_t>(8, (G + 47) / 48);
+  qa.n_group_chunks = (G + qa.groups_per_chunk - 1) / qa.groups_per_chunk;
+  qa.aux_per_chunk = std::max<uint32_t>(16, (A + 15) / 16);
+  qa.n_aux_chunks = (A + qa.aux_per_chunk - 1) / qa.aux_per_chunk;
+  qa.alpha0 = alpha0; qa.alpha1 = alpha1;
+  qa.g = wN; qa.g_inv = gl::inv(wN); qa.n_inv = gl::inv(N);
+  // per-coset constants: g_t = 7 * w_M^t, Z_H(g_t x) = g_t^n - 1 (constant on a coset)
+  for (uint32_t t = 0; t < R; t++) {
+    qa.g_t[t] = gl::mulc(gl::GENERATOR, gl::pow(wM, t));
+    qa.zh_t[t] = gl::subc(gl::pow(qa.g_t[t], N), 1);
+    qa.zh_inv_t[t] = gl::inv(qa.zh_t[t]);
+  }
+  qa.ctl = ctl;
+  const uint32_t n_chunks = qa.n_group_chunks + qa.n_aux_chunks;
+  if (2 * n_chunks > sizeof(cp->d_pows) / sizeof(cp->d_pows[0])) return fail(BP_ERR_UNSUPPORTED, "too many quotient chunks");
+  for (uint32_t c = 0; c < n_chunks; c++) {
+    uint32_t cnt;
+    if (c < qa.n_group_chunks) cnt = 3 * (std::min(G, (c + 1) * qa.groups_per_chunk) - c * qa.groups_per_chunk);
+    else {
+      uint32_t k = c - qa.n_group_chunks;
+      cnt = 2 * (std::min(A, (k + 1) * qa.aux_per_chunk) - k * qa.aux_per_chunk);
+    }
+    cp->d_pows[2 * c] = gl::pow(alpha0, cnt);
+    cp->d_pows[2 * c + 1] = gl::pow(alpha1, cnt);
+  }
+  return BP_OK;
+}
+
+// One FRI layer of n_l << r extension values on the domain shift * <w_{n_l 2^r}> (coset-major).
+int fri_layer_args(uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uint64_t shift, FriLayerArgs* out) {
+  FriLayerArgs& fa = *out;
+  const uint32_t R = 1u << rate_bits, arity = 1u << arity_bits;
+  if (arity_bits != 4) return fail(BP_ERR_UNSUPPORTED, "only arity_bits = 4 is built");
+  if (log_nl < arity_bits || rate_bits > 4) return fail(BP_ERR_INVALID_INPUT, "FRI layer too small or rate too high");
+  fa.log_nl = log_nl; fa.rate_bits = rate_bits; fa.arity_bits = arity_bits;
+  TRY(get_table(1, log_nl, 0, &fa.tw_nl_inv));
+  const uint64_t wMl = gl::root(log_nl + rate_bits), wa_inv = gl::inv(gl::root(arity_bits));
+  for (uint32_t t = 0; t < R; t++) fa.g_t_inv[t] = gl::inv(gl::mulc(shift, gl::pow(wMl, t)));
+  for (uint32_t k = 0; k < arity; k++) fa.wa_inv_pow[k] = gl::pow(wa_inv, k);
+  fa.arity_inv = gl::inv(arity);
+  return BP_OK;
+}
+
 // ------------------------------------------------------------------ one table
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
                 const uint64_t* d_tv, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof) {
@@ -259,32 +313,10 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
 
   // 3. quotient on the LDE coset -> per-coset iNTT -> chunk coefficients -> commitment
   QuotArgs qa{};
-  qa.trace_lde = trace.lde; qa.aux_lde = aux.lde; qa.const_lde = K ? consts->lde : nullptr;
-  qa.trace_stride = qa.aux_stride = qa.const_stride = M;
-  qa.tw_n = tw_n;
-  qa.log_n = log_n; qa.rate_bits = r; qa.n_cols = C; qa.n_const = K; qa.n_aux = A; qa.deg_pow = cfg.deg_pow;
-  const uint32_t G = C / 4;
-  qa.groups_per_chunk = std::max<uint32_t>(8, (G + 47) / 48);
-  qa.n_group_chunks = (G + qa.groups_per_chunk - 1) / qa.groups_per_chunk;
-  qa.aux_per_chunk = std::max<uint32_t>(16, (A + 15) / 16);
-  qa.n_aux_chunks = (A + qa.aux_per_chunk - 1) / qa.aux_per_chunk;
-  qa.alpha0 = alpha0; qa.alpha1 = alpha1;
-  qa.g = wN; qa.g_inv = gl::inv(wN); qa.n_inv = gl::inv(N);
-  std::memcpy(qa.g_t, g_t, sizeof(g_t)); std::memcpy(qa.zh_t, zh_t, sizeof(zh_t));
-  std::memcpy(qa.zh_inv_t, zh_inv_t, sizeof(zh_inv_t));
-  qa.ctl = ctl;
-  const uint32_t n_chunks = qa.n_group_chunks + qa.n_aux_chunks;
   ChunkPows cp{};
-  for (uint32_t c = 0; c < n_chunks; c++) {
-    uint32_t cnt;
-    if (c < qa.n_group_chunks) cnt = 3 * (std::min(G, (c + 1) * qa.groups_per_chunk) - c * qa.groups_per_chunk);
-    else {
-      uint32_t k = c - qa.n_group_chunks;
-      cnt = 2 * (std::min(A, (k + 1) * qa.aux_per_chunk) - k * qa.aux_per_chunk);
-    }
-    cp.d_pows[2 * c] = gl::pow(alpha0, cnt);
-    cp.d_pows[2 * c + 1] = gl::pow(alpha1, cnt);
-  }
+  qa.trace_lde = trace.lde; qa.aux_lde = aux.lde; qa.const_lde = K ? consts->lde : nullptr;
+  TRY(quotient_args(cfg, ctl, alpha0, alpha1, &qa, &cp));
+  const uint32_t n_chunks = qa.n_group_chunks + qa.n_aux_chunks;
   const size_t mark_q = w.arena.mark();
   ARENA_ALLOC(d_qc, (size_t)Q * N);  // chunk coefficients: live until the end (quotient oracle)
   const size_t mark_tmp = w.arena.mark();
@@ -414,13 +446,8 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
     ARENA_ALLOC(d_dig, dw);
     ARENA_ALLOC(d_next, (size_t)2 << log_leaves);
     FriLayerArgs fa{};
+    TRY(fri_layer_args(log_nl, r, ab, shift, &fa));
     fa.values = cur; fa.out = d_next; fa.digests = d_dig;
-    fa.log_nl = log_nl; fa.rate_bits = r; fa.arity_bits = ab;
-    TRY(get_table(1, log_nl, 0, &fa.tw_nl_inv));
-    const uint64_t wMl = gl::root(log_nl + r), wa_inv = gl::inv(gl::root(ab));
-    for (uint32_t t = 0; t < R; t++) fa.g_t_inv[t] = gl::inv(gl::mulc(shift, gl::pow(wMl, t)));
-    for (uint32_t k = 0; k < arity; k++) fa.wa_inv_pow[k] = gl::pow(wa_inv, k);
-    fa.arity_inv = gl::inv(arity);
     TRY(launch_fri_layer_leaves(fa, st));
     bool mirrored = false;
     TRY(merkle_upper_levels(d_dig, log_leaves, h, st, w.pinned_dev, &mirrored));

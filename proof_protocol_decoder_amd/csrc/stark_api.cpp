@@ -130,4 +130,87 @@ int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t co
   return rc;
 }
 
+// ---- L0: the remaining per-stage entry points of SURVEY.md section 8(b) -------------------------------
+
+static int quot_cfg(const bp_stark_cfg* shape, StarkCfg* c) {
+  if (!shape) return fail(BP_ERR_INVALID_INPUT, "null shape");
+  *c = StarkCfg{shape->log_n, shape->n_cols, shape->n_const, shape->deg_pow, shape->rate_bits, shape->cap_height,
+                shape->num_queries, shape->pow_bits, shape->arity_bits, shape->final_poly_bits};
+  return check_cfg(*c);
+}
+
+uint64_t bp_quotient_scratch_words(const bp_stark_cfg* shape) {
+  StarkCfg c;
+  if (quot_cfg(shape, &c)) return 0;
+  QuotArgs qa{};
+  ChunkPows cp{};
+  Ctl ctl{};
+  if (quotient_args(c, ctl, 1, 1, &qa, &cp)) return 0;
+  return (uint64_t)(qa.n_group_chunks + qa.n_aux_chunks) * 2 * (((uint64_t)1 << c.log_n) << c.rate_bits);
+}
+
+int bp_quotient_eval(const bp_stark_cfg* shape, const uint64_t* d_trace_lde, const uint64_t* d_aux_lde,
+                     const uint64_t* d_const_lde, const uint64_t ctl_in[4], const uint64_t alphas[2],
+                     uint64_t* d_scratch, uint64_t* d_qvals_out, void* stream) {
+  StarkCfg c;
+  int rc = quot_cfg(shape, &c);
+  if (rc) return rc;
+  if (!d_trace_lde || !d_aux_lde || (c.n_const && !d_const_lde) || !ctl_in || !alphas || !d_scratch || !d_qvals_out)
+    return fail(BP_ERR_INVALID_INPUT, "bp_quotient_eval: null argument");
+  for (int i = 0; i < 4; i++)
+    if (ctl_in[i] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_quotient_eval: non-canonical challenge");
+  if (alphas[0] >= gl::P || alphas[1] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_quotient_eval: non-canonical alpha");
+  if ((rc = init_ntt_kernels())) return rc;
+  Ctl ctl;
+  for (int i = 0; i < 4; i++) ctl.v[i] = ctl_in[i];
+  QuotArgs qa{};
+  ChunkPows cp{};
+  qa.trace_lde = d_trace_lde; qa.aux_lde = d_aux_lde; qa.const_lde = c.n_const ? d_const_lde : nullptr;
+  if ((rc = quotient_args(c, ctl, alphas[0], alphas[1], &qa, &cp))) return rc;
+  qa.partial = d_scratch; qa.qvals = d_qvals_out;
+  return launch_quotient(qa, cp, as_stream(stream));
+}
+
+int bp_fri_fold(const uint64_t* d_values, uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uint64_t shift,
+                const uint64_t beta[2], uint64_t* d_out, void* stream) {
+  if (!d_values || !d_out || !beta) return fail(BP_ERR_INVALID_INPUT, "bp_fri_fold: null argument");
+  if (shift == 0 || shift >= gl::P || beta[0] >= gl::P || beta[1] >= gl::P)
+    return fail(BP_ERR_INVALID_INPUT, "bp_fri_fold: non-canonical field element");
+  int rc = init_ntt_kernels();
+  if (rc) return rc;
+  FriLayerArgs fa{};
+  if ((rc = fri_layer_args(log_nl, rate_bits, arity_bits, shift, &fa))) return rc;
+  fa.values = d_values; fa.out = d_out; fa.digests = nullptr;
+  fa.beta = gl::Ext{beta[0], beta[1]};
+  return launch_fri_fold(fa, as_stream(stream));
+}
+
+int bp_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out, void* stream) {
+  if (!state || !nonce_out) return fail(BP_ERR_INVALID_INPUT, "bp_pow_grind: null argument");
+  if (pos >= 8 || bits == 0 || bits > 40) return fail(BP_ERR_INVALID_INPUT, "bp_pow_grind: pos must be a rate word, bits in 1..40");
+  hipStream_t st = as_stream(stream);
+  unsigned long long* d_res = nullptr;
+  BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_res), 8));
+  PowArgs pa{};
+  for (int i = 0; i < 12; i++) pa.state[i] = state[i];
+  pa.pos = pos; pa.bits = bits;
+  int rc = BP_OK;
+  unsigned long long res = ~0ULL;
+  if (hipMemsetAsync(d_res, 0xFF, 8, st) != hipSuccess) rc = fail(BP_ERR_DEVICE, "hipMemsetAsync failed");
+  uint32_t batch = std::min<uint32_t>(1u << 20, std::max<uint32_t>(1u << 12, 2u << bits));
+  for (uint64_t base = 0; rc == BP_OK; base += batch, batch = std::min<uint32_t>(1u << 20, batch * 2)) {
+    pa.base = base;
+    if ((rc = launch_pow(pa, batch, d_res, st))) break;
+    if (hipMemcpyAsync(&res, d_res, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      rc = fail(BP_ERR_DEVICE, "bp_pow_grind: copy back failed");
+      break;
+    }
+    if (res != ~0ULL) break;
+    if (base > ((uint64_t)1 << 44)) rc = fail(BP_ERR_DEVICE, "proof of work search exhausted");
+  }
+  (void)hipFree(d_res);
+  if (rc == BP_OK) *nonce_out = res;
+  return rc;
+}
+
 }  // extern "C"

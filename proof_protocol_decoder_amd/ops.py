@@ -60,6 +60,38 @@ def field_ops(a, b):
     return out
 
 
+def quotient_eval(cfg, trace_lde, aux_lde, const_lde, ctl, alphas):
+    """bp_quotient_eval: [2, n << rate_bits] quotient values (coset-major) of the synthetic AIR."""
+    _require_cuda(trace_lde)
+    _require_cuda(aux_lde)
+    if const_lde is not None:
+        _require_cuda(const_lde)
+    rows = trace_lde.shape[1]
+    scratch = torch.empty(int(lib().bp_quotient_scratch_words(C.byref(cfg))), dtype=torch.int64, device=trace_lde.device)
+    out = torch.empty((2, rows), dtype=torch.int64, device=trace_lde.device)
+    check(lib().bp_quotient_eval(C.byref(cfg), trace_lde.data_ptr(), aux_lde.data_ptr(),
+                                 const_lde.data_ptr() if const_lde is not None else None,
+                                 (C.c_uint64 * 4)(*[int(x) for x in ctl]), (C.c_uint64 * 2)(*[int(x) for x in alphas]),
+                                 scratch.data_ptr(), out.data_ptr(), _stream()))
+    return out
+
+
+def fri_fold(values, log_nl, rate_bits, shift, beta, arity_bits=4):
+    """bp_fri_fold: values [n_l << rate_bits, 2] (coset-major ext elements) -> next layer [(n_l >> 4) << rate_bits, 2]."""
+    _require_cuda(values)
+    out = torch.empty(((1 << (log_nl - arity_bits)) << rate_bits, 2), dtype=torch.int64, device=values.device)
+    check(lib().bp_fri_fold(values.data_ptr(), log_nl, rate_bits, arity_bits, int(shift),
+                            (C.c_uint64 * 2)(int(beta[0]), int(beta[1])), out.data_ptr(), _stream()))
+    return out
+
+
+def pow_grind(state, pos, bits):
+    """bp_pow_grind: smallest nonce for the 12-word sponge `state` (host ints) with `bits` leading zeros."""
+    nonce = C.c_uint64()
+    check(lib().bp_pow_grind((C.c_uint64 * 12)(*[int(x) for x in state]), pos, bits, C.byref(nonce), _stream()))
+    return nonce.value
+
+
 def merkle_commit(lde, log_n, rate_bits, cap_height):
     """Returns the level-order digest buffer [words/4, 4]; the last 2^cap_height rows are the cap."""
     _require_cuda(lde)

@@ -115,3 +115,62 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     bpg.lib().bp_tune_quad_threshold(1 << 15)
     assert (dig == want_dig).all()
     assert (dig[-(1 << cap_h):] == want_cap).all()
+
+
+# ---- the per-stage L0 entry points of SURVEY.md section 8(b): quotient, FRI fold, proof of work ----
+
+@pytest.mark.parametrize("log_n,n_cols,n_const,deg_pow,rate_bits", [(6, 16, 0, 1, 1), (9, 24, 0, 1, 1), (8, 19, 5, 3, 3),
+                                                                      (12, 136, 0, 1, 1), (10, 135, 7, 3, 3)])
+def test_quotient_eval_matches_oracle(bpg, oracle, log_n, n_cols, n_const, deg_pow, rate_bits):
+    """K5 alone: random LDE matrices (the constraints are evaluated on whatever is there), fixed challenges."""
+    rng = np.random.default_rng(300 + log_n)
+    n, rows = 1 << log_n, (1 << log_n) << rate_bits
+    trace = rand_field(rng, (n_cols, rows))
+    aux = rand_field(rng, (n_cols // 8, rows))
+    consts = rand_field(rng, (n_const, rows)) if n_const else None
+    ctl = rand_field(rng, (4,))
+    alphas = rand_field(rng, (2,))
+    want = oracle.quotient_values(oracle.make_cfg(log_n, n_cols, n_const=n_const, deg_pow=deg_pow, rate_bits=rate_bits),
+                                  consts, trace, aux, ctl, alphas[0], alphas[1])
+    # the device layout is coset-major: device position idx[i] holds natural point i
+    idx = coset_major_to_natural(log_n, rate_bits)
+
+    def to_cm(mat):
+        cm = np.empty_like(mat)
+        cm[:, idx] = mat
+        return to_dev(cm)
+    got = bpg.ops.quotient_eval(bpg.ops.stark_cfg(log_n, n_cols, n_const=n_const, deg_pow=deg_pow, rate_bits=rate_bits),
+                                to_cm(trace), to_cm(aux), to_cm(consts) if n_const else None, ctl, alphas)
+    assert (to_host(got)[:, idx] == want).all()
+
+
+@pytest.mark.parametrize("log_nl,rate_bits", [(4, 1), (6, 1), (9, 3), (13, 3), (16, 1)])
+def test_fri_fold_matches_oracle(bpg, oracle, log_nl, rate_bits):
+    """K6 alone: one arity-16 fold of random extension values, device coset-major vs oracle bit-reversed."""
+    rng = np.random.default_rng(400 + log_nl)
+    log_m = log_nl + rate_bits
+    m = 1 << log_m
+    vals = rand_field(rng, (m, 2))                      # natural order: index i <-> shift * w_m^i
+    beta = rand_field(rng, (2,))
+    shift = int(pow(7, 16, P))                          # a later layer's domain shift
+    br = bitrev_perm(log_m)
+    want_br = oracle.fri_fold(vals[br], 4, shift, beta)  # [m/16, 2] in bit-reversed order
+    idx = coset_major_to_natural(log_nl, rate_bits)       # coset-major position of each natural index
+    cm = np.empty_like(vals)
+    cm[idx] = vals
+    got = to_host(bpg.ops.fri_fold(to_dev(cm), log_nl, rate_bits, shift, beta))
+    nat = got[coset_major_to_natural(log_nl - 4, rate_bits)]   # natural order of the folded domain
+    assert (nat[bitrev_perm(log_m - 4)] == want_br).all()
+
+
+def test_pow_grind_smallest_witness(bpg, oracle):
+    """K9 alone: the smallest nonce, against an exhaustive search with the oracle's permutation."""
+    rng = np.random.default_rng(500)
+    for bits, pos in ((6, 0), (10, 3), (12, 7)):
+        state = rand_field(rng, (12,))
+        got = bpg.ops.pow_grind(state, pos, bits)
+        tries = np.tile(state, (got + 1, 1))
+        tries[:, pos] = np.arange(got + 1, dtype=np.uint64)
+        out = oracle.poseidon(tries)
+        ok = (out[:, 7] >> np.uint64(64 - bits)) == 0
+        assert ok[got] and not ok[:got].any()
