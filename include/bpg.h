@@ -131,6 +131,13 @@ int bp_quotient_eval(const struct bp_stark_cfg* shape, const uint64_t* d_trace_l
 int bp_fri_fold(const uint64_t* d_values, uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uint64_t shift,
                 const uint64_t beta[2], uint64_t* d_out, void* stream);
 
+/* K8.  Openings (plonky2_evm StarkOpeningSet::new / PolynomialBatch eval): every column polynomial of a
+ * bit-reversed coefficient matrix (as bp_lde_batch leaves it; column stride in words) evaluated at one
+ * or two extension-field points z0, z1 (z1 may be NULL).  d_pw_scratch: 4 << log_n words.
+ * d_out: 4 words per column = (p(z0).c0, p(z0).c1, p(z1).c0, p(z1).c1); the z1 pair is zero when z1 is NULL. */
+int bp_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, uint32_t n_cols, const uint64_t z0[2],
+                const uint64_t z1[2], uint64_t* d_pw_scratch, uint64_t* d_out, void* stream);
+
 /* K9.  Proof-of-work grind (plonky2 fri::prover::fri_proof_of_work): the SMALLEST nonce w such that the
  * Poseidon permutation of `state` with word `pos` (a rate word, < 8) replaced by w has `bits` leading
  * zero bits in output word 7.  Upstream accepts any witness; the minimum makes results reproducible.

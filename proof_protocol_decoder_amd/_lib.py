@@ -61,6 +61,7 @@ def lib():
     L.bp_quotient_scratch_words.restype = u64
     L.bp_quotient_eval.argtypes = [C.POINTER(StarkCfg), vp, vp, vp, C.POINTER(u64), C.POINTER(u64), vp, vp, vp]
     L.bp_fri_fold.argtypes = [vp, u32, u32, u32, u64, C.POINTER(u64), vp, vp]
+    L.bp_openings.argtypes = [vp, u64, u32, u32, C.POINTER(u64), C.POINTER(u64), vp, vp, vp]
     L.bp_pow_grind.argtypes = [C.POINTER(u64), u32, u32, C.POINTER(u64), vp]
     L.bp_merkle_digest_words.argtypes = [u32, u32]
     L.bp_merkle_digest_words.restype = u64

@@ -213,4 +213,19 @@ int bp_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t
   return rc;
 }
 
+int bp_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, uint32_t n_cols, const uint64_t z0[2],
+                const uint64_t z1[2], uint64_t* d_pw_scratch, uint64_t* d_out, void* stream) {
+  if (!n_cols) return BP_OK;
+  if (!d_coeffs || !z0 || !d_pw_scratch || !d_out) return fail(BP_ERR_INVALID_INPUT, "bp_openings: null argument");
+  if (log_n > 30 || stride < ((uint64_t)1 << log_n)) return fail(BP_ERR_INVALID_INPUT, "bp_openings: bad shape");
+  const uint64_t* zz[2] = {z0, z1 ? z1 : z0};
+  for (int k = 0; k < 2; k++)
+    if (zz[k][0] >= gl::P || zz[k][1] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_openings: non-canonical point");
+  hipStream_t st = as_stream(stream);
+  const uint32_t n_points = z1 ? 2 : 1;
+  int rc = launch_power_vectors(d_pw_scratch, log_n, gl::Ext{z0[0], z0[1]}, gl::Ext{zz[1][0], zz[1][1]}, n_points, st);
+  if (rc) return rc;
+  return launch_openings(d_coeffs, stride, log_n, n_cols, d_pw_scratch, n_points, d_out, st);
+}
+
 }  // extern "C"

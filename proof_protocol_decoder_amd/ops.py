@@ -85,6 +85,19 @@ def fri_fold(values, log_nl, rate_bits, shift, beta, arity_bits=4):
     return out
 
 
+def openings(coeffs, z0, z1=None):
+    """bp_openings: coeffs [n_cols, n] bit-reversed -> [n_cols, 4] = (p(z0), p(z1)) as extension pairs."""
+    _require_cuda(coeffs)
+    n_cols, n = coeffs.shape
+    pw = torch.empty(4 * n, dtype=torch.int64, device=coeffs.device)
+    out = torch.zeros((n_cols, 4), dtype=torch.int64, device=coeffs.device)
+    a0 = (C.c_uint64 * 2)(int(z0[0]), int(z0[1]))
+    a1 = (C.c_uint64 * 2)(int(z1[0]), int(z1[1])) if z1 is not None else None
+    check(lib().bp_openings(coeffs.data_ptr(), n, n.bit_length() - 1, n_cols, a0, a1, pw.data_ptr(), out.data_ptr(),
+                            _stream()))
+    return out
+
+
 def pow_grind(state, pos, bits):
     """bp_pow_grind: smallest nonce for the 12-word sponge `state` (host ints) with `bits` leading zeros."""
     nonce = C.c_uint64()

@@ -174,3 +174,25 @@ def test_pow_grind_smallest_witness(bpg, oracle):
         out = oracle.poseidon(tries)
         ok = (out[:, 7] >> np.uint64(64 - bits)) == 0
         assert ok[got] and not ok[:got].any()
+
+
+@pytest.mark.parametrize("log_n,n_cols", [(0, 2), (3, 3), (8, 5), (10, 2)])
+def test_openings_match_horner(bpg, log_n, n_cols):
+    """K8 alone: every column polynomial at two extension points, against Horner's rule on Python integers
+    in F_p[X]/(X^2 - 7)."""
+    rng = np.random.default_rng(600 + log_n)
+    n = 1 << log_n
+    coeffs = rand_field(rng, (n_cols, n))               # natural order
+    z0, z1 = rand_field(rng, (2,)), rand_field(rng, (2,))
+
+    def horner(c, z):
+        a0 = a1 = 0
+        for v in reversed([int(x) for x in c]):
+            a0, a1 = (a0 * z[0] + 7 * a1 * z[1] + v) % P, (a0 * z[1] + a1 * z[0]) % P
+        return a0, a1
+    got = to_host(bpg.ops.openings(to_dev(np.ascontiguousarray(coeffs[:, bitrev_perm(log_n)])), z0, z1))
+    for c in range(n_cols):
+        w0, w1 = horner(coeffs[c], [int(z0[0]), int(z0[1])]), horner(coeffs[c], [int(z1[0]), int(z1[1])])
+        assert tuple(int(v) for v in got[c]) == w0 + w1
+    one = to_host(bpg.ops.openings(to_dev(np.ascontiguousarray(coeffs[:, bitrev_perm(log_n)])), z0))
+    assert (one[:, :2] == got[:, :2]).all() and (one[:, 2:] == 0).all()
