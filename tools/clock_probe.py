@@ -1,3 +1,5 @@
+"""Kernel times right after a few seconds of saturating load (clock / power droop): the LDE and the Merkle
+commit are ~12 % slower for several seconds, which is why bench.py takes its single-stream roofline leg first."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch
