@@ -35,14 +35,14 @@ __global__ void __launch_bounds__(256) alu_kernel(uint64_t* out, uint64_t seed) 
       }
     }
     if (OP == 12) {  // 64-bit add as two VOP3B carry ops with SGPR-pair carries (4 interleaved)
-      uint32_t lo[4], hi[4], bl[4], rl[4], rh[4];
+      uint32_t lo[4], hi[4], bl[4];
       gl::cc::mask c[4], cx[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) { lo[k] = (uint32_t)a[k]; hi[k] = (uint32_t)(a[k] >> 32); bl[k] = (uint32_t)b; }
-      gl::cc::add_co(rl, c, lo, bl);
-      gl::cc::addc0_co(rh, cx, hi, c);
+      gl::cc::add_co(lo, c, bl);     // in place: lo += bl
+      gl::cc::addc0_co(hi, cx, c);   // hi += carry
 #pragma unroll
-      for (int k = 0; k < 4; k++) a[k] = gl::cc::mk64(rl[k], rh[k]);
+      for (int k = 0; k < 4; k++) a[k] = gl::cc::mk64(lo[k], hi[k]);
     }
     if (OP == 13) {  // v_cndmask_b32 x2 + v_cmp (compiler): select on a 64-bit compare
 #pragma unroll
