@@ -47,6 +47,35 @@ def test_table_proof_bit_exact(bpg, oracle, case):
     assert oracle.stark_verify(cfg, got, ctl, chv, const_cap) == 0
 
 
+def _random_cases(n, seed=20261004):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        e = int(rng.choice([1, 3]))
+        r = 1 if e == 1 else 3                      # quotient degree factor 2^r = 3*deg_pow - 1
+        log_n = int(rng.integers(6, 12))
+        C = int(rng.integers(8, 97))
+        K = int(rng.integers(0, 10))
+        nq = int(rng.integers(3, 40))
+        pb = int(rng.integers(3, 11))
+        out.append((log_n, C, K, e, r, nq, pb))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(14), ids=lambda c: "logn%d_C%d_K%d_e%d_q%d_p%d" % (c[0], c[1], c[2], c[3], c[5], c[6]))
+def test_random_shapes_bit_exact(bpg, oracle, case):
+    """Seeded sweep over ragged widths, constant counts, both constraint degrees, query counts and
+    proof-of-work difficulties: every proof word must equal the oracle's."""
+    log_n, C, K, e, r, nq, pb = case
+    seed, const_seed = 0xABCD000000000000 + 1000 * log_n + C, 9 + K
+    cfg, want, ctl, chv, const_cap = oracle_proof(oracle, case, seed, const_seed)
+    got = bpg.ops.stark_prove_synthetic(
+        bpg.ops.stark_cfg(log_n, C, n_const=K, deg_pow=e, rate_bits=r, num_queries=nq, pow_bits=pb), seed, const_seed)
+    bad = np.nonzero(got != want)[0]
+    assert got.shape == want.shape and bad.size == 0, "first mismatch at word %s of %d" % (bad[:1], want.size)
+    assert oracle.stark_verify(cfg, got, ctl, chv, const_cap) == 0
+
+
 def test_bad_shapes_are_rejected(bpg):
     from proof_protocol_decoder_amd import BpgError
     with pytest.raises(BpgError) as e:
