@@ -255,8 +255,17 @@ namespace bpg {
 int merkle_commit_cols(const uint64_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t*, hipStream_t, uint64_t*, bool*);
 
 // launches with fewer permutations than this use the quad-cooperative kernels (4x the waves)
-static std::atomic<uint64_t> g_quad_threshold{(uint64_t)1 << 15};
-uint64_t quad_threshold() { return g_quad_threshold.load(std::memory_order_relaxed); }
+// 0 = automatic: the quad form (4x the waves, 1.22x the instructions) pays while the chip is not full, so
+// the threshold follows the number of provers at work: few -> 2^17 (measured alone: quad wins up to there),
+// many -> 2^13 (under 24-stream load the instruction count decides; 2^11..2^13 measured best by ~1 %).
+static std::atomic<uint64_t> g_quad_threshold{0};
+static std::atomic<int> g_active_provers{0};
+void prover_active(int delta) { g_active_provers.fetch_add(delta, std::memory_order_relaxed); }
+uint64_t quad_threshold() {
+  const uint64_t t = g_quad_threshold.load(std::memory_order_relaxed);
+  if (t) return t;
+  return (uint64_t)1 << (g_active_provers.load(std::memory_order_relaxed) >= 6 ? 13 : 17);
+}
 static std::atomic<int> g_merkle_fused{0};  // measured: per-level launches are ~3% faster under 16-stream load
 
 // `mirror` (nullable): host-visible buffer that receives the 2^cap_height cap digests directly from

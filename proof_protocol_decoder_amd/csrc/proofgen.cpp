@@ -72,8 +72,10 @@ struct WorkerLease {
     w = s->idle.back();
     s->idle.pop_back();
     mark = w->arena.mark();
+    prover_active(+1);
   }
   ~WorkerLease() {
+    prover_active(-1);
     (void)hipStreamSynchronize(w->stream);
     w->arena.release(mark);
     w->abort_flag = nullptr;

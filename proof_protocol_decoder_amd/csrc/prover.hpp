@@ -125,6 +125,9 @@ int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uin
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
                 const uint64_t* d_trace_values, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof);
 
+// hash_kernels.hip: +1 / -1 as a prover starts / finishes (the Poseidon kernel choice follows the load)
+void prover_active(int delta);
+
 // launch-argument builders shared by the prover and the L0 entry points (stark_api.cpp)
 int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out, ChunkPows* cp);
 int fri_layer_args(uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uint64_t shift, FriLayerArgs* out);

@@ -104,7 +104,7 @@ def test_poseidon_noncanonical_inputs(bpg, oracle):
                                                           (6, 1, 13, 3)])
 def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap_h, quad):
     # both Poseidon kernel families (4 lanes per state with DPP exchange / one lane per state)
-    bpg.lib().bp_tune_quad_threshold((1 << 40) if quad else 0)
+    bpg.lib().bp_tune_quad_threshold((1 << 40) if quad else 1)  # 1: never quad; 0 would be automatic
     rng = np.random.default_rng(300 + log_n)
     rows = 1 << (log_n + rate_bits)
     lde_cm = rand_field(rng, (n_cols, rows))          # coset-major, as the LDE kernel writes it
@@ -112,7 +112,7 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     lde_nat = np.ascontiguousarray(lde_cm[:, idx])    # natural order for the oracle
     want_dig, want_cap = oracle.merkle_commit(lde_nat, cap_h, bitrev_rows=True)
     dig = to_host(bpg.ops.merkle_commit(to_dev(lde_cm), log_n, rate_bits, cap_h))
-    bpg.lib().bp_tune_quad_threshold(1 << 15)
+    bpg.lib().bp_tune_quad_threshold(0)  # back to automatic
     assert (dig == want_dig).all()
     assert (dig[-(1 << cap_h):] == want_cap).all()
 

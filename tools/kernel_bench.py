@@ -26,7 +26,7 @@ for name, log_n, C, r in shapes:
     t_intt = timeit(lambda: bpg.ops.ntt_batch_(v, bpg.ops.NTT_INV_NAT2BR))
     t_lde = timeit(lambda: bpg.ops.lde_batch(v, r))
     coeffs, lde = bpg.ops.lde_batch(v, r)
-    bpg.lib().bp_tune_quad_threshold(0)
+    bpg.lib().bp_tune_quad_threshold(1)  # 1: never quad (0 = automatic)
     t_mk = timeit(lambda: bpg.ops.merkle_commit(lde, log_n, r, 4))
     bpg.lib().bp_tune_quad_threshold(1 << 40)
     t_mq = timeit(lambda: bpg.ops.merkle_commit(lde, log_n, r, 4))
