@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline leg)")
     ap.add_argument("--no-in-situ-profile", action="store_true",
                     help="do not time the LDE launches inside the timed region (pooled HIP events: no measurable cost)")
+    ap.add_argument("--extra-workers", type=int, default=0,
+                    help="prover streams beyond --threads that idle until a txn can fan its seven recursion chains out "
+                         "to them (ends of shards, small blocks)")
     ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
     ap.add_argument("--merkle-fused", type=int, default=None, help="0: one launch per Merkle level")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
@@ -153,7 +156,7 @@ def main():
 
     t_build = time.time()
     # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
-    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads,
+    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads + args.extra_workers,
                                          arena_bytes=int(args.arena_gib * 2**30)).build()
     t_build = time.time() - t_build
     driver = BlockDriver(state, n_threads=args.threads)

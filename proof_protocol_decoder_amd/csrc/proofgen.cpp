@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include "prover.hpp"
 
 using namespace bpg;
@@ -75,6 +76,31 @@ struct WorkerLease {
     prover_active(+1);
   }
   ~WorkerLease() {
+    prover_active(-1);
+    (void)hipStreamSynchronize(w->stream);
+    w->arena.release(mark);
+    w->abort_flag = nullptr;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->idle.push_back(w);
+    s->cv.notify_one();
+  }
+};
+
+// A worker for a helper thread, only if one is idle right now (never waits).
+struct TryLease {
+  const bp_state* s;
+  Worker* w = nullptr;
+  size_t mark = 0;
+  explicit TryLease(const bp_state* st) : s(st) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->idle.empty()) return;
+    w = s->idle.back();
+    s->idle.pop_back();
+    mark = w->arena.mark();
+    prover_active(+1);
+  }
+  ~TryLease() {
+    if (!w) return;
     prover_active(-1);
     (void)hipStreamSynchronize(w->stream);
     w->arena.release(mark);
@@ -353,15 +379,53 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   }
   BPG_HIP(hipStreamSynchronize(w.stream));
   w.arena.release(lease.mark);  // traces are dead; the chains below only need digests
-  // per-table recursion-shaped chain (wrap + shrinks)
-  for (int t = 0; t < BP_NUM_TABLES; t++) {
+  // per-table recursion-shaped chains (wrap + shrinks).  The seven chains do not depend on each other:
+  // each one goes to a worker that is idle RIGHT NOW (end of a shard, small blocks, a lone txn), the rest
+  // run here.  Under full load no worker is idle and this is the plain sequential loop.
+  auto run_chain = [&](Worker& cw, int t) -> int {
     const Circuit& circ = s->table_circuits[s->table_offset[t] + (tcfg[t].log_n - cfg.table_log_lo[t])];
+    std::vector<uint64_t> chain_proof;
     for (uint32_t depth = 0; depth < cfg.shrink_depth; depth++) {
-      if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted in recursion chain of table %s", TABLE_NAMES[t]);
+      if (cw.aborted()) return fail(BP_ERR_ABORTED, "aborted in recursion chain of table %s", TABLE_NAMES[t]);
       std::vector<uint64_t> pi = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (uint64_t)t, depth};
-      if ((r = rec_prove(w, s->rec_cfg, circ, pi, proof))) return r;
-      proof_digest(s->rec_cfg, proof.data(), digest[t]);
+      int rc = rec_prove(cw, s->rec_cfg, circ, pi, chain_proof);
+      if (rc) return rc;
+      proof_digest(s->rec_cfg, chain_proof.data(), digest[t]);
     }
+    return BP_OK;
+  };
+  {
+    struct Helper { std::unique_ptr<TryLease> lease; std::thread th; int rc = BP_OK; std::string err; };
+    Helper helpers[BP_NUM_TABLES];
+    bool mine[BP_NUM_TABLES];
+    for (int t = 0; t < BP_NUM_TABLES; t++) {
+      mine[t] = true;
+      if (t == 0 || cfg.shrink_depth == 0) continue;  // this thread always has work of its own
+      std::unique_ptr<TryLease> l(new TryLease(s));
+      if (!l->w) continue;
+      mine[t] = false;
+      Helper& h = helpers[t];
+      h.lease = std::move(l);
+      h.lease->w->abort_flag = abort_flag;
+      h.th = std::thread([&, t] {
+        Helper& hh = helpers[t];
+        (void)hipSetDevice(cfg.device);
+        hh.rc = run_chain(*hh.lease->w, t);
+        if (hh.rc) hh.err = bp_last_error();
+      });
+    }
+    int first_rc = BP_OK;
+    std::string first_err;
+    for (int t = 0; t < BP_NUM_TABLES; t++)
+      if (mine[t] && first_rc == BP_OK && (first_rc = run_chain(w, t))) first_err = bp_last_error();
+    for (int t = 0; t < BP_NUM_TABLES; t++) {
+      Helper& h = helpers[t];
+      if (!h.th.joinable()) continue;
+      h.th.join();
+      h.lease.reset();
+      if (h.rc && first_rc == BP_OK) { first_rc = h.rc; first_err = h.err; }
+    }
+    if (first_rc) return fail(first_rc, "%s", first_err.c_str());
   }
   // root proof
   std::vector<uint64_t> pi;
