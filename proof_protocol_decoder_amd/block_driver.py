@@ -176,3 +176,37 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
         pg.check(L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out))
         root, gas = tuple(out), gas + 21000
     return irs
+
+
+def irs_from_block_trace(block_trace, block_number, table_log_n, table_width):
+    """Front door: a `trace_protocol.BlockTrace` payload -> the synthetic IRs of its transactions.
+
+    Mirrors the sequencing of `ProcessedBlockTrace::into_txn_proof_gen_ir` (protocol_decoder/src/decoding.rs:81-177):
+    transactions in payload order, `txn_number_before` = index, `gas_used_before/after` accumulated from
+    `TxnMeta.gas_used` (:122-124, :150-152), the state root threaded from one txn to the next (:129).  What the
+    reference derives with its MPT machinery is derived synthetically here: the chain starts at the
+    state root of the decoded compact witness (folded into four field elements) and each txn's witness seed is a
+    hash of its payload bytes.  The reference pads blocks of 0 or 1 transactions with dummy entries
+    (decoding.rs:304-347); the synthetic IR has no dummy form, so such blocks are refused.
+    """
+    import ctypes as C
+    from . import compact
+    if len(block_trace.txn_info) < 2:
+        raise ValueError("a block needs at least two transactions (the reference pads with dummy entries, "
+                         "decoding.rs:304-347; the synthetic IR has no dummy form)")
+    pre = block_trace.process_pre_images()
+    P = 0xFFFFFFFF00000001
+    root = tuple(int.from_bytes(pre.state_root[8 * i:8 * i + 8], "little") % P for i in range(4))
+    L = pg._bind()
+    L.bp_state_root_after.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    irs, gas = [], 0
+    for i, info in enumerate(block_trace.txn_info):
+        m = info.meta
+        digest = compact.keccak256(m.byte_code + m.new_txn_trie_node_byte + m.new_receipt_trie_node_byte)
+        seed = int.from_bytes(digest[:8], "little")
+        irs.append(pg.TxnProofGenIR(block_number, i, gas, gas + m.gas_used, root, seed, tuple(table_log_n),
+                                    tuple(table_width)))
+        out = (C.c_uint64 * 4)()
+        pg.check(L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out))
+        root, gas = tuple(out), gas + m.gas_used
+    return irs

@@ -155,3 +155,30 @@ def test_concurrent_callers_share_the_state(pg, p_state, o_state):
     again = pg.generate_txn_proof(p_state, irs[3])
     assert proofs[3].intern == again.intern                  # deterministic, independent of scheduling
     assert (words(proofs[5].intern) == o_state.txn(ir_words(9, 5, 0xABC005))).all()
+
+
+def test_block_trace_payload_to_block_proof(bpg, pg, p_state):
+    """The front door end to end: a trace_protocol JSON payload (combined compact pre-image = one of the
+    reference's golden witnesses, five transactions) -> IRs chained like decoding.rs:106-154 -> txn proofs,
+    aggregation tree, block proof -> VerifierState::verify."""
+    import json
+    import os
+    from proof_protocol_decoder_amd import trace_protocol as tp
+    from proof_protocol_decoder_amd.block_driver import BlockDriver, irs_from_block_trace
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compact_witness_vectors.json")))
+    txns = [{"traces": {"0x" + "%02x" % (17 + i) * 20: {"nonce": hex(i + 1)}},
+             "meta": {"byte_code": "0x%04x" % (0xf800 + i), "new_txn_trie_node_byte": "0x01", "new_receipt_trie_node_byte": "0x02",
+                      "gas_used": 21000 + i}} for i in range(5)]
+    bt = tp.BlockTrace.from_json({"trie_pre_images": {"combined": {"compact": "0x" + vec["complex"][2]["witness_hex"]}},
+                                  "txn_info": txns})
+    irs = irs_from_block_trace(bt, 9, LOG_N, WIDTH)
+    drv = BlockDriver(p_state, n_threads=2)
+    try:
+        blk = drv.prove_block_distributed(irs)
+    finally:
+        drv.close()
+    assert blk.b_height == 9
+    pg.VerifierState.from_prover_state(p_state).verify(blk)
+    pv, kind = pg.public_values_of(blk.intern)
+    assert kind == 2 and pv.txn_number_before == 0 and pv.txn_number_after == 5
+    assert pv.gas_used_after == sum(21000 + i for i in range(5)) and tuple(pv.state_root_before) == irs[0].state_root_before

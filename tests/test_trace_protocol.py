@@ -133,3 +133,38 @@ def test_malformed_payloads_are_errors(tp, mutate):
 def test_not_json(tp):
     with pytest.raises(tp.TraceProtocolError):
         tp.BlockTrace.from_json("{not json")
+
+
+def _block_payload(n_txns):
+    p = payload(VEC["complex"][1]["witness_hex"])
+    base = p["txn_info"][0]
+    p["txn_info"] = []
+    for i in range(n_txns):
+        t = json.loads(json.dumps(base))
+        t["meta"]["byte_code"] = "0x%04x" % (0xf800 + i)
+        t["meta"]["gas_used"] = 21000 + 1000 * i
+        p["txn_info"].append(t)
+    return p
+
+
+def test_irs_from_block_trace_chain_like_decoding_rs(tp):
+    """decoding.rs:106-154: txn_number_before = index, gas accumulates from TxnMeta.gas_used, each txn starts at
+    the state root the previous one ended on; the chain starts at the decoded witness's state root."""
+    from proof_protocol_decoder_amd.block_driver import irs_from_block_trace
+    bt = tp.BlockTrace.from_json(_block_payload(5))
+    irs = irs_from_block_trace(bt, 77, (6, 6, 6, 6, 6, 6, 6), (16, 16, 16, 16, 16, 16, 16))
+    assert [ir.txn_number_before for ir in irs] == [0, 1, 2, 3, 4] and all(ir.block_number == 77 for ir in irs)
+    gas = 0
+    for i, ir in enumerate(irs):
+        assert ir.gas_used_before == gas and ir.gas_used_after == gas + 21000 + 1000 * i
+        gas = ir.gas_used_after
+    root = bytes.fromhex(VEC["complex"][1]["state_root"])
+    P = 0xFFFFFFFF00000001
+    assert irs[0].state_root_before == tuple(int.from_bytes(root[8 * k:8 * k + 8], "little") % P for k in range(4))
+    assert len({ir.seed for ir in irs}) == 5 and len({ir.state_root_before for ir in irs}) == 5
+    # deterministic in the payload
+    again = irs_from_block_trace(tp.BlockTrace.from_json(_block_payload(5)), 77, (6,) * 7, (16,) * 7)
+    assert again == irs
+    for n in (0, 1):   # the reference pads these with dummy entries (decoding.rs:304-347); no synthetic dummy exists
+        with pytest.raises(ValueError, match="at least two"):
+            irs_from_block_trace(tp.BlockTrace.from_json(_block_payload(n)), 77, (6,) * 7, (16,) * 7)
