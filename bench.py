@@ -45,7 +45,6 @@ def main():
     ap.add_argument("--threads", type=int, default=0,
                     help="concurrent provers (HIP streams) per GPU; 0 = min(24, half this rank's txns): measured "
                          "optimum (profiles/README.md), the waits sleep so the count is not tied to host cores")
-    ap.add_argument("--spin-wait", action="store_true", help="leave HIP's default spinning host waits (for comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline leg)")
     ap.add_argument("--no-in-situ-profile", action="store_true",
@@ -76,8 +75,7 @@ def main():
         local_rank = 0
     # host waits must sleep, not spin (tools/wait_probe.hip): set before torch creates the device context
     import proof_protocol_decoder_amd as _pkg0
-    if not args.spin_wait:
-        _pkg0.lib().bp_use_blocking_sync(local_rank)
+    _pkg0.lib().bp_use_blocking_sync(local_rank)
     torch.cuda.set_device(local_rank)
     if world > 1:
         if share:
