@@ -407,12 +407,17 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
       Helper& h = helpers[t];
       h.lease = std::move(l);
       h.lease->w->abort_flag = abort_flag;
-      h.th = std::thread([&, t] {
-        Helper& hh = helpers[t];
-        (void)hipSetDevice(cfg.device);
-        hh.rc = run_chain(*hh.lease->w, t);
-        if (hh.rc) hh.err = bp_last_error();
-      });
+      try {
+        h.th = std::thread([&, t] {
+          Helper& hh = helpers[t];
+          (void)hipSetDevice(cfg.device);
+          hh.rc = run_chain(*hh.lease->w, t);
+          if (hh.rc) hh.err = bp_last_error();
+        });
+      } catch (...) {  // no thread to be had: the chain runs here like the others (nothing may throw across the ABI)
+        h.lease.reset();
+        mine[t] = true;
+      }
     }
     int first_rc = BP_OK;
     std::string first_err;
