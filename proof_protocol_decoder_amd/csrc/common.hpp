@@ -1,5 +1,6 @@
 // common.hpp -- error plumbing shared by the C-ABI translation units of libbpg.so.
 #pragma once
+#include <exception>
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
@@ -25,6 +26,12 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // guard is two branches.  Families: 0 = LDE coset NTT (DIT, LDS-resident), 1 = inverse NTT (DIF).
 enum { PROF_LDE_DIT = 0, PROF_INTT_DIF = 1, PROF_LEAF_HASH = 2, PROF_FAMILIES = 3 };  // family 2 counts permutations, not bytes
 bool profile_on();
+// Function-try-block tail of every allocating extern "C" entry: nothing may unwind across the C ABI
+// (include/bpg.h); an exception becomes BP_ERR_DEVICE with its message.
+#define BPG_ABI_CATCH(name)                                                                          \
+  catch (const std::exception& e) { return ::bpg::fail(BP_ERR_DEVICE, name ": %s", e.what()); }      \
+  catch (...) { return ::bpg::fail(BP_ERR_DEVICE, name ": unknown exception"); }
+
 struct KernelTimer {
   KernelTimer(int family, hipStream_t st, double alg_bytes);
   ~KernelTimer();

@@ -486,7 +486,7 @@ void bp_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
 // and the sizes of what was extracted.  Any pointer but `witness` may be NULL.
 int bp_compact_decode(const uint8_t* witness, size_t len, uint8_t* header_version, uint8_t state_root[32],
                       uint32_t* n_accounts, uint32_t* n_storage_tries, uint32_t* n_code,
-                      uint32_t* n_accounts_missing_storage) {
+                      uint32_t* n_accounts_missing_storage) try {
   if (!witness && len) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_compact_decode: null witness");
   uint8_t ver = 0;
   std::vector<Instr> ins;
@@ -510,10 +510,11 @@ int bp_compact_decode(const uint8_t* witness, size_t len, uint8_t* header_versio
   }
   return BP_OK;
 }
+BPG_ABI_CATCH("bp_compact_decode")
 
 // Instruction listing, one per line ("leaf <key nibbles hex> <value hex>", "branch <mask>", ...), for the
 // instruction-level KAT (compact_prestate_processing.rs:1471-1497).  Release with bp_free_buffer.
-int bp_compact_instructions(const uint8_t* witness, size_t len, uint8_t** text_out, size_t* text_len) {
+int bp_compact_instructions(const uint8_t* witness, size_t len, uint8_t** text_out, size_t* text_len) try {
   if ((!witness && len) || !text_out || !text_len) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_compact_instructions: null argument");
   uint8_t ver = 0;
   std::vector<Instr> ins;
@@ -548,5 +549,6 @@ int bp_compact_instructions(const uint8_t* witness, size_t len, uint8_t** text_o
   (*text_out)[s.size()] = 0;
   return BP_OK;
 }
+BPG_ABI_CATCH("bp_compact_instructions")
 
 }  // extern "C"

@@ -346,19 +346,21 @@ uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {
   return (((uint64_t)2 << log_leaves) - ((uint64_t)1 << cap_height)) * 4;
 }
 
-int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream) {
+int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream) try {
   if (!n) return BP_OK;
   if (!d_states) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_poseidon_perm_batch: null buffer");
   perm_batch_kernel<<<bpg::ceil_div(n, 256), 256, 0, bpg::as_stream(stream)>>>(d_states, n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+BPG_ABI_CATCH("bp_poseidon_perm_batch")
 
 int bp_merkle_commit(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n,
-                     uint32_t rate_bits, uint32_t cap_height, uint64_t* d_digests, void* stream) {
+                     uint32_t rate_bits, uint32_t cap_height, uint64_t* d_digests, void* stream) try {
   return bpg::merkle_commit_cols(d_lde, lde_stride, n_cols, log_n, rate_bits, cap_height, d_digests,
                                  bpg::as_stream(stream), nullptr, nullptr);
 }
+BPG_ABI_CATCH("bp_merkle_commit")
 
 }  // extern "C"
 

@@ -628,7 +628,7 @@ int init_ntt_kernels() {
 
 extern "C" {
 
-int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir, void* stream) {
+int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir, void* stream) try {
   if (n_cols == 0) return BP_OK;
   if (!d_cols) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_ntt_batch: null buffer");
   if (log_n > 30 || col_stride < ((uint64_t)1 << log_n))
@@ -652,10 +652,11 @@ int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col
       return bpg::fail(BP_ERR_INVALID_INPUT, "bp_ntt_batch: unknown dir %d", dir);
   }
 }
+BPG_ABI_CATCH("bp_ntt_batch")
 
 int bp_lde_batch(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_coeffs_out, uint64_t coeffs_stride,
                  uint64_t* d_lde_out, uint64_t lde_stride, uint32_t log_n, uint32_t rate_bits, uint32_t n_cols,
-                 int from_coeffs, void* stream) {
+                 int from_coeffs, void* stream) try {
   if (n_cols == 0) return BP_OK;
   const uint64_t n = (uint64_t)1 << log_n;
   if (!d_in || !d_lde_out || (!from_coeffs && !d_coeffs_out))
@@ -681,5 +682,6 @@ int bp_lde_batch(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_coeffs_ou
   return bpg::ntt_br2nat(coeffs, cstride, d_lde_out, lde_stride, n, log_n, n_cols, 1u << rate_bits, scale, false,
                          st);
 }
+BPG_ABI_CATCH("bp_lde_batch")
 
 }  // extern "C"

@@ -223,7 +223,7 @@ void bp_config_default(bp_config* c) {
   c->device = 0; c->n_workers = 4; c->arena_bytes = (uint64_t)6 << 30;
 }
 
-int bp_state_build(const bp_config* cfg, bp_state** out) {
+int bp_state_build(const bp_config* cfg, bp_state** out) try {
   if (!cfg || !out) return fail(BP_ERR_INVALID_INPUT, "bp_state_build: null argument");
   *out = nullptr;
   const StarkCfg rc = rec_cfg_of(*cfg);
@@ -270,6 +270,7 @@ int bp_state_build(const bp_config* cfg, bp_state** out) {
   *out = s.release();
   return BP_OK;
 }
+BPG_ABI_CATCH("bp_state_build")
 
 void bp_state_free(bp_state* s) {
   if (!s) return;
@@ -308,7 +309,7 @@ int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t t
   return BP_OK;
 }
 
-int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out) {
+int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out) try {
   if (!proof || len % 8 || len < (BOX_HDR + BP_PV_WORDS) * 8) return fail(BP_ERR_INVALID_INPUT, "proof: truncated");
   const uint64_t* w = reinterpret_cast<const uint64_t*>(proof);
   if (w[0] != PROOF_BOX_MAGIC || w[1] > 2 || w[2] < BP_PV_WORDS || w[2] > 64 || len / 8 < BOX_HDR + w[2])
@@ -317,9 +318,10 @@ int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_
   if (kind_out) *kind_out = (int)w[1];
   return BP_OK;
 }
+BPG_ABI_CATCH("bp_proof_public_values")
 
 int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
-                          uint8_t** out, size_t* out_len) {
+                          uint8_t** out, size_t* out_len) try {
   if (!s || !ir || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof: null argument");
   if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
   const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
@@ -439,9 +441,10 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   if ((r = rec_prove(w, s->rec_cfg, s->special[0], pi, proof))) return r;
   return emit_box(0, CIRCUIT_ROOT, pi, proof, out, out_len);
 }
+BPG_ABI_CATCH("bp_generate_txn_proof")
 
 int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
-                          const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len) {
+                          const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len) try {
   if (!s || !lhs || !rhs || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_agg_proof: null argument");
   Box L, R;
   int r;
@@ -467,9 +470,10 @@ int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len,
   if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[1], pi, proof))) return r;
   return emit_box(1, CIRCUIT_AGG, pi, proof, out, out_len);
 }
+BPG_ABI_CATCH("bp_generate_agg_proof")
 
 int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t parent_len, const uint8_t* agg,
-                            size_t agg_len, uint8_t** out, size_t* out_len, uint64_t* b_height) {
+                            size_t agg_len, uint8_t** out, size_t* out_len, uint64_t* b_height) try {
   if (!s || !agg || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_block_proof: null argument");
   Box A, Pb;
   int r;
@@ -493,8 +497,9 @@ int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t par
   if (b_height) *b_height = A.pv[12];  // block_metadata.block_number.low_u64(), proof_gen.rs:90-94
   return emit_box(2, CIRCUIT_BLOCK, pi, proof, out, out_len);
 }
+BPG_ABI_CATCH("bp_generate_block_proof")
 
-int bp_verifier_state_from_prover(const bp_state* s, bp_verifier_state** out) {
+int bp_verifier_state_from_prover(const bp_state* s, bp_verifier_state** out) try {
   if (!s || !out) return fail(BP_ERR_INVALID_INPUT, "bp_verifier_state_from_prover: null argument");
   bp_verifier_state* v = new bp_verifier_state();
   v->rec_cfg = s->rec_cfg;
@@ -505,8 +510,9 @@ int bp_verifier_state_from_prover(const bp_state* s, bp_verifier_state** out) {
   *out = v;
   return BP_OK;
 }
+BPG_ABI_CATCH("bp_verifier_state_from_prover")
 // ProverStateBuilder::build_verifier (verifier_state.rs:34-42): build the circuits, keep the light part.
-int bp_verifier_state_build(const bp_config* cfg, bp_verifier_state** out) {
+int bp_verifier_state_build(const bp_config* cfg, bp_verifier_state** out) try {
   bp_state* s = nullptr;
   bp_config c = *cfg;
   c.n_workers = 1;
@@ -516,9 +522,10 @@ int bp_verifier_state_build(const bp_config* cfg, bp_verifier_state** out) {
   bp_state_free(s);
   return r;
 }
+BPG_ABI_CATCH("bp_verifier_state_build")
 // Light verifier data from raw caps (what a verifier-only deployment would load from disk):
 // caps = root, agg, block constants caps, each 4 << stark_cap_height words.  CPU only.
-int bp_verifier_state_from_caps(const bp_config* cfg, const uint64_t* caps, bp_verifier_state** out) {
+int bp_verifier_state_from_caps(const bp_config* cfg, const uint64_t* caps, bp_verifier_state** out) try {
   if (!cfg || !caps || !out) return fail(BP_ERR_INVALID_INPUT, "bp_verifier_state_from_caps: null argument");
   const StarkCfg rc = rec_cfg_of(*cfg);
   int r = check_cfg(rc);
@@ -534,9 +541,10 @@ int bp_verifier_state_from_caps(const bp_config* cfg, const uint64_t* caps, bp_v
   *out = v;
   return BP_OK;
 }
+BPG_ABI_CATCH("bp_verifier_state_from_caps")
 void bp_verifier_state_free(bp_verifier_state* v) { delete v; }
 
-int bp_verify_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len) {
+int bp_verify_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len) try {
   if (!v || !proof) return fail(BP_ERR_INVALID_INPUT, "bp_verify_proof: null argument");
   Box b;
   int r = parse_box(proof, len, v->rec_cfg, &b);
@@ -546,7 +554,8 @@ int bp_verify_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len
   for (size_t i = 0; i < b.n_pi; i++) if (b.pi[i] >= gl::P) return fail(BP_ERR_VERIFY, "non-canonical public input");
   return rec_verify(v->rec_cfg, v->special[b.kind], b);
 }
-int bp_verify_block_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len) {
+BPG_ABI_CATCH("bp_verify_proof")
+int bp_verify_block_proof(const bp_verifier_state* v, const uint8_t* proof, size_t len) try {
   if (!v || !proof) return fail(BP_ERR_INVALID_INPUT, "bp_verify_block_proof: null argument");
   Box b;
   int r = parse_box(proof, len, v->rec_cfg, &b);
@@ -554,5 +563,6 @@ int bp_verify_block_proof(const bp_verifier_state* v, const uint8_t* proof, size
   if (b.kind != 2) return fail(BP_ERR_VERIFY, "not a block proof");
   return bp_verify_proof(v, proof, len);
 }
+BPG_ABI_CATCH("bp_verify_block_proof")
 
 }  // extern "C"

@@ -83,7 +83,7 @@ void bp_release_cached_memory(void) {
 }
 
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
-                             uint8_t** out, size_t* out_len) {
+                             uint8_t** out, size_t* out_len) try {
   if (!cfg || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_stark_prove_synthetic: null argument");
   StarkCfg c{cfg->log_n, cfg->n_cols, cfg->n_const, cfg->deg_pow, cfg->rate_bits, cfg->cap_height,
              cfg->num_queries, cfg->pow_bits, cfg->arity_bits, cfg->final_poly_bits};
@@ -129,6 +129,7 @@ int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t co
   park_worker(wp);
   return rc;
 }
+BPG_ABI_CATCH("bp_stark_prove_synthetic")
 
 // ---- L0: the remaining per-stage entry points of SURVEY.md section 8(b) -------------------------------
 
@@ -151,7 +152,7 @@ uint64_t bp_quotient_scratch_words(const bp_stark_cfg* shape) {
 
 int bp_quotient_eval(const bp_stark_cfg* shape, const uint64_t* d_trace_lde, const uint64_t* d_aux_lde,
                      const uint64_t* d_const_lde, const uint64_t ctl_in[4], const uint64_t alphas[2],
-                     uint64_t* d_scratch, uint64_t* d_qvals_out, void* stream) {
+                     uint64_t* d_scratch, uint64_t* d_qvals_out, void* stream) try {
   StarkCfg c;
   int rc = quot_cfg(shape, &c);
   if (rc) return rc;
@@ -170,9 +171,10 @@ int bp_quotient_eval(const bp_stark_cfg* shape, const uint64_t* d_trace_lde, con
   qa.partial = d_scratch; qa.qvals = d_qvals_out;
   return launch_quotient(qa, cp, as_stream(stream));
 }
+BPG_ABI_CATCH("bp_quotient_eval")
 
 int bp_fri_fold(const uint64_t* d_values, uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uint64_t shift,
-                const uint64_t beta[2], uint64_t* d_out, void* stream) {
+                const uint64_t beta[2], uint64_t* d_out, void* stream) try {
   if (!d_values || !d_out || !beta) return fail(BP_ERR_INVALID_INPUT, "bp_fri_fold: null argument");
   if (shift == 0 || shift >= gl::P || beta[0] >= gl::P || beta[1] >= gl::P)
     return fail(BP_ERR_INVALID_INPUT, "bp_fri_fold: non-canonical field element");
@@ -184,8 +186,9 @@ int bp_fri_fold(const uint64_t* d_values, uint32_t log_nl, uint32_t rate_bits, u
   fa.beta = gl::Ext{beta[0], beta[1]};
   return launch_fri_fold(fa, as_stream(stream));
 }
+BPG_ABI_CATCH("bp_fri_fold")
 
-int bp_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out, void* stream) {
+int bp_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out, void* stream) try {
   if (!state || !nonce_out) return fail(BP_ERR_INVALID_INPUT, "bp_pow_grind: null argument");
   if (pos >= 8 || bits == 0 || bits > 40) return fail(BP_ERR_INVALID_INPUT, "bp_pow_grind: pos must be a rate word, bits in 1..40");
   hipStream_t st = as_stream(stream);
@@ -212,9 +215,10 @@ int bp_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t
   if (rc == BP_OK) *nonce_out = res;
   return rc;
 }
+BPG_ABI_CATCH("bp_pow_grind")
 
 int bp_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, uint32_t n_cols, const uint64_t z0[2],
-                const uint64_t z1[2], uint64_t* d_pw_scratch, uint64_t* d_out, void* stream) {
+                const uint64_t z1[2], uint64_t* d_pw_scratch, uint64_t* d_out, void* stream) try {
   if (!n_cols) return BP_OK;
   if (!d_coeffs || !z0 || !d_pw_scratch || !d_out) return fail(BP_ERR_INVALID_INPUT, "bp_openings: null argument");
   if (log_n > 30 || stride < ((uint64_t)1 << log_n)) return fail(BP_ERR_INVALID_INPUT, "bp_openings: bad shape");
@@ -227,5 +231,6 @@ int bp_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, uint3
   if (rc) return rc;
   return launch_openings(d_coeffs, stride, log_n, n_cols, d_pw_scratch, n_points, d_out, st);
 }
+BPG_ABI_CATCH("bp_openings")
 
 }  // extern "C"
