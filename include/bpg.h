@@ -239,6 +239,12 @@ int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas
                  uint64_t gas_used_after, const uint64_t state_root_before[4], uint64_t seed,
                  const uint32_t table_log_n[BP_NUM_TABLES], const uint32_t table_width[BP_NUM_TABLES],
                  uint64_t out_words[BP_IR_WORDS]);
+/* A dummy entry (protocol_decoder/src/decoding.rs:484-520, used to pad blocks of 0 or 1 transactions to the two
+ * entries an aggregation needs, :304-347): proven like a transaction, but its public values do not
+ * advance -- txn_number_after = txn_number_before, gas unchanged, state_root_after = state_root_before. */
+int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_used, const uint64_t state_root[4],
+                       uint64_t seed, const uint32_t table_log_n[BP_NUM_TABLES],
+                       const uint32_t table_width[BP_NUM_TABLES], uint64_t ir_out[BP_IR_WORDS]);
 /* public values of a proof container: txn_before, txn_after, gas_before, gas_after, root_before[4],
  * root_after[4], block_number */
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out);

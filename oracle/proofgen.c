@@ -119,17 +119,22 @@ static gl_t* emit_box(uint64_t kind, const gl_t* pi, size_t n_pi, const gl_t* st
 /* generate_txn_proof (proof_gen.rs:39-56) on the synthetic workload */
 int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) {
   const orc_pg_config* cfg = &s->cfg;
-  if (I[0] != IR_MAGIC || I[1] != 1) return -2;
+  /* version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520: "Txn numbers before/after",
+   * "Gas used before/after" equal, tries unchanged) -- same tables proven, public values do not advance */
+  if (I[0] != IR_MAGIC || (I[1] != 1 && I[1] != 2)) return -2;
+  const int dummy = I[1] == 2;
+  if (dummy && I[4] != I[5]) return -2;
   orc_stark_cfg tcfg[NUM_TABLES];
   for (int t = 0; t < NUM_TABLES; t++) {
     if (I[11 + t] < cfg->table_log_lo[t] || I[11 + t] >= cfg->table_log_hi[t]) return -3;
     tcfg[t] = table_cfg_of(cfg, (uint32_t)I[11 + t], (uint32_t)I[18 + t]);
   }
   gl_t pv[PV_WORDS];
-  pv[0] = I[3]; pv[1] = I[3] + 1; pv[2] = I[4]; pv[3] = I[5];
+  pv[0] = I[3]; pv[1] = I[3] + (dummy ? 0 : 1); pv[2] = I[4]; pv[3] = I[5];
   memcpy(pv + 4, I + 6, 32);
   gl_t in6[6] = {I[6], I[7], I[8], I[9], gl_canon(I[10]), gl_canon(I[3])};
-  orc_hash_no_pad(in6, 6, pv + 8);
+  if (dummy) memcpy(pv + 8, I + 6, 32);
+  else orc_hash_no_pad(in6, 6, pv + 8);
   pv[12] = I[2];
   for (int i = 0; i < PV_WORDS; i++) pv[i] = gl_canon(pv[i]);
 

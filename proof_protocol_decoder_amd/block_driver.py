@@ -178,27 +178,51 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
     return irs
 
 
-def irs_from_block_trace(block_trace, block_number, table_log_n, table_width):
+DUMMY_SEED = 0x44554D4D59000000   # "DUMMY": witness seed of padding entries
+
+
+def pad_with_dummy_irs(irs, block_number, state_root, table_log_n, table_width, has_withdrawals=False):
+    """`pad_gen_inputs_with_dummy_inputs_if_needed` (protocol_decoder/src/decoding.rs:304-347): an aggregation
+    needs two entries and a block proof needs an aggregation, so a block of 0 transactions gets two dummy entries
+    and a block of 1 gets one -- BEFORE the transaction, or AFTER it when the block has withdrawals (the
+    withdrawals then ride on that last dummy, :356-402).  Dummy entries do not change state (:484-520).
+    `state_root` is the block's initial state root (used when there is no transaction to take it from).
+    Returns (irs, dummies_added).
+
+    One deliberate difference: the reference builds the prepended dummy from the counters AFTER the real
+    transaction (`extra_data`, :329-333: txn_number_before = 1, gas = the block's total); here it carries the
+    counters of its position (0, 0) so that txn number, gas and state root chain from entry to entry, which
+    `generate_agg_proof` checks (proof_types.rs:23-24).
+    """
+    irs = list(irs)
+    mk = lambda txn_no, gas, root, k: pg.TxnProofGenIR(block_number, txn_no, gas, gas, tuple(root), DUMMY_SEED + k,
+                                                       tuple(table_log_n), tuple(table_width), dummy=True)
+    if len(irs) == 0:
+        return [mk(0, 0, state_root, 0), mk(0, 0, state_root, 1)], True
+    if len(irs) == 1:
+        only = irs[0]
+        if has_withdrawals:   # dummy after the only txn: starts where the txn ended
+            after = pg.state_root_after(only.state_root_before, only.seed, only.txn_number_before)
+            return [only, mk(only.txn_number_before + 1, only.gas_used_after, after, 0)], True
+        return [mk(only.txn_number_before, only.gas_used_before, only.state_root_before, 0), only], True
+    return irs, False
+
+
+def irs_from_block_trace(block_trace, block_number, table_log_n, table_width, has_withdrawals=False):
     """Front door: a `trace_protocol.BlockTrace` payload -> the synthetic IRs of its transactions.
 
     Mirrors the sequencing of `ProcessedBlockTrace::into_txn_proof_gen_ir` (protocol_decoder/src/decoding.rs:81-177):
     transactions in payload order, `txn_number_before` = index, `gas_used_before/after` accumulated from
-    `TxnMeta.gas_used` (:122-124, :150-152), the state root threaded from one txn to the next (:129).  What the
-    reference derives with its MPT machinery is derived synthetically here: the chain starts at the
-    state root of the decoded compact witness (folded into four field elements) and each txn's witness seed is a
-    hash of its payload bytes.  The reference pads blocks of 0 or 1 transactions with dummy entries
-    (decoding.rs:304-347); the synthetic IR has no dummy form, so such blocks are refused.
+    `TxnMeta.gas_used` (:122-124, :150-152), the state root threaded from one txn to the next (:129), then the
+    dummy padding of `pad_with_dummy_irs` (:157-164).  What the reference derives with its MPT machinery is
+    derived synthetically here: the chain starts at the state root of the decoded compact witness
+    (folded into four field elements) and each txn's witness seed is a hash of its payload bytes.  Withdrawals
+    only steer where the padding goes (`has_withdrawals`); their balance updates (:404-428) are not modelled.
     """
-    import ctypes as C
     from . import compact
-    if len(block_trace.txn_info) < 2:
-        raise ValueError("a block needs at least two transactions (the reference pads with dummy entries, "
-                         "decoding.rs:304-347; the synthetic IR has no dummy form)")
     pre = block_trace.process_pre_images()
     P = 0xFFFFFFFF00000001
-    root = tuple(int.from_bytes(pre.state_root[8 * i:8 * i + 8], "little") % P for i in range(4))
-    L = pg._bind()
-    L.bp_state_root_after.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    root0 = root = tuple(int.from_bytes(pre.state_root[8 * i:8 * i + 8], "little") % P for i in range(4))
     irs, gas = [], 0
     for i, info in enumerate(block_trace.txn_info):
         m = info.meta
@@ -206,7 +230,5 @@ def irs_from_block_trace(block_trace, block_number, table_log_n, table_width):
         seed = int.from_bytes(digest[:8], "little")
         irs.append(pg.TxnProofGenIR(block_number, i, gas, gas + m.gas_used, root, seed, tuple(table_log_n),
                                     tuple(table_width)))
-        out = (C.c_uint64 * 4)()
-        pg.check(L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out))
-        root, gas = tuple(out), gas + m.gas_used
-    return irs
+        root, gas = pg.state_root_after(root, seed, i), gas + m.gas_used
+    return pad_with_dummy_irs(irs, block_number, root0, table_log_n, table_width, has_withdrawals)[0]

@@ -300,6 +300,14 @@ int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas
   return BP_OK;
 }
 
+int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_used, const uint64_t state_root[4],
+                       uint64_t seed, const uint32_t table_log_n[BP_NUM_TABLES], const uint32_t table_width[BP_NUM_TABLES],
+                       uint64_t o[BP_IR_WORDS]) {
+  int rc = bp_ir_encode(block_number, txn_number, gas_used, gas_used, state_root, seed, table_log_n, table_width, o);
+  if (rc == BP_OK) o[1] = 2;
+  return rc;
+}
+
 // root_after of one txn (the synthetic "state transition"): hash_no_pad(root_before, seed, txn_number).
 // Host-side, like the decoder that chains GenerationInputs in the reference (decoding.rs:106-154).
 int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]) {
@@ -325,8 +333,12 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   if (!s || !ir || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof: null argument");
   if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
   const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
-  if (I[0] != IR_MAGIC || I[1] != 1) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
+  // version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520): txn number, gas and state
+  // root do not advance, the same tables are proven
+  if (I[0] != IR_MAGIC || (I[1] != 1 && I[1] != 2)) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
+  const bool dummy = I[1] == 2;
   if (I[5] < I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: gas_used_after < gas_used_before");
+  if (dummy && I[5] != I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: a dummy entry must not use gas (decoding.rs:503-506)");
   const bp_config& cfg = s->cfg;
   StarkCfg tcfg[BP_NUM_TABLES];
   for (int t = 0; t < BP_NUM_TABLES; t++) {
@@ -342,9 +354,10 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   for (int i = 0; i < 4; i++) if (I[6 + i] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "IR: non-canonical state root");
   // PublicValues
   std::vector<uint64_t> pv(BP_PV_WORDS);
-  pv[0] = I[3]; pv[1] = I[3] + 1; pv[2] = I[4]; pv[3] = I[5];
+  pv[0] = I[3]; pv[1] = I[3] + (dummy ? 0 : 1); pv[2] = I[4]; pv[3] = I[5];
   std::memcpy(&pv[4], I + 6, 32);
-  root_after(I + 6, I[10], I[3], &pv[8]);
+  if (dummy) std::memcpy(&pv[8], I + 6, 32);
+  else root_after(I + 6, I[10], I[3], &pv[8]);
   pv[12] = I[2];
   for (auto& v : pv) v = gl::canon(v);
 

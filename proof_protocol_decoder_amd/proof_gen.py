@@ -58,6 +58,8 @@ def _bind():
     L.bp_verify_proof.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.bp_ir_encode.argtypes = [C.c_uint64] * 4 + [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32),
                                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.bp_ir_encode_dummy.argtypes = [C.c_uint64] * 3 + [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32),
+                                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.bp_proof_public_values.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L._pg_bound = True
     return L
@@ -77,6 +79,15 @@ class PublicValues:
     @classmethod
     def from_words(cls, w):
         return cls(w[0], w[1], w[2], w[3], tuple(w[4:8]), tuple(w[8:12]), w[12])
+
+
+def state_root_after(root_before, seed, txn_number):
+    """bp_state_root_after: the synthetic state transition of one (non-dummy) transaction."""
+    L = _bind()
+    L.bp_state_root_after.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    out = (C.c_uint64 * 4)()
+    check(L.bp_state_root_after((C.c_uint64 * 4)(*root_before), seed, txn_number, out))
+    return tuple(out)
 
 
 def public_values_of(proof_bytes):
@@ -99,14 +110,21 @@ class TxnProofGenIR:
     seed: int
     table_log_n: tuple
     table_width: tuple
+    dummy: bool = False   # a padding entry (decoding.rs:484-520): proven, but txn number / gas / state root stay
 
     def to_bytes(self):
         L = _bind()
         out = (C.c_uint64 * IR_WORDS)()
-        check(L.bp_ir_encode(self.block_number, self.txn_number_before, self.gas_used_before, self.gas_used_after,
-                             (C.c_uint64 * 4)(*self.state_root_before), self.seed,
-                             (C.c_uint32 * NUM_TABLES)(*self.table_log_n),
-                             (C.c_uint32 * NUM_TABLES)(*self.table_width), out))
+        root = (C.c_uint64 * 4)(*self.state_root_before)
+        logs, widths = (C.c_uint32 * NUM_TABLES)(*self.table_log_n), (C.c_uint32 * NUM_TABLES)(*self.table_width)
+        if self.dummy:
+            if self.gas_used_after != self.gas_used_before:
+                raise ValueError("a dummy entry uses no gas (decoding.rs:503-506)")
+            check(L.bp_ir_encode_dummy(self.block_number, self.txn_number_before, self.gas_used_before, root, self.seed,
+                                       logs, widths, out))
+        else:
+            check(L.bp_ir_encode(self.block_number, self.txn_number_before, self.gas_used_before, self.gas_used_after,
+                                 root, self.seed, logs, widths, out))
         return struct.pack("<%dQ" % IR_WORDS, *out)
 
 

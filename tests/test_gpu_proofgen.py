@@ -182,3 +182,36 @@ def test_block_trace_payload_to_block_proof(bpg, pg, p_state):
     pv, kind = pg.public_values_of(blk.intern)
     assert kind == 2 and pv.txn_number_before == 0 and pv.txn_number_after == 5
     assert pv.gas_used_after == sum(21000 + i for i in range(5)) and tuple(pv.state_root_before) == irs[0].state_root_before
+
+
+def test_dummy_entries_and_short_blocks(bpg, pg, p_state, o_state):
+    """Padding entries (decoding.rs:304-347, 484-520): the dummy IR is proven byte-for-byte like the oracle's, and
+    blocks of 0 and 1 transactions -- padded the way the reference pads them -- yield verifying block proofs."""
+    from proof_protocol_decoder_amd.block_driver import BlockDriver, pad_with_dummy_irs
+    d_ir = pg.TxnProofGenIR(7, 0, 100, 100, (1, 2, 3, 4), 0x44554D4D59000000, tuple(LOG_N), tuple(WIDTH), dummy=True)
+    got = pg.generate_txn_proof(p_state, d_ir)
+    want_ir = ir_words(7, 0, 0x44554D4D59000000, gas=(100, 100))
+    want_ir[1] = 2
+    assert (words(got.intern) == o_state.txn(want_ir)).all()
+    assert got.p_vals.txn_number_after == 0 and got.p_vals.state_root_after == got.p_vals.state_root_before
+    with pytest.raises(ValueError):
+        pg.TxnProofGenIR(7, 0, 100, 121, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), dummy=True).to_bytes()
+    v = pg.VerifierState.from_prover_state(p_state)
+    drv = BlockDriver(p_state, n_threads=2)
+    try:
+        empty, added = pad_with_dummy_irs([], 11, (5, 6, 7, 8), LOG_N, WIDTH)
+        assert added and len(empty) == 2
+        blk0 = drv.prove_block_distributed(empty)
+        v.verify(blk0)
+        pv0, _ = pg.public_values_of(blk0.intern)
+        assert (pv0.txn_number_before, pv0.txn_number_after) == (0, 0) and pv0.state_root_after == (5, 6, 7, 8)
+        for wd in (False, True):
+            one, added = pad_with_dummy_irs([make_ir(pg, 12, 0, 0x5EED0009, root=(5, 6, 7, 8), gas=(0, 21000))], 12,
+                                            (5, 6, 7, 8), LOG_N, WIDTH, has_withdrawals=wd)
+            assert added and [ir.dummy for ir in one] == ([False, True] if wd else [True, False])
+            blk1 = drv.prove_block_distributed(one)
+            v.verify(blk1)
+            pv1, _ = pg.public_values_of(blk1.intern)
+            assert pv1.txn_number_after == 1 and pv1.gas_used_after == 21000 and pv1.state_root_after != (5, 6, 7, 8)
+    finally:
+        drv.close()

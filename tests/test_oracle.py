@@ -195,3 +195,23 @@ def test_txn_agg_block_chain_on_cpu(oracle):
     bad = blk.copy()
     bad[-3] ^= np.uint64(4)
     assert st.verify(bad) != 0
+
+
+def test_dummy_entry_does_not_advance_public_values(oracle):
+    """IR version 2 = a padding entry (decoding.rs:484-520: txn numbers and gas before/after equal, tries
+    untouched): proven and verified like a txn, aggregates with its neighbours, public values stand still."""
+    st = oracle.PgState(**SMALL)
+    real = ir_words(7, 0, 0x5EED0001)
+    dummy = ir_words(7, 0, 0x44554D4D59000000, gas=(100, 100))
+    dummy[1] = 2
+    d, t = st.txn(dummy), st.txn(real)
+    pv_d, pv_t = d[4 + 28:4 + 41], t[4 + 28:4 + 41]
+    assert int(pv_d[0]) == int(pv_d[1]) == 0 and int(pv_d[2]) == int(pv_d[3]) == 100
+    assert (pv_d[4:8] == pv_d[8:12]).all() and int(pv_t[1]) == 1 and (pv_t[4:8] != pv_t[8:12]).any()
+    assert st.verify(d) == 0
+    agg = st.agg(d, False, t, False)            # dummy first, then the only real txn (decoding.rs:336-340)
+    assert st.verify(agg) == 0 and st.verify(st.block(None, agg)) == 0
+    bad = ir_words(7, 0, 1, gas=(100, 121))
+    bad[1] = 2
+    with pytest.raises(RuntimeError):           # a dummy that uses gas is refused (decoding.rs:503-506)
+        st.txn(bad)

@@ -165,6 +165,33 @@ def test_irs_from_block_trace_chain_like_decoding_rs(tp):
     # deterministic in the payload
     again = irs_from_block_trace(tp.BlockTrace.from_json(_block_payload(5)), 77, (6,) * 7, (16,) * 7)
     assert again == irs
-    for n in (0, 1):   # the reference pads these with dummy entries (decoding.rs:304-347); no synthetic dummy exists
-        with pytest.raises(ValueError, match="at least two"):
-            irs_from_block_trace(tp.BlockTrace.from_json(_block_payload(n)), 77, (6,) * 7, (16,) * 7)
+
+
+def test_dummy_padding_rule(tp):
+    """pad_gen_inputs_with_dummy_inputs_if_needed (decoding.rs:304-347): 0 txns -> two dummies; 1 txn -> one dummy,
+    before the txn, or after it when the block has withdrawals; >= 2 txns untouched.  Dummies do not advance txn
+    number, gas or state root (:484-520), and the padded list still chains."""
+    from proof_protocol_decoder_amd.block_driver import irs_from_block_trace
+    logs, widths = (6,) * 7, (16,) * 7
+
+    def chains(irs):
+        from proof_protocol_decoder_amd import proof_gen as pg
+        txn_no, gas, root = irs[0].txn_number_before, irs[0].gas_used_before, irs[0].state_root_before
+        for ir in irs:
+            assert (ir.txn_number_before, ir.gas_used_before, ir.state_root_before) == (txn_no, gas, root)
+            if ir.dummy:
+                assert ir.gas_used_after == ir.gas_used_before
+            else:
+                txn_no, root = txn_no + 1, pg.state_root_after(root, ir.seed, ir.txn_number_before)
+            gas = ir.gas_used_after
+        return txn_no, gas
+
+    empty = irs_from_block_trace(tp.BlockTrace.from_json(_block_payload(0)), 5, logs, widths)
+    assert [ir.dummy for ir in empty] == [True, True] and chains(empty) == (0, 0) and empty[0].seed != empty[1].seed
+    one = irs_from_block_trace(tp.BlockTrace.from_json(_block_payload(1)), 5, logs, widths)
+    assert [ir.dummy for ir in one] == [True, False] and chains(one) == (1, 21000)
+    one_w = irs_from_block_trace(tp.BlockTrace.from_json(_block_payload(1)), 5, logs, widths, has_withdrawals=True)
+    assert [ir.dummy for ir in one_w] == [False, True] and chains(one_w) == (1, 21000)
+    assert one_w[1].txn_number_before == 1 and one_w[1].state_root_before != one_w[0].state_root_before
+    three = irs_from_block_trace(tp.BlockTrace.from_json(_block_payload(3)), 5, logs, widths)
+    assert [ir.dummy for ir in three] == [False] * 3 and chains(three)[0] == 3
