@@ -185,7 +185,10 @@ class ProverState:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
 
 class ProverStateBuilder:
@@ -299,4 +302,7 @@ class VerifierState:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
