@@ -78,6 +78,9 @@ GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
 // one-instruction asm statement that CONSUMES a carry carries its own `s_nop 1`: on gfx940+ a VALU
 // write of an SGPR needs 2 wait states before a VALU read of it, and the compiler's hazard
 // recogniser does not look inside inline asm.  (Other waves of the SIMD issue during the nop.)
+// The same blindness holds the other way round: a compiler-generated DPP / permlane read of a VGPR
+// that an asm statement has just written is not given its 2 wait states either, so code that feeds
+// asm results straight into cross-lane moves inserts them itself (poseidon.cuh, permute_quad).
 namespace cc {
 typedef uint64_t mask;  // wave-wide carry mask, lives in an SGPR pair
 __device__ __forceinline__ uint64_t mad_co(uint32_t a, uint32_t b, uint64_t c, mask& co) {
