@@ -56,6 +56,10 @@ __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const 
           const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
           x[m + half] = r[i];
         }
+        // radix 32: four groups per stage in flight exhaust the SGPRs (each group holds ~9 carry masks) and
+        // the compiler starts parking SGPRs in VGPR lanes; a v_writelane of a mask right after the asm that
+        // wrote it is a hazard the recogniser cannot see, so the groups are kept apart instead
+        if constexpr (LOGR >= 5) __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
@@ -96,6 +100,7 @@ __device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const 
           x[m] = gl::add(a, t);   // a: any u64, t: canonical -> lazily reduced result
           x[m + step] = gl::sub(a, t);
         }
+        if constexpr (LOGR >= 5) __builtin_amdgcn_sched_barrier(0);  // see dif_butterflies
       }
     } else {
 #pragma unroll

@@ -475,6 +475,10 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
         gl::mul_n<4>(d, w, r);
 #pragma unroll
         for (int i = 0; i < 4; i++) r[i] = gl::canon(r[i]);
+        // keep the groups from being interleaved: each holds ~9 live carry masks, and SGPR pressure makes the
+        // compiler park masks in VGPR lanes with v_writelane right after the asm that wrote them -- a read the
+        // hazard recogniser does not space out (it cannot see the write inside inline asm)
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int i = 0; i < 2; i++) {
