@@ -6,8 +6,8 @@
 // Representation: every value stored to memory is canonical (< p).  In registers a value is any
 // u64 congruent to the element ("reduced"), and each helper states what it needs and returns.
 //
-// CDNA4 notes: there is no 64x64 multiplier; a 64x64->128 product is four v_mad_u64_u32 (~1.25
-// issue slots each) and the Goldilocks reduction uses 2^64 = 2^32 - 1, 2^96 = -1.  The compiler's
+// CDNA4 notes: there is no 64x64 multiplier; a 64x64->128 product is four v_mad_u64_u32 (full rate:
+// 4.7 cycles per wave64 like every other VOP3, tools/issue_rate.hip) and the Goldilocks reduction uses 2^64 = 2^32 - 1, 2^96 = -1.  The compiler's
 // rendering of mul_wide + reduce128 is 25 VALU instructions; the device forms below (namespace cc,
 // mul, mul_n, DotAcc) keep the carries as explicit SGPR masks and need 17.
 // No MFMA anywhere (integer field work).
