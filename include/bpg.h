@@ -92,8 +92,9 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
 
 /* Tuning knob: hashing launches with fewer rows/nodes than this use the quad-cooperative Poseidon
  * kernels (4 lanes per state, DPP exchange); larger ones use one lane per state.  Results are
- * identical either way.  0 (default) = automatic: 2^17 while fewer than 6 provers are at work on the
- * device, 2^13 under load. */
+ * identical either way.  0 (default) = automatic: 2^17 while fewer than 6 provers (bp_generate_*_proof
+ * calls) are at work on the device, 2^13 under load.  A caller that drives the L0 entry points from many
+ * streams itself should set 2^13: the library cannot see that load. */
 void bp_tune_quad_threshold(uint64_t n_perms);
 /* 1: Merkle levels below the quad threshold are fused, up to 7 per launch; 0 (default, ~3% faster under
  * multi-stream load): one launch per level.  Results are identical. */

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import proof_protocol_decoder_amd as bpg
 bpg.lib().bp_use_blocking_sync(0)
+# the automatic kernel-form choice follows the number of L1 provers at work; this probe drives L0 directly,
+# so it states the loaded-chip choice itself (one lane per state above 2^13 rows)
+bpg.lib().bp_tune_quad_threshold(1 << 13)
 torch.cuda.set_device(0)
 log_n, r, C = 13, 3, 135
 rows = 1 << (log_n + r)
