@@ -210,6 +210,7 @@ def main():
         }
         if world == 1:
             out["roofline_isolated"] = isolated_roofline(pkg, torch)
+            out["ntt_hbm_gbps"] = ntt_gbps(pkg, torch)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0])
         print(json.dumps(out), flush=True)
@@ -238,6 +239,29 @@ def isolated_roofline(pkg, torch):
     ach = alg / (best * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "ntt16_dit_kernel<14> (coset LDE), 2^14 x 2432, rate 2, alone", "achieved": round(ach, 1),
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "launch_ms": round(best, 4)}
+
+
+def ntt_gbps(pkg, torch):
+    """BASELINE metric (ii), Goldilocks NTT HBM GB/s: the batched inverse NTT (natural -> bit-reversed, one kernel
+    launch up to 2^14 rows, strided passes above) alone on the chip at four shapes of SURVEY.md section 8(d) S4.
+    Algorithmic bytes 16*n*C per transform; fraction of the 8 TB/s HBM peak beside it."""
+    out = {}
+    for log_n, cols in ((12, 2048), (14, 2048), (16, 256), (20, 64)):
+        v = torch.randint(0, 2**62, (cols, 1 << log_n), dtype=torch.int64, device="cuda")
+        pkg.ops.ntt_batch_(v, pkg.ops.NTT_INV_NAT2BR)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            pkg.ops.ntt_batch_(v, pkg.ops.NTT_INV_NAT2BR)
+            b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b))
+        gbps = 16.0 * (1 << log_n) * cols / (best * 1e-3) / 1e9
+        out["2^%d x %d" % (log_n, cols)] = {"GB/s": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+        del v
+    return out
 
 
 def usable_cores():
