@@ -47,20 +47,32 @@ class TorchGather:
         import torch.distributed as dist
         self.torch, self.dist, self.device = torch, dist, device
 
-    def gather_bytes(self, payload):
+    def gather_bytes(self, payload, failed=False):
+        """payload may be empty (a rank without transactions: rank 0 gets b"" for it).  `failed` marks a rank
+        whose shard raised: the length exchange doubles as the status exchange (length -1), and then EVERY
+        rank raises ShardFailed before the data gather, so nobody is left waiting in a collective."""
         torch, dist = self.torch, self.dist
         world, rank = dist.get_world_size(), dist.get_rank()
-        n = torch.tensor([len(payload)], dtype=torch.int64, device=self.device)
+        n = torch.tensor([-1 if failed else len(payload)], dtype=torch.int64, device=self.device)
         lens = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(lens, n)
-        max_len = max(int(x.item()) for x in lens)
+        lens = [int(x.item()) for x in lens]
+        bad = [r for r, l in enumerate(lens) if l < 0]
+        if bad:
+            raise ShardFailed("shard proving failed on rank(s) %s" % bad)
+        max_len = max(max(lens), 1)
         buf = torch.zeros(max_len, dtype=torch.uint8, device=self.device)
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self.device)
+        if payload:
+            buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self.device)
         out = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
         dist.gather(buf, out, dst=0)
         if rank != 0:
             return None
-        return [bytes(out[r][:int(lens[r].item())].cpu().numpy().tobytes()) for r in range(world)]
+        return [bytes(out[r][:lens[r]].cpu().numpy().tobytes()) for r in range(world)]
+
+
+class ShardFailed(RuntimeError):
+    """Raised on every rank when any rank's shard failed (see TorchGather.gather_bytes)."""
 
 
 class BlockDriver:
@@ -138,18 +150,35 @@ class BlockDriver:
         return results[root], [results[i] for i in range(n)]
 
     def prove_block_distributed(self, irs, rank=0, world_size=1, gather=None, parent=None):
-        """Returns the GeneratedBlockProof on rank 0, None elsewhere."""
+        """Returns the GeneratedBlockProof on rank 0, None elsewhere.
+
+        A block with fewer entries than ranks (decoding.rs:304-347 pads to two, so any block of 0 or 1
+        transactions on an 8-GPU node) leaves the high ranks without a slice: they join the gather with an
+        empty payload that rank 0 skips.  A rank whose shard raises reports it through the gather's length
+        exchange, and every rank raises instead of waiting for a payload that will never come."""
         lo, hi = shard_bounds(len(irs), rank, world_size)
-        if hi <= lo:
-            raise ValueError("rank %d has no transactions (block of %d over %d ranks)" % (rank, len(irs), world_size))
-        sub, _ = self.prove_shard(irs[lo:hi])
+        sub, err = None, None
+        try:
+            if hi > lo:
+                sub, _ = self.prove_shard(irs[lo:hi])
+        except Exception as e:  # held until the other ranks know
+            err = e
         if world_size > 1:
-            raws = gather.gather_bytes(sub.intern)
+            try:
+                raws = gather.gather_bytes(sub.intern if sub is not None else b"", failed=err is not None)
+            except ShardFailed:
+                if err is not None:
+                    raise err
+                raise
             if rank != 0:
                 return None
-            subs = [self.decode_proof(r) for r in raws]
+            subs = [self.decode_proof(r) for r in raws if r]
         else:
-            subs = [sub]
+            if err is not None:
+                raise err
+            subs = [sub] if sub is not None else []
+        if not subs:
+            raise ValueError("a block needs at least two transactions (decoding.rs:304-347 pads to >= 2)")
         top = tree_reduce(subs, self.prove_agg, self.pool)
         if not isinstance(top, pg.GeneratedAggProof):
             raise ValueError("a block needs at least two transactions (decoding.rs:304-347 pads to >= 2)")

@@ -19,6 +19,7 @@
 // Yellow Paper (appendix D) Merkle-Patricia hash, computed here directly on the witness node tree
 // (equal to inserting every leaf / hash node for a well-formed witness).  Pinned by the six state
 // roots and the instruction KAT the reference's own tests hold (tests/golden/).
+#include <algorithm>
 #include <array>
 #include <cstdlib>
 #include <cstring>
@@ -296,7 +297,12 @@ struct Node {
   H256 hash{};            // hash node
   NodeP child;            // extension
   NodeP children[16];     // branch
+  uint32_t height = 1;    // nodes on the longest path below and including this one
 };
+// A state / storage path is at most 64 nibbles: at most 64 branches with an extension between any two,
+// so no well-formed witness nests deeper than this.  The cap bounds every recursion over the tree
+// (encode_node, collect_code, the shared_ptr destructor chain), whatever the client-supplied payload.
+constexpr uint32_t MAX_TREE_HEIGHT = 160;
 
 const H256 EMPTY_TRIE_HASH = {86, 232, 31, 23, 27, 204, 85, 166, 255, 131, 69, 230, 146, 192, 248, 110,
                               91, 72, 224, 27, 153, 108, 173, 192, 1, 98, 47, 181, 227, 99, 180, 33};
@@ -403,6 +409,9 @@ bool build_tree(const std::vector<Instr>& ins, Decoded* d, NodeP* root, std::str
         n->kind = Kind::Extension;
         n->key = in.key;
         if (!pop(&n->child, "Extension")) return false;
+        if (n->child->kind == Kind::Extension)
+          return fail_msg(err, "Invalid block witness entries: an extension node cannot have an extension child");
+        n->height = n->child->height + 1;
         break;
       case Op::Branch: {
         n->kind = Kind::Branch;
@@ -416,7 +425,10 @@ bool build_tree(const std::vector<Instr>& ins, Decoded* d, NodeP* root, std::str
         // the earliest of the `cnt` preceding nodes goes to the lowest set bit (:486-510)
         size_t idx = st.size() - cnt;
         for (int i = 0; i < 16; i++)
-          if (in.mask & (1u << i)) n->children[i] = st[idx++];
+          if (in.mask & (1u << i)) {
+            n->children[i] = st[idx++];
+            n->height = std::max(n->height, n->children[i]->height + 1);
+          }
         if (in.mask >> 16) return fail_msg(err, "Branch mask has bits above the 16 children");
         st.resize(st.size() - cnt);
         break;
@@ -453,6 +465,8 @@ bool build_tree(const std::vector<Instr>& ins, Decoded* d, NodeP* root, std::str
         break;
       }
     }
+    if (n->height > MAX_TREE_HEIGHT)
+      return fail_msg(err, "Invalid block witness entries: node tree nests deeper than any 64-nibble path allows");
     st.push_back(n);
   }
   if (st.size() > 1) {

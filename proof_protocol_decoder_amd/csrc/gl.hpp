@@ -25,51 +25,6 @@ constexpr uint64_t GENERATOR = 7;        // multiplicative generator = LDE coset
 constexpr uint64_t TWO_ADIC_ROOT = 1753635133440165772ULL;  // 7^((p-1)/2^32)
 constexpr uint64_t W = 7;                // extension non-residue: X^2 = 7
 
-GL_HD uint64_t canon(uint64_t a) { return a >= P ? a - P : a; }
-
-// a: any u64, b: canonical.  Result: reduced (any u64).
-GL_HD uint64_t add(uint64_t a, uint64_t b) {
-  uint64_t s = a + b;
-  return s < b ? s + EPS : s;  // on wrap: s < b < p so s + EPS cannot wrap again
-}
-// a: any u64, b: canonical.  Result: reduced.
-GL_HD uint64_t sub(uint64_t a, uint64_t b) {
-  uint64_t d = a - b;
-  return a < b ? d - EPS : d;  // on borrow: d = a + 2^64 - b > EPS
-}
-// both canonical -> canonical
-GL_HD uint64_t addc(uint64_t a, uint64_t b) {
-  uint64_t s = a + b;
-  return (s < a || s >= P) ? s - P : s;
-}
-GL_HD uint64_t subc(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (P - b); }
-GL_HD uint64_t negc(uint64_t a) { return a ? P - a : 0; }
-
-// 128-bit (lo, hi) -> reduced u64
-GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
-  uint64_t hh = hi >> 32, hl = hi & EPS;
-  uint64_t t0 = lo - hh;
-  if (lo < hh) t0 -= EPS;
-  uint64_t t1 = (hl << 32) - hl;  // hl * (2^32 - 1)
-  uint64_t r = t0 + t1;
-  return r < t1 ? r + EPS : r;
-}
-
-GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // four 32x32->64 multiply-adds (v_mad_u64_u32)
-  uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-  uint64_t p00 = (uint64_t)a0 * b0;
-  uint64_t mid = (uint64_t)a0 * b1 + (p00 >> 32);
-  uint64_t mid2 = (uint64_t)a1 * b0 + (uint32_t)mid;
-  hi = (uint64_t)a1 * b1 + (mid >> 32) + (mid2 >> 32);
-  lo = (mid2 << 32) | (uint32_t)p00;
-#else
-  unsigned __int128 x = (unsigned __int128)a * b;
-  lo = (uint64_t)x;
-  hi = (uint64_t)(x >> 64);
-#endif
-}
 #if defined(__HIP__)  // both passes of a HIP compilation parse these; only the device pass emits them
 // ---- carry-chain primitives (device only).  The compiler never uses the carry-out of
 // v_mad_u64_u32 and forms (x, 0) register pairs with v_mov for every 32->64-bit addend (64-bit VGPR
@@ -128,6 +83,16 @@ __device__ __forceinline__ uint32_t sel_eps(mask m) {  // m ? 2^32-1 : 0
   asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d) : "s"(m));
   return d;
 }
+__device__ __forceinline__ uint32_t add_m1_co(uint32_t a, mask& co) {  // a + (2^32 - 1)
+  uint32_t d;
+  asm("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(d), "=s"(co) : "v"(a));
+  return d;
+}
+__device__ __forceinline__ uint32_t sel(mask m, uint32_t t, uint32_t f) {  // m ? t : f
+  uint32_t d;
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(f), "v"(t), "s"(m));
+  return d;
+}
 __device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 // t (true value t + c*2^64) -> t + c*EPS; the sum cannot wrap again when t is the low word of a sum
 // of a 64-bit value and a product below 2^64 - 2^33.
@@ -141,6 +106,105 @@ __device__ __forceinline__ uint64_t fold_carry(uint64_t t, mask c) {
 #include "gl_cc.inc"  // the same instructions in groups of N = 3, 4 independent elements (no s_nop needed)
 }  // namespace cc
 #endif
+// The device forms of canon / add / sub / addc / subc are carry chains on SGPR masks (namespace cc), not the
+// compare-and-select code the compiler makes of the portable expressions: that code selects 64-bit values with
+// PAIRS of v_cndmask_b32_e32 on VCC, and on gfx950 two independent VCC-reading v_cndmask_b32_e32 back to back
+// stall for ~20 cycles (tools/issue_rate5.hip, profiles/r2_issue_rates.md: cmp + 2 cndmask_e32 = 28 cycles per
+// wave64 against 13 for the same three instructions on an SGPR pair).
+GL_HD uint64_t canon(uint64_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  cc::mask k, c;  // a + EPS carries out of 64 bits iff a >= p, and the wrapped sum is a - p
+  const uint32_t lo = cc::add_m1_co((uint32_t)a, k);
+  const uint32_t hi = cc::addc0_co((uint32_t)(a >> 32), k, c);
+  return cc::mk64(cc::sel(c, lo, (uint32_t)a), cc::sel(c, hi, (uint32_t)(a >> 32)));
+#else
+  return a >= P ? a - P : a;
+#endif
+}
+
+// a: any u64, b: canonical.  Result: reduced (any u64).
+GL_HD uint64_t add(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  cc::mask c1, c2, c3, cx;
+  const uint32_t lo = cc::add_co((uint32_t)a, (uint32_t)b, c1);
+  const uint32_t hi = cc::addc_co((uint32_t)(a >> 32), (uint32_t)(b >> 32), c1, c2);
+  const uint32_t lo2 = cc::add_co(lo, cc::sel_eps(c2), c3);  // on wrap: s < b < p so s + EPS cannot wrap again
+  return cc::mk64(lo2, cc::addc0_co(hi, c3, cx));
+#else
+  uint64_t s = a + b;
+  return s < b ? s + EPS : s;  // on wrap: s < b < p so s + EPS cannot wrap again
+#endif
+}
+// a: any u64, b: canonical.  Result: reduced.
+GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  cc::mask b1, b2, b3, bx;
+  const uint32_t lo = cc::sub_co((uint32_t)a, (uint32_t)b, b1);
+  const uint32_t hi = cc::subb_co((uint32_t)(a >> 32), (uint32_t)(b >> 32), b1, b2);
+  const uint32_t lo2 = cc::sub_co(lo, cc::sel_eps(b2), b3);  // on borrow: d = a + 2^64 - b > EPS
+  return cc::mk64(lo2, cc::subb0_co(hi, b3, bx));
+#else
+  uint64_t d = a - b;
+  return a < b ? d - EPS : d;  // on borrow: d = a + 2^64 - b > EPS
+#endif
+}
+// both canonical -> canonical
+GL_HD uint64_t addc(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // s = a + b (carry c2); t = s + EPS = s - p mod 2^64 (carry c4 iff s >= p); take t when either carried
+  // (never both: after a wrap s < p - 1).  The OR of the two masks is a scalar instruction.
+  cc::mask c1, c2, c3, c4;
+  const uint32_t lo = cc::add_co((uint32_t)a, (uint32_t)b, c1);
+  const uint32_t hi = cc::addc_co((uint32_t)(a >> 32), (uint32_t)(b >> 32), c1, c2);
+  const uint32_t tlo = cc::add_m1_co(lo, c3);
+  const uint32_t thi = cc::addc0_co(hi, c3, c4);
+  const cc::mask m = c2 | c4;
+  return cc::mk64(cc::sel(m, tlo, lo), cc::sel(m, thi, hi));
+#else
+  uint64_t s = a + b;
+  return (s < a || s >= P) ? s - P : s;
+#endif
+}
+GL_HD uint64_t subc(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return sub(a, b);  // both canonical: a - b (+ p on borrow) is already canonical
+#else
+  return a >= b ? a - b : a + (P - b);
+#endif
+}
+GL_HD uint64_t negc(uint64_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return sub(0, a);
+#else
+  return a ? P - a : 0;
+#endif
+}
+
+// 128-bit (lo, hi) -> reduced u64
+GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
+  uint64_t hh = hi >> 32, hl = hi & EPS;
+  uint64_t t0 = lo - hh;
+  if (lo < hh) t0 -= EPS;
+  uint64_t t1 = (hl << 32) - hl;  // hl * (2^32 - 1)
+  uint64_t r = t0 + t1;
+  return r < t1 ? r + EPS : r;
+}
+
+GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // four 32x32->64 multiply-adds (v_mad_u64_u32)
+  uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+  uint64_t p00 = (uint64_t)a0 * b0;
+  uint64_t mid = (uint64_t)a0 * b1 + (p00 >> 32);
+  uint64_t mid2 = (uint64_t)a1 * b0 + (uint32_t)mid;
+  hi = (uint64_t)a1 * b1 + (mid >> 32) + (mid2 >> 32);
+  lo = (mid2 << 32) | (uint32_t)p00;
+#else
+  unsigned __int128 x = (unsigned __int128)a * b;
+  lo = (uint64_t)x;
+  hi = (uint64_t)(x >> 64);
+#endif
+}
 
 // any x any -> reduced
 GL_HD uint64_t mul(uint64_t a, uint64_t b) {
@@ -213,6 +277,57 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
   cc::subb0_co(t1, cx, b3);
 #pragma unroll
   for (int i = 0; i < N; i++) r[i] = cc::mk64(t0[i], t1[i]);
+}
+#endif
+#if defined(__HIP__)
+// N (= 3 or 4) independent lazy additions / subtractions / canonicalisations, instruction-interleaved like
+// mul_n: the same carry chains as add() / sub() / canon(), no s_nop.  a: any u64, b: canonical.
+template <int N>
+__device__ __forceinline__ void add_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
+  uint32_t lo[N], hi[N], bl[N], bh[N], e[N];
+  cc::mask c1[N], c2[N], c3[N], cx[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    lo[i] = (uint32_t)a[i]; hi[i] = (uint32_t)(a[i] >> 32); bl[i] = (uint32_t)b[i]; bh[i] = (uint32_t)(b[i] >> 32);
+  }
+  cc::add_co(lo, c1, bl);
+  cc::addc_co(hi, c2, bh, c1);
+  cc::sel_eps(e, c2);
+  cc::add_co(lo, c3, e);
+  cc::addc0_co(hi, cx, c3);
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = cc::mk64(lo[i], hi[i]);
+}
+template <int N>
+__device__ __forceinline__ void sub_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
+  uint32_t lo[N], hi[N], bl[N], bh[N], e[N];
+  cc::mask b1[N], b2[N], b3[N], bx[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    lo[i] = (uint32_t)a[i]; hi[i] = (uint32_t)(a[i] >> 32); bl[i] = (uint32_t)b[i]; bh[i] = (uint32_t)(b[i] >> 32);
+  }
+  cc::sub_co(lo, b1, bl);
+  cc::subb_co(hi, b2, bh, b1);
+  cc::sel_eps(e, b2);
+  cc::sub_co(lo, b3, e);
+  cc::subb0_co(hi, bx, b3);
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = cc::mk64(lo[i], hi[i]);
+}
+template <int N>
+__device__ __forceinline__ void canon_n(uint64_t (&a)[N]) {
+  uint32_t lo[N], hi[N], tl[N], th[N];
+  cc::mask k[N], c[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    lo[i] = tl[i] = (uint32_t)a[i]; hi[i] = th[i] = (uint32_t)(a[i] >> 32);
+  }
+  cc::add_m1_co(tl, k);
+  cc::addc0_co(th, c, k);
+  cc::sel(lo, tl, c);
+  cc::sel(hi, th, c);
+#pragma unroll
+  for (int i = 0; i < N; i++) a[i] = cc::mk64(lo[i], hi[i]);
 }
 #endif
 #if defined(__HIP__)

@@ -39,16 +39,23 @@ __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const 
     if constexpr (NB % 4 == 0) {
 #pragma unroll
       for (int k0 = 0; k0 < NB; k0 += 4) {
-        uint64_t d[4], w[4], r[4];
+        uint64_t a[4], b[4], d[4], w[4], r[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
           const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);  // position in block of size S>>s
-          w[i] = tw[(uint64_t)p << (tw_shift + s)];
-          // lazily reduced values: only the operand that must be canonical is canonicalised
-          const uint64_t a = x[m], b = gl::canon(x[m + half]);
-          x[m] = gl::add(a, b);
-          d[i] = gl::sub(a, b);
+          w[i] = tw[p << (tw_shift + s)];
+          a[i] = x[m];
+          b[i] = x[m + half];
+        }
+        // lazily reduced values: only the operand that must be canonical is canonicalised
+        gl::canon_n<4>(b);
+        gl::add_n<4>(a, b, r);
+        gl::sub_n<4>(a, b, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
+          x[m] = r[i];
         }
         gl::mul_n<4>(d, w, r);
 #pragma unroll
@@ -66,7 +73,7 @@ __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const 
       for (int m = 0; m < R; m++) {
         if (m & half) continue;
         const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);
-        const uint64_t w = tw[(uint64_t)p << (tw_shift + s)];
+        const uint64_t w = tw[p << (tw_shift + s)];
         const uint64_t a = x[m], b = gl::canon(x[m + half]);
         x[m] = gl::add(a, b);
         x[m + half] = gl::mul(gl::sub(a, b), w);
@@ -84,21 +91,24 @@ __device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const 
     if constexpr (NB % 4 == 0) {
 #pragma unroll
       for (int k0 = 0; k0 < NB; k0 += 4) {
-        uint64_t v[4], w[4], r[4];
+        uint64_t a[4], v[4], w[4], r[4], hi[4], lo[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int k = k0 + i, m = (k / step) * 2 * step + (k % step);
           const uint32_t p = j + ((uint32_t)(m & (step - 1)) << log_sub);
-          w[i] = tw[(uint64_t)p << (tw_shift + (LOGR - 1 - s))];
+          w[i] = tw[p << (tw_shift + (LOGR - 1 - s))];
           v[i] = x[m + step];
+          a[i] = x[m];
         }
         gl::mul_n<4>(v, w, r);
+        gl::canon_n<4>(r);
+        gl::add_n<4>(a, r, hi);   // a: any u64, r: canonical -> lazily reduced results
+        gl::sub_n<4>(a, r, lo);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int k = k0 + i, m = (k / step) * 2 * step + (k % step);
-          const uint64_t a = x[m], t = gl::canon(r[i]);
-          x[m] = gl::add(a, t);   // a: any u64, t: canonical -> lazily reduced result
-          x[m + step] = gl::sub(a, t);
+          x[m] = hi[i];
+          x[m + step] = lo[i];
         }
         if constexpr (LOGR >= 5) __builtin_amdgcn_sched_barrier(0);  // see dif_butterflies
       }
@@ -107,7 +117,7 @@ __device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const 
       for (int m = 0; m < R; m++) {
         if (m & step) continue;
         const uint32_t p = j + ((uint32_t)(m & (step - 1)) << log_sub);
-        const uint64_t w = tw[(uint64_t)p << (tw_shift + (LOGR - 1 - s))];
+        const uint64_t w = tw[p << (tw_shift + (LOGR - 1 - s))];
         const uint64_t a = x[m], t = gl::mulc(x[m + step], w);
         x[m] = gl::add(a, t);
         x[m + step] = gl::sub(a, t);
@@ -291,12 +301,20 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
         w[i] = a.out_scalar;
       }
       gl::mul_n<4>(v, w, r);
+      gl::canon_n<4>(r);
 #pragma unroll
-      for (int i = 0; i < 4; i++) dst[(m0 + i) * T + t] = gl::canon(r[i]);
+      for (int i = 0; i < 4; i++) dst[(m0 + i) * T + t] = r[i];
     }
   } else {
 #pragma unroll
-    for (int m = 0; m < 16; m++) dst[m * T + t] = gl::canon(buf[swz<L>(m * T + t)]);
+    for (int m0 = 0; m0 < 16; m0 += 4) {
+      uint64_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[i] = buf[swz<L>((m0 + i) * T + t)];
+      gl::canon_n<4>(v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[(m0 + i) * T + t] = v[i];
+    }
   }
 }
 
@@ -369,7 +387,12 @@ __global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per
   sub_butterflies<RT, 4 - RT, false, false>(x, tw, t2, L - 4, L - RT, 0);
   uint64_t* dst = a.out + col * a.out_stride + coset * a.out_coset_stride + off;
 #pragma unroll
-  for (int m = 0; m < 16; m++) dst[m * T + t2] = gl::canon(x[m]);
+  for (int m0 = 0; m0 < 16; m0 += 4) {
+    uint64_t v[4] = {x[m0], x[m0 + 1], x[m0 + 2], x[m0 + 3]};
+    gl::canon_n<4>(v);
+#pragma unroll
+    for (int i = 0; i < 4; i++) dst[(m0 + i) * T + t2] = v[i];
+  }
 }
 
 // Strided global pass for columns taller than one LDS block: the top LOGR stages (DIF) or the

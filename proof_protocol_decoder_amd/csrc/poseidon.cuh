@@ -188,14 +188,15 @@ __device__ __forceinline__ void permute_quad(uint64_t (&e)[3], const QuadCtx& c,
     const uint64_t kmask = rnd < 29 ? ~0ULL : 0ULL;
     if (full) {
       sbox_n<3>(e);
-      // The DPP broadcasts below read registers that the asm statements above have just written: a DPP
-      // read needs 2 wait states after a VALU write of its source, and the hazard recogniser does not see
-      // writes made inside inline asm.  The dependence on e[] pins this nop between the two.
-      asm volatile("s_nop 1" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]));
     } else {
       const uint64_t sb = sbox(e[0]);  // only state word 0 (lane q == 0, slot 0) takes it
       e[0] = c.q == 0 ? sb : e[0];
     }
+    // The DPP broadcasts below read registers that asm statements have just written (the S-boxes above,
+    // and in partial rounds e[1], e[2] straight from the previous round's reduce_rows): a DPP read needs
+    // 2 wait states after a VALU write of its source, and the hazard recogniser does not see writes made
+    // inside inline asm.  The dependence on e[] pins this nop between the two on every path.
+    asm volatile("s_nop 1" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]));
     // gather the whole state: b[p + 4a] = word (p + 4a), held by lane p
     uint32_t lo[12], hi[12];
 #pragma unroll

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include "prover.hpp"
 
@@ -199,6 +200,27 @@ int rec_verify(const StarkCfg& rc, const LightCircuit& circ, const Box& b) {
   Ctl ctl;
   for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
   return stark_verify(rc, circ.cap.data(), ctl, ch, b.stark, b.stark_words);
+}
+
+// What the real aggregation / block circuits do in-circuit (prove_aggregation / prove_block verify their
+// children, proof_gen.rs:66-75, 97-103) is done on the host here: a child container is accepted only if
+// it was made by the circuit its kind names, its public inputs are canonical and its proof verifies
+// against this state's preprocessed circuit.
+int verify_child(const bp_state* s, const Box& b, const char* what) {
+  if (b.circuit != CIRCUIT_ROOT + b.kind)
+    return fail(BP_ERR_VERIFY, "%s was made by circuit %llu, expected %u", what, (unsigned long long)b.circuit,
+                CIRCUIT_ROOT + (uint32_t)b.kind);
+  for (size_t i = 0; i < b.n_pi; i++)
+    if (b.pi[i] >= gl::P) return fail(BP_ERR_VERIFY, "%s: non-canonical public input", what);
+  LightCircuit lc;
+  lc.cap = s->special[b.kind].consts.cap;
+  std::memcpy(lc.digest, s->special[b.kind].digest, 32);
+  int r = rec_verify(s->rec_cfg, lc, b);
+  if (r) {
+    const std::string why = bp_last_error();
+    return fail(BP_ERR_VERIFY, "%s does not verify: %s", what, why.c_str());
+  }
+  return BP_OK;
 }
 
 void root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]) {
@@ -469,6 +491,7 @@ int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len,
                                       (unsigned long long)L.pv[1], (unsigned long long)R.pv[0]);
   if (L.pv[3] != R.pv[2] || std::memcmp(L.pv + 8, R.pv + 4, 32) != 0 || L.pv[12] != R.pv[12])
     return fail(BP_ERR_INVALID_INPUT, "children public values do not chain (gas / state root / block number)");
+  if ((r = verify_child(s, L, "lhs child proof")) || (r = verify_child(s, R, "rhs child proof"))) return r;
   std::vector<uint64_t> pi(10 + BP_PV_WORDS);
   proof_digest(s->rec_cfg, L.stark, &pi[0]);
   proof_digest(s->rec_cfg, R.stark, &pi[4]);
@@ -498,9 +521,11 @@ int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t par
     if (Pb.kind != 2) return fail(BP_ERR_INVALID_INPUT, "parent is not a block proof");
     if (Pb.pv[12] + 1 != A.pv[12]) return fail(BP_ERR_INVALID_INPUT, "parent block height %llu does not precede %llu",
                                                 (unsigned long long)Pb.pv[12], (unsigned long long)A.pv[12]);
+    if ((r = verify_child(s, Pb, "parent block proof"))) return r;
     proof_digest(s->rec_cfg, Pb.stark, &pi[0]);
     pi[8] = 1;
   }
+  if ((r = verify_child(s, A, "curr_block_agg_proof"))) return r;
   proof_digest(s->rec_cfg, A.stark, &pi[4]);
   std::memcpy(&pi[9], A.pv, BP_PV_WORDS * 8);
   (void)hipSetDevice(s->cfg.device);

@@ -67,6 +67,9 @@ int check_cfg(const StarkCfg& c) {
   if (c.arity_bits != 4) return fail(BP_ERR_UNSUPPORTED, "only arity_bits = 4 is built");
   if (c.num_queries == 0 || c.num_queries > 128) return fail(BP_ERR_INVALID_INPUT, "num_queries out of range");
   if (c.pow_bits > 32 || c.cap_height > 8) return fail(BP_ERR_INVALID_INPUT, "pow_bits/cap_height out of range");
+  // the final polynomial is interpolated on the host in O(len^2): at most 256 points by design
+  if (c.final_poly_bits > 8) return fail(BP_ERR_INVALID_INPUT, "final_poly_bits must be <= 8");
+  if (c.n_const > 4096) return fail(BP_ERR_INVALID_INPUT, "n_const out of range");
   if (n_fri_layers(c) > 8) return fail(BP_ERR_INVALID_INPUT, "too many FRI layers");
   return BP_OK;
 }
@@ -507,7 +510,7 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
     uint64_t nonce = 0;
     if (cfg.pow_bits) {
       // expected 2^pow_bits candidates: first batch 2x that (86% hit), then grow to 2^20
-      uint32_t batch = std::min<uint32_t>(1u << 20, std::max<uint32_t>(1u << 12, 2u << cfg.pow_bits));
+      uint32_t batch = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 12, (uint64_t)2 << cfg.pow_bits));
       unsigned long long res = ~0ULL;
       BPG_HIP(hipMemsetAsync(w.d_pow_result, 0xFF, 8, st));
       for (uint64_t base = 0;; base += batch, batch = std::min<uint32_t>(1u << 20, batch * 2)) {

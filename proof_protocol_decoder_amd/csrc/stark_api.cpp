@@ -200,7 +200,7 @@ int bp_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t
   int rc = BP_OK;
   unsigned long long res = ~0ULL;
   if (hipMemsetAsync(d_res, 0xFF, 8, st) != hipSuccess) rc = fail(BP_ERR_DEVICE, "hipMemsetAsync failed");
-  uint32_t batch = std::min<uint32_t>(1u << 20, std::max<uint32_t>(1u << 12, 2u << bits));
+  uint32_t batch = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 12, (uint64_t)2 << bits));
   for (uint64_t base = 0; rc == BP_OK; base += batch, batch = std::min<uint32_t>(1u << 20, batch * 2)) {
     pa.base = base;
     if ((rc = launch_pow(pa, batch, d_res, st))) break;
