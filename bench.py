@@ -33,7 +33,22 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
 S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
-TRAFFIC_OVER_ALGORITHMIC = 1.138  # PMC over this very leg: profiles/r1b_pmc_lde_family.txt
+# HBM traffic / algorithmic bytes of the roofline leg's launches comes from a PMC measurement kept under profiles/
+# (two rocprofv3 --pmc passes of this same command, tools/pmc_family_traffic.py).  bench.py cannot collect
+# counters itself, so it reads the tracked summary and names it (and the commit it was taken at) beside the
+# number; no file, no number.
+TRAFFIC_FILE = os.path.join("profiles", "r2_pmc_lde_family.txt")
+
+
+def traffic_ratio():
+    import re
+    try:
+        txt = open(os.path.join(ROOT, TRAFFIC_FILE)).read()
+        ratio = float(re.search(r"= ([0-9.]+) x algorithmic", txt).group(1))
+        head = re.search(r"HEAD ([0-9a-f]+)", txt)
+        return ratio, (head.group(1) if head else None)
+    except (OSError, AttributeError, ValueError):
+        return None, None
 
 
 def main():
@@ -99,12 +114,15 @@ def main():
         if not n.value:
             return None
         ach = by.value / (ms.value * 1e-3) / 1e9
+        ratio, head = traffic_ratio()
         return {"bound": "hbm", "kernel": "coset-LDE NTT family: ntt16_dit_kernel<12|13|14> + ntt_lds_kernel<DIT>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 # HBM bytes per launch = algorithmic x the ratio that two rocprofv3 --pmc passes (FETCH_SIZE x2,
                 # WRITE_SIZE) of this same command measured over the launches of the single-stream leg
-                # (tools/pmc_family_traffic.py; the leg is bracketed by marker dispatches): 36.38 / 31.98 MB
-                "traffic": round(by.value / n.value * TRAFFIC_OVER_ALGORITHMIC),
+                # (tools/pmc_family_traffic.py; the leg is bracketed by marker dispatches)
+                "traffic": round(by.value / n.value * ratio) if ratio else None,
+                "traffic_source": ("%s (PMC passes taken at HEAD %s)" % (TRAFFIC_FILE, head)) if ratio else
+                                  "no PMC summary under profiles/ for this code",
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "alg_bytes_per_launch": round(by.value / n.value), "note": note}
 
@@ -298,12 +316,19 @@ def cpu_baseline(ir):
                           shrink_depth=3)
     import struct
     words = list(struct.unpack("<25Q", ir.to_bytes()))
+    # like for like with the GPU figure, which excludes bp_state_build: the eight circuits this txn touches are
+    # preprocessed BEFORE the clock starts (the oracle builds circuits lazily) and that time is reported beside it
+    t0 = time.perf_counter()
+    st.preprocess(words)
+    t_pre = time.perf_counter() - t0
     t0 = time.perf_counter()
     st.txn(words)
     dt = time.perf_counter() - t0
     return {"value": round(1.0 / dt, 4), "unit": "txn-proofs/s", "cores": cores, "kind": "port",
-            "sample": "1 txn proof of the same block (7 tables + 22 recursion-shaped proofs), incl. lazy "
-                      "preprocessing of the 8 circuits it touches; %.1f s" % dt}
+            "sample": "1 txn proof of the same block (7 tables + 22 recursion-shaped proofs) on a warm state: %.1f s; "
+                      "preprocessing of the 8 circuits it touches, not in the figure: %.1f s" % (dt, t_pre),
+            "seconds_per_txn": round(dt, 2), "preprocess_s_excluded": round(t_pre, 2),
+            "value_incl_preprocessing": round(1.0 / (dt + t_pre), 4)}
 
 
 if __name__ == "__main__":

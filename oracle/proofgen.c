@@ -116,6 +116,18 @@ static gl_t* emit_box(uint64_t kind, const gl_t* pi, size_t n_pi, const gl_t* st
   return o;
 }
 
+/* Preprocess now what a txn proof of this IR will touch (its seven table circuits and the root circuit), as
+ * libbpg's eager bp_state_build has done before any proof is timed.  Lets a caller time orc_pg_txn alone. */
+int orc_pg_preprocess(orc_pg_state* s, const uint64_t* I) {
+  if (I[0] != IR_MAGIC) return -2;
+  for (int t = 0; t < NUM_TABLES; t++) {
+    if (I[11 + t] < s->cfg.table_log_lo[t] || I[11 + t] >= s->cfg.table_log_hi[t]) return -3;
+    table_circuit(s, t, (uint32_t)I[11 + t]);
+  }
+  special_circuit(s, 0);
+  return 0;
+}
+
 /* generate_txn_proof (proof_gen.rs:39-56) on the synthetic workload */
 int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) {
   const orc_pg_config* cfg = &s->cfg;

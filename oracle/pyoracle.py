@@ -105,6 +105,7 @@ def lib():
     L.orc_pg_state_build.restype = vp
     L.orc_pg_state_free.argtypes = [vp]
     L.orc_pg_txn.argtypes = [vp, u64p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_pg_preprocess.argtypes = [vp, u64p]
     L.orc_pg_agg.argtypes = [vp, u64p, sz, i, u64p, sz, i, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_block.argtypes = [vp, vp, sz, u64p, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_verify.argtypes = [vp, u64p, sz]
@@ -316,6 +317,12 @@ class PgState:
         out = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
         lib().orc_free(ptr)
         return out
+
+    def preprocess(self, ir_words):
+        """Build the circuits a txn proof of this IR touches (lazy otherwise), so the proof can be timed alone."""
+        rc = lib().orc_pg_preprocess(self.h, arr(ir_words))
+        if rc:
+            raise RuntimeError("orc_pg_preprocess failed: %d" % rc)
 
     def txn(self, ir_words):
         ptr, n = C.POINTER(C.c_uint64)(), C.c_size_t()

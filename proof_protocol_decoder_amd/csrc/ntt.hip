@@ -416,8 +416,96 @@ ntt_global_pass_kernel(const uint64_t* in, uint64_t in_stride, uint64_t* out, ui
   for (int m = 0; m < R; m++) x[m] = src[(uint64_t)m << log_sub];
   if (DIF) dif_butterflies<LOGR>(x, tw, j, log_sub, log_n - span_log);
   else dit_butterflies<LOGR>(x, tw, j, log_sub, log_n - span_log);
+  if constexpr (R % 4 == 0) {
 #pragma unroll
-  for (int m = 0; m < R; m++) dst[(uint64_t)m << log_sub] = gl::canon(x[m]);
+    for (int m0 = 0; m0 < R; m0 += 4) {
+      uint64_t v[4] = {x[m0], x[m0 + 1], x[m0 + 2], x[m0 + 3]};
+      gl::canon_n<4>(v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[(uint64_t)(m0 + i) << log_sub] = v[i];
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < R; m++) dst[(uint64_t)m << log_sub] = gl::canon(x[m]);
+  }
+}
+
+
+// Column pass THROUGH LDS for tall columns: the top A (6..8) stages of the DIF transform, or the last A stages of
+// the DIT one, in one HBM round trip (the register pass above tops out at five stages: 32 elements per lane).
+// The stage block (2^span_log elements) is viewed as R = 2^A rows of S = 2^(span_log - A) elements; a workgroup
+// takes 16 adjacent elements of every row (128-byte segments: a wave touches four full cache lines per access)
+// = R x 16 elements in LDS, and runs the R-point transform down each of its 16 columns as one radix-16 register
+// pass over rows q + m*R/16 and one radix-2^(A-4) pass over the R/16 consecutive rows of a sub-block, with an
+// LDS exchange between the two.  Row segments of a quarter wave are contiguous in LDS in both layouts.
+// grid = (tiles per column = n / (R*16), columns, cosets), block = R threads.
+template <int A, bool DIF>
+__global__ void __launch_bounds__(1 << A)
+ntt_tile_kernel(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride, uint64_t coset_stride,
+                uint32_t log_n, uint32_t span_log, const uint64_t* __restrict__ tw) {
+  constexpr int R = 1 << A, B = A - 4, R1 = 1 << B, G = 16 / R1;  // R1 rows per sub-block, G sub-blocks per lane
+  __shared__ uint64_t tile[R * 16];
+  const uint32_t log_s = span_log - A;                     // S = elements per row
+  const uint32_t tiles_per_blk = 1u << (log_s - 4);
+  const uint32_t blk = blockIdx.x / tiles_per_blk, s0 = (blockIdx.x % tiles_per_blk) << 4;
+  const uint32_t s = threadIdx.x & 15, hi = threadIdx.x >> 4;  // hi: q in [0, R/16) for the radix-16 pass
+  const uint64_t base = ((uint64_t)blk << span_log) + s0 + s;
+  const uint64_t* src = in + blockIdx.y * in_stride + blockIdx.z * coset_stride + base;
+  uint64_t* dst = out + blockIdx.y * out_stride + blockIdx.z * coset_stride + base;
+  const uint32_t j16 = (hi << log_s) + s0 + s;             // position of row `hi` modulo the radix-16 stride
+  uint64_t x[16];
+  if (DIF) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = src[(uint64_t)(hi + m * (R / 16)) << log_s];
+    dif_butterflies<4>(x, tw, j16, span_log - 4, log_n - span_log);
+#pragma unroll
+    for (int m = 0; m < 16; m++) tile[(hi + m * (R / 16)) * 16 + s] = x[m];
+    __syncthreads();
+    // sub-blocks hi*G + g, rows (hi*G + g)*R1 + u
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = tile[(hi * 16 + m) * 16 + s];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      uint64_t y[R1];
+#pragma unroll
+      for (int u = 0; u < R1; u++) y[u] = x[g * R1 + u];
+      dif_butterflies<B>(y, tw, s0 + s, log_s, log_n - span_log + 4);
+#pragma unroll
+      for (int u = 0; u < R1; u++) x[g * R1 + u] = y[u];
+    }
+#pragma unroll
+    for (int m0 = 0; m0 < 16; m0 += 4) {
+      uint64_t v[4] = {x[m0], x[m0 + 1], x[m0 + 2], x[m0 + 3]};
+      gl::canon_n<4>(v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[(uint64_t)(hi * 16 + m0 + i) << log_s] = v[i];
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = src[(uint64_t)(hi * 16 + m) << log_s];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      uint64_t y[R1];
+#pragma unroll
+      for (int u = 0; u < R1; u++) y[u] = x[g * R1 + u];
+      dit_butterflies<B>(y, tw, s0 + s, log_s, log_n - span_log + 4);
+#pragma unroll
+      for (int u = 0; u < R1; u++) x[g * R1 + u] = y[u];
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) tile[(hi * 16 + m) * 16 + s] = x[m];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = tile[(hi + m * (R / 16)) * 16 + s];
+    dit_butterflies<4>(x, tw, j16, span_log - 4, log_n - span_log);
+#pragma unroll
+    for (int m0 = 0; m0 < 16; m0 += 4) {
+      uint64_t v[4] = {x[m0], x[m0 + 1], x[m0 + 2], x[m0 + 3]};
+      gl::canon_n<4>(v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[(uint64_t)(hi + (m0 + i) * (R / 16)) << log_s] = v[i];
+    }
+  }
 }
 
 // table builders ------------------------------------------------------------------------------
@@ -493,6 +581,36 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
   return BP_OK;
 }
 
+// Plan for a column of 2^log_n elements: the LDS-resident block size and the global passes that come before it
+// (DIF) or after it (DIT).  Columns up to 2^14 are one block.  The 2^12-point LDS kernel is the most efficient one
+// (four workgroups per CU: load / compute / store of different workgroups overlap), so taller columns use the
+// smallest block that ONE global pass allows: a register pass of up to five stages (log_n <= 17), the LDS tile
+// pass of six to eight stages (log_n <= 22); beyond that register passes come on top (2^23..2^27: three round
+// trips, 2^28..2^30: four).
+struct NttPlan {
+  uint32_t log_blk;      // LDS block
+  uint32_t tile_bits;    // stages of the tile pass (0 = none), acting on span log_blk + tile_bits
+  uint32_t n_reg;        // register passes above that
+  uint32_t reg_bits[4];  // from the outermost span (log_n) inwards
+};
+static NttPlan plan_ntt(uint32_t log_n) {
+  NttPlan p{};
+  if (log_n <= LOG_BLK_MAX) { p.log_blk = log_n; return p; }
+  if (log_n <= 17) { p.log_blk = 12; p.n_reg = 1; p.reg_bits[0] = log_n - 12; return p; }
+  if (log_n <= 20) { p.log_blk = 12; p.tile_bits = log_n - 12; return p; }
+  if (log_n <= 22) { p.log_blk = log_n - 8; p.tile_bits = 8; return p; }
+  p.log_blk = 14; p.tile_bits = 8;
+  uint32_t left = log_n - 22;
+  p.n_reg = (left + 4) / 5;
+  for (uint32_t i = 0; i < p.n_reg; i++) {
+    const uint32_t k = (left + (p.n_reg - i) - 1) / (p.n_reg - i);
+    p.reg_bits[i] = k;
+    left -= k;
+  }
+  return p;
+}
+static uint32_t pick_log_blk(uint32_t log_n) { return plan_ntt(log_n).log_blk; }
+
 static uint32_t lds_threads(uint32_t log_blk) {
   uint32_t t = log_blk >= 3 ? (1u << (log_blk - 3)) : 1;
   return t < 64 ? 64 : (t > 1024 ? 1024 : t);
@@ -501,32 +619,34 @@ static uint32_t lds_threads(uint32_t log_blk) {
 template <bool DIF>
 static int launch_global_passes(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride,
                                 uint64_t coset_stride, uint32_t n_cols, uint32_t n_cosets, uint32_t log_n,
-                                const uint64_t* tw, hipStream_t st) {
-  // DIF: spans log_n, log_n-k1, ... down to > LOG_BLK_MAX;  DIT: the same spans in reverse order.
-  // As few passes as possible (each one streams the whole column through HBM): up to 5 bits (32
-  // elements per lane; 64 spill to scratch) per pass, split evenly.
-  uint32_t spans[8], radix[8], cnt = 0;
-  {
-    const uint32_t extra = log_n - LOG_BLK_MAX, n_pass = (extra + 4) / 5;
-    uint32_t span = log_n, left = extra;
-    for (uint32_t i = 0; i < n_pass; i++) {
-      const uint32_t k = (left + (n_pass - i) - 1) / (n_pass - i);
-      spans[cnt] = span; radix[cnt] = k; cnt++;
-      span -= k;
-      left -= k;
-    }
-  }
+                                uint32_t log_blk, const uint64_t* tw, hipStream_t st) {
+  // DIF: spans log_n, log_n-k1, ... down to > log_blk;  DIT: the same passes in reverse order.
+  const NttPlan p = plan_ntt(log_n);
+  uint32_t spans[8], bits[8], tiled[8], cnt = 0;
+  uint32_t span = log_n;
+  for (uint32_t i = 0; i < p.n_reg; i++) { spans[cnt] = span; bits[cnt] = p.reg_bits[i]; tiled[cnt] = 0; cnt++; span -= p.reg_bits[i]; }
+  if (p.tile_bits) { spans[cnt] = span; bits[cnt] = p.tile_bits; tiled[cnt] = 1; cnt++; span -= p.tile_bits; }
+  if (span != log_blk || log_blk != p.log_blk) return fail(BP_ERR_DEVICE, "NTT plan mismatch (log_n=%u)", log_n);
   for (uint32_t idx = 0; idx < cnt; idx++) {
-    uint32_t i = DIF ? idx : cnt - 1 - idx;
+    const uint32_t i = DIF ? idx : cnt - 1 - idx;
     const uint64_t* src = (idx == 0) ? in : out;
-    uint64_t src_stride = (idx == 0) ? in_stride : out_stride;
-    dim3 grid(ceil_div((uint64_t)1 << (log_n - radix[i]), 256), n_cols, n_cosets);
-    switch (radix[i]) {
-      case 1: ntt_global_pass_kernel<1, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
-      case 2: ntt_global_pass_kernel<2, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
-      case 3: ntt_global_pass_kernel<3, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
-      case 4: ntt_global_pass_kernel<4, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
-      default: ntt_global_pass_kernel<5, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+    const uint64_t src_stride = (idx == 0) ? in_stride : out_stride;
+    if (tiled[i]) {
+      const dim3 grid(1u << (log_n - bits[i] - 4), n_cols, n_cosets);
+      switch (bits[i]) {
+        case 6: ntt_tile_kernel<6, DIF><<<grid, 64, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+        case 7: ntt_tile_kernel<7, DIF><<<grid, 128, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+        default: ntt_tile_kernel<8, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+      }
+    } else {
+      const dim3 grid(ceil_div((uint64_t)1 << (log_n - bits[i]), 256), n_cols, n_cosets);
+      switch (bits[i]) {
+        case 1: ntt_global_pass_kernel<1, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+        case 2: ntt_global_pass_kernel<2, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+        case 3: ntt_global_pass_kernel<3, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+        case 4: ntt_global_pass_kernel<4, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+        default: ntt_global_pass_kernel<5, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+      }
     }
     BPG_LAUNCH_CHECK();
   }
@@ -537,7 +657,7 @@ static int launch_global_passes(const uint64_t* in, uint64_t in_stride, uint64_t
 int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t out_stride, uint32_t log_n,
                 uint32_t n_cols, bool inverse, hipStream_t st) {
   if (n_cols == 0) return BP_OK;
-  const uint32_t log_blk = log_n < LOG_BLK_MAX ? log_n : LOG_BLK_MAX;
+  const uint32_t log_blk = pick_log_blk(log_n);
   const uint64_t *tw_n = nullptr, *tw_b = nullptr;
   int rc;
   if ((rc = get_table(inverse ? 1 : 0, log_blk, 0, &tw_b))) return rc;
@@ -545,7 +665,7 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
   uint64_t src_stride = in_stride;
   if (log_n > LOG_BLK_MAX) {
     if ((rc = get_table(inverse ? 1 : 0, log_n, 0, &tw_n))) return rc;
-    if ((rc = launch_global_passes<true>(in, in_stride, out, out_stride, 0, n_cols, 1, log_n, tw_n, st))) return rc;
+    if ((rc = launch_global_passes<true>(in, in_stride, out, out_stride, 0, n_cols, 1, log_n, log_blk, tw_n, st))) return rc;
     src = out;
     src_stride = out_stride;
   }
@@ -583,7 +703,7 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
                uint32_t log_n, uint32_t n_cols, uint32_t n_cosets, const uint64_t* scale, bool inverse,
                hipStream_t st) {
   if (n_cols == 0) return BP_OK;
-  const uint32_t log_blk = log_n < LOG_BLK_MAX ? log_n : LOG_BLK_MAX;
+  const uint32_t log_blk = pick_log_blk(log_n);
   const uint64_t *tw_n = nullptr, *tw_b = nullptr;
   int rc;
   if ((rc = get_table(inverse ? 1 : 0, log_blk, 0, &tw_b))) return rc;
@@ -616,7 +736,7 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
   if (log_n > LOG_BLK_MAX) {
     if ((rc = get_table(inverse ? 1 : 0, log_n, 0, &tw_n))) return rc;
     if ((rc = launch_global_passes<false>(out, out_stride, out, out_stride, coset_stride, n_cols, n_cosets, log_n,
-                                          tw_n, st)))
+                                          log_blk, tw_n, st)))
       return rc;
   }
   return BP_OK;

@@ -215,3 +215,150 @@ def test_dummy_entries_and_short_blocks(bpg, pg, p_state, o_state):
             assert pv1.txn_number_after == 1 and pv1.gas_used_after == 21000 and pv1.state_root_after != (5, 6, 7, 8)
     finally:
         drv.close()
+
+
+def test_agg_and_block_refuse_children_that_do_not_verify(pg, p_state, chain):
+    """prove_aggregation / prove_block verify their children in-circuit (proof_gen.rs:66-75, 97-103); here the same
+    check runs on the host before aggregating: a child whose STARK words or public values were tampered with, or
+    that claims another circuit, is refused with BP_ERR_VERIFY and nothing is proven on top of it."""
+    t0, t1, t2, a01, a012, blk = chain
+    w = words(t1.intern).copy()
+    w[w.size // 2] ^= np.uint64(4)                         # garbage inside the STARK words
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_agg_proof(p_state, t0, pg.GeneratedTxnProof(t1.p_vals, w.tobytes()))
+    assert e.value.code == -5 and "rhs child" in e.value.message
+    # forged public values that still chain (gas_after of the right child): contiguity passes, verification must not
+    n_pi = int(words(t1.intern)[2])
+    f = words(t1.intern).copy()
+    f[4 + n_pi - 13 + 3] += np.uint64(1)
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_agg_proof(p_state, t0, pg.GeneratedTxnProof(t1.p_vals, f.tobytes()))
+    assert e.value.code == -5
+    c = words(a01.intern).copy()
+    c[3] = 7                                              # an agg container claiming the root circuit
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_agg_proof(p_state, pg.GeneratedAggProof(a01.p_vals, c.tobytes()), t2)
+    assert e.value.code == -5
+    g = words(a012.intern).copy()
+    g[-5] ^= np.uint64(1)
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_block_proof(p_state, None, pg.GeneratedAggProof(a012.p_vals, g.tobytes()))
+    assert e.value.code == -5
+    pb = words(blk.intern).copy()
+    pb[-9] ^= np.uint64(1 << 33)
+    nxt0 = pg.generate_txn_proof(p_state, make_ir(pg, 8, 0, 0x5EED0101))
+    nxt1 = pg.generate_txn_proof(p_state, make_ir(pg, 8, 1, 0x5EED0102, root=nxt0.p_vals.state_root_after, gas=(121, 130)))
+    agg = pg.generate_agg_proof(p_state, nxt0, nxt1)
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_block_proof(p_state, pg.GeneratedBlockProof(7, pb.tobytes()), agg)
+    assert e.value.code == -5 and "parent" in e.value.message
+
+
+S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
+S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
+
+
+def _sha(b):
+    import hashlib
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def test_block16_at_default_config_matches_golden(bpg, pg, oracle):
+    """BASELINE configs[1]: a 16-txn synthetic block of S1 (transfer-txn sized) transactions through L1 at
+    bp_config_default parameters (standard_fast_config: 84 queries, 16 PoW bits; recursion shape 2^13 x 135, 28
+    queries; default table ranges of constants.rs:6-18), one GPU.  Byte parity: txn proofs 0, 1 and 15, the
+    aggregation of 0 and 1 and the block proof of {0, 1} equal the oracle's (digests made in the build container by
+    tools/gen_hotpath_golden.py); the 16-txn block proof from BlockDriver.prove_block_distributed is accepted by
+    both verifiers."""
+    import json
+    import os
+    from proof_protocol_decoder_amd.block_driver import BlockDriver, synthetic_block_irs
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_golden.json")))["block16"]
+    st = pg.ProverStateBuilder().set(n_workers=8, arena_bytes=5 << 30).build()
+    try:
+        irs = synthetic_block_irs(gold["block_number"], 16, S1_LOG_N, S1_WIDTH)
+        assert list(struct.unpack("<25Q", irs[15].to_bytes())) == gold["ir15"]     # the chain the oracle was given
+        drv = BlockDriver(st, n_threads=8)
+        try:
+            top, txns = drv.prove_shard(irs)
+            blk = drv.prove_block_distributed(irs)
+        finally:
+            drv.close()
+        for i in (0, 1, 15):
+            assert words(txns[i].intern).size == gold["txn%d" % i]["n_words"]
+            assert _sha(txns[i].intern) == gold["txn%d" % i]["sha256"], "txn %d differs from the oracle's proof" % i
+        a01 = pg.generate_agg_proof(st, txns[0], txns[1])
+        assert _sha(a01.intern) == gold["agg_0_1"]["sha256"]
+        b01 = pg.generate_block_proof(st, None, a01)
+        assert _sha(b01.intern) == gold["block_of_0_1"]["sha256"]
+        pv, kind = pg.public_values_of(blk.intern)
+        assert kind == 2 and (pv.txn_number_before, pv.txn_number_after) == (0, 16) and pv.gas_used_after == 16 * 21000
+        assert pv.state_root_after == txns[15].p_vals.state_root_after and blk.b_height == gold["block_number"]
+        assert blk.intern == pg.generate_block_proof(st, None, top).intern           # same tree either way
+        pg.VerifierState.from_prover_state(st).verify(blk)
+        ost = oracle.PgState(table_log_lo=list(S1_LOG_N), table_log_hi=[x + 1 for x in S1_LOG_N], stark_rate_bits=1,
+                             stark_cap_height=4, stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5,
+                             rec_log_n=13, rec_n_cols=135, rec_n_const=82, rec_rate_bits=3, rec_num_queries=28,
+                             rec_pow_bits=16, shrink_depth=3)
+        assert ost.verify(words(blk.intern)) == 0
+        assert ost.verify(words(txns[7].intern)) == 0
+    finally:
+        st.close()
+
+
+RCCL_CHILD = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+import torch, torch.distributed as dist
+import proof_protocol_decoder_amd as pkg
+from proof_protocol_decoder_amd import proof_gen as pg
+from proof_protocol_decoder_amd.block_driver import BlockDriver, TorchGather, synthetic_block_irs
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+from pg_common import LOG_N, SMALL, WIDTH
+rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+pkg.lib().bp_use_blocking_sync(local_rank)
+torch.cuda.set_device(local_rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # bench.py's exact branch
+dev = torch.device("cuda", local_rank)
+b = pg.ProverStateBuilder()
+for t, name in enumerate(pg.TABLES):
+    getattr(b, "set_%s_circuit_size" % name)(range(SMALL["table_log_lo"][t], SMALL["table_log_hi"][t]))
+b.set(**{{k: v for k, v in SMALL.items() if not k.startswith("table_")}}, device=local_rank, n_workers=2, arena_bytes=256 << 20)
+st = b.build()
+drv = BlockDriver(st, n_threads=2)
+irs = synthetic_block_irs(31, 4, LOG_N, WIDTH)
+dist.barrier(); torch.cuda.synchronize()
+blk = drv.prove_block_distributed(irs, rank, world, TorchGather(dev))
+torch.cuda.synchronize(); dist.barrier()
+t = torch.tensor([1.25 + rank], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                                          # bench.py's max-over-ranks timing
+assert abs(t.item() - (1.25 + world - 1)) < 1e-9
+raws = TorchGather(dev).gather_bytes(b"rank%d" % rank)
+if rank == 0:
+    assert raws == [b"rank%d" % r for r in range(world)]
+    pg.VerifierState.from_prover_state(st).verify(blk)
+    pv, kind = pg.public_values_of(blk.intern)
+    assert kind == 2 and pv.txn_number_after == 4
+    print("RCCL_PATH_OK backend=%s world=%d" % (dist.get_backend(), world))
+drv.close(); st.close()
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_branch_of_the_bench_runs_at_world_size_1(tmp_path):
+    """bench.py's multi-GPU branch -- init_process_group("nccl", device_id=...), TorchGather on a cuda device
+    (all_gather of lengths + padded uint8 gather), all_reduce(MAX) -- executed for real on the one GPU this box
+    has: a fresh child process under torch.distributed.run (started before it touches the GPU), world size 1,
+    4-txn block, block proof verified.  The 8-GPU curve itself is the driver's to measure."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_child.py"
+    script.write_text(RCCL_CHILD.format(root=root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_PATH_OK backend=nccl world=1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -17,7 +17,7 @@ def fadd(a, b):
     return np.where((s < a) | (s >= np.uint64(P)), s - np.uint64(P), s)
 
 
-@pytest.mark.parametrize("log_n,n_cols", [(14, 64), (16, 16), (20, 4), (22, 2)])
+@pytest.mark.parametrize("log_n,n_cols", [(14, 64), (16, 16), (18, 3), (20, 4), (22, 2), (24, 2)])
 def test_ntt_round_trip_and_linearity(bpg, log_n, n_cols):
     rng = np.random.default_rng(log_n)
     a = rand_field(rng, (n_cols, 1 << log_n))

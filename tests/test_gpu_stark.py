@@ -1,4 +1,6 @@
 """GPU parity of the whole per-table prover (K2-K9) against the oracle: identical proof words."""
+import hashlib
+
 import numpy as np
 import pytest
 
@@ -93,10 +95,10 @@ FULL_SIZE = [
 
 
 @pytest.mark.parametrize("shape", FULL_SIZE, ids=lambda c: "logn%d_C%d" % c[:2])
-def test_full_size_table_proofs_are_accepted_by_the_oracle_verifier(bpg, oracle, shape):
-    """At BASELINE sizes the oracle prover is too slow to run per test, but its verifier is not:
-    a full-size GPU proof must verify (all queries, Merkle paths, FRI consistency, constraint check
-    at zeta), and stop verifying after a single bit flip."""
+def test_full_size_table_proofs_match_the_oracle(bpg, oracle, shape):
+    """At BASELINE sizes the oracle prover is too slow to run per test (its verifier is not): a full-size GPU
+    proof must verify (all queries, Merkle paths, FRI consistency, constraint check at zeta), stop verifying
+    after a single bit flip, and equal the oracle's own proof byte for byte (committed digest)."""
     log_n, C, K, e, r = shape
     nq = 84 if K == 0 else 28
     seed, const_seed = 0x5EED000000000000 + C, 99
@@ -119,3 +121,46 @@ def test_full_size_table_proofs_are_accepted_by_the_oracle_verifier(bpg, oracle,
     bad[got.size // 2] ^= np.uint64(2)
     ch, ctl = prologue(bad)
     assert oracle.stark_verify(cfg, bad, ctl, ch, const_cap) != 0
+    # byte parity at full size: the oracle's proof of the same table, made in the build container by
+    # tools/gen_hotpath_golden.py and committed as a digest
+    want = _golden()["tables"]["logn%d_C%d" % (log_n, C)]
+    assert want["shape"] == list(shape) and got.size == want["n_words"]
+    assert [int(x) for x in got[:6]] == want["head"] and [int(x) for x in got[-2:]] == want["tail"]
+    assert hashlib.sha256(np.ascontiguousarray(got, dtype="<u8").tobytes()).hexdigest() == want["sha256"]
+
+
+def _golden():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_golden.json")))
+
+
+def test_keccak_wide_table_2e20_x_2432(bpg, oracle):
+    """BASELINE configs[3]: one Keccak-wide table, 2^20 rows x 2432 columns, rate 2,
+    on one GPU (~100 GB of device memory: 20 GB trace, coefficients, 41 GB LDE, digests).  The oracle PROVER cannot
+    run this size in the build container (64 GB of host memory), so parity here is what the domain offers at full
+    size: the oracle's verifier accepts every query / Merkle path / FRI layer / the constraint check at zeta, a
+    single flipped bit is rejected, and a second run gives identical bytes."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120e9:
+        pytest.skip("needs ~100 GB of free device memory, %.0f GB free" % (free / 1e9))
+    log_n, C = 20, 2432
+    try:
+        got = bpg.ops.stark_prove_synthetic(bpg.ops.stark_cfg(log_n, C), 0x5EED000000000004)
+        again = bpg.ops.stark_prove_synthetic(bpg.ops.stark_cfg(log_n, C), 0x5EED000000000004)
+    finally:
+        bpg.lib().bp_release_cached_memory()
+    assert (got == again).all()
+    cfg = oracle.make_cfg(log_n, C)
+
+    def prologue(proof):
+        ch = oracle.PyChallenger()
+        ch.observe(proof[16:16 + 64])
+        return ch, np.array([ch.challenge() for _ in range(4)], dtype=np.uint64)
+    ch, ctl = prologue(got)
+    assert oracle.stark_verify(cfg, got, ctl, ch, None) == 0
+    bad = got.copy()
+    bad[got.size // 3] ^= np.uint64(1 << 17)
+    ch, ctl = prologue(bad)
+    assert oracle.stark_verify(cfg, bad, ctl, ch, None) != 0

@@ -149,19 +149,35 @@ def prove_block(parent, agg):
 L = pg._bind()
 L.bp_state_root_after.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
 irs, root, gas = [], (1, 2, 3, 4), 0
-for i in range(5):
+N_TXNS, FAIL_RANK = {n_txns}, {fail_rank}
+for i in range(N_TXNS):
     seed = 0x5EED1000 + i
     irs.append(ir_words(11, i, seed, root_before=root, gas=(gas, gas + 7)))
     out = (C.c_uint64 * 4)()
     assert L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out) == 0
     root, gas = tuple(out), gas + 7
+if rank == FAIL_RANK:
+    def prove_txn(ir): raise RuntimeError("injected failure on rank %d" % rank)
 drv = BlockDriver(n_threads=2, prove_txn=prove_txn, prove_agg=prove_agg, prove_block=prove_block)
+if FAIL_RANK >= 0:
+    from proof_protocol_decoder_amd.block_driver import ShardFailed
+    try:
+        drv.prove_block_distributed(irs, rank, world, TorchGather(torch.device("cpu")))
+    except ShardFailed as e:
+        assert rank != FAIL_RANK and str(FAIL_RANK) in str(e)
+    except RuntimeError as e:
+        assert rank == FAIL_RANK and "injected" in str(e)
+    else:
+        raise SystemExit("rank %d: no exception although rank %d failed" % (rank, FAIL_RANK))
+    dist.barrier()                     # every rank got here: nobody is stuck in the gather
+    dist.destroy_process_group()
+    sys.exit(0)
 blk = drv.prove_block_distributed(irs, rank, world, TorchGather(torch.device("cpu")))
 if rank == 0:
     w = np.frombuffer(blk.intern, dtype=np.uint64)
     assert st.verify(w) == 0
     pv, kind = pg.public_values_of(blk.intern)
-    assert kind == 2 and (pv.txn_number_before, pv.txn_number_after) == (0, 5) and pv.state_root_after == root
+    assert kind == 2 and (pv.txn_number_before, pv.txn_number_after) == (0, N_TXNS) and pv.state_root_after == root
     np.save({out!r}, w)
 else:
     assert blk is None
@@ -176,7 +192,7 @@ def test_block_driver_world_size_2_over_gloo(tmp_path, oracle):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     script = tmp_path / "drv.py"
     for world, out, port in ((2, out2, 29611), (1, out1, 29612)):
-        script.write_text(DRIVER_SCRIPT.format(root=ROOT, out=out))
+        script.write_text(DRIVER_SCRIPT.format(root=ROOT, out=out, n_txns=5, fail_rank=-1))
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                             "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                            env=env, capture_output=True, text=True, timeout=600)
@@ -184,3 +200,39 @@ def test_block_driver_world_size_2_over_gloo(tmp_path, oracle):
     a, b = np.load(out2), np.load(out1)
     # the tree shape differs (2 slices vs 1) so the proofs differ, but the public values must not
     assert a.shape == b.shape and (a[4 + 9:4 + 22] == b[4 + 9:4 + 22]).all()
+
+
+def _run_driver(tmp_path, world, n_txns, port, fail_rank=-1, omp="1"):
+    out = str(tmp_path / ("w%d_%d.npy" % (world, n_txns)))
+    script = tmp_path / ("drv_%d_%d_%d.py" % (world, n_txns, fail_rank))
+    script.write_text(DRIVER_SCRIPT.format(root=ROOT, out=out, n_txns=n_txns, fail_rank=fail_rank))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=omp)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return out
+
+
+def test_block_driver_world_size_8_uneven_split(tmp_path, oracle):
+    """The 8-rank shape of the driver's scaling run, rehearsed over gloo: 21 transactions over 8 ranks (slices of
+    3,3,3,3,3,2,2,2), local trees of different depth, gather, top tree of 8 sub-proofs, block proof; public values
+    equal the single-process run's."""
+    a = np.load(_run_driver(tmp_path, 8, 21, 29621))
+    b = np.load(_run_driver(tmp_path, 1, 21, 29622, omp="8"))
+    assert a.shape == b.shape and (a[4 + 9:4 + 22] == b[4 + 9:4 + 22]).all()
+
+
+def test_block_driver_fewer_entries_than_ranks(tmp_path, oracle):
+    """A block of 0 or 1 transactions is padded to exactly two entries (decoding.rs:304-347): on more than two
+    ranks the rest have an empty slice.  They must join the gather with an empty payload, not raise and leave
+    ranks 0 and 1 waiting in the collective."""
+    a = np.load(_run_driver(tmp_path, 4, 2, 29623))
+    b = np.load(_run_driver(tmp_path, 1, 2, 29624, omp="4"))
+    assert (a == b).all()          # two ranks with one txn each = the same tree as one rank with two
+
+
+def test_block_driver_failure_on_one_rank_raises_everywhere(tmp_path, oracle):
+    """A rank whose shard raises reports it through the gather's length exchange; every rank raises (ShardFailed on
+    the healthy ones, the original error on the failed one) and all of them reach the next barrier."""
+    _run_driver(tmp_path, 3, 6, 29625, fail_rank=1)

@@ -32,7 +32,11 @@ def bitrev(i, bits):
 
 
 def bitrev_perm(bits):
-    return np.array([bitrev(i, bits) for i in range(1 << bits)], dtype=np.int64)
+    i = np.arange(1 << bits, dtype=np.int64)
+    r = np.zeros_like(i)
+    for k in range(bits):
+        r |= ((i >> k) & 1) << (bits - 1 - k)
+    return r
 
 
 def coset_major_to_natural(log_n, rate_bits):
