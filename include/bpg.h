@@ -100,6 +100,11 @@ void bp_tune_quad_threshold(uint64_t n_perms);
  * multi-stream load): one launch per level.  Results are identical. */
 void bp_tune_merkle_fused(int on);
 
+/* Tuning knob for K2: 0 (default) = automatic, 1 = never, 2 = wherever possible: transform a 2^13 / 2^14-point
+ * block with TWO workgroups that each do half of the stage coupling its halves while loading (csrc/ntt.hip).
+ * Results are identical either way. */
+void bp_tune_ntt_split(int mode);
+
 /* K3.  Poseidon-Goldilocks permutation (width 12) on n states of 12 words, in place. */
 int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream);
 

@@ -83,16 +83,6 @@ __device__ __forceinline__ uint32_t sel_eps(mask m) {  // m ? 2^32-1 : 0
   asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d) : "s"(m));
   return d;
 }
-__device__ __forceinline__ uint32_t add_m1_co(uint32_t a, mask& co) {  // a + (2^32 - 1)
-  uint32_t d;
-  asm("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(d), "=s"(co) : "v"(a));
-  return d;
-}
-__device__ __forceinline__ uint32_t sel(mask m, uint32_t t, uint32_t f) {  // m ? t : f
-  uint32_t d;
-  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(f), "v"(t), "s"(m));
-  return d;
-}
 __device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 // t (true value t + c*2^64) -> t + c*EPS; the sum cannot wrap again when t is the low word of a sum
 // of a 64-bit value and a product below 2^64 - 2^33.
@@ -106,78 +96,35 @@ __device__ __forceinline__ uint64_t fold_carry(uint64_t t, mask c) {
 #include "gl_cc.inc"  // the same instructions in groups of N = 3, 4 independent elements (no s_nop needed)
 }  // namespace cc
 #endif
-// The device forms of canon / add / sub / addc / subc are carry chains on SGPR masks (namespace cc), not the
-// compare-and-select code the compiler makes of the portable expressions: that code selects 64-bit values with
-// PAIRS of v_cndmask_b32_e32 on VCC, and on gfx950 two independent VCC-reading v_cndmask_b32_e32 back to back
-// stall for ~20 cycles (tools/issue_rate5.hip, profiles/r2_issue_rates.md: cmp + 2 cndmask_e32 = 28 cycles per
-// wave64 against 13 for the same three instructions on an SGPR pair).
+// canon / add / sub / addc / subc keep their portable form (the compiler's compare-and-select code): single-element
+// carry-chain versions of them were measured SLOWER in the latency-bound STARK kernels (fri_fold 13.3 -> 17.2 us,
+// power_vector 9.8 -> 11.5 us: every mask consumer needs its own s_nop), although a microbenchmark of the
+// compiler's pattern looks worse (tools/issue_rate5.hip).  The interleaved group forms add_n / sub_n / canon_n
+// below have no nops and are what the NTT butterflies use (+5 %).
 GL_HD uint64_t canon(uint64_t a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  cc::mask k, c;  // a + EPS carries out of 64 bits iff a >= p, and the wrapped sum is a - p
-  const uint32_t lo = cc::add_m1_co((uint32_t)a, k);
-  const uint32_t hi = cc::addc0_co((uint32_t)(a >> 32), k, c);
-  return cc::mk64(cc::sel(c, lo, (uint32_t)a), cc::sel(c, hi, (uint32_t)(a >> 32)));
-#else
   return a >= P ? a - P : a;
-#endif
 }
 
 // a: any u64, b: canonical.  Result: reduced (any u64).
 GL_HD uint64_t add(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  cc::mask c1, c2, c3, cx;
-  const uint32_t lo = cc::add_co((uint32_t)a, (uint32_t)b, c1);
-  const uint32_t hi = cc::addc_co((uint32_t)(a >> 32), (uint32_t)(b >> 32), c1, c2);
-  const uint32_t lo2 = cc::add_co(lo, cc::sel_eps(c2), c3);  // on wrap: s < b < p so s + EPS cannot wrap again
-  return cc::mk64(lo2, cc::addc0_co(hi, c3, cx));
-#else
   uint64_t s = a + b;
   return s < b ? s + EPS : s;  // on wrap: s < b < p so s + EPS cannot wrap again
-#endif
 }
 // a: any u64, b: canonical.  Result: reduced.
 GL_HD uint64_t sub(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  cc::mask b1, b2, b3, bx;
-  const uint32_t lo = cc::sub_co((uint32_t)a, (uint32_t)b, b1);
-  const uint32_t hi = cc::subb_co((uint32_t)(a >> 32), (uint32_t)(b >> 32), b1, b2);
-  const uint32_t lo2 = cc::sub_co(lo, cc::sel_eps(b2), b3);  // on borrow: d = a + 2^64 - b > EPS
-  return cc::mk64(lo2, cc::subb0_co(hi, b3, bx));
-#else
   uint64_t d = a - b;
   return a < b ? d - EPS : d;  // on borrow: d = a + 2^64 - b > EPS
-#endif
 }
 // both canonical -> canonical
 GL_HD uint64_t addc(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // s = a + b (carry c2); t = s + EPS = s - p mod 2^64 (carry c4 iff s >= p); take t when either carried
-  // (never both: after a wrap s < p - 1).  The OR of the two masks is a scalar instruction.
-  cc::mask c1, c2, c3, c4;
-  const uint32_t lo = cc::add_co((uint32_t)a, (uint32_t)b, c1);
-  const uint32_t hi = cc::addc_co((uint32_t)(a >> 32), (uint32_t)(b >> 32), c1, c2);
-  const uint32_t tlo = cc::add_m1_co(lo, c3);
-  const uint32_t thi = cc::addc0_co(hi, c3, c4);
-  const cc::mask m = c2 | c4;
-  return cc::mk64(cc::sel(m, tlo, lo), cc::sel(m, thi, hi));
-#else
   uint64_t s = a + b;
   return (s < a || s >= P) ? s - P : s;
-#endif
 }
 GL_HD uint64_t subc(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return sub(a, b);  // both canonical: a - b (+ p on borrow) is already canonical
-#else
   return a >= b ? a - b : a + (P - b);
-#endif
 }
 GL_HD uint64_t negc(uint64_t a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return sub(0, a);
-#else
   return a ? P - a : 0;
-#endif
 }
 
 // 128-bit (lo, hi) -> reduced u64

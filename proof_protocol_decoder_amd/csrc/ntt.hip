@@ -14,6 +14,7 @@
 //   * n > 2^14 adds strided global radix passes (each lane owns 2^k elements n/2^k apart, so every
 //     wave access is a contiguous 512-byte run of one column).
 // Roofline: HBM (8 TB/s peak).  Algorithmic bytes: NTT/iNTT 16*n*C; iNTT+LDE 8*n*C*(2+2^r).
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -251,23 +252,69 @@ struct Ntt16Args {
   const uint64_t* tw;     // w_B^e, e < B/2, B = 2^L
   const uint64_t* scale;  // DIT: [coset][n_total] input scale, nullable
   uint64_t out_scalar;    // DIF: 1/n (1 = none)
-  uint32_t log_n_total, n_cosets, n_units;  // n_units = columns * blocks per column (DIT grid mapping)
+  uint32_t log_n_total, n_cosets, n_units;  // n_units = columns * blocks per column (1-D grid mapping)
+  const uint64_t* tw_top; // split kernels (F = 1): w_{2B}^e, e < B: the stage that joins the two halves
 };
 
-// natural -> bit-reversed.  grid = (blocks per column, columns)
-template <int L>
+// ---- "split" forms (template parameter F = 1): a block of 2^(L+1) elements is transformed by TWO workgroups of
+// the 2^L-point kernel, each doing half of the one radix-2 stage that couples the halves while it loads:
+//   DIF: workgroup h reads x[i] and x[i + 2^L] and keeps (h = 0) x[i] + x[i + 2^L] or (h = 1) their twiddled
+//        difference -- then it owns an independent 2^L-point transform (output half h);
+//   DIT: the same split on the COEFFICIENT index (pairs of adjacent bit-reversed positions 2p, 2p+1), after which
+//        workgroup h owns the outputs of parity h (stride-2 stores; the partner fills the other half of each line).
+// Both read the whole 2^(L+1) block (the second read is an L2 hit: the pair sits on one XCD, see the grid
+// mapping below) but no multiply is done twice.  Why: a 2^14-point block is ONE 128 KiB workgroup per CU, whose
+// load, compute and store phases cannot overlap with anything (73 % VALU-busy); as two 64 KiB workgroups they
+// overlap with each other (the 2^12 kernel reaches 88 %).  And a launch with few columns gets twice the
+// workgroups, i.e. half the latency where the chip is not full.
+
+// natural -> bit-reversed.  F = 0: grid = (blocks per column, columns).  F = 1: 1-D XCD-aware grid, id -> xcd = id % 8,
+// k = id / 8, h = k % 2, unit = (k / 2) * 8 + xcd = column * (2^(L+1)-blocks per column) + block.
+template <int L, int F>
 __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
   if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr uint32_t T = (1u << L) / 16;
   constexpr int RT = (L % 4 == 0) ? 4 : (L % 4);  // stages of the innermost pass
   const uint32_t t = threadIdx.x;
-  const uint64_t off = (uint64_t)blockIdx.x << L;
-  const uint64_t* src = a.in + blockIdx.y * a.in_stride + off;
-  uint64_t* dst = a.out + blockIdx.y * a.out_stride + off;
+  const uint64_t* src;
+  uint64_t* dst;
   uint64_t x[16];
+  if (F) {
+    const uint32_t id = blockIdx.x, k = id >> 3, h = k & 1, unit = (k >> 1) * 8 + (id & 7);
+    if (unit >= a.n_units) return;  // padding of the last group of eight
+    const uint32_t log_bpc = a.log_n_total - (L + 1);
+    const uint32_t col = unit >> log_bpc, blk = unit & ((1u << log_bpc) - 1);
+    const uint64_t off = (uint64_t)blk << (L + 1);
+    src = a.in + col * a.in_stride + off;
+    dst = a.out + col * a.out_stride + off + ((uint64_t)h << L);
 #pragma unroll
-  for (int m = 0; m < 16; m++) x[m] = src[m * T + t];
+    for (int m0 = 0; m0 < 16; m0 += 4) {
+      uint64_t lo[4], hi[4], r[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        lo[i] = src[(m0 + i) * T + t];
+        hi[i] = src[(m0 + i) * T + t + (1u << L)];  // canonical (memory invariant)
+      }
+      if (h == 0) {
+        gl::add_n<4>(lo, hi, r);
+      } else {
+        uint64_t d[4], w[4];
+        gl::sub_n<4>(lo, hi, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = a.tw_top[(m0 + i) * T + t];
+        gl::mul_n<4>(d, w, r);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[m0 + i] = r[i];
+    }
+  } else {
+    const uint64_t off = (uint64_t)blockIdx.x << L;
+    src = a.in + blockIdx.y * a.in_stride + off;
+    dst = a.out + blockIdx.y * a.out_stride + off;
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = src[m * T + t];
+  }
   dif_butterflies<4>(x, a.tw, t, L - 4, 0);
 #pragma unroll
   for (int m = 0; m < 16; m++) buf[swz<L>(m * T + t)] = x[m];
@@ -325,24 +372,67 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
 // XCD at about the same time and lets its L2 serve all but the first read (PMC: fetched bytes drop
 // from 2^r x to ~1 x the coefficients).  id -> xcd = id % 8, k = id / 8, coset = k % n_cosets,
 // unit = (k / n_cosets) * 8 + xcd, unit = column * blocks_per_column + block.  A speed choice only.
-template <int L>
+// F = 1 (split form, see Ntt16Args): k -> (coset, h) = ((k % (2 n_cosets)) / 2, k % 2), unit counts 2^(L+1)-blocks.
+template <int L, int F>
 __global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per_eu(4, 8))) ntt16_dit_kernel(Ntt16Args a) {
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr uint32_t T = (1u << L) / 16;
   constexpr int RT = (L % 4 == 0) ? 4 : (L % 4);  // stages of the outermost pass
   const uint32_t id = blockIdx.x, k = id >> 3;
-  const uint32_t coset = k % a.n_cosets, unit = (k / a.n_cosets) * 8 + (id & 7);
+  const uint32_t per = a.n_cosets << F;
+  const uint32_t ch = k % per, coset = ch >> F, h = F ? (ch & 1) : 0, unit = (k / per) * 8 + (id & 7);
   if (unit >= a.n_units) return;  // padding of the last group of eight (whole workgroup leaves together)
-  const uint32_t log_bpc = a.log_n_total - L;  // blocks per column
+  const uint32_t log_bpc = a.log_n_total - (L + F);  // blocks per column
   const uint32_t col = unit >> log_bpc, blk = unit & ((1u << log_bpc) - 1);
   const uint32_t t = threadIdx.x;
-  const uint64_t off = (uint64_t)blk << L;
+  const uint64_t off = (uint64_t)blk << (L + F);
   const uint64_t* src = a.in + col * a.in_stride + off;
   const uint64_t* tw = a.tw;
   uint64_t x[16];
   const uint32_t base = gl::bitrev(t, L - 4) << 4;
-  if (a.scale) {
+  if (F) {
+    // coefficient pairs (2p, 2p + 1): p = m*T + t is the input position of this workgroup's 2^L-point problem
+    const ulonglong2* src2 = reinterpret_cast<const ulonglong2*>(src);
+    const ulonglong2* sc2 = a.scale ? reinterpret_cast<const ulonglong2*>(a.scale + ((uint64_t)coset << a.log_n_total) + off) : nullptr;
+    constexpr uint32_t BR4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+#pragma unroll
+    for (int m0 = 0; m0 < 16; m0 += 4) {
+      uint64_t c0[4], c1[4], r[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const ulonglong2 c = src2[(m0 + i) * T + t];
+        c0[i] = c.x;
+        c1[i] = c.y;
+      }
+      if (sc2) {
+        uint64_t s0[4], s1[4], p0[4], p1[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const ulonglong2 sc = sc2[(m0 + i) * T + t];
+          s0[i] = sc.x;
+          s1[i] = sc.y;
+        }
+        gl::mul_n<4>(c0, s0, p0);
+        gl::mul_n<4>(c1, s1, p1);
+        gl::canon_n<4>(p1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { c0[i] = p0[i]; c1[i] = p1[i]; }
+      }
+      if (h == 0) {
+        gl::add_n<4>(c0, c1, r);
+      } else {
+        uint64_t d[4], w[4];
+        gl::sub_n<4>(c0, c1, d);
+        // twiddle of coefficient index bitrev_L(p) = (bitrev_{L-4}(t) << 4) | bitrev_4(m)
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = a.tw_top[base | BR4[m0 + i]];
+        gl::mul_n<4>(d, w, r);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) buf[swz<L>((m0 + i) * T + t)] = r[i];  // reduced, not canonical: fine as a butterfly input
+    }
+  } else if (a.scale) {
     const uint64_t* sc = a.scale + ((uint64_t)coset << a.log_n_total) + off;
 #pragma unroll
     for (int m0 = 0; m0 < 16; m0 += 4) {
@@ -391,7 +481,10 @@ __global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per
     uint64_t v[4] = {x[m0], x[m0 + 1], x[m0 + 2], x[m0 + 3]};
     gl::canon_n<4>(v);
 #pragma unroll
-    for (int i = 0; i < 4; i++) dst[(m0 + i) * T + t2] = v[i];
+    for (int i = 0; i < 4; i++) {
+      if (F) dst[2 * ((m0 + i) * T + t2) + h] = v[i];  // outputs of parity h
+      else dst[(m0 + i) * T + t2] = v[i];
+    }
   }
 }
 
@@ -611,6 +704,17 @@ static NttPlan plan_ntt(uint32_t log_n) {
 }
 static uint32_t pick_log_blk(uint32_t log_n) { return plan_ntt(log_n).log_blk; }
 
+// Split form (Ntt16Args), out of place only: always for 2^14-point blocks (one 128 KiB workgroup per CU cannot overlap its phases),
+// and for 2^13-point blocks when the launch has too few workgroups to fill the chip (latency, not throughput).
+static std::atomic<int> g_ntt_split{0};  // 0 = automatic, 1 = never, 2 = wherever possible (measurement knob)
+static bool use_split(uint32_t log_blk, uint64_t workgroups, const void* src, const void* dst) {
+  const int mode = g_ntt_split.load(std::memory_order_relaxed);
+  // never in place: each of the two workgroups reads the WHOLE block while its partner may already be storing
+  if (mode == 1 || log_blk < 13 || src == dst) return false;
+  if (mode == 2 || log_blk == 14) return true;
+  return workgroups < 512;
+}
+
 static uint32_t lds_threads(uint32_t log_blk) {
   uint32_t t = log_blk >= 3 ? (1u << (log_blk - 3)) : 1;
   return t < 64 ? 64 : (t > 1024 ? 1024 : t);
@@ -674,11 +778,21 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
     b.in = src; b.in_stride = src_stride; b.out = out; b.out_stride = out_stride; b.out_coset_stride = 0;
     b.tw = tw_b; b.scale = nullptr; b.out_scalar = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
     b.log_n_total = log_n; b.n_cosets = 1; b.n_units = 0;
-    dim3 grid16(1u << (log_n - log_blk), n_cols);
     KernelTimer kt(PROF_INTT_DIF, st, 16.0 * (double)n_cols * (double)((uint64_t)1 << log_n));
-    if (log_blk == 12) ntt16_dif_kernel<12><<<grid16, 256, 8u << 12, st>>>(b);
-    else if (log_blk == 13) ntt16_dif_kernel<13><<<grid16, 512, 8u << 13, st>>>(b);
-    else ntt16_dif_kernel<14><<<grid16, 1024, 8u << 14, st>>>(b);
+    if (use_split(log_blk, (uint64_t)n_cols << (log_n - log_blk), src, out)) {
+      // two workgroups of the next smaller kernel per block (see Ntt16Args)
+      if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
+      b.tw_top = tw_b;
+      b.n_units = n_cols << (log_n - log_blk);
+      const dim3 grid1((b.n_units + 7) / 8 * 8 * 2);
+      if (log_blk == 14) ntt16_dif_kernel<13, 1><<<grid1, 512, 8u << 13, st>>>(b);
+      else ntt16_dif_kernel<12, 1><<<grid1, 256, 8u << 12, st>>>(b);
+    } else {
+      const dim3 grid16(1u << (log_n - log_blk), n_cols);
+      if (log_blk == 12) ntt16_dif_kernel<12, 0><<<grid16, 256, 8u << 12, st>>>(b);
+      else if (log_blk == 13) ntt16_dif_kernel<13, 0><<<grid16, 512, 8u << 13, st>>>(b);
+      else ntt16_dif_kernel<14, 0><<<grid16, 1024, 8u << 14, st>>>(b);
+    }
     BPG_LAUNCH_CHECK();
     return BP_OK;
   }
@@ -712,12 +826,20 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
     b.in = in; b.in_stride = in_stride; b.out = out; b.out_stride = out_stride; b.out_coset_stride = coset_stride;
     b.tw = tw_b; b.scale = scale; b.out_scalar = 1; b.log_n_total = log_n; b.n_cosets = n_cosets;
     b.n_units = n_cols << (log_n - log_blk);
-    const dim3 grid16((b.n_units + 7) / 8 * 8 * n_cosets);
     {
       KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
-      if (log_blk == 12) ntt16_dit_kernel<12><<<grid16, 256, 8u << 12, st>>>(b);
-      else if (log_blk == 13) ntt16_dit_kernel<13><<<grid16, 512, 8u << 13, st>>>(b);
-      else ntt16_dit_kernel<14><<<grid16, 1024, 8u << 14, st>>>(b);
+      if (use_split(log_blk, (uint64_t)b.n_units * n_cosets, in, out)) {
+        if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
+        b.tw_top = tw_b;
+        const dim3 grid1((b.n_units + 7) / 8 * 8 * n_cosets * 2);
+        if (log_blk == 14) ntt16_dit_kernel<13, 1><<<grid1, 512, 8u << 13, st>>>(b);
+        else ntt16_dit_kernel<12, 1><<<grid1, 256, 8u << 12, st>>>(b);
+      } else {
+        const dim3 grid16((b.n_units + 7) / 8 * 8 * n_cosets);
+        if (log_blk == 12) ntt16_dit_kernel<12, 0><<<grid16, 256, 8u << 12, st>>>(b);
+        else if (log_blk == 13) ntt16_dit_kernel<13, 0><<<grid16, 512, 8u << 13, st>>>(b);
+        else ntt16_dit_kernel<14, 0><<<grid16, 1024, 8u << 14, st>>>(b);
+      }
     }
     BPG_LAUNCH_CHECK();
   } else {
@@ -755,13 +877,17 @@ static int init_ntt_kernels_once() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << LOG_BLK_MAX));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_lds_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << LOG_BLK_MAX));
-  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<14>),
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<14, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
-  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<14>),
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<14, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
-  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<13>),
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<13, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
-  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13>),
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<13, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
   return BP_OK;
 }
@@ -775,6 +901,8 @@ int init_ntt_kernels() {
 }  // namespace bpg
 
 extern "C" {
+
+void bp_tune_ntt_split(int mode) { bpg::g_ntt_split.store(mode); }
 
 int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir, void* stream) try {
   if (n_cols == 0) return BP_OK;
