@@ -222,6 +222,9 @@ uint64_t bp_state_device_bytes(const bp_state* s);
 /* abort_flag: nullable; polled between kernel stages (Option<Arc<AtomicBool>>, proof_gen.rs:42). */
 int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
                           uint8_t** out, size_t* out_len);
+/* the same call taking the reference's own flag: Arc<AtomicBool> is ONE byte, `flag.as_ptr()` binds here directly */
+int bp_generate_txn_proof_u8(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile uint8_t* abort_flag,
+                             uint8_t** out, size_t* out_len);
 int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
                           const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len);
 /* parent may be NULL (checkpoint heights, proof_gen.rs:83-84). *b_height = block number of the proof. */
@@ -267,9 +270,42 @@ int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_
 int bp_compact_decode(const uint8_t* witness, size_t len, uint8_t* header_version, uint8_t state_root[32],
                       uint32_t* n_accounts, uint32_t* n_storage_tries, uint32_t* n_code,
                       uint32_t* n_accounts_missing_storage);
+/* The reference's FULL output of the same call (ProcessedCompactOutput{header, witness_out{tries{state,
+ * storage}, code}}, compact_prestate_processing.rs:1243-1281), release with bp_free_buffer:
+ *   "BPGCWIT1" | version:u8 | state: len:u32 trie | n_storage:u32 (hashed_addr[32] len:u32 trie)* |
+ *   n_code:u32 (code_hash[32] len:u32 bytes)*
+ * Storage tries are keyed by HASHED ACCOUNT ADDRESS (the re-keying of compact_to_partial_trie.rs:167-190), lists
+ * in ascending key order, integers little-endian.  A trie is its nodes in preorder, one tag byte each:
+ *   0x00 empty | 0x01 hash[32] | 0x02 mask:u16 vlen:u32 value child* (present children, nibble order) |
+ *   0x03 nkey:u8 nibble[nkey] child | 0x04 nkey:u8 nibble[nkey] vlen:u32 value
+ * (leaf values are what the reference inserts: rlp(AccountRlp) for accounts, rlp(value) for storage slots). */
+int bp_compact_decode_full(const uint8_t* witness, size_t len, uint8_t** out, size_t* out_len);
 /* one instruction per text line; release with bp_free_buffer */
 int bp_compact_instructions(const uint8_t* witness, size_t len, uint8_t** text_out, size_t* text_len);
 void bp_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
+
+/* ------------------------------------------------------------------------------------------
+ * Next row: the txn IR producer, BlockTrace::into_txn_proof_gen_ir
+ * (protocol_decoder/src/processed_block_trace.rs:38-50, 210-332; decoding.rs:81-177, 179-292, 304-347, 356-428):
+ * compact pre-image + per-txn account traces -> one GenerationInputs per transaction (minimal partial tries,
+ * deltas replayed over the block's trie state, roots after), padded to >= 2 entries with dummies, withdrawals on
+ * the last dummy.  Host-only, sequential by nature.  Unpinned by the reference (it has no test for this path);
+ * pinned here by invariants (tests/test_decoding.py).  All integers little-endian, U256 as 32 bytes big-endian.
+ *
+ * in  = "BPGTRAC1" | witness: len:u32 bytes | n_txn:u32 txn* | checkpoint_state_trie_root[32] |
+ *       block_metadata: len:u32 bytes | block_hashes: len:u32 bytes (both opaque upstream types, copied through) |
+ *       n_withdrawals:u32 (address[20] amount[32])* | n_code:u32 (code_hash[32] len:u32 bytes)*  (CodeHashResolveFunc as a table)
+ * txn = n_traces:u32 trace* | byte_code: len:u32 bytes | new_txn_trie_node_byte | new_receipt_trie_node_byte | gas_used:u64
+ * trace = address[20] flags:u8 [balance[32]] [nonce[32]] [n:u32 slot[32]*] [n:u32 (slot[32] value[32])*] [code_hash[32] | len:u32 code]
+ *       flags: 1 balance, 2 nonce, 4 storage_read, 8 storage_written, 16 code_usage read, 32 code_usage write, 64 self_destructed
+ * out = "BPGGENI1" | n:u32 ir* | final_state_root[32]
+ * ir  = txn_number_before[32] gas_used_before[32] gas_used_after[32] | has_signed_txn:u8 signed_txn: len:u32 bytes |
+ *       n:u32 (address[20] amount[32])* withdrawals | tries: state, transactions, receipts (each len:u32 trie),
+ *       n:u32 (hashed_addr[32] len:u32 trie)* storage | trie_roots_after: state[32] transactions[32] receipts[32] |
+ *       checkpoint_state_trie_root[32] | n:u32 (code_hash[32] len:u32 bytes)* contract_code | block_metadata | block_hashes
+ * Release with bp_free_buffer.
+ * ------------------------------------------------------------------------------------------ */
+int bp_decode_block_trace(const uint8_t* trace, size_t len, uint8_t** out, size_t* out_len);
 
 /* state root after one synthetic txn (host-side helper for building a chain of IRs) */
 int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]);

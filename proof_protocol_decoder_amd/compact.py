@@ -26,6 +26,7 @@ def _bind():
     L = lib()
     L.bp_compact_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint8), C.c_char_p] + [C.POINTER(C.c_uint32)] * 4
     L.bp_compact_instructions.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    L.bp_compact_decode_full.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.bp_keccak256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
     L.bp_keccak256.restype = None
     return L
@@ -39,6 +40,39 @@ def process_compact_prestate(witness: bytes) -> ProcessedCompactOutput:
     check(L.bp_compact_decode(witness, len(witness), C.byref(ver), root, C.byref(na), C.byref(ns), C.byref(nc),
                               C.byref(miss)))
     return ProcessedCompactOutput(ver.value, root.raw, na.value, ns.value, nc.value, miss.value)
+
+
+@dataclass
+class WitnessOutput:
+    """`ProcessedCompactOutput{header, witness_out{tries{state, storage}, code}}`
+    (compact_prestate_processing.rs:1243-1260): storage tries keyed by hashed account address."""
+    header_version: int
+    state: "object"      # partial_trie.PartialTrie
+    storage: dict        # hashed account address (32 bytes) -> PartialTrie
+    code: dict           # code hash -> bytes
+
+
+def process_compact_prestate_full(witness: bytes) -> WitnessOutput:
+    """The reference's whole output, not just the root: the decoded tries and the code map (bp_compact_decode_full)."""
+    from .partial_trie import Reader
+    L = _bind()
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    check(L.bp_compact_decode_full(witness, len(witness), C.byref(out), C.byref(n)))
+    r = Reader(take_buffer(out, n))
+    if r.take(8) != b"BPGCWIT1":
+        raise ValueError("bad magic")
+    ver = r.u8()
+    state = r.trie()
+    storage = {}
+    for _ in range(r.u32()):
+        h = r.take(32)
+        storage[h] = r.trie()
+    code = {}
+    for _ in range(r.u32()):
+        h = r.take(32)
+        code[h] = r.blob()
+    assert r.done()
+    return WitnessOutput(ver, state, storage, code)
 
 
 def parse_just_to_instructions(witness: bytes):

@@ -20,121 +20,27 @@
 // (equal to inserting every leaf / hash node for a well-formed witness).  Pinned by the six state
 // roots and the instruction KAT the reference's own tests hold (tests/golden/).
 #include <algorithm>
+#include <algorithm>
 #include <array>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
-#include <set>
 #include <string>
 #include <vector>
 #include "common.hpp"
+#include "compact.hpp"
 
 namespace {
 
-using Bytes = std::vector<uint8_t>;
-using H256 = std::array<uint8_t, 32>;
-
-// ---------------------------------------------------------------- Keccak-256 (FIPS 202 permutation, 0x01 padding)
-void keccak_f(uint64_t st[25]) {
-  static const uint64_t RC[24] = {
-      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
-      0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
-      0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
-      0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
-      0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-  static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-  static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
-  for (int r = 0; r < 24; r++) {
-    uint64_t bc[5];
-    for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
-    for (int i = 0; i < 5; i++) {
-      uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63));
-      for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
-    }
-    uint64_t t = st[1];
-    for (int i = 0; i < 24; i++) {
-      int j = PIL[i];
-      uint64_t b = st[j];
-      st[j] = (t << ROT[i]) | (t >> (64 - ROT[i]));
-      t = b;
-    }
-    for (int j = 0; j < 25; j += 5) {
-      uint64_t row[5];
-      for (int i = 0; i < 5; i++) row[i] = st[j + i];
-      for (int i = 0; i < 5; i++) st[j + i] ^= (~row[(i + 1) % 5]) & row[(i + 2) % 5];
-    }
-    st[0] ^= RC[r];
-  }
-}
-H256 keccak256(const uint8_t* data, size_t len) {
-  uint64_t st[25] = {0};
-  const size_t rate = 136;
-  uint8_t block[136];
-  while (len >= rate) {
-    for (size_t i = 0; i < rate / 8; i++) {
-      uint64_t w;
-      std::memcpy(&w, data + 8 * i, 8);
-      st[i] ^= w;
-    }
-    keccak_f(st);
-    data += rate;
-    len -= rate;
-  }
-  std::memset(block, 0, rate);
-  std::memcpy(block, data, len);
-  block[len] ^= 0x01;
-  block[rate - 1] ^= 0x80;
-  for (size_t i = 0; i < rate / 8; i++) {
-    uint64_t w;
-    std::memcpy(&w, block + 8 * i, 8);
-    st[i] ^= w;
-  }
-  keccak_f(st);
-  H256 out;
-  std::memcpy(out.data(), st, 32);
-  return out;
-}
-H256 keccak256(const Bytes& b) { return keccak256(b.data(), b.size()); }
-
-// ---------------------------------------------------------------- RLP
-void rlp_len_prefix(Bytes& out, size_t len, uint8_t short_base) {
-  if (len < 56) {
-    out.push_back((uint8_t)(short_base + len));
-  } else {
-    uint8_t tmp[8];
-    int n = 0;
-    for (size_t l = len; l; l >>= 8) tmp[n++] = (uint8_t)l;
-    out.push_back((uint8_t)(short_base + 55 + n));
-    for (int i = n - 1; i >= 0; i--) out.push_back(tmp[i]);
-  }
-}
-Bytes rlp_string(const uint8_t* d, size_t len) {
-  Bytes out;
-  if (len == 1 && d[0] < 0x80) {
-    out.push_back(d[0]);
-    return out;
-  }
-  rlp_len_prefix(out, len, 0x80);
-  out.insert(out.end(), d, d + len);
-  return out;
-}
-Bytes rlp_string(const Bytes& b) { return rlp_string(b.data(), b.size()); }
-Bytes rlp_list(const std::vector<Bytes>& items) {
-  size_t total = 0;
-  for (auto& i : items) total += i.size();
-  Bytes out;
-  rlp_len_prefix(out, total, 0xc0);
-  for (auto& i : items) out.insert(out.end(), i.begin(), i.end());
-  return out;
-}
-// big-endian scalar with leading zeros stripped (U256 / u64 as RLP integers)
-Bytes rlp_scalar_be(const Bytes& be) {
-  size_t i = 0;
-  while (i < be.size() && be[i] == 0) i++;
-  return rlp_string(be.data() + i, be.size() - i);
-}
+using Bytes = mpt::Bytes;
+using H256 = mpt::H256;
+using mpt::EMPTY_CODE_HASH;
+using mpt::EMPTY_TRIE_HASH;
+using mpt::keccak256;
+using mpt::rlp_list;
+using mpt::rlp_scalar_be;
+using mpt::rlp_string;
 
 // ---------------------------------------------------------------- instructions
 using Nibbles = std::vector<uint8_t>;
@@ -286,7 +192,7 @@ bool parse_instructions(const uint8_t* data, size_t len, uint8_t* version, std::
   return true;
 }
 
-// ---------------------------------------------------------------- node tree + Merkle-Patricia hashing
+// ---------------------------------------------------------------- witness node tree
 struct Node;
 using NodeP = std::shared_ptr<Node>;
 enum class Kind { Branch, Code, Empty, Hash, ValueLeaf, AccountLeaf, Extension };
@@ -301,87 +207,33 @@ struct Node {
 };
 // A state / storage path is at most 64 nibbles: at most 64 branches with an extension between any two,
 // so no well-formed witness nests deeper than this.  The cap bounds every recursion over the tree
-// (encode_node, collect_code, the shared_ptr destructor chain), whatever the client-supplied payload.
+// (to_trie_node, collect_code, the trie code of mpt.cpp, the shared_ptr destructor chain), whatever the
+// client-supplied payload.
 constexpr uint32_t MAX_TREE_HEIGHT = 160;
 
-const H256 EMPTY_TRIE_HASH = {86, 232, 31, 23, 27, 204, 85, 166, 255, 131, 69, 230, 146, 192, 248, 110,
-                              91, 72, 224, 27, 153, 108, 173, 192, 1, 98, 47, 181, 227, 99, 180, 33};
-const H256 EMPTY_CODE_HASH = {197, 210, 70, 1, 134, 247, 35, 60, 146, 126, 125, 178, 220, 199, 3, 192,
-                              229, 0, 182, 83, 202, 130, 39, 59, 123, 250, 216, 4, 93, 133, 164, 112};
-
-Bytes hex_prefix(const Nibbles& k, bool leaf) {
-  Bytes out;
-  const uint8_t flag = (leaf ? 2 : 0) + (k.size() & 1);
-  size_t i = 0;
-  if (k.size() & 1) out.push_back((uint8_t)((flag << 4) | k[i++]));
-  else out.push_back((uint8_t)(flag << 4));
-  for (; i < k.size(); i += 2) out.push_back((uint8_t)((k[i] << 4) | k[i + 1]));
-  return out;
-}
-
-struct Decoded {
-  std::map<H256, Bytes> code;                 // code hash -> bytes
-  std::set<H256> storage_roots;               // storage tries extracted (keyed by their root)
-  std::vector<std::pair<Bytes, H256>> accounts;  // (key path nibbles, storage root) of every account leaf
-};
-
-// RLP of a trie node; `*is_hash_ref` set when the node is a hash node (its reference is the hash).
-Bytes encode_node(const Node& n, Decoded* d, Nibbles& path);
-
-// child reference inside a parent: raw RLP when shorter than 32 bytes, else keccak as a 32-byte string
-Bytes node_ref(const NodeP& n, Decoded* d, Nibbles& path) {
-  if (!n || n->kind == Kind::Empty) return Bytes{0x80};
-  if (n->kind == Kind::Hash) return rlp_string(n->hash.data(), 32);
-  Bytes enc = encode_node(*n, d, path);
-  if (enc.size() < 32) return enc;
-  H256 h = keccak256(enc);
-  return rlp_string(h.data(), 32);
-}
-Bytes encode_node(const Node& n, Decoded* d, Nibbles& path) {
-  switch (n.kind) {
+// witness node tree -> trie nodes (compact_to_partial_trie.rs:49-165): value leaves store rlp(value) (:119),
+// account leaves rlp(AccountRlp) (:141-165); code nodes and the empty root are not trie nodes.  The reference
+// re-inserts every leaf / hash node into an empty trie; for a well-formed witness the tree IS that trie.
+mpt::NodeP to_trie_node(const NodeP& n) {
+  if (!n) return mpt::make_empty();
+  switch (n->kind) {
     case Kind::Branch: {
-      std::vector<Bytes> items;
-      for (int i = 0; i < 16; i++) {
-        path.push_back((uint8_t)i);
-        items.push_back(node_ref(n.children[i], d, path));
-        path.pop_back();
-      }
-      items.push_back(Bytes{0x80});  // branches carry no value in state / storage tries
-      return rlp_list(items);
+      mpt::NodeP ch[16];
+      for (int i = 0; i < 16; i++) ch[i] = to_trie_node(n->children[i]);
+      return mpt::make_branch(ch);
     }
-    case Kind::Extension: {
-      const size_t keep = path.size();
-      path.insert(path.end(), n.key.begin(), n.key.end());
-      Bytes child = node_ref(n.child, d, path);
-      path.resize(keep);
-      return rlp_list({rlp_string(hex_prefix(n.key, false)), child});
-    }
-    case Kind::ValueLeaf:  // compact_to_partial_trie.rs:119: the stored value is rlp(raw bytes)
-      return rlp_list({rlp_string(hex_prefix(n.key, true)), rlp_string(rlp_string(n.payload))});
-    case Kind::AccountLeaf: {
-      if (d) {
-        Bytes full(path.begin(), path.end());
-        full.insert(full.end(), n.key.begin(), n.key.end());
-        d->accounts.push_back({full, n.hash});
-      }
-      return rlp_list({rlp_string(hex_prefix(n.key, true)), rlp_string(n.payload)});
-    }
-    default:
-      return Bytes{0x80};
+    case Kind::Extension: return mpt::make_extension(n->key, to_trie_node(n->child));
+    case Kind::Hash: return mpt::make_hash(n->hash);
+    case Kind::ValueLeaf: return mpt::make_leaf(n->key, rlp_string(n->payload));
+    case Kind::AccountLeaf: return mpt::make_leaf(n->key, n->payload);
+    default: return mpt::make_empty();
   }
 }
-// HashedPartialTrie::hash(): keccak of the root encoding; a lone hash node is its own root
-H256 trie_root(const NodeP& n, Decoded* d) {
-  if (!n || n->kind == Kind::Empty || n->kind == Kind::Code) return EMPTY_TRIE_HASH;
-  if (n->kind == Kind::Hash) return n->hash;
-  Nibbles path;
-  return keccak256(encode_node(*n, d, path));
-}
-void collect_code(const NodeP& n, Decoded* d) {  // Code nodes reachable in a (storage) subtree
+void collect_code(const NodeP& n, std::map<H256, Bytes>* code) {  // Code nodes reachable in a (storage) subtree
   if (!n) return;
-  if (n->kind == Kind::Code) d->code[keccak256(n->payload)] = n->payload;
-  if (n->kind == Kind::Extension) collect_code(n->child, d);
-  if (n->kind == Kind::Branch) for (auto& c : n->children) collect_code(c, d);
+  if (n->kind == Kind::Code) (*code)[keccak256(n->payload)] = n->payload;
+  if (n->kind == Kind::Extension) collect_code(n->child, code);
+  if (n->kind == Kind::Branch) for (auto& c : n->children) collect_code(c, code);
 }
 
 bool fail_msg(std::string* err, const std::string& m) {
@@ -390,7 +242,7 @@ bool fail_msg(std::string* err, const std::string& m) {
 }
 
 // compact_prestate_processing.rs:387-606 as a stack machine
-bool build_tree(const std::vector<Instr>& ins, Decoded* d, NodeP* root, std::string* err) {
+bool build_tree(const std::vector<Instr>& ins, bpg::CompactOut* d, NodeP* root, std::string* err) {
   std::vector<NodeP> st;
   auto pop = [&](NodeP* out, const char* who) {
     if (st.empty()) return fail_msg(err, std::string("Invalid block witness entries: ") + who + " has no preceding node");
@@ -441,9 +293,10 @@ bool build_tree(const std::vector<Instr>& ins, Decoded* d, NodeP* root, std::str
           NodeP s;
           if (!pop(&s, "AccountLeaf (storage)")) return false;
           if (s->kind == Kind::Code) return fail_msg(err, "Invalid block witness entries: a code node cannot be a storage root");
-          storage_root = trie_root(s, nullptr);
-          d->storage_roots.insert(storage_root);
-          collect_code(s, d);
+          mpt::Trie st(to_trie_node(s));
+          storage_root = st.hash();
+          d->storage_by_root[storage_root] = st;  // keyed by root first (compact_prestate_processing.rs:617-619)
+          collect_code(s, &d->code);
         }
         if (in.has_code) {     // then the code (bytes or hash)
           NodeP c;
@@ -489,6 +342,45 @@ std::string hex(const uint8_t* d, size_t n) {
 
 }  // namespace
 
+namespace bpg {
+
+// h_addr_nibs_to_h256 (protocol_decoder/src/utils.rs:47-58): left-pad a short path with zero bytes
+static H256 nibbles_to_h256(const mpt::Nibbles& k) {
+  Bytes b;
+  size_t i = 0;
+  if (k.size() & 1) b.push_back(k[i++]);
+  for (; i + 1 < k.size() + 1 && i < k.size(); i += 2) b.push_back((uint8_t)((k[i] << 4) | k[i + 1]));
+  H256 h{};
+  if (b.size() > 32) b.erase(b.begin(), b.end() - 32);
+  std::memcpy(h.data() + 32 - b.size(), b.data(), b.size());
+  return h;
+}
+
+// process_compact_prestate (compact_prestate_processing.rs:1240-1281) + the re-keying of
+// compact_to_partial_trie.rs:167-190 (storage tries keyed by hashed account address).
+bool decode_compact(const uint8_t* witness, size_t len, CompactOut* out, std::string* err) {
+  std::vector<Instr> ins;
+  if (!parse_instructions(witness, len, &out->header_version, &ins, err)) return false;
+  NodeP root;
+  if (!build_tree(ins, out, &root, err)) return false;
+  if (root && root->kind == Kind::Code) out->code[keccak256(root->payload)] = root->payload;
+  out->state = mpt::Trie(to_trie_node(root));
+  std::vector<mpt::Item> items;
+  out->state.items(&items);
+  for (auto& it : items) {
+    if (it.is_hash) continue;
+    mpt::Account acc;
+    if (!mpt::account_decode(it.value, &acc)) continue;  // a value leaf in the state trie: not an account
+    const H256 h_addr = nibbles_to_h256(it.path);
+    out->accounts.push_back({h_addr, acc});
+    auto st = out->storage_by_root.find(acc.storage_root);
+    if (st != out->storage_by_root.end()) out->storage[h_addr] = st->second;
+  }
+  return true;
+}
+
+}  // namespace bpg
+
 extern "C" {
 
 void bp_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
@@ -502,29 +394,53 @@ int bp_compact_decode(const uint8_t* witness, size_t len, uint8_t* header_versio
                       uint32_t* n_accounts, uint32_t* n_storage_tries, uint32_t* n_code,
                       uint32_t* n_accounts_missing_storage) try {
   if (!witness && len) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_compact_decode: null witness");
-  uint8_t ver = 0;
-  std::vector<Instr> ins;
+  bpg::CompactOut d;
   std::string err;
-  if (!parse_instructions(witness, len, &ver, &ins, &err)) return bpg::fail(BP_ERR_INVALID_INPUT, "%s", err.c_str());
-  Decoded d;
-  NodeP root;
-  if (!build_tree(ins, &d, &root, &err)) return bpg::fail(BP_ERR_INVALID_INPUT, "%s", err.c_str());
-  if (root && root->kind == Kind::Code) d.code[keccak256(root->payload)] = root->payload;
-  H256 sr = trie_root(root, &d);
-  if (header_version) *header_version = ver;
+  if (!bpg::decode_compact(witness, len, &d, &err)) return bpg::fail(BP_ERR_INVALID_INPUT, "%s", err.c_str());
+  const H256 sr = d.state.hash();
+  if (header_version) *header_version = d.header_version;
   if (state_root) std::memcpy(state_root, sr.data(), 32);
   if (n_accounts) *n_accounts = (uint32_t)d.accounts.size();
-  if (n_storage_tries) *n_storage_tries = (uint32_t)d.storage_roots.size();
+  if (n_storage_tries) *n_storage_tries = (uint32_t)d.storage_by_root.size();
   if (n_code) *n_code = (uint32_t)d.code.size();
   if (n_accounts_missing_storage) {  // complex_test_payloads.rs:73-90: every non-empty root must have its trie
     uint32_t miss = 0;
     for (auto& a : d.accounts)
-      if (a.second != EMPTY_TRIE_HASH && !d.storage_roots.count(a.second)) miss++;
+      if (a.second.storage_root != EMPTY_TRIE_HASH && !d.storage_by_root.count(a.second.storage_root)) miss++;
     *n_accounts_missing_storage = miss;
   }
   return BP_OK;
 }
 BPG_ABI_CATCH("bp_compact_decode")
+
+// The reference's full output (ProcessedCompactOutput{header, witness_out{tries{state, storage}, code}},
+// compact_prestate_processing.rs:1243-1281) in the byte layout of DESIGN.md section 8c:
+//   "BPGCWIT1" | version:u8 | state: len:u32 trie | n_storage:u32 (h_addr[32] len:u32 trie)* | n_code:u32 (hash[32] len:u32 bytes)*
+// storage tries keyed by HASHED ACCOUNT ADDRESS (after the re-keying of compact_to_partial_trie.rs:167-190), both
+// lists in ascending key order; tries in the node format of mpt.cpp.  Release with bp_free_buffer.
+int bp_compact_decode_full(const uint8_t* witness, size_t len, uint8_t** out, size_t* out_len) try {
+  if ((!witness && len) || !out || !out_len) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_compact_decode_full: null argument");
+  bpg::CompactOut d;
+  std::string err;
+  if (!bpg::decode_compact(witness, len, &d, &err)) return bpg::fail(BP_ERR_INVALID_INPUT, "%s", err.c_str());
+  Bytes o;
+  const char magic[8] = {'B', 'P', 'G', 'C', 'W', 'I', 'T', '1'};
+  o.insert(o.end(), magic, magic + 8);
+  o.push_back(d.header_version);
+  bpg::put_blob(&o, bpg::trie_bytes(d.state));
+  bpg::put_u32(&o, (uint32_t)d.storage.size());
+  for (auto& kv : d.storage) {
+    o.insert(o.end(), kv.first.begin(), kv.first.end());
+    bpg::put_blob(&o, bpg::trie_bytes(kv.second));
+  }
+  bpg::put_u32(&o, (uint32_t)d.code.size());
+  for (auto& kv : d.code) {
+    o.insert(o.end(), kv.first.begin(), kv.first.end());
+    bpg::put_blob(&o, kv.second);
+  }
+  return bpg::emit_bytes(o, out, out_len);
+}
+BPG_ABI_CATCH("bp_compact_decode_full")
 
 // Instruction listing, one per line ("leaf <key nibbles hex> <value hex>", "branch <mask>", ...), for the
 // instruction-level KAT (compact_prestate_processing.rs:1471-1497).  Release with bp_free_buffer.

@@ -81,6 +81,7 @@ struct WorkerLease {
     (void)hipStreamSynchronize(w->stream);
     w->arena.release(mark);
     w->abort_flag = nullptr;
+    w->abort_flag_u8 = nullptr;
     std::lock_guard<std::mutex> lk(s->mu);
     s->idle.push_back(w);
     s->cv.notify_one();
@@ -106,6 +107,7 @@ struct TryLease {
     (void)hipStreamSynchronize(w->stream);
     w->arena.release(mark);
     w->abort_flag = nullptr;
+    w->abort_flag_u8 = nullptr;
     std::lock_guard<std::mutex> lk(s->mu);
     s->idle.push_back(w);
     s->cv.notify_one();
@@ -350,8 +352,8 @@ int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_
 }
 BPG_ABI_CATCH("bp_proof_public_values")
 
-int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
-                          uint8_t** out, size_t* out_len) try {
+static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
+                          const volatile uint8_t* abort_flag_u8, uint8_t** out, size_t* out_len) {
   if (!s || !ir || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof: null argument");
   if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
   const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
@@ -387,6 +389,7 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   WorkerLease lease(s);
   Worker& w = *lease.w;
   w.abort_flag = abort_flag;
+  w.abort_flag_u8 = abort_flag_u8;
   if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before start");
   int r;
   // generate_traces + trace commitments for all tables, then the shared transcript prologue
@@ -444,6 +447,7 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
       Helper& h = helpers[t];
       h.lease = std::move(l);
       h.lease->w->abort_flag = abort_flag;
+      h.lease->w->abort_flag_u8 = abort_flag_u8;
       try {
         h.th = std::thread([&, t] {
           Helper& hh = helpers[t];
@@ -476,7 +480,18 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   if ((r = rec_prove(w, s->rec_cfg, s->special[0], pi, proof))) return r;
   return emit_box(0, CIRCUIT_ROOT, pi, proof, out, out_len);
 }
+int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
+                          uint8_t** out, size_t* out_len) try {
+  return txn_proof_impl(s, ir, ir_len, abort_flag, nullptr, out, out_len);
+}
 BPG_ABI_CATCH("bp_generate_txn_proof")
+// The same call with the reference's own flag type: Option<Arc<AtomicBool>> (proof_gen.rs:42) is one byte,
+// `flag.as_ptr()` binds directly.
+int bp_generate_txn_proof_u8(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile uint8_t* abort_flag,
+                             uint8_t** out, size_t* out_len) try {
+  return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len);
+}
+BPG_ABI_CATCH("bp_generate_txn_proof_u8")
 
 int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
                           const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len) try {

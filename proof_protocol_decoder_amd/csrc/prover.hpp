@@ -106,13 +106,14 @@ struct Worker {
   unsigned long long* d_pow_result = nullptr;
   hipEvent_t sync_event = nullptr;  // blocking-sync event: waiting threads sleep instead of spinning
   const volatile int32_t* abort_flag = nullptr;
+  const volatile uint8_t* abort_flag_u8 = nullptr;  // AtomicBool::as_ptr() of the reference's Arc<AtomicBool>
   int device = 0;
 
   int init(int device, size_t arena_bytes);
   void destroy();
   int d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words);  // async copy + stream sync
   int wait();  // everything queued on the stream has completed (blocking event)
-  bool aborted() const { return abort_flag && *abort_flag; }
+  bool aborted() const { return (abort_flag && *abort_flag) || (abort_flag_u8 && *abort_flag_u8); }
 };
 
 // PolynomialBatch::from_values / from_coeffs: LDE + Merkle.  d_in is n_cols x n (values natural, or

@@ -235,12 +235,18 @@ def _out():
 
 
 def generate_txn_proof(p_state, gen_inputs, abort_signal=None):
-    """proof_gen.rs:39-56.  abort_signal: optional ctypes.c_int32 shared flag (Arc<AtomicBool>)."""
+    """proof_gen.rs:39-56.  abort_signal: optional shared flag (the reference's Option<Arc<AtomicBool>>): a
+    ctypes.c_uint8 / c_bool (one byte, what AtomicBool is: bp_generate_txn_proof_u8) or a ctypes.c_int32."""
     L = _bind()
     ir = gen_inputs.to_bytes() if isinstance(gen_inputs, TxnProofGenIR) else bytes(gen_inputs)
     out, n = _out()
     flag = C.byref(abort_signal) if abort_signal is not None else None
-    check(L.bp_generate_txn_proof(p_state._h, ir, len(ir), flag, C.byref(out), C.byref(n)))
+    if abort_signal is not None and C.sizeof(abort_signal) == 1:
+        L.bp_generate_txn_proof_u8.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p,
+                                               C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        check(L.bp_generate_txn_proof_u8(p_state._h, ir, len(ir), flag, C.byref(out), C.byref(n)))
+    else:
+        check(L.bp_generate_txn_proof(p_state._h, ir, len(ir), flag, C.byref(out), C.byref(n)))
     intern = take_buffer(out, n)
     return GeneratedTxnProof(public_values_of(intern)[0], intern)
 

@@ -145,6 +145,13 @@ def test_abort_signal(pg, p_state):
     assert e.value.code == -1
     flag.value = 0
     pg.generate_txn_proof(p_state, make_ir(pg, 7, 0, 5), abort_signal=flag)   # the worker is reusable afterwards
+    # the reference's own flag type: Arc<AtomicBool> is one byte (proof_gen.rs:42)
+    flag8 = ctypes.c_uint8(1)
+    with pytest.raises(pg.ProofGenError) as e:
+        pg.generate_txn_proof(p_state, make_ir(pg, 7, 0, 5), abort_signal=flag8)
+    assert e.value.code == -1
+    flag8.value = 0
+    pg.generate_txn_proof(p_state, make_ir(pg, 7, 0, 5), abort_signal=flag8)
 
 
 def test_concurrent_callers_share_the_state(pg, p_state, o_state):
