@@ -260,19 +260,21 @@ def isolated_roofline(pkg, torch):
 
 
 def ntt_gbps(pkg, torch):
-    """BASELINE metric (ii), Goldilocks NTT HBM GB/s: the batched inverse NTT (natural -> bit-reversed, one kernel
-    launch up to 2^14 rows, strided passes above) alone on the chip at four shapes of SURVEY.md section 8(d) S4.
+    """BASELINE metric (ii), Goldilocks NTT HBM GB/s: the batched inverse NTT (natural -> bit-reversed, out of
+    place: bp_intt_batch; one kernel launch up to 2^14 rows, one more HBM round trip up to 2^22) alone on the chip
+    at four shapes of SURVEY.md section 8(d) S4.
     Algorithmic bytes 16*n*C per transform; fraction of the 8 TB/s HBM peak beside it."""
     out = {}
     for log_n, cols in ((12, 2048), (14, 2048), (16, 256), (20, 64)):
         v = torch.randint(0, 2**62, (cols, 1 << log_n), dtype=torch.int64, device="cuda")
-        pkg.ops.ntt_batch_(v, pkg.ops.NTT_INV_NAT2BR)
+        o = torch.empty_like(v)
+        pkg.ops.intt_batch(v, o)      # values -> coefficients, out of place as in PolynomialBatch::from_values
         torch.cuda.synchronize()
         best = 1e9
         for _ in range(5):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            pkg.ops.ntt_batch_(v, pkg.ops.NTT_INV_NAT2BR)
+            pkg.ops.intt_batch(v, o)
             b.record()
             torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b))

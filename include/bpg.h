@@ -71,6 +71,12 @@ enum { BP_NTT_FWD_BR2NAT = 0, BP_NTT_INV_NAT2BR = 1, BP_NTT_FWD_NAT = 2, BP_NTT_
 int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir,
                  void* stream);
 
+/* K2.  The inverse transform out of place (what PolynomialBatch::from_values does first: the values stay, the
+ * coefficients, bit-reversed and scaled by 1/n, go to d_coeffs_out).  The two buffers must be the same pointer
+ * (in place) or not overlap. */
+int bp_intt_batch(const uint64_t* d_values, uint64_t in_stride, uint64_t* d_coeffs_out, uint64_t out_stride,
+                  uint32_t log_n, uint32_t n_cols, void* stream);
+
 /* K2.  PolynomialBatch::from_values / from_coeffs low-degree extension.
  *   d_in: n_cols columns of n values (natural) or, if from_coeffs, n coefficients (bit-reversed);
  *   d_coeffs_out (nullable unless !from_coeffs... may alias nothing): n_cols x n coefficients, bit-reversed;

@@ -29,7 +29,31 @@ constexpr uint32_t LOG_BLK_MAX = 14;  // 2^14 * 8 B = 128 KiB of the 160 KiB LDS
 // S = sub << LOGR; j = base mod sub.  `tw` is the table w_N^e, e < N/2, tw_shift = log2(N/S).
 // The R/2 twiddle multiplies of a stage are independent: they go through gl::mul_n in groups of four
 // (instruction-interleaved carry chains, gl.hpp), falling back to the one-at-a-time form for R < 8.
-template <int LOGR>
+// J0: the caller guarantees j == 0 and log_sub == 0 (the innermost pass: 2^LOGR consecutive elements of a block
+// that starts at a multiple of 2^LOGR).  The twiddle of a butterfly is then a compile-time power w^(m mod half),
+// and a third to all of them are w^0 = 1: those multiplies are skipped (15 of the 32 of a radix-16 pass).
+// The remaining ones are gathered into groups of four / three for gl::mul_n; after full unrolling every index
+// below is a constant.
+template <int N>
+__device__ __forceinline__ void mul_group(uint64_t (&x)[16], const int (&idx)[4], const uint64_t (&d)[4], const uint64_t (&w)[4]) {
+  if constexpr (N == 4) {
+    uint64_t r[4];
+    gl::mul_n<4>(d, w, r);
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[idx[i]] = r[i];
+  } else if constexpr (N == 3) {
+    const uint64_t d3[3] = {d[0], d[1], d[2]}, w3[3] = {w[0], w[1], w[2]};
+    uint64_t r[3];
+    gl::mul_n<3>(d3, w3, r);
+#pragma unroll
+    for (int i = 0; i < 3; i++) x[idx[i]] = r[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) x[idx[i]] = gl::mul(d[i], w[i]);
+  }
+}
+
+template <int LOGR, bool J0 = false>
 __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const uint64_t* __restrict__ tw,
                                                 uint32_t j, uint32_t log_sub, uint32_t tw_shift) {
   constexpr int R = 1 << LOGR, NB = R / 2;
@@ -37,7 +61,56 @@ __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const 
   for (int s = 0; s < LOGR; s++) {
     const int half = R >> (s + 1);
     // butterfly k of the stage pairs x[m], x[m + half], m = (k / half) * 2 * half + k % half
-    if constexpr (NB % 4 == 0) {
+    if constexpr (NB % 4 == 0 && J0 && LOGR == 4) {
+      uint64_t dd[NB];
+#pragma unroll
+      for (int k0 = 0; k0 < NB; k0 += 4) {
+        uint64_t a[4], b[4], d[4], r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
+          a[i] = x[m];
+          b[i] = x[m + half];
+        }
+        gl::canon_n<4>(b);
+        gl::add_n<4>(a, b, r);
+        gl::sub_n<4>(a, b, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
+          x[m] = r[i];
+          dd[k] = d[i];
+        }
+      }
+      // multiply only where the twiddle is not 1
+      int cnt = 0;
+      int idx[4] = {0, 0, 0, 0};
+      uint64_t dv[4] = {0, 0, 0, 0}, wv[4] = {0, 0, 0, 0};
+      uint64_t xx[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) xx[i] = x[i];
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const int m = (k / half) * 2 * half + (k % half), e = m & (half - 1);
+        if (e == 0) {
+          xx[m + half] = dd[k];
+        } else {
+          idx[cnt] = m + half;
+          dv[cnt] = dd[k];
+          wv[cnt] = tw[(uint32_t)e << (tw_shift + s)];
+          cnt++;
+          if (cnt == 4) {
+            mul_group<4>(xx, idx, dv, wv);
+            cnt = 0;
+          }
+        }
+      }
+      if (cnt == 3) mul_group<3>(xx, idx, dv, wv);
+      else if (cnt == 2) mul_group<2>(xx, idx, dv, wv);
+      else if (cnt == 1) mul_group<1>(xx, idx, dv, wv);
+#pragma unroll
+      for (int i = 0; i < 16; i++) x[i] = xx[i];
+    } else if constexpr (NB % 4 == 0) {
 #pragma unroll
       for (int k0 = 0; k0 < NB; k0 += 4) {
         uint64_t a[4], b[4], d[4], w[4], r[4];
@@ -73,23 +146,70 @@ __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const 
 #pragma unroll
       for (int m = 0; m < R; m++) {
         if (m & half) continue;
-        const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);
-        const uint64_t w = tw[p << (tw_shift + s)];
         const uint64_t a = x[m], b = gl::canon(x[m + half]);
         x[m] = gl::add(a, b);
-        x[m + half] = gl::mul(gl::sub(a, b), w);
+        if (J0 && (m & (half - 1)) == 0) {
+          x[m + half] = gl::sub(a, b);  // twiddle w^0
+        } else {
+          const uint32_t p = j + ((uint32_t)(m & (half - 1)) << log_sub);
+          x[m + half] = gl::mul(gl::sub(a, b), tw[p << (tw_shift + s)]);
+        }
       }
     }
   }
 }
-template <int LOGR>
+template <int LOGR, bool J0 = false>
 __device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const uint64_t* __restrict__ tw,
                                                 uint32_t j, uint32_t log_sub, uint32_t tw_shift) {
   constexpr int R = 1 << LOGR, NB = R / 2;
 #pragma unroll
   for (int s = 0; s < LOGR; s++) {
     const int step = 1 << s;  // stage block size = sub << (s+1); tw_shift is for S = sub << LOGR
-    if constexpr (NB % 4 == 0) {
+    if constexpr (NB % 4 == 0 && J0 && LOGR == 4) {
+      // products first (only where the twiddle is not 1), then the additions of the whole stage
+      uint64_t xx[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) xx[i] = x[i];
+      int cnt = 0;
+      int idx[4] = {0, 0, 0, 0};
+      uint64_t dv[4] = {0, 0, 0, 0}, wv[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const int m = (k / step) * 2 * step + (k % step), e = m & (step - 1);
+        if (e != 0) {
+          idx[cnt] = m + step;
+          dv[cnt] = x[m + step];
+          wv[cnt] = tw[(uint32_t)e << (tw_shift + (LOGR - 1 - s))];
+          cnt++;
+          if (cnt == 4) {
+            mul_group<4>(xx, idx, dv, wv);
+            cnt = 0;
+          }
+        }
+      }
+      if (cnt == 3) mul_group<3>(xx, idx, dv, wv);
+      else if (cnt == 2) mul_group<2>(xx, idx, dv, wv);
+      else if (cnt == 1) mul_group<1>(xx, idx, dv, wv);
+#pragma unroll
+      for (int k0 = 0; k0 < NB; k0 += 4) {
+        uint64_t a[4], r[4], hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / step) * 2 * step + (k % step);
+          a[i] = xx[m];
+          r[i] = xx[m + step];
+        }
+        gl::canon_n<4>(r);
+        gl::add_n<4>(a, r, hi);
+        gl::sub_n<4>(a, r, lo);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = k0 + i, m = (k / step) * 2 * step + (k % step);
+          x[m] = hi[i];
+          x[m + step] = lo[i];
+        }
+      }
+    } else if constexpr (NB % 4 == 0) {
 #pragma unroll
       for (int k0 = 0; k0 < NB; k0 += 4) {
         uint64_t a[4], v[4], w[4], r[4], hi[4], lo[4];
@@ -118,8 +238,9 @@ __device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const 
       for (int m = 0; m < R; m++) {
         if (m & step) continue;
         const uint32_t p = j + ((uint32_t)(m & (step - 1)) << log_sub);
-        const uint64_t w = tw[p << (tw_shift + (LOGR - 1 - s))];
-        const uint64_t a = x[m], t = gl::mulc(x[m + step], w);
+        const uint64_t a = x[m];
+        const uint64_t t = (J0 && (m & (step - 1)) == 0) ? gl::canon(x[m + step])
+                                                         : gl::mulc(x[m + step], tw[p << (tw_shift + (LOGR - 1 - s))]);
         x[m] = gl::add(a, t);
         x[m + step] = gl::sub(a, t);
       }
@@ -234,8 +355,8 @@ __device__ __forceinline__ void sub_butterflies(uint64_t (&x)[16], const uint64_
 #pragma unroll
     for (int u = 0; u < (1 << R); u++) y[u] = CONTIG ? x[(g << R) + u] : x[g + (u << SH)];
     const uint32_t jj = CONTIG ? 0u : j + ((uint32_t)g << j_step_log);
-    if (DIF) dif_butterflies<R>(y, tw, jj, log_sub, tw_shift);
-    else dit_butterflies<R>(y, tw, jj, log_sub, tw_shift);
+    if (DIF) dif_butterflies<R, CONTIG>(y, tw, jj, log_sub, tw_shift);   // CONTIG is only used with j = 0, log_sub = 0
+    else dit_butterflies<R, CONTIG>(y, tw, jj, log_sub, tw_shift);
 #pragma unroll
     for (int u = 0; u < (1 << R); u++) {
       if (CONTIG) x[(g << R) + u] = y[u];
@@ -454,7 +575,7 @@ __global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per
   // innermost field [3:0]
 #pragma unroll
   for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(base | m)];
-  dit_butterflies<4>(x, tw, 0, 0, L - 4);
+  dit_butterflies<4, true>(x, tw, 0, 0, L - 4);
 #pragma unroll
   for (int m = 0; m < 16; m++) buf[swz<L>(base | m)] = x[m];
   __syncthreads();
@@ -929,6 +1050,23 @@ int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col
   }
 }
 BPG_ABI_CATCH("bp_ntt_batch")
+
+// The first half of PolynomialBatch::from_values as its own entry: values stay, coefficients go to a second
+// buffer.  Out of place lets a 2^13 / 2^14-point block be transformed by two workgroups (Ntt16Args).
+int bp_intt_batch(const uint64_t* d_values, uint64_t in_stride, uint64_t* d_coeffs_out, uint64_t out_stride,
+                  uint32_t log_n, uint32_t n_cols, void* stream) try {
+  if (n_cols == 0) return BP_OK;
+  if (!d_values || !d_coeffs_out) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_intt_batch: null buffer");
+  const uint64_t n = (uint64_t)1 << log_n;
+  if (log_n > 30 || in_stride < n || out_stride < n) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_intt_batch: bad shape (log_n=%u)", log_n);
+  const uint64_t span_in = in_stride * (n_cols - 1) + n, span_out = out_stride * (n_cols - 1) + n;
+  if (d_values != d_coeffs_out && d_values < d_coeffs_out + span_out && d_coeffs_out < d_values + span_in)
+    return bpg::fail(BP_ERR_INVALID_INPUT, "bp_intt_batch: buffers overlap (use the same pointer for in place)");
+  int rc;
+  if ((rc = bpg::init_ntt_kernels())) return rc;
+  return bpg::intt_nat2br(d_values, in_stride, d_coeffs_out, out_stride, log_n, n_cols, true, bpg::as_stream(stream));
+}
+BPG_ABI_CATCH("bp_intt_batch")
 
 int bp_lde_batch(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_coeffs_out, uint64_t coeffs_stride,
                  uint64_t* d_lde_out, uint64_t lde_stride, uint32_t log_n, uint32_t rate_bits, uint32_t n_cols,

@@ -33,6 +33,18 @@ def ntt_batch_(cols, direction):
     return cols
 
 
+def intt_batch(values, out=None):
+    """Out-of-place inverse NTT: values [n_cols, n] natural -> coefficients (bit-reversed, scaled by 1/n)."""
+    import ctypes as C
+    _require_cuda(values)
+    n_cols, n = values.shape
+    out = torch.empty_like(values) if out is None else out
+    L = lib()
+    L.bp_intt_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    check(L.bp_intt_batch(values.data_ptr(), n, out.data_ptr(), n, n.bit_length() - 1, n_cols, _stream()))
+    return out
+
+
 def lde_batch(inp, rate_bits, from_coeffs=False):
     """values/coeffs [n_cols, n] -> (coeffs [n_cols, n] bit-reversed, lde [n_cols, n << rate_bits] coset-major)."""
     _require_cuda(inp)

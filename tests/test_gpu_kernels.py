@@ -23,6 +23,10 @@ def test_ntt_matches_oracle(bpg, oracle, log_n, n_cols):
     want_vals = oracle.ntt_batch(vals, inverse=False)
     got = to_host(bpg.ops.ntt_batch_(to_dev(vals[:, br]), bpg.ops.NTT_FWD_BR2NAT))
     assert (got == want_vals).all()
+    # out of place (two workgroups per 2^13 / 2^14-point block): the same coefficients, input untouched
+    d_vals = to_dev(vals)
+    got = to_host(bpg.ops.intt_batch(d_vals))
+    assert (got[:, br] == want_coeffs).all() and (to_host(d_vals) == vals).all()
     # natural-order API (plonky2 fft/ifft semantics)
     got = to_host(bpg.ops.ntt_batch_(to_dev(vals), bpg.ops.NTT_FWD_NAT))
     assert (got == want_vals).all()
