@@ -828,12 +828,14 @@ static uint32_t pick_log_blk(uint32_t log_n) { return plan_ntt(log_n).log_blk; }
 // Split form (Ntt16Args), out of place only: always for 2^14-point blocks (one 128 KiB workgroup per CU cannot overlap its phases),
 // and for 2^13-point blocks when the launch has too few workgroups to fill the chip (latency, not throughput).
 static std::atomic<int> g_ntt_split{0};  // 0 = automatic, 1 = never, 2 = wherever possible (measurement knob)
-static bool use_split(uint32_t log_blk, uint64_t workgroups, const void* src, const void* dst) {
+static bool use_split(uint32_t log_blk, uint64_t workgroups, const void* src, const void* dst, bool dit) {
   const int mode = g_ntt_split.load(std::memory_order_relaxed);
   // never in place: each of the two workgroups reads the WHOLE block while its partner may already be storing
   if (mode == 1 || log_blk < 13 || src == dst) return false;
   if (mode == 2 || log_blk == 14) return true;
-  return workgroups < 512;
+  // small launches: the DIF form halves their latency (2^13 x 16: 23 -> 19 us); the DIT form gains nothing there
+  // (tools/ntt_split_probe.py) and its stride-2 stores cost HBM write traffic (PMC: +14 %), so it stays unsplit
+  return !dit && workgroups < 512;
 }
 
 static uint32_t lds_threads(uint32_t log_blk) {
@@ -900,7 +902,7 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
     b.tw = tw_b; b.scale = nullptr; b.out_scalar = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
     b.log_n_total = log_n; b.n_cosets = 1; b.n_units = 0;
     KernelTimer kt(PROF_INTT_DIF, st, 16.0 * (double)n_cols * (double)((uint64_t)1 << log_n));
-    if (use_split(log_blk, (uint64_t)n_cols << (log_n - log_blk), src, out)) {
+    if (use_split(log_blk, (uint64_t)n_cols << (log_n - log_blk), src, out, false)) {
       // two workgroups of the next smaller kernel per block (see Ntt16Args)
       if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
       b.tw_top = tw_b;
@@ -949,7 +951,7 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
     b.n_units = n_cols << (log_n - log_blk);
     {
       KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
-      if (use_split(log_blk, (uint64_t)b.n_units * n_cosets, in, out)) {
+      if (use_split(log_blk, (uint64_t)b.n_units * n_cosets, in, out, true)) {
         if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
         b.tw_top = tw_b;
         const dim3 grid1((b.n_units + 7) / 8 * 8 * n_cosets * 2);
