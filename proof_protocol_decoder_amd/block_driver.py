@@ -261,3 +261,34 @@ def irs_from_block_trace(block_trace, block_number, table_log_n, table_width, ha
                                     tuple(table_width)))
         root, gas = pg.state_root_after(root, seed, i), gas + m.gas_used
     return pad_with_dummy_irs(irs, block_number, root0, table_log_n, table_width, has_withdrawals)[0]
+
+
+def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width):
+    """`Vec<TxnProofGenIR>` as produced by `decoding.into_txn_proof_gen_ir` (the reference's
+    BlockTrace::into_txn_proof_gen_ir: minimal tries, delta replay, dummy padding, withdrawals) -> the IRs this
+    library's prover takes.  The zkEVM that would consume the partial tries is upstream-only, so
+    each entry is bound to its proof through the witness seed: seed = keccak(signed_txn | state, transactions and
+    receipts roots after | withdrawals), i.e. a different decoded state transition gives a different proof.  Txn
+    number and gas come from the decoded entries; the state-root public value starts at the decoded pre-state
+    root (folded into four field elements) and chains entry to entry.  Entries without a transaction (dummy
+    padding, the withdrawal carrier) become dummy IRs: proven, counters do not advance (decoding.rs:484-520) --
+    a prepended dummy is renumbered to its position, as pad_with_dummy_irs documents."""
+    from . import compact
+    P = 0xFFFFFFFF00000001
+    first = gen_inputs[0].tries.state_trie.hash()
+    root = tuple(int.from_bytes(first[8 * i:8 * i + 8], "little") % P for i in range(4))
+    irs, txn_no, gas = [], 0, 0
+    for k, g in enumerate(gen_inputs):
+        r = g.trie_roots_after
+        blob = (g.signed_txn or b"") + r.state_root + r.transactions_root + r.receipts_root
+        blob += b"".join(bytes(a) + int(v).to_bytes(32, "big") for a, v in g.withdrawals)
+        seed = int.from_bytes(compact.keccak256(blob)[:8], "little")
+        if g.signed_txn is None:
+            irs.append(pg.TxnProofGenIR(block_number, txn_no, gas, gas, root, seed, tuple(table_log_n), tuple(table_width),
+                                        dummy=True))
+            continue
+        used = g.gas_used_after - g.gas_used_before
+        irs.append(pg.TxnProofGenIR(block_number, txn_no, gas, gas + used, root, seed, tuple(table_log_n),
+                                    tuple(table_width)))
+        root, txn_no, gas = pg.state_root_after(root, seed, txn_no), txn_no + 1, gas + used
+    return irs

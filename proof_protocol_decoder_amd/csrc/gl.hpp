@@ -231,14 +231,14 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
 // mul_n: the same carry chains as add() / sub() / canon(), no s_nop.  a: any u64, b: canonical.
 template <int N>
 __device__ __forceinline__ void add_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
-  uint32_t lo[N], hi[N], bl[N], bh[N], e[N];
+  uint32_t al[N], ah[N], bl[N], bh[N], lo[N], hi[N], e[N];
   cc::mask c1[N], c2[N], c3[N], cx[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    lo[i] = (uint32_t)a[i]; hi[i] = (uint32_t)(a[i] >> 32); bl[i] = (uint32_t)b[i]; bh[i] = (uint32_t)(b[i] >> 32);
+    al[i] = (uint32_t)a[i]; ah[i] = (uint32_t)(a[i] >> 32); bl[i] = (uint32_t)b[i]; bh[i] = (uint32_t)(b[i] >> 32);
   }
-  cc::add_co(lo, c1, bl);
-  cc::addc_co(hi, c2, bh, c1);
+  cc::add_co_o(lo, c1, al, bl);      // out of place: a and b stay live for the caller without copies
+  cc::addc_co_o(hi, c2, ah, bh, c1);
   cc::sel_eps(e, c2);
   cc::add_co(lo, c3, e);
   cc::addc0_co(hi, cx, c3);
@@ -247,14 +247,14 @@ __device__ __forceinline__ void add_n(const uint64_t (&a)[N], const uint64_t (&b
 }
 template <int N>
 __device__ __forceinline__ void sub_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
-  uint32_t lo[N], hi[N], bl[N], bh[N], e[N];
+  uint32_t al[N], ah[N], bl[N], bh[N], lo[N], hi[N], e[N];
   cc::mask b1[N], b2[N], b3[N], bx[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    lo[i] = (uint32_t)a[i]; hi[i] = (uint32_t)(a[i] >> 32); bl[i] = (uint32_t)b[i]; bh[i] = (uint32_t)(b[i] >> 32);
+    al[i] = (uint32_t)a[i]; ah[i] = (uint32_t)(a[i] >> 32); bl[i] = (uint32_t)b[i]; bh[i] = (uint32_t)(b[i] >> 32);
   }
-  cc::sub_co(lo, b1, bl);
-  cc::subb_co(hi, b2, bh, b1);
+  cc::sub_co_o(lo, b1, al, bl);
+  cc::subb_co_o(hi, b2, ah, bh, b1);
   cc::sel_eps(e, b2);
   cc::sub_co(lo, b3, e);
   cc::subb0_co(hi, bx, b3);
@@ -267,10 +267,10 @@ __device__ __forceinline__ void canon_n(uint64_t (&a)[N]) {
   cc::mask k[N], c[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    lo[i] = tl[i] = (uint32_t)a[i]; hi[i] = th[i] = (uint32_t)(a[i] >> 32);
+    lo[i] = (uint32_t)a[i]; hi[i] = (uint32_t)(a[i] >> 32);
   }
-  cc::add_m1_co(tl, k);
-  cc::addc0_co(th, c, k);
+  cc::add_m1_co_o(tl, k, lo);
+  cc::addc0_co_o(th, c, hi, k);
   cc::sel(lo, tl, c);
   cc::sel(hi, th, c);
 #pragma unroll

@@ -397,3 +397,25 @@ def test_trie_operations_against_from_scratch_builds():
         m.acc[Cc][2] = st
         assert ir.trie_roots_after.state_root == m.state_trie().hash()
     assert m.storage_trie(Cc).hash() == pt.EMPTY_TRIE_HASH
+
+
+def test_generation_inputs_map_to_prover_irs():
+    """decoded GenerationInputs -> the prover's IRs: counters from the decoded entries, dummies do not advance,
+    the seed commits to the decoded roots (a different state transition = a different witness seed)."""
+    from proof_protocol_decoder_amd.block_driver import irs_from_generation_inputs
+    m = fresh_model()
+    txns = block(m)
+    other = decoding.OtherBlockData(decoding.BlockLevelData(withdrawals=[(B, 100)]))
+    gis = decoding.into_txn_proof_gen_ir(make_trace(m, [t for t, _ in txns]), other)
+    irs = irs_from_generation_inputs(gis, 17, (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8))
+    assert [ir.dummy for ir in irs] == [False, False, False, True]
+    assert [ir.txn_number_before for ir in irs] == [0, 1, 2, 3]
+    assert [(ir.gas_used_before, ir.gas_used_after) for ir in irs] == [(0, 21000), (21000, 71000), (71000, 161000), (161000, 161000)]
+    assert all(len(ir.to_bytes()) == 200 for ir in irs)
+    # same payload but a different balance in txn 0: every seed from there on changes
+    m2 = fresh_model()
+    t2 = block(m2)
+    t2[0][0].traces[B].balance += 1
+    irs2 = irs_from_generation_inputs(decoding.into_txn_proof_gen_ir(make_trace(m2, [t for t, _ in t2]), other), 17,
+                                      (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8))
+    assert irs2[0].state_root_before == irs[0].state_root_before and all(a.seed != b.seed for a, b in zip(irs, irs2))

@@ -191,6 +191,29 @@ def test_block_trace_payload_to_block_proof(bpg, pg, p_state):
     assert pv.gas_used_after == sum(21000 + i for i in range(5)) and tuple(pv.state_root_before) == irs[0].state_root_before
 
 
+def test_decoded_block_trace_to_block_proof(bpg, pg, p_state):
+    """Front door with the REAL decoder: a block trace whose compact pre-image and
+    account traces are replayed natively (minimal tries, deltas, withdrawals: bp_decode_block_trace) -> IRs ->
+    txn proofs, aggregation tree, block proof -> VerifierState::verify."""
+    import test_decoding as td
+    from proof_protocol_decoder_amd import decoding
+    from proof_protocol_decoder_amd.block_driver import BlockDriver, irs_from_generation_inputs
+    m = td.fresh_model()
+    infos = [t for t, _ in td.block(m)]
+    other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", [(td.B, 100)]), b"\x22" * 32)
+    gis = decoding.into_txn_proof_gen_ir(td.make_trace(m, infos, hash_out_storage_of=(td.E,)), other)
+    irs = irs_from_generation_inputs(gis, 21, LOG_N, WIDTH)
+    drv = BlockDriver(p_state, n_threads=2)
+    try:
+        blk = drv.prove_block_distributed(irs)
+    finally:
+        drv.close()
+    pg.VerifierState.from_prover_state(p_state).verify(blk)
+    pv, kind = pg.public_values_of(blk.intern)
+    assert kind == 2 and blk.b_height == 21 and (pv.txn_number_before, pv.txn_number_after) == (0, 3)
+    assert pv.gas_used_after == 161000 and tuple(pv.state_root_before) == irs[0].state_root_before
+
+
 def test_dummy_entries_and_short_blocks(bpg, pg, p_state, o_state):
     """Padding entries (decoding.rs:304-347, 484-520): the dummy IR is proven byte-for-byte like the oracle's, and
     blocks of 0 and 1 transactions -- padded the way the reference pads them -- yield verifying block proofs."""
