@@ -825,17 +825,20 @@ static NttPlan plan_ntt(uint32_t log_n) {
 }
 static uint32_t pick_log_blk(uint32_t log_n) { return plan_ntt(log_n).log_blk; }
 
-// Split form (Ntt16Args), out of place only: always for 2^14-point blocks (one 128 KiB workgroup per CU cannot overlap its phases),
-// and for 2^13-point blocks when the launch has too few workgroups to fill the chip (latency, not throughput).
+// Split form (Ntt16Args), out of place only.
 static std::atomic<int> g_ntt_split{0};  // 0 = automatic, 1 = never, 2 = wherever possible (measurement knob)
 static bool use_split(uint32_t log_blk, uint64_t workgroups, const void* src, const void* dst, bool dit) {
   const int mode = g_ntt_split.load(std::memory_order_relaxed);
   // never in place: each of the two workgroups reads the WHOLE block while its partner may already be storing
   if (mode == 1 || log_blk < 13 || src == dst) return false;
-  if (mode == 2 || log_blk == 14) return true;
-  // small launches: the DIF form halves their latency (2^13 x 16: 23 -> 19 us); the DIT form gains nothing there
-  // (tools/ntt_split_probe.py) and its stride-2 stores cost HBM write traffic (PMC: +14 %), so it stays unsplit
-  return !dit && workgroups < 512;
+  if (mode == 2) return true;
+  // The DIT form stays off by default: its stride-2 stores (each workgroup writes every other word of a line)
+  // inflate the HBM write traffic of the 2^14 x 2432 LDE by 1.66x (PMC WRITE_SIZE: 1,036,585 KiB against
+  // 622,592 KiB algorithmic) for a 6 % shorter launch, and it gains nothing on small launches.  The DIF form
+  // writes contiguous halves: 2^14-point blocks always (+23 %), 2^13-point blocks when the launch has too few
+  // workgroups to fill the chip (2^13 x 16: 23 -> 19 us).
+  if (dit) return false;
+  return log_blk == 14 || workgroups < 512;
 }
 
 static uint32_t lds_threads(uint32_t log_blk) {
