@@ -190,7 +190,7 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
   // every step overwrites one of its operands (gl_cc.inc): per element P, M, Q and one scratch word
   uint32_t a1[N], b0[N], t0[N], t1[N], m0[N], m1[N], q0[N], q1[N], e[N];
   uint64_t P[N], M[N], Q[N];
-  cc::mask C[N], c1[N], c2[N], c3[N], c4[N], cx[N], bw[N], bw2[N], b3[N];
+  cc::mask C[N], c1[N], c2[N], c3[N], c4[N], bw[N], bw2[N], b3[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
     const uint32_t a0 = (uint32_t)a[i], b1 = (uint32_t)(b[i] >> 32);
@@ -208,7 +208,7 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
   }
   cc::add_co(t1, c1, m0);        // U = (P0, P1 + M0)
   cc::addc_co(m1, c2, q0, c1);   // S = M1 + Q0 + c1 (mod 2^32), carry c2
-  cc::addc0_co(q1, cx, C);       // K = Q1 + C
+  cc::addc0_cv(q1, C);           // K = Q1 + C (no carry: Q1 <= 2^32 - 2)
 #pragma unroll
   for (int i = 0; i < N; i++) P[i] = cc::mk64(t0[i], t1[i]);
   cc::mad_eps_co(P, c3, m1);     // T = U + S*EPS, carry c3 (weight 2^64 = EPS)
@@ -216,12 +216,15 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
 #pragma unroll
   for (int i = 0; i < N; i++) { t0[i] = (uint32_t)P[i]; t1[i] = (uint32_t)(P[i] >> 32); }
   cc::add_co(t0, c4, e);         // T += c3 ? EPS : 0 (cannot wrap again)
-  cc::addc0_co(t1, cx, c4);
+  cc::addc0_cv(t1, c4);
   cc::subb_co(t0, bw, q1, c2);   // T -= K + c2
   cc::subb0_co(t1, bw2, bw);
   cc::sel_eps(e, bw2);           // on borrow the true value is 2^64 less: subtract EPS
   cc::sub_co(t0, b3, e);
-  cc::subb0_co(t1, cx, b3);
+  cc::subb0_cv(t1, b3);
+  // (Merging the two +-EPS corrections into one 64-bit addition saves one instruction of 17 when scalar
+  // instructions do the mask algebra -- built and measured: the masks it keeps live make the Poseidon kernels
+  // spill SGPRs, which the hazard rules forbid (tests/test_build.py), so the two-correction form stays.)
 #pragma unroll
   for (int i = 0; i < N; i++) r[i] = cc::mk64(t0[i], t1[i]);
 }
@@ -232,7 +235,7 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
 template <int N>
 __device__ __forceinline__ void add_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
   uint32_t al[N], ah[N], bl[N], bh[N], lo[N], hi[N], e[N];
-  cc::mask c1[N], c2[N], c3[N], cx[N];
+  cc::mask c1[N], c2[N], c3[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
     al[i] = (uint32_t)a[i]; ah[i] = (uint32_t)(a[i] >> 32); bl[i] = (uint32_t)b[i]; bh[i] = (uint32_t)(b[i] >> 32);
@@ -241,14 +244,14 @@ __device__ __forceinline__ void add_n(const uint64_t (&a)[N], const uint64_t (&b
   cc::addc_co_o(hi, c2, ah, bh, c1);
   cc::sel_eps(e, c2);
   cc::add_co(lo, c3, e);
-  cc::addc0_co(hi, cx, c3);
+  cc::addc0_cv(hi, c3);
 #pragma unroll
   for (int i = 0; i < N; i++) r[i] = cc::mk64(lo[i], hi[i]);
 }
 template <int N>
 __device__ __forceinline__ void sub_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
   uint32_t al[N], ah[N], bl[N], bh[N], lo[N], hi[N], e[N];
-  cc::mask b1[N], b2[N], b3[N], bx[N];
+  cc::mask b1[N], b2[N], b3[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
     al[i] = (uint32_t)a[i]; ah[i] = (uint32_t)(a[i] >> 32); bl[i] = (uint32_t)b[i]; bh[i] = (uint32_t)(b[i] >> 32);
@@ -257,7 +260,7 @@ __device__ __forceinline__ void sub_n(const uint64_t (&a)[N], const uint64_t (&b
   cc::subb_co_o(hi, b2, ah, bh, b1);
   cc::sel_eps(e, b2);
   cc::sub_co(lo, b3, e);
-  cc::subb0_co(hi, bx, b3);
+  cc::subb0_cv(hi, b3);
 #pragma unroll
   for (int i = 0; i < N; i++) r[i] = cc::mk64(lo[i], hi[i]);
 }

@@ -219,14 +219,18 @@ __global__ void __launch_bounds__(256) field_ops_kernel(const uint64_t* __restri
   }
   uint64_t r4[4], r3[3];
   gl::mul_n<4>(x, y, r4);
+  __builtin_amdgcn_sched_barrier(0);
   const uint64_t x3[3] = {x[1], x[2], x[3]}, y3[3] = {y[1], y[2], y[3]};
   gl::mul_n<3>(x3, y3, r3);
   __builtin_amdgcn_sched_barrier(0);  // one group of carry masks at a time (SGPR pressure, see stark_kernels.hip fri_fold)
   gl::DotAcc d[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
   gl::dot_mad4(d, x, y);
+  __builtin_amdgcn_sched_barrier(0);
   gl::dot_mad4(d, y, x);           // 2*a*b, through the wrap counters when the operands are large
+  __builtin_amdgcn_sched_barrier(0);
   const uint64_t yy[4] = {y[0], y[0], y[0], y[0]};
   gl::dot_mad4(d, x, yy);          // + a_k * b_0
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const uint64_t i = i0 + k;

@@ -42,27 +42,26 @@ __device__ __forceinline__ void sbox_all(uint64_t (&s)[12]) {
   }
 }
 
-// N accumulator pairs (L + H*2^32 < 2^74, L and H below 2^42) -> reduced words, carry-chain form:
-// (L0, L1 + H0) + (H1 + carry)*EPS, then fold the multiply-add's carry-out.
+// N accumulator pairs (L + H*2^32 < 2^74, L and H below 2^42) -> reduced words, carry-chain form in 5 instructions:
+// H = h0 + h1*2^32 with h1 < 2^10, so L + H*2^32 = (L + h1*EPS) + h0*2^32 (mod p).  X = L + h1*EPS < 2^43 needs
+// no carry; adding h0 to X's high word can carry once (weight 2^64 = EPS), and folding that carry cannot carry
+// again (the high word is then below 2^11).
 template <int N>
 __device__ __forceinline__ void reduce_rows(const uint64_t (&L)[N], const uint64_t (&H)[N], uint64_t (&out)[N]) {
   uint32_t l0[N], l1[N], h0[N], h1[N], e[N];
   uint64_t T[N];
-  gl::cc::mask c1[N], c3[N], c4[N], cx[N];
+  gl::cc::mask c1[N], c4[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    l0[i] = (uint32_t)L[i]; l1[i] = (uint32_t)(L[i] >> 32); h0[i] = (uint32_t)H[i]; h1[i] = (uint32_t)(H[i] >> 32);
+    T[i] = L[i]; h0[i] = (uint32_t)H[i]; h1[i] = (uint32_t)(H[i] >> 32);
   }
-  gl::cc::add_co(l1, c1, h0);
-  gl::cc::addc0_co(h1, cx, c1);  // top < 2^11
-#pragma unroll
-  for (int i = 0; i < N; i++) T[i] = gl::cc::mk64(l0[i], l1[i]);
-  gl::cc::mad_eps_co(T, c3, h1);  // carry => T < 2^43, so folding it cannot wrap
-  gl::cc::sel_eps(e, c3);
+  gl::cc::mad_eps_cv(T, h1);      // X = L + h1*EPS (no carry: both below 2^42)
 #pragma unroll
   for (int i = 0; i < N; i++) { l0[i] = (uint32_t)T[i]; l1[i] = (uint32_t)(T[i] >> 32); }
+  gl::cc::add_co(l1, c1, h0);
+  gl::cc::sel_eps(e, c1);
   gl::cc::add_co(l0, c4, e);
-  gl::cc::addc0_co(l1, cx, c4);
+  gl::cc::addc0_cv(l1, c4);
 #pragma unroll
   for (int i = 0; i < N; i++) out[i] = gl::cc::mk64(l0[i], l1[i]);
 }

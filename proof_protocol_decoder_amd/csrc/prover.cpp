@@ -509,11 +509,17 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
     pa.bits = cfg.pow_bits;
     uint64_t nonce = 0;
     if (cfg.pow_bits) {
-      // expected 2^pow_bits candidates: first batch 2x that (86% hit), then grow to 2^20
-      uint32_t batch = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 12, (uint64_t)2 << cfg.pow_bits));
+      // The smallest witness is geometric with mean 2^pow_bits and every candidate costs a whole permutation, so
+      // the batch size decides how many permutations are wasted past the winner: batches of 2^(pow_bits-1) stop
+      // after 2.5 launches and 83 k permutations on average at 16 bits (one batch of 2 x 2^16 followed by
+      // doubling: 168 k).  Proof of work is 7 % of a txn proof's VALU work (tools/valu_work_breakdown.py), the
+      // extra launches are latency on one of 24 streams.  After 8 misses the batch grows (tiny bit counts, bad luck).
+      const uint32_t batch0 = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 12, (uint64_t)1 << (cfg.pow_bits ? cfg.pow_bits - 1 : 0)));
+      uint32_t batch = batch0, n_batches = 0;
       unsigned long long res = ~0ULL;
       BPG_HIP(hipMemsetAsync(w.d_pow_result, 0xFF, 8, st));
-      for (uint64_t base = 0;; base += batch, batch = std::min<uint32_t>(1u << 20, batch * 2)) {
+      for (uint64_t base = 0;; base += batch) {
+        if (++n_batches > 8) batch = std::min<uint32_t>(1u << 20, batch * 2);
         pa.base = base;
         TRY(launch_pow(pa, batch, w.d_pow_result, st));
         TRY(w.d2h(reinterpret_cast<uint64_t*>(&res), reinterpret_cast<uint64_t*>(w.d_pow_result), 1));

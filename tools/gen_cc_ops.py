@@ -21,6 +21,13 @@ OPS = {
     "add_m1_co":  ("v_add_co_u32_e64 {x}, {co}, {x}, -1", ("uint32_t", "x"), True, []),                                                          # x += 2^32-1
     "sel":        ("v_cndmask_b32_e64 {x}, {x}, {b}, {ci}", ("uint32_t", "x"), False, [("uint32_t", "v", "b"), ("mask", "s", "ci")]),             # x = ci ? b : x
     "sel_eps":    ("v_cndmask_b32_e64 {x}, 0, -1, {ci}", ("uint32_t", "x"), False, [("mask", "s", "ci")]),                                    # x = ci ? 2^32-1 : 0
+    # carry-out not needed: it goes to VCC (clobbered), which frees an SGPR pair per element -- the Poseidon kernels
+    # keep 24 round-constant SGPRs live and must not spill masks (tests/test_build.py)
+    "addc0_cv":   ("v_addc_co_u32_e64 {x}, vcc, {x}, 0, {ci}", ("uint32_t", "x"), False, [("mask", "s", "ci")]),                              # x += ci
+    "addc_cv":    ("v_addc_co_u32_e64 {x}, vcc, {x}, {b}, {ci}", ("uint32_t", "x"), False, [("uint32_t", "v", "b"), ("mask", "s", "ci")]),    # x += b + ci
+    "subb0_cv":   ("v_subbrev_co_u32_e64 {x}, vcc, 0, {x}, {ci}", ("uint32_t", "x"), False, [("mask", "s", "ci")]),                           # x -= ci
+    "mad_eps_cv": ("v_mad_u64_u32 {x}, vcc, {a}, -1, {x}", ("uint64_t", "x"), False, [("uint32_t", "v", "a")]),                               # x += a*(2^32-1), no carry wanted
+    "sel_one":    ("v_cndmask_b32_e64 {x}, {x}, 1, {ci}", ("uint32_t", "x"), False, [("mask", "s", "ci")]),                                   # x = ci ? 1 : x
     # out-of-place forms (x is write-only): an operand that is still needed afterwards costs no v_mov copy
     "add_co_o":   ("v_add_co_u32_e64 {x}, {co}, {a}, {b}", ("uint32_t", "x"), True, [("uint32_t", "v", "a"), ("uint32_t", "v", "b")]),          # x = a + b
     "addc_co_o":  ("v_addc_co_u32_e64 {x}, {co}, {a}, {b}, {ci}", ("uint32_t", "x"), True, [("uint32_t", "v", "a"), ("uint32_t", "v", "b"), ("mask", "s", "ci")]),
@@ -35,6 +42,7 @@ def emit(n):
     out = []
     for name, (line, (xt, xa), has_co, ins) in OPS.items():
         write_only = name == "sel_eps" or name.endswith("_o")
+        clobber = ' : "vcc"' if name.endswith("_cv") else ""
         params = [f"{xt} (&{xa})[{n}]"] + ([f"mask (&co)[{n}]"] if has_co else []) + [f"const {t} (&{a})[{n}]" for t, _, a in ins]
         out.append(f"__device__ __forceinline__ void {name}(" + ", ".join(params) + ") {")
         idx, slots = 0, {}
@@ -49,7 +57,7 @@ def emit(n):
         if has_co:
             o += [f'"=&s"(co[{i}])' for i in range(n)]  # a carry-out must not land on a later element's carry-in
         ii = ", ".join(f'"{c}"({a}[{i}])' for _, c, a in ins for i in range(n))
-        out.append(f'  asm("{text}"\n      : {", ".join(o)}\n      : {ii});')
+        out.append(f'  asm("{text}"\n      : {", ".join(o)}\n      : {ii}{clobber});')
         out.append("}")
     return "\n".join(out)
 
