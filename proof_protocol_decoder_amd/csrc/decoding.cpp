@@ -441,7 +441,11 @@ int bp_decode_block_trace(const uint8_t* trace, size_t len, uint8_t** out, size_
   if (len < 8 || std::memcmp(trace, "BPGTRAC1", 8) != 0) return bpg::fail(BP_ERR_INVALID_INPUT, "block trace: bad magic");
   in.pos = 8;
   const Bytes witness = in.blob();
-  std::vector<TxnInfo> txns(in.ok ? std::min<uint32_t>(in.u32(), 1u << 20) : 0);
+  // a transaction is at least 24 bytes of this form: a count larger than the bytes left is malformed, not a
+  // reason to allocate
+  const uint32_t n_txn = in.u32();
+  if (!in.ok || n_txn > (len - in.pos) / 24) return bpg::fail(BP_ERR_INVALID_INPUT, "block trace: transaction count exceeds the payload");
+  std::vector<TxnInfo> txns(n_txn);
   for (auto& t : txns) {
     const uint32_t nt = in.u32();
     for (uint32_t i = 0; i < nt && in.ok; i++) {

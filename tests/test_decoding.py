@@ -419,3 +419,48 @@ def test_generation_inputs_map_to_prover_irs():
     irs2 = irs_from_generation_inputs(decoding.into_txn_proof_gen_ir(make_trace(m2, [t for t, _ in t2]), other), 17,
                                       (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8))
     assert irs2[0].state_root_before == irs[0].state_root_before and all(a.seed != b.seed for a, b in zip(irs, irs2))
+
+
+def test_mutated_payloads_never_crash():
+    """Client-supplied bytes: every mutation of a valid "BPGTRAC1" payload must come back as BP_OK or
+    BP_ERR_INVALID_INPUT (bpg.h: nothing aborts across the ABI) -- 3000 random byte flips, truncations and
+    length-field corruptions, including inside the compact witness."""
+    import ctypes as C
+    import random
+    from proof_protocol_decoder_amd._lib import lib
+    m = fresh_model()
+    raw = decoding.trace_to_binary(make_trace(m, [t for t, _ in block(m)], hash_out_storage_of=(E,)),
+                                   decoding.OtherBlockData(decoding.BlockLevelData(b"m", b"h", [(B, 5)])))
+    L = lib()
+    L.bp_decode_block_trace.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    L.bp_compact_decode_full.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    rng = random.Random(11)
+    seen = {0: 0, -2: 0}
+    wit = raw[12:12 + int.from_bytes(raw[8:12], "little")]
+    for it in range(3000):
+        b = bytearray(raw)
+        kind = it % 4
+        if kind == 0:
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(8, len(b))] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            b = b[:rng.randrange(0, len(b))]
+        elif kind == 2:
+            o = rng.randrange(8, len(b) - 4)
+            b[o:o + 4] = rng.choice([b"\xff\xff\xff\xff", b"\x00\x00\x00\x80", b"\x00\x00\x00\x00"])
+        else:
+            o = rng.randrange(12, 12 + len(wit))              # inside the compact witness
+            b[o] = rng.randrange(256)
+        out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        rc = L.bp_decode_block_trace(bytes(b), len(b), C.byref(out), C.byref(n))
+        assert rc in (0, -2), rc
+        seen[rc] += 1
+        if rc == 0:
+            L.bp_free_buffer(out)
+        w = bytearray(wit)
+        w[rng.randrange(len(w))] = rng.randrange(256)
+        rc = L.bp_compact_decode_full(bytes(w), len(w), C.byref(out), C.byref(n))
+        assert rc in (0, -2), rc
+        if rc == 0:
+            L.bp_free_buffer(out)
+    assert seen[0] > 0 and seen[-2] > 1000
