@@ -69,6 +69,7 @@ def main():
                          "to them (ends of shards, small blocks)")
     ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
     ap.add_argument("--merkle-fused", type=int, default=None, help="0: one launch per Merkle level")
+    ap.add_argument("--ntt-split", type=int, default=None, help="bp_tune_ntt_split mode (measurement knob)")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
                     help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
     args = ap.parse_args()
@@ -107,6 +108,8 @@ def main():
         L.bp_tune_merkle_fused(args.merkle_fused)
     if args.quad_threshold_log2 is not None:
         L.bp_tune_quad_threshold(1 << args.quad_threshold_log2)
+    if args.ntt_split is not None:
+        L.bp_tune_ntt_split(args.ntt_split)
 
     def read_family(note):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()

@@ -214,7 +214,12 @@ typedef struct bp_config {
   uint32_t shrink_depth; /* recursion-shaped proofs per table before the root (3) */
   int32_t device;        /* HIP device index */
   uint32_t n_workers;    /* concurrent provers (one HIP stream + arena each) */
-  uint64_t arena_bytes;  /* device arena per worker */
+  uint64_t arena_bytes;  /* device arena per worker.  A table height inside its configured range is PROVABLE when
+                          * the table's working set -- about 8 * 2^log_n * width * (2 + 2^rate_bits) * 1.3 bytes: values,
+                          * coefficients, LDE, digests and FRI scratch -- fits here; otherwise the call returns
+                          * BP_ERR_DEVICE ("device arena exhausted").  The default ranges are the reference's
+                          * (constants.rs:6-18, up to 2^30 rows), the arena is the deployment's choice: 5-6 GiB
+                          * holds the S1 transfer-txn shapes, a 2^20 x 2432 table needs ~100 GiB. */
 } bp_config;
 
 typedef struct bp_state bp_state;                   /* ProverState (prover_state.rs:17-20) */

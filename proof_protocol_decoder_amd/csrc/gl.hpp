@@ -184,7 +184,7 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
 // N (= 3 or 4) independent products at once, instruction-interleaved: same arithmetic as mul(), but
 // every carry consumer sits N-1 >= 2 instructions behind its producer, so no s_nop is spent.  This is
 // the form the throughput kernels use (12 S-boxes of a Poseidon round, 8 butterflies of an NTT stage).
-template <int N>
+template <int N, bool MERGED = false>
 __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
   static_assert(N == 3 || N == 4, "groups of 3 or 4");
   // every step overwrites one of its operands (gl_cc.inc): per element P, M, Q and one scratch word
@@ -211,20 +211,40 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
   cc::addc0_cv(q1, C);           // K = Q1 + C (no carry: Q1 <= 2^32 - 2)
 #pragma unroll
   for (int i = 0; i < N; i++) P[i] = cc::mk64(t0[i], t1[i]);
-  cc::mad_eps_co(P, c3, m1);     // T = U + S*EPS, carry c3 (weight 2^64 = EPS)
-  cc::sel_eps(e, c3);
+  cc::mad_eps_co(P, c3, m1);     // T = U + S*EPS mod 2^64, carry c3 (weight 2^64 = EPS)
 #pragma unroll
   for (int i = 0; i < N; i++) { t0[i] = (uint32_t)P[i]; t1[i] = (uint32_t)(P[i] >> 32); }
-  cc::add_co(t0, c4, e);         // T += c3 ? EPS : 0 (cannot wrap again)
-  cc::addc0_cv(t1, c4);
-  cc::subb_co(t0, bw, q1, c2);   // T -= K + c2
-  cc::subb0_co(t1, bw2, bw);
-  cc::sel_eps(e, bw2);           // on borrow the true value is 2^64 less: subtract EPS
-  cc::sub_co(t0, b3, e);
-  cc::subb0_cv(t1, b3);
-  // (Merging the two +-EPS corrections into one 64-bit addition saves one instruction of 17 when scalar
-  // instructions do the mask algebra -- built and measured: the masks it keeps live make the Poseidon kernels
-  // spill SGPRs, which the hazard rules forbid (tests/test_build.py), so the two-correction form stays.)
+  if constexpr (MERGED) {
+    // 16 instructions: u = T - K - c2 first (borrow bw2, weight -EPS), then ONE correction for both wraps: the
+    // true value is u + (c3 - bw2) * 2^64 = u, u + EPS or u - EPS.  +EPS cannot carry (then u < 2^64 - 2^33 + 1)
+    // and -EPS cannot borrow (then u >= 2^64 - 2^32), so it is one 64-bit addition of 0, (2^32 - 1, 0) or the
+    // two's complement (1, 2^32 - 1).  The mask algebra runs on the scalar unit, in place: c3 := c3 & ~bw2 (plus),
+    // bw2 := bw2 & ~c3 (minus).  It keeps c3 live four instructions longer: only for callers with SGPRs to spare
+    // (with groups of four the Poseidon kernels spill masks, which the hazard rules forbid).
+    cc::subb_co(t0, bw, q1, c2);
+    cc::subb0_co(t1, bw2, bw);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      c3[i] ^= bw2[i];   // the two differ
+      bw2[i] &= c3[i];   // minus
+      c3[i] ^= bw2[i];   // plus = differ \ minus
+    }
+    uint32_t eh[N];
+    cc::sel_eps(e, c3);
+    cc::sel_one(e, bw2);
+    cc::sel_eps(eh, bw2);
+    cc::add_co(t0, b3, e);
+    cc::addc_cv(t1, eh, b3);
+  } else {
+    cc::sel_eps(e, c3);
+    cc::add_co(t0, c4, e);         // T += c3 ? EPS : 0 (cannot wrap again)
+    cc::addc0_cv(t1, c4);
+    cc::subb_co(t0, bw, q1, c2);   // T -= K + c2
+    cc::subb0_co(t1, bw2, bw);
+    cc::sel_eps(e, bw2);           // on borrow the true value is 2^64 less: subtract EPS
+    cc::sub_co(t0, b3, e);
+    cc::subb0_cv(t1, b3);
+  }
 #pragma unroll
   for (int i = 0; i < N; i++) r[i] = cc::mk64(t0[i], t1[i]);
 }

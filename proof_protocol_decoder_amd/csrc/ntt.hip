@@ -826,7 +826,7 @@ static NttPlan plan_ntt(uint32_t log_n) {
 static uint32_t pick_log_blk(uint32_t log_n) { return plan_ntt(log_n).log_blk; }
 
 // Split form (Ntt16Args), out of place only.
-static std::atomic<int> g_ntt_split{0};  // 0 = automatic, 1 = never, 2 = wherever possible (measurement knob)
+static std::atomic<int> g_ntt_split{0};  // 0 = automatic, 1 = never, 2 = wherever possible, 3 = automatic + small DIT launches (measurement knobs)
 static bool use_split(uint32_t log_blk, uint64_t workgroups, const void* src, const void* dst, bool dit) {
   const int mode = g_ntt_split.load(std::memory_order_relaxed);
   // never in place: each of the two workgroups reads the WHOLE block while its partner may already be storing
@@ -837,7 +837,7 @@ static bool use_split(uint32_t log_blk, uint64_t workgroups, const void* src, co
   // 622,592 KiB algorithmic) for a 6 % shorter launch, and it gains nothing on small launches.  The DIF form
   // writes contiguous halves: 2^14-point blocks always (+23 %), 2^13-point blocks when the launch has too few
   // workgroups to fill the chip (2^13 x 16: 23 -> 19 us).
-  if (dit) return false;
+  if (dit) return mode == 3 && log_blk == 13 && workgroups < 512;  // 3: measurement mode, small DIT launches only
   return log_blk == 14 || workgroups < 512;
 }
 
