@@ -184,7 +184,7 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
 // N (= 3 or 4) independent products at once, instruction-interleaved: same arithmetic as mul(), but
 // every carry consumer sits N-1 >= 2 instructions behind its producer, so no s_nop is spent.  This is
 // the form the throughput kernels use (12 S-boxes of a Poseidon round, 8 butterflies of an NTT stage).
-template <int N, bool MERGED = false>
+template <int N, bool MERGED = true>
 __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
   static_assert(N == 3 || N == 4, "groups of 3 or 4");
   // every step overwrites one of its operands (gl_cc.inc): per element P, M, Q and one scratch word

@@ -24,7 +24,7 @@ __device__ __forceinline__ uint64_t sbox(uint64_t x) {
 }
 
 // x^7 on N (3 or 4) independent words with the interleaved multiply (gl::mul_n)
-template <int N, bool MERGED = false>
+template <int N, bool MERGED = true>
 __device__ __forceinline__ void sbox_n(uint64_t (&x)[N]) {
   uint64_t x2[N], x4[N], x3[N];
   gl::mul_n<N, MERGED>(x, x, x2);
