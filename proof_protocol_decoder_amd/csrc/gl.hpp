@@ -83,16 +83,12 @@ __device__ __forceinline__ uint32_t sel_eps(mask m) {  // m ? 2^32-1 : 0
   asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d) : "s"(m));
   return d;
 }
-__device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
-// t (true value t + c*2^64) -> t + c*EPS; the sum cannot wrap again when t is the low word of a sum
-// of a 64-bit value and a product below 2^64 - 2^33.
-__device__ __forceinline__ uint64_t fold_carry(uint64_t t, mask c) {
-  mask c4, c5;
-  const uint32_t e = sel_eps(c);
-  const uint32_t lo = add_co((uint32_t)t, e, c4);
-  const uint32_t hi = addc0_co((uint32_t)(t >> 32), c4, c5);
-  return mk64(lo, hi);
+__device__ __forceinline__ uint32_t sel_one(uint32_t x, mask m) {  // m ? 1 : x
+  uint32_t d;
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(d) : "v"(x), "s"(m));
+  return d;
 }
+__device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 #include "gl_cc.inc"  // the same instructions in groups of N = 3, 4 independent elements (no s_nop needed)
 }  // namespace cc
 #endif
@@ -167,12 +163,15 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
   const uint32_t p1 = cc::add_co((uint32_t)(P >> 32), (uint32_t)M, c1);
   const uint32_t S = cc::addc_co((uint32_t)(M >> 32), (uint32_t)Q, c1, c2);
   const uint32_t K = cc::addc0_co((uint32_t)(Q >> 32), C, cx);
-  const uint64_t T = cc::fold_carry(cc::mad_eps_co(S, cc::mk64((uint32_t)P, p1), c3), c3);
-  // T - K - c2; on borrow the true value is 2^64 less: subtract EPS (the wrapped value is > EPS)
-  const uint32_t u0 = cc::subb_co((uint32_t)T, K, c2, bw);
-  const uint32_t u1 = cc::subb0_co((uint32_t)(T >> 32), bw, bw2);
-  const uint32_t r0 = cc::sub_co(u0, cc::sel_eps(bw2), b3);
-  const uint32_t r1 = cc::subb0_co(u1, b3, cx);
+  // V = U + S*EPS mod 2^64 (carry c3, weight +EPS), u = V - K - c2 (borrow bw2, weight -EPS), then ONE correction
+  // for both wraps, as in mul_n: u + (c3 - bw2)*EPS is u, u + EPS (cannot carry) or u - EPS (cannot borrow)
+  const uint64_t V = cc::mad_eps_co(S, cc::mk64((uint32_t)P, p1), c3);
+  const uint32_t u0 = cc::subb_co((uint32_t)V, K, c2, bw);
+  const uint32_t u1 = cc::subb0_co((uint32_t)(V >> 32), bw, bw2);
+  const cc::mask plus = c3 & ~bw2, minus = bw2 & ~c3;  // scalar unit
+  const uint32_t e_lo = cc::sel_one(cc::sel_eps(plus), minus), e_hi = cc::sel_eps(minus);
+  const uint32_t r0 = cc::add_co(u0, e_lo, b3);
+  const uint32_t r1 = cc::addc_co(u1, e_hi, b3, cx);
   return cc::mk64(r0, r1);
 #else
   uint64_t lo, hi;
