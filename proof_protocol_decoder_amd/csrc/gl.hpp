@@ -83,11 +83,6 @@ __device__ __forceinline__ uint32_t sel_eps(mask m) {  // m ? 2^32-1 : 0
   asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d) : "s"(m));
   return d;
 }
-__device__ __forceinline__ uint32_t sel_one(uint32_t x, mask m) {  // m ? 1 : x
-  uint32_t d;
-  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(d) : "v"(x), "s"(m));
-  return d;
-}
 __device__ __forceinline__ uint64_t mk64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 #include "gl_cc.inc"  // the same instructions in groups of N = 3, 4 independent elements (no s_nop needed)
 }  // namespace cc
@@ -163,15 +158,15 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
   const uint32_t p1 = cc::add_co((uint32_t)(P >> 32), (uint32_t)M, c1);
   const uint32_t S = cc::addc_co((uint32_t)(M >> 32), (uint32_t)Q, c1, c2);
   const uint32_t K = cc::addc0_co((uint32_t)(Q >> 32), C, cx);
-  // V = U + S*EPS mod 2^64 (carry c3, weight +EPS), u = V - K - c2 (borrow bw2, weight -EPS), then ONE correction
-  // for both wraps, as in mul_n: u + (c3 - bw2)*EPS is u, u + EPS (cannot carry) or u - EPS (cannot borrow)
+  // V = U + S*EPS mod 2^64 (carry c3: + EPS, cannot wrap), then - K - c2 (borrow bw2: - EPS, cannot borrow);
+  // +-EPS under a mask is two instructions (see mul_n)
   const uint64_t V = cc::mad_eps_co(S, cc::mk64((uint32_t)P, p1), c3);
-  const uint32_t u0 = cc::subb_co((uint32_t)V, K, c2, bw);
-  const uint32_t u1 = cc::subb0_co((uint32_t)(V >> 32), bw, bw2);
-  const cc::mask plus = c3 & ~bw2, minus = bw2 & ~c3;  // scalar unit
-  const uint32_t e_lo = cc::sel_one(cc::sel_eps(plus), minus), e_hi = cc::sel_eps(minus);
-  const uint32_t r0 = cc::add_co(u0, e_lo, b3);
-  const uint32_t r1 = cc::addc_co(u1, e_hi, b3, cx);
+  const uint32_t t0 = cc::subb0_co((uint32_t)V, c3, b3);
+  const uint32_t t1 = cc::addc0_co((uint32_t)(V >> 32), c3 & ~b3, cx);
+  const uint32_t u0 = cc::subb_co(t0, K, c2, bw);
+  const uint32_t u1 = cc::subb0_co(t1, bw, bw2);
+  const uint32_t r0 = cc::addc0_co(u0, bw2, b3);
+  const uint32_t r1 = cc::subb0_co(u1, bw2 & ~b3, cx);
   return cc::mk64(r0, r1);
 #else
   uint64_t lo, hi;
@@ -183,13 +178,13 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
 // N (= 3 or 4) independent products at once, instruction-interleaved: same arithmetic as mul(), but
 // every carry consumer sits N-1 >= 2 instructions behind its producer, so no s_nop is spent.  This is
 // the form the throughput kernels use (12 S-boxes of a Poseidon round, 8 butterflies of an NTT stage).
-template <int N, bool MERGED = true>
+template <int N>
 __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
   static_assert(N == 3 || N == 4, "groups of 3 or 4");
   // every step overwrites one of its operands (gl_cc.inc): per element P, M, Q and one scratch word
-  uint32_t a1[N], b0[N], t0[N], t1[N], m0[N], m1[N], q0[N], q1[N], e[N];
+  uint32_t a1[N], b0[N], t0[N], t1[N], m0[N], m1[N], q0[N], q1[N];
   uint64_t P[N], M[N], Q[N];
-  cc::mask C[N], c1[N], c2[N], c3[N], c4[N], bw[N], bw2[N], b3[N];
+  cc::mask C[N], c1[N], c2[N], c3[N], bw[N], bw2[N], b3[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
     const uint32_t a0 = (uint32_t)a[i], b1 = (uint32_t)(b[i] >> 32);
@@ -210,40 +205,23 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
   cc::addc0_cv(q1, C);           // K = Q1 + C (no carry: Q1 <= 2^32 - 2)
 #pragma unroll
   for (int i = 0; i < N; i++) P[i] = cc::mk64(t0[i], t1[i]);
-  cc::mad_eps_co(P, c3, m1);     // T = U + S*EPS mod 2^64, carry c3 (weight 2^64 = EPS)
+  cc::mad_eps_co(P, c3, m1);     // V = U + S*EPS mod 2^64, carry c3 (weight 2^64 = EPS)
 #pragma unroll
   for (int i = 0; i < N; i++) { t0[i] = (uint32_t)P[i]; t1[i] = (uint32_t)(P[i] >> 32); }
-  if constexpr (MERGED) {
-    // 16 instructions: u = T - K - c2 first (borrow bw2, weight -EPS), then ONE correction for both wraps: the
-    // true value is u + (c3 - bw2) * 2^64 = u, u + EPS or u - EPS.  +EPS cannot carry (then u < 2^64 - 2^33 + 1)
-    // and -EPS cannot borrow (then u >= 2^64 - 2^32), so it is one 64-bit addition of 0, (2^32 - 1, 0) or the
-    // two's complement (1, 2^32 - 1).  The mask algebra runs on the scalar unit, in place: c3 := c3 & ~bw2 (plus),
-    // bw2 := bw2 & ~c3 (minus).  It keeps c3 live four instructions longer: only for callers with SGPRs to spare
-    // (with groups of four the Poseidon kernels spill masks, which the hazard rules forbid).
-    cc::subb_co(t0, bw, q1, c2);
-    cc::subb0_co(t1, bw2, bw);
+  // Adding or subtracting EPS = 2^32 - 1 under a mask m takes TWO instructions, not three, when the 64-bit result
+  // is known not to wrap: x + m*EPS = (lo - m) + (hi + m)*2^32, where lo - m borrows (b) only for lo = 0 and then
+  // hands the 2^32 back, i.e. hi + (m & ~b); the mask algebra is one scalar instruction.  Likewise
+  // x - m*EPS = (lo + m) + (hi - (m & ~carry))*2^32.
+  cc::subb0_co(t0, b3, c3);      // T = V + c3*EPS (cannot wrap: then V < 2^64 - 2^33)
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      c3[i] ^= bw2[i];   // the two differ
-      bw2[i] &= c3[i];   // minus
-      c3[i] ^= bw2[i];   // plus = differ \ minus
-    }
-    uint32_t eh[N];
-    cc::sel_eps(e, c3);
-    cc::sel_one(e, bw2);
-    cc::sel_eps(eh, bw2);
-    cc::add_co(t0, b3, e);
-    cc::addc_cv(t1, eh, b3);
-  } else {
-    cc::sel_eps(e, c3);
-    cc::add_co(t0, c4, e);         // T += c3 ? EPS : 0 (cannot wrap again)
-    cc::addc0_cv(t1, c4);
-    cc::subb_co(t0, bw, q1, c2);   // T -= K + c2
-    cc::subb0_co(t1, bw2, bw);
-    cc::sel_eps(e, bw2);           // on borrow the true value is 2^64 less: subtract EPS
-    cc::sub_co(t0, b3, e);
-    cc::subb0_cv(t1, b3);
-  }
+  for (int i = 0; i < N; i++) c3[i] &= ~b3[i];
+  cc::addc0_cv(t1, c3);
+  cc::subb_co(t0, bw, q1, c2);   // u = T - K - c2, borrow bw2
+  cc::subb0_co(t1, bw2, bw);
+  cc::addc0_co(t0, b3, bw2);     // u - bw2*EPS (cannot borrow: then u >= 2^64 - 2^32)
+#pragma unroll
+  for (int i = 0; i < N; i++) bw2[i] &= ~b3[i];
+  cc::subb0_cv(t1, bw2);
 #pragma unroll
   for (int i = 0; i < N; i++) r[i] = cc::mk64(t0[i], t1[i]);
 }
@@ -253,7 +231,7 @@ __device__ __forceinline__ void mul_n(const uint64_t (&a)[N], const uint64_t (&b
 // mul_n: the same carry chains as add() / sub() / canon(), no s_nop.  a: any u64, b: canonical.
 template <int N>
 __device__ __forceinline__ void add_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
-  uint32_t al[N], ah[N], bl[N], bh[N], lo[N], hi[N], e[N];
+  uint32_t al[N], ah[N], bl[N], bh[N], lo[N], hi[N];
   cc::mask c1[N], c2[N], c3[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
@@ -261,15 +239,16 @@ __device__ __forceinline__ void add_n(const uint64_t (&a)[N], const uint64_t (&b
   }
   cc::add_co_o(lo, c1, al, bl);      // out of place: a and b stay live for the caller without copies
   cc::addc_co_o(hi, c2, ah, bh, c1);
-  cc::sel_eps(e, c2);
-  cc::add_co(lo, c3, e);
-  cc::addc0_cv(hi, c3);
+  cc::subb0_co(lo, c3, c2);          // + c2*EPS in two instructions (mul_n): the sum cannot wrap again
+#pragma unroll
+  for (int i = 0; i < N; i++) c2[i] &= ~c3[i];
+  cc::addc0_cv(hi, c2);
 #pragma unroll
   for (int i = 0; i < N; i++) r[i] = cc::mk64(lo[i], hi[i]);
 }
 template <int N>
 __device__ __forceinline__ void sub_n(const uint64_t (&a)[N], const uint64_t (&b)[N], uint64_t (&r)[N]) {
-  uint32_t al[N], ah[N], bl[N], bh[N], lo[N], hi[N], e[N];
+  uint32_t al[N], ah[N], bl[N], bh[N], lo[N], hi[N];
   cc::mask b1[N], b2[N], b3[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
@@ -277,9 +256,10 @@ __device__ __forceinline__ void sub_n(const uint64_t (&a)[N], const uint64_t (&b
   }
   cc::sub_co_o(lo, b1, al, bl);
   cc::subb_co_o(hi, b2, ah, bh, b1);
-  cc::sel_eps(e, b2);
-  cc::sub_co(lo, b3, e);
-  cc::subb0_cv(hi, b3);
+  cc::addc0_co(lo, b3, b2);          // - b2*EPS in two instructions (mul_n): the difference cannot borrow again
+#pragma unroll
+  for (int i = 0; i < N; i++) b2[i] &= ~b3[i];
+  cc::subb0_cv(hi, b2);
 #pragma unroll
   for (int i = 0; i < N; i++) r[i] = cc::mk64(lo[i], hi[i]);
 }

@@ -137,10 +137,10 @@ __device__ __forceinline__ void dif_butterflies(uint64_t (&x)[1 << LOGR], const 
           const int k = k0 + i, m = (k / half) * 2 * half + (k % half);
           x[m + half] = r[i];
         }
-        // radix 32: four groups per stage in flight exhaust the SGPRs (each group holds ~9 carry masks) and
-        // the compiler starts parking SGPRs in VGPR lanes; a v_writelane of a mask right after the asm that
-        // wrote it is a hazard the recogniser cannot see, so the groups are kept apart instead
-        if constexpr (LOGR >= 5) __builtin_amdgcn_sched_barrier(0);
+        // groups in flight at once exhaust the SGPRs (each group of four holds ~9 carry masks) and the compiler
+        // starts parking SGPRs in VGPR lanes; a v_writelane of a mask right after the asm that wrote it is a
+        // hazard the recogniser cannot see, so the groups are kept apart instead
+        if constexpr (LOGR >= 4) __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
@@ -231,7 +231,7 @@ __device__ __forceinline__ void dit_butterflies(uint64_t (&x)[1 << LOGR], const 
           x[m] = hi[i];
           x[m + step] = lo[i];
         }
-        if constexpr (LOGR >= 5) __builtin_amdgcn_sched_barrier(0);  // see dif_butterflies
+        if constexpr (LOGR >= 4) __builtin_amdgcn_sched_barrier(0);  // see dif_butterflies
       }
     } else {
 #pragma unroll
@@ -798,9 +798,10 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
 // Plan for a column of 2^log_n elements: the LDS-resident block size and the global passes that come before it
 // (DIF) or after it (DIT).  Columns up to 2^14 are one block.  The 2^12-point LDS kernel is the most efficient one
 // (four workgroups per CU: load / compute / store of different workgroups overlap), so taller columns use the
-// smallest block that ONE global pass allows: a register pass of up to five stages (log_n <= 17), the LDS tile
-// pass of six to eight stages (log_n <= 22); beyond that register passes come on top (2^23..2^27: three round
-// trips, 2^28..2^30: four).
+// smallest block that ONE global pass allows: a register pass of up to four stages (log_n <= 17; a fifth stage =
+// 32 elements and 31 scalar row offsets per lane does not fit the SGPR file next to the carry masks), the LDS tile
+// pass of six to eight stages (log_n <= 22); beyond that register passes come on top (2^23..2^26: three round
+// trips, 2^27..2^30: four).
 struct NttPlan {
   uint32_t log_blk;      // LDS block
   uint32_t tile_bits;    // stages of the tile pass (0 = none), acting on span log_blk + tile_bits
@@ -810,12 +811,12 @@ struct NttPlan {
 static NttPlan plan_ntt(uint32_t log_n) {
   NttPlan p{};
   if (log_n <= LOG_BLK_MAX) { p.log_blk = log_n; return p; }
-  if (log_n <= 17) { p.log_blk = 12; p.n_reg = 1; p.reg_bits[0] = log_n - 12; return p; }
+  if (log_n <= 17) { p.log_blk = log_n <= 16 ? 12 : 13; p.n_reg = 1; p.reg_bits[0] = log_n - p.log_blk; return p; }
   if (log_n <= 20) { p.log_blk = 12; p.tile_bits = log_n - 12; return p; }
   if (log_n <= 22) { p.log_blk = log_n - 8; p.tile_bits = 8; return p; }
   p.log_blk = 14; p.tile_bits = 8;
   uint32_t left = log_n - 22;
-  p.n_reg = (left + 4) / 5;
+  p.n_reg = (left + 3) / 4;
   for (uint32_t i = 0; i < p.n_reg; i++) {
     const uint32_t k = (left + (p.n_reg - i) - 1) / (p.n_reg - i);
     p.reg_bits[i] = k;
@@ -875,7 +876,7 @@ static int launch_global_passes(const uint64_t* in, uint64_t in_stride, uint64_t
         case 2: ntt_global_pass_kernel<2, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
         case 3: ntt_global_pass_kernel<3, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
         case 4: ntt_global_pass_kernel<4, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
-        default: ntt_global_pass_kernel<5, DIF><<<grid, 256, 0, st>>>(src, src_stride, out, out_stride, coset_stride, log_n, spans[i], tw); break;
+        default: return fail(BP_ERR_DEVICE, "NTT plan asks for a %u-stage register pass", bits[i]);
       }
     }
     BPG_LAUNCH_CHECK();

@@ -24,22 +24,21 @@ __device__ __forceinline__ uint64_t sbox(uint64_t x) {
 }
 
 // x^7 on N (3 or 4) independent words with the interleaved multiply (gl::mul_n)
-template <int N, bool MERGED = true>
+template <int N>
 __device__ __forceinline__ void sbox_n(uint64_t (&x)[N]) {
   uint64_t x2[N], x4[N], x3[N];
-  gl::mul_n<N, MERGED>(x, x, x2);
-  gl::mul_n<N, MERGED>(x2, x2, x4);
-  gl::mul_n<N, MERGED>(x2, x, x3);
-  gl::mul_n<N, MERGED>(x3, x4, x);
+  gl::mul_n<N>(x, x, x2);
+  gl::mul_n<N>(x2, x2, x4);
+  gl::mul_n<N>(x2, x, x3);
+  gl::mul_n<N>(x3, x4, x);
 }
-// Twelve S-boxes as four groups of THREE with the 16-instruction multiply: groups of three keep a quarter fewer
-// carry masks live than groups of four, which is what lets the merged-correction multiply (one mask live longer)
-// fit the SGPR file next to the 24 round-constant registers without spilling.
+// Twelve S-boxes as four groups of THREE, one group's carry masks at a time: next to the 24 round-constant SGPRs the
+// masks of two overlapped groups of four do not fit the SGPR file, and a spilled mask is a hazard (gl.hpp).
 __device__ __forceinline__ void sbox_all(uint64_t (&s)[12]) {
 #pragma unroll
   for (int g = 0; g < 4; g++) {
     uint64_t y[3] = {s[3 * g], s[3 * g + 1], s[3 * g + 2]};
-    sbox_n<3, true>(y);
+    sbox_n<3>(y);
 #pragma unroll
     for (int i = 0; i < 3; i++) s[3 * g + i] = y[i];
     __builtin_amdgcn_sched_barrier(0);  // one group's masks at a time: the scheduler otherwise overlaps two groups and spills
