@@ -9,7 +9,7 @@
 // CDNA4 notes: there is no 64x64 multiplier; a 64x64->128 product is four v_mad_u64_u32 (full rate:
 // 4.7 cycles per wave64 like every other VOP3, tools/issue_rate.hip) and the Goldilocks reduction uses 2^64 = 2^32 - 1, 2^96 = -1.  The compiler's
 // rendering of mul_wide + reduce128 is 25 VALU instructions; the device forms below (namespace cc,
-// mul, mul_n, DotAcc) keep the carries as explicit SGPR masks and need 16.
+// mul, mul_n, DotAcc) keep the carries as explicit SGPR masks and need 15.
 // No MFMA anywhere (integer field work).
 #pragma once
 #include <cstdint>
@@ -29,7 +29,7 @@ constexpr uint64_t W = 7;                // extension non-residue: X^2 = 7
 // ---- carry-chain primitives (device only).  The compiler never uses the carry-out of
 // v_mad_u64_u32 and forms (x, 0) register pairs with v_mov for every 32->64-bit addend (64-bit VGPR
 // operands must be even-aligned), which makes its modular multiply 25 VALU instructions.  With the
-// carries kept as explicit wave masks in SGPR pairs the same product + reduction is 16.  Each
+// carries kept as explicit wave masks in SGPR pairs the same product + reduction is 15.  Each
 // one-instruction asm statement that CONSUMES a carry carries its own `s_nop 1`: on gfx940+ a VALU
 // write of an SGPR needs 2 wait states before a VALU read of it, and the compiler's hazard
 // recogniser does not look inside inline asm.  (Other waves of the SIMD issue during the nop.)
