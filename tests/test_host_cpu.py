@@ -236,3 +236,14 @@ def test_block_driver_failure_on_one_rank_raises_everywhere(tmp_path, oracle):
     """A rank whose shard raises reports it through the gather's length exchange; every rank raises (ShardFailed on
     the healthy ones, the original error on the failed one) and all of them reach the next barrier."""
     _run_driver(tmp_path, 3, 6, 29625, fail_rank=1)
+
+
+def test_config_bounds_are_checked_before_any_device_work():
+    """check_cfg (csrc/prover.cpp): a final polynomial longer than 256 points would be interpolated on the host in
+    O(len^2), and 2 << pow_bits must not overflow: both are refused as invalid input, without a GPU."""
+    from proof_protocol_decoder_amd import proof_gen as pg
+    for kw in (dict(final_poly_bits=9), dict(final_poly_bits=31), dict(rec_pow_bits=33), dict(rec_n_const=5000),
+               dict(arity_bits=3), dict(rec_num_queries=0)):
+        with pytest.raises(pg.ProofGenError) as e:
+            pg.ProverStateBuilder().set(**kw).build()
+        assert e.value.code in (-2, -6), (kw, e.value.code)
