@@ -325,6 +325,11 @@ def test_block16_at_default_config_matches_golden(bpg, pg, oracle):
         assert kind == 2 and (pv.txn_number_before, pv.txn_number_after) == (0, 16) and pv.gas_used_after == 16 * 21000
         assert pv.state_root_after == txns[15].p_vals.state_root_after and blk.b_height == gold["block_number"]
         assert blk.intern == pg.generate_block_proof(st, None, top).intern           # same tree either way
+        # the WHOLE block, byte for byte: the oracle proved all 16 txns, the 15 aggregations and the block proof once
+        # on the GPU box's host cores (tools/gen_block16_golden.py)
+        full = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_golden.json")))["block16_full"]
+        assert [_sha(t.intern) for t in txns] == full["txn_sha256"]
+        assert _sha(blk.intern) == full["block_sha256"] and words(blk.intern).size == full["block_words"]
         pg.VerifierState.from_prover_state(st).verify(blk)
         ost = oracle.PgState(table_log_lo=list(S1_LOG_N), table_log_hi=[x + 1 for x in S1_LOG_N], stark_rate_bits=1,
                              stark_cap_height=4, stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5,

@@ -19,6 +19,15 @@ import numpy as np  # noqa: E402
 from oracle import pyoracle as orc  # noqa: E402
 
 log_n, C = int(sys.argv[1]), 2432
+try:  # OpenMP would otherwise start one thread per host core, not per core of this process's share
+    import ctypes
+    _n = len(os.sched_getaffinity(0))
+    _q, _p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+    if _q != "max":
+        _n = min(_n, max(1, int(int(_q) / int(_p))))
+    ctypes.CDLL("libgomp.so.1").omp_set_num_threads(min(_n, 64))
+except (OSError, ValueError):
+    pass
 orc.build()
 
 
