@@ -90,10 +90,11 @@ int bp_debug_copy_u64(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* s
 
 /* K1 self-check: every device form of the Goldilocks arithmetic (types.rs:10 fixes the field) on n
  * operand pairs, for tests against big-integer arithmetic.  d_a/d_b: any u64 values (non-canonical
- * allowed); d_out: 11 planes of n canonical words: a*b by the one-element carry chain, in groups of
+ * allowed); d_out: 15 planes of n canonical words: a*b by the one-element carry chain, in groups of
  * four, in groups of three, by the compiler form; a+b; a-b; the unreduced dot-product accumulator
  * (2*a*b + a*b[first of its group of four]); 7*a; a^-1; the two components of the extension product
- * (a, b) * (b, a^b). */
+ * (a, b) * (b, a^b); then the interleaved group forms the NTT butterflies use: a + canon(b), a - canon(b),
+ * canon(a), canon(b). */
 int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream);
 
 /* Tuning knob: hashing launches with fewer rows/nodes than this use the quad-cooperative Poseidon

@@ -204,7 +204,7 @@ calib_copy_u64_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ ou
 }
 
 // K1 check kernel: every device form of the field arithmetic on caller-supplied operand pairs.
-// out[op][i]; a is ANY u64 (also non-canonical), b likewise for the multiplies; the add/sub forms get
+// out[op][i] (15 planes); a is ANY u64 (also non-canonical), b likewise for the multiplies; the add/sub forms get
 // canon(b) as the contract of gl::add / gl::sub demands.
 __global__ void __launch_bounds__(256) field_ops_kernel(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
                                                         uint64_t* __restrict__ out, uint64_t n) {
@@ -231,6 +231,16 @@ __global__ void __launch_bounds__(256) field_ops_kernel(const uint64_t* __restri
   const uint64_t yy[4] = {y[0], y[0], y[0], y[0]};
   gl::dot_mad4(d, x, yy);          // + a_k * b_0
   __builtin_amdgcn_sched_barrier(0);
+  // the interleaved group forms of the lazy add / sub / canonicalisation (the NTT butterflies' arithmetic)
+  uint64_t cy[4] = {y[0], y[1], y[2], y[3]}, sum4[4], dif4[4], cx4[4] = {x[0], x[1], x[2], x[3]};
+  gl::canon_n<4>(cy);
+  __builtin_amdgcn_sched_barrier(0);
+  gl::add_n<4>(x, cy, sum4);
+  __builtin_amdgcn_sched_barrier(0);
+  gl::sub_n<4>(x, cy, dif4);
+  __builtin_amdgcn_sched_barrier(0);
+  gl::canon_n<4>(cx4);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const uint64_t i = i0 + k;
@@ -250,6 +260,10 @@ __global__ void __launch_bounds__(256) field_ops_kernel(const uint64_t* __restri
     const gl::Ext e = gl::mul(gl::Ext{gl::canon(x[k]), cb}, gl::Ext{cb, gl::canon(x[k] ^ y[k])});
     out[9 * n + i] = e.c0;
     out[10 * n + i] = e.c1;
+    out[11 * n + i] = gl::canon(sum4[k]);   // add_n<4>: a + canon(b), lazily reduced
+    out[12 * n + i] = gl::canon(dif4[k]);   // sub_n<4>
+    out[13 * n + i] = cx4[k];               // canon_n<4>(a): must already be canonical
+    out[14 * n + i] = cy[k];
   }
 }
 

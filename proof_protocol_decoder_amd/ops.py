@@ -63,11 +63,11 @@ def poseidon_perm_batch_(states):
 
 
 def field_ops(a, b):
-    """bp_debug_field_ops: [11, n] planes of canonical results for operand vectors a, b (any u64 patterns)."""
+    """bp_debug_field_ops: [15, n] planes of canonical results for operand vectors a, b (any u64 patterns)."""
     _require_cuda(a)
     _require_cuda(b)
     n = a.numel()
-    out = torch.empty((11, n), dtype=torch.int64, device=a.device)
+    out = torch.empty((15, n), dtype=torch.int64, device=a.device)
     check(lib().bp_debug_field_ops(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, _stream()))
     return out
 

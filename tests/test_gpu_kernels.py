@@ -80,6 +80,9 @@ def test_field_ops_against_big_integers(bpg):
         assert got[8][i] == (pow(x % P, P - 2, P) if x % P else 0)
         e0, e1, f0, f1 = x % P, y % P, y % P, (x ^ y) % P
         assert got[9][i] == (e0 * f0 + 7 * e1 * f1) % P and got[10][i] == (e0 * f1 + e1 * f0) % P
+        # group forms (gl::add_n / sub_n / canon_n): +-EPS under a mask in two instructions, on every edge pair
+        assert got[11][i] == (x + y) % P and got[12][i] == (x - y) % P, (i, hex(x), hex(y))
+        assert got[13][i] == x % P and got[14][i] == y % P, (i, hex(x), hex(y))
 
 
 def test_poseidon_kat_and_random(bpg, oracle):
