@@ -464,3 +464,19 @@ def test_mutated_payloads_never_crash():
         if rc == 0:
             L.bp_free_buffer(out)
     assert seen[0] > 0 and seen[-2] > 1000
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_golden_witnesses_as_pre_images_of_an_empty_block(i):
+    """The reference's own golden witnesses through the IR producer: an empty block over each of them is padded to two
+    dummy entries (decoding.rs:315-325) whose hashed-out state trie carries the GOLDEN state root, before and after."""
+    v = VEC["complex"][i]
+    bt = tp.BlockTrace(tp.CombinedPreImages(tp.TrieCompact(bytes.fromhex(v["witness_hex"]))), [])
+    irs, final_root = decoding.into_txn_proof_gen_ir(bt, decoding.OtherBlockData(), with_final_root=True)
+    assert len(irs) == 2 and final_root.hex() == v["state_root"]
+    full = compact.process_compact_prestate_full(bytes.fromhex(v["witness_hex"]))
+    for ir in irs:
+        assert ir.signed_txn is None and ir.tries.state_trie.hash().hex() == v["state_root"] == ir.trie_roots_after.state_root.hex()
+        assert ir.trie_roots_after.transactions_root == pt.EMPTY_TRIE_HASH and ir.contract_code == {}
+        assert {h for h, _ in ir.tries.storage_tries} == set(full.storage)
+        assert all(t.hash() == full.storage[h].hash() for h, t in ir.tries.storage_tries)
