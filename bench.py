@@ -111,13 +111,14 @@ def main():
     if args.ntt_split is not None:
         L.bp_tune_ntt_split(args.ntt_split)
 
-    def read_family(note):
+    def read_family(note, leg=True):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
         pkg._lib.check(L.bp_profile_read(0, C.byref(n), C.byref(ms), C.byref(by)))
         if not n.value:
             return None
         ach = by.value / (ms.value * 1e-3) / 1e9
-        ratio, head = traffic_ratio()
+        # the PMC ratio was measured over the single-stream leg's launches: it says nothing about the timed region
+        ratio, head = traffic_ratio() if leg else (None, None)
         return {"bound": "hbm", "kernel": "coset-LDE NTT family: ntt16_dit_kernel<12|13|14> + ntt_lds_kernel<DIT>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 # HBM bytes per launch = algorithmic x the ratio that two rocprofv3 --pmc passes (FETCH_SIZE x2,
@@ -125,7 +126,8 @@ def main():
                 # (tools/pmc_family_traffic.py; the leg is bracketed by marker dispatches)
                 "traffic": round(by.value / n.value * ratio) if ratio else None,
                 "traffic_source": ("%s (PMC passes taken at HEAD %s)" % (TRAFFIC_FILE, head)) if ratio else
-                                  "no PMC summary under profiles/ for this code",
+                                  ("no PMC summary under profiles/ for this code" if leg else
+                                   "not measured in the timed region (see roofline.traffic)"),
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "alg_bytes_per_launch": round(by.value / n.value), "note": note}
 
@@ -210,7 +212,7 @@ def main():
     if not args.no_profile and not args.no_in_situ_profile:
         roofline_in_situ = read_family("HIP events around every launch in the timed region; %d prover streams share "
                                        "the chip, mostly with integer-ALU-bound Poseidon kernels, so a launch's "
-                                       "duration is not the kernel's own cost" % args.threads)
+                                       "duration is not the kernel's own cost" % args.threads, leg=False)
 
     if rank == 0:
         # acceptance: the block proof verifies (VerifierState::verify, verifier_state.rs:56-71)

@@ -9,6 +9,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <deque>
+#include <set>
+#include "mpt.hpp"
 #include "prover.hpp"
 
 using namespace bpg;
@@ -56,6 +59,12 @@ struct bp_state {
   mutable std::condition_variable cv;
   mutable std::vector<std::unique_ptr<Worker>> workers;
   mutable std::vector<Worker*> idle;
+  // Keccak-256 of every proof container this state has produced (bounded): aggregation verifies its children on the
+  // host (verify_child), which costs 10 ms of CPU per recursion-shaped proof against 5 ms of GPU to make one -- a child
+  // that this very state has just produced, byte for byte, is recognised instead of being verified again
+  mutable std::mutex seen_mu;
+  mutable std::set<mpt::H256> seen;
+  mutable std::deque<mpt::H256> seen_order;
 };
 struct bp_verifier_state {
   StarkCfg rec_cfg;
@@ -208,7 +217,25 @@ int rec_verify(const StarkCfg& rc, const LightCircuit& circ, const Box& b) {
 // children, proof_gen.rs:66-75, 97-103) is done on the host here: a child container is accepted only if
 // it was made by the circuit its kind names, its public inputs are canonical and its proof verifies
 // against this state's preprocessed circuit.
-int verify_child(const bp_state* s, const Box& b, const char* what) {
+constexpr size_t SEEN_MAX = 8192;
+void remember_proof(const bp_state* s, const uint8_t* bytes, size_t len) {
+  const mpt::H256 h = mpt::keccak256(bytes, len);
+  std::lock_guard<std::mutex> lk(s->seen_mu);
+  if (!s->seen.insert(h).second) return;
+  s->seen_order.push_back(h);
+  if (s->seen_order.size() > SEEN_MAX) {
+    s->seen.erase(s->seen_order.front());
+    s->seen_order.pop_front();
+  }
+}
+bool produced_here(const bp_state* s, const uint8_t* bytes, size_t len) {
+  const mpt::H256 h = mpt::keccak256(bytes, len);
+  std::lock_guard<std::mutex> lk(s->seen_mu);
+  return s->seen.count(h) != 0;
+}
+
+int verify_child(const bp_state* s, const Box& b, const char* what, const uint8_t* bytes, size_t len) {
+  if (produced_here(s, bytes, len)) return BP_OK;
   if (b.circuit != CIRCUIT_ROOT + b.kind)
     return fail(BP_ERR_VERIFY, "%s was made by circuit %llu, expected %u", what, (unsigned long long)b.circuit,
                 CIRCUIT_ROOT + (uint32_t)b.kind);
@@ -478,7 +505,9 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   for (int t = 0; t < BP_NUM_TABLES; t++) pi.insert(pi.end(), digest[t], digest[t] + 4);
   pi.insert(pi.end(), pv.begin(), pv.end());
   if ((r = rec_prove(w, s->rec_cfg, s->special[0], pi, proof))) return r;
-  return emit_box(0, CIRCUIT_ROOT, pi, proof, out, out_len);
+  if ((r = emit_box(0, CIRCUIT_ROOT, pi, proof, out, out_len))) return r;
+  remember_proof(s, *out, *out_len);
+  return BP_OK;
 }
 int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
                           uint8_t** out, size_t* out_len) try {
@@ -506,7 +535,28 @@ int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len,
                                       (unsigned long long)L.pv[1], (unsigned long long)R.pv[0]);
   if (L.pv[3] != R.pv[2] || std::memcmp(L.pv + 8, R.pv + 4, 32) != 0 || L.pv[12] != R.pv[12])
     return fail(BP_ERR_INVALID_INPUT, "children public values do not chain (gas / state root / block number)");
-  if ((r = verify_child(s, L, "lhs child proof")) || (r = verify_child(s, R, "rhs child proof"))) return r;
+  {
+    // the two children are verified side by side (10 ms of host Poseidon each when they were not produced here,
+    // e.g. the sub-block proofs gathered from other ranks): the helper's message is thread-local, so it is carried over
+    int r_rhs = BP_OK;
+    std::string rhs_err;
+    std::thread helper;
+    bool threaded = false;
+    try {
+      helper = std::thread([&] {
+        r_rhs = verify_child(s, R, "rhs child proof", rhs, rhs_len);
+        if (r_rhs) rhs_err = bp_last_error();
+      });
+      threaded = true;
+    } catch (...) {  // no thread to be had: verify in this one
+    }
+    r = verify_child(s, L, "lhs child proof", lhs, lhs_len);
+    const std::string lhs_err = r ? bp_last_error() : "";
+    if (threaded) helper.join();
+    else if ((r_rhs = verify_child(s, R, "rhs child proof", rhs, rhs_len))) rhs_err = bp_last_error();
+    if (r) return fail(r, "%s", lhs_err.c_str());
+    if (r_rhs) return fail(r_rhs, "%s", rhs_err.c_str());
+  }
   std::vector<uint64_t> pi(10 + BP_PV_WORDS);
   proof_digest(s->rec_cfg, L.stark, &pi[0]);
   proof_digest(s->rec_cfg, R.stark, &pi[4]);
@@ -519,7 +569,9 @@ int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len,
   WorkerLease lease(s);
   std::vector<uint64_t> proof;
   if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[1], pi, proof))) return r;
-  return emit_box(1, CIRCUIT_AGG, pi, proof, out, out_len);
+  if ((r = emit_box(1, CIRCUIT_AGG, pi, proof, out, out_len))) return r;
+  remember_proof(s, *out, *out_len);
+  return BP_OK;
 }
 BPG_ABI_CATCH("bp_generate_agg_proof")
 
@@ -536,11 +588,11 @@ int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t par
     if (Pb.kind != 2) return fail(BP_ERR_INVALID_INPUT, "parent is not a block proof");
     if (Pb.pv[12] + 1 != A.pv[12]) return fail(BP_ERR_INVALID_INPUT, "parent block height %llu does not precede %llu",
                                                 (unsigned long long)Pb.pv[12], (unsigned long long)A.pv[12]);
-    if ((r = verify_child(s, Pb, "parent block proof"))) return r;
+    if ((r = verify_child(s, Pb, "parent block proof", parent, parent_len))) return r;
     proof_digest(s->rec_cfg, Pb.stark, &pi[0]);
     pi[8] = 1;
   }
-  if ((r = verify_child(s, A, "curr_block_agg_proof"))) return r;
+  if ((r = verify_child(s, A, "curr_block_agg_proof", agg, agg_len))) return r;
   proof_digest(s->rec_cfg, A.stark, &pi[4]);
   std::memcpy(&pi[9], A.pv, BP_PV_WORDS * 8);
   (void)hipSetDevice(s->cfg.device);
@@ -548,7 +600,9 @@ int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t par
   std::vector<uint64_t> proof;
   if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[2], pi, proof))) return r;
   if (b_height) *b_height = A.pv[12];  // block_metadata.block_number.low_u64(), proof_gen.rs:90-94
-  return emit_box(2, CIRCUIT_BLOCK, pi, proof, out, out_len);
+  if ((r = emit_box(2, CIRCUIT_BLOCK, pi, proof, out, out_len))) return r;
+  remember_proof(s, *out, *out_len);
+  return BP_OK;
 }
 BPG_ABI_CATCH("bp_generate_block_proof")
 
