@@ -106,6 +106,10 @@ void bp_tune_quad_threshold(uint64_t n_perms);
 /* 1: Merkle levels below the quad threshold are fused, up to 7 per launch; 0 (default, ~3% faster under
  * multi-stream load): one launch per level.  Results are identical. */
 void bp_tune_merkle_fused(int on);
+/* 1 (default): hashing launches at or above the quad threshold use the matrix-core form of the permutation
+ * (csrc/poseidon_mx.cuh: the MDS layer as int8 MFMAs on the byte planes of the state); 0: one lane per state.
+ * Results are identical either way. */
+void bp_tune_poseidon_mx(int on);
 
 /* Tuning knob for K2: 0 (default) = automatic, 1 = never, 2 = wherever possible: transform a 2^13 / 2^14-point
  * block with TWO workgroups that each do half of the stage coupling its halves while loading (csrc/ntt.hip).

@@ -8,6 +8,7 @@
 #include <atomic>
 #include "common.hpp"
 #include "poseidon.cuh"
+#include "poseidon_mx.cuh"
 
 namespace {
 
@@ -194,6 +195,109 @@ merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ p
   }
 }
 
+// ---- matrix-core ("mx") form, poseidon_mx.cuh: a wave owns 64 rows / nodes / states as four sets of 16; lane
+// (n = lane & 15, kb = lane >> 4) holds words kb, kb + 4, kb + 8 of item 16m + n of every set m.  No lane leaves before
+// the permutations are done (an MFMA is a whole-wave instruction): out-of-range items are clamped for the loads and
+// masked at the store.
+__global__ void __launch_bounds__(256) perm_batch_mx_kernel(uint64_t* __restrict__ states, uint64_t n) {
+  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
+  poseidon::mx::build_cin(cin);
+  __syncthreads();
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
+  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 15);
+  uint64_t e[4][3];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const uint64_t i = base + 16 * m < n ? base + 16 * m : n - 1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) e[m][a] = states[i * 12 + c.kb + 4 * a];
+  }
+  poseidon::mx::permute<4>(e, c);
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const uint64_t i = base + 16 * m;
+    if (i < n) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) states[i * 12 + c.kb + 4 * a] = gl::canon(e[m][a]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
+                    uint32_t rate_bits, uint64_t* __restrict__ digests) {
+  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
+  poseidon::mx::build_cin(cin);
+  __syncthreads();
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
+  const uint64_t rows = (uint64_t)1 << (log_n + rate_bits);
+  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 15);
+  const uint32_t kb = c.kb;
+  const uint64_t* p[4];
+  uint64_t e[4][3];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const uint64_t pos = base + 16 * m < rows ? base + 16 * m : rows - 1;
+    p[m] = lde + pos;
+    e[m][0] = e[m][1] = e[m][2] = 0;
+  }
+  if (n_cols <= 4) {  // hash_or_noop: short rows are the digest
+    if (kb < n_cols) {
+#pragma unroll
+      for (int m = 0; m < 4; m++) e[m][0] = p[m][(uint64_t)kb * stride];
+    }
+  } else {
+    for (uint32_t col = 0; col < n_cols; col += 8) {  // wave-uniform trip count
+      if (col + kb < n_cols) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) e[m][0] = p[m][(uint64_t)(col + kb) * stride];
+      }
+      if (col + 4 + kb < n_cols) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) e[m][1] = p[m][(uint64_t)(col + 4 + kb) * stride];
+      }
+      poseidon::mx::permute<4>(e, c);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const uint64_t pos = base + 16 * m;
+    if (pos < rows) {
+      const uint32_t t = (uint32_t)(pos >> log_n), mm = (uint32_t)(pos & ((1u << log_n) - 1));
+      const uint64_t leaf = ((uint64_t)gl::bitrev(t, rate_bits) << log_n) | gl::bitrev(mm, log_n);
+      digests[leaf * 4 + kb] = gl::canon(e[m][0]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
+                       uint64_t* __restrict__ mirror) {
+  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
+  poseidon::mx::build_cin(cin);
+  __syncthreads();
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
+  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 15);
+  uint64_t e[4][3];
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const uint64_t i = base + 16 * m < n_parents ? base + 16 * m : n_parents - 1;
+    e[m][0] = child[i * 8 + c.kb];
+    e[m][1] = child[i * 8 + 4 + c.kb];
+    e[m][2] = 0;
+  }
+  poseidon::mx::permute<4>(e, c);
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const uint64_t i = base + 16 * m;
+    if (i < n_parents) {
+      const uint64_t d = gl::canon(e[m][0]);
+      parent[i * 4 + c.kb] = d;
+      if (mirror) mirror[i * 4 + c.kb] = d;
+    }
+  }
+}
+
 // 8-byte-per-lane streaming copy: calibrates the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the
 // access width every field kernel here uses (MI355X_MICROARCH.md, HBM section).
 __global__ void __launch_bounds__(256)
@@ -286,6 +390,8 @@ uint64_t quad_threshold() {
   return (uint64_t)1 << (g_active_provers.load(std::memory_order_relaxed) >= 6 ? 13 : 17);
 }
 static std::atomic<int> g_merkle_fused{0};  // measured: per-level launches are ~3% faster under 16-stream load
+// launches at or above the quad threshold: 1 = matrix-core form (poseidon_mx.cuh), 0 = one lane per state
+static std::atomic<int> g_poseidon_mx{1};
 
 // `mirror` (nullable): host-visible buffer that receives the 2^cap_height cap digests directly from
 // the kernel that produces them, so the caller needs no device->host copy, only a stream wait.
@@ -302,8 +408,12 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     const bool fused = parents <= 4096 && parents < quad_threshold() && g_merkle_fused.load(std::memory_order_relaxed);
     if (!fused) {
       uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;
-      if (parents >= quad_threshold())  // big level: one lane per node is the most instruction-efficient
-        merkle_level_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
+      if (parents >= quad_threshold()) {  // big level: the forms with all 64 lanes busy in the partial rounds
+        if (g_poseidon_mx.load(std::memory_order_relaxed))
+          merkle_level_mx_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
+        else
+          merkle_level_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
+      }
       else
         merkle_level_quad_kernel<<<ceil_div(cnt * 2, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
       BPG_LAUNCH_CHECK();
@@ -360,6 +470,7 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
 
 void bp_tune_merkle_fused(int on) { bpg::g_merkle_fused.store(on != 0); }
 void bp_tune_quad_threshold(uint64_t n_perms) { bpg::g_quad_threshold.store(n_perms); }
+void bp_tune_poseidon_mx(int on) { bpg::g_poseidon_mx.store(on != 0); }
 
 uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {
   return (((uint64_t)2 << log_leaves) - ((uint64_t)1 << cap_height)) * 4;
@@ -368,7 +479,10 @@ uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {
 int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream) try {
   if (!n) return BP_OK;
   if (!d_states) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_poseidon_perm_batch: null buffer");
-  perm_batch_kernel<<<bpg::ceil_div(n, 256), 256, 0, bpg::as_stream(stream)>>>(d_states, n);
+  if (bpg::g_poseidon_mx.load(std::memory_order_relaxed))
+    perm_batch_mx_kernel<<<bpg::ceil_div(n, 256), 256, 0, bpg::as_stream(stream)>>>(d_states, n);
+  else
+    perm_batch_kernel<<<bpg::ceil_div(n, 256), 256, 0, bpg::as_stream(stream)>>>(d_states, n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -400,6 +514,8 @@ int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_co
     if (rows < quad_threshold())
       leaf_hash_quad_kernel<<<ceil_div(rows * 4, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
                                                                    d_digests);
+    else if (g_poseidon_mx.load(std::memory_order_relaxed))
+      leaf_hash_mx_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests);
     else
       leaf_hash_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests);
   }

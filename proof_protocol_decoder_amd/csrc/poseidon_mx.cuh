@@ -1,0 +1,189 @@
+// poseidon_mx.cuh -- Poseidon-Goldilocks with the MDS layer on the matrix cores (third kernel form, "mx").
+//
+// Same permutation as poseidon.cuh (upstream plonky2::hash::poseidon, reached from
+// plonky_block_proof_gen/src/proof_gen.rs:44-52 through MerkleTree::new), bit for bit.  Why a matrix-core form of an
+// integer hash: the field kernels are bound by VALU issue, and in the one-lane form the MDS layer is more than half
+// of the instructions of a permutation (288 32x6-bit multiply-adds + 48 for the row reductions per round, against 60
+// per S-box).  The MDS layer is a genuine matrix product -- a constant 12x12 matrix of 6-bit entries times the state
+// -- and it is exact on the int8 MFMA: split every state word into its 8 BYTES (the register bytes as they are: no
+// data movement), multiply each byte plane by the matrix (products < 2^14, row sums < 2^17 in the i32 accumulators),
+// and recombine the 8 plane sums of a word with shifts: y = sum_p a_p * 2^(8p) (mod p).  That replaces 28 VALU
+// instructions per output word by 12, and the MFMA pipe was idle.
+//
+// Layout.  A wave owns 64 states as NS = 4 "sets" of 16.  Lane l = (n = l & 15, kb = l >> 4) holds, for every set m,
+// words kb, kb + 4, kb + 8 of state 16m + n: e[m][a] = word kb + 4a.  This is exactly the operand map of
+// v_mfma_i32_16x16x64_i8 (checked on the device, tools/mfma_probe.hip): B[k][col]: lane (col = l & 15, k-block l >> 4)
+// supplies 16 bytes, A[row][k] likewise with row = l & 15, products are paired by (k-block, byte), and the result
+// D[row][col] lands in lane (col, row >> 2), register row & 3.
+//   B operand of (set m, half h): dwords { half h of e[m][0], of e[m][1], of e[m][2], 0 } ^ 0x80808080: byte 4a + pp is
+//     plane 4h + pp of input word kb + 4a.  The XOR makes the byte x the signed x - 128 the MFMA multiplies.
+//   A operand of output slot g (constant, 3 x 4 VGPRs): lane (r, kb), dword a = M[(r >> 2) + 4g][kb + 4a] << 8(r & 3):
+//     row r of the tile is (output word (r >> 2) + 4g, plane r & 3 of the half) and takes only that plane's bytes.
+//   C operand: 128 * rowsum (undoes the -128) + the matching byte of the NEXT round's constant: the constant layer
+//     rides in the accumulators exactly as in the one-lane form.  30 x 4 x 24 dwords, built in LDS per workgroup.
+//   D of (g, h): lane (n, ib) register reg = plane 4h + reg of output word ib + 4g of state n -- the layout the state
+//     had: no lane ever moves data in the MDS layer.
+// Six MFMAs per set and round.  Partial rounds: word 0 of the four sets sits in lanes 0..15 of four registers; three
+// v_permlane{16,32}_swap per 32-bit half gather them into one dense register (all 64 lanes busy in the S-box) and the
+// same three swaps, being involutions, put everything back.
+#pragma once
+#include "poseidon.cuh"
+
+namespace poseidon {
+namespace mx {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int CIN_PER_ROUND = 4 * 24;            // [ib][2g + h][reg]
+constexpr int CIN_WORDS = 30 * CIN_PER_ROUND;    // 11,520 bytes of LDS
+
+__device__ __forceinline__ uint32_t mds_entry(uint32_t i, uint32_t k) {  // M[i][k] = C[(k - i) mod 12] (+ 8 at [0][0])
+  constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  const uint32_t d = (k + 12 - i) % 12;
+  uint32_t v = 0;
+#pragma unroll
+  for (int j = 0; j < 12; j++) v = d == (uint32_t)j ? C[j] : v;
+  return v + ((i | k) == 0 ? 8u : 0u);
+}
+
+// the whole workgroup fills the C-operand table (call once, then __syncthreads)
+__device__ __forceinline__ void build_cin(uint32_t* __restrict__ cin) {
+  for (uint32_t i = threadIdx.x; i < (uint32_t)CIN_WORDS; i += blockDim.x) {
+    const uint32_t rnd = i / CIN_PER_ROUND, rem = i % CIN_PER_ROUND, ib = rem / 24, idx = rem % 24;
+    const uint32_t g = idx >> 3, h = (idx >> 2) & 1, reg = idx & 3, wo = ib + 4 * g;
+    uint32_t v = 128u * (256u + (wo == 0 ? 8u : 0u));
+    if (rnd < 29) v += (uint32_t)(RC[(rnd + 1) * 12 + wo] >> (8 * (4 * h + reg))) & 0xFFu;
+    cin[i] = v;
+  }
+}
+
+struct Ctx {
+  v4i A[3];          // the MDS matrix as the A operand of output slot g
+  uint32_t kb;       // lane >> 4: this lane holds words kb, kb + 4, kb + 8
+  const uint32_t* cin;  // LDS table, already offset to this lane's row group
+};
+__device__ __forceinline__ Ctx make_ctx(const uint32_t* cin_lds) {
+  Ctx c;
+  const uint32_t lane = threadIdx.x & 63, r = lane & 15;
+  c.kb = lane >> 4;
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) c.A[g][a] = (int)(mds_entry((r >> 2) + 4 * g, c.kb + 4 * a) << (8 * (r & 3)));
+    c.A[g][3] = 0;
+  }
+  c.cin = cin_lds + c.kb * 24;
+  return c;
+}
+
+// four plane sums (each < 2^17) -> a0 + a1*2^8 + a2*2^16 + a3*2^24 < 2^42
+__device__ __forceinline__ uint64_t planes(const v4i& d) {
+  const uint32_t e = (uint32_t)d[0] + ((uint32_t)d[1] << 8), f = (uint32_t)d[2] + ((uint32_t)d[3] << 8);
+  return (uint64_t)e + ((uint64_t)f << 16);
+}
+
+// MDS layer (+ next round's constants) of every set
+template <int NS>
+__device__ __forceinline__ void mds(uint64_t (&e)[NS][3], const Ctx& c, int rnd) {
+  const v4i* cr = (const v4i*)(c.cin + rnd * CIN_PER_ROUND);
+  v4i cin[6];
+#pragma unroll
+  for (int t = 0; t < 6; t++) cin[t] = cr[t];
+#pragma unroll
+  for (int m = 0; m < NS; m++) {
+    v4i blo, bhi;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      blo[a] = (int)((uint32_t)e[m][a] ^ 0x80808080u);
+      bhi[a] = (int)((uint32_t)(e[m][a] >> 32) ^ 0x80808080u);
+    }
+    blo[3] = 0;
+    bhi[3] = 0;
+    uint64_t L[3], H[3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      const v4i dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(c.A[g], blo, cin[2 * g], 0, 0, 0);
+      const v4i dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(c.A[g], bhi, cin[2 * g + 1], 0, 0, 0);
+      L[g] = planes(dl);
+      H[g] = planes(dh);
+    }
+    reduce_rows<3>(L, H, e[m]);
+  }
+}
+
+// S-box on state word 0 only (partial rounds)
+template <int NS>
+__device__ __forceinline__ void sbox_word0(uint64_t (&e)[NS][3], const Ctx& c) {
+  if constexpr (NS == 4) {
+    uint32_t l0 = (uint32_t)e[0][0], l1 = (uint32_t)e[1][0], l2 = (uint32_t)e[2][0], l3 = (uint32_t)e[3][0];
+    uint32_t h0 = (uint32_t)(e[0][0] >> 32), h1 = (uint32_t)(e[1][0] >> 32), h2 = (uint32_t)(e[2][0] >> 32),
+             h3 = (uint32_t)(e[3][0] >> 32);
+    // rows (16 lanes) of x0 become [x0.r0, x1.r0, x2.r0, x3.r0]: word 0 of all 64 states.  The operands come from asm
+    // statements (reduce_rows), which the hazard recogniser does not see: 2 wait states before every swap that reads a
+    // register an earlier instruction has just written.
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+        "s_nop 0\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %4, %6\n\ts_nop 1"
+        : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3));
+    const uint64_t y = sbox(gl::cc::mk64(l0, h0));
+    l0 = (uint32_t)y;
+    h0 = (uint32_t)(y >> 32);
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %4, %6\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\ts_nop 1"
+        : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3));
+    e[0][0] = gl::cc::mk64(l0, h0);
+    e[1][0] = gl::cc::mk64(l1, h1);
+    e[2][0] = gl::cc::mk64(l2, h2);
+    e[3][0] = gl::cc::mk64(l3, h3);
+  } else {
+#pragma unroll
+    for (int m = 0; m < NS; m++) {
+      const uint64_t y = sbox(e[m][0]);
+      e[m][0] = c.kb == 0 ? y : e[m][0];
+    }
+  }
+}
+
+template <int NS>
+__device__ __forceinline__ void sbox_full(uint64_t (&e)[NS][3]) {
+#pragma unroll
+  for (int m = 0; m < NS; m++) {
+    sbox_n<3>(e[m]);
+    __builtin_amdgcn_sched_barrier(0);  // one group's carry masks at a time (poseidon.cuh, sbox_all)
+  }
+}
+
+// e[m][a] = word kb + 4a of state 16m + n, any u64 in, reduced out
+template <int NS>
+__device__ __forceinline__ void permute(uint64_t (&e)[NS][3], const Ctx& c) {
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const uint64_t k = RC[c.kb + 4 * a];
+#pragma unroll
+    for (int m = 0; m < NS; m++) e[m][a] = gl::add(e[m][a], k);
+  }
+  int rnd = 0;
+#pragma unroll 1
+  for (int k = 0; k < 4; k++, rnd++) {
+    sbox_full<NS>(e);
+    mds<NS>(e, c, rnd);
+  }
+#pragma unroll 1
+  for (int k = 0; k < 22; k++, rnd++) {
+    sbox_word0<NS>(e, c);
+    mds<NS>(e, c, rnd);
+  }
+#pragma unroll 1
+  for (int k = 0; k < 4; k++, rnd++) {
+    sbox_full<NS>(e);
+    mds<NS>(e, c, rnd);
+  }
+}
+
+}  // namespace mx
+}  // namespace poseidon

@@ -4,6 +4,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the code-generation flags of csrc/Makefile
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def test_build_entry_compiles_everything():
@@ -25,7 +27,7 @@ def test_no_kernel_spills_sgprs(tmp_path):
     bad = []
     for src in ("hash_kernels.hip", "ntt.hip", "stark_kernels.hip"):
         out = tmp_path / (src + ".s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+        subprocess.run(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-S", "--cuda-device-only",
                         "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(csrc, src)],
                        check=True, capture_output=True)
         name = None
@@ -62,7 +64,7 @@ def test_no_dpp_reads_a_fresh_asm_result(tmp_path):
     bad = []
     for src in ("hash_kernels.hip", "stark_kernels.hip"):
         out = tmp_path / (src + ".s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+        subprocess.run(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-S", "--cuda-device-only",
                         "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(csrc, src)],
                        check=True, capture_output=True)
         in_asm = False
@@ -86,16 +88,17 @@ def test_no_dpp_reads_a_fresh_asm_result(tmp_path):
             if op == "s_nop":
                 states = int(operands[0], 0) + 1
             is_dpp = "_dpp" in op or "quad_perm" in t or "row_" in t or op.startswith("v_permlane")
+            is_swap = op.startswith("v_permlane") and "swap" in op  # reads AND writes both of its operands
             if is_dpp:
                 n_dpp += 1
                 srcs = set()
-                for o in operands[1:]:
+                for o in (operands if is_swap else operands[1:]):
                     srcs |= _vregs(o.split()[0] if o else o)
                 for age, regs in recent:
                     if age < 2 and regs & srcs:
                         bad.append((src, ln, t))
             recent = [(age + states, regs) for age, regs in recent if age + states < 2]
             if in_asm and op.startswith("v_") and operands:
-                recent.append((0, _vregs(operands[0])))
+                recent.append((0, _vregs(operands[0]) | (_vregs(operands[1]) if is_swap and len(operands) > 1 else set())))
         assert n_dpp > 0 or src != "hash_kernels.hip", "scanner found no DPP instruction in " + src
     assert not bad, bad

@@ -85,7 +85,15 @@ def test_field_ops_against_big_integers(bpg):
         assert got[13][i] == x % P and got[14][i] == y % P, (i, hex(x), hex(y))
 
 
-def test_poseidon_kat_and_random(bpg, oracle):
+@pytest.fixture(params=["mx", "lane"])
+def perm_form(request, bpg):
+    """the two forms of the batch permutation: MDS on the matrix cores / one lane per state"""
+    bpg.lib().bp_tune_poseidon_mx(1 if request.param == "mx" else 0)
+    yield request.param
+    bpg.lib().bp_tune_poseidon_mx(1)
+
+
+def test_poseidon_kat_and_random(bpg, oracle, perm_form):
     rng = np.random.default_rng(7)
     states = rand_field(rng, (4099, 12))
     states[0] = 0
@@ -98,22 +106,40 @@ def test_poseidon_kat_and_random(bpg, oracle):
     assert (got == oracle.poseidon(states)).all()
 
 
-def test_poseidon_noncanonical_inputs(bpg, oracle):
+def test_poseidon_noncanonical_inputs(bpg, oracle, perm_form):
     # inputs in [p, 2^64) must behave as their residues
     s = np.full((64, 12), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
     s[1] = P
     s[2] = P + 5
+    s[3] = 0xFFFFFFFF                      # every byte plane of the low half at its maximum
+    s[4] = 0xFFFFFFFF00000000
+    s[5, ::2] = P - 1
     got = to_host(bpg.ops.poseidon_perm_batch_(to_dev(s)))
     assert (got == oracle.poseidon(s % np.uint64(P))).all()
 
 
-@pytest.mark.parametrize("quad", [True, False], ids=["quad", "lane"])
+def test_poseidon_byte_plane_extremes(bpg, oracle, perm_form):
+    # the matrix-core MDS sums byte planes: states whose words are all-0xFF / all-0x00 / 0x80 / 0x7F bytes drive every
+    # plane sum to its bounds (and the signed-byte offset to both ends); ragged batch sizes cover the clamped tail
+    pats = [0, 0xFFFFFFFFFFFFFFFF % P, 0x8080808080808080, 0x7F7F7F7F7F7F7F7F, 0xFF00FF00FF00FF00, 0x00FF00FF00FF00FF,
+            0x0101010101010101, 0xFEFEFEFEFEFEFEFE]
+    rng = np.random.default_rng(11)
+    for n in (1, 15, 16, 17, 63, 64, 65, 255, 257):
+        s = np.array([[pats[(i + k * (i % 3 + 1)) % len(pats)] for k in range(12)] for i in range(n)], dtype=np.uint64)
+        s[n // 2] = rand_field(rng, (12,))
+        got = to_host(bpg.ops.poseidon_perm_batch_(to_dev(s.copy())))
+        assert (got == oracle.poseidon(s % np.uint64(P))).all(), n
+
+
+@pytest.mark.parametrize("quad", ["quad", "lane", "mx"])
 @pytest.mark.parametrize("log_n,rate_bits,n_cols,cap_h", [(3, 1, 3, 4), (4, 1, 4, 0), (6, 1, 8, 4), (7, 3, 19, 4),
                                                           (10, 1, 135, 4), (12, 1, 33, 2), (9, 3, 2, 4), (5, 1, 9, 1),
                                                           (6, 1, 13, 3)])
 def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap_h, quad):
-    # both Poseidon kernel families (4 lanes per state with DPP exchange / one lane per state)
-    bpg.lib().bp_tune_quad_threshold((1 << 40) if quad else 1)  # 1: never quad; 0 would be automatic
+    # the three Poseidon kernel families: 4 lanes per state with DPP exchange / one lane per state / MDS on the
+    # matrix cores (four sets of 16 states per wave)
+    bpg.lib().bp_tune_quad_threshold((1 << 40) if quad == "quad" else 1)  # 1: never quad; 0 would be automatic
+    bpg.lib().bp_tune_poseidon_mx(1 if quad == "mx" else 0)
     rng = np.random.default_rng(300 + log_n)
     rows = 1 << (log_n + rate_bits)
     lde_cm = rand_field(rng, (n_cols, rows))          # coset-major, as the LDE kernel writes it
@@ -122,6 +148,7 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     want_dig, want_cap = oracle.merkle_commit(lde_nat, cap_h, bitrev_rows=True)
     dig = to_host(bpg.ops.merkle_commit(to_dev(lde_cm), log_n, rate_bits, cap_h))
     bpg.lib().bp_tune_quad_threshold(0)  # back to automatic
+    bpg.lib().bp_tune_poseidon_mx(1)
     assert (dig == want_dig).all()
     assert (dig[-(1 << cap_h):] == want_cap).all()
 
