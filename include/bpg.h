@@ -110,6 +110,9 @@ void bp_tune_merkle_fused(int on);
  * (csrc/poseidon_mx.cuh: the MDS layer as int8 MFMAs on the byte planes of the state); 0: one lane per state.
  * Results are identical either way. */
 void bp_tune_poseidon_mx(int on);
+/* Sets of 16 states a wave of the matrix-core form carries: 4, 2 or 1 (fewer sets = more waves for the same launch);
+ * 0 (default) = by launch size: 4 from the quad threshold up, 2 from half of it, else 1.  Results are identical. */
+void bp_tune_poseidon_mx_sets(int sets);
 
 /* Tuning knob for K2: 0 (default) = automatic, 1 = never, 2 = wherever possible: transform a 2^13 / 2^14-point
  * block with TWO workgroups that each do half of the stage coupling its halves while loading (csrc/ntt.hip).

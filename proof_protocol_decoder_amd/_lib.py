@@ -74,6 +74,8 @@ def lib():
     L.bp_tune_quad_threshold.restype = None
     L.bp_tune_poseidon_mx.argtypes = [i]
     L.bp_tune_poseidon_mx.restype = None
+    L.bp_tune_poseidon_mx_sets.argtypes = [i]
+    L.bp_tune_poseidon_mx_sets.restype = None
     _lib = L
     return L
 

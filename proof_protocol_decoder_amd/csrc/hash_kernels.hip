@@ -195,26 +195,28 @@ merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ p
   }
 }
 
-// ---- matrix-core ("mx") form, poseidon_mx.cuh: a wave owns 64 rows / nodes / states as four sets of 16; lane
+// ---- matrix-core ("mx") form, poseidon_mx.cuh: a wave owns 16 * NS rows / nodes / states as NS sets of 16; lane
 // (n = lane & 15, kb = lane >> 4) holds words kb, kb + 4, kb + 8 of item 16m + n of every set m.  No lane leaves before
 // the permutations are done (an MFMA is a whole-wave instruction): out-of-range items are clamped for the loads and
-// masked at the store.
+// masked at the store.  NS = 4 is the throughput form, NS = 1 (4x the waves, like the quad form, at 0.65x its
+// instructions) the one for launches that cannot fill the chip.
+template <int NS>
 __global__ void __launch_bounds__(256) perm_batch_mx_kernel(uint64_t* __restrict__ states, uint64_t n) {
   __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
   poseidon::mx::build_cin(cin);
   __syncthreads();
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
-  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 15);
-  uint64_t e[4][3];
+  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS) + (threadIdx.x & 15);
+  uint64_t e[NS][3];
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
+  for (int m = 0; m < NS; m++) {
     const uint64_t i = base + 16 * m < n ? base + 16 * m : n - 1;
 #pragma unroll
     for (int a = 0; a < 3; a++) e[m][a] = states[i * 12 + c.kb + 4 * a];
   }
-  poseidon::mx::permute<4>(e, c);
+  poseidon::mx::permute<NS>(e, c);
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
+  for (int m = 0; m < NS; m++) {
     const uint64_t i = base + 16 * m;
     if (i < n) {
 #pragma unroll
@@ -223,20 +225,22 @@ __global__ void __launch_bounds__(256) perm_batch_mx_kernel(uint64_t* __restrict
   }
 }
 
+template <int NS>
 __global__ void __launch_bounds__(256)
 leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
                     uint32_t rate_bits, uint64_t* __restrict__ digests) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
   poseidon::mx::build_cin(cin);
   __syncthreads();
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
   const uint64_t rows = (uint64_t)1 << (log_n + rate_bits);
-  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 15);
+  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS) + (threadIdx.x & 15);
   const uint32_t kb = c.kb;
-  const uint64_t* p[4];
-  uint64_t e[4][3];
+  const uint64_t* p[NS];
+  uint64_t e[NS][3];
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
+  for (int m = 0; m < NS; m++) {
     const uint64_t pos = base + 16 * m < rows ? base + 16 * m : rows - 1;
     p[m] = lde + pos;
     e[m][0] = e[m][1] = e[m][2] = 0;
@@ -244,23 +248,23 @@ leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t 
   if (n_cols <= 4) {  // hash_or_noop: short rows are the digest
     if (kb < n_cols) {
 #pragma unroll
-      for (int m = 0; m < 4; m++) e[m][0] = p[m][(uint64_t)kb * stride];
+      for (int m = 0; m < NS; m++) e[m][0] = p[m][(uint64_t)kb * stride];
     }
   } else {
     for (uint32_t col = 0; col < n_cols; col += 8) {  // wave-uniform trip count
       if (col + kb < n_cols) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) e[m][0] = p[m][(uint64_t)(col + kb) * stride];
+        for (int m = 0; m < NS; m++) e[m][0] = p[m][(uint64_t)(col + kb) * stride];
       }
       if (col + 4 + kb < n_cols) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) e[m][1] = p[m][(uint64_t)(col + 4 + kb) * stride];
+        for (int m = 0; m < NS; m++) e[m][1] = p[m][(uint64_t)(col + 4 + kb) * stride];
       }
-      poseidon::mx::permute<4>(e, c);
+      poseidon::mx::permute<NS>(e, c);
     }
   }
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
+  for (int m = 0; m < NS; m++) {
     const uint64_t pos = base + 16 * m;
     if (pos < rows) {
       const uint32_t t = (uint32_t)(pos >> log_n), mm = (uint32_t)(pos & ((1u << log_n) - 1));
@@ -270,25 +274,27 @@ leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t 
   }
 }
 
+template <int NS>
 __global__ void __launch_bounds__(256)
 merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
                        uint64_t* __restrict__ mirror) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
   poseidon::mx::build_cin(cin);
   __syncthreads();
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
-  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 15);
-  uint64_t e[4][3];
+  const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS) + (threadIdx.x & 15);
+  uint64_t e[NS][3];
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
+  for (int m = 0; m < NS; m++) {
     const uint64_t i = base + 16 * m < n_parents ? base + 16 * m : n_parents - 1;
     e[m][0] = child[i * 8 + c.kb];
     e[m][1] = child[i * 8 + 4 + c.kb];
     e[m][2] = 0;
   }
-  poseidon::mx::permute<4>(e, c);
+  poseidon::mx::permute<NS>(e, c);
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
+  for (int m = 0; m < NS; m++) {
     const uint64_t i = base + 16 * m;
     if (i < n_parents) {
       const uint64_t d = gl::canon(e[m][0]);
@@ -382,16 +388,40 @@ int merkle_commit_cols(const uint64_t*, uint64_t, uint32_t, uint32_t, uint32_t, 
 // the threshold follows the number of provers at work: few -> 2^17 (measured alone: quad wins up to there),
 // many -> 2^13 (under 24-stream load the instruction count decides; 2^11..2^13 measured best by ~1 %).
 static std::atomic<uint64_t> g_quad_threshold{0};
+static bool g_poseidon_mx_on();
 static std::atomic<int> g_active_provers{0};
 void prover_active(int delta) { g_active_provers.fetch_add(delta, std::memory_order_relaxed); }
 uint64_t quad_threshold() {
   const uint64_t t = g_quad_threshold.load(std::memory_order_relaxed);
   if (t) return t;
-  return (uint64_t)1 << (g_active_provers.load(std::memory_order_relaxed) >= 6 ? 13 : 17);
+  const bool loaded = g_active_provers.load(std::memory_order_relaxed) >= 6;
+  // with the matrix-core forms the small-launch form (one set per wave) costs 0.65x the quad form's instructions
+  // and wins alone up to 2^18 items (tools/kernel_bench.py: 2^17 rows 1.8-2.0 against 1.5-1.8 Gperm/s for four sets)
+  if (g_poseidon_mx_on()) return (uint64_t)1 << (loaded ? 13 : 19);
+  return (uint64_t)1 << (loaded ? 13 : 17);
 }
 static std::atomic<int> g_merkle_fused{0};  // measured: per-level launches are ~3% faster under 16-stream load
 // launches at or above the quad threshold: 1 = matrix-core form (poseidon_mx.cuh), 0 = one lane per state
 static std::atomic<int> g_poseidon_mx{1};
+bool poseidon_mx() { return g_poseidon_mx.load(std::memory_order_relaxed) != 0; }
+static bool g_poseidon_mx_on() { return poseidon_mx(); }
+// Sets of 16 states per wave for an mx launch of n items (0 = matrix-core form off).  Four sets are the throughput
+// form (all 64 lanes busy in the partial-round S-box); a launch below the quad threshold takes fewer sets = more
+// waves, as the quad form did (which the one-set form replaces at 0.65x the instructions).
+static std::atomic<int> g_mx_sets{0};  // 0 = by size, else 1 / 2 / 4
+int mx_sets(uint64_t n) {
+  if (!poseidon_mx()) return 0;
+  const int f = g_mx_sets.load(std::memory_order_relaxed);
+  if (f) return f;
+  const uint64_t t = quad_threshold();
+  return n >= t ? 4 : (n >= t / 2 ? 2 : 1);
+}
+#define BPG_MX_DISPATCH(NS_EXPR, KERNEL, ITEMS, ...)                                                        \
+  switch (NS_EXPR) {                                                                                       \
+    case 4: KERNEL<4><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__); break;                        \
+    case 2: KERNEL<2><<<ceil_div((ITEMS), 128), 256, 0, st>>>(__VA_ARGS__); break;                        \
+    default: KERNEL<1><<<ceil_div((ITEMS), 64), 256, 0, st>>>(__VA_ARGS__); break;                        \
+  }
 
 // `mirror` (nullable): host-visible buffer that receives the 2^cap_height cap digests directly from
 // the kernel that produces them, so the caller needs no device->host copy, only a stream wait.
@@ -408,12 +438,10 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     const bool fused = parents <= 4096 && parents < quad_threshold() && g_merkle_fused.load(std::memory_order_relaxed);
     if (!fused) {
       uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;
-      if (parents >= quad_threshold()) {  // big level: the forms with all 64 lanes busy in the partial rounds
-        if (g_poseidon_mx.load(std::memory_order_relaxed))
-          merkle_level_mx_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
-        else
-          merkle_level_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
-      }
+      if (const int ns = mx_sets(parents)) {
+        BPG_MX_DISPATCH(ns, merkle_level_mx_kernel, parents, lvl, nxt, parents, mir)
+      } else if (parents >= quad_threshold())  // big level: one lane per node
+        merkle_level_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
       else
         merkle_level_quad_kernel<<<ceil_div(cnt * 2, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
       BPG_LAUNCH_CHECK();
@@ -471,6 +499,7 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
 void bp_tune_merkle_fused(int on) { bpg::g_merkle_fused.store(on != 0); }
 void bp_tune_quad_threshold(uint64_t n_perms) { bpg::g_quad_threshold.store(n_perms); }
 void bp_tune_poseidon_mx(int on) { bpg::g_poseidon_mx.store(on != 0); }
+void bp_tune_poseidon_mx_sets(int sets) { bpg::g_mx_sets.store(sets == 1 || sets == 2 || sets == 4 ? sets : 0); }
 
 uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {
   return (((uint64_t)2 << log_leaves) - ((uint64_t)1 << cap_height)) * 4;
@@ -479,10 +508,12 @@ uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {
 int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream) try {
   if (!n) return BP_OK;
   if (!d_states) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_poseidon_perm_batch: null buffer");
-  if (bpg::g_poseidon_mx.load(std::memory_order_relaxed))
-    perm_batch_mx_kernel<<<bpg::ceil_div(n, 256), 256, 0, bpg::as_stream(stream)>>>(d_states, n);
-  else
-    perm_batch_kernel<<<bpg::ceil_div(n, 256), 256, 0, bpg::as_stream(stream)>>>(d_states, n);
+  hipStream_t st = bpg::as_stream(stream);
+  using bpg::ceil_div;
+  if (const int ns = bpg::mx_sets(n)) {
+    BPG_MX_DISPATCH(ns, perm_batch_mx_kernel, n, d_states, n)
+  } else
+    perm_batch_kernel<<<bpg::ceil_div(n, 256), 256, 0, st>>>(d_states, n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -511,11 +542,11 @@ int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_co
   {
     // integer-ALU-bound family: the "bytes" slot of the profiler carries permutations
     KernelTimer kt(PROF_LEAF_HASH, st, n_cols > 4 ? (double)rows * (double)((n_cols + 7) / 8) : 0.0);
-    if (rows < quad_threshold())
+    if (const int ns = mx_sets(rows)) {
+      BPG_MX_DISPATCH(ns, leaf_hash_mx_kernel, rows, d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests)
+    } else if (rows < quad_threshold())
       leaf_hash_quad_kernel<<<ceil_div(rows * 4, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
                                                                    d_digests);
-    else if (g_poseidon_mx.load(std::memory_order_relaxed))
-      leaf_hash_mx_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests);
     else
       leaf_hash_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests);
   }

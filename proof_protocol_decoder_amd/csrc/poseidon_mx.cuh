@@ -10,7 +10,7 @@
 // and recombine the 8 plane sums of a word with shifts: y = sum_p a_p * 2^(8p) (mod p).  That replaces 28 VALU
 // instructions per output word by 12, and the MFMA pipe was idle.
 //
-// Layout.  A wave owns 64 states as NS = 4 "sets" of 16.  Lane l = (n = l & 15, kb = l >> 4) holds, for every set m,
+// Layout.  A wave owns 16 * NS states as NS (4, 2 or 1) "sets" of 16.  Lane l = (n = l & 15, kb = l >> 4) holds, for every set m,
 // words kb, kb + 4, kb + 8 of state 16m + n: e[m][a] = word kb + 4a.  This is exactly the operand map of
 // v_mfma_i32_16x16x64_i8 (checked on the device, tools/mfma_probe.hip): B[k][col]: lane (col = l & 15, k-block l >> 4)
 // supplies 16 bytes, A[row][k] likewise with row = l & 15, products are paired by (k-block, byte), and the result
@@ -25,7 +25,8 @@
 //     had: no lane ever moves data in the MDS layer.
 // Six MFMAs per set and round.  Partial rounds: word 0 of the four sets sits in lanes 0..15 of four registers; three
 // v_permlane{16,32}_swap per 32-bit half gather them into one dense register (all 64 lanes busy in the S-box) and the
-// same three swaps, being involutions, put everything back.
+// same three swaps, being involutions, put everything back.  NS = 2 and 1 (32 and 16 states per wave: 2x and 4x the
+// waves for a launch too small to fill 1024 SIMDs otherwise) use one swap or none and leave lanes idle in that S-box.
 #pragma once
 #include "poseidon.cuh"
 
@@ -46,15 +47,32 @@ __device__ __forceinline__ uint32_t mds_entry(uint32_t i, uint32_t k) {  // M[i]
   return v + ((i | k) == 0 ? 8u : 0u);
 }
 
-// the whole workgroup fills the C-operand table (call once, then __syncthreads)
-__device__ __forceinline__ void build_cin(uint32_t* __restrict__ cin) {
-  for (uint32_t i = threadIdx.x; i < (uint32_t)CIN_WORDS; i += blockDim.x) {
-    const uint32_t rnd = i / CIN_PER_ROUND, rem = i % CIN_PER_ROUND, ib = rem / 24, idx = rem % 24;
-    const uint32_t g = idx >> 3, h = (idx >> 2) & 1, reg = idx & 3, wo = ib + 4 * g;
+// The C-operand table, made at compile time: [round][ib][2g + h][reg] = 128 * rowsum(word ib + 4g) + byte 4h + reg of
+// the NEXT round's constant of that word (none after the last round).
+struct CinTable {
+  uint32_t v[CIN_WORDS];
+};
+constexpr CinTable make_cin_table() {
+  constexpr uint64_t rc[360] = {
+#include "poseidon_rc.inc"
+  };
+  CinTable t{};
+  for (int i = 0; i < CIN_WORDS; i++) {
+    const int rnd = i / CIN_PER_ROUND, rem = i % CIN_PER_ROUND, ib = rem / 24, idx = rem % 24;
+    const int g = idx >> 3, h = (idx >> 2) & 1, reg = idx & 3, wo = ib + 4 * g;
     uint32_t v = 128u * (256u + (wo == 0 ? 8u : 0u));
-    if (rnd < 29) v += (uint32_t)(RC[(rnd + 1) * 12 + wo] >> (8 * (4 * h + reg))) & 0xFFu;
-    cin[i] = v;
+    if (rnd < 29) v += (uint32_t)(rc[(rnd + 1) * 12 + wo] >> (8 * (4 * h + reg))) & 0xFFu;
+    t.v[i] = v;
   }
+  return t;
+}
+static __device__ const CinTable CIN_TABLE __attribute__((aligned(16))) = make_cin_table();
+
+// the whole workgroup copies the table into LDS, 16 bytes per lane and step (call once, then __syncthreads)
+__device__ __forceinline__ void build_cin(uint32_t* __restrict__ cin) {
+  const uint4* src = (const uint4*)CIN_TABLE.v;
+  uint4* dst = (uint4*)cin;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)CIN_WORDS / 4; i += blockDim.x) dst[i] = src[i];
 }
 
 struct Ctx {
@@ -76,10 +94,13 @@ __device__ __forceinline__ Ctx make_ctx(const uint32_t* cin_lds) {
   return c;
 }
 
-// four plane sums (each < 2^17) -> a0 + a1*2^8 + a2*2^16 + a3*2^24 < 2^42
+// four plane sums (each < 2^17) -> a0 + a1*2^8 + a2*2^16 + a3*2^24 < 2^42: two shift-adds and one multiply-add (the
+// compiler's own rendering of the 64-bit shift and add is five to six instructions)
 __device__ __forceinline__ uint64_t planes(const v4i& d) {
   const uint32_t e = (uint32_t)d[0] + ((uint32_t)d[1] << 8), f = (uint32_t)d[2] + ((uint32_t)d[3] << 8);
-  return (uint64_t)e + ((uint64_t)f << 16);
+  uint64_t r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(f), "s"(65536u), "v"((uint64_t)e) : "vcc");
+  return r;
 }
 
 // MDS layer (+ next round's constants) of every set
@@ -140,12 +161,23 @@ __device__ __forceinline__ void sbox_word0(uint64_t (&e)[NS][3], const Ctx& c) {
     e[1][0] = gl::cc::mk64(l1, h1);
     e[2][0] = gl::cc::mk64(l2, h2);
     e[3][0] = gl::cc::mk64(l3, h3);
+  } else if constexpr (NS == 2) {
+    // one swap per half puts word 0 of both sets into lanes 0..31; lanes 32..63 (words 2 of the two sets) keep theirs
+    uint32_t l0 = (uint32_t)e[0][0], l1 = (uint32_t)e[1][0], h0 = (uint32_t)(e[0][0] >> 32), h1 = (uint32_t)(e[1][0] >> 32);
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+        : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1));
+    const uint64_t y = sbox(gl::cc::mk64(l0, h0));
+    const bool word0 = c.kb < 2;
+    l0 = word0 ? (uint32_t)y : l0;
+    h0 = word0 ? (uint32_t)(y >> 32) : h0;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+        : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1));
+    e[0][0] = gl::cc::mk64(l0, h0);
+    e[1][0] = gl::cc::mk64(l1, h1);
   } else {
-#pragma unroll
-    for (int m = 0; m < NS; m++) {
-      const uint64_t y = sbox(e[m][0]);
-      e[m][0] = c.kb == 0 ? y : e[m][0];
-    }
+    static_assert(NS == 1, "1, 2 or 4 sets per wave");
+    const uint64_t y = sbox(e[0][0]);
+    e[0][0] = c.kb == 0 ? y : e[0][0];
   }
 }
 

@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "gl.hpp"
 #include "poseidon.cuh"
+#include "poseidon_mx.cuh"
 #include "stark_kernels.hpp"
 
 namespace {
@@ -428,6 +429,47 @@ __global__ void __launch_bounds__(256) fri_layer_leaf_quad_kernel(bpg::FriLayerA
   const uint64_t leaf = gl::bitrev((uint32_t)(t + ((uint64_t)m0 << a.rate_bits)), log_q + a.rate_bits);
   a.digests[leaf * 4 + qc.q] = gl::canon(e[0]);
 }
+// Matrix-core form (poseidon_mx.cuh): a wave takes 16 * NS leaves; lane (n, kb) of set m carries state words kb and
+// kb + 4 of leaf 16m + n, i.e. component (kb & 1) of ext elements (kb >> 1) and 2 + (kb >> 1) of every absorb.
+template <int NS>
+__global__ void __launch_bounds__(256) fri_layer_leaf_mx_kernel(bpg::FriLayerArgs a) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
+  poseidon::mx::build_cin(cin);
+  __syncthreads();
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
+  const uint32_t log_q = a.log_nl - a.arity_bits;
+  const uint64_t n_leaves = (uint64_t)1 << (log_q + a.rate_bits);
+  const uint64_t id0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS) + (threadIdx.x & 15);
+  const uint32_t arity = 1u << a.arity_bits, u = c.kb >> 1, comp = c.kb & 1;
+  uint64_t base[NS], e[NS][3];
+#pragma unroll
+  for (int m = 0; m < NS; m++) {
+    const uint64_t id = id0 + 16 * m < n_leaves ? id0 + 16 * m : n_leaves - 1;
+    const uint32_t t = (uint32_t)(id >> log_q), m0 = (uint32_t)(id & ((1u << log_q) - 1));
+    base[m] = ((uint64_t)t << a.log_nl) + m0;
+    e[m][0] = e[m][1] = e[m][2] = 0;
+  }
+  for (uint32_t j = 0; j < arity; j += 4) {
+    const uint64_t o0 = (uint64_t)gl::bitrev(j + u, a.arity_bits) << log_q;
+    const uint64_t o1 = (uint64_t)gl::bitrev(j + 2 + u, a.arity_bits) << log_q;
+#pragma unroll
+    for (int m = 0; m < NS; m++) {
+      e[m][0] = a.values[2 * (base[m] + o0) + comp];
+      e[m][1] = a.values[2 * (base[m] + o1) + comp];
+    }
+    poseidon::mx::permute<NS>(e, c);
+  }
+#pragma unroll
+  for (int m = 0; m < NS; m++) {
+    const uint64_t id = id0 + 16 * m;
+    if (id < n_leaves) {
+      const uint32_t t = (uint32_t)(id >> log_q), m0 = (uint32_t)(id & ((1u << log_q) - 1));
+      const uint64_t leaf = gl::bitrev((uint32_t)(t + ((uint64_t)m0 << a.rate_bits)), log_q + a.rate_bits);
+      a.digests[leaf * 4 + c.kb] = gl::canon(e[m][0]);
+    }
+  }
+}
 // P'(x0^a) = sum_i (beta/x0)^i u_i,  u_i = 1/a * sum_j' w_a^(-i j') P(x0 w_a^j')
 __global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
@@ -511,6 +553,31 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned
   s[a.pos] = cand;
   poseidon::permute(s);
   if ((gl::canon(s[7]) >> (64 - a.bits)) == 0) atomicMin(result, (unsigned long long)cand);
+}
+// The same search with the MDS layer on the matrix cores (poseidon_mx.cuh): a wave takes 64 consecutive candidates
+// as four sets of 16, lane (n, kb) holds words kb, kb + 4, kb + 8 of candidate 16m + n; word 7 is slot 1 of lanes kb = 3.
+__global__ void __launch_bounds__(256) pow_grind_mx_kernel(bpg::PowArgs a, unsigned long long* result) {
+  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
+  poseidon::mx::build_cin(cin);
+  __syncthreads();
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
+  const uint64_t cand0 = a.base + ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 15);
+  uint64_t e[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    uint64_t w = a.state[4 * s];
+#pragma unroll
+    for (int q = 1; q < 4; q++) w = c.kb == (uint32_t)q ? a.state[4 * s + q] : w;
+    const bool mine = c.kb + 4 * s == a.pos;
+#pragma unroll
+    for (int m = 0; m < 4; m++) e[m][s] = mine ? cand0 + 16 * m : w;
+  }
+  poseidon::mx::permute<4>(e, c);
+  if (c.kb == 3) {
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+      if ((gl::canon(e[m][1]) >> (64 - a.bits)) == 0) atomicMin(result, (unsigned long long)(cand0 + 16 * m));
+  }
 }
 
 // ---------------------------------------------------------------- query openings
@@ -646,9 +713,15 @@ int launch_fri_init(const FriInitArgs& a, hipStream_t st) {
   return BP_OK;
 }
 uint64_t quad_threshold();  // hash_kernels.hip
+bool poseidon_mx();         // hash_kernels.hip
+int mx_sets(uint64_t n);    // hash_kernels.hip
 int launch_fri_layer_leaves(const FriLayerArgs& a, hipStream_t st) {
   uint64_t n = (uint64_t)1 << (a.log_nl - a.arity_bits + a.rate_bits);
-  if (n < quad_threshold()) fri_layer_leaf_quad_kernel<<<ceil_div(n * 4, 256), 256, 0, st>>>(a);
+  if (const int ns = mx_sets(n)) {
+    if (ns == 4) fri_layer_leaf_mx_kernel<4><<<ceil_div(n, 256), 256, 0, st>>>(a);
+    else if (ns == 2) fri_layer_leaf_mx_kernel<2><<<ceil_div(n, 128), 256, 0, st>>>(a);
+    else fri_layer_leaf_mx_kernel<1><<<ceil_div(n, 64), 256, 0, st>>>(a);
+  } else if (n < quad_threshold()) fri_layer_leaf_quad_kernel<<<ceil_div(n * 4, 256), 256, 0, st>>>(a);
   else fri_layer_leaf_kernel<<<ceil_div(n, 256), 256, 0, st>>>(a);
   BPG_LAUNCH_CHECK();
   return BP_OK;
@@ -660,7 +733,10 @@ int launch_fri_fold(const FriLayerArgs& a, hipStream_t st) {
   return BP_OK;
 }
 int launch_pow(const PowArgs& a, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st) {
-  pow_grind_kernel<<<n_candidates / 256, 256, 0, st>>>(a, d_result);
+  if (poseidon_mx())
+    pow_grind_mx_kernel<<<n_candidates / 256, 256, 0, st>>>(a, d_result);
+  else
+    pow_grind_kernel<<<n_candidates / 256, 256, 0, st>>>(a, d_result);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
