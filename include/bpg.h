@@ -118,6 +118,9 @@ void bp_tune_poseidon_mx_sets(int sets);
  * block with TWO workgroups that each do half of the stage coupling its halves while loading (csrc/ntt.hip).
  * Results are identical either way. */
 void bp_tune_ntt_split(int mode);
+/* 1 (default): 2^12..2^14-point NTT blocks run as three radix-16 passes whose 16-point DFTs are int8 MFMAs on the
+ * bytes of the elements (csrc/ntt_mx.cuh); 0: the VALU butterfly kernels.  Results are identical either way. */
+void bp_tune_ntt_mx(int on);
 
 /* K3.  Poseidon-Goldilocks permutation (width 12) on n states of 12 words, in place. */
 int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream);

@@ -72,6 +72,8 @@ def lib():
     L.bp_free_buffer.restype = None
     L.bp_tune_quad_threshold.argtypes = [u64]
     L.bp_tune_quad_threshold.restype = None
+    L.bp_tune_ntt_mx.argtypes = [i]
+    L.bp_tune_ntt_mx.restype = None
     L.bp_tune_poseidon_mx.argtypes = [i]
     L.bp_tune_poseidon_mx.restype = None
     L.bp_tune_poseidon_mx_sets.argtypes = [i]

@@ -18,8 +18,10 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <memory>
 #include "common.hpp"
 #include "gl.hpp"
+#include "mx_arith.cuh"
 
 namespace {
 
@@ -609,6 +611,8 @@ __global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per
   }
 }
 
+#include "ntt_mx.cuh"  // the same blocks with the 16-point DFTs on the matrix cores
+
 // Strided global pass for columns taller than one LDS block: the top LOGR stages (DIF) or the
 // last LOGR stages (DIT) of the n-point transform.  Lane q owns elements q + m*(S>>LOGR).
 // grid = (ceil(n >> LOGR / 256), columns, cosets).  `tw` is the n-point table.
@@ -795,6 +799,30 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
   return BP_OK;
 }
 
+// Constants of the matrix-core kernels (ntt_mx.cuh), one device image per (device, kind, direction), built once.
+static std::atomic<int> g_ntt_mx{1};  // 1: 2^12..2^14-point blocks on the matrix cores, 0: the VALU kernels
+static std::mutex g_mx_mu;
+static std::map<std::tuple<int, int, int>, mxn::Tables*> g_mx_tabs;
+static int get_mx_tables(int kind, bool inverse, const mxn::Tables** out) {
+  int dev = 0;
+  BPG_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mx_mu);
+  const auto key = std::make_tuple(dev, kind, inverse ? 1 : 0);
+  auto it = g_mx_tabs.find(key);
+  if (it != g_mx_tabs.end()) {
+    *out = it->second;
+    return BP_OK;
+  }
+  auto host = std::make_unique<mxn::Tables>();
+  mxn::build_tables(*host, kind, inverse);
+  mxn::Tables* d = nullptr;
+  BPG_HIP(hipMalloc(&d, sizeof(mxn::Tables)));
+  BPG_HIP(hipMemcpy(d, host.get(), sizeof(mxn::Tables), hipMemcpyHostToDevice));
+  g_mx_tabs[key] = d;
+  *out = d;
+  return BP_OK;
+}
+
 // Plan for a column of 2^log_n elements: the LDS-resident block size and the global passes that come before it
 // (DIF) or after it (DIT).  Columns up to 2^14 are one block.  The 2^12-point LDS kernel is the most efficient one
 // (four workgroups per CU: load / compute / store of different workgroups overlap), so taller columns use the
@@ -906,7 +934,14 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
     b.tw = tw_b; b.scale = nullptr; b.out_scalar = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
     b.log_n_total = log_n; b.n_cosets = 1; b.n_units = 0;
     KernelTimer kt(PROF_INTT_DIF, st, 16.0 * (double)n_cols * (double)((uint64_t)1 << log_n));
-    if (use_split(log_blk, (uint64_t)n_cols << (log_n - log_blk), src, out, false)) {
+    if (g_ntt_mx.load(std::memory_order_relaxed)) {
+      const mxn::Tables* tab = nullptr;
+      if ((rc = get_mx_tables(0, inverse, &tab))) return rc;
+      const dim3 grid16(1u << (log_n - log_blk), n_cols);
+      if (log_blk == 12) mxn::ntt_mx_dif_kernel<0><<<grid16, 256, 8u << 12, st>>>(b, tab);
+      else if (log_blk == 13) mxn::ntt_mx_dif_kernel<1><<<grid16, 512, 8u << 13, st>>>(b, tab);
+      else mxn::ntt_mx_dif_kernel<2><<<grid16, 512, 8u << 14, st>>>(b, tab);
+    } else if (use_split(log_blk, (uint64_t)n_cols << (log_n - log_blk), src, out, false)) {
       // two workgroups of the next smaller kernel per block (see Ntt16Args)
       if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
       b.tw_top = tw_b;
@@ -955,7 +990,14 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
     b.n_units = n_cols << (log_n - log_blk);
     {
       KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
-      if (use_split(log_blk, (uint64_t)b.n_units * n_cosets, in, out, true)) {
+      if (g_ntt_mx.load(std::memory_order_relaxed)) {
+        const mxn::Tables* tab = nullptr;
+        if ((rc = get_mx_tables(1, inverse, &tab))) return rc;
+        const dim3 grid16((b.n_units + 7) / 8 * 8 * n_cosets);
+        if (log_blk == 12) mxn::ntt_mx_dit_kernel<0><<<grid16, 256, 8u << 12, st>>>(b, tab);
+        else if (log_blk == 13) mxn::ntt_mx_dit_kernel<1><<<grid16, 512, 8u << 13, st>>>(b, tab);
+        else mxn::ntt_mx_dit_kernel<2><<<grid16, 512, 8u << 14, st>>>(b, tab);
+      } else if (use_split(log_blk, (uint64_t)b.n_units * n_cosets, in, out, true)) {
         if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
         b.tw_top = tw_b;
         const dim3 grid1((b.n_units + 7) / 8 * 8 * n_cosets * 2);
@@ -1012,6 +1054,14 @@ static int init_ntt_kernels_once() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxn::ntt_mx_dif_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxn::ntt_mx_dif_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxn::ntt_mx_dit_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxn::ntt_mx_dit_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<13, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13, 1>),
@@ -1030,6 +1080,7 @@ int init_ntt_kernels() {
 extern "C" {
 
 void bp_tune_ntt_split(int mode) { bpg::g_ntt_split.store(mode); }
+void bp_tune_ntt_mx(int on) { bpg::g_ntt_mx.store(on != 0); }
 
 int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir, void* stream) try {
   if (n_cols == 0) return BP_OK;

@@ -1,0 +1,366 @@
+// ntt_mx.cuh -- K2 with the butterflies on the matrix cores: the LDS-block kernels (2^12..2^14 points) as three
+// radix-16 passes whose 16-point DFTs are int8 MFMAs.  Included by ntt.hip (which owns Ntt16Args and the planner).
+//
+// Restates plonky2_field::fft / ifft / coset_fft like ntt.hip (reached from plonky_block_proof_gen/src/
+// proof_gen.rs:44-52 through PolynomialBatch::from_values); results are bit-identical to the VALU kernels.
+//
+// Why: the VALU kernels are bound by instruction issue (a radix-2 butterfly is 27 instructions, 15 of them the
+// modular multiply: ~214 per element for 2^14 points).  In Goldilocks 2 is a 192nd root of unity and the 16th root
+// of the plonky2 generator is w16 = 2^156 = -2^60, so EVERY entry w16^(jk) * 2^(8p) of "16-point DFT acting on the
+// bytes of its inputs" is +-2^e or +-(2^a - 2^b): written in balanced base-256 digits it is an int8 matrix
+//     A[(k, q)][(j, p)] = digit q of (w16^(jk) * 2^(8p) mod p),      y_k = sum_q 2^(8q) * sum_(j,p) A * byte p of x_j,
+// 128 x 128, exact in the i32 accumulators (|sum| < 2^21).  One pass = 16 v_mfma_i32_16x16x64_i8 per 256 elements
+// (one per 16 elements, ~0.7 issue cycles per element) + per element: 2 XORs (byte x -> signed x - 128), the
+// shift recombination of 8 plane sums (12 instructions, mx_arith.cuh) and ONE modular multiply by the inter-pass
+// twiddle: ~30 instructions per element and pass against 4 x 13.5 for four radix-2 stages.  tools/ntt_mx_model.py is
+// the integer model of all of this (digits, bias, pass structure, LDS swizzle).
+//
+// Layout of a pass.  A tile = 16 groups of 16 elements; lane (n = lane & 15, kb = lane >> 4) supplies elements
+// j = 2kb, 2kb+1 (K-chunk 0) and 8+2kb, 8+2kb+1 (chunk 1) of group n -- its registers as they are, XOR 0x80808080 --
+// and receives outputs k = ib + 4a (ib = lane >> 4, a = 0..3), digits 4h + reg of row block 2a + h.  Row constants
+// (C operand): a bias that is a multiple of p and makes every plane sum non-negative, plus 128 * the row's digit sum
+// (undoes the -128).  A wave does four tiles ("sets") per pass: 16 elements per lane, like the VALU kernels.
+//   decimation in frequency (natural -> bit-reversed): pass S = 4096, 256, 16 on position blk*S + j*(S/16) + i:
+//     y_k = DFT16(x_j), times w_S^(i k), stored at blk*S + bitrev4(k)*(S/16) + i;
+//   decimation in time (bit-reversed -> natural): the transposed pipeline, S = 16, 256, 4096, twiddle before the DFT;
+//     its input slots and output rows are assigned through bitrev4 so that its LDS accesses are the same two
+//     conflict-free patterns.
+// 2^13 / 2^14-point blocks: one / two radix-2 stages (VALU, the twiddles of ntt.hip) join 2 / 4 sub-blocks of 4096,
+// done in registers next to the outermost pass, which reads from / writes to global memory directly (128-byte runs).
+#pragma once
+#include "mx_arith.cuh"
+
+namespace mxn {
+
+using mxa::v4i;
+
+// device image of the constants of one (kind, direction): kind 0 = DIF matrix, 1 = DIT matrix
+struct Tables {
+  uint32_t a[8 * 2 * 64 * 4];   // A operand: [row block][K chunk][lane] x 16 bytes
+  uint32_t c[8 * 4 * 4];        // C operand: [row block][ib] x 4 i32
+  uint64_t tw256[16 * 256];     // w_4096^(i k), [k][i]
+  uint64_t tw16[16 * 16];       // w_256^(i k), [k][i]
+};
+
+__device__ __forceinline__ uint32_t swz12(uint32_t pos) {  // XOR swizzle of a 4096-element LDS image (8-byte words)
+  return pos ^ ((pos >> 4) & 15u) ^ ((((pos >> 1) ^ (pos >> 3) ^ (pos >> 9) ^ (pos >> 11)) & 1u) << 4);
+}
+__host__ __device__ __forceinline__ constexpr uint32_t br4(uint32_t k) {
+  return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
+}
+
+struct Frag {
+  v4i a[8][2];
+  v4i c[8];
+};
+__device__ __forceinline__ void load_frag(Frag& f, const Tables* __restrict__ t) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint4* pa = reinterpret_cast<const uint4*>(t->a);
+  const uint4* pc = reinterpret_cast<const uint4*>(t->c);
+#pragma unroll
+  for (int rb = 0; rb < 8; rb++) {
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+      const uint4 v = pa[(rb * 2 + ch) * 64 + lane];
+      f.a[rb][ch] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    }
+    const uint4 v = pc[rb * 4 + (lane >> 4)];
+    f.c[rb] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+  }
+}
+
+// x[e]: input slot e of this lane (chunk e >> 1, element e & 1), any u64.  y[a]: output row a, reduced.
+__device__ __forceinline__ void dft16(const uint64_t (&x)[4], const Frag& f, uint64_t (&y)[4]) {
+  v4i b0, b1;
+  b0[0] = (int)((uint32_t)x[0] ^ 0x80808080u); b0[1] = (int)((uint32_t)(x[0] >> 32) ^ 0x80808080u);
+  b0[2] = (int)((uint32_t)x[1] ^ 0x80808080u); b0[3] = (int)((uint32_t)(x[1] >> 32) ^ 0x80808080u);
+  b1[0] = (int)((uint32_t)x[2] ^ 0x80808080u); b1[1] = (int)((uint32_t)(x[2] >> 32) ^ 0x80808080u);
+  b1[2] = (int)((uint32_t)x[3] ^ 0x80808080u); b1[3] = (int)((uint32_t)(x[3] >> 32) ^ 0x80808080u);
+  uint64_t L[4], H[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    v4i dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a][0], b0, f.c[2 * a], 0, 0, 0);
+    dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a][1], b1, dl, 0, 0, 0);
+    v4i dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a + 1][0], b0, f.c[2 * a + 1], 0, 0, 0);
+    dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a + 1][1], b1, dh, 0, 0, 0);
+    L[a] = mxa::planes(dl);
+    H[a] = mxa::planes(dh);
+  }
+  mxa::reduce_rows<4>(L, H, y);
+}
+
+// ---- decimation in frequency: natural -> bit-reversed.  X = log2(sub-blocks of 4096): block = 4096 << X points.
+// grid = (blocks per column, columns); 256 threads (X = 0) or 512 (two groups of 256).
+template <int X>
+__global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, const Tables* __restrict__ tab) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  extern __shared__ uint64_t buf[];
+  constexpr int NSUB = 1 << X, NGRP = X ? 2 : 1, SPG = NSUB / NGRP;  // sub-blocks, thread groups, sub-blocks per group
+  constexpr int MPT = 4 / NGRP;                                      // sets of the outermost pass per thread
+  const uint32_t tid = threadIdx.x, ut = tid >> 8, t = tid & 255, lane = tid & 63, w = t >> 6, n = lane & 15,
+                 kb = lane >> 4;
+  Frag f;
+  load_frag(f, tab);
+  const uint64_t off = (uint64_t)blockIdx.x << (12 + X);
+  const uint64_t* src = a.in + blockIdx.y * a.in_stride + off;
+  uint64_t* dst = a.out + blockIdx.y * a.out_stride + off;
+
+  // outermost pass (S = 4096 inside every sub-block) straight from global memory, after the X radix-2 stages
+  // that couple the sub-blocks
+#pragma unroll 1
+  for (int mi = 0; mi < MPT; mi++) {
+    const uint32_t G = 64 * w + 16 * (ut * MPT + mi) + n;
+    uint64_t xin[NSUB][4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t r = (8 * (e >> 1) + 2 * kb + (e & 1)) * 256 + G;
+#pragma unroll
+      for (int u = 0; u < NSUB; u++) xin[u][e] = src[u * 4096 + r];
+      if constexpr (X > 0) {
+        uint64_t yy[NSUB];
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) yy[u] = xin[u][e];
+        dif_butterflies<X>(yy, a.tw, r, 12, 0);
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) xin[u][e] = yy[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NSUB; u++) {
+      uint64_t y[4], tw[4];
+      dft16(xin[u], f, y);
+#pragma unroll
+      for (int q = 0; q < 4; q++) tw[q] = tab->tw256[(kb + 4 * q) * 256 + G];
+      gl::mul_n<4>(y, tw, y);
+#pragma unroll
+      for (int q = 0; q < 4; q++) buf[u * 4096 + swz12(br4(kb + 4 * q) * 256 + G)] = y[q];
+    }
+  }
+  __syncthreads();
+  // S = 256
+#pragma unroll 1
+  for (int s = 0; s < SPG; s++) {
+    uint64_t* sb = buf + (ut * SPG + s) * 4096;
+#pragma unroll 1
+    for (int m = 0; m < 4; m++) {
+      const uint32_t base = (4 * w + m) * 256 + n;
+      uint64_t x[4], y[4], tw[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = sb[swz12(base + (8 * (e >> 1) + 2 * kb + (e & 1)) * 16)];
+      dft16(x, f, y);
+#pragma unroll
+      for (int q = 0; q < 4; q++) tw[q] = tab->tw16[(kb + 4 * q) * 16 + n];
+      gl::mul_n<4>(y, tw, y);
+#pragma unroll
+      for (int q = 0; q < 4; q++) sb[swz12(base + br4(kb + 4 * q) * 16)] = y[q];
+    }
+  }
+  __syncthreads();
+  // S = 16 (no twiddle), then the 1/n of the inverse transform
+#pragma unroll 1
+  for (int s = 0; s < SPG; s++) {
+    uint64_t* sb = buf + (ut * SPG + s) * 4096;
+#pragma unroll 1
+    for (int m = 0; m < 4; m++) {
+      const uint32_t base = (64 * w + 16 * m + n) * 16;
+      uint64_t x[4], y[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = sb[swz12(base + 8 * (e >> 1) + 2 * kb + (e & 1))];
+      dft16(x, f, y);
+      if (a.out_scalar != 1) {
+        const uint64_t sc[4] = {a.out_scalar, a.out_scalar, a.out_scalar, a.out_scalar};
+        gl::mul_n<4>(y, sc, y);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) sb[swz12(base + br4(kb + 4 * q))] = y[q];
+    }
+  }
+  __syncthreads();
+  // coalesced store of the bit-reversed block
+#pragma unroll 1
+  for (int s = 0; s < SPG; s++) {
+    const uint32_t sub = (ut * SPG + s) * 4096;
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+      uint64_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[i] = buf[sub + swz12((i0 + i) * 256 + t)];
+      gl::canon_n<4>(v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[sub + (i0 + i) * 256 + t] = v[i];
+    }
+  }
+}
+
+// ---- decimation in time: bit-reversed -> natural, optional per-coset input scale (the coset LDE).  One workgroup =
+// one (column block, coset) on the XCD-aware 1-D grid of ntt16_dit_kernel (ntt.hip): id -> xcd = id % 8,
+// k = id / 8, coset = k % n_cosets, unit = (k / n_cosets) * 8 + xcd = column * blocks_per_column + block.
+// Input slot (chunk c, element eps) of lane kb is element kin = bitrev4(8c + 2kb + eps); output row a of lane ib is
+// j = bitrev4(ib + 4a) (the matrix is built that way, see build_tables).
+template <int X>
+__global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dit_kernel(Ntt16Args a, const Tables* __restrict__ tab) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  extern __shared__ uint64_t buf[];
+  constexpr int NSUB = 1 << X, NGRP = X ? 2 : 1, SPG = NSUB / NGRP, MPT = 4 / NGRP;
+  const uint32_t id = blockIdx.x, kk = id >> 3;
+  const uint32_t coset = kk % a.n_cosets, unit = (kk / a.n_cosets) * 8 + (id & 7);
+  if (unit >= a.n_units) return;  // padding of the last group of eight (whole workgroup leaves together)
+  const uint32_t log_bpc = a.log_n_total - (12 + X);
+  const uint32_t col = unit >> log_bpc, blk = unit & ((1u << log_bpc) - 1);
+  const uint32_t tid = threadIdx.x, ut = tid >> 8, t = tid & 255, lane = tid & 63, w = t >> 6, n = lane & 15,
+                 kb = lane >> 4;
+  Frag f;
+  load_frag(f, tab);
+  const uint64_t off = (uint64_t)blk << (12 + X);
+  const uint64_t* src = a.in + col * a.in_stride + off;
+  const uint64_t* sc = a.scale ? a.scale + ((uint64_t)coset << a.log_n_total) + off : nullptr;
+  uint64_t* dst = a.out + col * a.out_stride + coset * a.out_coset_stride + off;
+
+  // coalesced load (times the coset scale) into the swizzled LDS image
+#pragma unroll 1
+  for (int s = 0; s < SPG; s++) {
+    const uint32_t sub = (ut * SPG + s) * 4096;
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+      uint64_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[i] = src[sub + (i0 + i) * 256 + t];
+      if (sc) {
+        uint64_t s4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) s4[i] = sc[sub + (i0 + i) * 256 + t];
+        gl::mul_n<4>(v, s4, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) buf[sub + swz12((i0 + i) * 256 + t)] = v[i];
+    }
+  }
+  __syncthreads();
+  // S = 16 (no twiddle)
+#pragma unroll 1
+  for (int s = 0; s < SPG; s++) {
+    uint64_t* sb = buf + (ut * SPG + s) * 4096;
+#pragma unroll 1
+    for (int m = 0; m < 4; m++) {
+      const uint32_t base = (64 * w + 16 * m + n) * 16;
+      uint64_t x[4], y[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = sb[swz12(base + 8 * (e >> 1) + 2 * kb + (e & 1))];  // = base + bitrev4(kin)
+      dft16(x, f, y);
+#pragma unroll
+      for (int q = 0; q < 4; q++) sb[swz12(base + br4(kb + 4 * q))] = y[q];                   // = base + j
+    }
+  }
+  __syncthreads();
+  // S = 256: twiddle w_256^(i kin) first
+#pragma unroll 1
+  for (int s = 0; s < SPG; s++) {
+    uint64_t* sb = buf + (ut * SPG + s) * 4096;
+#pragma unroll 1
+    for (int m = 0; m < 4; m++) {
+      const uint32_t base = (4 * w + m) * 256 + n;
+      uint64_t x[4], y[4], tw[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint32_t slot = 8 * (e >> 1) + 2 * kb + (e & 1);
+        x[e] = sb[swz12(base + slot * 16)];
+        tw[e] = tab->tw16[br4(slot) * 16 + n];
+      }
+      gl::mul_n<4>(x, tw, x);
+      dft16(x, f, y);
+#pragma unroll
+      for (int q = 0; q < 4; q++) sb[swz12(base + br4(kb + 4 * q) * 16)] = y[q];
+    }
+  }
+  __syncthreads();
+  // S = 4096 with the twiddle w_4096^(i kin) first, then the X radix-2 stages that join the sub-blocks, straight
+  // to global memory
+#pragma unroll 1
+  for (int mi = 0; mi < MPT; mi++) {
+    const uint32_t G = 64 * w + 16 * (ut * MPT + mi) + n;
+    uint64_t yo[NSUB][4];
+#pragma unroll
+    for (int u = 0; u < NSUB; u++) {
+      uint64_t x[4], tw[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint32_t slot = 8 * (e >> 1) + 2 * kb + (e & 1);
+        x[e] = buf[u * 4096 + swz12(slot * 256 + G)];
+        tw[e] = tab->tw256[br4(slot) * 256 + G];
+      }
+      gl::mul_n<4>(x, tw, x);
+      dft16(x, f, yo[u]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t r = br4(kb + 4 * q) * 256 + G;
+      if constexpr (X > 0) {
+        uint64_t yy[NSUB];
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) yy[u] = yo[u][q];
+        dit_butterflies<X>(yy, a.tw, r, 12, 0);
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) dst[u * 4096 + r] = gl::canon(yy[u]);
+      } else {
+        dst[r] = gl::canon(yo[0][q]);
+      }
+    }
+  }
+}
+
+// ---- host side: the constants of one (kind, direction) --------------------------------------------------------------
+// kind 0 (DIF): column (c, kb, eps) is input j = 8c + 2kb + eps, row (ib, a) is output k = ib + 4a.
+// kind 1 (DIT): column is input kin = bitrev4(8c + 2kb + eps), row is output j = bitrev4(ib + 4a).
+inline void digits8(uint64_t wv, int (&d)[8]) {  // balanced base-256 digits of wv or wv - p, whichever fits eight
+  const unsigned __int128 lim = (unsigned __int128)127 * 0xFFFFFFFFFFFFFFFFULL / 255;
+  __int128 v = wv <= (uint64_t)lim ? (__int128)wv : (__int128)wv - (__int128)gl::P;
+  for (int q = 0; q < 8; q++) {
+    int x = (int)(((v + 128) % 256 + 256) % 256) - 128;
+    d[q] = x;
+    v = (v - x) / 256;   // exact: v - x is a multiple of 256
+  }
+}
+inline void build_tables(Tables& t, int kind, bool inverse) {
+  uint64_t w4096 = gl::root(12);
+  if (inverse) w4096 = gl::inv(w4096);
+  const uint64_t w256 = gl::pow(w4096, 16), w16 = gl::pow(w4096, 256);
+  auto in_index = [&](int slot) { return kind ? (int)br4((uint32_t)slot) : slot; };
+  auto out_index = [&](int row) { return kind ? (int)br4((uint32_t)row) : row; };
+  // bias: 2^22 + dd[q] per plane with sum_q (2^22 + dd[q]) 2^(8q) = 0 (mod p)
+  unsigned __int128 base = 0;
+  for (int q = 0; q < 8; q++) base += (unsigned __int128)(1u << 22) << (8 * q);
+  const uint64_t delta = (uint64_t)(((unsigned __int128)gl::P - base % gl::P) % gl::P);
+  static int dig[16][16][8][8];  // [out][in][p][q]
+  for (int o = 0; o < 16; o++)
+    for (int i = 0; i < 16; i++)
+      for (int p = 0; p < 8; p++) {
+        const uint64_t wv = gl::mulc(gl::pow(w16, (uint64_t)(o * i)), gl::canon((uint64_t)1 << (8 * p)));
+        digits8(wv, dig[o][i][p]);
+      }
+  uint8_t* ab = reinterpret_cast<uint8_t*>(t.a);
+  for (int rb = 0; rb < 8; rb++) {
+    const int a = rb >> 1, h = rb & 1;
+    for (int ch = 0; ch < 2; ch++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int r = lane & 15, kb = lane >> 4, o = out_index((r >> 2) + 4 * a), q = 4 * h + (r & 3);
+        for (int b = 0; b < 16; b++) {
+          const int i = in_index(8 * ch + 2 * kb + (b >> 3)), p = b & 7;
+          ab[((rb * 2 + ch) * 64 + lane) * 16 + b] = (uint8_t)(int8_t)dig[o][i][p][q];
+        }
+      }
+    for (int ib = 0; ib < 4; ib++)
+      for (int reg = 0; reg < 4; reg++) {
+        const int o = out_index(ib + 4 * a), q = 4 * h + reg;
+        int sum = 0;
+        for (int i = 0; i < 16; i++)
+          for (int p = 0; p < 8; p++) sum += dig[o][i][p][q];
+        t.c[(rb * 4 + ib) * 4 + reg] = (uint32_t)((1 << 22) + (int)((delta >> (8 * q)) & 0xFF) + 128 * sum);
+      }
+  }
+  for (int k = 0; k < 16; k++) {
+    for (int i = 0; i < 256; i++) t.tw256[k * 256 + i] = gl::pow(w4096, (uint64_t)(i * k));
+    for (int i = 0; i < 16; i++) t.tw16[k * 16 + i] = gl::pow(w256, (uint64_t)(i * k));
+  }
+}
+
+}  // namespace mxn

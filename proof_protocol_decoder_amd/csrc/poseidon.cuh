@@ -8,6 +8,7 @@
 // Integer-ALU bound: no HBM-roofline claim is made for these kernels.
 #pragma once
 #include "gl.hpp"
+#include "mx_arith.cuh"
 
 namespace poseidon {
 
@@ -45,31 +46,7 @@ __device__ __forceinline__ void sbox_all(uint64_t (&s)[12]) {
   }
 }
 
-// N accumulator pairs (L + H*2^32 < 2^74, L and H below 2^42) -> reduced words, carry-chain form in 4 instructions:
-// H = h0 + h1*2^32 with h1 < 2^10, so L + H*2^32 = (L + h1*EPS) + h0*2^32 (mod p).  X = L + h1*EPS < 2^43 needs
-// no carry; adding h0 to X's high word can carry once (c, weight 2^64 = EPS = 2^32 - 1): the result is
-// (lo - c) + (hi + c)*2^32, where lo - c borrows (b) only if lo = 0 and then gives the 2^32 back: hi + (c & ~b).
-// hi is below 2^11 whenever c is set, so nothing carries further.  The mask c & ~b is a scalar instruction.
-template <int N>
-__device__ __forceinline__ void reduce_rows(const uint64_t (&L)[N], const uint64_t (&H)[N], uint64_t (&out)[N]) {
-  uint32_t l0[N], l1[N], h0[N], h1[N];
-  uint64_t T[N];
-  gl::cc::mask c1[N], b[N];
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    T[i] = L[i]; h0[i] = (uint32_t)H[i]; h1[i] = (uint32_t)(H[i] >> 32);
-  }
-  gl::cc::mad_eps_cv(T, h1);      // X = L + h1*EPS (no carry: both below 2^42)
-#pragma unroll
-  for (int i = 0; i < N; i++) { l0[i] = (uint32_t)T[i]; l1[i] = (uint32_t)(T[i] >> 32); }
-  gl::cc::add_co(l1, c1, h0);
-  gl::cc::subb0_co(l0, b, c1);
-#pragma unroll
-  for (int i = 0; i < N; i++) c1[i] &= ~b[i];
-  gl::cc::addc0_cv(l1, c1);
-#pragma unroll
-  for (int i = 0; i < N; i++) out[i] = gl::cc::mk64(l0[i], l1[i]);
-}
+using mxa::reduce_rows;  // mx_arith.cuh: (L, H) accumulator pairs -> reduced words
 
 // MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...).  Entries are < 2^6, so the
 // 32-bit halves of the state are accumulated separately in 64 bits (no overflow: 12*41*2^32 plus a

@@ -33,7 +33,7 @@
 namespace poseidon {
 namespace mx {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
+using mxa::v4i;
 
 constexpr int CIN_PER_ROUND = 4 * 24;            // [ib][2g + h][reg]
 constexpr int CIN_WORDS = 30 * CIN_PER_ROUND;    // 11,520 bytes of LDS
@@ -94,14 +94,7 @@ __device__ __forceinline__ Ctx make_ctx(const uint32_t* cin_lds) {
   return c;
 }
 
-// four plane sums (each < 2^17) -> a0 + a1*2^8 + a2*2^16 + a3*2^24 < 2^42: two shift-adds and one multiply-add (the
-// compiler's own rendering of the 64-bit shift and add is five to six instructions)
-__device__ __forceinline__ uint64_t planes(const v4i& d) {
-  const uint32_t e = (uint32_t)d[0] + ((uint32_t)d[1] << 8), f = (uint32_t)d[2] + ((uint32_t)d[3] << 8);
-  uint64_t r;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(f), "s"(65536u), "v"((uint64_t)e) : "vcc");
-  return r;
-}
+using mxa::planes;  // four plane sums -> a0 + a1*2^8 + a2*2^16 + a3*2^24
 
 // MDS layer (+ next round's constants) of every set
 template <int NS>

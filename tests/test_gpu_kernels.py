@@ -7,10 +7,18 @@ from util import (P, bitrev_perm, coset_major_to_natural, rand_field, to_dev, to
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("log_n,n_cols", [(0, 3), (1, 2), (2, 5), (3, 4), (5, 7), (9, 16), (12, 9), (14, 5),
+@pytest.fixture(params=["mx", "valu"])
+def ntt_form(request, bpg):
+    """2^12..2^14-point blocks: 16-point DFTs on the matrix cores (ntt_mx.cuh) / VALU butterflies"""
+    bpg.lib().bp_tune_ntt_mx(1 if request.param == "mx" else 0)
+    yield request.param
+    bpg.lib().bp_tune_ntt_mx(1)
+
+
+@pytest.mark.parametrize("log_n,n_cols", [(0, 3), (1, 2), (2, 5), (3, 4), (5, 7), (9, 16), (12, 9), (13, 3), (14, 5),
                                           (15, 3), (16, 2), (17, 2), (18, 2), (19, 1), (20, 2), (21, 1), (22, 1),
                                           (23, 1)])
-def test_ntt_matches_oracle(bpg, oracle, log_n, n_cols):
+def test_ntt_matches_oracle(bpg, oracle, log_n, n_cols, ntt_form):
     rng = np.random.default_rng(100 + log_n)
     n = 1 << log_n
     vals = rand_field(rng, (n_cols, n))
@@ -37,7 +45,7 @@ def test_ntt_matches_oracle(bpg, oracle, log_n, n_cols):
 @pytest.mark.parametrize("log_n,rate_bits,n_cols", [(3, 1, 2), (6, 1, 5), (9, 1, 16), (12, 3, 7), (14, 1, 4),
                                                     (13, 3, 3), (16, 1, 2), (17, 1, 1), (18, 1, 2), (19, 2, 1), (20, 1, 1),
                                                     (21, 1, 1)])
-def test_lde_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols):
+def test_lde_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, ntt_form):
     rng = np.random.default_rng(200 + log_n)
     vals = rand_field(rng, (n_cols, 1 << log_n))
     want_coeffs, want_lde = oracle.lde_batch(vals, rate_bits)
