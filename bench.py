@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
     ap.add_argument("--merkle-fused", type=int, default=None, help="0: one launch per Merkle level")
     ap.add_argument("--ntt-split", type=int, default=None, help="bp_tune_ntt_split mode (measurement knob)")
+    ap.add_argument("--ntt-mx", type=int, default=None, help="bp_tune_ntt_mx mode (measurement knob)")
+    ap.add_argument("--poseidon-mx", type=int, default=None, help="bp_tune_poseidon_mx (measurement knob)")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
                     help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
     args = ap.parse_args()
@@ -110,6 +112,10 @@ def main():
         L.bp_tune_quad_threshold(1 << args.quad_threshold_log2)
     if args.ntt_split is not None:
         L.bp_tune_ntt_split(args.ntt_split)
+    if args.ntt_mx is not None:
+        L.bp_tune_ntt_mx(args.ntt_mx)
+    if args.poseidon_mx is not None:
+        L.bp_tune_poseidon_mx(args.poseidon_mx)
 
     def read_family(note, leg=True):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()

@@ -118,9 +118,13 @@ void bp_tune_poseidon_mx_sets(int sets);
  * block with TWO workgroups that each do half of the stage coupling its halves while loading (csrc/ntt.hip).
  * Results are identical either way. */
 void bp_tune_ntt_split(int mode);
-/* 1 (default): 2^12..2^14-point NTT blocks run as three radix-16 passes whose 16-point DFTs are int8 MFMAs on the
- * bytes of the elements (csrc/ntt_mx.cuh); 0: the VALU butterfly kernels.  Results are identical either way. */
-void bp_tune_ntt_mx(int on);
+/* NTT blocks as three radix-16 passes whose 16-point DFTs are int8 MFMAs on the bytes of the elements
+ * (csrc/ntt_mx.cuh): 0 (default) = off, the VALU butterfly kernels everywhere; 1 = 2^12- and 2^13-point blocks;
+ * 2 = 2^14-point blocks too.  Alone on the chip the form is level to +17 %, under the multi-stream block run its
+ * register footprint loses 12 %, hence opt-in.  Results are identical either way. */
+void bp_tune_ntt_mx(int mode);
+/* Measurement knob: resident workgroups per CU of the (persistent) matrix-core NTT kernels; 0 = default. */
+void bp_tune_ntt_mx_wg_per_cu(int n);
 
 /* K3.  Poseidon-Goldilocks permutation (width 12) on n states of 12 words, in place. */
 int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream);

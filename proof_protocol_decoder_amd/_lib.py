@@ -74,6 +74,8 @@ def lib():
     L.bp_tune_quad_threshold.restype = None
     L.bp_tune_ntt_mx.argtypes = [i]
     L.bp_tune_ntt_mx.restype = None
+    L.bp_tune_ntt_mx_wg_per_cu.argtypes = [i]
+    L.bp_tune_ntt_mx_wg_per_cu.restype = None
     L.bp_tune_poseidon_mx.argtypes = [i]
     L.bp_tune_poseidon_mx.restype = None
     L.bp_tune_poseidon_mx_sets.argtypes = [i]

@@ -800,9 +800,35 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
 }
 
 // Constants of the matrix-core kernels (ntt_mx.cuh), one device image per (device, kind, direction), built once.
-static std::atomic<int> g_ntt_mx{1};  // 1: 2^12..2^14-point blocks on the matrix cores, 0: the VALU kernels
+// 0 (default): the VALU kernels; 1: 2^12- and 2^13-point blocks on the matrix cores; 2: 2^14-point blocks too.
+// Measured (tools/ntt_mx_probe.py, profiles/r2_ntt_mx_probe.txt): alone on the chip the matrix-core form is level at
+// 2^12 points (+2..3 %), ahead at 2^13 x 135 rate 8 (+7 % LDE, +17 % inverse transform) and behind at 2^14 (it spills:
+// -25 %); it issues half the VALU instructions but holds 224-240 VGPRs (96 of them MFMA constants), i.e. two waves
+// per SIMD, and is latency-bound there.  Under the 24-stream block run that register footprint costs more than the
+// instructions save: 29.8 against 34.1 txn-proofs/s (bench.py --ntt-mx 1 / 0) -- its waves crowd out the Poseidon
+// kernels' waves.  So it stays an opt-in form.
+static std::atomic<int> g_ntt_mx{0};
+static bool use_ntt_mx(uint32_t log_blk) {
+  const int m = g_ntt_mx.load(std::memory_order_relaxed);
+  return m == 2 || (m == 1 && log_blk <= 13);
+}
 static std::mutex g_mx_mu;
 static std::map<std::tuple<int, int, int>, mxn::Tables*> g_mx_tabs;
+// Persistent grid of the matrix-core kernels: every workgroup loads the 24 KB of MFMA constants once and then walks
+// over its share of the work items, so the grid is what is resident at once (a multiple of 8: the XCD-aware id
+// mapping of the DIT kernel needs id mod 8 to stay fixed along a workgroup's walk).
+static std::atomic<int> g_mx_wg_per_cu{0};  // 0 = default (2 for 2^12-point blocks, 1 above)
+static uint32_t mx_grid(uint32_t items, uint32_t log_blk) {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  int per = g_mx_wg_per_cu.load(std::memory_order_relaxed);
+  if (per <= 0) per = log_blk == 12 ? 2 : 1;
+  const uint32_t resident = ((uint32_t)cus * per + 7) / 8 * 8;
+  return items < resident ? items : resident;
+}
 static int get_mx_tables(int kind, bool inverse, const mxn::Tables** out) {
   int dev = 0;
   BPG_HIP(hipGetDevice(&dev));
@@ -934,13 +960,14 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
     b.tw = tw_b; b.scale = nullptr; b.out_scalar = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
     b.log_n_total = log_n; b.n_cosets = 1; b.n_units = 0;
     KernelTimer kt(PROF_INTT_DIF, st, 16.0 * (double)n_cols * (double)((uint64_t)1 << log_n));
-    if (g_ntt_mx.load(std::memory_order_relaxed)) {
+    if (use_ntt_mx(log_blk)) {
       const mxn::Tables* tab = nullptr;
       if ((rc = get_mx_tables(0, inverse, &tab))) return rc;
-      const dim3 grid16(1u << (log_n - log_blk), n_cols);
-      if (log_blk == 12) mxn::ntt_mx_dif_kernel<0><<<grid16, 256, 8u << 12, st>>>(b, tab);
-      else if (log_blk == 13) mxn::ntt_mx_dif_kernel<1><<<grid16, 512, 8u << 13, st>>>(b, tab);
-      else mxn::ntt_mx_dif_kernel<2><<<grid16, 512, 8u << 14, st>>>(b, tab);
+      b.n_units = n_cols << (log_n - log_blk);
+      const uint32_t g = mx_grid(b.n_units, log_blk);
+      if (log_blk == 12) mxn::ntt_mx_dif_kernel<0><<<g, 256, 8u << 12, st>>>(b, tab);
+      else if (log_blk == 13) mxn::ntt_mx_dif_kernel<1><<<g, 512, 8u << 13, st>>>(b, tab);
+      else mxn::ntt_mx_dif_kernel<2><<<g, 512, 8u << 14, st>>>(b, tab);
     } else if (use_split(log_blk, (uint64_t)n_cols << (log_n - log_blk), src, out, false)) {
       // two workgroups of the next smaller kernel per block (see Ntt16Args)
       if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
@@ -990,13 +1017,13 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
     b.n_units = n_cols << (log_n - log_blk);
     {
       KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
-      if (g_ntt_mx.load(std::memory_order_relaxed)) {
+      if (use_ntt_mx(log_blk)) {
         const mxn::Tables* tab = nullptr;
         if ((rc = get_mx_tables(1, inverse, &tab))) return rc;
-        const dim3 grid16((b.n_units + 7) / 8 * 8 * n_cosets);
-        if (log_blk == 12) mxn::ntt_mx_dit_kernel<0><<<grid16, 256, 8u << 12, st>>>(b, tab);
-        else if (log_blk == 13) mxn::ntt_mx_dit_kernel<1><<<grid16, 512, 8u << 13, st>>>(b, tab);
-        else mxn::ntt_mx_dit_kernel<2><<<grid16, 512, 8u << 14, st>>>(b, tab);
+        const uint32_t g = mx_grid((b.n_units + 7) / 8 * 8 * n_cosets, log_blk);
+        if (log_blk == 12) mxn::ntt_mx_dit_kernel<0><<<g, 256, 8u << 12, st>>>(b, tab);
+        else if (log_blk == 13) mxn::ntt_mx_dit_kernel<1><<<g, 512, 8u << 13, st>>>(b, tab);
+        else mxn::ntt_mx_dit_kernel<2><<<g, 512, 8u << 14, st>>>(b, tab);
       } else if (use_split(log_blk, (uint64_t)b.n_units * n_cosets, in, out, true)) {
         if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
         b.tw_top = tw_b;
@@ -1080,7 +1107,8 @@ int init_ntt_kernels() {
 extern "C" {
 
 void bp_tune_ntt_split(int mode) { bpg::g_ntt_split.store(mode); }
-void bp_tune_ntt_mx(int on) { bpg::g_ntt_mx.store(on != 0); }
+void bp_tune_ntt_mx(int mode) { bpg::g_ntt_mx.store(mode < 0 || mode > 2 ? 0 : mode); }
+void bp_tune_ntt_mx_wg_per_cu(int n) { bpg::g_mx_wg_per_cu.store(n); }
 
 int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir, void* stream) try {
   if (n_cols == 0) return BP_OK;

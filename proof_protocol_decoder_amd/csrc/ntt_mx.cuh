@@ -89,111 +89,149 @@ __device__ __forceinline__ void dft16(const uint64_t (&x)[4], const Frag& f, uin
   mxa::reduce_rows<4>(L, H, y);
 }
 
+// LDS addresses.  swz12 is linear over GF(2), and in every pass the set index m occupies position bits no other term
+// touches, so address(m) = (lane constant) ^ swz12(m's bits): the lane constants are made once per pass.
+__device__ __forceinline__ uint32_t mterm_hi(uint32_t m) { return (m << 8) ^ ((m & 2u) << 3); }   // swz12(m << 8)
+__device__ __forceinline__ uint32_t mterm_lo(uint32_t m) { return (m << 4) ^ m; }                 // swz12(m << 4)
+#define MXN_SLOT(e) (8u * ((e) >> 1) + 2u * kb + ((e) & 1u))   /* input slot of element e of this lane */
+#define MXN_ROW(q) br4(kb + 4u * (q))                           /* bit-reversed output row q of this lane */
+
 // ---- decimation in frequency: natural -> bit-reversed.  X = log2(sub-blocks of 4096): block = 4096 << X points.
-// grid = (blocks per column, columns); 256 threads (X = 0) or 512 (two groups of 256).
+// 1-D grid of persistent workgroups: workgroup g takes units g, g + gridDim.x, ... (unit = column * blocks per column +
+// block; a.n_units of them); 256 threads (X = 0) or 512 (two groups of 256).
 template <int X>
 __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, const Tables* __restrict__ tab) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr int NSUB = 1 << X, NGRP = X ? 2 : 1, SPG = NSUB / NGRP;  // sub-blocks, thread groups, sub-blocks per group
   constexpr int MPT = 4 / NGRP;                                      // sets of the outermost pass per thread
   const uint32_t tid = threadIdx.x, ut = tid >> 8, t = tid & 255, lane = tid & 63, w = t >> 6, n = lane & 15,
                  kb = lane >> 4;
   Frag f;
-  load_frag(f, tab);
-  const uint64_t off = (uint64_t)blockIdx.x << (12 + X);
-  const uint64_t* src = a.in + blockIdx.y * a.in_stride + off;
-  uint64_t* dst = a.out + blockIdx.y * a.out_stride + off;
+  load_frag(f, tab);   // 24 x 16 bytes per lane: loaded once, the workgroup then walks over its share of the blocks
+  const uint32_t log_bpc = a.log_n_total - (12 + X);  // blocks per column
+#pragma unroll 1
+  for (uint32_t unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+    const uint64_t off = (uint64_t)(unit & ((1u << log_bpc) - 1)) << (12 + X);
+    const uint64_t* src = a.in + (unit >> log_bpc) * a.in_stride + off;
+    uint64_t* dst = a.out + (unit >> log_bpc) * a.out_stride + off;
 
-  // outermost pass (S = 4096 inside every sub-block) straight from global memory, after the X radix-2 stages
-  // that couple the sub-blocks
-#pragma unroll 1
-  for (int mi = 0; mi < MPT; mi++) {
-    const uint32_t G = 64 * w + 16 * (ut * MPT + mi) + n;
-    uint64_t xin[NSUB][4];
+    // outermost pass (S = 4096 inside every sub-block) straight from global memory, after the X radix-2 stages
+    // that couple the sub-blocks
+    {
+      uint32_t wr[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const uint32_t r = (8 * (e >> 1) + 2 * kb + (e & 1)) * 256 + G;
+      for (int q = 0; q < 4; q++) wr[q] = swz12((MXN_ROW(q) << 8) | (w << 6) | n);
+#pragma unroll 2
+      for (int mi = 0; mi < MPT; mi++) {
+        const uint32_t ms = ut * MPT + mi, G = 64 * w + 16 * ms + n, mt = mterm_lo(ms);
+        uint64_t xin[NSUB][4];
 #pragma unroll
-      for (int u = 0; u < NSUB; u++) xin[u][e] = src[u * 4096 + r];
-      if constexpr (X > 0) {
-        uint64_t yy[NSUB];
+        for (int e = 0; e < 4; e++) {
+          const uint32_t r = MXN_SLOT(e) * 256 + G;
 #pragma unroll
-        for (int u = 0; u < NSUB; u++) yy[u] = xin[u][e];
-        dif_butterflies<X>(yy, a.tw, r, 12, 0);
+          for (int u = 0; u < NSUB; u++) xin[u][e] = src[u * 4096 + r];
+          if constexpr (X > 0) {
+            uint64_t yy[NSUB];
 #pragma unroll
-        for (int u = 0; u < NSUB; u++) xin[u][e] = yy[u];
+            for (int u = 0; u < NSUB; u++) yy[u] = xin[u][e];
+            dif_butterflies<X>(yy, a.tw, r, 12, 0);
+#pragma unroll
+            for (int u = 0; u < NSUB; u++) xin[u][e] = yy[u];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) {
+          uint64_t y[4], tw[4];
+          dft16(xin[u], f, y);
+#pragma unroll
+          for (int q = 0; q < 4; q++) tw[q] = tab->tw256[(kb + 4 * q) * 256 + G];
+          gl::mul_n<4>(y, tw, y);
+#pragma unroll
+          for (int q = 0; q < 4; q++) buf[u * 4096 + (wr[q] ^ mt)] = y[q];
+        }
       }
     }
+    __syncthreads();
+    // S = 256
+    {
+      uint32_t rd[4], wr[4];
 #pragma unroll
-    for (int u = 0; u < NSUB; u++) {
-      uint64_t y[4], tw[4];
-      dft16(xin[u], f, y);
-#pragma unroll
-      for (int q = 0; q < 4; q++) tw[q] = tab->tw256[(kb + 4 * q) * 256 + G];
-      gl::mul_n<4>(y, tw, y);
-#pragma unroll
-      for (int q = 0; q < 4; q++) buf[u * 4096 + swz12(br4(kb + 4 * q) * 256 + G)] = y[q];
-    }
-  }
-  __syncthreads();
-  // S = 256
-#pragma unroll 1
-  for (int s = 0; s < SPG; s++) {
-    uint64_t* sb = buf + (ut * SPG + s) * 4096;
-#pragma unroll 1
-    for (int m = 0; m < 4; m++) {
-      const uint32_t base = (4 * w + m) * 256 + n;
-      uint64_t x[4], y[4], tw[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) x[e] = sb[swz12(base + (8 * (e >> 1) + 2 * kb + (e & 1)) * 16)];
-      dft16(x, f, y);
-#pragma unroll
-      for (int q = 0; q < 4; q++) tw[q] = tab->tw16[(kb + 4 * q) * 16 + n];
-      gl::mul_n<4>(y, tw, y);
-#pragma unroll
-      for (int q = 0; q < 4; q++) sb[swz12(base + br4(kb + 4 * q) * 16)] = y[q];
-    }
-  }
-  __syncthreads();
-  // S = 16 (no twiddle), then the 1/n of the inverse transform
-#pragma unroll 1
-  for (int s = 0; s < SPG; s++) {
-    uint64_t* sb = buf + (ut * SPG + s) * 4096;
-#pragma unroll 1
-    for (int m = 0; m < 4; m++) {
-      const uint32_t base = (64 * w + 16 * m + n) * 16;
-      uint64_t x[4], y[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) x[e] = sb[swz12(base + 8 * (e >> 1) + 2 * kb + (e & 1))];
-      dft16(x, f, y);
-      if (a.out_scalar != 1) {
-        const uint64_t sc[4] = {a.out_scalar, a.out_scalar, a.out_scalar, a.out_scalar};
-        gl::mul_n<4>(y, sc, y);
+      for (int e = 0; e < 4; e++) {
+        rd[e] = swz12((w << 10) | (MXN_SLOT(e) << 4) | n);
+        wr[e] = swz12((w << 10) | (MXN_ROW(e) << 4) | n);
       }
+      uint64_t twv[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) sb[swz12(base + br4(kb + 4 * q))] = y[q];
-    }
-  }
-  __syncthreads();
-  // coalesced store of the bit-reversed block
+      for (int q = 0; q < 4; q++) twv[q] = tab->tw16[(kb + 4 * q) * 16 + n];
 #pragma unroll 1
-  for (int s = 0; s < SPG; s++) {
-    const uint32_t sub = (ut * SPG + s) * 4096;
+      for (int s = 0; s < SPG; s++) {
+        uint64_t* sb = buf + (ut * SPG + s) * 4096;
+#pragma unroll 2
+        for (int m = 0; m < 4; m++) {
+          const uint32_t mt = mterm_hi(m);
+          uint64_t x[4], y[4];
 #pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += 4) {
-      uint64_t v[4];
+          for (int e = 0; e < 4; e++) x[e] = sb[rd[e] ^ mt];
+          dft16(x, f, y);
+          gl::mul_n<4>(y, twv, y);
 #pragma unroll
-      for (int i = 0; i < 4; i++) v[i] = buf[sub + swz12((i0 + i) * 256 + t)];
-      gl::canon_n<4>(v);
-#pragma unroll
-      for (int i = 0; i < 4; i++) dst[sub + (i0 + i) * 256 + t] = v[i];
+          for (int q = 0; q < 4; q++) sb[wr[q] ^ mt] = y[q];
+        }
+      }
     }
+    __syncthreads();
+    // S = 16 (no twiddle), then the 1/n of the inverse transform
+    {
+      uint32_t rd[4], wr[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        rd[e] = swz12((w << 10) | (n << 4) | MXN_SLOT(e));
+        wr[e] = swz12((w << 10) | (n << 4) | MXN_ROW(e));
+      }
+#pragma unroll 1
+      for (int s = 0; s < SPG; s++) {
+        uint64_t* sb = buf + (ut * SPG + s) * 4096;
+#pragma unroll 2
+        for (int m = 0; m < 4; m++) {
+          const uint32_t mt = mterm_hi(m);
+          uint64_t x[4], y[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) x[e] = sb[rd[e] ^ mt];
+          dft16(x, f, y);
+          if (a.out_scalar != 1) {
+            const uint64_t sc[4] = {a.out_scalar, a.out_scalar, a.out_scalar, a.out_scalar};
+            gl::mul_n<4>(y, sc, y);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) sb[wr[q] ^ mt] = y[q];
+        }
+      }
+    }
+    __syncthreads();
+    // coalesced store of the bit-reversed block
+    {
+      const uint32_t st0 = swz12(t);
+#pragma unroll 1
+      for (int s = 0; s < SPG; s++) {
+        const uint32_t sub = (ut * SPG + s) * 4096;
+#pragma unroll
+        for (int i0 = 0; i0 < 16; i0 += 4) {
+          uint64_t v[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[i] = buf[sub + (st0 ^ swz12((uint32_t)(i0 + i) << 8))];
+          gl::canon_n<4>(v);
+#pragma unroll
+          for (int i = 0; i < 4; i++) dst[sub + (i0 + i) * 256 + t] = v[i];
+        }
+      }
+    }
+    __syncthreads();  // the LDS image is reused by the next block
   }
 }
 
-// ---- decimation in time: bit-reversed -> natural, optional per-coset input scale (the coset LDE).  One workgroup =
-// one (column block, coset) on the XCD-aware 1-D grid of ntt16_dit_kernel (ntt.hip): id -> xcd = id % 8,
+// ---- decimation in time: bit-reversed -> natural, optional per-coset input scale (the coset LDE).  One work item =
+// one (column block, coset) in the XCD-aware id order of ntt16_dit_kernel (ntt.hip): id -> xcd = id % 8,
 // k = id / 8, coset = k % n_cosets, unit = (k / n_cosets) * 8 + xcd = column * blocks_per_column + block.
 // Input slot (chunk c, element eps) of lane kb is element kin = bitrev4(8c + 2kb + eps); output row a of lane ib is
 // j = bitrev4(ib + 4a) (the matrix is built that way, see build_tables).
@@ -202,111 +240,138 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dit_kernel(Ntt16Args a, 
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr int NSUB = 1 << X, NGRP = X ? 2 : 1, SPG = NSUB / NGRP, MPT = 4 / NGRP;
-  const uint32_t id = blockIdx.x, kk = id >> 3;
-  const uint32_t coset = kk % a.n_cosets, unit = (kk / a.n_cosets) * 8 + (id & 7);
-  if (unit >= a.n_units) return;  // padding of the last group of eight (whole workgroup leaves together)
-  const uint32_t log_bpc = a.log_n_total - (12 + X);
-  const uint32_t col = unit >> log_bpc, blk = unit & ((1u << log_bpc) - 1);
   const uint32_t tid = threadIdx.x, ut = tid >> 8, t = tid & 255, lane = tid & 63, w = t >> 6, n = lane & 15,
                  kb = lane >> 4;
   Frag f;
-  load_frag(f, tab);
-  const uint64_t off = (uint64_t)blk << (12 + X);
-  const uint64_t* src = a.in + col * a.in_stride + off;
-  const uint64_t* sc = a.scale ? a.scale + ((uint64_t)coset << a.log_n_total) + off : nullptr;
-  uint64_t* dst = a.out + col * a.out_stride + coset * a.out_coset_stride + off;
+  load_frag(f, tab);   // loaded once; the workgroup then walks over ids blockIdx.x, + gridDim.x (a multiple of 8), ...
+  const uint32_t log_bpc = a.log_n_total - (12 + X);
+  const uint32_t n_ids = (a.n_units + 7) / 8 * 8 * a.n_cosets;
+#pragma unroll 1
+  for (uint32_t id = blockIdx.x; id < n_ids; id += gridDim.x) {
+    const uint32_t kk = id >> 3;
+    const uint32_t coset = kk % a.n_cosets, unit = (kk / a.n_cosets) * 8 + (id & 7);
+    if (unit >= a.n_units) continue;  // padding of the last group of eight (whole workgroup skips together)
+    const uint32_t col = unit >> log_bpc, blk = unit & ((1u << log_bpc) - 1);
+    const uint64_t off = (uint64_t)blk << (12 + X);
+    const uint64_t* src = a.in + col * a.in_stride + off;
+    const uint64_t* sc = a.scale ? a.scale + ((uint64_t)coset << a.log_n_total) + off : nullptr;
+    uint64_t* dst = a.out + col * a.out_stride + coset * a.out_coset_stride + off;
 
-  // coalesced load (times the coset scale) into the swizzled LDS image
+    // coalesced load (times the coset scale) into the swizzled LDS image
+    {
+      const uint32_t st0 = swz12(t);
 #pragma unroll 1
-  for (int s = 0; s < SPG; s++) {
-    const uint32_t sub = (ut * SPG + s) * 4096;
+      for (int s = 0; s < SPG; s++) {
+        const uint32_t sub = (ut * SPG + s) * 4096;
 #pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += 4) {
-      uint64_t v[4];
+        for (int i0 = 0; i0 < 16; i0 += 4) {
+          uint64_t v[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) v[i] = src[sub + (i0 + i) * 256 + t];
-      if (sc) {
-        uint64_t s4[4];
+          for (int i = 0; i < 4; i++) v[i] = src[sub + (i0 + i) * 256 + t];
+          if (sc) {
+            uint64_t s4[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) s4[i] = sc[sub + (i0 + i) * 256 + t];
-        gl::mul_n<4>(v, s4, v);
+            for (int i = 0; i < 4; i++) s4[i] = sc[sub + (i0 + i) * 256 + t];
+            gl::mul_n<4>(v, s4, v);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) buf[sub + (st0 ^ swz12((uint32_t)(i0 + i) << 8))] = v[i];
+        }
       }
-#pragma unroll
-      for (int i = 0; i < 4; i++) buf[sub + swz12((i0 + i) * 256 + t)] = v[i];
     }
-  }
-  __syncthreads();
-  // S = 16 (no twiddle)
-#pragma unroll 1
-  for (int s = 0; s < SPG; s++) {
-    uint64_t* sb = buf + (ut * SPG + s) * 4096;
-#pragma unroll 1
-    for (int m = 0; m < 4; m++) {
-      const uint32_t base = (64 * w + 16 * m + n) * 16;
-      uint64_t x[4], y[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) x[e] = sb[swz12(base + 8 * (e >> 1) + 2 * kb + (e & 1))];  // = base + bitrev4(kin)
-      dft16(x, f, y);
-#pragma unroll
-      for (int q = 0; q < 4; q++) sb[swz12(base + br4(kb + 4 * q))] = y[q];                   // = base + j
-    }
-  }
-  __syncthreads();
-  // S = 256: twiddle w_256^(i kin) first
-#pragma unroll 1
-  for (int s = 0; s < SPG; s++) {
-    uint64_t* sb = buf + (ut * SPG + s) * 4096;
-#pragma unroll 1
-    for (int m = 0; m < 4; m++) {
-      const uint32_t base = (4 * w + m) * 256 + n;
-      uint64_t x[4], y[4], tw[4];
+    __syncthreads();
+    // S = 16 (no twiddle): slot e sits at base + bitrev4(kin) = base + slot, row q goes to base + j
+    {
+      uint32_t rd[4], wr[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const uint32_t slot = 8 * (e >> 1) + 2 * kb + (e & 1);
-        x[e] = sb[swz12(base + slot * 16)];
-        tw[e] = tab->tw16[br4(slot) * 16 + n];
+        rd[e] = swz12((w << 10) | (n << 4) | MXN_SLOT(e));
+        wr[e] = swz12((w << 10) | (n << 4) | MXN_ROW(e));
       }
-      gl::mul_n<4>(x, tw, x);
-      dft16(x, f, y);
-#pragma unroll
-      for (int q = 0; q < 4; q++) sb[swz12(base + br4(kb + 4 * q) * 16)] = y[q];
-    }
-  }
-  __syncthreads();
-  // S = 4096 with the twiddle w_4096^(i kin) first, then the X radix-2 stages that join the sub-blocks, straight
-  // to global memory
 #pragma unroll 1
-  for (int mi = 0; mi < MPT; mi++) {
-    const uint32_t G = 64 * w + 16 * (ut * MPT + mi) + n;
-    uint64_t yo[NSUB][4];
+      for (int s = 0; s < SPG; s++) {
+        uint64_t* sb = buf + (ut * SPG + s) * 4096;
+#pragma unroll 2
+        for (int m = 0; m < 4; m++) {
+          const uint32_t mt = mterm_hi(m);
+          uint64_t x[4], y[4];
 #pragma unroll
-    for (int u = 0; u < NSUB; u++) {
-      uint64_t x[4], tw[4];
+          for (int e = 0; e < 4; e++) x[e] = sb[rd[e] ^ mt];
+          dft16(x, f, y);
+#pragma unroll
+          for (int q = 0; q < 4; q++) sb[wr[q] ^ mt] = y[q];
+        }
+      }
+    }
+    __syncthreads();
+    // S = 256: twiddle w_256^(i kin) first
+    {
+      uint32_t rd[4], wr[4];
+      uint64_t twv[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const uint32_t slot = 8 * (e >> 1) + 2 * kb + (e & 1);
-        x[e] = buf[u * 4096 + swz12(slot * 256 + G)];
-        tw[e] = tab->tw256[br4(slot) * 256 + G];
+        rd[e] = swz12((w << 10) | (MXN_SLOT(e) << 4) | n);
+        wr[e] = swz12((w << 10) | (MXN_ROW(e) << 4) | n);
+        twv[e] = tab->tw16[br4(MXN_SLOT(e)) * 16 + n];
       }
-      gl::mul_n<4>(x, tw, x);
-      dft16(x, f, yo[u]);
-    }
+#pragma unroll 1
+      for (int s = 0; s < SPG; s++) {
+        uint64_t* sb = buf + (ut * SPG + s) * 4096;
+#pragma unroll 2
+        for (int m = 0; m < 4; m++) {
+          const uint32_t mt = mterm_hi(m);
+          uint64_t x[4], y[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint32_t r = br4(kb + 4 * q) * 256 + G;
-      if constexpr (X > 0) {
-        uint64_t yy[NSUB];
+          for (int e = 0; e < 4; e++) x[e] = sb[rd[e] ^ mt];
+          gl::mul_n<4>(x, twv, x);
+          dft16(x, f, y);
 #pragma unroll
-        for (int u = 0; u < NSUB; u++) yy[u] = yo[u][q];
-        dit_butterflies<X>(yy, a.tw, r, 12, 0);
-#pragma unroll
-        for (int u = 0; u < NSUB; u++) dst[u * 4096 + r] = gl::canon(yy[u]);
-      } else {
-        dst[r] = gl::canon(yo[0][q]);
+          for (int q = 0; q < 4; q++) sb[wr[q] ^ mt] = y[q];
+        }
       }
     }
+    __syncthreads();
+    // S = 4096 with the twiddle w_4096^(i kin) first, then the X radix-2 stages that join the sub-blocks, straight
+    // to global memory
+    {
+      uint32_t rd[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) rd[e] = swz12((MXN_SLOT(e) << 8) | (w << 6) | n);
+#pragma unroll 2
+      for (int mi = 0; mi < MPT; mi++) {
+        const uint32_t ms = ut * MPT + mi, G = 64 * w + 16 * ms + n, mt = mterm_lo(ms);
+        uint64_t yo[NSUB][4], tw[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) tw[e] = tab->tw256[br4(MXN_SLOT(e)) * 256 + G];
+#pragma unroll
+        for (int u = 0; u < NSUB; u++) {
+          uint64_t x[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) x[e] = buf[u * 4096 + (rd[e] ^ mt)];
+          gl::mul_n<4>(x, tw, x);
+          dft16(x, f, yo[u]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t r = MXN_ROW(q) * 256 + G;
+          if constexpr (X > 0) {
+            uint64_t yy[NSUB];
+#pragma unroll
+            for (int u = 0; u < NSUB; u++) yy[u] = yo[u][q];
+            dit_butterflies<X>(yy, a.tw, r, 12, 0);
+#pragma unroll
+            for (int u = 0; u < NSUB; u++) dst[u * 4096 + r] = gl::canon(yy[u]);
+          } else {
+            dst[r] = gl::canon(yo[0][q]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // the LDS image is reused by the next block
   }
 }
+#undef MXN_SLOT
+#undef MXN_ROW
 
 // ---- host side: the constants of one (kind, direction) --------------------------------------------------------------
 // kind 0 (DIF): column (c, kb, eps) is input j = 8c + 2kb + eps, row (ib, a) is output k = ib + 4a.
