@@ -97,11 +97,13 @@ int bp_debug_copy_u64(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* s
  * canon(a), canon(b). */
 int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream);
 
-/* Tuning knob: hashing launches with fewer rows/nodes than this use the quad-cooperative Poseidon
- * kernels (4 lanes per state, DPP exchange); larger ones use one lane per state.  Results are
- * identical either way.  0 (default) = automatic: 2^17 while fewer than 6 provers (bp_generate_*_proof
- * calls) are at work on the device, 2^13 under load.  A caller that drives the L0 entry points from many
- * streams itself should set 2^13: the library cannot see that load. */
+/* Tuning knob: the size (rows / nodes / candidates of one launch) from which the hashing kernels put 64 Poseidon
+ * states on a wave.  Matrix-core form (default): four sets of 16 states per wave from this size up, two from half of
+ * it, one below.  With bp_tune_poseidon_mx(0): one lane per state from this size up, the quad-cooperative kernels
+ * (4 lanes per state, DPP exchange) below.  Results are identical either way.  0 (default) = automatic: 2^19 (2^17
+ * without the matrix-core form) while fewer than 6 provers (bp_generate_*_proof calls) are at work on the device,
+ * 2^13 under load.  A caller that drives the L0 entry points from many streams itself should set 2^13: the library
+ * cannot see that load. */
 void bp_tune_quad_threshold(uint64_t n_perms);
 /* 1: Merkle levels below the quad threshold are fused, up to 7 per launch; 0 (default, ~3% faster under
  * multi-stream load): one launch per level.  Results are identical. */
@@ -119,9 +121,10 @@ void bp_tune_poseidon_mx_sets(int sets);
  * Results are identical either way. */
 void bp_tune_ntt_split(int mode);
 /* NTT blocks as three radix-16 passes whose 16-point DFTs are int8 MFMAs on the bytes of the elements
- * (csrc/ntt_mx.cuh): 0 (default) = off, the VALU butterfly kernels everywhere; 1 = 2^12- and 2^13-point blocks;
- * 2 = 2^14-point blocks too.  Alone on the chip the form is level to +17 %, under the multi-stream block run its
- * register footprint loses 12 %, hence opt-in.  Results are identical either way. */
+ * (csrc/ntt_mx.cuh): 0 = never (the VALU butterfly kernels everywhere), 1 = 2^12- and 2^13-point blocks, 2 = 2^14-point
+ * blocks too, 3 (default) = 2^13-point blocks while fewer than 6 provers are at work on the device.  Alone
+ * on the chip the form is level to +17 %; under the multi-stream block run its register footprint loses 12 %
+ * (DESIGN.md section 7).  Results are identical either way. */
 void bp_tune_ntt_mx(int mode);
 /* Measurement knob: resident workgroups per CU of the (persistent) matrix-core NTT kernels; 0 = default. */
 void bp_tune_ntt_mx_wg_per_cu(int n);

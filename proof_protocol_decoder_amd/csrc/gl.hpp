@@ -10,7 +10,8 @@
 // 4.7 cycles per wave64 like every other VOP3, tools/issue_rate.hip) and the Goldilocks reduction uses 2^64 = 2^32 - 1, 2^96 = -1.  The compiler's
 // rendering of mul_wide + reduce128 is 25 VALU instructions; the device forms below (namespace cc,
 // mul, mul_n, DotAcc) keep the carries as explicit SGPR masks and need 15.
-// No MFMA anywhere (integer field work).
+// The field arithmetic itself is VALU work; the matrix cores are used where a constant matrix acts on many elements
+// (the Poseidon MDS layer, poseidon_mx.cuh; opt-in the NTT's 16-point DFTs, ntt_mx.cuh) through byte planes.
 #pragma once
 #include <cstdint>
 #include <hip/hip_runtime.h>

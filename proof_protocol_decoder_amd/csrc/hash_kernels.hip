@@ -391,6 +391,7 @@ static std::atomic<uint64_t> g_quad_threshold{0};
 static bool g_poseidon_mx_on();
 static std::atomic<int> g_active_provers{0};
 void prover_active(int delta) { g_active_provers.fetch_add(delta, std::memory_order_relaxed); }
+bool device_loaded() { return g_active_provers.load(std::memory_order_relaxed) >= 6; }  // several provers share the chip
 uint64_t quad_threshold() {
   const uint64_t t = g_quad_threshold.load(std::memory_order_relaxed);
   if (t) return t;

@@ -799,19 +799,22 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
   return BP_OK;
 }
 
-// Constants of the matrix-core kernels (ntt_mx.cuh), one device image per (device, kind, direction), built once.
-// 0 (default): the VALU kernels; 1: 2^12- and 2^13-point blocks on the matrix cores; 2: 2^14-point blocks too.
-// Measured (tools/ntt_mx_probe.py, profiles/r2_ntt_mx_probe.txt): alone on the chip the matrix-core form is level at
-// 2^12 points (+2..3 %), ahead at 2^13 x 135 rate 8 (+7 % LDE, +17 % inverse transform) and behind at 2^14 (it spills:
-// -25 %); it issues half the VALU instructions but holds 224-240 VGPRs (96 of them MFMA constants), i.e. two waves
-// per SIMD, and is latency-bound there.  Under the 24-stream block run that register footprint costs more than the
-// instructions save: 29.8 against 34.1 txn-proofs/s (bench.py --ntt-mx 1 / 0) -- its waves crowd out the Poseidon
-// kernels' waves.  So it stays an opt-in form.
-static std::atomic<int> g_ntt_mx{0};
+// Matrix-core form of the block kernels (ntt_mx.cuh).  0: never; 1: 2^12- and 2^13-point blocks; 2: 2^14-point blocks
+// too (tests); 3 (default): 2^13-point blocks -- where it clearly wins -- while the device is not loaded (fewer than six
+// provers at work).  Measured (tools/ntt_mx_probe.py, profiles/r2_ntt_mx_probe.txt): alone on the chip the matrix-core form is
+// level at 2^12 points (+2..3 %), ahead at 2^13 x 135 rate 8 (+7 % LDE, +17 % inverse transform) and behind at 2^14
+// (it spills: -25 %); it issues half the VALU instructions but holds 224-240 VGPRs (96 of them MFMA constants), i.e.
+// two waves per SIMD, and is latency-bound there.  Under the 24-stream block run that register footprint costs more
+// than the instructions save: 29.8 against 34.1 txn-proofs/s (bench.py --ntt-mx 1 / 0, profiles/r2_ntt_mx_block_ab.txt)
+// -- its waves crowd out the Poseidon kernels' waves.  Hence: only where a proof has the chip to itself.
+bool device_loaded();  // hash_kernels.hip
+static std::atomic<int> g_ntt_mx{3};
 static bool use_ntt_mx(uint32_t log_blk) {
   const int m = g_ntt_mx.load(std::memory_order_relaxed);
+  if (m == 3) return log_blk == 13 && !device_loaded();
   return m == 2 || (m == 1 && log_blk <= 13);
 }
+// Constants of the matrix-core kernels, one device image per (device, kind, direction), built once.
 static std::mutex g_mx_mu;
 static std::map<std::tuple<int, int, int>, mxn::Tables*> g_mx_tabs;
 // Persistent grid of the matrix-core kernels: every workgroup loads the 24 KB of MFMA constants once and then walks
@@ -1107,7 +1110,7 @@ int init_ntt_kernels() {
 extern "C" {
 
 void bp_tune_ntt_split(int mode) { bpg::g_ntt_split.store(mode); }
-void bp_tune_ntt_mx(int mode) { bpg::g_ntt_mx.store(mode < 0 || mode > 2 ? 0 : mode); }
+void bp_tune_ntt_mx(int mode) { bpg::g_ntt_mx.store(mode < 0 || mode > 3 ? 3 : mode); }
 void bp_tune_ntt_mx_wg_per_cu(int n) { bpg::g_mx_wg_per_cu.store(n); }
 
 int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir, void* stream) try {

@@ -12,7 +12,7 @@ def ntt_form(request, bpg):
     """2^12..2^14-point blocks: 16-point DFTs on the matrix cores (ntt_mx.cuh) / VALU butterflies"""
     bpg.lib().bp_tune_ntt_mx(2 if request.param == "mx" else 0)   # 2: also the 2^14-point blocks
     yield request.param
-    bpg.lib().bp_tune_ntt_mx(0)
+    bpg.lib().bp_tune_ntt_mx(3)
 
 
 @pytest.mark.parametrize("log_n,n_cols", [(0, 3), (1, 2), (2, 5), (3, 4), (5, 7), (9, 16), (12, 9), (13, 3), (14, 5),

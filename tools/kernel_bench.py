@@ -29,7 +29,7 @@ for name, log_n, C, r in shapes:
     bpg.lib().bp_tune_ntt_mx(2)          # 16-point DFTs on the matrix cores
     t_intt = timeit(lambda: bpg.ops.ntt_batch_(v, bpg.ops.NTT_INV_NAT2BR))
     t_lde = timeit(lambda: bpg.ops.lde_batch(v, r))
-    bpg.lib().bp_tune_ntt_mx(0)
+    bpg.lib().bp_tune_ntt_mx(3)
     coeffs, lde = bpg.ops.lde_batch(v, r)
     bpg.lib().bp_tune_quad_threshold(1)  # 1: never quad (0 = automatic)
     bpg.lib().bp_tune_poseidon_mx(1)     # MDS layer on the matrix cores, 4 / 2 / 1 sets of 16 states per wave

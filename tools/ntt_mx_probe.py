@@ -30,5 +30,5 @@ for name, log_n, C, r in [("sweep12", 12, 2048, 1), ("keccak", 14, 2432, 1), ("r
         t_l = timeit(lambda: bpg.ops.lde_batch(v, r, from_coeffs=True))
         row += " %s intt %5.0f lde %5.0f |" % (label, 16 * n * C / t_i / 1e6, 8 * n * C * (1 + (1 << r)) / t_l / 1e6)
     print(row, flush=True)
-L.bp_tune_ntt_mx(0)
+L.bp_tune_ntt_mx(3)
 L.bp_tune_ntt_mx_wg_per_cu(0)
