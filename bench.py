@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
 # (two rocprofv3 --pmc passes of this same command, tools/pmc_family_traffic.py).  bench.py cannot collect
 # counters itself, so it reads the tracked summary and names it (and the commit it was taken at) beside the
 # number; no file, no number.
-TRAFFIC_FILE = os.path.join("profiles", "r2_pmc_lde_family.txt")
+TRAFFIC_FILE = os.path.join("profiles", "r2b_pmc_lde_family.txt")
 
 
 def traffic_ratio():
@@ -86,8 +86,12 @@ def main():
     # BPG_SHARE_GPU=1 is a rehearsal mode for a 1-GPU box: all ranks use device 0 and the gather runs
     # over gloo (RCCL needs one device per rank).  The driver's real runs never set it.
     if args.threads <= 0:
+        # at most 24 streams (the chip is full from ~16 on), and as many as divide the shard into equally full
+        # rounds: a 32-txn shard on 24 streams runs 24 + 8 (30.1 txn-proofs/s), on 16 streams 16 + 16 (32.8); a 16-txn
+        # shard wants all 16 at once (32.0 against 27.7 on 8).  profiles/r2_shard_streams.txt
         shard = (args.txns + world - 1) // world
-        args.threads = max(4, min(24, (shard + 1) // 2))
+        rounds = (shard + 23) // 24
+        args.threads = max(4, (shard + rounds - 1) // rounds)
     share = os.environ.get("BPG_SHARE_GPU") == "1"
     if share:
         local_rank = 0
@@ -125,7 +129,7 @@ def main():
         ach = by.value / (ms.value * 1e-3) / 1e9
         # the PMC ratio was measured over the single-stream leg's launches: it says nothing about the timed region
         ratio, head = traffic_ratio() if leg else (None, None)
-        return {"bound": "hbm", "kernel": "coset-LDE NTT family: ntt16_dit_kernel<12|13|14> + ntt_lds_kernel<DIT>", "achieved": round(ach, 1),
+        return {"bound": "hbm", "kernel": "coset-LDE NTT family: ntt16_dit_kernel<12|13|14> + ntt_mx_dit_kernel<13> + ntt_lds_kernel<DIT>", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 # HBM bytes per launch = algorithmic x the ratio that two rocprofv3 --pmc passes (FETCH_SIZE x2,
                 # WRITE_SIZE) of this same command measured over the launches of the single-stream leg
@@ -246,6 +250,13 @@ def main():
                 peak = poseidon_peak(pkg, torch)
                 alu_kernel["peak_measured"] = peak
                 alu_kernel["valu_issue_frac"] = round(alu_kernel["achieved"] / peak, 3)
+                # what the MDS layer asks of the matrix cores at that rate: 30 rounds x 6 v_mfma_i32_16x16x64_i8
+                # (32768 int8 ops each) per 16 states.  Informational: the kernel is bound by VALU issue, and three
+                # quarters of these multiplies are by the zeros of a plane-diagonal matrix.
+                INT8_DENSE_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md: I8 = 2 x the BF16 rate per clock
+                tops = peak * 1e9 * 30 * 6 * 32768 / 16 / 1e12
+                alu_kernel["mfma_int8"] = {"achieved_at_peak_rate": round(tops, 1), "peak": INT8_DENSE_PEAK_TOPS,
+                                           "unit": "TOP/s", "frac": round(tops / INT8_DENSE_PEAK_TOPS, 3)}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0])
         print(json.dumps(out), flush=True)

@@ -41,9 +41,9 @@ for name, log_n, C, r in shapes:
     t_mx = t_ms[0]
     bpg.lib().bp_tune_poseidon_mx(0)     # one lane per state
     t_mk = timeit(lambda: bpg.ops.merkle_commit(lde, log_n, r, 4))
-    bpg.lib().bp_tune_poseidon_mx(1)
-    bpg.lib().bp_tune_quad_threshold(1 << 40)
+    bpg.lib().bp_tune_quad_threshold(1 << 40)   # quad-cooperative kernels (matrix-core form still off)
     t_mq = timeit(lambda: bpg.ops.merkle_commit(lde, log_n, r, 4))
+    bpg.lib().bp_tune_poseidon_mx(1)
     perms = (n << r) * ((C + 7) // 8) + (n << r)
     print("%-10s logn=%2d C=%4d r=%d | intt %7.3f ms %6.0f GB/s (valu %6.0f) | intt+lde %7.3f ms %6.0f GB/s(alg) (valu %6.0f) | merkle mx4 %8.3f ms %6.3f Gperm/s mx2 %6.3f mx1 %6.3f | lane %8.3f ms %6.3f Gperm/s | quad %8.3f ms %6.3f Gperm/s" % (
         name, log_n, C, r, t_intt, 16 * n * C / t_intt / 1e6, 16 * n * C / t_intt_v / 1e6, t_lde, 8 * n * C * (2 + (1 << r)) / t_lde / 1e6, 8 * n * C * (2 + (1 << r)) / t_lde_v / 1e6, t_mx, perms / t_mx / 1e6, perms / t_ms[1] / 1e6, perms / t_ms[2] / 1e6, t_mk, perms / t_mk / 1e6, t_mq, perms / t_mq / 1e6), flush=True)

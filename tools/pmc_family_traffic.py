@@ -13,7 +13,7 @@ dispatches; the family launches between them are the leg, and their algorithmic 
 JSON line of the same run."""
 import csv, glob, json, os, sys
 
-FAMILY = ("ntt16_dit_kernel", "ntt_lds_kernel<false>")
+FAMILY = ("ntt16_dit_kernel", "ntt_mx_dit_kernel", "ntt_lds_kernel<false>")
 
 
 def family_rows(d, counter):
