@@ -500,6 +500,14 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
 void bp_tune_merkle_fused(int on) { bpg::g_merkle_fused.store(on != 0); }
 void bp_tune_quad_threshold(uint64_t n_perms) { bpg::g_quad_threshold.store(n_perms); }
 void bp_tune_poseidon_mx(int on) { bpg::g_poseidon_mx.store(on != 0); }
+// Host only: the C-operand table of the matrix-core Poseidon kernels (poseidon_mx.cuh), 30 x 4 x 24 u32, for the CPU test
+// that re-derives it from the round constants.
+int bp_debug_poseidon_mx_cin(uint32_t* out) {
+  if (!out) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_debug_poseidon_mx_cin: null buffer");
+  static const poseidon::mx::CinTable t = poseidon::mx::make_cin_table();
+  for (int i = 0; i < poseidon::mx::CIN_WORDS; i++) out[i] = t.v[i];
+  return BP_OK;
+}
 void bp_tune_poseidon_mx_sets(int sets) { bpg::g_mx_sets.store(sets == 1 || sets == 2 || sets == 4 ? sets : 0); }
 
 uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {

@@ -18,6 +18,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <cstring>
 #include <memory>
 #include "common.hpp"
 #include "gl.hpp"
@@ -1112,6 +1113,26 @@ extern "C" {
 void bp_tune_ntt_split(int mode) { bpg::g_ntt_split.store(mode); }
 void bp_tune_ntt_mx(int mode) { bpg::g_ntt_mx.store(mode < 0 || mode > 3 ? 3 : mode); }
 void bp_tune_ntt_mx_wg_per_cu(int n) { bpg::g_mx_wg_per_cu.store(n); }
+
+// Host only (no device call): the constants of the matrix-core NTT kernels as the device gets them, for the CPU tests
+// that pin them to the integer model (tools/ntt_mx_model.py).  out_a: 16384 bytes, out_c: 128 i32,
+// out_tw256: 4096 u64, out_tw16: 256 u64.
+int bp_debug_ntt_mx_tables(int kind, int inverse, uint8_t* out_a, int32_t* out_c, uint64_t* out_tw256,
+                           uint64_t* out_tw16) try {
+  if ((kind != 0 && kind != 1) || !out_a || !out_c || !out_tw256 || !out_tw16)
+    return bpg::fail(BP_ERR_INVALID_INPUT, "bp_debug_ntt_mx_tables: bad argument");
+  auto t = std::make_unique<mxn::Tables>();
+  {
+    std::lock_guard<std::mutex> lk(bpg::g_mx_mu);  // build_tables keeps its digit scratch in a static array
+    mxn::build_tables(*t, kind, inverse != 0);
+  }
+  memcpy(out_a, t->a, sizeof(t->a));
+  memcpy(out_c, t->c, sizeof(t->c));
+  memcpy(out_tw256, t->tw256, sizeof(t->tw256));
+  memcpy(out_tw16, t->tw16, sizeof(t->tw16));
+  return BP_OK;
+}
+BPG_ABI_CATCH("bp_debug_ntt_mx_tables")
 
 int bp_ntt_batch(uint64_t* d_cols, uint32_t log_n, uint32_t n_cols, uint64_t col_stride, int dir, void* stream) try {
   if (n_cols == 0) return BP_OK;
