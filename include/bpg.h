@@ -130,7 +130,7 @@ void bp_tune_ntt_mx(int mode);
 void bp_tune_ntt_mx_wg_per_cu(int n);
 /* Host only (no GPU needed): the constants the matrix-core kernels run on, as the device gets them, so that CPU tests
  * can pin them to an independent derivation.  NTT (csrc/ntt_mx.cuh): kind 0 = DIF / 1 = DIT matrix, inverse = root
- * direction; out_a 16384 bytes ([row block 8][K chunk 2][lane 64][16] int8), out_c 128 i32, out_tw256 4096 u64,
+ * direction; out_a 8192 bytes ([row block 8][lane 64][16] int8, K-chunk 0), out_c 128 i32, out_tw256 4096 u64,
  * out_tw16 256 u64.  Poseidon (csrc/poseidon_mx.cuh): the C-operand table, 30 x 4 x 24 u32. */
 int bp_debug_ntt_mx_tables(int kind, int inverse, uint8_t* out_a, int32_t* out_c, uint64_t* out_tw256,
                            uint64_t* out_tw16);

@@ -801,13 +801,18 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
 }
 
 // Matrix-core form of the block kernels (ntt_mx.cuh).  0: never; 1: 2^12- and 2^13-point blocks; 2: 2^14-point blocks
-// too (tests); 3 (default): 2^13-point blocks -- where it clearly wins -- while the device is not loaded (fewer than six
-// provers at work).  Measured (tools/ntt_mx_probe.py, profiles/r2_ntt_mx_probe.txt): alone on the chip the matrix-core form is
-// level at 2^12 points (+2..3 %), ahead at 2^13 x 135 rate 8 (+7 % LDE, +17 % inverse transform) and behind at 2^14
-// (it spills: -25 %); it issues half the VALU instructions but holds 224-240 VGPRs (96 of them MFMA constants), i.e.
-// two waves per SIMD, and is latency-bound there.  Under the 24-stream block run that register footprint costs more
-// than the instructions save: 29.8 against 34.1 txn-proofs/s (bench.py --ntt-mx 1 / 0, profiles/r2_ntt_mx_block_ab.txt)
-// -- its waves crowd out the Poseidon kernels' waves.  Hence: only where a proof has the chip to itself.
+// too (tests); 3 (default): 2^13-point blocks -- where it wins a little -- while the device is not loaded (fewer than
+// six provers at work).  Measured (tools/ntt_mx_probe.py, bench.py --ntt-mx 1 / 0 back to back on one box):
+//   first version, MFMA constants in 96 VGPRs, 224-240 VGPRs = two waves per SIMD (profiles/r2_ntt_mx_probe.txt,
+//   r2_ntt_mx_block_ab.txt): alone level at 2^12 points, +7 % LDE / +17 % inverse at 2^13 x 135 rate 8, -25 % at 2^14
+//   (spills); under the 24-stream block run 29.8 against 34.1 txn-proofs/s -- its fat waves crowd out the Poseidon
+//   kernels' waves;
+//   this version, constants cut to 32 VGPRs (chunk 1 = +-chunk 0, C operands in LDS), 136-168 VGPRs = three waves per
+//   SIMD (profiles/r2_ntt_mx_lean_ab.txt): alone level at 2^12, +3..4 % at 2^13 x 135, still behind at 2^14; under
+//   load 34.7 against 35.3.
+// It issues half the VALU instructions of the butterfly kernels, but every 16 elements of a pass cost one MFMA, which
+// blocks its SIMD for ~12 cycles (tools/mfma_probe.hip), and the kernel stays latency-bound at three waves: no win
+// over the VALU kernels on this workload, so it is used only where it measures ahead.
 bool device_loaded();  // hash_kernels.hip
 static std::atomic<int> g_ntt_mx{3};
 static bool use_ntt_mx(uint32_t log_blk) {
@@ -969,9 +974,9 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
       if ((rc = get_mx_tables(0, inverse, &tab))) return rc;
       b.n_units = n_cols << (log_n - log_blk);
       const uint32_t g = mx_grid(b.n_units, log_blk);
-      if (log_blk == 12) mxn::ntt_mx_dif_kernel<0><<<g, 256, 8u << 12, st>>>(b, tab);
-      else if (log_blk == 13) mxn::ntt_mx_dif_kernel<1><<<g, 512, 8u << 13, st>>>(b, tab);
-      else mxn::ntt_mx_dif_kernel<2><<<g, 512, 8u << 14, st>>>(b, tab);
+      if (log_blk == 12) mxn::ntt_mx_dif_kernel<0><<<g, 256, (8u << 12) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
+      else if (log_blk == 13) mxn::ntt_mx_dif_kernel<1><<<g, 512, (8u << 13) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
+      else mxn::ntt_mx_dif_kernel<2><<<g, 512, (8u << 14) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
     } else if (use_split(log_blk, (uint64_t)n_cols << (log_n - log_blk), src, out, false)) {
       // two workgroups of the next smaller kernel per block (see Ntt16Args)
       if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
@@ -1025,9 +1030,9 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
         const mxn::Tables* tab = nullptr;
         if ((rc = get_mx_tables(1, inverse, &tab))) return rc;
         const uint32_t g = mx_grid((b.n_units + 7) / 8 * 8 * n_cosets, log_blk);
-        if (log_blk == 12) mxn::ntt_mx_dit_kernel<0><<<g, 256, 8u << 12, st>>>(b, tab);
-        else if (log_blk == 13) mxn::ntt_mx_dit_kernel<1><<<g, 512, 8u << 13, st>>>(b, tab);
-        else mxn::ntt_mx_dit_kernel<2><<<g, 512, 8u << 14, st>>>(b, tab);
+        if (log_blk == 12) mxn::ntt_mx_dit_kernel<0><<<g, 256, (8u << 12) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
+        else if (log_blk == 13) mxn::ntt_mx_dit_kernel<1><<<g, 512, (8u << 13) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
+        else mxn::ntt_mx_dit_kernel<2><<<g, 512, (8u << 14) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
       } else if (use_split(log_blk, (uint64_t)b.n_units * n_cosets, in, out, true)) {
         if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
         b.tw_top = tw_b;
@@ -1086,13 +1091,13 @@ static int init_ntt_kernels_once() {
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxn::ntt_mx_dif_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (8 << 13) + 4 * mxn::C_LDS_WORDS));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxn::ntt_mx_dif_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (8 << 14) + 4 * mxn::C_LDS_WORDS));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxn::ntt_mx_dit_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (8 << 13) + 4 * mxn::C_LDS_WORDS));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxn::ntt_mx_dit_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (8 << 14) + 4 * mxn::C_LDS_WORDS));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<13, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13, 1>),
@@ -1115,7 +1120,7 @@ void bp_tune_ntt_mx(int mode) { bpg::g_ntt_mx.store(mode < 0 || mode > 3 ? 3 : m
 void bp_tune_ntt_mx_wg_per_cu(int n) { bpg::g_mx_wg_per_cu.store(n); }
 
 // Host only (no device call): the constants of the matrix-core NTT kernels as the device gets them, for the CPU tests
-// that pin them to the integer model (tools/ntt_mx_model.py).  out_a: 16384 bytes, out_c: 128 i32,
+// that pin them to the integer model (tools/ntt_mx_model.py).  out_a: 8192 bytes, out_c: 128 i32,
 // out_tw256: 4096 u64, out_tw16: 256 u64.
 int bp_debug_ntt_mx_tables(int kind, int inverse, uint8_t* out_a, int32_t* out_c, uint64_t* out_tw256,
                            uint64_t* out_tw16) try {

@@ -36,11 +36,12 @@ using mxa::v4i;
 
 // device image of the constants of one (kind, direction): kind 0 = DIF matrix, 1 = DIT matrix
 struct Tables {
-  uint32_t a[8 * 2 * 64 * 4];   // A operand: [row block][K chunk][lane] x 16 bytes
+  uint32_t a[8 * 64 * 4];       // A operand of K-chunk 0: [row block][lane] x 16 bytes (chunk 1 = +-the same, see dft16)
   uint32_t c[8 * 4 * 4];        // C operand: [row block][ib] x 4 i32
   uint64_t tw256[16 * 256];     // w_4096^(i k), [k][i]
   uint64_t tw16[16 * 16];       // w_256^(i k), [k][i]
 };
+constexpr int C_LDS_WORDS = 8 * 4 * 4;   // the C operands live in LDS behind the data image (512 bytes)
 
 __device__ __forceinline__ uint32_t swz12(uint32_t pos) {  // XOR swizzle of a 4096-element LDS image (8-byte words)
   return pos ^ ((pos >> 4) & 15u) ^ ((((pos >> 1) ^ (pos >> 3) ^ (pos >> 9) ^ (pos >> 11)) & 1u) << 4);
@@ -49,58 +50,79 @@ __host__ __device__ __forceinline__ constexpr uint32_t br4(uint32_t k) {
   return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
 }
 
+// Register budget.  The constants are what makes this kernel fat, and its waves share the SIMDs with other streams'
+// kernels, so they are cut to 32 VGPRs: (i) input j + 8 of a 16-point DFT contributes w16^((j+8)k) = (-1)^k w16^(jk),
+// and the rows of one MFMA tile are given outputs of ONE parity (row a of lane group ib is output 4 ib + a, resp.
+// (a & 1) + 2 ib + 8 (a >> 1) in the DIT kernel), so K-chunk 1 reuses chunk 0's A registers: as they are for even
+// rows, and for odd rows against the bytes XOR 0x7F (= 127 - x = -(x - 128) - 1: the negated operand, exact; the -1
+// per entry is a row constant and sits in the C operand); (ii) the C operands are read from LDS next to each MFMA.
 struct Frag {
-  v4i a[8][2];
-  v4i c[8];
+  v4i a[8];
 };
 __device__ __forceinline__ void load_frag(Frag& f, const Tables* __restrict__ t) {
   const uint32_t lane = threadIdx.x & 63;
   const uint4* pa = reinterpret_cast<const uint4*>(t->a);
-  const uint4* pc = reinterpret_cast<const uint4*>(t->c);
 #pragma unroll
   for (int rb = 0; rb < 8; rb++) {
-#pragma unroll
-    for (int ch = 0; ch < 2; ch++) {
-      const uint4 v = pa[(rb * 2 + ch) * 64 + lane];
-      f.a[rb][ch] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-    }
-    const uint4 v = pc[rb * 4 + (lane >> 4)];
-    f.c[rb] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    const uint4 v = pa[rb * 64 + lane];
+    f.a[rb] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
   }
+}
+// the whole workgroup copies the C operands behind the data image (call before the first __syncthreads)
+__device__ __forceinline__ void load_c_lds(uint32_t* __restrict__ c_lds, const Tables* __restrict__ t) {
+  for (uint32_t i = threadIdx.x; i < (uint32_t)C_LDS_WORDS; i += blockDim.x) c_lds[i] = t->c[i];
 }
 
 // x[e]: input slot e of this lane (chunk e >> 1, element e & 1), any u64.  y[a]: output row a, reduced.
-__device__ __forceinline__ void dft16(const uint64_t (&x)[4], const Frag& f, uint64_t (&y)[4]) {
-  v4i b0, b1;
+// cl: this lane group's C operands in LDS ([row block] stride 4 x v4i).
+__device__ __forceinline__ void dft16(const uint64_t (&x)[4], const Frag& f, const v4i* __restrict__ cl, uint64_t (&y)[4]) {
+  v4i b0, b1, b1n;
   b0[0] = (int)((uint32_t)x[0] ^ 0x80808080u); b0[1] = (int)((uint32_t)(x[0] >> 32) ^ 0x80808080u);
   b0[2] = (int)((uint32_t)x[1] ^ 0x80808080u); b0[3] = (int)((uint32_t)(x[1] >> 32) ^ 0x80808080u);
   b1[0] = (int)((uint32_t)x[2] ^ 0x80808080u); b1[1] = (int)((uint32_t)(x[2] >> 32) ^ 0x80808080u);
   b1[2] = (int)((uint32_t)x[3] ^ 0x80808080u); b1[3] = (int)((uint32_t)(x[3] >> 32) ^ 0x80808080u);
+  b1n[0] = (int)((uint32_t)x[2] ^ 0x7F7F7F7Fu); b1n[1] = (int)((uint32_t)(x[2] >> 32) ^ 0x7F7F7F7Fu);
+  b1n[2] = (int)((uint32_t)x[3] ^ 0x7F7F7F7Fu); b1n[3] = (int)((uint32_t)(x[3] >> 32) ^ 0x7F7F7F7Fu);
   uint64_t L[4], H[4];
 #pragma unroll
   for (int a = 0; a < 4; a++) {
-    v4i dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a][0], b0, f.c[2 * a], 0, 0, 0);
-    dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a][1], b1, dl, 0, 0, 0);
-    v4i dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a + 1][0], b0, f.c[2 * a + 1], 0, 0, 0);
-    dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a + 1][1], b1, dh, 0, 0, 0);
+    const v4i bb = (a & 1) ? b1n : b1;
+    v4i dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a], b0, cl[(2 * a) * 4], 0, 0, 0);
+    dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a], bb, dl, 0, 0, 0);
+    v4i dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a + 1], b0, cl[(2 * a + 1) * 4], 0, 0, 0);
+    dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[2 * a + 1], bb, dh, 0, 0, 0);
     L[a] = mxa::planes(dl);
     H[a] = mxa::planes(dh);
   }
   mxa::reduce_rows<4>(L, H, y);
 }
 
+#ifndef MXN_SETS_IN_FLIGHT
+#define MXN_SETS_IN_FLIGHT 1   /* unroll factor of the set loops: 2 has more ILP and ~50 more VGPRs */
+#endif
+#define MXN_STR2(x) #x
+#define MXN_STR(x) MXN_STR2(x)
+#define MXN_PRAGMA_UNROLL_SETS _Pragma(MXN_STR(unroll MXN_SETS_IN_FLIGHT))
+#ifndef MXN_WAVES
+#define MXN_WAVES 3   /* waves per SIMD the register allocation aims at (128 VGPRs) */
+#endif
 // LDS addresses.  swz12 is linear over GF(2), and in every pass the set index m occupies position bits no other term
 // touches, so address(m) = (lane constant) ^ swz12(m's bits): the lane constants are made once per pass.
 __device__ __forceinline__ uint32_t mterm_hi(uint32_t m) { return (m << 8) ^ ((m & 2u) << 3); }   // swz12(m << 8)
 __device__ __forceinline__ uint32_t mterm_lo(uint32_t m) { return (m << 4) ^ m; }                 // swz12(m << 4)
-#define MXN_SLOT(e) (8u * ((e) >> 1) + 2u * kb + ((e) & 1u))   /* input slot of element e of this lane */
-#define MXN_ROW(q) br4(kb + 4u * (q))                           /* bit-reversed output row q of this lane */
+// DIF: input slot e (chunk e >> 1, element e & 1) is element j = 8c + 2kb + eps at field j; output row q is k = 4kb + q,
+// stored at field bitrev4(k).  DIT: input slot e is element kin = 8c + 4eps + kb, found at field bitrev4(kin); output
+// row q is j = (q & 1) + 2kb + 8(q >> 1), stored at field j.  (Chunk 1 = chunk 0's element + 8; a row's parity = q & 1.)
+#define MXN_DIF_J(e) (8u * ((e) >> 1) + 2u * kb + ((e) & 1u))
+#define MXN_DIF_K(q) (4u * kb + (q))
+#define MXN_DIT_KIN(e) (8u * ((e) >> 1) + 4u * ((e) & 1u) + kb)
+#define MXN_DIT_J(q) (((q) & 1u) + 2u * kb + 8u * ((q) >> 1))
 
 // ---- decimation in frequency: natural -> bit-reversed.  X = log2(sub-blocks of 4096): block = 4096 << X points.
 // 1-D grid of persistent workgroups: workgroup g takes units g, g + gridDim.x, ... (unit = column * blocks per column +
 // block; a.n_units of them); 256 threads (X = 0) or 512 (two groups of 256).
 template <int X>
-__global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, const Tables* __restrict__ tab) {
+__global__ void __launch_bounds__(X ? 512 : 256) __attribute__((amdgpu_waves_per_eu(MXN_WAVES, MXN_WAVES))) ntt_mx_dif_kernel(Ntt16Args a, const Tables* __restrict__ tab) {
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr int NSUB = 1 << X, NGRP = X ? 2 : 1, SPG = NSUB / NGRP;  // sub-blocks, thread groups, sub-blocks per group
@@ -108,7 +130,11 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, 
   const uint32_t tid = threadIdx.x, ut = tid >> 8, t = tid & 255, lane = tid & 63, w = t >> 6, n = lane & 15,
                  kb = lane >> 4;
   Frag f;
-  load_frag(f, tab);   // 24 x 16 bytes per lane: loaded once, the workgroup then walks over its share of the blocks
+  load_frag(f, tab);   // 8 x 16 bytes per lane: loaded once, the workgroup then walks over its share of the blocks
+  uint32_t* c_lds = reinterpret_cast<uint32_t*>(buf + (4096u << X));
+  load_c_lds(c_lds, tab);
+  const v4i* cl = reinterpret_cast<const v4i*>(c_lds) + kb;   // [row block] stride 4: this lane group's C operands
+  __syncthreads();
   const uint32_t log_bpc = a.log_n_total - (12 + X);  // blocks per column
 #pragma unroll 1
   for (uint32_t unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
@@ -121,14 +147,14 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, 
     {
       uint32_t wr[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) wr[q] = swz12((MXN_ROW(q) << 8) | (w << 6) | n);
-#pragma unroll 2
+      for (int q = 0; q < 4; q++) wr[q] = swz12((br4(MXN_DIF_K(q)) << 8) | (w << 6) | n);
+MXN_PRAGMA_UNROLL_SETS
       for (int mi = 0; mi < MPT; mi++) {
         const uint32_t ms = ut * MPT + mi, G = 64 * w + 16 * ms + n, mt = mterm_lo(ms);
         uint64_t xin[NSUB][4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const uint32_t r = MXN_SLOT(e) * 256 + G;
+          const uint32_t r = MXN_DIF_J(e) * 256 + G;
 #pragma unroll
           for (int u = 0; u < NSUB; u++) xin[u][e] = src[u * 4096 + r];
           if constexpr (X > 0) {
@@ -143,9 +169,9 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, 
 #pragma unroll
         for (int u = 0; u < NSUB; u++) {
           uint64_t y[4], tw[4];
-          dft16(xin[u], f, y);
+          dft16(xin[u], f, cl, y);
 #pragma unroll
-          for (int q = 0; q < 4; q++) tw[q] = tab->tw256[(kb + 4 * q) * 256 + G];
+          for (int q = 0; q < 4; q++) tw[q] = tab->tw256[MXN_DIF_K(q) * 256 + G];
           gl::mul_n<4>(y, tw, y);
 #pragma unroll
           for (int q = 0; q < 4; q++) buf[u * 4096 + (wr[q] ^ mt)] = y[q];
@@ -158,22 +184,22 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, 
       uint32_t rd[4], wr[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        rd[e] = swz12((w << 10) | (MXN_SLOT(e) << 4) | n);
-        wr[e] = swz12((w << 10) | (MXN_ROW(e) << 4) | n);
+        rd[e] = swz12((w << 10) | (MXN_DIF_J(e) << 4) | n);
+        wr[e] = swz12((w << 10) | (br4(MXN_DIF_K(e)) << 4) | n);
       }
       uint64_t twv[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) twv[q] = tab->tw16[(kb + 4 * q) * 16 + n];
+      for (int q = 0; q < 4; q++) twv[q] = tab->tw16[MXN_DIF_K(q) * 16 + n];
 #pragma unroll 1
       for (int s = 0; s < SPG; s++) {
         uint64_t* sb = buf + (ut * SPG + s) * 4096;
-#pragma unroll 2
+MXN_PRAGMA_UNROLL_SETS
         for (int m = 0; m < 4; m++) {
           const uint32_t mt = mterm_hi(m);
           uint64_t x[4], y[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) x[e] = sb[rd[e] ^ mt];
-          dft16(x, f, y);
+          dft16(x, f, cl, y);
           gl::mul_n<4>(y, twv, y);
 #pragma unroll
           for (int q = 0; q < 4; q++) sb[wr[q] ^ mt] = y[q];
@@ -186,19 +212,19 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, 
       uint32_t rd[4], wr[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        rd[e] = swz12((w << 10) | (n << 4) | MXN_SLOT(e));
-        wr[e] = swz12((w << 10) | (n << 4) | MXN_ROW(e));
+        rd[e] = swz12((w << 10) | (n << 4) | MXN_DIF_J(e));
+        wr[e] = swz12((w << 10) | (n << 4) | br4(MXN_DIF_K(e)));
       }
 #pragma unroll 1
       for (int s = 0; s < SPG; s++) {
         uint64_t* sb = buf + (ut * SPG + s) * 4096;
-#pragma unroll 2
+MXN_PRAGMA_UNROLL_SETS
         for (int m = 0; m < 4; m++) {
           const uint32_t mt = mterm_hi(m);
           uint64_t x[4], y[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) x[e] = sb[rd[e] ^ mt];
-          dft16(x, f, y);
+          dft16(x, f, cl, y);
           if (a.out_scalar != 1) {
             const uint64_t sc[4] = {a.out_scalar, a.out_scalar, a.out_scalar, a.out_scalar};
             gl::mul_n<4>(y, sc, y);
@@ -236,7 +262,7 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dif_kernel(Ntt16Args a, 
 // Input slot (chunk c, element eps) of lane kb is element kin = bitrev4(8c + 2kb + eps); output row a of lane ib is
 // j = bitrev4(ib + 4a) (the matrix is built that way, see build_tables).
 template <int X>
-__global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dit_kernel(Ntt16Args a, const Tables* __restrict__ tab) {
+__global__ void __launch_bounds__(X ? 512 : 256) __attribute__((amdgpu_waves_per_eu(MXN_WAVES, MXN_WAVES))) ntt_mx_dit_kernel(Ntt16Args a, const Tables* __restrict__ tab) {
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   extern __shared__ uint64_t buf[];
   constexpr int NSUB = 1 << X, NGRP = X ? 2 : 1, SPG = NSUB / NGRP, MPT = 4 / NGRP;
@@ -244,6 +270,10 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dit_kernel(Ntt16Args a, 
                  kb = lane >> 4;
   Frag f;
   load_frag(f, tab);   // loaded once; the workgroup then walks over ids blockIdx.x, + gridDim.x (a multiple of 8), ...
+  uint32_t* c_lds = reinterpret_cast<uint32_t*>(buf + (4096u << X));
+  load_c_lds(c_lds, tab);
+  const v4i* cl = reinterpret_cast<const v4i*>(c_lds) + kb;
+  __syncthreads();
   const uint32_t log_bpc = a.log_n_total - (12 + X);
   const uint32_t n_ids = (a.n_units + 7) / 8 * 8 * a.n_cosets;
 #pragma unroll 1
@@ -285,19 +315,19 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dit_kernel(Ntt16Args a, 
       uint32_t rd[4], wr[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        rd[e] = swz12((w << 10) | (n << 4) | MXN_SLOT(e));
-        wr[e] = swz12((w << 10) | (n << 4) | MXN_ROW(e));
+        rd[e] = swz12((w << 10) | (n << 4) | br4(MXN_DIT_KIN(e)));
+        wr[e] = swz12((w << 10) | (n << 4) | MXN_DIT_J(e));
       }
 #pragma unroll 1
       for (int s = 0; s < SPG; s++) {
         uint64_t* sb = buf + (ut * SPG + s) * 4096;
-#pragma unroll 2
+MXN_PRAGMA_UNROLL_SETS
         for (int m = 0; m < 4; m++) {
           const uint32_t mt = mterm_hi(m);
           uint64_t x[4], y[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) x[e] = sb[rd[e] ^ mt];
-          dft16(x, f, y);
+          dft16(x, f, cl, y);
 #pragma unroll
           for (int q = 0; q < 4; q++) sb[wr[q] ^ mt] = y[q];
         }
@@ -310,21 +340,21 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dit_kernel(Ntt16Args a, 
       uint64_t twv[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        rd[e] = swz12((w << 10) | (MXN_SLOT(e) << 4) | n);
-        wr[e] = swz12((w << 10) | (MXN_ROW(e) << 4) | n);
-        twv[e] = tab->tw16[br4(MXN_SLOT(e)) * 16 + n];
+        rd[e] = swz12((w << 10) | (br4(MXN_DIT_KIN(e)) << 4) | n);
+        wr[e] = swz12((w << 10) | (MXN_DIT_J(e) << 4) | n);
+        twv[e] = tab->tw16[MXN_DIT_KIN(e) * 16 + n];
       }
 #pragma unroll 1
       for (int s = 0; s < SPG; s++) {
         uint64_t* sb = buf + (ut * SPG + s) * 4096;
-#pragma unroll 2
+MXN_PRAGMA_UNROLL_SETS
         for (int m = 0; m < 4; m++) {
           const uint32_t mt = mterm_hi(m);
           uint64_t x[4], y[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) x[e] = sb[rd[e] ^ mt];
           gl::mul_n<4>(x, twv, x);
-          dft16(x, f, y);
+          dft16(x, f, cl, y);
 #pragma unroll
           for (int q = 0; q < 4; q++) sb[wr[q] ^ mt] = y[q];
         }
@@ -336,24 +366,24 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dit_kernel(Ntt16Args a, 
     {
       uint32_t rd[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) rd[e] = swz12((MXN_SLOT(e) << 8) | (w << 6) | n);
-#pragma unroll 2
+      for (int e = 0; e < 4; e++) rd[e] = swz12((br4(MXN_DIT_KIN(e)) << 8) | (w << 6) | n);
+MXN_PRAGMA_UNROLL_SETS
       for (int mi = 0; mi < MPT; mi++) {
         const uint32_t ms = ut * MPT + mi, G = 64 * w + 16 * ms + n, mt = mterm_lo(ms);
         uint64_t yo[NSUB][4], tw[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) tw[e] = tab->tw256[br4(MXN_SLOT(e)) * 256 + G];
+        for (int e = 0; e < 4; e++) tw[e] = tab->tw256[MXN_DIT_KIN(e) * 256 + G];
 #pragma unroll
         for (int u = 0; u < NSUB; u++) {
           uint64_t x[4];
 #pragma unroll
           for (int e = 0; e < 4; e++) x[e] = buf[u * 4096 + (rd[e] ^ mt)];
           gl::mul_n<4>(x, tw, x);
-          dft16(x, f, yo[u]);
+          dft16(x, f, cl, yo[u]);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const uint32_t r = MXN_ROW(q) * 256 + G;
+          const uint32_t r = MXN_DIT_J(q) * 256 + G;
           if constexpr (X > 0) {
             uint64_t yy[NSUB];
 #pragma unroll
@@ -370,12 +400,16 @@ __global__ void __launch_bounds__(X ? 512 : 256) ntt_mx_dit_kernel(Ntt16Args a, 
     __syncthreads();  // the LDS image is reused by the next block
   }
 }
-#undef MXN_SLOT
-#undef MXN_ROW
+#undef MXN_DIF_J
+#undef MXN_DIF_K
+#undef MXN_DIT_KIN
+#undef MXN_DIT_J
 
 // ---- host side: the constants of one (kind, direction) --------------------------------------------------------------
-// kind 0 (DIF): column (c, kb, eps) is input j = 8c + 2kb + eps, row (ib, a) is output k = ib + 4a.
-// kind 1 (DIT): column is input kin = bitrev4(8c + 2kb + eps), row is output j = bitrev4(ib + 4a).
+// kind 0 (DIF): column (c, kb, eps) is input j = 8c + 2kb + eps, row (ib, a) is output k = 4 ib + a.
+// kind 1 (DIT): column is input kin = 8c + 4eps + kb, row is output j = (a & 1) + 2 ib + 8 (a >> 1).
+// Only chunk c = 0 is stored: the coefficient of input index + 8 is (-1)^(output index) times it, and the parity of a
+// row's output index is a & 1 in both kinds (dft16).
 inline void digits8(uint64_t wv, int (&d)[8]) {  // balanced base-256 digits of wv or wv - p, whichever fits eight
   const unsigned __int128 lim = (unsigned __int128)127 * 0xFFFFFFFFFFFFFFFFULL / 255;
   __int128 v = wv <= (uint64_t)lim ? (__int128)wv : (__int128)wv - (__int128)gl::P;
@@ -389,8 +423,8 @@ inline void build_tables(Tables& t, int kind, bool inverse) {
   uint64_t w4096 = gl::root(12);
   if (inverse) w4096 = gl::inv(w4096);
   const uint64_t w256 = gl::pow(w4096, 16), w16 = gl::pow(w4096, 256);
-  auto in_index = [&](int slot) { return kind ? (int)br4((uint32_t)slot) : slot; };
-  auto out_index = [&](int row) { return kind ? (int)br4((uint32_t)row) : row; };
+  auto in_index = [&](int kb, int eps) { return kind ? 4 * eps + kb : 2 * kb + eps; };             // chunk 0
+  auto out_index = [&](int ib, int a) { return kind ? (a & 1) + 2 * ib + 8 * (a >> 1) : 4 * ib + a; };
   // bias: 2^22 + dd[q] per plane with sum_q (2^22 + dd[q]) 2^(8q) = 0 (mod p)
   unsigned __int128 base = 0;
   for (int q = 0; q < 8; q++) base += (unsigned __int128)(1u << 22) << (8 * q);
@@ -405,21 +439,21 @@ inline void build_tables(Tables& t, int kind, bool inverse) {
   uint8_t* ab = reinterpret_cast<uint8_t*>(t.a);
   for (int rb = 0; rb < 8; rb++) {
     const int a = rb >> 1, h = rb & 1;
-    for (int ch = 0; ch < 2; ch++)
-      for (int lane = 0; lane < 64; lane++) {
-        const int r = lane & 15, kb = lane >> 4, o = out_index((r >> 2) + 4 * a), q = 4 * h + (r & 3);
-        for (int b = 0; b < 16; b++) {
-          const int i = in_index(8 * ch + 2 * kb + (b >> 3)), p = b & 7;
-          ab[((rb * 2 + ch) * 64 + lane) * 16 + b] = (uint8_t)(int8_t)dig[o][i][p][q];
-        }
-      }
+    for (int lane = 0; lane < 64; lane++) {
+      const int r = lane & 15, kb = lane >> 4, o = out_index(r >> 2, a), q = 4 * h + (r & 3);
+      for (int b = 0; b < 16; b++) ab[(rb * 64 + lane) * 16 + b] = (uint8_t)(int8_t)dig[o][in_index(kb, b >> 3)][b & 7][q];
+    }
     for (int ib = 0; ib < 4; ib++)
       for (int reg = 0; reg < 4; reg++) {
-        const int o = out_index(ib + 4 * a), q = 4 * h + reg;
-        int sum = 0;
-        for (int i = 0; i < 16; i++)
-          for (int p = 0; p < 8; p++) sum += dig[o][i][p][q];
-        t.c[(rb * 4 + ib) * 4 + reg] = (uint32_t)((1 << 22) + (int)((delta >> (8 * q)) & 0xFF) + 128 * sum);
+        const int o = out_index(ib, a), q = 4 * h + reg;
+        int s0 = 0;   // digit sum of the row over the 64 bytes of chunk 0 (chunk 1 multiplies the same A registers)
+        for (int kb = 0; kb < 4; kb++)
+          for (int eps = 0; eps < 2; eps++)
+            for (int p = 0; p < 8; p++) s0 += dig[o][in_index(kb, eps)][p][q];
+        // chunk 0 and an even row's chunk 1 see x - 128: + 128 s0 each; an odd row's chunk 1 sees 127 - x against
+        // the un-negated digits: the true term is the computed one - 127 s0
+        const int corr = 128 * s0 + ((a & 1) ? -127 * s0 : 128 * s0);
+        t.c[(rb * 4 + ib) * 4 + reg] = (uint32_t)((1 << 22) + (int)((delta >> (8 * q)) & 0xFF) + corr);
       }
   }
   for (int k = 0; k < 16; k++) {

@@ -74,39 +74,71 @@ def test_ntt_mx_integer_model():
 
 def test_ntt_mx_tables_match_the_model():
     """The A / C operand images and twiddle tables the device kernels load (built on the host by
-    mxn::build_tables), against the integer model's matrix with the kernels' lane / row / slot assignment."""
+    mxn::build_tables), against the integer model's matrix with the kernels' lane / row / slot assignment.
+    Only K-chunk 0 is stored: the coefficient of input index + 8 is (-1)^(output index) times it, every tile row has
+    an output index of parity a & 1, and odd rows run chunk 1 against the bytes XOR 0x7F (= 127 - x), which moves
+    -127 * (digit sum) instead of +128 * (digit sum) into the row constant."""
     import ntt_mx_model as m
     L = _lib()
     L.bp_debug_ntt_mx_tables.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    br4 = lambda k: m.bitrev(k, 4)
     for kind in (0, 1):
+        in_index = (lambda kb, eps: 4 * eps + kb) if kind else (lambda kb, eps: 2 * kb + eps)
+        out_index = (lambda ib, a: (a & 1) + 2 * ib + 8 * (a >> 1)) if kind else (lambda ib, a: 4 * ib + a)
+        assert sorted(out_index(ib, a) for ib in range(4) for a in range(4)) == list(range(16))
+        assert sorted(8 * c + in_index(kb, e) for c in range(2) for kb in range(4) for e in range(2)) == list(range(16))
+        assert all(out_index(ib, a) % 2 == a % 2 for ib in range(4) for a in range(4))
         for inverse in (0, 1):
-            a = (C.c_uint8 * 16384)()
-            c = (C.c_int32 * 128)()
+            a_img = (C.c_uint8 * 8192)()
+            c_img = (C.c_int32 * 128)()
             tw256 = (C.c_uint64 * 4096)()
             tw16 = (C.c_uint64 * 256)()
-            assert L.bp_debug_ntt_mx_tables(kind, inverse, a, c, tw256, tw16) == 0
-            a = np.frombuffer(a, dtype=np.int8).reshape(8, 2, 64, 16)
-            c = np.frombuffer(c, dtype=np.int32).reshape(8, 4, 4)
+            assert L.bp_debug_ntt_mx_tables(kind, inverse, a_img, c_img, tw256, tw16) == 0
+            a_img = np.frombuffer(a_img, dtype=np.int8).reshape(8, 64, 16)
+            c_img = np.frombuffer(c_img, dtype=np.int32).reshape(8, 4, 4)
             w4096 = m.root(12)
             if inverse:
                 w4096 = pow(w4096, P - 2, P)
-            A, Cc = m.dft16_matrix(pow(w4096, 256, P))     # A[(k, q)][(j, p)], C[(k, q)]
-            idx = (lambda x: br4(x)) if kind else (lambda x: x)
+            w16 = pow(w4096, 256, P)
+            A, _ = m.dft16_matrix(w16)                     # A[(k, q)][(j, p)]: balanced digits of w16^(jk) 2^(8p)
+            base = sum((1 << 22) << (8 * q) for q in range(8))
+            delta = (-base) % P
             for rb in range(8):
-                g, h = rb >> 1, rb & 1
-                for ch in range(2):
-                    for lane in range(64):
-                        r, kb = lane & 15, lane >> 4
-                        out = idx((r >> 2) + 4 * g)
-                        q = 4 * h + (r & 3)
-                        for b in range(16):
-                            inp = idx(8 * ch + 2 * kb + (b >> 3))
-                            assert int(a[rb, ch, lane, b]) == A[out * 8 + q][inp * 8 + (b & 7)]
+                a, h = rb >> 1, rb & 1
+                for lane in range(64):
+                    r, kb = lane & 15, lane >> 4
+                    out, q = out_index(r >> 2, a), 4 * h + (r & 3)
+                    for b in range(16):
+                        assert int(a_img[rb, lane, b]) == A[out * 8 + q][in_index(kb, b >> 3) * 8 + (b & 7)]
                 for ib in range(4):
                     for reg in range(4):
-                        assert int(c[rb, ib, reg]) == Cc[idx(ib + 4 * g) * 8 + 4 * h + reg]
+                        out, q = out_index(ib, a), 4 * h + reg
+                        s0 = sum(A[out * 8 + q][in_index(kb, e) * 8 + p] for kb in range(4) for e in range(2)
+                                 for p in range(8))
+                        want = (1 << 22) + ((delta >> (8 * q)) & 0xFF) + 128 * s0 + (-127 * s0 if a & 1 else 128 * s0)
+                        assert int(c_img[rb, ib, reg]) == want
+            # the two-chunk product with these operands IS the 16-point DFT: integer check on random inputs
+            rng = np.random.default_rng(9 + kind)
+            xs = [int(v) for v in rng.integers(0, 1 << 64, 16, dtype=np.uint64)]
+            for ib in range(4):
+                for a in range(4):
+                    out = out_index(ib, a)
+                    planes = []
+                    for q in range(8):
+                        rb, reg = 2 * a + (q >> 2), q & 3
+                        acc = int(c_img[rb, ib, reg])
+                        for kb in range(4):
+                            for e in range(2):
+                                i0 = in_index(kb, e)
+                                for p in range(8):
+                                    d = A[out * 8 + q][i0 * 8 + p]
+                                    x0 = (xs[i0] >> (8 * p)) & 0xFF
+                                    x1 = (xs[i0 + 8] >> (8 * p)) & 0xFF
+                                    acc += d * (x0 - 128) + d * ((127 - x1) if a & 1 else (x1 - 128))
+                        assert 0 <= acc < (1 << 23)
+                        planes.append(acc)
+                    got = sum(v << (8 * q) for q, v in enumerate(planes)) % P
+                    assert got == sum(xs[j] * pow(w16, j * out, P) for j in range(16)) % P
             t256 = np.frombuffer(tw256, dtype=np.uint64).reshape(16, 256)
             t16 = np.frombuffer(tw16, dtype=np.uint64).reshape(16, 16)
             w256 = pow(w4096, 16, P)

@@ -179,16 +179,20 @@ def check_swizzle():
             for e in range(4):       # reads: element j = 8c + 2kb + eps; writes: output k = ib + 4a
                 c, eps = e >> 1, e & 1
                 j = lambda kb: 8 * c + 2 * kb + eps
-                k = lambda ib: ib + 4 * e
-                # the DIT kernel assigns its input slots and output rows through bitrev4 so that its reads and writes
-                # are these same two patterns (natural-side read, bit-reversed-side write) with the roles swapped
-                pats.append(("A nat", lambda n, q, G=G, j=j: j(q) * 256 + G + n))
-                pats.append(("A br", lambda n, q, G=G, k=k: br4(k(q)) * 256 + G + n))
+                # DIF: slot (c, kb, eps) = input j = 8c + 2kb + eps read at field j, row (ib, a) = output k = 4 ib + a written
+                # at field bitrev4(k).  DIT: slot = input kin = 8c + 4 eps + kb read at field bitrev4(kin), row = output
+                # j = (a & 1) + 2 ib + 8 (a >> 1) written at field j.
+                kd = lambda ib: 4 * ib + e
+                kin = lambda kb: 8 * c + 4 * eps + kb
+                jt = lambda ib: (e & 1) + 2 * ib + 8 * (e >> 1)
                 blk = 4 * w + m
-                pats.append(("B nat", lambda n, q, blk=blk, j=j: blk * 256 + j(q) * 16 + n))
-                pats.append(("B br", lambda n, q, blk=blk, k=k: blk * 256 + br4(k(q)) * 16 + n))
-                pats.append(("C nat", lambda n, q, G=G, j=j: (G + n) * 16 + j(q)))
-                pats.append(("C br", lambda n, q, G=G, k=k: (G + n) * 16 + br4(k(q))))
+                for tag, rf, wf in (("dif", j, lambda q: br4(kd(q))), ("dit", lambda q: br4(kin(q)), jt)):
+                    pats.append(("A rd " + tag, lambda n, q, G=G, rf=rf: rf(q) * 256 + G + n))
+                    pats.append(("A wr " + tag, lambda n, q, G=G, wf=wf: wf(q) * 256 + G + n))
+                    pats.append(("B rd " + tag, lambda n, q, blk=blk, rf=rf: blk * 256 + rf(q) * 16 + n))
+                    pats.append(("B wr " + tag, lambda n, q, blk=blk, wf=wf: blk * 256 + wf(q) * 16 + n))
+                    pats.append(("C rd " + tag, lambda n, q, G=G, rf=rf: (G + n) * 16 + rf(q)))
+                    pats.append(("C wr " + tag, lambda n, q, G=G, wf=wf: (G + n) * 16 + wf(q)))
     for i in range(16):              # coalesced staging: lane t of 256 takes position i * 256 + t
         for w in range(4):
             pats.append(("stage", lambda n, q, i=i, w=w: i * 256 + 64 * w + 16 * q + n))
