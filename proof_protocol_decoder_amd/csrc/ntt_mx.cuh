@@ -10,21 +10,24 @@
 // bytes of its inputs" is +-2^e or +-(2^a - 2^b): written in balanced base-256 digits it is an int8 matrix
 //     A[(k, q)][(j, p)] = digit q of (w16^(jk) * 2^(8p) mod p),      y_k = sum_q 2^(8q) * sum_(j,p) A * byte p of x_j,
 // 128 x 128, exact in the i32 accumulators (|sum| < 2^21).  One pass = 16 v_mfma_i32_16x16x64_i8 per 256 elements
-// (one per 16 elements, ~0.7 issue cycles per element) + per element: 2 XORs (byte x -> signed x - 128), the
+// (one per 16 elements; each blocks its SIMD for ~12 cycles, tools/mfma_probe.hip) + per element: 2 XORs (byte x -> signed x - 128), the
 // shift recombination of 8 plane sums (12 instructions, mx_arith.cuh) and ONE modular multiply by the inter-pass
 // twiddle: ~30 instructions per element and pass against 4 x 13.5 for four radix-2 stages.  tools/ntt_mx_model.py is
 // the integer model of all of this (digits, bias, pass structure, LDS swizzle).
 //
-// Layout of a pass.  A tile = 16 groups of 16 elements; lane (n = lane & 15, kb = lane >> 4) supplies elements
-// j = 2kb, 2kb+1 (K-chunk 0) and 8+2kb, 8+2kb+1 (chunk 1) of group n -- its registers as they are, XOR 0x80808080 --
-// and receives outputs k = ib + 4a (ib = lane >> 4, a = 0..3), digits 4h + reg of row block 2a + h.  Row constants
-// (C operand): a bias that is a multiple of p and makes every plane sum non-negative, plus 128 * the row's digit sum
-// (undoes the -128).  A wave does four tiles ("sets") per pass: 16 elements per lane, like the VALU kernels.
+// Layout of a pass.  A tile = 16 groups of 16 elements; lane (n = lane & 15, kb = lane >> 4) supplies four elements of
+// group n -- its registers as they are, XOR 0x80808080 -- two in K-chunk 0 and the two with index + 8 in chunk 1, and
+// receives four outputs, digits 4h + reg of row block 2a + h (a = 0..3).  Row constants (C operand): a bias that is a
+// multiple of p and makes every plane sum non-negative, plus the correction for the -128.  A wave does four tiles
+// ("sets") per pass: 16 elements per lane, like the VALU kernels.
 //   decimation in frequency (natural -> bit-reversed): pass S = 4096, 256, 16 on position blk*S + j*(S/16) + i:
-//     y_k = DFT16(x_j), times w_S^(i k), stored at blk*S + bitrev4(k)*(S/16) + i;
+//     y_k = DFT16(x_j), times w_S^(i k), stored at blk*S + bitrev4(k)*(S/16) + i; slot (chunk c, element eps) of lane
+//     kb is input j = 8c + 2kb + eps, row a of lane ib is output k = 4 ib + a;
 //   decimation in time (bit-reversed -> natural): the transposed pipeline, S = 16, 256, 4096, twiddle before the DFT;
-//     its input slots and output rows are assigned through bitrev4 so that its LDS accesses are the same two
-//     conflict-free patterns.
+//     slot = input kin = 8c + 4 eps + kb (found at field bitrev4(kin)), row = output j = (a & 1) + 2 ib + 8 (a >> 1).
+//   With these assignments every LDS access of a pass is bank-conflict free under one XOR swizzle (swz12; checked
+//   exhaustively by tools/ntt_mx_model.py), chunk 1 is "chunk 0's input + 8", and all rows of a tile have outputs of
+//   one parity (a & 1) -- which is what lets chunk 1 reuse chunk 0's A registers (Frag, below).
 // 2^13 / 2^14-point blocks: one / two radix-2 stages (VALU, the twiddles of ntt.hip) join 2 / 4 sub-blocks of 4096,
 // done in registers next to the outermost pass, which reads from / writes to global memory directly (128-byte runs).
 #pragma once
