@@ -78,6 +78,63 @@ mix_kernel(uint32_t* out, uint32_t seed) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// the same loop with other MFMA shapes: KIND 1 = v_mfma_i32_16x16x32_i8 (8-byte operands), 2 = v_mfma_i32_32x32x32_i8
+typedef int v16i __attribute__((ext_vector_type(16)));
+template <int NM, int WAVES_PER_EU, int KIND>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU, WAVES_PER_EU)))
+mix2_kernel(uint32_t* out, uint32_t seed) {
+  uint32_t b = seed + threadIdx.x, c = seed * 7 + 3;
+  uint64_t w[ACC];
+  v4i acc[NM], fa, fb;
+  v16i big[KIND == 2 ? 2 : 1];
+  long a8 = seed * 3 + threadIdx.x, b8 = seed * 5 + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < ACC; i++) w[i] = seed + i * 977 + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { fa[i] = seed * 3 + i + threadIdx.x; fb[i] = seed * 5 + i * threadIdx.x; }
+#pragma unroll
+  for (int i = 0; i < NM; i++) acc[i] = (v4i){0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 16; i++) { big[0][i] = 0; if (KIND == 2) big[KIND == 2 ? 1 : 0][i] = 0; }
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < ACC; i++) {
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(b), "v"(c) : "vcc");
+      if ((i % (ACC / NM)) == 0) {
+        const int m = i / (ACC / NM);
+        if (m < NM) {
+          if (KIND == 1) asm volatile("v_mfma_i32_16x16x32_i8 %0, %1, %2, %0" : "+v"(acc[m]) : "v"(a8), "v"(b8));
+          if (KIND == 2) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(big[m & 1]) : "v"(fa), "v"(fb));
+        }
+      }
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15");
+  uint32_t r = 0;
+#pragma unroll
+  for (int i = 0; i < ACC; i++) r ^= (uint32_t)w[i] ^ (uint32_t)(w[i] >> 32);
+#pragma unroll
+  for (int i = 0; i < NM; i++) r ^= acc[i][0] ^ acc[i][1] ^ acc[i][2] ^ acc[i][3];
+#pragma unroll
+  for (int i = 0; i < 16; i++) r ^= big[0][i] ^ big[KIND == 2 ? 1 : 0][i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int NM, int W, int KIND>
+static void run_mix2(int cus, uint32_t* out) {
+  const int blocks = cus * W;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  mix2_kernel<NM, W, KIND><<<blocks, 256>>>(out, 1);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int r = 0; r < 3; r++) {
+    hipEventRecord(e0); mix2_kernel<NM, W, KIND><<<blocks, 256>>>(out, r + 2); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+  }
+  printf("mix: %d waves/SIMD, 24 v_mad_u64_u32 + %d %s per iteration: %7.3f ms, %.1f cycles per iteration per SIMD (at 2.4 GHz)\n",
+         W, NM, KIND == 1 ? "mfma_16x16x32_i8" : "mfma_32x32x32_i8", best, best * 1e-3 * 2.4e9 / ((double)W * ITERS));
+}
+
 template <int NM, int W>
 static void run_mix(int cus, uint32_t* out) {
   const int blocks = cus * W;  // W blocks x 4 waves per CU = W waves per SIMD
@@ -158,6 +215,9 @@ int main() {
     const int cus = p.multiProcessorCount;
     run_mix<0, 8>(cus, out); run_mix<2, 8>(cus, out); run_mix<4, 8>(cus, out); run_mix<6, 8>(cus, out); run_mix<8, 8>(cus, out);
     run_mix<0, 2>(cus, out); run_mix<4, 2>(cus, out); run_mix<8, 2>(cus, out);
+    run_mix<0, 4>(cus, out); run_mix<4, 4>(cus, out); run_mix<8, 4>(cus, out);
+    run_mix<0, 3>(cus, out); run_mix<8, 3>(cus, out);
+    run_mix2<8, 2, 1>(cus, out); run_mix2<8, 4, 1>(cus, out); run_mix2<4, 2, 2>(cus, out); run_mix2<8, 2, 2>(cus, out);
     run_mix<0, 1>(cus, out); run_mix<4, 1>(cus, out);
   }
   return 0;
