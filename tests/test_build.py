@@ -12,7 +12,8 @@ def test_build_entry_compiles_everything():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.build()
-    for rel in ("proof_protocol_decoder_amd/lib/libbpg.so", "oracle/liboracle.so", "tools/microbench", "tools/wait_probe", "tools/issue_rate"):
+    for rel in ("proof_protocol_decoder_amd/lib/libbpg.so", "oracle/liboracle.so", "tools/microbench", "tools/wait_probe", "tools/issue_rate",
+                "tools/mfma_probe"):
         assert os.path.exists(os.path.join(ROOT, rel)), rel
 
 
