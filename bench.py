@@ -10,10 +10,16 @@ witness of each txn is generated on the GPU inside generate_txn_proof, as genera
 inside the reference's call (proof_gen.rs:44-52).
 
 Extra objects on the JSON line:
-  roofline      -- the LDE coset-NTT kernel (the HBM-roofline kernel the metric names), measured
-                   with HIP events on the kernel's own stream over the timed region;
+  roofline      -- the coset-LDE NTT kernel family (the HBM-roofline kernel the metric names): HIP events on the
+                   kernel's own stream over a single-stream leg run before the block (2 txn proofs, nothing else on
+                   the chip); traffic = algorithmic bytes x the PMC-measured ratio of a tracked profiles/ summary;
+  roofline_in_situ  -- the same launches inside the timed region (24 streams share the chip: not the kernel's cost);
   roofline_isolated -- the same kernel alone on the chip at the widest table shape;
-  cpu_baseline  -- the oracle (CPU restatement, OpenMP) proving ONE txn of the same block.
+  ntt_hbm_gbps  -- BASELINE's second figure: the batched inverse NTT alone at four shapes;
+  alu_kernel    -- Merkle leaf hashing (Poseidon; the time-dominant kernels, VALU-issue-bound) over the same leg, against
+                   the rate the same kernels reach with the chip full, measured in this run (poseidon_peak), and what
+                   that rate asks of the int8 matrix cores;
+  cpu_baseline  -- the oracle (CPU restatement, OpenMP) proving ONE txn of the same block on a warm state.
 """
 import argparse
 import ctypes as C
