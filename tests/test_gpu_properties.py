@@ -99,3 +99,50 @@ def test_same_inputs_same_proof_bytes(bpg):
     p2 = bpg.ops.stark_prove_synthetic(cfg, 99)
     p3 = bpg.ops.stark_prove_synthetic(cfg, 100)
     assert (p1 == p2).all() and (p1 != p3).any()
+
+
+def test_every_kernel_form_gives_the_same_commitment_on_random_shapes(bpg):
+    """Differential test of the Poseidon kernel families on shapes the oracle-backed tests do not list: the
+    matrix-core forms (4 / 2 / 1 sets of 16 states per wave, and the size-dependent mix), one lane per state and the
+    quad-cooperative kernels must produce the same digest buffer for ragged widths (absorb tails of 1..7 words,
+    hash_or_noop rows of <= 4 columns), leaf counts below one wave and cap heights up to the leaf level."""
+    rng = np.random.default_rng(20261004)
+    L = bpg.lib()
+    shapes = [(int(rng.integers(0, 12)), int(rng.integers(0, 3)), int(rng.integers(1, 41))) for _ in range(40)]
+    shapes += [(0, 0, 1), (0, 0, 9), (1, 0, 5), (2, 1, 4), (13, 1, 23), (14, 1, 8), (11, 3, 17)]
+    try:
+        for log_n, rate_bits, n_cols in shapes:
+            rows = 1 << (log_n + rate_bits)
+            cap_h = int(rng.integers(0, min(4, log_n + rate_bits) + 1))
+            lde = to_dev(rand_field(rng, (n_cols, rows)))
+            got = {}
+            for form, (mx, sets, thr) in {"lane": (0, 0, 1), "quad": (0, 0, 1 << 40), "mx4": (1, 4, 1), "mx2": (1, 2, 1),
+                                          "mx1": (1, 1, 1), "mx": (1, 0, max(2, rows // 2))}.items():
+                L.bp_tune_poseidon_mx(mx)
+                L.bp_tune_poseidon_mx_sets(sets)
+                L.bp_tune_quad_threshold(thr)
+                got[form] = to_host(bpg.ops.merkle_commit(lde, log_n, rate_bits, cap_h))
+            for form, dig in got.items():
+                assert (dig == got["lane"]).all(), (form, log_n, rate_bits, n_cols, cap_h)
+    finally:
+        L.bp_tune_poseidon_mx(1)
+        L.bp_tune_poseidon_mx_sets(0)
+        L.bp_tune_quad_threshold(0)
+
+
+def test_permutation_forms_agree_on_a_large_random_batch(bpg):
+    rng = np.random.default_rng(77)
+    L = bpg.lib()
+    s = rng.integers(0, 1 << 64, (100003, 12), dtype=np.uint64)   # non-canonical words included, ragged tail
+    try:
+        outs = []
+        for mx, sets in ((0, 0), (1, 4), (1, 2), (1, 1)):
+            L.bp_tune_poseidon_mx(mx)
+            L.bp_tune_poseidon_mx_sets(sets)
+            outs.append(to_host(bpg.ops.poseidon_perm_batch_(to_dev(s.copy()))))
+        for o in outs[1:]:
+            assert (o == outs[0]).all()
+        assert (outs[0] < np.uint64(P)).all()
+    finally:
+        L.bp_tune_poseidon_mx(1)
+        L.bp_tune_poseidon_mx_sets(0)
