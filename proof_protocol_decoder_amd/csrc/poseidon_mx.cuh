@@ -8,10 +8,11 @@
 // -- and it is exact on the int8 MFMA: split every state word into its 8 BYTES (the register bytes as they are: no
 // data movement), multiply each byte plane by the matrix (products < 2^14, row sums < 2^17 in the i32 accumulators),
 // and recombine the 8 plane sums of a word with shifts: y = sum_p a_p * 2^(8p) (mod p).  That replaces 28 VALU
-// instructions per output word by 12, and the MFMA pipe was idle.
+// instructions per output word by 12, and the MFMA pipe was idle.  An MFMA is not free next to VALU work on this
+// chip (~10 SIMD cycles each, tools/mfma_probe.hip), but one replaces about twenty multiply-adds here.
 //
-// Layout.  A wave owns 16 * NS states as NS (4, 2 or 1) "sets" of 16.  Lane l = (n = l & 15, kb = l >> 4) holds, for every set m,
-// words kb, kb + 4, kb + 8 of state 16m + n: e[m][a] = word kb + 4a.  This is exactly the operand map of
+// Layout.  A wave owns 16 * NS states as NS (4, 2 or 1) "sets" of 16.  Lane l = (n = l & 15, kb = l >> 4) holds, for
+// every set m, words kb, kb + 4, kb + 8 of state 16m + n: e[m][a] = word kb + 4a.  This is exactly the operand map of
 // v_mfma_i32_16x16x64_i8 (checked on the device, tools/mfma_probe.hip): B[k][col]: lane (col = l & 15, k-block l >> 4)
 // supplies 16 bytes, A[row][k] likewise with row = l & 15, products are paired by (k-block, byte), and the result
 // D[row][col] lands in lane (col, row >> 2), register row & 3.
@@ -20,7 +21,8 @@
 //   A operand of output slot g (constant, 3 x 4 VGPRs): lane (r, kb), dword a = M[(r >> 2) + 4g][kb + 4a] << 8(r & 3):
 //     row r of the tile is (output word (r >> 2) + 4g, plane r & 3 of the half) and takes only that plane's bytes.
 //   C operand: 128 * rowsum (undoes the -128) + the matching byte of the NEXT round's constant: the constant layer
-//     rides in the accumulators exactly as in the one-lane form.  30 x 4 x 24 dwords, built in LDS per workgroup.
+//     rides in the accumulators exactly as in the one-lane form.  30 x 4 x 24 dwords, a compile-time table each
+//     workgroup copies into LDS.
 //   D of (g, h): lane (n, ib) register reg = plane 4h + reg of output word ib + 4g of state n -- the layout the state
 //     had: no lane ever moves data in the MDS layer.
 // Six MFMAs per set and round.  Partial rounds: word 0 of the four sets sits in lanes 0..15 of four registers; three
