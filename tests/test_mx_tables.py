@@ -66,6 +66,13 @@ def test_mds_on_byte_planes_equals_the_field_mds():
         assert got == want
 
 
+def test_partial_round_linear_forms_model():
+    """groundwork for a cheaper partial-round form: the 22 S-box inputs as linear forms of the
+    11 untouched words and the earlier S-box outputs reproduce the plain rounds"""
+    import poseidon_partial_model
+    poseidon_partial_model.main()
+
+
 def test_ntt_mx_integer_model():
     import ntt_mx_model
     ntt_mx_model.main()            # DFT16 on byte planes, three-pass DIF / DIT pipelines, accumulator bounds
