@@ -122,7 +122,8 @@ void bp_tune_poseidon_mx_sets(int sets);
 void bp_tune_ntt_split(int mode);
 /* NTT blocks as three radix-16 passes whose 16-point DFTs are int8 MFMAs on the bytes of the elements
  * (csrc/ntt_mx.cuh): 0 = never (the VALU butterfly kernels everywhere), 1 = 2^12- and 2^13-point blocks, 2 = 2^14-point
- * blocks too, 3 (default) = 2^13-point blocks while fewer than 6 provers are at work on the device.  Alone
+ * blocks too, 3 (default) = 2^13-point blocks while fewer than 6 provers are at work on the device, 4 / 5 = like 1 for
+ * the inverse (DIF) / forward (DIT) direction only (measurement).  Alone
  * on the chip the form is level to +17 %; under the multi-stream block run its register footprint loses 12 %
  * (DESIGN.md section 7).  Results are identical either way. */
 void bp_tune_ntt_mx(int mode);

@@ -815,9 +815,11 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
 // over the VALU kernels on this workload, so it is used only where it measures ahead.
 bool device_loaded();  // hash_kernels.hip
 static std::atomic<int> g_ntt_mx{3};
-static bool use_ntt_mx(uint32_t log_blk) {
+static bool use_ntt_mx(uint32_t log_blk, bool dit) {
   const int m = g_ntt_mx.load(std::memory_order_relaxed);
   if (m == 3) return log_blk == 13 && !device_loaded();
+  if (m == 4) return !dit && log_blk <= 13;   // measurement modes: one direction only
+  if (m == 5) return dit && log_blk <= 13;
   return m == 2 || (m == 1 && log_blk <= 13);
 }
 // Constants of the matrix-core kernels, one device image per (device, kind, direction), built once.
@@ -969,7 +971,7 @@ int intt_nat2br(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t 
     b.tw = tw_b; b.scale = nullptr; b.out_scalar = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
     b.log_n_total = log_n; b.n_cosets = 1; b.n_units = 0;
     KernelTimer kt(PROF_INTT_DIF, st, 16.0 * (double)n_cols * (double)((uint64_t)1 << log_n));
-    if (use_ntt_mx(log_blk)) {
+    if (use_ntt_mx(log_blk, false)) {
       const mxn::Tables* tab = nullptr;
       if ((rc = get_mx_tables(0, inverse, &tab))) return rc;
       b.n_units = n_cols << (log_n - log_blk);
@@ -1026,7 +1028,7 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
     b.n_units = n_cols << (log_n - log_blk);
     {
       KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
-      if (use_ntt_mx(log_blk)) {
+      if (use_ntt_mx(log_blk, true)) {
         const mxn::Tables* tab = nullptr;
         if ((rc = get_mx_tables(1, inverse, &tab))) return rc;
         const uint32_t g = mx_grid((b.n_units + 7) / 8 * 8 * n_cosets, log_blk);
@@ -1116,7 +1118,7 @@ int init_ntt_kernels() {
 extern "C" {
 
 void bp_tune_ntt_split(int mode) { bpg::g_ntt_split.store(mode); }
-void bp_tune_ntt_mx(int mode) { bpg::g_ntt_mx.store(mode < 0 || mode > 3 ? 3 : mode); }
+void bp_tune_ntt_mx(int mode) { bpg::g_ntt_mx.store(mode < 0 || mode > 5 ? 3 : mode); }
 void bp_tune_ntt_mx_wg_per_cu(int n) { bpg::g_mx_wg_per_cu.store(n); }
 
 // Host only (no device call): the constants of the matrix-core NTT kernels as the device gets them, for the CPU tests
