@@ -80,7 +80,28 @@ def main():
     ap.add_argument("--poseidon-mx", type=int, default=None, help="bp_tune_poseidon_mx (measurement knob)")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
                     help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
+    ap.add_argument("--leg-only", action="store_true",
+                    help="(internal) run only the alone-on-the-chip measurements -- single-stream roofline leg, isolated "
+                         "LDE, inverse-NTT sweep, Poseidon peak -- and print them as one JSON object; the main run "
+                         "starts this as a fresh child process AFTER its timed region")
+    ap.add_argument("--leg-first", action="store_true",
+                    help="(measurement knob) round 2's order: the single-stream leg in this process BEFORE the block")
     args = ap.parse_args()
+    if args.txns < 2:
+        raise SystemExit("--txns must be >= 2 (a block needs an aggregation: decoding.rs:304-347 pads to two)")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` without a launcher: this process has not touched the GPU (no torch.cuda, no
+        # bp_* call yet) and starts the N ranks itself as fresh children, relays rank 0's JSON line and exits with
+        # the launcher's code.  Under torch.distributed.run (WORLD_SIZE set) this branch is never taken.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     import torch
     import torch.distributed as dist
@@ -88,7 +109,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # BPG_SHARE_GPU=1 is a rehearsal mode for a 1-GPU box: all ranks use device 0 and the gather runs
     # over gloo (RCCL needs one device per rank).  The driver's real runs never set it.
     if args.threads <= 0:
@@ -101,6 +122,8 @@ def main():
     share = os.environ.get("BPG_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    if args.leg_only:
+        local_rank = int(os.environ.get("BPG_LEG_DEVICE", local_rank))
     # host waits must sleep, not spin (tools/wait_probe.hip): set before torch creates the device context
     import proof_protocol_decoder_amd as _pkg0
     _pkg0.lib().bp_use_blocking_sync(local_rank)
@@ -162,12 +185,10 @@ def main():
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "perms_per_launch": round(perms.value / n.value)}
 
-    # ---- roofline leg (rank 0), BEFORE the block run: the same workload with ONE prover stream on a fresh
-    # device, so every launch of the kernel has the chip to itself and event time == kernel time (this is what
-    # the rocprof summary in profiles/ is taken from).  Measured after the 24-stream region the same leg read
-    # anything from 1x to 0.5x of this figure.
-    roofline = alu_kernel = None
-    if not args.no_profile and rank == 0:
+    def single_stream_leg():
+        """The same workload with ONE prover stream and nothing else on the chip, so every launch of the kernel
+        has the device to itself and event time == kernel time (this is what the rocprof summary in profiles/ is
+        taken from)."""
         solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=5 << 30).build()
         solo_driver = BlockDriver(solo, n_threads=1)
         irs = synthetic_block_irs(1000, 2, S1_LOG_N, S1_WIDTH)
@@ -185,11 +206,26 @@ def main():
         L.bp_profile_enable(0)
         L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
         torch.cuda.synchronize()
-        roofline = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one "
-                               "stream (no co-running kernels); all 29 proofs x 3 commitments x tables per txn")
-        alu_kernel = read_leaf_hash()
+        roof = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one "
+                           "stream (no co-running kernels); all 29 proofs x 3 commitments x tables per txn")
+        alu = read_leaf_hash()
         solo_driver.close()
         solo.close()
+        return roof, alu
+
+    if args.leg_only:
+        # child mode: everything that is measured alone on the chip, in a process of its own
+        roof, alu = single_stream_leg()
+        out = {"roofline": roof, "alu_kernel": alu, "roofline_isolated": isolated_roofline(pkg, torch),
+               "ntt_hbm_gbps": ntt_gbps(pkg, torch)}
+        if alu:
+            finish_alu_kernel(alu, poseidon_peak(pkg, torch))
+        print(json.dumps(out), flush=True)
+        return
+
+    roofline = alu_kernel = None
+    if args.leg_first and not args.no_profile and rank == 0:
+        roofline, alu_kernel = single_stream_leg()
 
     t_build = time.time()
     # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
@@ -233,43 +269,113 @@ def main():
     if rank == 0:
         # acceptance: the block proof verifies (VerifierState::verify, verifier_state.rs:56-71)
         pg.VerifierState.from_prover_state(state).verify(last)
-        out = {
-            "metric": "txn-proofs/sec (whole node), 256-txn synthetic block",
-            "value": round(args.txns * args.steps / dt, 3), "unit": "txn-proofs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 2),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64 (Goldilocks field)",
-            "data": "synthetic",
-            "config": {"workload": "%d-txn synthetic block, S1 transfer-txn tables logN=%s widths=%s, 7 table STARKs "
-                                   "+ 22 recursion-shaped proofs per txn, %d agg proofs + 1 block proof per block"
-                                   % (args.txns, list(S1_LOG_N), list(S1_WIDTH), args.txns - 1),
-                       "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
-                       "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
-                       "state_build_s": round(t_build, 2), "state_device_gib": round(state.device_bytes / 2**30, 2)},
-            "roofline": roofline, "roofline_in_situ": roofline_in_situ, "alu_kernel": alu_kernel,
-        }
-        if world == 1:
-            out["roofline_isolated"] = isolated_roofline(pkg, torch)
-            out["ntt_hbm_gbps"] = ntt_gbps(pkg, torch)
-            if alu_kernel:
-                # fraction of the rate the same kernels reach with the chip full (every SIMD's VALU port busy:
-                # DESIGN.md section 7), measured now rather than quoted
-                peak = poseidon_peak(pkg, torch)
-                alu_kernel["peak_measured"] = peak
-                alu_kernel["valu_issue_frac"] = round(alu_kernel["achieved"] / peak, 3)
-                # what the MDS layer asks of the matrix cores at that rate: 30 rounds x 6 v_mfma_i32_16x16x64_i8
-                # (32768 int8 ops each) per 16 states.  Informational: the kernel is bound by VALU issue, and three
-                # quarters of these multiplies are by the zeros of a plane-diagonal matrix.
-                INT8_DENSE_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md: I8 = 2 x the BF16 rate per clock
-                tops = peak * 1e9 * 30 * 6 * 32768 / 16 / 1e12
-                alu_kernel["mfma_int8"] = {"achieved_at_peak_rate": round(tops, 1), "peak": INT8_DENSE_PEAK_TOPS,
-                                           "unit": "TOP/s", "frac": round(tops / INT8_DENSE_PEAK_TOPS, 3)}
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0])
-        print(json.dumps(out), flush=True)
+    t_build_info = {"state_build_s": round(t_build, 2), "state_device_gib": round(state.device_bytes / 2**30, 2)}
     driver.close()
     state.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+
+    out = {
+        "metric": "txn-proofs/sec (whole node), %d-txn synthetic block" % args.txns,
+        "value": round(args.txns * args.steps / dt, 3), "unit": "txn-proofs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64 (Goldilocks field)",
+        "data": "synthetic",
+        "config": {"workload": "%d-txn synthetic block, S1 transfer-txn tables logN=%s widths=%s, 7 table STARKs "
+                               "+ 22 recursion-shaped proofs per txn, %d agg proofs + 1 block proof per block"
+                               % (args.txns, list(S1_LOG_N), list(S1_WIDTH), args.txns - 1),
+                   "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
+                   "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
+                   **t_build_info},
+    }
+    alone = {}
+    if not args.no_profile:
+        if args.leg_first:
+            alone = {"roofline": roofline, "alu_kernel": alu_kernel}
+            if world == 1:
+                alone["roofline_isolated"] = isolated_roofline(pkg, torch)
+                alone["ntt_hbm_gbps"] = ntt_gbps(pkg, torch)
+                if alu_kernel:
+                    finish_alu_kernel(alu_kernel, poseidon_peak(pkg, torch))
+        else:
+            # Everything that is measured ALONE on the chip runs after the timed region, in a fresh child process:
+            # this process's prover state is closed (its 126 GiB are back), every other rank has passed the
+            # barrier above, and the timed region itself always starts on a device nothing has run on -- so
+            # `value` is the same number with and without --no-profile.
+            import subprocess
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            env["BPG_LEG_DEVICE"] = str(local_rank)
+            knobs = []
+            for flag, val in (("--merkle-fused", args.merkle_fused), ("--ntt-split", args.ntt_split),
+                              ("--ntt-mx", args.ntt_mx), ("--poseidon-mx", args.poseidon_mx),
+                              ("--quad-threshold-log2", args.quad_threshold_log2)):
+                if val is not None:
+                    knobs += [flag, str(val)]
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg-only"] + knobs, env=env,
+                               stdout=subprocess.PIPE, text=True)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise SystemExit("the --leg-only child failed (exit %d)" % r.returncode)
+            alone = json.loads(lines[-1])
+    out["roofline"] = alone.get("roofline")
+    out["roofline_in_situ"] = roofline_in_situ
+    out["alu_kernel"] = alone.get("alu_kernel")
+    for k in ("roofline_isolated", "ntt_hbm_gbps"):
+        if k in alone:
+            out[k] = alone[k]
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0])
+    print(json.dumps(out), flush=True)
+
+
+# Hardware ceiling of a VALU-issue-bound kernel: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every
+# 4 cycles (a SIMD has 16 lanes), at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md).
+N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
+VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * PEAK_CLOCK_HZ / 4
+SQ_FILE = os.path.join("profiles", "r2b_hash_sq_counters.txt")
+
+
+def valu_insts_per_perm():
+    """VALU wave-instructions per Poseidon permutation of leaf_hash_mx_kernel<4>, from the tracked SQ-counter
+    summary (rocprofv3 --pmc SQ_INSTS_VALU over 2^21 rows x 8 permutations; tools/prof_hash_counters.sh)."""
+    import re
+    try:
+        txt = open(os.path.join(ROOT, SQ_FILE)).read()
+        blk = txt[txt.index("leaf_hash_mx_kernel<4>"):]
+        insts = float(re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+)", blk).group(1))
+        mfma = float(re.search(r"SQ_INSTS_MFMA\s+([0-9.e+]+)", blk).group(1))
+        m = re.search(r"([0-9.e+]+) permutations", txt)
+        perms = float(m.group(1)) if m else float((1 << 21) * 8)
+        return insts / perms, mfma / perms
+    except (OSError, AttributeError, ValueError):
+        return None, None
+
+
+def finish_alu_kernel(alu, peak):
+    """Anchor the Poseidon family to the hardware's VALU issue rate (not to its own best run): wave-instructions
+    per second = Gperm/s x instructions per permutation (SQ counters, tracked file) against SIMDs x clock / 4."""
+    per_perm, mfma_per_perm = valu_insts_per_perm()
+    alu["peak_measured"] = peak
+    alu["frac_of_peak_measured"] = round(alu["achieved"] / peak, 3)
+    if per_perm:
+        alu["valu_insts_per_perm"] = round(per_perm, 1)
+        alu["mfma_insts_per_perm"] = round(mfma_per_perm, 2)
+        alu["valu_insts_source"] = SQ_FILE
+        alu["valu_issue_peak_insts_per_s"] = VALU_PEAK_WAVE_INSTS_PER_S
+        alu["valu_issue_frac"] = round(alu["achieved"] * 1e9 * per_perm / VALU_PEAK_WAVE_INSTS_PER_S, 3)
+        alu["valu_issue_frac_chip_full"] = round(peak * 1e9 * per_perm / VALU_PEAK_WAVE_INSTS_PER_S, 3)
+    # what the MDS layer asks of the matrix cores at the chip-full rate: 30 rounds x 6 v_mfma_i32_16x16x64_i8
+    # (32768 int8 ops each) per 16 states.  Informational: the kernel is bound by VALU issue, and three
+    # quarters of these multiplies are by the zeros of a plane-diagonal matrix.
+    INT8_DENSE_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md: I8 = 2 x the BF16 rate per clock
+    tops = peak * 1e9 * 30 * 6 * 32768 / 16 / 1e12
+    alu["mfma_int8"] = {"achieved_at_peak_rate": round(tops, 1), "peak": INT8_DENSE_PEAK_TOPS,
+                        "unit": "TOP/s", "frac": round(tops / INT8_DENSE_PEAK_TOPS, 3)}
 
 
 def isolated_roofline(pkg, torch):

@@ -79,8 +79,11 @@ int bp_intt_batch(const uint64_t* d_values, uint64_t in_stride, uint64_t* d_coef
 
 /* K2.  PolynomialBatch::from_values / from_coeffs low-degree extension.
  *   d_in: n_cols columns of n values (natural) or, if from_coeffs, n coefficients (bit-reversed);
- *   d_coeffs_out (nullable unless !from_coeffs... may alias nothing): n_cols x n coefficients, bit-reversed;
- *   d_lde_out: n_cols x (n << rate_bits), coset-major.  Strides in elements. */
+ *   d_coeffs_out (nullable if from_coeffs): n_cols x n coefficients, bit-reversed; the same pointer as d_in
+ *   (in place) or not overlapping it;
+ *   d_lde_out: n_cols x (n << rate_bits), coset-major, overlapping neither.  Strides in elements.
+ * Inputs may be any u64 (reduced mod p on the way in), outputs are canonical; overlapping buffers are refused
+ * with BP_ERR_INVALID_INPUT. */
 int bp_lde_batch(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_coeffs_out, uint64_t coeffs_stride,
                  uint64_t* d_lde_out, uint64_t lde_stride, uint32_t log_n, uint32_t rate_bits,
                  uint32_t n_cols, int from_coeffs, void* stream);

@@ -418,8 +418,9 @@ __global__ void __launch_bounds__((1 << L) / 16) ntt16_dif_kernel(Ntt16Args a) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         lo[i] = src[(m0 + i) * T + t];
-        hi[i] = src[(m0 + i) * T + t + (1u << L)];  // canonical (memory invariant)
+        hi[i] = src[(m0 + i) * T + t + (1u << L)];
       }
+      gl::canon_n<4>(hi);  // add_n / sub_n want b < p; caller memory may hold any u64 (bpg.h)
       if (h == 0) {
         gl::add_n<4>(lo, hi, r);
       } else {
@@ -542,6 +543,8 @@ __global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per
         gl::canon_n<4>(p1);
 #pragma unroll
         for (int i = 0; i < 4; i++) { c0[i] = p0[i]; c1[i] = p1[i]; }
+      } else {
+        gl::canon_n<4>(c1);  // unscaled: straight from caller memory, any u64
       }
       if (h == 0) {
         gl::add_n<4>(c0, c1, r);
@@ -1194,6 +1197,18 @@ int bp_lde_batch(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_coeffs_ou
   if (log_n + rate_bits > 30 || rate_bits > 4 || in_stride < n || lde_stride < (n << rate_bits) ||
       (d_coeffs_out && coeffs_stride < n))
     return bpg::fail(BP_ERR_INVALID_INPUT, "bp_lde_batch: bad shape (log_n=%u rate_bits=%u)", log_n, rate_bits);
+  if (d_coeffs_out && d_coeffs_out != d_in) {  // as bp_intt_batch: the split kernels read a block while its partner stores
+    const uint64_t span_in = in_stride * (n_cols - 1) + n, span_c = coeffs_stride * (n_cols - 1) + n;
+    if (d_in < d_coeffs_out + span_c && d_coeffs_out < d_in + span_in)
+      return bpg::fail(BP_ERR_INVALID_INPUT, "bp_lde_batch: input and coefficient buffers overlap (use the same pointer for in place)");
+  }
+  {
+    const uint64_t* src = from_coeffs ? d_in : d_coeffs_out;  // what the forward transform reads
+    const uint64_t span_s = (from_coeffs ? in_stride : coeffs_stride) * (n_cols - 1) + n;
+    const uint64_t span_l = lde_stride * (n_cols - 1) + (n << rate_bits);
+    if (src < d_lde_out + span_l && d_lde_out < src + span_s)
+      return bpg::fail(BP_ERR_INVALID_INPUT, "bp_lde_batch: the LDE output overlaps the coefficients it is computed from");
+  }
   hipStream_t st = bpg::as_stream(stream);
   int rc;
   if ((rc = bpg::init_ntt_kernels())) return rc;

@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <deque>
 #include <set>
@@ -234,8 +235,7 @@ bool produced_here(const bp_state* s, const uint8_t* bytes, size_t len) {
   return s->seen.count(h) != 0;
 }
 
-int verify_child(const bp_state* s, const Box& b, const char* what, const uint8_t* bytes, size_t len) {
-  if (produced_here(s, bytes, len)) return BP_OK;
+int verify_foreign(const bp_state* s, const Box& b, const char* what) {
   if (b.circuit != CIRCUIT_ROOT + b.kind)
     return fail(BP_ERR_VERIFY, "%s was made by circuit %llu, expected %u", what, (unsigned long long)b.circuit,
                 CIRCUIT_ROOT + (uint32_t)b.kind);
@@ -250,6 +250,10 @@ int verify_child(const bp_state* s, const Box& b, const char* what, const uint8_
     return fail(BP_ERR_VERIFY, "%s does not verify: %s", what, why.c_str());
   }
   return BP_OK;
+}
+
+int verify_child(const bp_state* s, const Box& b, const char* what, const uint8_t* bytes, size_t len) {
+  return produced_here(s, bytes, len) ? BP_OK : verify_foreign(s, b, what);
 }
 
 void root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]) {
@@ -301,7 +305,31 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
   // persistent memory: per circuit K*n values + K*n coeffs + K*m LDE + digests
   const uint64_t N = (uint64_t)1 << rc.log_n, M = N << rc.rate_bits;
   const size_t per = ((size_t)rc.n_const * (2 * N + M) + 2 * M * 4 + 4096) * 8;
-  if ((r = s->builder.init(cfg->device, per * (n_circ + 3) + (64u << 20)))) return r;
+  const size_t circuits_bytes = per * (n_circ + 3) + (64u << 20);
+  {
+    // size the whole state against the device BEFORE the first allocation: a late hipMalloc failure would name one
+    // arena, not the configuration that does not fit
+    (void)hipSetDevice(cfg->device);
+    size_t free_b = 0, total_b = 0;
+    BPG_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double need = (double)circuits_bytes + (double)cfg->n_workers * (double)cfg->arena_bytes;
+    if (need > (double)free_b)
+      return fail(BP_ERR_DEVICE,
+                  "prover state does not fit device %d: %u preprocessed circuits %.1f GiB + %u prover arenas x %.1f GiB = "
+                  "%.1f GiB, %.1f GiB free of %.1f GiB (lower n_workers or arena_bytes, or narrow the table ranges)",
+                  cfg->device, n_circ + 3, circuits_bytes / 1073741824.0, cfg->n_workers,
+                  cfg->arena_bytes / 1073741824.0, need / 1073741824.0, free_b / 1073741824.0, total_b / 1073741824.0);
+  }
+  // from here on device memory is owned by *s: release it on every early return
+  struct Unbuild {
+    std::unique_ptr<bp_state>& s;
+    ~Unbuild() {
+      if (!s) return;
+      for (auto& w : s->workers) w->destroy();
+      s->builder.destroy();
+    }
+  } unbuild{s};
+  if ((r = s->builder.init(cfg->device, circuits_bytes))) return r;
   s->table_circuits.resize(n_circ);
   uint32_t idx = 0;
   for (int t = 0; t < BP_NUM_TABLES; t++) {
@@ -536,24 +564,38 @@ int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len,
   if (L.pv[3] != R.pv[2] || std::memcmp(L.pv + 8, R.pv + 4, 32) != 0 || L.pv[12] != R.pv[12])
     return fail(BP_ERR_INVALID_INPUT, "children public values do not chain (gas / state root / block number)");
   {
-    // the two children are verified side by side (10 ms of host Poseidon each when they were not produced here,
-    // e.g. the sub-block proofs gathered from other ranks): the helper's message is thread-local, so it is carried over
+    // A child this state produced is recognised by its hash and costs one Keccak; only two FOREIGN children (the
+    // sub-block proofs gathered from other ranks, 10 ms of host Poseidon each) are verified side by side.  The
+    // helper's message is thread-local, so it is carried over; the guard joins on every way out of the scope, so
+    // an exception on this thread cannot reach a joinable std::thread's destructor (std::terminate).
+    const bool l_known = produced_here(s, lhs, lhs_len), r_known = produced_here(s, rhs, rhs_len);
     int r_rhs = BP_OK;
-    std::string rhs_err;
+    std::string lhs_err, rhs_err;
     std::thread helper;
-    bool threaded = false;
-    try {
-      helper = std::thread([&] {
-        r_rhs = verify_child(s, R, "rhs child proof", rhs, rhs_len);
-        if (r_rhs) rhs_err = bp_last_error();
-      });
-      threaded = true;
-    } catch (...) {  // no thread to be had: verify in this one
+    struct Joiner {
+      std::thread& t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{helper};
+    bool rhs_done = r_known;
+    if (!l_known && !r_known) {
+      try {
+        helper = std::thread([&] {
+          try {
+            r_rhs = verify_foreign(s, R, "rhs child proof");
+            if (r_rhs) rhs_err = bp_last_error();
+          } catch (...) {
+            r_rhs = BP_ERR_DEVICE;
+            rhs_err = "rhs child proof: out of memory while verifying";
+          }
+        });
+        rhs_done = true;
+      } catch (const std::system_error&) {  // no thread to be had: verify in this one
+      }
     }
-    r = verify_child(s, L, "lhs child proof", lhs, lhs_len);
-    const std::string lhs_err = r ? bp_last_error() : "";
-    if (threaded) helper.join();
-    else if ((r_rhs = verify_child(s, R, "rhs child proof", rhs, rhs_len))) rhs_err = bp_last_error();
+    r = l_known ? BP_OK : verify_foreign(s, L, "lhs child proof");
+    if (r) lhs_err = bp_last_error();
+    if (helper.joinable()) helper.join();
+    if (!rhs_done && (r_rhs = verify_foreign(s, R, "rhs child proof"))) rhs_err = bp_last_error();
     if (r) return fail(r, "%s", lhs_err.c_str());
     if (r_rhs) return fail(r_rhs, "%s", rhs_err.c_str());
   }

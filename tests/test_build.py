@@ -4,8 +4,11 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the code-generation flags of csrc/Makefile
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+import subprocess
+
+# the code-generation flags csrc/Makefile gives the kernel sources (it probes the optional MFMA form flag)
+HIPCC_FLAGS = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc"),
+                              "print-hip-flags"], check=True, capture_output=True, text=True).stdout.split()
 
 
 def test_build_entry_compiles_everything():
@@ -103,3 +106,116 @@ def test_no_dpp_reads_a_fresh_asm_result(tmp_path):
                 recent.append((0, _vregs(operands[0]) | (_vregs(operands[1]) if is_swap and len(operands) > 1 else set())))
         assert n_dpp > 0 or src != "hash_kernels.hip", "scanner found no DPP instruction in " + src
     assert not bad, bad
+
+
+def _sregs(tok):
+    """scalar registers named by one operand token: s7 -> {7}, s[4:5] -> {4, 5}, vcc -> {"vcc"}"""
+    import re
+    tok = tok.split()[0] if tok.split() else tok
+    m = re.fullmatch(r"s(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    if tok in ("vcc", "vcc_lo", "vcc_hi"):
+        return {"vcc"}
+    return set()
+
+
+def scan_carry_mask_hazards(text):
+    """-> (violations, number of VALU writes of scalar registers inside asm regions) for one device assembly text."""
+    import re
+    bad, n_asm_writes = [], 0
+    in_asm = False
+    recent = []  # (wait states since the write, scalar registers written by a VALU instruction inside asm)
+    for ln, line in enumerate(text.splitlines(), 1):
+        t = line.strip()
+        if "ASMSTART" in t and t.startswith(";"):
+            in_asm = True
+            continue
+        if "ASMEND" in t and t.startswith(";"):
+            in_asm = False
+            continue
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        if not re.match(r"[sv]_|ds_|global_|buffer_|flat_|scratch_", op):
+            continue
+        operands = [x.strip() for x in t[len(op):].split(";")[0].split(",")]
+        states = int(operands[0], 0) + 1 if op == "s_nop" else 1
+        n_dst = 2 if ("_co_" in op or op.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_div_scale"))) else 1
+        if op.startswith("v_"):
+            reads = set()
+            for o in operands[n_dst:]:
+                reads |= _sregs(o)
+            for age, regs in recent:
+                if age < 2 and regs & reads:
+                    bad.append((ln, t))
+        if op.startswith("s_") and operands and not op.startswith(("s_nop", "s_cmp", "s_waitcnt", "s_cbranch")):
+            # a scalar-unit write replaces the mask: the later read is of THAT value (no VALU-write hazard)
+            over = _sregs(operands[0])
+            recent = [(age, regs - over) for age, regs in recent]
+        recent = [(age + states, regs) for age, regs in recent if age + states < 2 and regs]
+        if in_asm and op.startswith("v_"):
+            written = set()
+            for o in operands[:n_dst]:
+                written |= _sregs(o)
+            if written:
+                n_asm_writes += 1
+                recent.append((0, written))
+    return bad, n_asm_writes
+
+
+def test_carry_mask_scanner_sees_a_violation():
+    ok = """
+	;;#ASMSTART
+	v_add_co_u32_e64 v3, s[8:9], v3, v4
+	v_add_co_u32_e64 v5, s[10:11], v5, v6
+	v_add_co_u32_e64 v7, s[12:13], v7, v8
+	v_addc_co_u32_e64 v4, s[8:9], v5, v1, s[8:9]
+	;;#ASMEND
+	;;#ASMSTART
+	v_add_co_u32_e64 v3, s[8:9], v3, v4
+	;;#ASMEND
+	;;#ASMSTART
+	s_nop 1
+	v_addc_co_u32_e64 v4, s[8:9], v5, v1, s[8:9]
+	;;#ASMEND
+	;;#ASMSTART
+	v_add_co_u32_e64 v3, s[6:7], v3, v4
+	;;#ASMEND
+	s_mov_b64 s[6:7], 0xffffffff
+	v_lshl_add_u64 v[6:7], v[2:3], 0, s[6:7]
+"""
+    assert scan_carry_mask_hazards(ok) == ([], 7)
+    for between in ("", "\tv_mov_b32 v9, v10\n", "\ts_nop 0\n"):
+        bad_text = ("\t;;#ASMSTART\n\tv_add_co_u32_e64 v3, s[8:9], v3, v4\n\t;;#ASMEND\n" + between +
+                    "\tv_cndmask_b32_e64 v1, v2, v3, s[8:9]\n")
+        bad, n = scan_carry_mask_hazards(bad_text)
+        assert n == 1 and len(bad) == 1, (between, bad)
+    bad, _ = scan_carry_mask_hazards("\t;;#ASMSTART\n\tv_cmp_lt_u64_e64 vcc, v[1:2], v[3:4]\n\t;;#ASMEND\n"
+                                     "\tv_cndmask_b32_e32 v1, v2, v3, vcc\n")
+    assert len(bad) == 1
+
+
+def test_no_valu_reads_a_fresh_asm_carry_mask(tmp_path):
+    """gfx940+ needs 2 wait states between a VALU write of an SGPR (a carry-out / compare mask) and a VALU read of
+    it.  The hazard recogniser inserts them for the compiler's own instructions but does not look inside inline
+    asm, and the whole carry-chain arithmetic (csrc/gl.hpp, gl_cc.inc) keeps its carries in SGPR pairs written
+    there: tools/gen_cc_ops.py interleaves 3-4 independent elements per asm statement so that every consumer is
+    >= 2 instructions behind its producer, and the one-element forms carry `s_nop 1`.  This scans the device
+    assembly for the rule itself: no VALU instruction (inside asm or emitted by the compiler) may read an SGPR
+    that a VALU instruction inside an ASMSTART/ASMEND region wrote fewer than 2 wait states earlier."""
+    csrc = os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc")
+    bad, n_asm_writes = [], 0
+    for src in ("hash_kernels.hip", "ntt.hip", "stark_kernels.hip"):
+        out = tmp_path / (src + ".s")
+        subprocess.run(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-S", "--cuda-device-only",
+                        "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(csrc, src)],
+                       check=True, capture_output=True)
+        b, n = scan_carry_mask_hazards(out.read_text())
+        bad += [(src,) + x for x in b]
+        n_asm_writes += n
+    assert n_asm_writes > 1000, "scanner found only %d carry-mask writes inside asm: is it still parsing?" % n_asm_writes
+    assert not bad, bad[:10]

@@ -42,6 +42,47 @@ def test_ntt_matches_oracle(bpg, oracle, log_n, n_cols, ntt_form):
     assert (got == want_coeffs).all()
 
 
+@pytest.mark.parametrize("log_n,n_cols", [(9, 4), (12, 5), (13, 3), (14, 2), (15, 2), (18, 1)])
+def test_ntt_takes_any_u64_in_every_kernel_form(bpg, log_n, n_cols):
+    """include/bpg.h: NTT / LDE inputs may be ANY u64 (reduced mod p on the way in), whichever kernel a launch size
+    or tuning knob selects.  The split kernels (two workgroups per 2^13 / 2^14-point block, the default for small
+    out-of-place launches) used to feed caller words straight into add_n / sub_n, which need b < p: a = b = 2^64 - 1
+    gave 2^32 - 3 instead of 2^33 - 4.  Every form must agree with the transform of the reduced input."""
+    rng = np.random.default_rng(900 + log_n)
+    n = 1 << log_n
+    raw = rng.integers(0, 1 << 64, size=(n_cols, n), dtype=np.uint64)
+    raw[:, ::3] = np.uint64(2**64 - 1)            # all-ones and other words >= p, in both halves of every block
+    raw[:, 1::5] = np.uint64(P)
+    raw[:, n // 2 + 1::7] = np.uint64(P + 12345)
+    red = raw % np.uint64(P)
+    br = bitrev_perm(log_n)
+    try:
+        outs = {}
+        for mode in (1, 2, 0):                    # never split / split wherever possible / automatic
+            bpg.lib().bp_tune_ntt_split(mode)
+            for mx in (0, 3):
+                bpg.lib().bp_tune_ntt_mx(mx)
+                d = to_dev(raw)
+                inv = to_host(bpg.ops.intt_batch(d))                      # out of place: split DIF eligible
+                assert (to_host(d) == raw).all()
+                inv_red = to_host(bpg.ops.intt_batch(to_dev(red)))
+                assert (inv == inv_red).all(), ("inverse", mode, mx)
+                _, lde = bpg.ops.lde_batch(to_dev(raw[:, br]), 1, from_coeffs=True)   # unscaled + scaled split DIT
+                _, lde_red = bpg.ops.lde_batch(to_dev(red[:, br]), 1, from_coeffs=True)
+                assert (to_host(lde) == to_host(lde_red)).all(), ("lde", mode, mx)
+                fwd = to_host(bpg.ops.ntt_batch_(to_dev(raw[:, br]), bpg.ops.NTT_FWD_BR2NAT))
+                fwd_red = to_host(bpg.ops.ntt_batch_(to_dev(red[:, br]), bpg.ops.NTT_FWD_BR2NAT))
+                assert (fwd == fwd_red).all(), ("forward", mode, mx)
+                outs[(mode, mx)] = (inv, to_host(lde), fwd)
+                assert (inv < np.uint64(P)).all() and (fwd < np.uint64(P)).all()
+        first = outs[(1, 0)]
+        for k, v in outs.items():
+            assert all((a == b).all() for a, b in zip(first, v)), k
+    finally:
+        bpg.lib().bp_tune_ntt_split(0)
+        bpg.lib().bp_tune_ntt_mx(3)
+
+
 @pytest.mark.parametrize("log_n,rate_bits,n_cols", [(3, 1, 2), (6, 1, 5), (9, 1, 16), (12, 3, 7), (14, 1, 4),
                                                     (13, 3, 3), (16, 1, 2), (17, 1, 1), (18, 1, 2), (19, 2, 1), (20, 1, 1),
                                                     (21, 1, 1)])

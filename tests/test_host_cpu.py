@@ -247,3 +247,37 @@ def test_config_bounds_are_checked_before_any_device_work():
         with pytest.raises(pg.ProofGenError) as e:
             pg.ProverStateBuilder().set(**kw).build()
         assert e.value.code in (-2, -6), (kw, e.value.code)
+
+
+def test_bench_spawns_its_own_ranks_when_started_without_a_launcher(monkeypatch):
+    """`python3 bench.py --gpus 8` as the driver's scaling run starts it (no WORLD_SIZE): the parent must start
+    torch.distributed.run with the same arguments BEFORE importing torch or touching the library, and exit with the
+    launcher's code."""
+    import importlib
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        seen["torch_loaded_by_bench"] = "torch" in bench.__dict__
+        return subprocess.CompletedProcess(cmd, 7)
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and "127.0.0.1" in cmd
+    assert cmd[-7:] == [os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert not seen["torch_loaded_by_bench"]
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--txns", "0"])
+    with pytest.raises(SystemExit, match="--txns must be >= 2"):
+        bench.main()
