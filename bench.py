@@ -84,6 +84,8 @@ def main():
                     help="(internal) run only the alone-on-the-chip measurements -- single-stream roofline leg, isolated "
                          "LDE, inverse-NTT sweep, Poseidon peak -- and print them as one JSON object; the main run "
                          "starts this as a fresh child process AFTER its timed region")
+    ap.add_argument("--phase-marks", action="store_true",
+                    help="(measurement knob) write `@phase <name>` lines to stderr for tools/smi_sampler.py")
     ap.add_argument("--leg-first", action="store_true",
                     help="(measurement knob) round 2's order: the single-stream leg in this process BEFORE the block")
     args = ap.parse_args()
@@ -223,9 +225,17 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
+    def phase(name):
+        if args.phase_marks and rank == 0:
+            free_b, total_b = torch.cuda.mem_get_info()
+            print("@phase %s (device memory free %.1f of %.1f GiB)" % (name, free_b / 2**30, total_b / 2**30),
+                  file=sys.stderr, flush=True)
+
     roofline = alu_kernel = None
     if args.leg_first and not args.no_profile and rank == 0:
+        phase("single-stream leg")
         roofline, alu_kernel = single_stream_leg()
+    phase("state build")
 
     t_build = time.time()
     # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
@@ -243,17 +253,23 @@ def main():
 
     blocks = [synthetic_block_irs(b, args.txns, S1_LOG_N, S1_WIDTH) for b in range(args.warmup + args.steps)]
     last = None
+    phase("warmup")
     for b in range(args.warmup):
         last = driver.prove_block_distributed(blocks[b], rank, world, gather)
     if not args.no_profile and not args.no_in_situ_profile:
         L.bp_profile_reset()
         L.bp_profile_enable(1)
     barrier()
+    step_ms = []
     t0 = time.perf_counter()
     for b in range(args.warmup, args.warmup + args.steps):
-        last = driver.prove_block_distributed(blocks[b], rank, world, gather)
+        phase("timed step %d" % (b - args.warmup))
+        t_s = time.perf_counter()
+        last = driver.prove_block_distributed(blocks[b], rank, world, gather)   # returns with the block proof
+        step_ms.append(round((time.perf_counter() - t_s) * 1e3, 1))
     barrier()
     dt = time.perf_counter() - t0
+    phase("after the timed region")
     L.bp_profile_enable(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
@@ -289,7 +305,7 @@ def main():
                                % (args.txns, list(S1_LOG_N), list(S1_WIDTH), args.txns - 1),
                    "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
                    "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
-                   **t_build_info},
+                   "ms_of_each_step_rank0": step_ms, **t_build_info},
     }
     alone = {}
     if not args.no_profile:

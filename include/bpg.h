@@ -152,18 +152,51 @@ int bp_merkle_commit(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols
                      uint32_t rate_bits, uint32_t cap_height, uint64_t* d_digests, void* stream);
 
 struct bp_stark_cfg;
-/* K5.  Constraint / quotient evaluation on the extended domain for the synthetic AIR:
- * what plonky2_evm's compute_quotient_polys does for one table (reached from proof_gen.rs:44-52).
+/* K5.  The AIRs the library can prove (csrc/air.hpp).  What upstream expresses as `impl Stark for ...`
+ * (eval_packed_generic / eval_ext, evaluated by plonky2_evm's compute_quotient_polys, reached from
+ * proof_gen.rs:44-52; the seven zkEVM tables of prover_state.rs:85-93, Keccak range constants.rs:12) is here an
+ * air_id: 0 = the synthetic AIR of DESIGN.md section 4 (any width), 1 = keccak_f, one round of Keccak-f[1600] per
+ * row on 2430 columns, written from FIPS 202 (not upstream's column layout).  bp_air_describe returns the shape and
+ * the constraint list of an AIR as families (first index, count, kind, degree); the list is followed, for every
+ * air_id, by the two constraints of each cross-table-lookup-like auxiliary column (n_cols / 8 of them). */
+typedef struct bp_air_family {
+  uint32_t first_index, count;
+  uint32_t kind;   /* 0 all rows, 1 transition (x (X - g^(n-1))), 2 first row (x L_0), 3 last row (x L_(n-1)) */
+  uint32_t degree; /* in the trace polynomials, before the selector */
+} bp_air_family;
+typedef struct bp_air_desc {
+  uint32_t air_id;
+  char name[24];
+  uint32_t fixed_n_cols;      /* 0: the AIR takes any width */
+  uint32_t n_const_max;       /* preprocessed constant columns it can use */
+  uint32_t degree;            /* constraint degree: rate_bits must give 2^rate_bits >= degree - 1 */
+  uint32_t n_cols, n_aux;     /* for the width asked about */
+  uint32_t n_air_constraints, n_ctl_constraints;
+  uint32_t n_units;           /* independently evaluable slices of the list (the kernel's grid.y granularity) */
+  uint32_t n_families;
+  bp_air_family families[16]; /* interleaved families (synthetic AIR, CTL) list the index of their first member */
+} bp_air_desc;
+uint32_t bp_air_count(void);
+int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t deg_pow, bp_air_desc* out);
+
+/* K5.  Constraint / quotient evaluation on the extended domain: what compute_quotient_polys does for one table.
  * shape: log_n, n_cols, n_const, deg_pow, rate_bits of the table (the other fields must make a valid
  * configuration: use the values of the proof the quotient belongs to).  The three LDE matrices are
  * column-major and coset-major with column stride n << rate_bits (d_aux_lde: n_cols/8 columns; d_const_lde may
  * be NULL when n_const == 0).  ctl = beta0, gamma0, beta1, gamma1; alphas = the two constraint challenges.
- * d_scratch: bp_quotient_scratch_words(shape) words.  d_qvals_out: [2][n << rate_bits], coset-major:
- * position t*n + m = quotient value at 7 * w_{n 2^r}^(t + 2^r m), already divided by Z_H. */
-uint64_t bp_quotient_scratch_words(const struct bp_stark_cfg* shape);
-int bp_quotient_eval(const struct bp_stark_cfg* shape, const uint64_t* d_trace_lde, const uint64_t* d_aux_lde,
-                     const uint64_t* d_const_lde, const uint64_t ctl[4], const uint64_t alphas[2],
-                     uint64_t* d_scratch, uint64_t* d_qvals_out, void* stream);
+ * d_scratch: bp_quotient_scratch_words(air_id, shape) words.  d_qvals_out: [2][n << rate_bits], coset-major:
+ * position t*n + m = quotient value at 7 * w_{n 2^r}^(t + 2^r m), already divided by Z_H.
+ * One kernel serves every AIR; the random linear combination stays in registers, and a table tall enough to fill
+ * the chip is evaluated in one pass without partial sums in HBM. */
+uint64_t bp_quotient_scratch_words(uint32_t air_id, const struct bp_stark_cfg* shape);
+int bp_quotient_eval(uint32_t air_id, const struct bp_stark_cfg* shape, const uint64_t* d_trace_lde,
+                     const uint64_t* d_aux_lde, const uint64_t* d_const_lde, const uint64_t ctl[4],
+                     const uint64_t alphas[2], uint64_t* d_scratch, uint64_t* d_qvals_out, void* stream);
+
+/* Witness of AIR 1 (generate_traces is inside the reference's call too, proof_gen.rs:44-52): n = 2^log_n rows x 2430
+ * columns, column-major, row r = round r % 24 of permutation r / 24.  d_inputs: [ceil(n / 24)][25] input lanes
+ * (any u64; lane x + 5y), or NULL to draw them from `seed` (splitmix64(seed ^ (lane << 32) ^ permutation)). */
+int bp_keccak_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
 /* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
  * folded domain), done in the evaluation domain.  d_values: the layer's n_l << rate_bits extension values
@@ -200,6 +233,15 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
+/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1: n_cols = 2430, n_const = 0,
+ * deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
+int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
+                       uint8_t** out, size_t* out_len);
+/* The CPU verifier (csrc/verifier.cpp, what VerifierState::verify runs per proof, verifier_state.rs:56-71) on one
+ * table proof of bp_stark_prove_air: same transcript prologue.  const_cap: the 2^cap_height x 4 words of the
+ * constants commitment when n_const > 0, else NULL.  Host only; BP_ERR_VERIFY + bp_last_error() on rejection. */
+int bp_stark_verify_air(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint8_t* proof,
+                        size_t len);
 /* bp_stark_prove_synthetic keeps one worker (stream + device arena, up to ~100 GB for a 2^20 x 2432
  * table) parked per device between calls, because re-allocating it costs more than the proof.
  * This frees the parked workers. */

@@ -66,7 +66,37 @@ void orc_fri_fold(const gl2_t* in, gl2_t* out, unsigned log_m, unsigned arity_bi
 typedef struct {
   uint32_t log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits,
       arity_bits, final_poly_bits;
+  uint32_t air_id; /* 0: the synthetic AIR (stark.c), 1: Keccak-f[1600] (keccak_air.c); header word 14 of a proof */
 } orc_stark_cfg;
+#define ORC_AIR_SYNTHETIC 0u
+#define ORC_AIR_KECCAK_F 1u
+#define ORC_KECCAK_COLS 2430u
+#define ORC_KECCAK_CONSTRAINTS 2826u
+
+/* starky ConstraintConsumer: acc_j = acc_j * alpha_j + constraint, in list order; base field (the LDE coset)
+ * and extension field (the verifier at zeta; the alphas stay in the base field). */
+typedef struct {
+  gl_t alpha[2], acc[2];
+  gl_t z_last; /* x - g^-1 */
+  gl_t l_first, l_last;
+} orc_consumer;
+static inline void orc_cons(orc_consumer* k, gl_t c) {
+  k->acc[0] = gl_add(gl_mul(k->acc[0], k->alpha[0]), c);
+  k->acc[1] = gl_add(gl_mul(k->acc[1], k->alpha[1]), c);
+}
+typedef struct {
+  gl_t alpha[2]; gl2_t acc[2];
+  gl2_t z_last, l_first, l_last;
+} orc_consumer2;
+static inline void orc_cons2(orc_consumer2* k, gl2_t c) {
+  k->acc[0] = gl2_add(gl2_scale(k->acc[0], k->alpha[0]), c);
+  k->acc[1] = gl2_add(gl2_scale(k->acc[1], k->alpha[1]), c);
+}
+/* keccak_air.c */
+void orc_keccak_f(uint64_t lanes[25]);
+void orc_keccak_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
+void orc_keccak_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
+void orc_keccak_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
 
 uint32_t orc_cfg_n_aux(const orc_stark_cfg* c);
 uint32_t orc_cfg_n_quot(const orc_stark_cfg* c);

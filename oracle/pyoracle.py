@@ -27,7 +27,7 @@ def build(force=False):
 
 class StarkCfg(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("log_n", "n_cols", "n_const", "deg_pow", "rate_bits", "cap_height",
-                                           "num_queries", "pow_bits", "arity_bits", "final_poly_bits")]
+                                           "num_queries", "pow_bits", "arity_bits", "final_poly_bits", "air_id")]
 
 
 class Challenger(C.Structure):
@@ -89,6 +89,8 @@ def lib():
     L.orc_proof_words.restype = sz
     L.orc_synth_constants.argtypes = [u6, u, sz, u64p]
     L.orc_synth_trace.argtypes = [u6, cfgp, vp, u64p]
+    L.orc_keccak_f.argtypes = [u64p]
+    L.orc_keccak_trace.argtypes = [u6, vp, u, u64p]
     L.orc_commit_values.argtypes = [u64p, u, sz, u, u]
     L.orc_commit_values.restype = vp
     L.orc_commit_coeffs.argtypes = [u64p, u, sz, u, u]
@@ -219,10 +221,31 @@ class PyChallenger:
         return o
 
 
+AIR_SYNTHETIC, AIR_KECCAK_F = 0, 1
+KECCAK_COLS = 2430
+
+
 def make_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, num_queries=84, pow_bits=16,
-             arity_bits=4, final_poly_bits=5):
+             arity_bits=4, final_poly_bits=5, air_id=AIR_SYNTHETIC):
     return StarkCfg(log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits, arity_bits,
-                    final_poly_bits)
+                    final_poly_bits, air_id)
+
+
+def keccak_f(lanes):
+    """orc_keccak_f: the permutation on 25 lanes (index x + 5y)."""
+    a = np.ascontiguousarray(lanes, dtype=np.uint64).copy()
+    lib().orc_keccak_f(a)
+    return a
+
+
+def keccak_trace(log_n, seed=0, inputs=None):
+    """orc_keccak_trace: the AIR-1 witness [2430, 2^log_n]."""
+    out = np.zeros((KECCAK_COLS, 1 << log_n), dtype=np.uint64)
+    inp = np.ascontiguousarray(inputs, dtype=np.uint64) if inputs is not None else None
+    if inp is not None:
+        assert inp.shape == (((1 << log_n) + 23) // 24, 25)
+    lib().orc_keccak_trace(seed, inp.ctypes.data if inp is not None else None, log_n, out)
+    return out
 
 
 class Committed:

@@ -156,19 +156,16 @@ void orc_committed_free(orc_committed* c) {
 /* Constraint order (both prover and verifier): per group g: all-rows, transition, first-row;
  * then per aux column k: transition, last-row.  Consumer: acc_j = acc_j*alpha_j + constraint
  * (starky ConstraintConsumer::constraint).  Base-field version used on the LDE coset. */
-typedef struct {
-  gl_t alpha[2], acc[2];
-  gl_t z_last;  /* x - g^-1 */
-  gl_t l_first, l_last;
-} consumer_t;
-static inline void cons(consumer_t* k, gl_t c) {
-  k->acc[0] = gl_add(gl_mul(k->acc[0], k->alpha[0]), c);
-  k->acc[1] = gl_add(gl_mul(k->acc[1], k->alpha[1]), c);
-}
+typedef orc_consumer consumer_t;
+#define cons orc_cons
 static void eval_constraints_base(const orc_stark_cfg* cf, const gl_t* cst, const gl_t* loc,
                                   const gl_t* nxt, const gl_t* aux, const gl_t* aux_nxt,
                                   const gl_t ctl[4], consumer_t* k) {
   size_t G = cf->n_cols / 4, A = cf->n_cols / 8;
+  if (cf->air_id == ORC_AIR_KECCAK_F) { /* the AIR's own list (keccak_air.c), then the CTL part below */
+    orc_keccak_constraints_base(loc, nxt, k);
+    G = 0;
+  }
   for (size_t g = 0; g < G; g++) {
     gl_t a = loc[4 * g], b = loc[4 * g + 1], c = loc[4 * g + 2], d = loc[4 * g + 3];
     gl_t q = cf->n_const ? cst[g % cf->n_const] : 1;
@@ -186,19 +183,17 @@ static void eval_constraints_base(const orc_stark_cfg* cf, const gl_t* cst, cons
   }
 }
 /* Extension-field version for the verifier's check at zeta (alphas stay in the base field). */
-typedef struct {
-  gl_t alpha[2]; gl2_t acc[2];
-  gl2_t z_last, l_first, l_last;
-} consumer2_t;
-static inline void cons2(consumer2_t* k, gl2_t c) {
-  k->acc[0] = gl2_add(gl2_scale(k->acc[0], k->alpha[0]), c);
-  k->acc[1] = gl2_add(gl2_scale(k->acc[1], k->alpha[1]), c);
-}
+typedef orc_consumer2 consumer2_t;
+#define cons2 orc_cons2
 static inline gl2_t pow_e2(gl2_t t, uint32_t e) { return e == 3 ? gl2_mul(gl2_sqr(t), t) : t; }
 static void eval_constraints_ext(const orc_stark_cfg* cf, const gl2_t* cst, const gl2_t* loc,
                                  const gl2_t* nxt, const gl2_t* aux, const gl2_t* aux_nxt,
                                  const gl_t ctl[4], consumer2_t* k) {
   size_t G = cf->n_cols / 4, A = cf->n_cols / 8;
+  if (cf->air_id == ORC_AIR_KECCAK_F) {
+    orc_keccak_constraints_ext(loc, nxt, k);
+    G = 0;
+  }
   for (size_t g = 0; g < G; g++) {
     gl2_t a = loc[4 * g], b = loc[4 * g + 1], c = loc[4 * g + 2], d = loc[4 * g + 3];
     gl2_t q = cf->n_const ? cst[g % cf->n_const] : gl2_from(1);
@@ -309,12 +304,14 @@ int orc_stark_prove(const orc_stark_cfg* cf, const orc_committed* consts, const 
   const size_t N = (size_t)1 << log_n, M = N << r, C = cf->n_cols, K = cf->n_const, A = L.n_aux,
                Q = L.n_quot, qdf = (size_t)1 << r;
   if ((cf->deg_pow != 1 && cf->deg_pow != 3) || qdf != 3 * cf->deg_pow - 1 || C < 8 || log_m < h ||
-      (K && !consts))
+      (K && !consts) || cf->air_id > ORC_AIR_KECCAK_F ||
+      (cf->air_id == ORC_AIR_KECCAK_F && (C != ORC_KECCAK_COLS || K != 0 || cf->deg_pow != 1)))
     return -1;
   memset(proof, 0, L.total * sizeof(gl_t));
   proof[0] = MAGIC; proof[1] = log_n; proof[2] = C; proof[3] = K; proof[4] = A; proof[5] = Q;
   proof[6] = r; proof[7] = h; proof[8] = cf->num_queries; proof[9] = L.n_layers;
   proof[10] = L.final_len; proof[11] = cf->deg_pow; proof[12] = cf->pow_bits; proof[13] = cf->arity_bits;
+  proof[14] = cf->air_id;
   memcpy(proof + L.trace_cap, orc_committed_cap(trace), L.cap_words * 8);
 
   /* 1. auxiliary (CTL-Z-like) columns: suffix products of term = gamma + a + beta*b */
@@ -529,7 +526,7 @@ int orc_stark_verify(const orc_stark_cfg* cf, const gl_t* const_cap, const gl_t 
   const size_t N = (size_t)1 << log_n, M = N << r, C = cf->n_cols, K = cf->n_const, A = L.n_aux,
                Q = L.n_quot, qdf = (size_t)1 << r, arity = (size_t)1 << cf->arity_bits;
   if (proof[0] != MAGIC || proof[1] != log_n || proof[2] != C || proof[3] != K || proof[6] != r ||
-      proof[8] != cf->num_queries || proof[9] != L.n_layers || proof[10] != L.final_len)
+      proof[8] != cf->num_queries || proof[9] != L.n_layers || proof[10] != L.final_len || proof[14] != cf->air_id)
     return -1;
   for (size_t i = HDR_WORDS; i < L.total; i++) if (i < L.queries && proof[i] >= GL_P) return -2;
 

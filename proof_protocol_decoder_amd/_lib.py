@@ -25,6 +25,19 @@ class StarkCfg(C.Structure):
                                            "num_queries", "pow_bits", "arity_bits", "final_poly_bits")]
 
 
+class AirFamily(C.Structure):
+    """bp_air_family: a run of constraints of one kind and degree."""
+    _fields_ = [(n, C.c_uint32) for n in ("first_index", "count", "kind", "degree")]
+
+
+class AirDesc(C.Structure):
+    """bp_air_desc (include/bpg.h)."""
+    _fields_ = ([("air_id", C.c_uint32), ("name", C.c_char * 24)]
+                + [(n, C.c_uint32) for n in ("fixed_n_cols", "n_const_max", "degree", "n_cols", "n_aux",
+                                             "n_air_constraints", "n_ctl_constraints", "n_units", "n_families")]
+                + [("families", AirFamily * 16)])
+
+
 def take_buffer(ptr, length):
     """Copy a library-allocated buffer into bytes and release it with bp_free_buffer."""
     try:
@@ -57,9 +70,15 @@ def lib():
     L.bp_lde_batch.argtypes = [vp, u64, vp, u64, vp, u64, u32, u32, u32, i, vp]
     L.bp_poseidon_perm_batch.argtypes = [vp, u64, vp]
     L.bp_debug_field_ops.argtypes = [vp, vp, vp, u64, vp]
-    L.bp_quotient_scratch_words.argtypes = [C.POINTER(StarkCfg)]
+    L.bp_quotient_scratch_words.argtypes = [u32, C.POINTER(StarkCfg)]
     L.bp_quotient_scratch_words.restype = u64
-    L.bp_quotient_eval.argtypes = [C.POINTER(StarkCfg), vp, vp, vp, C.POINTER(u64), C.POINTER(u64), vp, vp, vp]
+    L.bp_quotient_eval.argtypes = [u32, C.POINTER(StarkCfg), vp, vp, vp, C.POINTER(u64), C.POINTER(u64), vp, vp, vp]
+    L.bp_air_count.restype = u32
+    L.bp_air_describe.argtypes = [u32, u32, u32, u32, C.POINTER(AirDesc)]
+    L.bp_keccak_trace.argtypes = [vp, u64, u32, vp, vp]
+    L.bp_stark_verify_air.argtypes = [u32, C.POINTER(StarkCfg), C.POINTER(u64), C.c_char_p, C.c_size_t]
+    L.bp_stark_prove_air.argtypes = [u32, C.POINTER(StarkCfg), u64, u64, i, C.POINTER(C.POINTER(C.c_uint8)),
+                                     C.POINTER(C.c_size_t)]
     L.bp_fri_fold.argtypes = [vp, u32, u32, u32, u64, C.POINTER(u64), vp, vp]
     L.bp_openings.argtypes = [vp, u64, u32, u32, C.POINTER(u64), C.POINTER(u64), vp, vp, vp]
     L.bp_pow_grind.argtypes = [C.POINTER(u64), u32, u32, C.POINTER(u64), vp]

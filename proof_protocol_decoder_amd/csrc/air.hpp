@@ -1,0 +1,405 @@
+// air.hpp -- the AIRs this library can prove, as code shared by the device quotient kernel (K5) and the host verifier.
+//
+// What upstream calls a `Stark` (plonky2_evm: eval_packed_generic / eval_ext, reached from
+// plonky_block_proof_gen/src/proof_gen.rs:44-52 through prove_single_table / compute_quotient_polys) is here an
+// `air_id` plus ONE templated evaluation routine: the same source is instantiated over canonical base-field words on
+// the device (every point of the LDE coset) and over the quadratic extension on the host (the verifier's check at
+// zeta).  An AIR is described by
+//   * its shape (columns, preprocessed constant columns, constraint degree),
+//   * its constraint list: every constraint has a fixed INDEX i in [0, n_constraints), a kind
+//     (all rows / transition = times (x - g^(n-1)) / first row = times L_0 / last row = times L_(n-1)) and a degree,
+//   * its units: disjoint slices of the list that can be evaluated independently (the kernel spreads the units of a
+//     short table over workgroups).
+// The random linear combination of starky's ConstraintConsumer, acc = acc * alpha + c in list order, equals
+// sum_i c_i * alpha^(T-1-i) with T the total number of constraints (AIR + cross-table-lookup part); the evaluators
+// hand (index, value) pairs to the consumer, which weighs them with a table of alpha powers, so a unit may emit its
+// constraints in whatever order keeps its operands in registers and the partial sums of units simply add.
+//
+// AIR 0  synthetic     DESIGN.md section 4 (any width; groups of four columns; degree 3 * deg_pow)
+// AIR 1  keccak_f      one round of Keccak-f[1600] per row, 24 rows per permutation, 2430 columns, degree 3;
+//                      written from the public specification (FIPS 202 / the Keccak reference), in the style of
+//                      upstream's keccak table (~2.4 k columns, constants.rs:12) but NOT upstream's column layout,
+//                      which nothing under /root/reference shows [UPSTREAM-UNVERIFIED].
+// The cross-table-lookup-like auxiliary columns (running products over trace columns 8k, 8k+1) are a property of
+// the protocol, not of an AIR (as upstream's CTL checks sit beside Stark::eval): their constraints follow the AIR's
+// in the list for every air_id.
+#pragma once
+#include <cstdint>
+#include "gl.hpp"
+
+namespace bpg {
+namespace air {
+
+constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, COUNT = 2;
+
+struct Shape {
+  uint32_t air_id, n_cols, n_const, deg_pow;
+};
+
+// ------------------------------------------------------------------------------------------ field policies
+// Ops<T>: the arithmetic an evaluator needs.  T = uint64_t: canonical base-field words (device).  T = gl::Ext: host.
+template <class T>
+struct Ops;
+
+#if defined(__HIP__)
+template <>
+struct Ops<uint64_t> {
+  typedef uint64_t T;
+  static __device__ __forceinline__ T k(uint64_t c) { return c; }  // a constant < p
+  static __device__ __forceinline__ T add(T a, T b) { return gl::addc(a, b); }
+  static __device__ __forceinline__ T sub(T a, T b) { return gl::subc(a, b); }
+  static __device__ __forceinline__ T mul(T a, T b) { return gl::mulc(a, b); }
+  static __device__ __forceinline__ T dbl(T a) { return gl::addc(a, a); }
+  // four independent products, instruction-interleaved carry chains (gl::mul_n), canonical results
+  static __device__ __forceinline__ void mul4(const T (&a)[4], const T (&b)[4], T (&r)[4]) {
+    // fenced: the scheduler would otherwise overlap two groups and double the live carry masks (SGPR pairs);
+    // a mask spilled to a VGPR lane right after the asm that wrote it is a hazard the compiler cannot see
+    __builtin_amdgcn_sched_barrier(0);
+    gl::mul_n<4>(a, b, r);
+    gl::canon_n<4>(r);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+#endif
+template <>
+struct Ops<gl::Ext> {
+  typedef gl::Ext T;
+  static T k(uint64_t c) { return gl::ext(c); }
+  static T add(T a, T b) { return gl::add(a, b); }
+  static T sub(T a, T b) { return gl::sub(a, b); }
+  static T mul(T a, T b) { return gl::mul(a, b); }
+  static T dbl(T a) { return gl::add(a, a); }
+  static void mul4(const T (&a)[4], const T (&b)[4], T (&r)[4]) {
+    for (int i = 0; i < 4; i++) r[i] = gl::mul(a[i], b[i]);
+  }
+};
+
+// ------------------------------------------------------------------------------------------ AIR 0: synthetic
+// Per group g of four columns (a, b, c, d), q = constant column g mod K (or 1):
+//   index 3g     all rows    c - a*b - q*a
+//   index 3g+1   transition  d' - (a*b*c)^e - b
+//   index 3g+2   first row   d - a - b
+// One unit = `per_unit` consecutive groups.
+namespace synthetic {
+GL_HD uint32_t n_constraints(const Shape& s) { return 3 * (s.n_cols / 4); }
+GL_HD uint32_t per_unit(const Shape& s) {
+  const uint32_t G = s.n_cols / 4, u = (G + 47) / 48;
+  return u < 8 ? 8 : u;
+}
+GL_HD uint32_t n_units(const Shape& s) {
+  const uint32_t G = s.n_cols / 4, pu = per_unit(s);
+  return (G + pu - 1) / pu;
+}
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const uint32_t G = s.n_cols / 4, pu = per_unit(s), g0 = unit * pu, g1 = g0 + pu < G ? g0 + pu : G;
+#pragma unroll 1
+  for (uint32_t g = g0; g < g1; g++) {
+    const T a = row.loc(4 * g), b = row.loc(4 * g + 1), c = row.loc(4 * g + 2), d = row.loc(4 * g + 3);
+    const T dn = row.nxt(4 * g + 3);
+    const T q = s.n_const ? row.cst(g % s.n_const) : F::k(1);
+    const T x4[4] = {a, q, a, a}, y4[4] = {b, a, b, b};  // a*b and q*a (two slots spare)
+    T p4[4];
+    F::mul4(x4, y4, p4);
+    const T ab = p4[0], qa = p4[1];
+    T t = F::mul(ab, c);
+    if (s.deg_pow == 3) t = F::mul(F::mul(t, t), t);
+    out.all(3 * g, F::sub(F::sub(c, ab), qa));
+    out.transition(3 * g + 1, F::sub(F::sub(dn, t), b));
+    out.first(3 * g + 2, F::sub(F::sub(d, a), b));
+  }
+}
+}  // namespace synthetic
+
+// ------------------------------------------------------------------------------------------ AIR 1: Keccak-f[1600]
+// Row r of the trace is round r mod 24 of permutation r / 24 (a trace of 2^k rows ends inside a permutation: the
+// transition constraints do not apply to the last row).  State lanes A[x][y] (x = column, y = row of the 5 x 5
+// sheet, lane index l = x + 5y), bit z of a lane = 2^z.  One round (FIPS 202, section 3.2):
+//   theta  C[x] = xor_y A[x][y];  D[x] = C[x-1] ^ rot(C[x+1], 1);  A'[x][y] = A[x][y] ^ D[x]
+//   rho/pi B[y][2x+3y] = rot(A'[x][y], R[x][y])
+//   chi    A''[x][y] = B[x][y] ^ (~B[x+1][y] & B[x+2][y])
+//   iota   A'''[0][0] = A''[0][0] ^ RC[round]
+// Columns (all values are field elements; "bits" are 0 / 1 on the trace):
+//   0    .. 23     s_i        round flags (one-hot)
+//   24   .. 73     A          input lanes as two 32-bit limbs: 24 + 2 l + h
+//   74   .. 393    C[x][z]    bits: 74 + 64 x + z
+//   394  .. 713    C'[x][z]   bits of C[x] ^ D[x]: 394 + 64 x + z
+//   714  .. 2313   A'[l][z]   bits: 714 + 64 l + z
+//   2314 .. 2363   A''        limbs: 2314 + 2 l + h
+//   2364 .. 2427   A''[0][0]  bits
+//   2428 .. 2429   A'''[0][0] limbs
+// Constraints (index ranges; degree; kind):
+//   F0  0    .. 23    first row   s_0 - 1, s_i                                                   deg 1
+//   F1  24   .. 47    transition  s'_((i+1) mod 24) - s_i                                        deg 1
+//   F2  48   .. 2031  all rows    b (b - 1) for the bits of C (320), A' (1600), A''[0][0] (64)   deg 2
+//   F3  2032 .. 2351  all rows    C'[x][z] - xor3(C[x][z], C[x-1][z], C[x+1][z-1])               deg 3
+//   F4  2352 .. 2671  all rows    d (d - 2)(d - 4), d = sum_y A'[x][y][z] - C'[x][z]             deg 3
+//                                 (the column parity of A' is C': together with F5 this forces C = xor_y A)
+//   F5  2672 .. 2721  all rows    A limb - sum_z 2^z xor(A'[l][z], C[x][z] ^ C'[x][z])           deg 3
+//                                 (A = A' ^ D with D = C ^ C')
+//   F6  2722 .. 2771  all rows    A'' limb - sum_z 2^z (B0 ^ (~B1 & B2)),  B from A' by rho / pi deg 3
+//   F7  2772 .. 2773  all rows    A''[0][0] limb - sum_z 2^z bit_z                               deg 1
+//   F8  2774 .. 2775  all rows    A''' limb - sum_z 2^z xor(bit_z, sum_i s_i RC_i[z])            deg 2
+//   F9  2776 .. 2825  transition  (1 - s_23) (A'_next limb - output limb), output = A''' for lane 0 else A''  deg 2
+// Units: 0 = F0, F1, F7, F8, F9 and the A''[0][0] bits of F2; 1 + x = the x-slices of F2 .. F6.
+namespace keccak {
+constexpr uint32_t N_COLS = 2430, N_CONSTRAINTS = 2826, N_UNITS = 6;
+constexpr uint32_t COL_STEP = 0, COL_A = 24, COL_C = 74, COL_CP = 394, COL_AP = 714, COL_APP = 2314, COL_APP0_BITS = 2364,
+                   COL_APPP = 2428;
+constexpr uint32_t F0 = 0, F1 = 24, F2 = 48, F3 = 2032, F4 = 2352, F5 = 2672, F6 = 2722, F7 = 2772, F8 = 2774, F9 = 2776;
+GL_HD uint64_t round_constant(uint32_t i) {
+  constexpr uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+      0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+      0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+      0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+      0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  return RC[i];
+}
+// rho offsets R[x][y] (FIPS 202 table 2), indexed by lane x + 5y
+GL_HD uint32_t rho(uint32_t l) {
+  constexpr uint8_t R[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  return R[l];
+}
+// B[X][Y] = rot(A'[x][y], R[x][y]) with (X, Y) = (y, 2x + 3y): the source lane of B[X][Y] is x = (X + 3Y) mod 5, y = X
+GL_HD uint32_t pi_source(uint32_t X, uint32_t Y) { return (X + 3 * Y) % 5 + 5 * X; }
+
+// a ^ b for 0/1 values as a polynomial: a + b - 2ab, given the product
+template <class T>
+GL_HD T xor_from_product(T a, T b, T ab) {
+  typedef Ops<T> F;
+  return F::sub(F::add(a, b), F::dbl(ab));
+}
+
+// Loop shape matters on the device: what must stay in registers and is indexed by a loop counter (the limb
+// accumulators, the groups of four) sits in fully unrolled loops; the long loops are kept rolled (`unroll 1`), so
+// the kernel's register footprint is that of one group of four bits and only a few of the consumer's wave-uniform
+// alpha-power loads are in flight at a time (each holds an SGPR pair).
+template <class T, class Row, class Emit>
+GL_HD void eval_control_unit(const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  // F0, F1: the round flags start at (1, 0, ..., 0) and rotate
+#pragma unroll 1
+  for (uint32_t i = 0; i < 24; i++) {
+    const T si = row.loc(COL_STEP + i);
+    out.first(F0 + i, i == 0 ? F::sub(si, F::k(1)) : si);
+    out.transition(F1 + i, F::sub(row.nxt(COL_STEP + (i + 1) % 24), si));
+  }
+  // A''[0][0] bits: booleanity (F2 tail), limb decomposition (F7), iota (F8)
+#pragma unroll 1
+  for (uint32_t h = 0; h < 2; h++) {
+    T dec = F::k(0), iota = F::k(0);
+#pragma unroll 1
+    for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
+      T b[4], bb[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) b[i] = row.loc(COL_APP0_BITS + 32 * h + z0 - 1 - i);  // high to low
+      F::mul4(b, b, bb);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t z = 32 * h + z0 - 1 - i;
+        out.all(F2 + 1920 + z, F::sub(bb[i], b[i]));
+        dec = F::add(F::dbl(dec), b[i]);
+        T x = b[i];
+        if (((z + 1) & z) == 0) {  // only z = 2^j - 1 is ever set in a round constant
+          T rc = F::k(0);          // rc_z = sum of the flags of the rounds whose constant has bit z set
+#pragma unroll 1
+          for (uint32_t r = 0; r < 24; r++)
+            if ((round_constant(r) >> z) & 1) rc = F::add(rc, row.loc(COL_STEP + r));
+          x = xor_from_product<T>(b[i], rc, F::mul(b[i], rc));
+        }
+        iota = F::add(F::dbl(iota), x);
+      }
+    }
+    out.all(F7 + h, F::sub(row.loc(COL_APP + h), dec));
+    out.all(F8 + h, F::sub(row.loc(COL_APPP + h), iota));
+  }
+  // F9: the next row's input is this row's output, except across permutations
+  const T not_last = F::sub(F::k(1), row.loc(COL_STEP + 23));
+#pragma unroll 1
+  for (uint32_t l = 0; l < 25; l++)
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2; h++) {
+      const T o = l == 0 ? row.loc(COL_APPP + h) : row.loc(COL_APP + 2 * l + h);
+      out.transition(F9 + 2 * l + h, F::mul(not_last, F::sub(row.nxt(COL_A + 2 * l + h), o)));
+    }
+}
+
+template <class T, class Row, class Emit>
+GL_HD void eval_column_unit(uint32_t x, const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const uint32_t xm = (x + 4) % 5, xp = (x + 1) % 5;
+  // pass 1, per group of four bits of column x: F2 (C bits), F3 (theta), F4 (column parity of A')
+#pragma unroll 1
+  for (uint32_t zt = 63; zt < 64; zt -= 4) {  // the group is bits zt, zt - 1, zt - 2, zt - 3
+    T c[4], cp[4], cm[4], cq[4], t1[4], t2[4], u[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      c[i] = row.loc(COL_C + 64 * x + zt - i);
+      cp[i] = row.loc(COL_CP + 64 * x + zt - i);
+      cm[i] = row.loc(COL_C + 64 * xm + zt - i);
+      cq[i] = row.loc(COL_C + 64 * xp + (zt - i + 63) % 64);
+    }
+    // C' = xor3(C, C[x-1], rot(C[x+1], 1)) = u + w - 2uw with u = C ^ C[x-1], w = the rotated bit
+    F::mul4(c, c, t1);
+    F::mul4(c, cm, t2);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      out.all(F2 + 64 * x + zt - i, F::sub(t1[i], c[i]));
+      u[i] = xor_from_product<T>(c[i], cm[i], t2[i]);
+    }
+    F::mul4(u, cq, t1);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      out.all(F3 + 64 * x + zt - i, F::sub(cp[i], xor_from_product<T>(u[i], cq[i], t1[i])));
+      u[i] = F::sub(F::k(0), cp[i]);  // becomes d = sum_y A'[x][y][z] - C'[x][z]
+    }
+#pragma unroll 1
+    for (uint32_t y = 0; y < 5; y++)
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) u[i] = F::add(u[i], row.loc(COL_AP + 64 * (x + 5 * y) + zt - i));
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      t1[i] = F::sub(u[i], F::k(2));
+      t2[i] = F::sub(u[i], F::k(4));
+    }
+    F::mul4(u, t1, c);
+    F::mul4(c, t2, cp);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) out.all(F4 + 64 * x + zt - i, cp[i]);
+  }
+  // pass 2, per lane (x, y) and half: F2 (A' bits) and F5, the input limb = sum_z 2^z (A' ^ D), D = C ^ C' (Horner
+  // from the top bit down; D is recomputed per lane so that one accumulator is live, not five)
+#pragma unroll 1
+  for (uint32_t y = 0; y < 5; y++)
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2; h++) {
+      T alimb = F::k(0);
+#pragma unroll 1
+      for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
+        const uint32_t zt = 32 * h + z0 - 1;
+        T c[4], cp[4], ap[4], dd[4], apap[4], apd[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+          c[i] = row.loc(COL_C + 64 * x + zt - i);
+          cp[i] = row.loc(COL_CP + 64 * x + zt - i);
+          ap[i] = row.loc(COL_AP + 64 * (x + 5 * y) + zt - i);
+        }
+        F::mul4(c, cp, dd);
+        F::mul4(ap, ap, apap);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) dd[i] = xor_from_product<T>(c[i], cp[i], dd[i]);
+        F::mul4(ap, dd, apd);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+          out.all(F2 + 320 + 64 * (x + 5 * y) + zt - i, F::sub(apap[i], ap[i]));
+          alimb = F::add(F::dbl(alimb), xor_from_product<T>(ap[i], dd[i], apd[i]));
+        }
+      }
+      out.all(F5 + 2 * (x + 5 * y) + h, F::sub(row.loc(COL_A + 2 * (x + 5 * y) + h), alimb));
+    }
+  // F6: chi on the five output lanes (x, y)
+#pragma unroll 1
+  for (uint32_t y = 0; y < 5; y++) {
+    const uint32_t l0 = pi_source(x, y), l1 = pi_source((x + 1) % 5, y), l2 = pi_source((x + 2) % 5, y);
+    const uint32_t r0 = rho(l0), r1 = rho(l1), r2 = rho(l2);
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2; h++) {
+      T acc = F::k(0);
+#pragma unroll 1
+      for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
+        T b0[4], nb1[4], b2[4], t[4], bt[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+          const uint32_t z = 32 * h + z0 - 1 - i;  // B[.][z] = A'[source][(z - rho) mod 64]
+          b0[i] = row.loc(COL_AP + 64 * l0 + (z + 64 - r0) % 64);
+          nb1[i] = F::sub(F::k(1), row.loc(COL_AP + 64 * l1 + (z + 64 - r1) % 64));
+          b2[i] = row.loc(COL_AP + 64 * l2 + (z + 64 - r2) % 64);
+        }
+        F::mul4(nb1, b2, t);
+        F::mul4(b0, t, bt);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) acc = F::add(F::dbl(acc), xor_from_product<T>(b0[i], t[i], bt[i]));
+      }
+      out.all(F6 + 2 * (x + 5 * y) + h, F::sub(row.loc(COL_APP + 2 * (x + 5 * y) + h), acc));
+    }
+  }
+}
+
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(uint32_t unit, const Row& row, Emit& out) {
+  if (unit == 0) eval_control_unit<T>(row, out);
+  else eval_column_unit<T>(unit - 1, row, out);
+}
+
+// One round on 25 lanes; optionally the intermediate values a trace row needs.
+struct Round {
+  uint64_t c[5], cp[5], ap[25], app[25], appp0;
+};
+GL_HD void round(const uint64_t a[25], uint32_t rnd, Round& o) {
+  for (uint32_t x = 0; x < 5; x++) o.c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+  for (uint32_t x = 0; x < 5; x++) {
+    const uint64_t n = o.c[(x + 1) % 5];
+    const uint64_t d = o.c[(x + 4) % 5] ^ ((n << 1) | (n >> 63));
+    o.cp[x] = o.c[x] ^ d;
+    for (uint32_t y = 0; y < 5; y++) o.ap[x + 5 * y] = a[x + 5 * y] ^ d;
+  }
+  uint64_t b[25];
+  for (uint32_t X = 0; X < 5; X++)
+    for (uint32_t Y = 0; Y < 5; Y++) {
+      const uint32_t l = pi_source(X, Y), r = rho(l);
+      b[X + 5 * Y] = r ? ((o.ap[l] << r) | (o.ap[l] >> (64 - r))) : o.ap[l];
+    }
+  for (uint32_t y = 0; y < 5; y++)
+    for (uint32_t x = 0; x < 5; x++) o.app[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+  o.appp0 = o.app[0] ^ round_constant(rnd);
+}
+}  // namespace keccak
+
+// ------------------------------------------------------------------------------------------ registry
+GL_HD uint32_t n_constraints(const Shape& s) {
+  return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS : synthetic::n_constraints(s);
+}
+GL_HD uint32_t n_units(const Shape& s) { return s.air_id == KECCAK_F ? keccak::N_UNITS : synthetic::n_units(s); }
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
+  if (s.air_id == KECCAK_F) keccak::eval_unit<T>(unit, row, out);
+  else synthetic::eval_unit<T>(s, unit, row, out);
+}
+
+// Cross-table-lookup-like running products (protocol level, every air_id): aux column k over trace columns 8k, 8k+1
+// with the challenge set (beta, gamma) = ctl[k mod 2]:  term = gamma + a + beta * b
+//   index base + 2k     transition  z - z' * term
+//   index base + 2k+1   last row    z - term
+template <class T, class Row, class Emit>
+GL_HD void eval_ctl(uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ctl[4], const Row& row, Emit& out) {
+  typedef Ops<T> F;
+#pragma unroll 1
+  for (uint32_t k = k0; k < k1; k++) {
+    const T beta = F::k(ctl[2 * (k & 1)]), gamma = F::k(ctl[2 * (k & 1) + 1]);
+    const T a = row.loc(8 * k), b = row.loc(8 * k + 1), z = row.aux(k), zn = row.aux_nxt(k);
+    const T term = F::add(F::add(gamma, a), F::mul(beta, b));
+    out.transition(base + 2 * k, F::sub(z, F::mul(zn, term)));
+    out.last(base + 2 * k + 1, F::sub(z, term));
+  }
+}
+
+struct Info {
+  uint32_t air_id;
+  const char* name;
+  uint32_t n_cols;       // 0: any width (multiple of 4 not required; groups of four columns are constrained)
+  uint32_t n_const_max;  // preprocessed constant columns the AIR can use
+  uint32_t degree;       // constraint degree (x deg_pow for the synthetic AIR); rate_bits must give 2^r >= degree - 1
+};
+inline const Info* info(uint32_t air_id) {
+  static const Info table[COUNT] = {
+      {SYNTHETIC, "synthetic", 0, 4096, 3},
+      {KECCAK_F, "keccak_f", keccak::N_COLS, 0, 3},
+  };
+  return air_id < COUNT ? &table[air_id] : nullptr;
+}
+
+}  // namespace air
+}  // namespace bpg

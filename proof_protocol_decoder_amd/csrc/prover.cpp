@@ -58,6 +58,11 @@ static uint32_t n_fri_layers(const StarkCfg& c) {  // FriReductionStrategy::Cons
   return n;
 }
 int check_cfg(const StarkCfg& c) {
+  const air::Info* ai = air::info(c.air_id);
+  if (!ai) return fail(BP_ERR_INVALID_INPUT, "unknown air_id %u (bp_air_count() AIRs are built in)", c.air_id);
+  if (ai->n_cols && (c.n_cols != ai->n_cols || c.n_const != 0 || c.deg_pow != 1))
+    return fail(BP_ERR_INVALID_INPUT, "AIR %u (%s) has %u columns, no constant columns and degree %u (deg_pow 1): got n_cols=%u "
+                "n_const=%u deg_pow=%u", c.air_id, ai->name, ai->n_cols, ai->degree, c.n_cols, c.n_const, c.deg_pow);
   if (c.deg_pow != 1 && c.deg_pow != 3) return fail(BP_ERR_INVALID_INPUT, "deg_pow must be 1 or 3");
   if ((1u << c.rate_bits) != 3 * c.deg_pow - 1)
     return fail(BP_ERR_INVALID_INPUT, "quotient degree factor 3*deg_pow-1 must equal 2^rate_bits");
@@ -220,19 +225,27 @@ int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uin
 
 // Everything of the quotient launch that follows from the table shape and the challenges (the caller
 // sets the three LDE pointers and the two output buffers).  Used by stark_prove and bp_quotient_eval.
-int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out, ChunkPows* cp) {
+int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out) {
   QuotArgs& qa = *out;
   const uint32_t log_n = cfg.log_n, r = cfg.rate_bits, R = 1u << r, C = cfg.n_cols, K = cfg.n_const, A = C / 8;
   const uint64_t N = (uint64_t)1 << log_n, M = N << r;
   const uint64_t wM = gl::root(log_n + r), wN = gl::root(log_n);
   qa.trace_stride = qa.aux_stride = qa.const_stride = M;
   TRY(get_table(0, log_n, 0, &qa.tw_n));
+  qa.air_id = cfg.air_id;
   qa.log_n = log_n; qa.rate_bits = r; qa.n_cols = C; qa.n_const = K; qa.n_aux = A; qa.deg_pow = cfg.deg_pow;
-  const uint32_t G = C / 4;
-  qa.groups_per_chunk = std::max<uint32_t>(8, (G + 47) / 48);
-  qa.n_group_chunks = (G + qa.groups_per_chunk - 1) / qa.groups_per_chunk;
-  qa.aux_per_chunk = std::max<uint32_t>(16, (A + 15) / 16);
-  qa.n_aux_chunks = (A + qa.aux_per_chunk - 1) / qa.aux_per_chunk;
+  // the constraint list and its units (air.hpp)
+  const air::Shape shape{cfg.air_id, C, K, cfg.deg_pow};
+  qa.n_air_constraints = air::n_constraints(shape);
+  qa.n_constraints = qa.n_air_constraints + 2 * A;
+  qa.n_air_units = air::n_units(shape);
+  qa.aux_per_unit = std::max<uint32_t>(16, (A + 15) / 16);
+  qa.n_ctl_units = (A + qa.aux_per_unit - 1) / qa.aux_per_unit;
+  // One pass (the alpha fold never leaves the registers) once the rows alone fill the chip: 2048 workgroups of
+  // 256 lanes = 2 per SIMD.  Shorter tables spread their units over grid.y until the launch has that many.
+  const uint32_t n_units = qa.n_air_units + qa.n_ctl_units, wg_x = (uint32_t)((M + 255) / 256);
+  const uint32_t want_rows = std::min<uint32_t>(n_units, std::max<uint32_t>(1, (2048 + wg_x - 1) / wg_x));
+  qa.units_per_wg = (n_units + want_rows - 1) / want_rows;
   qa.alpha0 = alpha0; qa.alpha1 = alpha1;
   qa.g = wN; qa.g_inv = gl::inv(wN); qa.n_inv = gl::inv(N);
   // per-coset constants: g_t = 7 * w_M^t, Z_H(g_t x) = g_t^n - 1 (constant on a coset)
@@ -242,19 +255,11 @@ int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t
     qa.zh_inv_t[t] = gl::inv(qa.zh_t[t]);
   }
   qa.ctl = ctl;
-  const uint32_t n_chunks = qa.n_group_chunks + qa.n_aux_chunks;
-  if (2 * n_chunks > sizeof(cp->d_pows) / sizeof(cp->d_pows[0])) return fail(BP_ERR_UNSUPPORTED, "too many quotient chunks");
-  for (uint32_t c = 0; c < n_chunks; c++) {
-    uint32_t cnt;
-    if (c < qa.n_group_chunks) cnt = 3 * (std::min(G, (c + 1) * qa.groups_per_chunk) - c * qa.groups_per_chunk);
-    else {
-      uint32_t k = c - qa.n_group_chunks;
-      cnt = 2 * (std::min(A, (k + 1) * qa.aux_per_chunk) - k * qa.aux_per_chunk);
-    }
-    cp->d_pows[2 * c] = gl::pow(alpha0, cnt);
-    cp->d_pows[2 * c + 1] = gl::pow(alpha1, cnt);
-  }
   return BP_OK;
+}
+size_t quotient_partial_words(const QuotArgs& qa) {
+  const uint32_t n_units = qa.n_air_units + qa.n_ctl_units, wg_rows = (n_units + qa.units_per_wg - 1) / qa.units_per_wg;
+  return wg_rows > 1 ? (size_t)wg_rows * 2 * (((size_t)1 << qa.log_n) << qa.rate_bits) : 0;
 }
 
 // One FRI layer of n_l << r extension values on the domain shift * <w_{n_l 2^r}> (coset-major).
@@ -286,7 +291,7 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
   uint64_t* P = proof.data();
   P[0] = PROOF_MAGIC; P[1] = log_n; P[2] = C; P[3] = K; P[4] = A; P[5] = Q; P[6] = r; P[7] = h;
   P[8] = cfg.num_queries; P[9] = L.n_layers; P[10] = L.final_len; P[11] = cfg.deg_pow; P[12] = cfg.pow_bits;
-  P[13] = cfg.arity_bits;
+  P[13] = cfg.arity_bits; P[14] = cfg.air_id;
   std::memcpy(P + L.trace_cap, trace.cap.data(), L.cap_words * 8);
   if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before auxiliary commitment");
 
@@ -316,17 +321,16 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
 
   // 3. quotient on the LDE coset -> per-coset iNTT -> chunk coefficients -> commitment
   QuotArgs qa{};
-  ChunkPows cp{};
   qa.trace_lde = trace.lde; qa.aux_lde = aux.lde; qa.const_lde = K ? consts->lde : nullptr;
-  TRY(quotient_args(cfg, ctl, alpha0, alpha1, &qa, &cp));
-  const uint32_t n_chunks = qa.n_group_chunks + qa.n_aux_chunks;
+  TRY(quotient_args(cfg, ctl, alpha0, alpha1, &qa));
   const size_t mark_q = w.arena.mark();
   ARENA_ALLOC(d_qc, (size_t)Q * N);  // chunk coefficients: live until the end (quotient oracle)
   const size_t mark_tmp = w.arena.mark();
-  ARENA_ALLOC(d_partial, (size_t)n_chunks * 2 * M);
+  ARENA_ALLOC(d_cpow, 2 * (size_t)qa.n_constraints + 48);
+  ARENA_ALLOC(d_partial, quotient_partial_words(qa) + 1);
   ARENA_ALLOC(d_qvals, 2 * M);
-  qa.partial = d_partial; qa.qvals = d_qvals;
-  TRY(launch_quotient(qa, cp, st));
+  qa.apow = d_cpow; qa.partial = d_partial; qa.qvals = d_qvals;
+  TRY(launch_quotient(qa, st));
   TRY(intt_nat2br(d_qvals, N, d_qvals, N, log_n, 2 * R, true, st));  // 2 challenges x 2^r cosets, in place
   ChunkArgs ca{};
   ca.e = d_qvals; ca.inv_scale = coset_scale_inv; ca.out = d_qc; ca.out_stride = N; ca.log_n = log_n; ca.rate_bits = r;

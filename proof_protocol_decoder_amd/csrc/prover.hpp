@@ -61,6 +61,7 @@ class Challenger {
 struct StarkCfg {
   uint32_t log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits, arity_bits,
       final_poly_bits;
+  uint32_t air_id = air::SYNTHETIC;  // which AIR the table proves (air.hpp); header word 14 of the proof
 };
 struct ProofLayout {
   size_t cap_words, trace_cap, aux_cap, quot_cap, open_zeta, open_next, open_first, fri_caps, final_poly, pow,
@@ -130,7 +131,9 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
 void prover_active(int delta);
 
 // launch-argument builders shared by the prover and the L0 entry points (stark_api.cpp)
-int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out, ChunkPows* cp);
+// fills everything but the matrix pointers, apow (2 * n_constraints words) and partial (quotient_partial_words)
+int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out);
+size_t quotient_partial_words(const QuotArgs& qa);  // 0 when the table takes one pass
 int fri_layer_args(uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uint64_t shift, FriLayerArgs* out);
 
 // CPU verifier (verifier.cpp).  The caller has driven `ch` through the same prologue as the prover.

@@ -1,5 +1,6 @@
 // stark_api.cpp -- C ABI entry for one synthetic-AIR table proof (include/bpg.h, L0.5).
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 #include "prover.hpp"
@@ -82,11 +83,11 @@ void bp_release_cached_memory(void) {
     }
 }
 
-int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
-                             uint8_t** out, size_t* out_len) try {
-  if (!cfg || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_stark_prove_synthetic: null argument");
+int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
+                       uint8_t** out, size_t* out_len) try {
+  if (!cfg || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_stark_prove_air: null argument");
   StarkCfg c{cfg->log_n, cfg->n_cols, cfg->n_const, cfg->deg_pow, cfg->rate_bits, cfg->cap_height,
-             cfg->num_queries, cfg->pow_bits, cfg->arity_bits, cfg->final_poly_bits};
+             cfg->num_queries, cfg->pow_bits, cfg->arity_bits, cfg->final_poly_bits, air_id};
   int rc = check_cfg(c);
   if (rc) return rc;
   const uint64_t N = (uint64_t)1 << c.log_n, M = N << c.rate_bits;
@@ -110,7 +111,8 @@ int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t co
     }
     uint64_t* d_trace = w.arena.alloc_words((size_t)c.n_cols * N);
     if (!d_trace) return fail(BP_ERR_DEVICE, "arena exhausted");
-    int r2 = launch_synth_trace(d_trace, d_consts, c.log_n, c.n_cols, c.n_const, c.deg_pow, seed, w.stream);
+    int r2 = c.air_id == air::KECCAK_F ? launch_keccak_trace(d_trace, nullptr, c.log_n, seed, w.stream)
+                                       : launch_synth_trace(d_trace, d_consts, c.log_n, c.n_cols, c.n_const, c.deg_pow, seed, w.stream);
     if (r2) return r2;
     if ((r2 = commit(w, d_trace, c.n_cols, c.log_n, c.rate_bits, c.cap_height, false, &trace))) return r2;
     ch.observe(trace.cap.data(), trace.cap.size());
@@ -129,32 +131,105 @@ int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t co
   park_worker(wp);
   return rc;
 }
-BPG_ABI_CATCH("bp_stark_prove_synthetic")
+BPG_ABI_CATCH("bp_stark_prove_air")
+
+int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
+                             uint8_t** out, size_t* out_len) {
+  return bp_stark_prove_air(air::SYNTHETIC, cfg, seed, const_seed, device, out, out_len);
+}
+
+// The CPU verifier for one table proof of bp_stark_prove_air (same transcript prologue: constants cap if any, trace
+// cap, four CTL challenges).  Host only: runs without a GPU.
+int bp_stark_verify_air(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint8_t* proof,
+                        size_t len) try {
+  if (!cfg || !proof) return fail(BP_ERR_INVALID_INPUT, "bp_stark_verify_air: null argument");
+  StarkCfg c{cfg->log_n, cfg->n_cols, cfg->n_const, cfg->deg_pow, cfg->rate_bits, cfg->cap_height,
+             cfg->num_queries, cfg->pow_bits, cfg->arity_bits, cfg->final_poly_bits, air_id};
+  int rc = check_cfg(c);
+  if (rc) return rc;
+  if (c.n_const && !const_cap) return fail(BP_ERR_INVALID_INPUT, "bp_stark_verify_air: the table has constant columns: pass their cap");
+  const ProofLayout L = proof_layout(c);
+  if (len != L.total * 8) return fail(BP_ERR_VERIFY, "proof has %zu bytes, expected %zu", len, L.total * 8);
+  std::vector<uint64_t> w(L.total);
+  std::memcpy(w.data(), proof, len);
+  Challenger ch;
+  if (c.n_const) ch.observe(const_cap, L.cap_words);
+  ch.observe(w.data() + L.trace_cap, L.cap_words);
+  Ctl ctl;
+  for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
+  return stark_verify(c, c.n_const ? const_cap : nullptr, ctl, ch, w.data(), w.size());
+}
+BPG_ABI_CATCH("bp_stark_verify_air")
+
+// ---- the AIR registry (air.hpp) --------------------------------------------------------------------------
+
+uint32_t bp_air_count(void) { return air::COUNT; }
+
+int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t deg_pow, bp_air_desc* out) try {
+  const air::Info* ai = air::info(air_id);
+  if (!ai || !out) return fail(BP_ERR_INVALID_INPUT, "bp_air_describe: unknown air_id %u or null output", air_id);
+  std::memset(out, 0, sizeof(*out));
+  out->air_id = air_id;
+  std::strncpy(out->name, ai->name, sizeof(out->name) - 1);
+  out->fixed_n_cols = ai->n_cols;
+  out->n_const_max = ai->n_const_max;
+  const uint32_t C = ai->n_cols ? ai->n_cols : n_cols, dp = ai->n_cols ? 1 : (deg_pow ? deg_pow : 1);
+  const air::Shape shape{air_id, C, ai->n_cols ? 0 : n_const, dp};
+  out->degree = ai->degree * dp;
+  out->n_cols = C;
+  out->n_aux = C / 8;
+  out->n_air_constraints = air::n_constraints(shape);
+  out->n_ctl_constraints = 2 * (C / 8);
+  out->n_units = air::n_units(shape);
+  // families: (first index, count, kind, degree); kinds: 0 all rows, 1 transition, 2 first row, 3 last row
+  uint32_t n = 0;
+  auto fam = [&](uint32_t first, uint32_t count, uint32_t kind, uint32_t degree) {
+    if (n < 16) out->families[n++] = bp_air_family{first, count, kind, degree};
+  };
+  if (air_id == air::KECCAK_F) {
+    namespace kk = air::keccak;
+    fam(kk::F0, 24, 2, 1); fam(kk::F1, 24, 1, 1); fam(kk::F2, 1984, 0, 2); fam(kk::F3, 320, 0, 3); fam(kk::F4, 320, 0, 3);
+    fam(kk::F5, 50, 0, 3); fam(kk::F6, 50, 0, 3); fam(kk::F7, 2, 0, 1); fam(kk::F8, 2, 0, 2); fam(kk::F9, 50, 1, 2);
+  } else {
+    // interleaved per group of four columns: 3g all rows, 3g + 1 transition, 3g + 2 first row
+    fam(0, C / 4, 0, 2); fam(1, C / 4, 1, 3 * dp); fam(2, C / 4, 2, 1);
+  }
+  fam(out->n_air_constraints, C / 8, 1, 2); fam(out->n_air_constraints + 1, C / 8, 3, 1);  // CTL: interleaved 2k, 2k + 1
+  out->n_families = n;
+  return BP_OK;
+}
+BPG_ABI_CATCH("bp_air_describe")
+
+int bp_keccak_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream) try {
+  if (!d_trace_out) return fail(BP_ERR_INVALID_INPUT, "bp_keccak_trace: null output");
+  if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_keccak_trace: log_n out of range");
+  return launch_keccak_trace(d_trace_out, d_inputs, log_n, seed, as_stream(stream));
+}
+BPG_ABI_CATCH("bp_keccak_trace")
 
 // ---- L0: the remaining per-stage entry points of SURVEY.md section 8(b) -------------------------------
 
-static int quot_cfg(const bp_stark_cfg* shape, StarkCfg* c) {
+static int quot_cfg(uint32_t air_id, const bp_stark_cfg* shape, StarkCfg* c) {
   if (!shape) return fail(BP_ERR_INVALID_INPUT, "null shape");
   *c = StarkCfg{shape->log_n, shape->n_cols, shape->n_const, shape->deg_pow, shape->rate_bits, shape->cap_height,
-                shape->num_queries, shape->pow_bits, shape->arity_bits, shape->final_poly_bits};
+                shape->num_queries, shape->pow_bits, shape->arity_bits, shape->final_poly_bits, air_id};
   return check_cfg(*c);
 }
 
-uint64_t bp_quotient_scratch_words(const bp_stark_cfg* shape) {
+uint64_t bp_quotient_scratch_words(uint32_t air_id, const bp_stark_cfg* shape) {
   StarkCfg c;
-  if (quot_cfg(shape, &c)) return 0;
+  if (quot_cfg(air_id, shape, &c)) return 0;
   QuotArgs qa{};
-  ChunkPows cp{};
   Ctl ctl{};
-  if (quotient_args(c, ctl, 1, 1, &qa, &cp)) return 0;
-  return (uint64_t)(qa.n_group_chunks + qa.n_aux_chunks) * 2 * (((uint64_t)1 << c.log_n) << c.rate_bits);
+  if (init_ntt_kernels() || quotient_args(c, ctl, 1, 1, &qa)) return 0;
+  return 2 * (uint64_t)qa.n_constraints + 48 + quotient_partial_words(qa);
 }
 
-int bp_quotient_eval(const bp_stark_cfg* shape, const uint64_t* d_trace_lde, const uint64_t* d_aux_lde,
+int bp_quotient_eval(uint32_t air_id, const bp_stark_cfg* shape, const uint64_t* d_trace_lde, const uint64_t* d_aux_lde,
                      const uint64_t* d_const_lde, const uint64_t ctl_in[4], const uint64_t alphas[2],
                      uint64_t* d_scratch, uint64_t* d_qvals_out, void* stream) try {
   StarkCfg c;
-  int rc = quot_cfg(shape, &c);
+  int rc = quot_cfg(air_id, shape, &c);
   if (rc) return rc;
   if (!d_trace_lde || !d_aux_lde || (c.n_const && !d_const_lde) || !ctl_in || !alphas || !d_scratch || !d_qvals_out)
     return fail(BP_ERR_INVALID_INPUT, "bp_quotient_eval: null argument");
@@ -165,11 +240,10 @@ int bp_quotient_eval(const bp_stark_cfg* shape, const uint64_t* d_trace_lde, con
   Ctl ctl;
   for (int i = 0; i < 4; i++) ctl.v[i] = ctl_in[i];
   QuotArgs qa{};
-  ChunkPows cp{};
   qa.trace_lde = d_trace_lde; qa.aux_lde = d_aux_lde; qa.const_lde = c.n_const ? d_const_lde : nullptr;
-  if ((rc = quotient_args(c, ctl, alphas[0], alphas[1], &qa, &cp))) return rc;
-  qa.partial = d_scratch; qa.qvals = d_qvals_out;
-  return launch_quotient(qa, cp, as_stream(stream));
+  if ((rc = quotient_args(c, ctl, alphas[0], alphas[1], &qa))) return rc;
+  qa.apow = d_scratch; qa.partial = d_scratch + 2 * (size_t)qa.n_constraints + 48; qa.qvals = d_qvals_out;
+  return launch_quotient(qa, as_stream(stream));
 }
 BPG_ABI_CATCH("bp_quotient_eval")
 

@@ -73,6 +73,56 @@ synth_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ consts
   if (i + 1 < n) a[3 * (uint64_t)n + i + 1] = gl::addc(pow_e(gl::mulc(ab, cv), deg_pow), bv);
 }
 
+// ---------------------------------------------------------------- Keccak-f witness (AIR 1, air.hpp)
+// Row r = round r % 24 of permutation r / 24.  A lane owns one row: it replays the earlier rounds of its
+// permutation in registers (at most 23 rounds of 64-bit logic, nothing next to the 2430 words it then stores) so
+// that every store of the launch is coalesced across rows.  grid.y splits the columns: 0 = flags, limbs, C, C',
+// A''; 1..5 = the A' bits of sheet row y - 1.  Input lanes: `inputs` ([permutation][25], any u64) or, when null,
+// splitmix64(seed ^ (lane << 32) ^ permutation) -- the same stream the oracle draws.
+__global__ void __launch_bounds__(256)
+keccak_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  namespace kk = bpg::air::keccak;
+  const uint32_t n = 1u << log_n;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t perm = i / 24, rnd_no = i % 24;
+  uint64_t a[25];
+  for (uint32_t l = 0; l < 25; l++)
+    a[l] = inputs ? inputs[(uint64_t)perm * 25 + l] : splitmix64(seed ^ ((uint64_t)l << 32) ^ perm);
+  kk::Round R;
+  for (uint32_t r = 0; r < rnd_no; r++) {
+    kk::round(a, r, R);
+    for (uint32_t l = 0; l < 25; l++) a[l] = R.app[l];
+    a[0] = R.appp0;
+  }
+  kk::round(a, rnd_no, R);
+  auto put = [&](uint32_t col, uint64_t v) { t[(uint64_t)col * n + i] = v; };
+  if (blockIdx.y == 0) {
+    for (uint32_t k = 0; k < 24; k++) put(kk::COL_STEP + k, k == rnd_no);
+    for (uint32_t l = 0; l < 25; l++) {
+      put(kk::COL_A + 2 * l, (uint32_t)a[l]);
+      put(kk::COL_A + 2 * l + 1, a[l] >> 32);
+      put(kk::COL_APP + 2 * l, (uint32_t)R.app[l]);
+      put(kk::COL_APP + 2 * l + 1, R.app[l] >> 32);
+    }
+    for (uint32_t x = 0; x < 5; x++)
+      for (uint32_t z = 0; z < 64; z++) {
+        put(kk::COL_C + 64 * x + z, (R.c[x] >> z) & 1);
+        put(kk::COL_CP + 64 * x + z, (R.cp[x] >> z) & 1);
+      }
+    for (uint32_t z = 0; z < 64; z++) put(kk::COL_APP0_BITS + z, (R.app[0] >> z) & 1);
+    put(kk::COL_APPP, (uint32_t)R.appp0);
+    put(kk::COL_APPP + 1, R.appp0 >> 32);
+  } else {
+    const uint32_t y = blockIdx.y - 1;
+    for (uint32_t x = 0; x < 5; x++) {
+      const uint64_t v = R.ap[x + 5 * y];
+      for (uint32_t z = 0; z < 64; z++) put(kk::COL_AP + 64 * (x + 5 * y) + z, (v >> z) & 1);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
 // z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
 // One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
@@ -135,21 +185,22 @@ aux_suffix_product_kernel(const uint64_t* __restrict__ trace, uint64_t* __restri
 }
 
 // ---------------------------------------------------------------- K5 quotient
-// Constraint order: per group g: all-rows, transition, first-row; then per
-// aux column: transition, last-row.  acc_j = acc_j*alpha_j + c (starky ConstraintConsumer).
-struct Acc {
-  uint64_t a0, a1, al0, al1;
-  __device__ __forceinline__ void push(uint64_t c) {
-    a0 = gl::addc(gl::mulc(a0, al0), c);
-    a1 = gl::addc(gl::mulc(a1, al1), c);
-  }
-};
+// One kernel for every AIR (air.hpp): a lane owns one point of the LDE coset, evaluates the units its workgroup
+// row was given and folds the constraints with the alpha powers IN REGISTERS:
+//   acc_j = sum_i c_i * alpha_j^(T-1-i)      (= starky's acc = acc * alpha + c over the whole list),
+// kept as unreduced dot-product accumulators (gl::DotAcc: 8 VALU per term, one reduction at the end).  A table
+// tall enough to fill the chip takes ONE pass (grid.y = 1): the quotient value is written straight away and no
+// partial sums ever reach HBM.  Short tables spread their units over grid.y workgroup rows; the partial sums of
+// the rows simply add (every term carries its absolute power), which quotient_sum_kernel does.
 struct RowPoint {
   uint64_t z_last, l_first, l_last;
 };
 __device__ __forceinline__ RowPoint row_point(const bpg::QuotArgs& q, uint32_t t, uint32_t m) {
-  const uint64_t x = gl::mulc(q.g_t[t], root_pow(q.tw_n, q.log_n, m));
-  const uint64_t zh = q.zh_t[t];
+  // per-coset constants from the table alpha_table_kernel left behind the alpha powers (t is a per-lane value:
+  // indexing the kernel-argument arrays with it would pull all 48 words into SGPRs)
+  const uint64_t* coset = q.apow + 2 * (size_t)q.n_constraints;
+  const uint64_t x = gl::mulc(coset[t], root_pow(q.tw_n, q.log_n, m));
+  const uint64_t zh = coset[16 + t];
   RowPoint p;
   p.z_last = gl::subc(x, q.g_inv);
   const uint64_t zn = gl::mulc(zh, q.n_inv);
@@ -160,62 +211,107 @@ __device__ __forceinline__ RowPoint row_point(const bpg::QuotArgs& q, uint32_t t
   p.l_last = gl::mulc(both, df);
   return p;
 }
-// grid = (rows/256, n_chunks).  Chunk y < n_group_chunks covers groups [y*GC, ...); the remaining
-// chunks cover aux columns.  partial[(chunk*2 + j)*rows + pos] = Horner partial of that chunk.
-__global__ void __launch_bounds__(256) quotient_partial_kernel(bpg::QuotArgs q) {
+struct DevRow {  // one point of the coset: column-major matrices, lanes = consecutive rows (coalesced)
+  const uint64_t *trace, *aux_, *cst_;
+  uint64_t ts, as, cs, pos, pos_next;
+  __device__ __forceinline__ uint64_t loc(uint32_t c) const { return trace[(uint64_t)c * ts + pos]; }
+  __device__ __forceinline__ uint64_t nxt(uint32_t c) const { return trace[(uint64_t)c * ts + pos_next]; }
+  __device__ __forceinline__ uint64_t cst(uint32_t k) const { return cst_[(uint64_t)k * cs + pos]; }
+  __device__ __forceinline__ uint64_t aux(uint32_t k) const { return aux_[(uint64_t)k * as + pos]; }
+  __device__ __forceinline__ uint64_t aux_nxt(uint32_t k) const { return aux_[(uint64_t)k * as + pos_next]; }
+};
+struct DevEmit {  // the constraint consumer: two constraints (x two challenges) per dot_mad4
+  const uint64_t* apow;  // [2][T]: alpha_j^e (wave-uniform reads)
+  uint32_t T;
+  RowPoint rp;
+  gl::DotAcc acc[4];  // 0, 1: challenge 0 / 1 of the first constraint of a pair; 2, 3: of the second
+  uint64_t pend_v;
+  uint32_t pend_e;
+  bool has;
+  __device__ __forceinline__ void push(uint32_t idx, uint64_t v) {
+    const uint32_t e = T - 1 - idx;
+    if (!has) {
+      pend_v = v; pend_e = e; has = true;
+      return;
+    }
+    const uint64_t a[4] = {pend_v, pend_v, v, v};
+    const uint64_t w[4] = {apow[pend_e], apow[T + pend_e], apow[e], apow[T + e]};
+    gl::dot_mad4(acc, a, w);
+    has = false;
+  }
+  __device__ __forceinline__ void all(uint32_t idx, uint64_t v) { push(idx, v); }
+  __device__ __forceinline__ void transition(uint32_t idx, uint64_t v) { push(idx, gl::mulc(v, rp.z_last)); }
+  __device__ __forceinline__ void first(uint32_t idx, uint64_t v) { push(idx, gl::mulc(v, rp.l_first)); }
+  __device__ __forceinline__ void last(uint32_t idx, uint64_t v) { push(idx, gl::mulc(v, rp.l_last)); }
+  __device__ __forceinline__ uint64_t result(int j) {
+    if (has) {
+      const uint64_t a[4] = {pend_v, pend_v, 0, 0};
+      const uint64_t w[4] = {apow[pend_e], apow[T + pend_e], 0, 0};
+      gl::dot_mad4(acc, a, w);
+      has = false;
+    }
+    return gl::addc(gl::dot_reduce(acc[j]), gl::dot_reduce(acc[2 + j]));
+  }
+};
+// grid = (rows / 256, workgroup rows); workgroup row y evaluates units [y * units_per_wg, ...) of the list
+// "AIR units, then CTL units".
+template <uint32_t AIR>
+__global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
   const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
   const uint32_t n = 1u << q.log_n;
   const uint32_t t = (uint32_t)(pos >> q.log_n), m = (uint32_t)(pos & (n - 1));
-  const uint64_t pos_next = ((uint64_t)t << q.log_n) | ((m + 1) & (n - 1));
-  const RowPoint rp = row_point(q, t, m);
-  Acc acc{0, 0, q.alpha0, q.alpha1};
-  const uint32_t chunk = blockIdx.y;
-  if (chunk < q.n_group_chunks) {
-    const uint32_t g0 = chunk * q.groups_per_chunk, g1 = min(g0 + q.groups_per_chunk, q.n_cols / 4);
-    for (uint32_t g = g0; g < g1; g++) {
-      const uint64_t* col = q.trace_lde + (uint64_t)(4 * g) * q.trace_stride;
-      const uint64_t a = col[pos], b = col[q.trace_stride + pos], c = col[2 * q.trace_stride + pos],
-                     d = col[3 * q.trace_stride + pos], dn = col[3 * q.trace_stride + pos_next];
-      const uint64_t qc = q.n_const ? q.const_lde[(uint64_t)(g % q.n_const) * q.const_stride + pos] : 1;
-      const uint64_t ab = gl::mulc(a, b);
-      acc.push(gl::subc(gl::subc(c, ab), gl::mulc(qc, a)));
-      const uint64_t tt = pow_e(gl::mulc(ab, c), q.deg_pow);
-      acc.push(gl::mulc(gl::subc(gl::subc(dn, tt), b), rp.z_last));
-      acc.push(gl::mulc(gl::subc(gl::subc(d, a), b), rp.l_first));
-    }
-  } else {
-    const uint32_t k0 = (chunk - q.n_group_chunks) * q.aux_per_chunk, k1 = min(k0 + q.aux_per_chunk, q.n_aux);
-    for (uint32_t k = k0; k < k1; k++) {
-      const uint64_t beta = q.ctl.v[2 * (k & 1)], gamma = q.ctl.v[2 * (k & 1) + 1];
-      const uint64_t a = q.trace_lde[(uint64_t)(8 * k) * q.trace_stride + pos],
-                     b = q.trace_lde[(uint64_t)(8 * k + 1) * q.trace_stride + pos];
-      const uint64_t z = q.aux_lde[(uint64_t)k * q.aux_stride + pos],
-                     zn = q.aux_lde[(uint64_t)k * q.aux_stride + pos_next];
-      const uint64_t term = gl::addc(gl::addc(gamma, a), gl::mulc(beta, b));
-      acc.push(gl::mulc(gl::subc(z, gl::mulc(zn, term)), rp.z_last));
-      acc.push(gl::mulc(gl::subc(z, term), rp.l_last));
+  DevRow row{q.trace_lde, q.aux_lde, q.const_lde, q.trace_stride, q.aux_stride, q.const_stride, pos,
+             ((uint64_t)t << q.log_n) | ((m + 1) & (n - 1))};
+  DevEmit out{q.apow, q.n_constraints, row_point(q, t, m),
+              {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()}, 0, 0, false};
+  const bpg::air::Shape shape{AIR, q.n_cols, q.n_const, q.deg_pow};
+  const uint32_t n_units = q.n_air_units + q.n_ctl_units;
+  const uint32_t u0 = blockIdx.y * q.units_per_wg, u1 = min(u0 + q.units_per_wg, n_units);
+#pragma unroll 1
+  for (uint32_t u = u0; u < u1; u++) {
+    if (u < q.n_air_units) {
+      if constexpr (AIR == bpg::air::KECCAK_F) bpg::air::keccak::eval_unit<uint64_t>(u, row, out);
+      else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
+    } else {
+      const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
+      bpg::air::eval_ctl<uint64_t>(q.n_air_constraints, k0, k1, q.ctl.v, row, out);
     }
   }
-  q.partial[((uint64_t)chunk * 2) * rows + pos] = acc.a0;
-  q.partial[((uint64_t)chunk * 2 + 1) * rows + pos] = acc.a1;
+  const uint64_t r0 = out.result(0), r1 = out.result(1);
+  if (gridDim.y == 1) {
+    const uint64_t zh_inv = q.apow[2 * (size_t)q.n_constraints + 32 + t];
+    q.qvals[pos] = gl::mulc(r0, zh_inv);
+    q.qvals[rows + pos] = gl::mulc(r1, zh_inv);
+  } else {
+    q.partial[((uint64_t)blockIdx.y * 2) * rows + pos] = r0;
+    q.partial[((uint64_t)blockIdx.y * 2 + 1) * rows + pos] = r1;
+  }
 }
-// acc = sum over chunks in order: acc*alpha^(#constraints in chunk) + partial; then / Z_H.
-__global__ void __launch_bounds__(256) quotient_combine_kernel(bpg::QuotArgs q, bpg::ChunkPows cp) {
+// qvals = (sum of the workgroup rows' partial sums) / Z_H.   grid = (rows / 256, 2 challenges)
+__global__ void __launch_bounds__(256) quotient_sum_kernel(bpg::QuotArgs q, uint32_t n_wg_rows) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
   const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
   const uint32_t j = blockIdx.y, t = (uint32_t)(pos >> q.log_n);
-  const uint32_t n_chunks = q.n_group_chunks + q.n_aux_chunks;
   uint64_t acc = 0;
-  for (uint32_t c = 0; c < n_chunks; c++) {
-    const uint64_t ap = cp.d_pows[c * 2 + j];
-    acc = gl::addc(gl::mulc(acc, ap), q.partial[((uint64_t)c * 2 + j) * rows + pos]);
-  }
-  q.qvals[(uint64_t)j * rows + pos] = gl::mulc(acc, q.zh_inv_t[t]);
+  for (uint32_t c = 0; c < n_wg_rows; c++) acc = gl::addc(acc, q.partial[((uint64_t)c * 2 + j) * rows + pos]);
+  q.qvals[(uint64_t)j * rows + pos] = gl::mulc(acc, q.apow[2 * (size_t)q.n_constraints + 32 + t]);
+}
+// apow[j * T + e] = alpha_j^e, then the per-coset constants: g_t[16], zh_t[16], zh_inv_t[16]
+struct CosetTab {
+  uint64_t v[48];
+};
+__global__ void __launch_bounds__(256)
+alpha_table_kernel(uint64_t* __restrict__ out, uint32_t T, uint64_t a0, uint64_t a1, CosetTab ct) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.y == 0 && e < 48) out[2 * (uint64_t)T + e] = ct.v[e];
+  if (e >= T) return;
+  out[(uint64_t)blockIdx.y * T + e] = gl::pow(blockIdx.y ? a1 : a0, e);
 }
 // After the per-coset inverse NTT: E_t[pos] (bit-reversed n0).  c_{n0 + n*n1} =
 // (s^n)^(-n1) / 2^r * sum_t w_{2^r}^(-t n1) * E_t[pos] * g_t^(-n0).   grid = (n/256, 2 challenges)
@@ -648,6 +744,12 @@ int launch_synth_trace(uint64_t* d_trace, const uint64_t* d_consts, uint32_t log
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_keccak_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 6);
+  keccak_trace_kernel<<<grid, 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
                hipStream_t st) {
   if (!n_aux) return BP_OK;
@@ -657,14 +759,23 @@ int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_quotient(const QuotArgs& q, const ChunkPows& cp, hipStream_t st) {
-  uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
-  dim3 g1(ceil_div(rows, 256), q.n_group_chunks + q.n_aux_chunks);
-  quotient_partial_kernel<<<g1, 256, 0, st>>>(q);
+int launch_quotient(const QuotArgs& q, hipStream_t st) {
+  const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
+  // the alpha-power table of this proof's two challenges (a few thousand words, read wave-uniformly)
+  CosetTab ct;
+  for (int t = 0; t < 16; t++) { ct.v[t] = q.g_t[t]; ct.v[16 + t] = q.zh_t[t]; ct.v[32 + t] = q.zh_inv_t[t]; }
+  alpha_table_kernel<<<dim3(ceil_div(q.n_constraints, 256), 2), 256, 0, st>>>(const_cast<uint64_t*>(q.apow), q.n_constraints,
+                                                                             q.alpha0, q.alpha1, ct);
   BPG_LAUNCH_CHECK();
-  dim3 g2(ceil_div(rows, 256), 2);
-  quotient_combine_kernel<<<g2, 256, 0, st>>>(q, cp);
+  const uint32_t n_units = q.n_air_units + q.n_ctl_units, wg_rows = ceil_div(n_units, q.units_per_wg);
+  dim3 g1(ceil_div(rows, 256), wg_rows);
+  if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(q);
+  else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(q);
   BPG_LAUNCH_CHECK();
+  if (wg_rows > 1) {
+    quotient_sum_kernel<<<dim3(ceil_div(rows, 256), 2), 256, 0, st>>>(q, wg_rows);
+    BPG_LAUNCH_CHECK();
+  }
   return BP_OK;
 }
 int launch_quotient_chunks(const ChunkArgs& c, hipStream_t st) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "air.hpp"
 #include "gl.hpp"
 
 namespace bpg {
@@ -14,16 +15,15 @@ struct Ctl {
 struct QuotArgs {
   const uint64_t *trace_lde, *aux_lde, *const_lde;
   uint64_t trace_stride, aux_stride, const_stride;
-  uint64_t *partial, *qvals;
-  const uint64_t* tw_n;  // w_n^e, e < n/2
-  uint32_t log_n, rate_bits, n_cols, n_const, n_aux, deg_pow;
-  uint32_t n_group_chunks, groups_per_chunk, n_aux_chunks, aux_per_chunk;
+  uint64_t *partial, *qvals;  // partial: [wg rows][2][rows], only when the units are spread over grid.y
+  const uint64_t* tw_n;       // w_n^e, e < n/2
+  const uint64_t* apow;       // [2][n_constraints] alpha_j^e, then 48 per-coset words; filled by launch_quotient
+  uint32_t air_id, log_n, rate_bits, n_cols, n_const, n_aux, deg_pow;
+  // the constraint list (air.hpp): AIR constraints, then two per aux column; units = AIR units, then CTL units
+  uint32_t n_air_constraints, n_constraints, n_air_units, n_ctl_units, aux_per_unit, units_per_wg;
   uint64_t alpha0, alpha1, g, g_inv, n_inv;
   uint64_t g_t[16], zh_t[16], zh_inv_t[16];  // per coset: 7*w_M^t, g_t^n - 1 and its inverse
   Ctl ctl;
-};
-struct ChunkPows {
-  uint64_t d_pows[128];  // [chunk][challenge]: alpha_j^(#constraints in the chunk)
 };
 struct ChunkArgs {
   const uint64_t* e;          // [2][2^r][n] per-coset inverse NTT output (bit-reversed)
@@ -94,9 +94,11 @@ struct QueryLayerArgs {
 int launch_synth_constants(uint64_t* d_out, uint32_t log_n, uint32_t n_const, uint64_t seed, hipStream_t st);
 int launch_synth_trace(uint64_t* d_trace, const uint64_t* d_consts, uint32_t log_n, uint32_t n_cols,
                        uint32_t n_const, uint32_t deg_pow, uint64_t seed, hipStream_t st);
+// AIR 1 witness: n rows x 2430 columns; d_inputs [ceil(n / 24)][25] lanes or null (then drawn from seed)
+int launch_keccak_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
                hipStream_t st);
-int launch_quotient(const QuotArgs& q, const ChunkPows& cp, hipStream_t st);
+int launch_quotient(const QuotArgs& q, hipStream_t st);
 int launch_quotient_chunks(const ChunkArgs& c, hipStream_t st);
 int launch_power_vectors(uint64_t* d_out, uint32_t log_n, gl::Ext z0, gl::Ext z1, uint32_t n_points,
                          hipStream_t st);

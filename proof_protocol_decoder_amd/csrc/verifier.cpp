@@ -38,15 +38,39 @@ bool merkle_verify(const uint64_t* leaf, size_t leaf_len, uint64_t index, const 
   return std::memcmp(cur, cap + 4 * index, 32) == 0;
 }
 
-struct Consumer {  // starky ConstraintConsumer over the extension field, base-field alphas
-  uint64_t alpha[2];
-  Ext acc[2];
-  void push(Ext c) {
-    for (int j = 0; j < 2; j++) acc[j] = gl::add(gl::scale(acc[j], alpha[j]), c);
-  }
-};
 Ext rd(const uint64_t* p, size_t i) { return Ext{p[2 * i], p[2 * i + 1]}; }
-Ext pow_e(Ext t, uint32_t e) { return e == 3 ? gl::mul(gl::mul(t, t), t) : t; }
+// The opened row at zeta / g*zeta as the AIR evaluators (air.hpp) read it.
+struct OpenedRow {
+  const uint64_t *cst_, *loc_, *nxt_, *aux_, *aux_nxt_;
+  Ext cst(uint32_t k) const { return rd(cst_, k); }
+  Ext loc(uint32_t c) const { return rd(loc_, c); }
+  Ext nxt(uint32_t c) const { return rd(nxt_, c); }
+  Ext aux(uint32_t k) const { return rd(aux_, k); }
+  Ext aux_nxt(uint32_t k) const { return rd(aux_nxt_, k); }
+};
+// starky ConstraintConsumer over the extension field with base-field alphas: acc_j = sum_i c_i alpha_j^(T-1-i),
+// which is acc = acc * alpha + c over the list, whatever order the evaluators emit in.
+struct Consumer {
+  std::vector<uint64_t> apow[2];  // alpha_j^e, e < T
+  uint32_t T;
+  Ext z_last, l_first, l_last;
+  Ext acc[2];
+  Consumer(uint32_t T_, uint64_t a0, uint64_t a1) : T(T_) {
+    const uint64_t al[2] = {a0, a1};
+    for (int j = 0; j < 2; j++) {
+      apow[j].resize(T);
+      uint64_t p = 1;
+      for (uint32_t e = 0; e < T; e++, p = gl::mulc(p, al[j])) apow[j][e] = p;
+      acc[j] = gl::ext(0);
+    }
+  }
+  void all(uint32_t idx, Ext c) {
+    for (int j = 0; j < 2; j++) acc[j] = gl::add(acc[j], gl::scale(c, apow[j][T - 1 - idx]));
+  }
+  void transition(uint32_t idx, Ext c) { all(idx, gl::mul(c, z_last)); }
+  void first(uint32_t idx, Ext c) { all(idx, gl::mul(c, l_first)); }
+  void last(uint32_t idx, Ext c) { all(idx, gl::mul(c, l_last)); }
+};
 
 // fri::verifier::compute_evaluation: interpolate the arity coset values, evaluate at beta.
 Ext compute_evaluation(uint64_t x, uint32_t in_coset_br, uint32_t arity_bits, const uint64_t* evals, Ext beta) {
@@ -85,7 +109,7 @@ int stark_verify(const StarkCfg& cfg, const uint64_t* const_cap, const Ctl& ctl,
   const uint64_t N = (uint64_t)1 << log_n, M = N << r;
   const uint32_t C = cfg.n_cols, K = cfg.n_const, A = L.n_aux, Q = L.n_quot, qdf = 1u << r, arity = 1u << cfg.arity_bits;
   if (P[0] != PROOF_MAGIC || P[1] != log_n || P[2] != C || P[3] != K || P[6] != r || P[8] != cfg.num_queries ||
-      P[9] != L.n_layers || P[10] != L.final_len)
+      P[9] != L.n_layers || P[10] != L.final_len || P[14] != cfg.air_id)
     REJECT("proof header does not match the circuit shape");
   for (size_t i = PROOF_HDR_WORDS; i < L.queries; i++)
     if (P[i] >= gl::P) REJECT("non-canonical field element at word %zu", i);
@@ -102,26 +126,15 @@ int stark_verify(const StarkCfg& cfg, const uint64_t* const_cap, const Ctl& ctl,
     const Ext zn = gl::pow(zeta, N), zh = gl::sub(zn, gl::ext(1));
     if (gl::eq(zh, gl::ext(0))) REJECT("Opening point is in the subgroup.");
     const Ext zhn = gl::scale(zh, gl::inv(N));
-    Consumer k{{alpha0, alpha1}, {gl::ext(0), gl::ext(0)}};
-    const Ext z_last = gl::sub(zeta, gl::ext(gl::inv(g)));
-    const Ext l_first = gl::mul(zhn, gl::inv(gl::sub(zeta, gl::ext(1))));
-    const Ext l_last = gl::mul(zhn, gl::inv(gl::sub(gl::scale(zeta, g), gl::ext(1))));
-    const uint64_t *loc = oz + 2 * (size_t)K, *ax = oz + 2 * (size_t)(K + C), *axn = on + 2 * (size_t)C;
-    for (uint32_t gi = 0; gi < C / 4; gi++) {
-      const Ext a = rd(loc, 4 * gi), b = rd(loc, 4 * gi + 1), c = rd(loc, 4 * gi + 2), d = rd(loc, 4 * gi + 3);
-      const Ext q = K ? rd(oz, gi % K) : gl::ext(1);
-      const Ext ab = gl::mul(a, b);
-      k.push(gl::sub(gl::sub(c, ab), gl::mul(q, a)));
-      const Ext t = pow_e(gl::mul(ab, c), cfg.deg_pow);
-      k.push(gl::mul(gl::sub(gl::sub(rd(on, 4 * gi + 3), t), b), z_last));
-      k.push(gl::mul(gl::sub(gl::sub(d, a), b), l_first));
-    }
-    for (uint32_t j = 0; j < A; j++) {
-      const uint64_t beta = ctl.v[2 * (j & 1)], gamma = ctl.v[2 * (j & 1) + 1];
-      const Ext term = gl::add(gl::add(gl::ext(gamma), rd(loc, 8 * j)), gl::scale(rd(loc, 8 * j + 1), beta));
-      k.push(gl::mul(gl::sub(rd(ax, j), gl::mul(rd(axn, j), term)), z_last));
-      k.push(gl::mul(gl::sub(rd(ax, j), term), l_last));
-    }
+    const air::Shape shape{cfg.air_id, C, K, cfg.deg_pow};
+    const uint32_t n_air = air::n_constraints(shape);
+    Consumer k(n_air + 2 * A, alpha0, alpha1);
+    k.z_last = gl::sub(zeta, gl::ext(gl::inv(g)));
+    k.l_first = gl::mul(zhn, gl::inv(gl::sub(zeta, gl::ext(1))));
+    k.l_last = gl::mul(zhn, gl::inv(gl::sub(gl::scale(zeta, g), gl::ext(1))));
+    const OpenedRow row{oz, oz + 2 * (size_t)K, on, oz + 2 * (size_t)(K + C), on + 2 * (size_t)C};
+    for (uint32_t u = 0; u < air::n_units(shape); u++) air::eval_unit<Ext>(shape, u, row, k);
+    air::eval_ctl<Ext>(n_air, 0, A, ctl.v, row, k);
     const uint64_t* oq = oz + 2 * (size_t)(K + C + A);
     for (int j = 0; j < 2; j++) {
       Ext acc = gl::ext(0);

@@ -72,16 +72,40 @@ def field_ops(a, b):
     return out
 
 
-def quotient_eval(cfg, trace_lde, aux_lde, const_lde, ctl, alphas):
-    """bp_quotient_eval: [2, n << rate_bits] quotient values (coset-major) of the synthetic AIR."""
+AIR_SYNTHETIC, AIR_KECCAK_F = 0, 1
+KECCAK_COLS = 2430
+
+
+def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
+    """bp_air_describe: shape and constraint list of a built-in AIR."""
+    from ._lib import AirDesc
+    d = AirDesc()
+    check(lib().bp_air_describe(air_id, n_cols, n_const, deg_pow, C.byref(d)))
+    return d
+
+
+def keccak_trace(log_n, seed=0, inputs=None, device="cuda"):
+    """bp_keccak_trace: the AIR-1 witness [2430, 2^log_n]; inputs [n_perm, 25] int64 lanes on the device, or drawn
+    from `seed`."""
+    out = torch.empty((KECCAK_COLS, 1 << log_n), dtype=torch.int64, device=device)
+    if inputs is not None:
+        _require_cuda(inputs)
+        assert inputs.shape == (((1 << log_n) + 23) // 24, 25)
+    check(lib().bp_keccak_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
+    return out
+
+
+def quotient_eval(cfg, trace_lde, aux_lde, const_lde, ctl, alphas, air_id=AIR_SYNTHETIC):
+    """bp_quotient_eval: [2, n << rate_bits] quotient values (coset-major) of AIR `air_id`."""
     _require_cuda(trace_lde)
     _require_cuda(aux_lde)
     if const_lde is not None:
         _require_cuda(const_lde)
     rows = trace_lde.shape[1]
-    scratch = torch.empty(int(lib().bp_quotient_scratch_words(C.byref(cfg))), dtype=torch.int64, device=trace_lde.device)
+    scratch = torch.empty(int(lib().bp_quotient_scratch_words(air_id, C.byref(cfg))), dtype=torch.int64,
+                          device=trace_lde.device)
     out = torch.empty((2, rows), dtype=torch.int64, device=trace_lde.device)
-    check(lib().bp_quotient_eval(C.byref(cfg), trace_lde.data_ptr(), aux_lde.data_ptr(),
+    check(lib().bp_quotient_eval(air_id, C.byref(cfg), trace_lde.data_ptr(), aux_lde.data_ptr(),
                                  const_lde.data_ptr() if const_lde is not None else None,
                                  (C.c_uint64 * 4)(*[int(x) for x in ctl]), (C.c_uint64 * 2)(*[int(x) for x in alphas]),
                                  scratch.data_ptr(), out.data_ptr(), _stream()))
@@ -133,6 +157,14 @@ def stark_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, nu
               arity_bits=4, final_poly_bits=5):
     return StarkCfg(log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits, arity_bits,
                     final_poly_bits)
+
+
+def stark_prove_air(air_id, cfg, seed, const_seed=0, device=0):
+    """One table proof on AIR `air_id`, witness generated on the device.  Returns proof words (u64)."""
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    check(lib().bp_stark_prove_air(air_id, C.byref(cfg), seed, const_seed, device, C.byref(out), C.byref(n)))
+    return np.frombuffer(take_buffer(out, n), dtype=np.uint64).copy()
 
 
 def stark_prove_synthetic(cfg, seed, const_seed=0, device=0):

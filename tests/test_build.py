@@ -20,13 +20,16 @@ def test_build_entry_compiles_everything():
         assert os.path.exists(os.path.join(ROOT, rel)), rel
 
 
-def test_no_kernel_spills_sgprs(tmp_path):
+def test_no_throughput_kernel_spills_sgprs(tmp_path):
     """The carry-chain arithmetic (csrc/gl.hpp) keeps carries as wave masks in SGPR pairs written by inline asm.
     If register pressure made the compiler park such a mask in a VGPR lane (v_writelane) right after the asm
     wrote it, the read would need 2 wait states that the hazard recogniser cannot provide (it does not see writes
-    inside inline asm).  The kernels are therefore kept free of SGPR spills; this compiles them and checks."""
+    inside inline asm).  The rule itself is checked instruction by instruction on every kernel by
+    test_no_valu_reads_a_fresh_asm_carry_mask (which also sees v_writelane / v_readlane); on top of it the
+    throughput kernels (Poseidon, NTT) are kept free of SGPR spills altogether, which is also what their speed
+    wants.  The AIR-generic quotient kernel of stark_kernels.hip holds ~50 SGPRs of kernel arguments next to the
+    masks and spills a handful of those arguments (never a mask: the scan proves it), so it is exempt here."""
     import re
-    import subprocess
     csrc = os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc")
     bad = []
     for src in ("hash_kernels.hip", "ntt.hip", "stark_kernels.hip"):
@@ -40,8 +43,11 @@ def test_no_kernel_spills_sgprs(tmp_path):
             if m:
                 name = m.group(1)
             m = re.match(r"\s+\.sgpr_spill_count:\s+(\d+)", line)
-            if m and int(m.group(1)):
+            if m and int(m.group(1)) and "quotient_air_kernel" not in name:
                 bad.append((src, name, int(m.group(1))))
+            m = re.match(r"\s+\.sgpr_spill_count:\s+(\d+)", line)
+            if m and "quotient_air_kernel" in name:
+                assert int(m.group(1)) <= 16, (name, "spills far more than a few kernel arguments: look at it")
     assert not bad, bad
 
 
@@ -128,7 +134,7 @@ def scan_carry_mask_hazards(text):
     import re
     bad, n_asm_writes = [], 0
     in_asm = False
-    recent = []  # (wait states since the write, scalar registers written by a VALU instruction inside asm)
+    recent = []  # (wait states since the write, scalar registers a VALU instruction wrote, was it inside asm)
     for ln, line in enumerate(text.splitlines(), 1):
         t = line.strip()
         if "ASMSTART" in t and t.startswith(";"):
@@ -149,21 +155,21 @@ def scan_carry_mask_hazards(text):
             reads = set()
             for o in operands[n_dst:]:
                 reads |= _sregs(o)
-            for age, regs in recent:
-                if age < 2 and regs & reads:
-                    bad.append((ln, t))
+            # the compiler protects pairs of its own instructions; everything with one end inside asm is ours
+            if any(age < 2 and regs & reads and (w_in_asm or in_asm) for age, regs, w_in_asm in recent):
+                bad.append((ln, t))
         if op.startswith("s_") and operands and not op.startswith(("s_nop", "s_cmp", "s_waitcnt", "s_cbranch")):
             # a scalar-unit write replaces the mask: the later read is of THAT value (no VALU-write hazard)
             over = _sregs(operands[0])
-            recent = [(age, regs - over) for age, regs in recent]
-        recent = [(age + states, regs) for age, regs in recent if age + states < 2 and regs]
-        if in_asm and op.startswith("v_"):
+            recent = [(age, regs - over, a) for age, regs, a in recent]
+        recent = [(age + states, regs, a) for age, regs, a in recent if age + states < 2 and regs]
+        if op.startswith("v_"):
             written = set()
             for o in operands[:n_dst]:
                 written |= _sregs(o)
             if written:
-                n_asm_writes += 1
-                recent.append((0, written))
+                n_asm_writes += in_asm
+                recent.append((0, written, in_asm))
     return bad, n_asm_writes
 
 
@@ -197,6 +203,17 @@ def test_carry_mask_scanner_sees_a_violation():
     bad, _ = scan_carry_mask_hazards("\t;;#ASMSTART\n\tv_cmp_lt_u64_e64 vcc, v[1:2], v[3:4]\n\t;;#ASMEND\n"
                                      "\tv_cndmask_b32_e32 v1, v2, v3, vcc\n")
     assert len(bad) == 1
+    # a spilled mask coming back (v_readlane, the compiler's own instruction) read by asm right away: ours to catch;
+    # the same pair outside asm is the hazard recogniser's business
+    reload = "\tv_readlane_b32 s8, v116, 3\n\tv_readlane_b32 s9, v116, 4\n"
+    bad, _ = scan_carry_mask_hazards(reload + "\t;;#ASMSTART\n\tv_addc_co_u32_e64 v4, s[10:11], v5, v1, s[8:9]\n\t;;#ASMEND\n")
+    assert len(bad) == 1
+    bad, _ = scan_carry_mask_hazards(reload + "\tv_addc_co_u32_e64 v4, s[10:11], v5, v1, s[8:9]\n")
+    assert bad == []
+    # spilling a fresh mask: v_writelane is a VALU read of the SGPR
+    bad, _ = scan_carry_mask_hazards("\t;;#ASMSTART\n\tv_add_co_u32_e64 v3, s[8:9], v3, v4\n\t;;#ASMEND\n"
+                                     "\tv_writelane_b32 v116, s8, 0\n")
+    assert len(bad) == 1
 
 
 def test_no_valu_reads_a_fresh_asm_carry_mask(tmp_path):
@@ -206,7 +223,9 @@ def test_no_valu_reads_a_fresh_asm_carry_mask(tmp_path):
     there: tools/gen_cc_ops.py interleaves 3-4 independent elements per asm statement so that every consumer is
     >= 2 instructions behind its producer, and the one-element forms carry `s_nop 1`.  This scans the device
     assembly for the rule itself: no VALU instruction (inside asm or emitted by the compiler) may read an SGPR
-    that a VALU instruction inside an ASMSTART/ASMEND region wrote fewer than 2 wait states earlier."""
+    that a VALU instruction inside an ASMSTART/ASMEND region wrote fewer than 2 wait states earlier, and no VALU
+    instruction inside such a region may read one that ANY VALU instruction wrote that recently (a v_readlane that
+    brings a spilled mask back, a compiler-made compare)."""
     csrc = os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc")
     bad, n_asm_writes = [], 0
     for src in ("hash_kernels.hip", "ntt.hip", "stark_kernels.hip"):

@@ -18,7 +18,11 @@ import numpy as np  # noqa: E402
 
 from oracle import pyoracle as orc  # noqa: E402
 
-log_n, C = int(sys.argv[1]), 2432
+log_n = int(sys.argv[1])
+# second argument "keccak_f": the same configuration as a REAL Keccak-f[1600] trace (AIR 1, 2430 columns, witness
+# drawn from the seed); merge under "tables" as logn<k>_keccak_f
+AIR = 1 if len(sys.argv) > 2 and sys.argv[2] == "keccak_f" else 0
+C = 2430 if AIR else 2432
 try:  # OpenMP would otherwise start one thread per host core, not per core of this process's share
     import ctypes
     _n = len(os.sched_getaffinity(0))
@@ -44,8 +48,8 @@ def _heartbeat():  # the GPU box takes 7 silent minutes for a hang
 
 _heartbeat()
 t0 = time.time()
-cfg = orc.make_cfg(log_n, C)
-tr = orc.synth_trace(0x5EED000000000004, cfg, None)
+cfg = orc.make_cfg(log_n, C, air_id=AIR)
+tr = orc.keccak_trace(log_n, seed=0x5EED000000000004) if AIR else orc.synth_trace(0x5EED000000000004, cfg, None)
 t1 = time.time()
 tc = orc.Committed.from_values(tr, 1, 4)
 t2 = time.time()
@@ -55,7 +59,7 @@ ctl = np.array([ch.challenge() for _ in range(4)], dtype=np.uint64)
 proof = orc.stark_prove(cfg, tr, ctl, ch, None, tc)
 t3 = time.time()
 w = np.ascontiguousarray(proof, dtype="<u8")
-print(json.dumps({"shape": [log_n, C, 0, 1, 1], "seed": "0x5EED000000000004", "sha256": hashlib.sha256(w.tobytes()).hexdigest(),
+print(json.dumps({"air_id": AIR, "shape": [log_n, C, 0, 1, 1], "seed": "0x5EED000000000004", "sha256": hashlib.sha256(w.tobytes()).hexdigest(),
                   "n_words": int(w.size), "head": [int(x) for x in w[:6]], "tail": [int(x) for x in w[-2:]],
                   "oracle_seconds": {"trace": round(t1 - t0, 1), "commit": round(t2 - t1, 1), "prove": round(t3 - t2, 1)},
                   "peak_rss_gib": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 2**20, 1)}))
