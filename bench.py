@@ -225,6 +225,10 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
+    if args.phase_marks and rank == 0:
+        pr = torch.cuda.get_device_properties(local_rank)
+        print("@pci %04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id), file=sys.stderr, flush=True)
+
     def phase(name):
         if args.phase_marks and rank == 0:
             free_b, total_b = torch.cuda.mem_get_info()

@@ -108,9 +108,10 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
  * 2^13 under load.  A caller that drives the L0 entry points from many streams itself should set 2^13: the library
  * cannot see that load. */
 void bp_tune_quad_threshold(uint64_t n_perms);
-/* 1: Merkle levels below the quad threshold are fused, up to 7 per launch; 0 (default, ~3% faster under
- * multi-stream load): one launch per level.  Results are identical. */
-void bp_tune_merkle_fused(int on);
+/* Merkle levels of at most 4096 nodes: 1 = fused, up to 7 levels per launch (LDS hand-down); 0 = one launch per
+ * level (0-3 % faster under multi-stream load, where no single launch is waited for); -1 (default) = fused while
+ * fewer than 6 provers are at work on the device (a lone proof, the tail of a shard).  Results are identical. */
+void bp_tune_merkle_fused(int mode);
 /* 1 (default): hashing launches at or above the quad threshold use the matrix-core form of the permutation
  * (csrc/poseidon_mx.cuh: the MDS layer as int8 MFMAs on the byte planes of the state); 0: one lane per state.
  * Results are identical either way. */

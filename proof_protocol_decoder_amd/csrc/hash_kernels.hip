@@ -401,7 +401,12 @@ uint64_t quad_threshold() {
   if (g_poseidon_mx_on()) return (uint64_t)1 << (loaded ? 13 : 19);
   return (uint64_t)1 << (loaded ? 13 : 17);
 }
-static std::atomic<int> g_merkle_fused{0};  // measured: per-level launches are ~3% faster under 16-stream load
+// Levels near the root are each one latency-bound launch (a lone txn proof spends ~30 % of its kernel time in them,
+// profiles/r2b_kernel_stats_4txn_1stream.csv); merkle_subtree_quad_kernel hands up to seven of them down through LDS
+// in one launch.  Under full load the per-level launches were 0-3 % faster (nothing waits on any single launch), so
+// the fused form follows the load: -1 = fused while fewer than six provers are at work (a lone txn, the tail of a
+// shard, small blocks), 0 = never, 1 = always.
+static std::atomic<int> g_merkle_fused{-1};
 // launches at or above the quad threshold: 1 = matrix-core form (poseidon_mx.cuh), 0 = one lane per state
 static std::atomic<int> g_poseidon_mx{1};
 bool poseidon_mx() { return g_poseidon_mx.load(std::memory_order_relaxed) != 0; }
@@ -436,7 +441,8 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     const uint64_t cnt = (uint64_t)1 << l, parents = cnt / 2;
     uint64_t* nxt = lvl + cnt * 4;
     // fuse only what fits in <= 64 workgroups: those launches are latency-critical and run at raised priority
-    const bool fused = parents <= 4096 && parents < quad_threshold() && g_merkle_fused.load(std::memory_order_relaxed);
+    const int fmode = g_merkle_fused.load(std::memory_order_relaxed);
+    const bool fused = parents <= 4096 && parents < quad_threshold() && (fmode > 0 || (fmode < 0 && !device_loaded()));
     if (!fused) {
       uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;
       if (const int ns = mx_sets(parents)) {
@@ -497,7 +503,7 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
   return BP_OK;
 }
 
-void bp_tune_merkle_fused(int on) { bpg::g_merkle_fused.store(on != 0); }
+void bp_tune_merkle_fused(int mode) { bpg::g_merkle_fused.store(mode < 0 ? -1 : (mode != 0)); }
 void bp_tune_quad_threshold(uint64_t n_perms) { bpg::g_quad_threshold.store(n_perms); }
 void bp_tune_poseidon_mx(int on) { bpg::g_poseidon_mx.store(on != 0); }
 // Host only: the C-operand table of the matrix-core Poseidon kernels (poseidon_mx.cuh), 30 x 4 x 24 u32, for the CPU test

@@ -4,10 +4,9 @@ timestamps the command writes to stderr as lines `@phase <name>` (bench.py --pha
 
     python tools/smi_sampler.py gpurun_out/smi_A.csv -- python bench.py --phase-marks ...
 
-Reads only world-readable sysfs files of card 0's device; falls back to `rocm-smi --json` at 2 Hz when none exist.
+Reads only world-readable sysfs files of the card the command names (`@pci <domain:bus:dev.fn>` on stderr).
 """
 import glob
-import json
 import os
 import subprocess
 import sys
@@ -15,10 +14,14 @@ import threading
 import time
 
 
-def find_sources():
+def find_sources(bdf=None):
+    """sysfs files of the card whose PCI address is `bdf` (the command names it on stderr as `@pci <bdf>`: a GPU box
+    shows all of the host's cards in sysfs, only one of which is ours); the first card when none is named."""
     src = {}
     for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
         if not os.path.exists(os.path.join(dev, "gpu_busy_percent")):
+            continue
+        if bdf and os.path.basename(os.path.realpath(dev)).lower() != bdf.lower():
             continue
         src["busy"] = os.path.join(dev, "gpu_busy_percent")
         for name, pat in (("power_uW", "hwmon/hwmon*/power1_average"), ("power_uW", "hwmon/hwmon*/power1_input"),
@@ -52,12 +55,12 @@ def dpm_current(txt):
 def main():
     out_csv = sys.argv[1]
     cmd = sys.argv[sys.argv.index("--") + 1:]
-    src = find_sources()
-    keys = sorted(src)
-    rows, phases, stop = [], [], threading.Event()
+    src, keys = {}, []
+    rows, phases, stop, have_card = [], [], threading.Event(), threading.Event()
     t0 = time.time()
 
     def sample():
+        have_card.wait(120)          # the command names its card first
         while not stop.is_set():
             r = [time.time() - t0]
             for k in keys:
@@ -66,29 +69,25 @@ def main():
             rows.append(r)
             time.sleep(0.05)
 
-    def sample_smi():
-        while not stop.is_set():
-            try:
-                j = json.loads(subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--showuse", "--json"],
-                                              capture_output=True, text=True, timeout=10).stdout)
-                rows.append([time.time() - t0, json.dumps(j.get("card0", j))])
-            except Exception as e:  # noqa: BLE001
-                rows.append([time.time() - t0, "rocm-smi failed: %s" % e])
-            time.sleep(0.5)
-
-    th = threading.Thread(target=sample if src else sample_smi, daemon=True)
+    th = threading.Thread(target=sample, daemon=True)
     th.start()
     p = subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)
     for line in p.stderr:
-        if line.startswith("@phase "):
+        if line.startswith("@pci ") and not have_card.is_set():
+            src.update(find_sources(line.split()[1]) or find_sources())
+            keys.extend(sorted(src))
+            print("sampling %s" % os.path.dirname(src.get("busy", "?")), file=sys.stderr)
+            have_card.set()
+        elif line.startswith("@phase "):
             phases.append((time.time() - t0, line.split(None, 1)[1].strip()))
         else:
             sys.stderr.write(line)
     rc = p.wait()
     stop.set()
+    have_card.set()
     th.join()
     with open(out_csv, "w") as f:
-        f.write(",".join(["t"] + (keys if src else ["rocm_smi_json"])) + "\n")
+        f.write(",".join(["t"] + keys) + "\n")
         for r in rows:
             f.write(",".join(str(x).replace(",", ";") for x in r) + "\n")
     if src:
