@@ -13,7 +13,8 @@ Extra objects on the JSON line:
   roofline      -- the coset-LDE NTT kernel family (the HBM-roofline kernel the metric names): HIP events on the
                    kernel's own stream over a single-stream leg run before the block (2 txn proofs, nothing else on
                    the chip); traffic = algorithmic bytes x the PMC-measured ratio of a tracked profiles/ summary;
-  roofline_in_situ  -- the same launches inside the timed region (24 streams share the chip: not the kernel's cost);
+  roofline_in_situ  -- (only with --in-situ-profile: the event records cost 2.4 % of the rate) the same launches inside
+                       the timed region (24 streams share the chip: not the kernel's cost);
   roofline_isolated -- the same kernel alone on the chip at the widest table shape;
   ntt_hbm_gbps  -- BASELINE's second figure: the batched inverse NTT alone at four shapes;
   alu_kernel    -- Merkle leaf hashing (Poseidon; the time-dominant kernels, VALU-issue-bound) over the same leg, against
@@ -68,8 +69,10 @@ def main():
                          "optimum (profiles/README.md), the waits sleep so the count is not tied to host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline leg)")
-    ap.add_argument("--no-in-situ-profile", action="store_true",
-                    help="do not time the LDE launches inside the timed region (pooled HIP events: no measurable cost)")
+    ap.add_argument("--in-situ-profile", action="store_true",
+                    help="also time every LDE launch INSIDE the timed region with HIP events (roofline_in_situ).  Off by "
+                         "default: the event records cost 2.4 %% of the block rate (profiles/r3_order_experiment.txt)")
+    ap.add_argument("--no-in-situ-profile", action="store_true", help="(accepted for older command lines: the default)")
     ap.add_argument("--extra-workers", type=int, default=0,
                     help="prover streams beyond --threads that idle until a txn can fan its seven recursion chains out "
                          "to them (ends of shards, small blocks)")
@@ -78,6 +81,7 @@ def main():
     ap.add_argument("--ntt-split", type=int, default=None, help="bp_tune_ntt_split mode (measurement knob)")
     ap.add_argument("--ntt-mx", type=int, default=None, help="bp_tune_ntt_mx mode (measurement knob)")
     ap.add_argument("--poseidon-mx", type=int, default=None, help="bp_tune_poseidon_mx (measurement knob)")
+    ap.add_argument("--poseidon-grouped", type=int, default=None, help="bp_tune_poseidon_grouped (measurement knob)")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
                     help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
     ap.add_argument("--leg-only", action="store_true",
@@ -151,6 +155,8 @@ def main():
         L.bp_tune_ntt_mx(args.ntt_mx)
     if args.poseidon_mx is not None:
         L.bp_tune_poseidon_mx(args.poseidon_mx)
+    if args.poseidon_grouped is not None:
+        L.bp_tune_poseidon_grouped(args.poseidon_grouped)
 
     def read_family(note, leg=True):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
@@ -260,7 +266,8 @@ def main():
     phase("warmup")
     for b in range(args.warmup):
         last = driver.prove_block_distributed(blocks[b], rank, world, gather)
-    if not args.no_profile and not args.no_in_situ_profile:
+    in_situ = args.in_situ_profile and not args.no_profile and not args.no_in_situ_profile
+    if in_situ:
         L.bp_profile_reset()
         L.bp_profile_enable(1)
     barrier()
@@ -281,7 +288,7 @@ def main():
         dt = float(t.item())
 
     roofline_in_situ = None
-    if not args.no_profile and not args.no_in_situ_profile:
+    if in_situ:
         roofline_in_situ = read_family("HIP events around every launch in the timed region; %d prover streams share "
                                        "the chip, mostly with integer-ALU-bound Poseidon kernels, so a launch's "
                                        "duration is not the kernel's own cost" % args.threads, leg=False)
@@ -333,6 +340,7 @@ def main():
             knobs = []
             for flag, val in (("--merkle-fused", args.merkle_fused), ("--ntt-split", args.ntt_split),
                               ("--ntt-mx", args.ntt_mx), ("--poseidon-mx", args.poseidon_mx),
+                              ("--poseidon-grouped", args.poseidon_grouped),
                               ("--quad-threshold-log2", args.quad_threshold_log2)):
                 if val is not None:
                     knobs += [flag, str(val)]

@@ -108,9 +108,9 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
  * 2^13 under load.  A caller that drives the L0 entry points from many streams itself should set 2^13: the library
  * cannot see that load. */
 void bp_tune_quad_threshold(uint64_t n_perms);
-/* Merkle levels of at most 4096 nodes: 1 = fused, up to 7 levels per launch (LDS hand-down); 0 = one launch per
- * level (0-3 % faster under multi-stream load, where no single launch is waited for); -1 (default) = fused while
- * fewer than 6 provers are at work on the device (a lone proof, the tail of a shard).  Results are identical. */
+/* Merkle levels of at most 4096 nodes: 0 (default) = one launch per level; 1 = fused, up to 7 levels per launch
+ * (LDS hand-down, quad-cooperative permutation); -1 = fused while fewer than 6 provers are at work on the device.
+ * Measured: the fused form is 0-4 % slower, loaded or not (profiles/r3_small_shards.txt).  Results are identical. */
 void bp_tune_merkle_fused(int mode);
 /* 1 (default): hashing launches at or above the quad threshold use the matrix-core form of the permutation
  * (csrc/poseidon_mx.cuh: the MDS layer as int8 MFMAs on the byte planes of the state); 0: one lane per state.
@@ -119,6 +119,11 @@ void bp_tune_poseidon_mx(int on);
 /* Sets of 16 states a wave of the matrix-core form carries: 4, 2 or 1 (fewer sets = more waves for the same launch);
  * 0 (default) = by launch size: 4 from the quad threshold up, 2 from half of it, else 1.  Results are identical. */
 void bp_tune_poseidon_mx_sets(int sets);
+/* 1 (default): the four-set matrix-core kernels take 16 of the 22 partial rounds in two groups of eight: within a
+ * group only the next S-box input (an affine form of the untouched words and the earlier S-box outputs, evaluated by
+ * int8 MFMAs on their bytes) is recombined per round, the twelve words once per group (csrc/poseidon_mx.cuh, grp;
+ * tools/poseidon_group_model.py).  0: every round by itself.  Results are identical either way. */
+void bp_tune_poseidon_grouped(int on);
 
 /* Tuning knob for K2: 0 (default) = automatic, 1 = never, 2 = wherever possible: transform a 2^13 / 2^14-point
  * block with TWO workgroups that each do half of the stage coupling its halves while loading (csrc/ntt.hip).

@@ -6,6 +6,10 @@
 // row, so a wave reads 512 contiguous bytes per column) but is integer-ALU bound: ceil(C/8)
 // permutations per row.
 #include <atomic>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
 #include "common.hpp"
 #include "poseidon.cuh"
 #include "poseidon_mx.cuh"
@@ -200,11 +204,31 @@ merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ p
 // the permutations are done (an MFMA is a whole-wave instruction): out-of-range items are clamped for the loads and
 // masked at the store.  NS = 4 is the throughput form, NS = 1 (4x the waves, like the quad form, at 0.65x its
 // instructions) the one for launches that cannot fill the chip.
-template <int NS>
-__global__ void __launch_bounds__(256) perm_batch_mx_kernel(uint64_t* __restrict__ states, uint64_t n) {
-  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
-  poseidon::mx::build_cin(cin);
+// At least three waves per SIMD (<= 168 VGPRs): with the grouped rounds' operands the four-set kernels otherwise take
+// 172..192 VGPRs, two waves per SIMD, and lose more to the exposed MFMA / LDS latency than the groups save.
+#define BPG_MX_OCC __attribute__((amdgpu_waves_per_eu(3)))
+// GR (NS = 4 only): the partial rounds 4..19 in two groups of eight; gtab = the device image of the operand tables
+// (poseidon_mx.cuh, grp), copied into LDS.  GR = false: every round by itself (NS = 1, 2; the knob; no tables).
+#define BPG_MX_TABLES(NS, GR, gtab)                                                                           \
+  static_assert(!(GR) || (NS) == 4, "groups exist for four sets per wave");                                   \
+  __shared__ __attribute__((aligned(16)))                                                                     \
+      uint32_t cin[(GR) ? poseidon::mx::CIN_GROUPED_WORDS : poseidon::mx::CIN_WORDS];                         \
+  __shared__ __attribute__((aligned(16))) uint32_t gt[(GR) ? poseidon::mx::grp::TABLE_WORDS : 4];            \
+  if constexpr (GR) {                                                                                         \
+    poseidon::mx::build_cin_grouped(cin);                                                                     \
+    poseidon::mx::grp::load_tables(gt, gtab);                                                                 \
+  } else {                                                                                                    \
+    poseidon::mx::build_cin(cin);                                                                             \
+  }                                                                                                           \
   __syncthreads();
+#define BPG_MX_PERMUTE(NS, GR, e, c)                                      \
+  if constexpr (GR) poseidon::mx::permute_grouped(e, c, gt);              \
+  else poseidon::mx::permute<NS>(e, c);
+
+template <int NS, bool GR>
+__global__ void __launch_bounds__(256) BPG_MX_OCC perm_batch_mx_kernel(uint64_t* __restrict__ states, uint64_t n,
+                                                            const uint32_t* __restrict__ gtab) {
+  BPG_MX_TABLES(NS, GR, gtab)
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
   const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS) + (threadIdx.x & 15);
   uint64_t e[NS][3];
@@ -214,7 +238,7 @@ __global__ void __launch_bounds__(256) perm_batch_mx_kernel(uint64_t* __restrict
 #pragma unroll
     for (int a = 0; a < 3; a++) e[m][a] = states[i * 12 + c.kb + 4 * a];
   }
-  poseidon::mx::permute<NS>(e, c);
+  BPG_MX_PERMUTE(NS, GR, e, c)
 #pragma unroll
   for (int m = 0; m < NS; m++) {
     const uint64_t i = base + 16 * m;
@@ -225,24 +249,24 @@ __global__ void __launch_bounds__(256) perm_batch_mx_kernel(uint64_t* __restrict
   }
 }
 
-template <int NS>
-__global__ void __launch_bounds__(256)
+template <int NS, bool GR>
+__global__ void __launch_bounds__(256) BPG_MX_OCC
 leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
-                    uint32_t rate_bits, uint64_t* __restrict__ digests) {
+                    uint32_t rate_bits, uint64_t* __restrict__ digests, const uint32_t* __restrict__ gtab) {
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
-  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
-  poseidon::mx::build_cin(cin);
-  __syncthreads();
+  BPG_MX_TABLES(NS, GR, gtab)
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
   const uint64_t rows = (uint64_t)1 << (log_n + rate_bits);
   const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS) + (threadIdx.x & 15);
   const uint32_t kb = c.kb;
+  // rows is a power of two >= 16 * NS here (the launcher picks NS by size), so the sets of a wave are 16 rows apart
+  // and none is out of range unless the whole wave is: one pointer, immediate offsets
+  const uint64_t* p0 = lde + (base < rows ? base : (uint64_t)(threadIdx.x & 15));
   const uint64_t* p[NS];
   uint64_t e[NS][3];
 #pragma unroll
   for (int m = 0; m < NS; m++) {
-    const uint64_t pos = base + 16 * m < rows ? base + 16 * m : rows - 1;
-    p[m] = lde + pos;
+    p[m] = p0 + 16 * m;
     e[m][0] = e[m][1] = e[m][2] = 0;
   }
   if (n_cols <= 4) {  // hash_or_noop: short rows are the digest
@@ -260,7 +284,7 @@ leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t 
 #pragma unroll
         for (int m = 0; m < NS; m++) e[m][1] = p[m][(uint64_t)(col + 4 + kb) * stride];
       }
-      poseidon::mx::permute<NS>(e, c);
+      BPG_MX_PERMUTE(NS, GR, e, c)
     }
   }
 #pragma unroll
@@ -274,14 +298,12 @@ leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t 
   }
 }
 
-template <int NS>
-__global__ void __launch_bounds__(256)
+template <int NS, bool GR>
+__global__ void __launch_bounds__(256) BPG_MX_OCC
 merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
-                       uint64_t* __restrict__ mirror) {
+                       uint64_t* __restrict__ mirror, const uint32_t* __restrict__ gtab) {
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
-  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
-  poseidon::mx::build_cin(cin);
-  __syncthreads();
+  BPG_MX_TABLES(NS, GR, gtab)
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
   const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS) + (threadIdx.x & 15);
   uint64_t e[NS][3];
@@ -292,7 +314,7 @@ merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict_
     e[m][1] = child[i * 8 + 4 + c.kb];
     e[m][2] = 0;
   }
-  poseidon::mx::permute<NS>(e, c);
+  BPG_MX_PERMUTE(NS, GR, e, c)
 #pragma unroll
   for (int m = 0; m < NS; m++) {
     const uint64_t i = base + 16 * m;
@@ -403,10 +425,11 @@ uint64_t quad_threshold() {
 }
 // Levels near the root are each one latency-bound launch (a lone txn proof spends ~30 % of its kernel time in them,
 // profiles/r2b_kernel_stats_4txn_1stream.csv); merkle_subtree_quad_kernel hands up to seven of them down through LDS
-// in one launch.  Under full load the per-level launches were 0-3 % faster (nothing waits on any single launch), so
-// the fused form follows the load: -1 = fused while fewer than six provers are at work (a lone txn, the tail of a
-// shard, small blocks), 0 = never, 1 = always.
-static std::atomic<int> g_merkle_fused{-1};
+// in one launch.  Measured in round 3 (profiles/r3_small_shards.txt), fused while fewer than six provers are at work
+// against one launch per level: 2 txns 150.0 against 143.9 ms, 16 txns 516 against 504 ms, 32 txns 993 against 1000 ms
+// -- the quad-form permutation of the fused kernel (~12 us per level) costs what the launch gaps save, so the default
+// stays one matrix-core launch per level.  0 = never (default), 1 = always, -1 = while the device is not loaded.
+static std::atomic<int> g_merkle_fused{0};
 // launches at or above the quad threshold: 1 = matrix-core form (poseidon_mx.cuh), 0 = one lane per state
 static std::atomic<int> g_poseidon_mx{1};
 bool poseidon_mx() { return g_poseidon_mx.load(std::memory_order_relaxed) != 0; }
@@ -422,11 +445,70 @@ int mx_sets(uint64_t n) {
   const uint64_t t = quad_threshold();
   return n >= t ? 4 : (n >= t / 2 ? 2 : 1);
 }
+// ---- operand tables of the grouped partial rounds (poseidon_group.hpp): built once per process on the host,
+// uploaded once per device; the four-set kernels copy them into LDS.  nullptr = per-round form (knob, or no tables).
+static std::atomic<int> g_poseidon_grouped{1};
+static std::mutex g_group_mu;
+static const uint32_t* g_group_dev[16] = {};
+static int g_group_state[16] = {};  // 0 not tried, 1 ready, -1 failed
+static std::vector<uint32_t>* g_group_image = nullptr;
+
+static bool build_group_image() {
+  namespace pg = poseidon::group;
+  namespace gx = poseidon::mx::grp;
+  if (g_group_image) return true;
+  auto img = std::make_unique<std::vector<uint32_t>>(gx::TABLE_WORDS, 0);
+  for (int g = 0; g < gx::N_GROUPS; g++) {
+    pg::Tables t;
+    if (!pg::build(gx::K, 4 + gx::K * g, &t) || (int)t.ops.size() != gx::OPS_WORDS * 4) return false;
+    if (g == 0) std::memcpy(img->data(), t.ops.data(), t.ops.size());
+    else if (std::memcmp(img->data(), t.ops.data(), t.ops.size()) != 0) return false;  // the A operands do not depend on r0
+    uint32_t* c = img->data() + gx::OPS_WORDS + g * gx::C_WORDS;
+    std::memcpy(c, t.cform.data(), pg::CFORM_WORDS * 4);
+    std::memcpy(c + pg::CFORM_WORDS, t.cmain.data(), pg::CMAIN_WORDS * 4);
+  }
+  // the per-round MDS layer's A operands as poseidon::mx::make_ctx builds them: lane (r, kb), dword a =
+  // M[(r >> 2) + 4g][kb + 4a] << 8 (r & 3)
+  static const uint32_t MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  uint32_t* am = img->data() + gx::OPS_WORDS + gx::N_GROUPS * gx::C_WORDS;
+  for (uint32_t g = 0; g < 3; g++)
+    for (uint32_t lane = 0; lane < 64; lane++)
+      for (uint32_t a = 0; a < 3; a++) {
+        const uint32_t r = lane & 15, kb = lane >> 4, i = (r >> 2) + 4 * g, k = kb + 4 * a;
+        am[(g * 64 + lane) * 4 + a] = (MC[(k + 12 - i) % 12] + ((i | k) == 0 ? 8u : 0u)) << (8 * (r & 3));
+      }
+  g_group_image = img.release();
+  return true;
+}
+// the current device's copy of the image (uploaded on first use), or nullptr
+const uint32_t* group_tables() {
+  if (!g_poseidon_grouped.load(std::memory_order_relaxed)) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (g_group_state[dev] > 0) return g_group_dev[dev];  // set last, after the pointer (mutex release below)
+  std::lock_guard<std::mutex> lk(g_group_mu);
+  if (g_group_state[dev] != 0) return g_group_state[dev] > 0 ? g_group_dev[dev] : nullptr;
+  void* d = nullptr;
+  if (!build_group_image() || hipMalloc(&d, poseidon::mx::grp::TABLE_WORDS * 4) != hipSuccess ||
+      hipMemcpy(d, g_group_image->data(), poseidon::mx::grp::TABLE_WORDS * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    g_group_state[dev] = -1;
+    return nullptr;
+  }
+  g_group_dev[dev] = static_cast<const uint32_t*>(d);
+  __atomic_store_n(&g_group_state[dev], 1, __ATOMIC_RELEASE);
+  return g_group_dev[dev];
+}
+
 #define BPG_MX_DISPATCH(NS_EXPR, KERNEL, ITEMS, ...)                                                        \
   switch (NS_EXPR) {                                                                                       \
-    case 4: KERNEL<4><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__); break;                        \
-    case 2: KERNEL<2><<<ceil_div((ITEMS), 128), 256, 0, st>>>(__VA_ARGS__); break;                        \
-    default: KERNEL<1><<<ceil_div((ITEMS), 64), 256, 0, st>>>(__VA_ARGS__); break;                        \
+    case 4:                                                                                                \
+      if (const uint32_t* gtab_ = bpg::group_tables())                                                     \
+        KERNEL<4, true><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, gtab_);                      \
+      else                                                                                                 \
+        KERNEL<4, false><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, nullptr);                   \
+      break;                                                                                               \
+    case 2: KERNEL<2, false><<<ceil_div((ITEMS), 128), 256, 0, st>>>(__VA_ARGS__, nullptr); break;        \
+    default: KERNEL<1, false><<<ceil_div((ITEMS), 64), 256, 0, st>>>(__VA_ARGS__, nullptr); break;        \
   }
 
 // `mirror` (nullable): host-visible buffer that receives the 2^cap_height cap digests directly from
@@ -514,6 +596,28 @@ int bp_debug_poseidon_mx_cin(uint32_t* out) {
   for (int i = 0; i < poseidon::mx::CIN_WORDS; i++) out[i] = t.v[i];
   return BP_OK;
 }
+/* 1 (default): the four-set matrix-core kernels take the partial rounds 4..19 in two groups of eight
+ * (csrc/poseidon_mx.cuh, grp); 0: every round by itself.  Results are identical. */
+void bp_tune_poseidon_grouped(int on) { bpg::g_poseidon_grouped.store(on != 0); }
+
+// Host only: the operand images of one group as the device gets them (tests/test_mx_tables.py pins them to the
+// integer model tools/poseidon_group_model.py).  out_ops: bp_debug_poseidon_group_ops(K) x 1024 bytes, out_cform: 64
+// i32, out_cmain: 96 i32.
+uint32_t bp_debug_poseidon_group_ops(uint32_t K) { return K >= 2 && K <= 8 ? (uint32_t)poseidon::group::layout((int)K).n_ops : 0; }
+int bp_debug_poseidon_group_tables(uint32_t K, uint32_t r0, uint8_t* out_ops, int32_t* out_cform, int32_t* out_cmain,
+                                   int32_t* out_max_plane_sum) try {
+  if (!out_ops || !out_cform || !out_cmain) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_debug_poseidon_group_tables: null output");
+  poseidon::group::Tables t;
+  if (!poseidon::group::build((int)K, (int)r0, &t))
+    return bpg::fail(BP_ERR_INVALID_INPUT, "bp_debug_poseidon_group_tables: no such group (K=%u r0=%u)", K, r0);
+  std::memcpy(out_ops, t.ops.data(), t.ops.size());
+  std::memcpy(out_cform, t.cform.data(), t.cform.size() * 4);
+  std::memcpy(out_cmain, t.cmain.data(), t.cmain.size() * 4);
+  if (out_max_plane_sum) *out_max_plane_sum = t.max_plane_sum;
+  return BP_OK;
+}
+BPG_ABI_CATCH("bp_debug_poseidon_group_tables")
+
 void bp_tune_poseidon_mx_sets(int sets) { bpg::g_mx_sets.store(sets == 1 || sets == 2 || sets == 4 ? sets : 0); }
 
 uint64_t bp_merkle_digest_words(uint32_t log_leaves, uint32_t cap_height) {

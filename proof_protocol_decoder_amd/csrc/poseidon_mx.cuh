@@ -31,6 +31,7 @@
 // waves for a launch too small to fill 1024 SIMDs otherwise) use one swap or none and leave lanes idle in that S-box.
 #pragma once
 #include "poseidon.cuh"
+#include "poseidon_group.hpp"
 
 namespace poseidon {
 namespace mx {
@@ -182,6 +183,251 @@ __device__ __forceinline__ void sbox_full(uint64_t (&e)[NS][3]) {
   for (int m = 0; m < NS; m++) {
     sbox_n<3>(e[m]);
     __builtin_amdgcn_sched_barrier(0);  // one group's carry masks at a time (poseidon.cuh, sbox_all)
+  }
+}
+
+// ---- grouped partial rounds (four sets per wave only) -----------------------------------------------------------
+// K = 8 partial rounds at a time (poseidon_group.hpp; integer model tools/poseidon_group_model.py): within a group
+// only ONE word per state and round -- the next S-box input, an affine form of the eleven untouched words and the
+// earlier S-box outputs -- comes out of the matrix cores and is recombined; the twelve words are recombined once per
+// group.  228 -> ~140 VALU instructions per round and 64 states, 6 -> 5 MFMAs per set and round.
+//   operands (LDS, 1 KiB each, shared by the four sets): W = forms over the bytes of w, D = one more sigma into the
+//   forms still to come, MAIN = the new state over (w, sigma_0..7); C tables per group hold the round constants.
+//   B operands: blo / bhi = the state's byte planes as in mds(); bsig: lane group g holds sigma_g and sigma_{g+4}.
+//   Form f of a pair comes out in lane group f % 4 (rows 4(f%4)..+3 of the tile), so the gather into the dense
+//   S-box register and the way back come in four variants of the same three permlane swaps.
+namespace grp {
+constexpr int K = 8;
+constexpr poseidon::group::Layout LAY = poseidon::group::layout(K);
+constexpr int N_GROUPS = 2;                       // partial rounds 4..11 and 12..19; 20..25 take the per-round form
+constexpr int OPS_WORDS = LAY.n_ops * 256;        // 40 KiB
+constexpr int C_WORDS = poseidon::group::CFORM_WORDS + poseidon::group::CMAIN_WORDS;
+constexpr int MDS_A_WORDS = 3 * 256;              // the per-round MDS layer's three A operands (Ctx::A), read from LDS
+                                                  // per round instead of living in 12 VGPRs through the groups
+// device image: group operands, per group cform + cmain, the MDS layer's A operands
+constexpr int TABLE_WORDS = OPS_WORDS + N_GROUPS * C_WORDS + MDS_A_WORDS;
+
+// the whole workgroup copies the image into LDS, 16 bytes per lane and step (call once, then __syncthreads)
+__device__ __forceinline__ void load_tables(uint32_t* __restrict__ lds, const uint32_t* __restrict__ glob) {
+  const uint4* src = (const uint4*)glob;
+  uint4* dst = (uint4*)lds;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)TABLE_WORDS / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+// gather<F>: x[m] holds set m's value in lane group F; afterwards x[F] holds set j's value in lane group j.
+// The same instructions in reverse order undo it (each swap is an involution).  Operands come from / go to asm
+// statements the hazard recogniser does not see: 2 wait states around every swap by hand.
+template <int F>
+__device__ __forceinline__ void gather(uint32_t (&l)[4], uint32_t (&h)[4]) {
+  if constexpr ((F & 1) == 0)
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+        "s_nop 0\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %4, %6\n\ts_nop 1"
+        : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+  else
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+        "s_nop 0\n\t"
+        "v_permlane32_swap_b32 %1, %3\n\tv_permlane32_swap_b32 %5, %7\n\ts_nop 1"
+        : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+}
+template <int F>
+__device__ __forceinline__ void scatter(uint32_t (&l)[4], uint32_t (&h)[4]) {
+  if constexpr ((F & 1) == 0)
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %4, %6\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\ts_nop 1"
+        : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+  else
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %1, %3\n\tv_permlane32_swap_b32 %5, %7\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+        "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\ts_nop 1"
+        : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+}
+
+struct State {
+  v4i blo[4], bhi[4], bsig[4];  // B operands of the four sets (bytes ^ 0x80)
+  v4i acc[4][2];                // the live form pair: tile L / H of every set
+};
+
+// step J of a group: S-box input J -> sigma_J into bsig and into the forms still to come
+template <int J>
+__device__ __forceinline__ void step(State& s, uint64_t (&e)[4][3], const v4i* ops, const int* cform, uint32_t lane) {
+  constexpr int P = J / 4, F = J % 4;
+  const uint32_t kb = lane >> 4;
+  if constexpr (F == 0) {  // start pair P: constants + the forms over w (+ the sigmas known so far)
+    constexpr int nw = LAY.w_per_half[P];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const v4i c0 = ((const v4i*)(cform + (P * 2 + half) * 16))[kb];
+      const v4i a_lo = ops[(LAY.w_base[P] + half * nw) * 64 + lane], a_hi = ops[(LAY.w_base[P] + half * nw + 1) * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        s.acc[m][half] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_lo, s.blo[m], c0, 0, 0, 0);
+        s.acc[m][half] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hi, s.bhi[m], s.acc[m][half], 0, 0, 0);
+      }
+      if constexpr (P > 0) {
+        const v4i a_sg = ops[(LAY.w_base[P] + half * nw + 2) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < 4; m++) s.acc[m][half] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_sg, s.bsig[m], s.acc[m][half], 0, 0, 0);
+      }
+    }
+  }
+  uint32_t l[4], h[4];
+  if constexpr (J == 0) {  // F_0 is the state's own word 0 (lane group 0)
+#pragma unroll
+    for (int m = 0; m < 4; m++) { l[m] = (uint32_t)e[m][0]; h[m] = (uint32_t)(e[m][0] >> 32); }
+  } else {                 // form J: planes 0..3 / 4..7 in this lane's registers of tile L / H (lane group F)
+    uint64_t L[4], H[4], x[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) { L[m] = planes(s.acc[m][0]); H[m] = planes(s.acc[m][1]); }
+    reduce_rows<4>(L, H, x);
+#pragma unroll
+    for (int m = 0; m < 4; m++) { l[m] = (uint32_t)x[m]; h[m] = (uint32_t)(x[m] >> 32); }
+  }
+  gather<F>(l, h);
+  const uint64_t y = sbox(gl::cc::mk64(l[F], h[F])) ^ 0x8080808080808080ULL;  // sigma_J of all 64 states, as a B operand
+  l[F] = (uint32_t)y;
+  h[F] = (uint32_t)(y >> 32);
+  scatter<F>(l, h);        // set m's sigma_J in lane group F of (l[m], h[m])
+#pragma unroll
+  for (int m = 0; m < 4; m++) {  // ... into its slot of bsig: only row F of the wave is written
+    s.bsig[m][2 * (J / 4)] = __builtin_amdgcn_update_dpp(s.bsig[m][2 * (J / 4)], (int)l[m], 0xE4, 1 << F, 0xF, false);
+    s.bsig[m][2 * (J / 4) + 1] = __builtin_amdgcn_update_dpp(s.bsig[m][2 * (J / 4) + 1], (int)h[m], 0xE4, 1 << F, 0xF, false);
+  }
+  if constexpr (J >= LAY.d_first[P] && J < LAY.d_first[P] + LAY.d_count[P]) {  // a later form of the pair needs sigma_J
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const v4i a = ops[(LAY.d_base[P] + 2 * (J - LAY.d_first[P]) + half) * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < 4; m++) s.acc[m][half] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, s.bsig[m], s.acc[m][half], 0, 0, 0);
+    }
+  }
+}
+
+// rounds r0 .. r0 + 7 of the partial rounds: e = t(r0) in, t(r0 + 8) out (S-box-input form, constants included)
+__device__ __forceinline__ void partial_group(uint64_t (&e)[4][3], const uint32_t* tab, int grp) {
+  const uint32_t lane = threadIdx.x & 63, kb = lane >> 4;
+  const v4i* ops = (const v4i*)tab;
+  const int* cform = (const int*)(tab + OPS_WORDS + grp * C_WORDS);
+  const int* cmain = cform + poseidon::group::CFORM_WORDS;
+  State s;
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      s.blo[m][a] = (int)((uint32_t)e[m][a] ^ 0x80808080u);
+      s.bhi[m][a] = (int)((uint32_t)(e[m][a] >> 32) ^ 0x80808080u);
+    }
+    s.blo[m][3] = 0;
+    s.bhi[m][3] = 0;
+    s.bsig[m] = v4i{0, 0, 0, 0};
+  }
+  step<0>(s, e, ops, cform, lane);
+  step<1>(s, e, ops, cform, lane);
+  step<2>(s, e, ops, cform, lane);
+  step<3>(s, e, ops, cform, lane);
+  step<4>(s, e, ops, cform, lane);
+  step<5>(s, e, ops, cform, lane);
+  step<6>(s, e, ops, cform, lane);
+  step<7>(s, e, ops, cform, lane);
+  // the new state: twelve words over (w, sigma_0 .. sigma_7), recombined as in mds()
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    v4i d[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const v4i c0 = ((const v4i*)(cmain + (g * 2 + h) * 16))[kb];
+      const v4i a_lo = ops[(LAY.main_base + (g * 2 + h) * 3) * 64 + lane], a_hi = ops[(LAY.main_base + (g * 2 + h) * 3 + 1) * 64 + lane],
+                a_sg = ops[(LAY.main_base + (g * 2 + h) * 3 + 2) * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_lo, s.blo[m], c0, 0, 0, 0);
+        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hi, s.bhi[m], d[m][h], 0, 0, 0);
+        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_sg, s.bsig[m], d[m][h], 0, 0, 0);
+      }
+    }
+    uint64_t L[4], H[4], x[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) { L[m] = planes(d[m][0]); H[m] = planes(d[m][1]); }
+    reduce_rows<4>(L, H, x);
+#pragma unroll
+    for (int m = 0; m < 4; m++) e[m][g] = x[m];
+  }
+}
+}  // namespace grp
+
+// The grouped kernels keep the C table of the per-round MDS layer only for the rounds that still use it: 0..3 and
+// 20..29 (14 x 384 bytes instead of 30 x 384: with the 45 KiB of group operands three workgroups still fit a CU's LDS)
+constexpr int CIN_GROUPED_ROUNDS = 14;
+constexpr int CIN_GROUPED_WORDS = CIN_GROUPED_ROUNDS * CIN_PER_ROUND;
+__device__ __forceinline__ int cin_slot(int rnd) { return rnd < 4 ? rnd : rnd - 16; }
+__device__ __forceinline__ void build_cin_grouped(uint32_t* __restrict__ cin) {
+  const uint4* src = (const uint4*)CIN_TABLE.v;
+  uint4* dst = (uint4*)cin;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)CIN_GROUPED_WORDS / 4; i += blockDim.x)
+    dst[i] = src[i < 4 * CIN_PER_ROUND / 4 ? i : i + 16 * CIN_PER_ROUND / 4];
+}
+
+// mds<4> with the A operands read from the LDS image (one ds_read_b128 each per round, shared by the four sets)
+__device__ __forceinline__ void mds4_lds(uint64_t (&e)[4][3], const Ctx& c, int rnd, const uint32_t* tab) {
+  const v4i* cr = (const v4i*)(c.cin + cin_slot(rnd) * CIN_PER_ROUND);
+  const v4i* am = (const v4i*)(tab + grp::OPS_WORDS + grp::N_GROUPS * grp::C_WORDS) + (threadIdx.x & 63);
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    v4i blo, bhi;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      blo[a] = (int)((uint32_t)e[m][a] ^ 0x80808080u);
+      bhi[a] = (int)((uint32_t)(e[m][a] >> 32) ^ 0x80808080u);
+    }
+    blo[3] = 0;
+    bhi[3] = 0;
+    uint64_t L[3], H[3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      const v4i A = am[g * 64];
+      const v4i dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, blo, cr[2 * g], 0, 0, 0);
+      const v4i dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bhi, cr[2 * g + 1], 0, 0, 0);
+      L[g] = planes(dl);
+      H[g] = planes(dh);
+    }
+    reduce_rows<3>(L, H, e[m]);
+  }
+}
+
+// The permutation with the partial rounds 4..19 grouped (four sets per wave; tab = the LDS image of grp::load_tables)
+__device__ __forceinline__ void permute_grouped(uint64_t (&e)[4][3], const Ctx& c, const uint32_t* tab) {
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const uint64_t k = RC[c.kb + 4 * a];
+#pragma unroll
+    for (int m = 0; m < 4; m++) e[m][a] = gl::add(e[m][a], k);
+  }
+  int rnd = 0;
+#pragma unroll 1
+  for (int k = 0; k < 4; k++, rnd++) {
+    sbox_full<4>(e);
+    mds4_lds(e, c, rnd, tab);
+  }
+#pragma unroll 1
+  for (int g = 0; g < grp::N_GROUPS; g++, rnd += grp::K) grp::partial_group(e, tab, g);
+#pragma unroll 1
+  for (; rnd < 26; rnd++) {
+    sbox_word0<4>(e, c);
+    mds4_lds(e, c, rnd, tab);
+  }
+#pragma unroll 1
+  for (int k = 0; k < 4; k++, rnd++) {
+    sbox_full<4>(e);
+    mds4_lds(e, c, rnd, tab);
   }
 }
 

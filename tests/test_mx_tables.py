@@ -7,6 +7,7 @@ import re
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -154,3 +155,42 @@ def test_ntt_mx_tables_match_the_model():
                     assert int(t256[k, i]) == pow(w4096, i * k, P)
                 for i in (0, 3, 15):
                     assert int(t16[k, i]) == pow(w256, i * k, P)
+
+
+# ---- grouped partial rounds of the matrix-core Poseidon kernels (csrc/poseidon_group.cpp) -----------------------
+@pytest.mark.parametrize("K,r0", [(8, 4), (8, 12), (6, 20), (4, 8)])
+def test_poseidon_group_tables_match_the_integer_model(K, r0):
+    """The operand images the library uploads (A operands: balanced base-256 digits of the 64-bit coefficients of the
+    grouped rounds' affine forms, in the MFMA lane layout; C operands: bias, non-negativity offsets, round constants)
+    are byte for byte those of tools/poseidon_group_model.py -- whose check() runs the kernel's own sequence on these
+    images, on exact integers, against the plain permutation.  Host only: no GPU."""
+    import ctypes as C
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import poseidon_group_model as model
+    import proof_protocol_decoder_amd as pkg
+    L = pkg.lib()
+    L.bp_debug_poseidon_group_ops.restype = C.c_uint32
+    n_ops = L.bp_debug_poseidon_group_ops(K)
+    G = model.check(K, r0, n=3)                      # grouped == plain rounds, tile form and device order
+    ops, cform, cmain = model.device_images(G)
+    assert n_ops == model.layout(K)["n_ops"] == len(ops) // 1024
+    got_ops = (C.c_uint8 * (n_ops * 1024))()
+    got_cf, got_cm, bound = (C.c_int32 * 64)(), (C.c_int32 * 96)(), C.c_int32()
+    assert L.bp_debug_poseidon_group_tables(K, r0, got_ops, got_cf, got_cm, C.byref(bound)) == 0
+    assert bytes(got_ops) == ops
+    assert list(got_cf) == cform and list(got_cm) == cmain
+    assert bound.value == G["bound"] < (1 << 23)
+    assert L.bp_debug_poseidon_group_tables(9, 4, got_ops, got_cf, got_cm, None) != 0
+    assert L.bp_debug_poseidon_group_tables(8, 20, got_ops, got_cf, got_cm, None) != 0     # would run past round 25
+
+
+def test_poseidon_group_operands_do_not_depend_on_the_round():
+    """Both groups of the kernel (rounds 4..11 and 12..19) share ONE set of A operands; only the C tables differ."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import poseidon_group_model as model
+    a, b = model.device_images(model.build_group(8, 4)), model.device_images(model.build_group(8, 12))
+    assert a[0] == b[0] and a[1] != b[1] and a[2] != b[2]

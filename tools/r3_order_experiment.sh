@@ -1,11 +1,16 @@
 #!/bin/bash
-# Order effects of the single-stream leg: the same block run (a) alone, (b) after the leg in the
-# same process (round 2's order), (c) with the leg in a child AFTER it (round 3's order), clocks / power sampled.
+# Order / instrumentation effects on the headline, clocks and power of OUR card sampled:
+#   A  --no-profile                      (no leg, no HIP events in the timed region)
+#   D  default, --no-in-situ-profile     (leg in a child AFTER the timed region, no events in it)
+#   C  default                           (leg after, events around every LDE launch of the timed region)
+#   B  --leg-first                       (round 2's order: leg in this process BEFORE the block)
+#   A2 --no-profile again                (drift of the box over the experiment)
 set -o pipefail
 mkdir -p gpurun_out
-for tag in A_noprofile B_legfirst C_default A2_noprofile; do
+for tag in A_noprofile D_no_in_situ C_default B_legfirst A2_noprofile; do
   case $tag in
     A_noprofile|A2_noprofile) extra="--no-profile";;
+    D_no_in_situ) extra="--no-in-situ-profile";;
     B_legfirst) extra="--leg-first";;
     C_default) extra="";;
   esac
