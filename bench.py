@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--ntt-split", type=int, default=None, help="bp_tune_ntt_split mode (measurement knob)")
     ap.add_argument("--ntt-mx", type=int, default=None, help="bp_tune_ntt_mx mode (measurement knob)")
     ap.add_argument("--poseidon-mx", type=int, default=None, help="bp_tune_poseidon_mx (measurement knob)")
+    ap.add_argument("--keccak-air", action="store_true",
+                    help="every transaction's Keccak table is a real Keccak-f[1600] trace (AIR 1, 2430 columns) instead "
+                         "of the 2432-column synthetic table BASELINE's metric is quoted on")
     ap.add_argument("--poseidon-grouped", type=int, default=None, help="bp_tune_poseidon_grouped (measurement knob)")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
                     help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
@@ -261,7 +264,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    blocks = [synthetic_block_irs(b, args.txns, S1_LOG_N, S1_WIDTH) for b in range(args.warmup + args.steps)]
+    blocks = [synthetic_block_irs(b, args.txns, S1_LOG_N, S1_WIDTH, keccak_air=args.keccak_air)
+              for b in range(args.warmup + args.steps)]
     last = None
     phase("warmup")
     for b in range(args.warmup):
@@ -314,6 +318,7 @@ def main():
         "config": {"workload": "%d-txn synthetic block, S1 transfer-txn tables logN=%s widths=%s, 7 table STARKs "
                                "+ 22 recursion-shaped proofs per txn, %d agg proofs + 1 block proof per block"
                                % (args.txns, list(S1_LOG_N), list(S1_WIDTH), args.txns - 1),
+                   "keccak_table": "Keccak-f[1600] AIR, 2430 columns" if args.keccak_air else "synthetic AIR, 2432 columns",
                    "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
                    "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
                    "ms_of_each_step_rank0": step_ms, **t_build_info},

@@ -108,9 +108,10 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
  * 2^13 under load.  A caller that drives the L0 entry points from many streams itself should set 2^13: the library
  * cannot see that load. */
 void bp_tune_quad_threshold(uint64_t n_perms);
-/* Merkle levels of at most 4096 nodes: 0 (default) = one launch per level; 1 = fused, up to 7 levels per launch
- * (LDS hand-down, quad-cooperative permutation); -1 = fused while fewer than 6 provers are at work on the device.
- * Measured: the fused form is 0-4 % slower, loaded or not (profiles/r3_small_shards.txt).  Results are identical. */
+/* Merkle levels of at most 4096 nodes: 1 (default) = fused, up to 7 levels per launch (LDS hand-down, one-set
+ * matrix-core permutation; +2.8 % on the 256-txn block, +3..5 % on 16- and 32-txn shards: fewer launches on every
+ * proof's critical path); 0 = one launch per level; -1 = fused only while fewer than 6 provers are at work on the
+ * device.  Results are identical. */
 void bp_tune_merkle_fused(int mode);
 /* 1 (default): hashing launches at or above the quad threshold use the matrix-core form of the permutation
  * (csrc/poseidon_mx.cuh: the MDS layer as int8 MFMAs on the byte planes of the state); 0: one lane per state.
@@ -342,6 +343,10 @@ int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas
 int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_used, const uint64_t state_root[4],
                        uint64_t seed, const uint32_t table_log_n[BP_NUM_TABLES],
                        const uint32_t table_width[BP_NUM_TABLES], uint64_t ir_out[BP_IR_WORDS]);
+/* Marks an encoded IR (flag 0x100 of the version word) so that its Keccak table -- table index 3 in the positional
+ * order of prover_state.rs:85-93 -- is proven with the Keccak-f[1600] AIR (air_id 1: 2430 columns, the witness is
+ * ceil(2^log_n / 24) permutations drawn from the seed) instead of the synthetic AIR.  The table's width must be 2430. */
+int bp_ir_set_keccak_air(uint64_t ir[BP_IR_WORDS], int on);
 /* public values of a proof container: txn_before, txn_after, gas_before, gas_after, root_before[4],
  * root_after[4], block_number */
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out);

@@ -133,13 +133,20 @@ int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words
   const orc_pg_config* cfg = &s->cfg;
   /* version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520: "Txn numbers before/after",
    * "Gas used before/after" equal, tries unchanged) -- same tables proven, public values do not advance */
-  if (I[0] != IR_MAGIC || (I[1] != 1 && I[1] != 2)) return -2;
-  const int dummy = I[1] == 2;
+  /* flags above the version byte: 0x100 = the Keccak table (index 3, prover_state.rs:85-93) is proven with the
+   * Keccak-f AIR (keccak_air.c) instead of the synthetic one: 2430 columns, witness drawn from the seed */
+  const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
+  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 1) return -2;
+  const int dummy = ver == 2, keccak_air = (int)(flags & 1);
   if (dummy && I[4] != I[5]) return -2;
   orc_stark_cfg tcfg[NUM_TABLES];
   for (int t = 0; t < NUM_TABLES; t++) {
     if (I[11 + t] < cfg->table_log_lo[t] || I[11 + t] >= cfg->table_log_hi[t]) return -3;
     tcfg[t] = table_cfg_of(cfg, (uint32_t)I[11 + t], (uint32_t)I[18 + t]);
+  }
+  if (keccak_air) {
+    if (tcfg[3].n_cols != ORC_KECCAK_COLS) return -2;
+    tcfg[3].air_id = ORC_AIR_KECCAK_F;
   }
   gl_t pv[PV_WORDS];
   pv[0] = I[3]; pv[1] = I[3] + (dummy ? 0 : 1); pv[2] = I[4]; pv[3] = I[5];
@@ -157,7 +164,8 @@ int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words
   for (int t = 0; t < NUM_TABLES; t++) {
     size_t n = (size_t)1 << tcfg[t].log_n;
     trace[t] = (gl_t*)malloc(tcfg[t].n_cols * n * sizeof(gl_t));
-    orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
+    if (tcfg[t].air_id == ORC_AIR_KECCAK_F) orc_keccak_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
+    else orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
     tc[t] = orc_commit_values(trace[t], tcfg[t].log_n, tcfg[t].n_cols, tcfg[t].rate_bits, tcfg[t].cap_height);
     orc_ch_observe_many(&ch, orc_committed_cap(tc[t]), (size_t)4 << tcfg[t].cap_height);
   }

@@ -326,6 +326,54 @@ merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict_
   }
 }
 
+// Up to seven Merkle levels in one launch, matrix-core form with ONE set of 16 states per wave (the low-latency form:
+// ~3.8 k VALU instructions per permutation and wave instead of 12.6 k).  A workgroup of four waves takes 64 parents
+// of the first level from global memory and hands every level down through LDS: 64 -> 32 -> ... -> 1 (or until the
+// cap); every level is still written to the level-order digest buffer (Merkle paths need all of them).  Replaces
+// up to seven latency-bound single-level launches on a proof's critical path (merkle_subtree_quad_kernel is the same
+// with the quad-cooperative permutation, ~12 us per level against ~8).
+__global__ void __launch_bounds__(256)
+merkle_subtree_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ out, uint64_t n_parents,
+                         uint32_t levels, uint64_t* __restrict__ mirror) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
+  __shared__ uint64_t sm[2][64 * 4];
+  poseidon::mx::build_cin(cin);
+  __syncthreads();
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
+  const uint32_t wave = threadIdx.x >> 6, n = threadIdx.x & 15;
+  uint64_t level_parents = n_parents;                                  // parents of the level being produced
+  uint32_t wg_parents = n_parents < 64 ? (uint32_t)n_parents : 64u;    // ... and in this workgroup
+  uint64_t wg_first = (uint64_t)blockIdx.x * 64;
+  uint64_t* dst = out;
+  for (uint32_t l = 0; l < levels; l++) {
+    if (wave * 16 < wg_parents) {  // whole waves only: an MFMA is a wave-wide instruction
+      const uint32_t q = wave * 16 + n, qc = q < wg_parents ? q : wg_parents - 1;
+      uint64_t e[1][3];
+      if (l == 0) {
+        e[0][0] = child[(wg_first + qc) * 8 + c.kb];
+        e[0][1] = child[(wg_first + qc) * 8 + 4 + c.kb];
+      } else {
+        e[0][0] = sm[(l - 1) & 1][(2 * qc) * 4 + c.kb];
+        e[0][1] = sm[(l - 1) & 1][(2 * qc + 1) * 4 + c.kb];
+      }
+      e[0][2] = 0;
+      poseidon::mx::permute<1>(e, c);
+      if (q < wg_parents) {
+        const uint64_t d = gl::canon(e[0][0]);
+        dst[(wg_first + q) * 4 + c.kb] = d;
+        if (mirror && l + 1 == levels) mirror[(wg_first + q) * 4 + c.kb] = d;
+        sm[l & 1][q * 4 + c.kb] = d;
+      }
+    }
+    __syncthreads();
+    dst += level_parents * 4;
+    level_parents >>= 1;
+    wg_parents >>= 1;
+    wg_first >>= 1;
+  }
+}
+
 // 8-byte-per-lane streaming copy: calibrates the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the
 // access width every field kernel here uses (MI355X_MICROARCH.md, HBM section).
 __global__ void __launch_bounds__(256)
@@ -424,12 +472,15 @@ uint64_t quad_threshold() {
   return (uint64_t)1 << (loaded ? 13 : 17);
 }
 // Levels near the root are each one latency-bound launch (a lone txn proof spends ~30 % of its kernel time in them,
-// profiles/r2b_kernel_stats_4txn_1stream.csv); merkle_subtree_quad_kernel hands up to seven of them down through LDS
-// in one launch.  Measured in round 3 (profiles/r3_small_shards.txt), fused while fewer than six provers are at work
-// against one launch per level: 2 txns 150.0 against 143.9 ms, 16 txns 516 against 504 ms, 32 txns 993 against 1000 ms
-// -- the quad-form permutation of the fused kernel (~12 us per level) costs what the launch gaps save, so the default
-// stays one matrix-core launch per level.  0 = never (default), 1 = always, -1 = while the device is not loaded.
-static std::atomic<int> g_merkle_fused{0};
+// and under the 24-stream load they are 40 % of all launches, each stretched from 19 to ~120 us by sharing:
+// profiles/r2b_kernel_stats_4txn_1stream.csv, r3_kernel_stats_64txn_24streams.csv).  merkle_subtree_mx_kernel hands
+// up to seven levels of at most 4096 nodes down through LDS in one launch, in the one-set matrix-core form.
+// Measured in round 3 (profiles/r3_small_shards.txt), fused against one launch per level: 256 txns 36.2 against 35.2
+// txn-proofs/s, 32 txns 33.6 against 32.5, 16 txns 33.1 against 31.6, a lone pair of txns 150.8 against 148.2 ms.
+// (With the quad-cooperative permutation -- round 2's fused kernel, still used when the matrix-core forms are switched
+// off -- the fused form lost 0-4 %: ~12 us per level cost what the launch gaps saved.)
+// 1 = fused (default), 0 = one launch per level, -1 = fused only while fewer than six provers are at work.
+static std::atomic<int> g_merkle_fused{1};
 // launches at or above the quad threshold: 1 = matrix-core form (poseidon_mx.cuh), 0 = one lane per state
 static std::atomic<int> g_poseidon_mx{1};
 bool poseidon_mx() { return g_poseidon_mx.load(std::memory_order_relaxed) != 0; }
@@ -547,7 +598,8 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     for (uint64_t p = parents >= 64 ? 64 : parents; p > 1; p >>= 1) max_levels++;
     if (levels > max_levels) levels = max_levels;
     uint64_t* mir = (l - levels == cap_height) ? mirror : nullptr;
-    merkle_subtree_quad_kernel<<<wgs, 256, 0, st>>>(lvl, nxt, parents, levels, mir);
+    if (poseidon_mx()) merkle_subtree_mx_kernel<<<wgs, 256, 0, st>>>(lvl, nxt, parents, levels, mir);
+    else merkle_subtree_quad_kernel<<<wgs, 256, 0, st>>>(lvl, nxt, parents, levels, mir);
     BPG_LAUNCH_CHECK();
     if (mir && mirrored) *mirrored = true;
     for (uint32_t k = 0; k < levels; k++) {

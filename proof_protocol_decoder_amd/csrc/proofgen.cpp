@@ -379,6 +379,15 @@ int bp_ir_encode(uint64_t block_number, uint64_t txn_number_before, uint64_t gas
   return BP_OK;
 }
 
+int bp_ir_set_keccak_air(uint64_t ir[BP_IR_WORDS], int on) {
+  if (!ir || ir[0] != IR_MAGIC) return fail(BP_ERR_INVALID_INPUT, "bp_ir_set_keccak_air: not an IR");
+  if (on && ir[18 + 3] != air::keccak::N_COLS)
+    return fail(BP_ERR_INVALID_INPUT, "the Keccak-f AIR has %u columns: the IR gives table keccak %llu", air::keccak::N_COLS,
+                (unsigned long long)ir[18 + 3]);
+  ir[1] = (ir[1] & 0xFF) | (on ? 0x100 : 0);
+  return BP_OK;
+}
+
 int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_used, const uint64_t state_root[4],
                        uint64_t seed, const uint32_t table_log_n[BP_NUM_TABLES], const uint32_t table_width[BP_NUM_TABLES],
                        uint64_t o[BP_IR_WORDS]) {
@@ -414,8 +423,11 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
   // version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520): txn number, gas and state
   // root do not advance, the same tables are proven
-  if (I[0] != IR_MAGIC || (I[1] != 1 && I[1] != 2)) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
-  const bool dummy = I[1] == 2;
+  // flags above the version byte: 0x100 = the Keccak table (index 3, prover_state.rs:85-93) is proven with the
+  // Keccak-f AIR (air.hpp, AIR 1) instead of the synthetic one: 2430 columns, witness drawn from the seed
+  const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
+  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 1) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
+  const bool dummy = ver == 2, keccak_air = (flags & 1) != 0;
   if (I[5] < I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: gas_used_after < gas_used_before");
   if (dummy && I[5] != I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: a dummy entry must not use gas (decoding.rs:503-506)");
   const bp_config& cfg = s->cfg;
@@ -427,6 +439,7 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
                   (unsigned long long)ln, cfg.table_log_lo[t], cfg.table_log_hi[t]);
     if (wd > 65536) return fail(BP_ERR_INVALID_INPUT, "table %s: width out of range", TABLE_NAMES[t]);
     tcfg[t] = table_cfg_of(cfg, (uint32_t)ln, (uint32_t)wd);
+    if (keccak_air && t == 3) tcfg[t].air_id = air::KECCAK_F;  // check_cfg insists on its 2430 columns
     int r = check_cfg(tcfg[t]);
     if (r) return r;
   }
@@ -455,7 +468,10 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
     const uint64_t N = (uint64_t)1 << tcfg[t].log_n;
     d_trace[t] = w.arena.alloc_words((size_t)tcfg[t].n_cols * N);
     if (!d_trace[t]) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) for table %s", w.arena.capacity() >> 20, TABLE_NAMES[t]);
-    if ((r = launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, I[10] ^ splitmix64(t + 1), w.stream))) return r;
+    r = tcfg[t].air_id == air::KECCAK_F
+            ? launch_keccak_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
+            : launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, I[10] ^ splitmix64(t + 1), w.stream);
+    if (r) return r;
     if ((r = commit(w, d_trace[t], tcfg[t].n_cols, tcfg[t].log_n, tcfg[t].rate_bits, tcfg[t].cap_height, false, &trace[t]))) return r;
     ch.observe(trace[t].cap.data(), trace[t].cap.size());
   }

@@ -60,6 +60,7 @@ def _bind():
                                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.bp_ir_encode_dummy.argtypes = [C.c_uint64] * 3 + [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32),
                                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.bp_ir_set_keccak_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_proof_public_values.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L._pg_bound = True
     return L
@@ -111,6 +112,7 @@ class TxnProofGenIR:
     table_log_n: tuple
     table_width: tuple
     dummy: bool = False   # a padding entry (decoding.rs:484-520): proven, but txn number / gas / state root stay
+    keccak_air: bool = False   # the Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1, 2430 columns)
 
     def to_bytes(self):
         L = _bind()
@@ -125,6 +127,8 @@ class TxnProofGenIR:
         else:
             check(L.bp_ir_encode(self.block_number, self.txn_number_before, self.gas_used_before, self.gas_used_after,
                                  root, self.seed, logs, widths, out))
+        if self.keccak_air:
+            check(L.bp_ir_set_keccak_air(out, 1))
         return struct.pack("<%dQ" % IR_WORDS, *out)
 
 

@@ -284,6 +284,28 @@ def test_agg_and_block_refuse_children_that_do_not_verify(pg, p_state, chain):
     assert e.value.code == -5 and "parent" in e.value.message
 
 
+def test_txn_with_a_real_keccak_table_matches_the_oracle(pg, p_state, o_state):
+    """IR flag 0x100: the Keccak table of the transaction (index 3, prover_state.rs:85-93) is a real Keccak-f[1600]
+    trace proven with AIR 1 (2430 columns, witness drawn from the seed) next to six synthetic tables.  Byte parity of
+    the txn proof with the oracle, aggregation with an ordinary txn, block proof accepted by both verifiers."""
+    width = list(WIDTH)
+    width[3] = 2430
+    ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0010, tuple(LOG_N), tuple(width), keccak_air=True)
+    t0 = pg.generate_txn_proof(p_state, ir0)
+    iw = list(struct.unpack("<25Q", ir0.to_bytes()))
+    assert iw[1] == 0x101 and iw[18 + 3] == 2430
+    want = o_state.txn(iw)
+    assert (words(t0.intern) == want).all()
+    plain = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0010, tuple(LOG_N), tuple(width))
+    assert pg.generate_txn_proof(p_state, plain).intern != t0.intern          # the same table proven with AIR 0 differs
+    t1 = pg.generate_txn_proof(p_state, make_ir(pg, 9, 1, 0x5EED0011, root=t0.p_vals.state_root_after, gas=(21000, 42000)))
+    blk = pg.generate_block_proof(p_state, None, pg.generate_agg_proof(p_state, t0, t1))
+    pg.VerifierState.from_prover_state(p_state).verify(blk)
+    assert o_state.verify(words(blk.intern)) == 0
+    with pytest.raises(pg.ProofGenError, match="2430"):                        # the AIR's width is not negotiable
+        pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), keccak_air=True).to_bytes()
+
+
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
 S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
 

@@ -153,3 +153,22 @@ def test_air_registry_describes_both_airs():
     from proof_protocol_decoder_amd._lib import BpgError
     with pytest.raises(BpgError):
         pkg.ops.air_describe(7)
+
+
+def test_oracle_txn_with_the_keccak_flag_differs_only_through_table_3(oracle):
+    """The IR flag 0x100 (Keccak table = AIR 1) in the oracle's generate_txn_proof: accepted, different from the
+    all-synthetic proof of the same IR, refused when table 3 is not 2430 columns wide."""
+    from pg_common import LOG_N, SMALL, WIDTH, ir_words
+    st = oracle.PgState(**SMALL)
+    width = list(WIDTH)
+    width[3] = 2430
+    iw = ir_words(5, 0, 0x5EED0042, width=tuple(width))
+    plain = st.txn(iw)
+    iw[1] = 0x101
+    flagged = st.txn(iw)
+    assert plain.shape == flagged.shape and (plain != flagged).any()
+    assert st.verify(flagged) == 0
+    bad = ir_words(5, 0, 0x5EED0042)
+    bad[1] = 0x101
+    with pytest.raises(Exception):
+        st.txn(bad)

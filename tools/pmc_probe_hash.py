@@ -7,9 +7,11 @@ import proof_protocol_decoder_amd as bpg
 L = bpg.lib()
 log_n, cols, r = 20, 64, 1
 lde = torch.randint(0, 2**62, (cols, 1 << (log_n + r)), dtype=torch.int64, device="cuda")
-for mx in (1, 0):
+for mx, grouped in ((1, 1), (1, 0), (0, 0)):     # matrix cores + grouped partial rounds / per round / one lane per state
     L.bp_tune_poseidon_mx(mx)
+    L.bp_tune_poseidon_grouped(grouped)
     bpg.ops.merkle_commit(lde, log_n, r, 4)
     torch.cuda.synchronize()
 L.bp_tune_poseidon_mx(1)
+L.bp_tune_poseidon_grouped(1)
 print("perms per commit:", (1 << (log_n + r)) * 9)

@@ -1,0 +1,62 @@
+"""Summaries of tools/prof_round3.sh's counter passes (written under gpurun_out/, copied into profiles/ by hand):
+  r3_sq_loaded_by_kernel.txt  per kernel family, the LOADED 64-txn run: VALU wave-instructions, MFMAs, share
+  r3_hash_sq_counters.txt     leaf hashing 2^21 rows x 8 permutations alone on the chip, per kernel form
+"""
+import collections
+import csv
+import glob
+import os
+
+R = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+O = os.path.join(R, "gpurun_out")
+HEAD = open(os.path.join(R, ".head_for_profiles")).read().strip() if os.path.exists(os.path.join(R, ".head_for_profiles")) else "?"
+
+
+def rows(dirs):
+    for d in dirs:
+        for f in glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True):
+            yield from csv.DictReader(open(f))
+
+
+def family(k):
+    for name in ("leaf_hash_mx_kernel", "leaf_hash_rows", "leaf_hash", "merkle_level_mx_kernel", "merkle_level", "merkle_subtree",
+                 "pow_grind", "perm_batch", "fri_layer_leaves", "ntt", "quotient_air_kernel", "quotient", "fri_", "openings",
+                 "aux_suffix", "synth_", "keccak_trace", "query", "combine", "power_vector", "alpha"):
+        if name in k:
+            return name
+    return k.split("(")[0][-40:]
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in rows(("r3_sq_loaded1", "r3_sq_loaded2")):
+    acc[family(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+with open(os.path.join(O, "r3_sq_loaded_by_kernel.txt"), "w") as out:
+    out.write("# HEAD %s.  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES (pass 1), "
+              "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES (pass 2) -- python bench.py --txns 64 --steps 1 --warmup 0 "
+              "--no-cpu-baseline --no-profile   (64 txns on 24 prover streams: the loaded chip; counters are summed over the "
+              "launches of a family; under rocprofv3 --pmc kernels are serialised, so these are instruction COUNTS of the "
+              "loaded run's kernel mix, not its timing)\n" % HEAD)
+    tot = sum(v.get("SQ_INSTS_VALU", 0) for v in acc.values())
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
+        out.write("%-28s VALU %.4e (%5.1f %%)  MFMA %.3e  waves %.3e  active_inst_valu %.3e  busy_cycles %.3e\n" % (
+            k, v.get("SQ_INSTS_VALU", 0), 100 * v.get("SQ_INSTS_VALU", 0) / max(tot, 1), v.get("SQ_INSTS_MFMA", 0),
+            v.get("SQ_WAVES", 0), v.get("SQ_ACTIVE_INST_VALU", 0), v.get("SQ_BUSY_CYCLES", 0)))
+    out.write("total VALU wave-instructions %.5e for 64 txn proofs + 63 aggregations + 1 block proof + bp_state_build\n" % tot)
+    out.write("total MFMA %.5e\n" % sum(v.get("SQ_INSTS_MFMA", 0) for v in acc.values()))
+print(open(os.path.join(O, "r3_sq_loaded_by_kernel.txt")).read())
+
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in rows(("r3_hash_sq1", "r3_hash_sq2")):
+    k = r["Kernel_Name"]
+    if "leaf_hash" in k:
+        name = ("leaf_hash_mx_kernel<4, grouped>" if "Lb1" in k or "true" in k else "leaf_hash_mx_kernel<4, per round>") if "mx" in k \
+            else "leaf_hash_kernel (one lane per state)"
+        acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
+with open(os.path.join(O, "r3_hash_sq_counters.txt"), "w") as out:
+    out.write("# HEAD %s.  rocprofv3 --kernel-trace --pmc <SQ counters, two passes> -- python tools/pmc_probe_hash.py: leaf hashing "
+              "of 2^21 rows x 8 permutations = 16777216 permutations per kernel form\n" % HEAD)
+    for k, v in acc.items():
+        out.write(k + "\n")
+        for n, x in sorted(v.items()):
+            out.write("    %-28s %.4e\n" % (n, x))
+print(open(os.path.join(O, "r3_hash_sq_counters.txt")).read())

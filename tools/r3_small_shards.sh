@@ -1,10 +1,11 @@
 #!/bin/bash
-# Small shards (what one rank of an 8-GPU run proves of the 256-txn block) and a lone txn, Merkle tail fused by
-# load (-1, default) against one launch per level (0).  VERDICT r2 next #6.
+# Small shards (what one rank of an 8-GPU run proves of the 256-txn block) and a lone txn pair, Merkle levels of at
+# most 4096 nodes fused (1: up to seven per launch, matrix-core one-set form), fused by load (-1) or one launch per
+# level (0).  VERDICT r2 next #6.
 set -o pipefail
 mkdir -p gpurun_out
 for txns in 2 16 32; do
-  for fused in 0 -1; do
+  for fused in 0 1 -1; do
     timeout -k 10 300 python bench.py --no-cpu-baseline --no-profile --txns $txns --steps 4 --warmup 1 --merkle-fused $fused \
         > gpurun_out/r3_shard_${txns}_f$fused.json 2> gpurun_out/r3_shard.err || { echo "FAILED $txns $fused"; tail -5 gpurun_out/r3_shard.err; exit 1; }
     python - <<PY
