@@ -47,9 +47,12 @@ const char* bp_version(void);
 /* number of visible HIP devices; negative on error.  Does not initialise a context. */
 int bp_device_count(void);
 /* Makes host threads SLEEP while they wait for this device (hipDeviceScheduleBlockingSync) instead of
- * spinning; call it once per process before proving (bp_state_build does, but a process that has
- * already created the device context through another library should call it first thing).  A prover
- * stream per host thread needs this to use more streams than the host has cores. */
+ * spinning.  A prover stream per host thread needs this to use more streams than the host has cores.
+ * The mode is decided ONCE per device, by whoever comes first -- this call, or the first worker the
+ * library creates on the device (bp_state_build, bp_stark_prove_air) -- and is never changed
+ * afterwards: later calls return BP_OK and do nothing (switching the mode while one of the library's
+ * streams is alive makes a later hipFree hang).  A process that creates the device context through
+ * another library should call it first thing. */
 int bp_use_blocking_sync(int device);
 
 /* ------------------------------------------------------------------------------------------

@@ -148,6 +148,12 @@ int bp_use_blocking_sync(int device) {
   // with hipEventBlockingSync) spins at 100 % of a core unless the device was given
   // hipDeviceScheduleBlockingSync (tools/wait_probe.hip: 100 % -> 1 %).  With one prover thread per
   // stream the spinning threads fill the box's cores and more streams than cores lose throughput.
+  // Decided once per device, by the first caller -- an explicit call (bench.py, before torch creates the context) or
+  // the first worker this library creates (Worker::init) -- and never changed afterwards: switching the mode while
+  // one of our streams is alive hangs a later hipFree (tools/hang_probe.py).
+  static std::atomic<int> decided[64];
+  if (device < 0 || device >= 64) return bpg::fail(BP_ERR_DEVICE, "device %d out of range", device);
+  if (decided[device].exchange(1)) return BP_OK;
   int prev = 0;
   (void)hipGetDevice(&prev);
   hipError_t e = hipSetDevice(device);

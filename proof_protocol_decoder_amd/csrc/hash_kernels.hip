@@ -575,7 +575,8 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     uint64_t* nxt = lvl + cnt * 4;
     // fuse only what fits in <= 64 workgroups: those launches are latency-critical and run at raised priority
     const int fmode = g_merkle_fused.load(std::memory_order_relaxed);
-    const bool fused = parents <= 4096 && parents < quad_threshold() && (fmode > 0 || (fmode < 0 && !device_loaded()));
+    const uint64_t flimit = fmode >= 8 ? (uint64_t)1 << fmode : 4096;  // measurement knob: modes 8..20 = fuse from 2^mode nodes down
+    const bool fused = parents <= flimit && (parents < quad_threshold() || fmode >= 8) && (fmode > 0 || (fmode < 0 && !device_loaded()));
     if (!fused) {
       uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;
       if (const int ns = mx_sets(parents)) {
@@ -637,7 +638,7 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
   return BP_OK;
 }
 
-void bp_tune_merkle_fused(int mode) { bpg::g_merkle_fused.store(mode < 0 ? -1 : (mode != 0)); }
+void bp_tune_merkle_fused(int mode) { bpg::g_merkle_fused.store(mode < 0 ? -1 : (mode >= 8 && mode <= 20 ? mode : (mode != 0))); }
 void bp_tune_quad_threshold(uint64_t n_perms) { bpg::g_quad_threshold.store(n_perms); }
 void bp_tune_poseidon_mx(int on) { bpg::g_poseidon_mx.store(on != 0); }
 // Host only: the C-operand table of the matrix-core Poseidon kernels (poseidon_mx.cuh), 30 x 4 x 24 u32, for the CPU test

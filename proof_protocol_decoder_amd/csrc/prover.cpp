@@ -5,6 +5,8 @@
 // Poseidon duplexing, K7) and the byte assembly of the proof.  Every host<->device hand-off is a
 // challenge boundary of the protocol: caps and openings come down, challenges go up as kernel
 // arguments.
+#include <cstdio>
+#include <cstdlib>
 #include "prover.hpp"
 #include <algorithm>
 
@@ -141,6 +143,11 @@ uint64_t* DeviceArena::alloc_words(size_t words) {
 }
 int Worker::init(int dev, size_t arena_bytes) {
   device = dev;
+  // The device's host-wait mode is chosen BEFORE this library makes its first stream on it and never changed after:
+  // a worker whose stream and event were made under spinning waits and that is still alive when the device is
+  // switched to blocking waits makes a later hipFree (a device-wide wait) hang forever (tools/hang_probe.py; found
+  // in round 3 by running the table-proof tests, which park a worker, before the first bp_state_build).
+  (void)bp_use_blocking_sync(dev);
   BPG_HIP(hipSetDevice(dev));
   BPG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   int rc = arena.init(arena_bytes);
@@ -357,23 +364,32 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
   const gl::Ext zeta_next = gl::scale(zeta, wN);
 
   // 5. openings: dot products of bit-reversed coefficient columns with zeta^bitrev(pos)
-  ARENA_ALLOC(d_pw, 4 * N);
-  ARENA_ALLOC(d_pw1, 2 * N);
-  TRY(launch_power_vectors(d_pw, log_n, zeta, zeta_next, 2, st));
-  TRY(launch_power_vectors(d_pw1, log_n, gl::ext(1), gl::ext(1), 1, st));
+  ARENA_ALLOC(d_pw, 6 * N);  // zeta, g zeta and 1 in one launch
+  const uint64_t* d_pw1 = d_pw + 4 * N;
+  TRY(launch_power_vectors(d_pw, log_n, zeta, zeta_next, 3, st, gl::ext(1)));
   const size_t open_cols = (size_t)K + C + A + Q + A;
   if (open_cols * 4 > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "too many columns for the opening mailbox");
   uint64_t* d_open = w.pinned_dev;  // kernels write the openings straight into host-visible memory
-  uint64_t* d_o = d_open;
-  if (K) TRY(launch_openings(consts->coeffs, N, log_n, K, d_pw, 1, d_o, st));
-  d_o += (size_t)K * 4;
-  TRY(launch_openings(trace.coeffs, N, log_n, C, d_pw, 2, d_o, st));
-  d_o += (size_t)C * 4;
-  TRY(launch_openings(aux.coeffs, N, log_n, A, d_pw, 2, d_o, st));
-  d_o += (size_t)A * 4;
-  TRY(launch_openings(quot.coeffs, N, log_n, Q, d_pw, 1, d_o, st));
-  d_o += (size_t)Q * 4;
-  TRY(launch_openings(aux.coeffs, N, log_n, A, d_pw1, 1, d_o, st));
+  {
+    // one launch for the five opening sets (they used to be five launches in a row on the critical path)
+    OpenMulti om{};
+    om.stride = N; om.log_n = log_n;
+    uint64_t* d_o = d_open;
+    auto seg = [&](const uint64_t* coeffs, uint32_t n_cols, const uint64_t* pw, uint32_t n_points) {
+      if (n_cols) {
+        const uint32_t k = om.n_segs++;
+        om.coeffs[k] = coeffs; om.pw[k] = pw; om.out[k] = d_o; om.n_points[k] = n_points;
+        om.first_col[k + 1] = om.first_col[k] + n_cols;
+      }
+      d_o += (size_t)n_cols * 4;
+    };
+    seg(K ? consts->coeffs : nullptr, K, d_pw, 1);
+    seg(trace.coeffs, C, d_pw, 2);
+    seg(aux.coeffs, A, d_pw, 2);
+    seg(quot.coeffs, Q, d_pw, 1);
+    seg(aux.coeffs, A, d_pw1, 1);
+    TRY(launch_openings_multi(om, st));
+  }
   TRY(w.wait());
   std::vector<uint64_t> ho(w.pinned, w.pinned + open_cols * 4);
   {
@@ -406,16 +422,16 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
   for (int o = 0; o < n_or; o++) total_chunks += (refs[o].c->n_cols + cols_per_chunk - 1) / cols_per_chunk;
   ARENA_ALLOC(d_cpart, (size_t)total_chunks * 6 * N);
   uint32_t chunk_base = 0;
-  for (int o = 0; o < n_or; o++) {
-    CombineArgs cb{};
+  CombineMulti cm{};
+  for (int o = 0; o < n_or; o++) {  // one launch over the chunks of all oracles
+    CombineArgs& cb = cm.a[cm.n_oracles++];
     cb.coeffs = refs[o].c->coeffs; cb.stride = N; cb.log_n = log_n; cb.n_cols = refs[o].c->n_cols;
     cb.cols_per_chunk = cols_per_chunk; cb.chunk_base = chunk_base;
     for (int b = 0; b < 3; b++) cb.exp_base[b] = refs[o].e[b];
     cb.alpha_pows = d_apow; cb.partial = d_cpart;
-    const uint32_t nc = (cb.n_cols + cols_per_chunk - 1) / cols_per_chunk;
-    TRY(launch_combine_partial(cb, nc, st));
-    chunk_base += nc;
+    chunk_base += (cb.n_cols + cols_per_chunk - 1) / cols_per_chunk;
   }
+  TRY(launch_combine_partial_multi(cm, total_chunks, st));
   ARENA_ALLOC(d_g, 6 * N);
   TRY(launch_combine_reduce(d_cpart, total_chunks, log_n, d_g, st));
   ARENA_ALLOC(d_glde, 6 * M);

@@ -333,12 +333,12 @@ __global__ void __launch_bounds__(256) quotient_chunks_kernel(bpg::ChunkArgs c) 
 // ---------------------------------------------------------------- K8 openings
 // pw[0..n) = zeta^bitrev(pos) (c0 plane), pw[n..2n) c1 plane; same for the second point at 2n.
 __global__ void __launch_bounds__(256)
-power_vector_kernel(uint64_t* __restrict__ out, uint32_t log_n, Ext z0, Ext z1) {
+power_vector_kernel(uint64_t* __restrict__ out, uint32_t log_n, Ext z0, Ext z1, Ext z2) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << log_n;
   if (pos >= n) return;
   const uint32_t e = gl::bitrev(pos, log_n);
-  const Ext z = blockIdx.y ? z1 : z0;
+  const Ext z = blockIdx.y == 0 ? z0 : (blockIdx.y == 1 ? z1 : z2);
   const Ext r = gl::pow(z, e);
   uint64_t* o = out + (uint64_t)blockIdx.y * 2 * n;
   o[pos] = r.c0;
@@ -353,13 +353,11 @@ __global__ void __launch_bounds__(256) alpha_pows_kernel(uint64_t* __restrict__ 
   out[2 * j + 1] = r.c1;
 }
 // One workgroup per coefficient column: out[col] = (sum c*p0.c0, sum c*p0.c1, sum c*p1.c0, sum c*p1.c1)
-__global__ void __launch_bounds__(256)
-openings_kernel(const uint64_t* __restrict__ coeffs, uint64_t stride, uint32_t log_n,
-                const uint64_t* __restrict__ pw, uint32_t n_points, uint64_t* __restrict__ out) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__device__ __forceinline__ void
+openings_column(const uint64_t* __restrict__ c, uint32_t log_n, const uint64_t* __restrict__ pw, uint32_t n_points,
+                uint64_t* __restrict__ out4) {
   __shared__ uint64_t red[4][256];
   const uint32_t n = 1u << log_n;
-  const uint64_t* c = coeffs + blockIdx.x * stride;
   // unreduced accumulation (gl::DotAcc): 8 VALU per product, one reduction per lane at the end
   gl::DotAcc dacc[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -382,18 +380,34 @@ openings_kernel(const uint64_t* __restrict__ coeffs, uint64_t stride, uint32_t l
       for (int k = 0; k < 4; k++) red[k][threadIdx.x] = gl::addc(red[k][threadIdx.x], red[k][threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x < 4) out[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+  if (threadIdx.x < 4) out4[threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ void __launch_bounds__(256)
+openings_kernel(const uint64_t* __restrict__ coeffs, uint64_t stride, uint32_t log_n,
+                const uint64_t* __restrict__ pw, uint32_t n_points, uint64_t* __restrict__ out) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  openings_column(coeffs + blockIdx.x * stride, log_n, pw, n_points, out + (uint64_t)blockIdx.x * 4);
+}
+// every opening set of a proof (constants, trace, aux, quotient at zeta [/ g zeta], aux at 1) in ONE launch: the
+// five launches it replaces sat one behind the other on the proof's critical path
+__global__ void __launch_bounds__(256) openings_multi_kernel(bpg::OpenMulti m) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 1; k < 5; k++)
+    if (k < (int)m.n_segs && blockIdx.x >= m.first_col[k]) s = k;
+  const uint32_t col = blockIdx.x - m.first_col[s];
+  openings_column(m.coeffs[s] + (uint64_t)col * m.stride, m.log_n, m.pw[s], m.n_points[s], m.out[s] + (uint64_t)col * 4);
 }
 
 // ---------------------------------------------------------------- K6a FRI combine
 // Coefficient-space alpha reduction.  For a block of columns of ONE oracle, accumulates into up to
 // three batch polynomials:  G_b[pos] += sum_col alpha^(e_b + col) * coeff[col][pos].
 // grid = (n/256, column chunks).  partial layout: [chunk][b][2][n]
-__global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineArgs a) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__device__ __forceinline__ void fri_combine_partial_body(const bpg::CombineArgs& a, uint32_t chunk) {
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << a.log_n;
   if (pos >= n) return;
-  const uint32_t c0 = blockIdx.y * a.cols_per_chunk, c1 = min(c0 + a.cols_per_chunk, a.n_cols);
+  const uint32_t c0 = chunk * a.cols_per_chunk, c1 = min(c0 + a.cols_per_chunk, a.n_cols);
   // six unreduced accumulators (3 batches x 2 extension components) in two groups of four
   gl::DotAcc d01[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
   gl::DotAcc d2[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
@@ -423,12 +437,25 @@ __global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineAr
   }
   const Ext acc[3] = {Ext{gl::dot_reduce(d01[0]), gl::dot_reduce(d01[1])}, Ext{gl::dot_reduce(d01[2]), gl::dot_reduce(d01[3])},
                       Ext{gl::dot_reduce(d2[0]), gl::dot_reduce(d2[1])}};
-  uint64_t* out = a.partial + (uint64_t)(a.chunk_base + blockIdx.y) * 6 * n;
+  uint64_t* out = a.partial + (uint64_t)(a.chunk_base + chunk) * 6 * n;
 #pragma unroll
   for (int b = 0; b < 3; b++) {
     out[(2 * b) * (uint64_t)n + pos] = acc[b].c0;
     out[(2 * b + 1) * (uint64_t)n + pos] = acc[b].c1;
   }
+}
+__global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineArgs a) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  fri_combine_partial_body(a, blockIdx.y);
+}
+// all oracles of a proof (constants, trace, aux, quotient) in one launch: grid.y runs over the chunks of all of them
+__global__ void __launch_bounds__(256) fri_combine_partial_multi_kernel(bpg::CombineMulti m) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);
+  uint32_t o = 0;
+#pragma unroll
+  for (int k = 1; k < 4; k++)
+    if (k < (int)m.n_oracles && blockIdx.y >= m.a[k].chunk_base) o = k;
+  fri_combine_partial_body(m.a[o], blockIdx.y - m.a[o].chunk_base);
 }
 // g[6][n] = sum over chunks.  grid = (n/256, 6)
 __global__ void __launch_bounds__(256)
@@ -785,9 +812,9 @@ int launch_quotient_chunks(const ChunkArgs& c, hipStream_t st) {
   return BP_OK;
 }
 int launch_power_vectors(uint64_t* d_out, uint32_t log_n, gl::Ext z0, gl::Ext z1, uint32_t n_points,
-                         hipStream_t st) {
+                         hipStream_t st, gl::Ext z2) {
   dim3 grid(ceil_div((uint64_t)1 << log_n, 256), n_points);
-  power_vector_kernel<<<grid, 256, 0, st>>>(d_out, log_n, z0, z1);
+  power_vector_kernel<<<grid, 256, 0, st>>>(d_out, log_n, z0, z1, z2);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -803,10 +830,24 @@ int launch_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, u
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_openings_multi(const OpenMulti& m, hipStream_t st) {
+  const uint32_t total = m.first_col[m.n_segs];
+  if (!total) return BP_OK;
+  openings_multi_kernel<<<total, 256, 0, st>>>(m);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_combine_partial(const CombineArgs& a, uint32_t n_chunks, hipStream_t st) {
   if (!a.n_cols) return BP_OK;
   dim3 grid(ceil_div((uint64_t)1 << a.log_n, 256), n_chunks);
   fri_combine_partial_kernel<<<grid, 256, 0, st>>>(a);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_combine_partial_multi(const CombineMulti& m, uint32_t total_chunks, hipStream_t st) {
+  if (!total_chunks) return BP_OK;
+  dim3 grid(ceil_div((uint64_t)1 << m.a[0].log_n, 256), total_chunks);
+  fri_combine_partial_multi_kernel<<<grid, 256, 0, st>>>(m);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }

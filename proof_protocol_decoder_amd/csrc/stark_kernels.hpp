@@ -42,6 +42,18 @@ struct CombineArgs {
   const uint64_t* alpha_pows;  // ext pairs alpha^j
   uint64_t* partial;           // [chunks][6][n]
 };
+struct CombineMulti {  // the oracles of one proof; a[o].chunk_base = first global chunk of oracle o (ascending)
+  CombineArgs a[4];
+  uint32_t n_oracles;
+};
+struct OpenMulti {  // up to five opening sets in one launch: segment s covers blocks [first_col[s], first_col[s + 1])
+  const uint64_t* coeffs[5];
+  const uint64_t* pw[5];
+  uint64_t* out[5];
+  uint32_t first_col[6], n_points[5];
+  uint64_t stride;
+  uint32_t log_n, n_segs;
+};
 struct FriInitArgs {
   const uint64_t* glde;  // [6][rows]
   uint64_t* out;         // ext AoS [rows]
@@ -100,11 +112,14 @@ int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_
                hipStream_t st);
 int launch_quotient(const QuotArgs& q, hipStream_t st);
 int launch_quotient_chunks(const ChunkArgs& c, hipStream_t st);
+// d_out: n_points (<= 3) vectors of 2n words each: point y at d_out + y * 2n
 int launch_power_vectors(uint64_t* d_out, uint32_t log_n, gl::Ext z0, gl::Ext z1, uint32_t n_points,
-                         hipStream_t st);
+                         hipStream_t st, gl::Ext z2 = gl::Ext{1, 0});
 int launch_alpha_pows(uint64_t* d_out, uint32_t count, gl::Ext alpha, hipStream_t st);
 int launch_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, uint32_t n_cols,
                     const uint64_t* d_pw, uint32_t n_points, uint64_t* d_out, hipStream_t st);
+int launch_openings_multi(const OpenMulti& m, hipStream_t st);
+int launch_combine_partial_multi(const CombineMulti& m, uint32_t total_chunks, hipStream_t st);
 int launch_combine_partial(const CombineArgs& a, uint32_t n_chunks, hipStream_t st);
 int launch_combine_reduce(const uint64_t* d_partial, uint32_t n_chunks, uint32_t log_n, uint64_t* d_g,
                           hipStream_t st);

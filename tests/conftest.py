@@ -12,6 +12,33 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# A test stuck inside a native call (a device wait that never returns, a join) cannot be interrupted by a Python
+# signal handler; faulthandler's watchdog THREAD can still dump every thread's Python stack and end the process, so a
+# hang fails within minutes with the line it sits on instead of being killed silently by the box.  Re-armed at the
+# start of every test (module fixtures are torn down inside the last test's window).  BPG_TEST_WATCHDOG=0 disables.
+_WATCHDOG_S = int(os.environ.get("BPG_TEST_WATCHDOG", "360"))
+_WATCHDOG_FILE = None
+
+
+def pytest_runtest_logstart(nodeid, location):
+    global _WATCHDOG_FILE
+    if _WATCHDOG_S > 0:
+        import faulthandler
+        if _WATCHDOG_FILE is None:  # pytest captures fd 2 while a test runs: the dump goes to a file of its own
+            d = os.path.join(ROOT, "gpurun_out")
+            _WATCHDOG_FILE = open(os.path.join(d if os.path.isdir(d) else "/tmp", "test_watchdog.txt"), "w")
+        _WATCHDOG_FILE.seek(0)
+        _WATCHDOG_FILE.truncate()
+        _WATCHDOG_FILE.write("watchdog armed for %s (%d s)\n" % (nodeid, _WATCHDOG_S))
+        _WATCHDOG_FILE.flush()
+        faulthandler.dump_traceback_later(_WATCHDOG_S, exit=True, file=_WATCHDOG_FILE)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU restatement (test infrastructure).  Built on demand with gcc."""

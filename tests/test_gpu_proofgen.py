@@ -363,6 +363,19 @@ def test_block16_at_default_config_matches_golden(bpg, pg, oracle):
         st.close()
 
 
+def test_closing_a_state_after_a_table_proof_parked_a_worker_does_not_hang():
+    """Found in round 3: bp_stark_prove_air leaves a parked worker on the device; when the first bp_state_build then
+    switched the device to blocking host waits, the hipFree of bp_state_free never returned.  The wait mode is now
+    fixed before the library's first stream.  Fresh process (the order of calls in the process is the point)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "hang_probe.py"), "s"], capture_output=True, text=True,
+                       timeout=300, cwd=root, env=dict(os.environ, WD="120"))
+    assert r.returncode == 0 and "state closed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 RCCL_CHILD = r'''
 import os, sys
 sys.path.insert(0, {root!r})
