@@ -44,7 +44,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
 # (two rocprofv3 --pmc passes of this same command, tools/pmc_family_traffic.py).  bench.py cannot collect
 # counters itself, so it reads the tracked summary and names it (and the commit it was taken at) beside the
 # number; no file, no number.
-TRAFFIC_FILE = os.path.join("profiles", "r2b_pmc_lde_family.txt")
+TRAFFIC_FILE = os.path.join("profiles", "r3_pmc_lde_family.txt")
 
 
 def traffic_ratio():
@@ -188,8 +188,8 @@ def main():
         if not n.value:
             return None
         rate = perms.value / (ms.value * 1e-3) / 1e9
-        return {"kernel": "Merkle leaf hashing: leaf_hash_mx_kernel<4|2|1> (Poseidon, width 12, MDS layer on the int8 "
-                          "matrix cores)",
+        return {"kernel": "Merkle leaf hashing: leaf_hash_mx_kernel<4|2|1> (Poseidon, width 12, MDS layer and the grouped "
+                          "partial rounds on the int8 matrix cores)",
                 "bound": "int-ALU (VALU issue)", "achieved": round(rate, 3), "unit": "Gperm/s",
                 # valu_issue_frac / peak_measured are filled in below from a live measurement of the same kernel
                 # family with the chip full (poseidon_peak: 2^21 rows)
@@ -370,19 +370,20 @@ def main():
 # 4 cycles (a SIMD has 16 lanes), at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md).
 N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
 VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * PEAK_CLOCK_HZ / 4
-SQ_FILE = os.path.join("profiles", "r2b_hash_sq_counters.txt")
+SQ_FILE = os.path.join("profiles", "r3_hash_sq_counters.txt")
 
 
 def valu_insts_per_perm():
-    """VALU wave-instructions per Poseidon permutation of leaf_hash_mx_kernel<4>, from the tracked SQ-counter
-    summary (rocprofv3 --pmc SQ_INSTS_VALU over 2^21 rows x 8 permutations; tools/prof_hash_counters.sh)."""
+    """VALU wave-instructions per Poseidon permutation of the shipped leaf-hash kernel (four sets per wave, grouped
+    partial rounds), from the tracked SQ-counter summary (rocprofv3 --pmc SQ_INSTS_VALU over 2^21 rows x 8
+    permutations; tools/prof_round3.sh)."""
     import re
     try:
         txt = open(os.path.join(ROOT, SQ_FILE)).read()
-        blk = txt[txt.index("leaf_hash_mx_kernel<4>"):]
+        blk = txt[txt.index("leaf_hash_mx_kernel<4, grouped>"):]
         insts = float(re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+)", blk).group(1))
         mfma = float(re.search(r"SQ_INSTS_MFMA\s+([0-9.e+]+)", blk).group(1))
-        m = re.search(r"([0-9.e+]+) permutations", txt)
+        m = re.search(r"= ([0-9]+) permutations", txt)
         perms = float(m.group(1)) if m else float((1 << 21) * 8)
         return insts / perms, mfma / perms
     except (OSError, AttributeError, ValueError):
@@ -402,11 +403,11 @@ def finish_alu_kernel(alu, peak):
         alu["valu_issue_peak_insts_per_s"] = VALU_PEAK_WAVE_INSTS_PER_S
         alu["valu_issue_frac"] = round(alu["achieved"] * 1e9 * per_perm / VALU_PEAK_WAVE_INSTS_PER_S, 3)
         alu["valu_issue_frac_chip_full"] = round(peak * 1e9 * per_perm / VALU_PEAK_WAVE_INSTS_PER_S, 3)
-    # what the MDS layer asks of the matrix cores at the chip-full rate: 30 rounds x 6 v_mfma_i32_16x16x64_i8
-    # (32768 int8 ops each) per 16 states.  Informational: the kernel is bound by VALU issue, and three
-    # quarters of these multiplies are by the zeros of a plane-diagonal matrix.
+    # what the kernel asks of the matrix cores at the chip-full rate: MFMA wave-instructions per permutation (SQ
+    # summary; 11.25 = 30 rounds x 6 per 16 states before the grouped rounds) x 32768 int8 ops each.  Informational: the
+    # kernel is bound by VALU issue, and most of these multiplies are by the zeros of plane-diagonal or sparse operands.
     INT8_DENSE_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md: I8 = 2 x the BF16 rate per clock
-    tops = peak * 1e9 * 30 * 6 * 32768 / 16 / 1e12
+    tops = peak * 1e9 * (mfma_per_perm or 11.25) * 32768 / 1e12
     alu["mfma_int8"] = {"achieved_at_peak_rate": round(tops, 1), "peak": INT8_DENSE_PEAK_TOPS,
                         "unit": "TOP/s", "frac": round(tops / INT8_DENSE_PEAK_TOPS, 3)}
 

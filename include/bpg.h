@@ -111,7 +111,7 @@ int bp_debug_field_ops(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out
  * 2^13 under load.  A caller that drives the L0 entry points from many streams itself should set 2^13: the library
  * cannot see that load. */
 void bp_tune_quad_threshold(uint64_t n_perms);
-/* Merkle levels of at most 4096 nodes: 1 (default) = fused, up to 7 levels per launch (LDS hand-down, one-set
+/* Merkle levels of at most 2048 nodes: 1 (default) = fused, up to 7 levels per launch (LDS hand-down, one-set
  * matrix-core permutation; +2.8 % on the 256-txn block, +3..5 % on 16- and 32-txn shards: fewer launches on every
  * proof's critical path); 0 = one launch per level; -1 = fused only while fewer than 6 provers are at work on the
  * device.  Results are identical. */

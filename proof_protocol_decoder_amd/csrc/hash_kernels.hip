@@ -474,7 +474,7 @@ uint64_t quad_threshold() {
 // Levels near the root are each one latency-bound launch (a lone txn proof spends ~30 % of its kernel time in them,
 // and under the 24-stream load they are 40 % of all launches, each stretched from 19 to ~120 us by sharing:
 // profiles/r2b_kernel_stats_4txn_1stream.csv, r3_kernel_stats_64txn_24streams.csv).  merkle_subtree_mx_kernel hands
-// up to seven levels of at most 4096 nodes down through LDS in one launch, in the one-set matrix-core form.
+// up to seven levels of at most 2048 nodes down through LDS in one launch, in the one-set matrix-core form.
 // Measured in round 3 (profiles/r3_small_shards.txt), fused against one launch per level: 256 txns 36.2 against 35.2
 // txn-proofs/s, 32 txns 33.6 against 32.5, 16 txns 33.1 against 31.6, a lone pair of txns 150.8 against 148.2 ms.
 // (With the quad-cooperative permutation -- round 2's fused kernel, still used when the matrix-core forms are switched
@@ -575,7 +575,9 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     uint64_t* nxt = lvl + cnt * 4;
     // fuse only what fits in <= 64 workgroups: those launches are latency-critical and run at raised priority
     const int fmode = g_merkle_fused.load(std::memory_order_relaxed);
-    const uint64_t flimit = fmode >= 8 ? (uint64_t)1 << fmode : 4096;  // measurement knob: modes 8..20 = fuse from 2^mode nodes down
+    // from 2^11 nodes down (measured 2^10 / 2^11 / 2^12 / 2^13 / 2^14: 36.9 / 37.0 / 36.8 / 35.2 / 34.7 txn-proofs/s: wider
+    // levels are throughput work for the four-set kernels); modes 8..20 of the knob = fuse from 2^mode nodes down
+    const uint64_t flimit = fmode >= 8 ? (uint64_t)1 << fmode : 2048;
     const bool fused = parents <= flimit && (parents < quad_threshold() || fmode >= 8) && (fmode > 0 || (fmode < 0 && !device_loaded()));
     if (!fused) {
       uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;

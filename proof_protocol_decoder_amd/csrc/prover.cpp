@@ -250,8 +250,10 @@ int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t
   qa.n_ctl_units = (A + qa.aux_per_unit - 1) / qa.aux_per_unit;
   // One pass (the alpha fold never leaves the registers) once the rows alone fill the chip: 2048 workgroups of
   // 256 lanes = 2 per SIMD.  Shorter tables spread their units over grid.y until the launch has that many.
+  // While several provers share the device nothing needs filling: one pass, one launch fewer on the proof's
+  // critical path and no partial sums.
   const uint32_t n_units = qa.n_air_units + qa.n_ctl_units, wg_x = (uint32_t)((M + 255) / 256);
-  const uint32_t want_rows = std::min<uint32_t>(n_units, std::max<uint32_t>(1, (2048 + wg_x - 1) / wg_x));
+  const uint32_t want_rows = device_loaded() ? 1 : std::min<uint32_t>(n_units, std::max<uint32_t>(1, (2048 + wg_x - 1) / wg_x));
   qa.units_per_wg = (n_units + want_rows - 1) / want_rows;
   qa.alpha0 = alpha0; qa.alpha1 = alpha1;
   qa.g = wN; qa.g_inv = gl::inv(wN); qa.n_inv = gl::inv(N);
@@ -431,9 +433,13 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
     cb.alpha_pows = d_apow; cb.partial = d_cpart;
     chunk_base += (cb.n_cols + cols_per_chunk - 1) / cols_per_chunk;
   }
-  TRY(launch_combine_partial_multi(cm, total_chunks, st));
   ARENA_ALLOC(d_g, 6 * N);
-  TRY(launch_combine_reduce(d_cpart, total_chunks, log_n, d_g, st));
+  if (device_loaded()) {  // several provers share the device: one pass, no partial sums, one launch instead of two
+    TRY(launch_combine_all(cm, d_g, st));
+  } else {
+    TRY(launch_combine_partial_multi(cm, total_chunks, st));
+    TRY(launch_combine_reduce(d_cpart, total_chunks, log_n, d_g, st));
+  }
   ARENA_ALLOC(d_glde, 6 * M);
   TRY(ntt_br2nat(d_g, N, d_glde, M, N, log_n, 6, R, coset_scale, false, st));
   FriInitArgs fi{};

@@ -129,6 +129,7 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
 
 // hash_kernels.hip: +1 / -1 as a prover starts / finishes (the Poseidon kernel choice follows the load)
 void prover_active(int delta);
+bool device_loaded();  // six or more provers at work on the device
 
 // launch-argument builders shared by the prover and the L0 entry points (stark_api.cpp)
 // fills everything but the matrix pointers, apow (2 * n_constraints words) and partial (quotient_partial_words)

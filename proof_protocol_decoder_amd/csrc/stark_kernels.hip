@@ -404,13 +404,9 @@ __global__ void __launch_bounds__(256) openings_multi_kernel(bpg::OpenMulti m) {
 // Coefficient-space alpha reduction.  For a block of columns of ONE oracle, accumulates into up to
 // three batch polynomials:  G_b[pos] += sum_col alpha^(e_b + col) * coeff[col][pos].
 // grid = (n/256, column chunks).  partial layout: [chunk][b][2][n]
-__device__ __forceinline__ void fri_combine_partial_body(const bpg::CombineArgs& a, uint32_t chunk) {
-  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << a.log_n;
-  if (pos >= n) return;
-  const uint32_t c0 = chunk * a.cols_per_chunk, c1 = min(c0 + a.cols_per_chunk, a.n_cols);
-  // six unreduced accumulators (3 batches x 2 extension components) in two groups of four
-  gl::DotAcc d01[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
-  gl::DotAcc d2[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
+// columns [c0, c1) of one oracle into the six unreduced accumulators (3 batches x 2 extension components, two groups)
+__device__ __forceinline__ void fri_combine_accumulate(const bpg::CombineArgs& a, uint32_t c0, uint32_t c1, uint32_t pos,
+                                                       gl::DotAcc (&d01)[4], gl::DotAcc (&d2)[4]) {
   const bool on0 = a.exp_base[0] >= 0, on1 = a.exp_base[1] >= 0, on2 = a.exp_base[2] >= 0;
   for (uint32_t c = c0; c < c1; c++) {
     const uint64_t v = a.coeffs[(uint64_t)c * a.stride + pos];
@@ -435,14 +431,35 @@ __device__ __forceinline__ void fri_combine_partial_body(const bpg::CombineArgs&
       gl::dot_mad4(d2, vv, w);
     }
   }
+}
+__device__ __forceinline__ void fri_combine_store(gl::DotAcc (&d01)[4], gl::DotAcc (&d2)[4], uint64_t* out, uint32_t n, uint32_t pos) {
   const Ext acc[3] = {Ext{gl::dot_reduce(d01[0]), gl::dot_reduce(d01[1])}, Ext{gl::dot_reduce(d01[2]), gl::dot_reduce(d01[3])},
                       Ext{gl::dot_reduce(d2[0]), gl::dot_reduce(d2[1])}};
-  uint64_t* out = a.partial + (uint64_t)(a.chunk_base + chunk) * 6 * n;
 #pragma unroll
   for (int b = 0; b < 3; b++) {
     out[(2 * b) * (uint64_t)n + pos] = acc[b].c0;
     out[(2 * b + 1) * (uint64_t)n + pos] = acc[b].c1;
   }
+}
+__device__ __forceinline__ void fri_combine_partial_body(const bpg::CombineArgs& a, uint32_t chunk) {
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << a.log_n;
+  if (pos >= n) return;
+  const uint32_t c0 = chunk * a.cols_per_chunk, c1 = min(c0 + a.cols_per_chunk, a.n_cols);
+  gl::DotAcc d01[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
+  gl::DotAcc d2[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
+  fri_combine_accumulate(a, c0, c1, pos, d01, d2);
+  fri_combine_store(d01, d2, a.partial + (uint64_t)(a.chunk_base + chunk) * 6 * n, n, pos);
+}
+// Every column of every oracle in one pass, straight into g[6][n]: no partial sums, no reduce launch.  For a
+// device that several provers share (nothing needs filling); the sums are exact, so the bytes are the same.
+__global__ void __launch_bounds__(256) fri_combine_all_kernel(bpg::CombineMulti m, uint64_t* __restrict__ g) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+  const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << m.a[0].log_n;
+  if (pos >= n) return;
+  gl::DotAcc d01[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
+  gl::DotAcc d2[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
+  for (uint32_t o = 0; o < m.n_oracles; o++) fri_combine_accumulate(m.a[o], 0, m.a[o].n_cols, pos, d01, d2);
+  fri_combine_store(d01, d2, g, n, pos);
 }
 __global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineArgs a) {
   if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
@@ -679,9 +696,19 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned
 }
 // The same search with the MDS layer on the matrix cores (poseidon_mx.cuh): a wave takes 64 consecutive candidates
 // as four sets of 16, lane (n, kb) holds words kb, kb + 4, kb + 8 of candidate 16m + n; word 7 is slot 1 of lanes kb = 3.
-__global__ void __launch_bounds__(256) pow_grind_mx_kernel(bpg::PowArgs a, unsigned long long* result) {
-  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
-  poseidon::mx::build_cin(cin);
+// GR: the partial rounds 4..19 in two groups of eight (gtab = the device image of the operand tables, as in
+// hash_kernels.hip); otherwise every round by itself.
+template <bool GR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+pow_grind_mx_kernel(bpg::PowArgs a, unsigned long long* result, const uint32_t* __restrict__ gtab) {
+  __shared__ __attribute__((aligned(16))) uint32_t cin[GR ? poseidon::mx::CIN_GROUPED_WORDS : poseidon::mx::CIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t gt[GR ? poseidon::mx::grp::TABLE_WORDS : 4];
+  if constexpr (GR) {
+    poseidon::mx::build_cin_grouped(cin);
+    poseidon::mx::grp::load_tables(gt, gtab);
+  } else {
+    poseidon::mx::build_cin(cin);
+  }
   __syncthreads();
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
   const uint64_t cand0 = a.base + ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 15);
@@ -695,7 +722,8 @@ __global__ void __launch_bounds__(256) pow_grind_mx_kernel(bpg::PowArgs a, unsig
 #pragma unroll
     for (int m = 0; m < 4; m++) e[m][s] = mine ? cand0 + 16 * m : w;
   }
-  poseidon::mx::permute<4>(e, c);
+  if constexpr (GR) poseidon::mx::permute_grouped(e, c, gt);
+  else poseidon::mx::permute<4>(e, c);
   if (c.kb == 3) {
 #pragma unroll
     for (int m = 0; m < 4; m++)
@@ -851,6 +879,11 @@ int launch_combine_partial_multi(const CombineMulti& m, uint32_t total_chunks, h
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_combine_all(const CombineMulti& m, uint64_t* d_g, hipStream_t st) {
+  fri_combine_all_kernel<<<ceil_div((uint64_t)1 << m.a[0].log_n, 256), 256, 0, st>>>(m, d_g);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_combine_reduce(const uint64_t* d_partial, uint32_t n_chunks, uint32_t log_n, uint64_t* d_g,
                           hipStream_t st) {
   dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 6);
@@ -885,9 +918,10 @@ int launch_fri_fold(const FriLayerArgs& a, hipStream_t st) {
   return BP_OK;
 }
 int launch_pow(const PowArgs& a, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st) {
-  if (poseidon_mx())
-    pow_grind_mx_kernel<<<n_candidates / 256, 256, 0, st>>>(a, d_result);
-  else
+  if (poseidon_mx()) {
+    if (const uint32_t* gtab = group_tables()) pow_grind_mx_kernel<true><<<n_candidates / 256, 256, 0, st>>>(a, d_result, gtab);
+    else pow_grind_mx_kernel<false><<<n_candidates / 256, 256, 0, st>>>(a, d_result, nullptr);
+  } else
     pow_grind_kernel<<<n_candidates / 256, 256, 0, st>>>(a, d_result);
   BPG_LAUNCH_CHECK();
   return BP_OK;

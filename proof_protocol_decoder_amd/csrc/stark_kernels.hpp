@@ -120,6 +120,7 @@ int launch_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, u
                     const uint64_t* d_pw, uint32_t n_points, uint64_t* d_out, hipStream_t st);
 int launch_openings_multi(const OpenMulti& m, hipStream_t st);
 int launch_combine_partial_multi(const CombineMulti& m, uint32_t total_chunks, hipStream_t st);
+int launch_combine_all(const CombineMulti& m, uint64_t* d_g, hipStream_t st);  // one pass, straight into g[6][n]
 int launch_combine_partial(const CombineArgs& a, uint32_t n_chunks, hipStream_t st);
 int launch_combine_reduce(const uint64_t* d_partial, uint32_t n_chunks, uint32_t log_n, uint64_t* d_g,
                           hipStream_t st);
@@ -139,6 +140,7 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
                uint32_t log_n, uint32_t n_cols, uint32_t n_cosets, const uint64_t* scale, bool inverse,
                hipStream_t st);
 // hash_kernels.hip
+const uint32_t* group_tables();  // the current device's image of the grouped-Poseidon operand tables, or nullptr (knob off)
 int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st,
                         uint64_t* mirror, bool* mirrored);
 int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
