@@ -94,6 +94,9 @@ def main():
                          "starts this as a fresh child process AFTER its timed region")
     ap.add_argument("--phase-marks", action="store_true",
                     help="(measurement knob) write `@phase <name>` lines to stderr for tools/smi_sampler.py")
+    ap.add_argument("--leg-skip-extras", action="store_true",
+                    help="(with --leg-only, for rocprofv3 passes) only the single-stream leg: no isolated LDE launch, "
+                         "NTT sweep or Poseidon peak, so the profiler's per-kernel averages are the leg's own")
     ap.add_argument("--leg-first", action="store_true",
                     help="(measurement knob) round 2's order: the single-stream leg in this process BEFORE the block")
     args = ap.parse_args()
@@ -229,10 +232,11 @@ def main():
     if args.leg_only:
         # child mode: everything that is measured alone on the chip, in a process of its own
         roof, alu = single_stream_leg()
-        out = {"roofline": roof, "alu_kernel": alu, "roofline_isolated": isolated_roofline(pkg, torch),
-               "ntt_hbm_gbps": ntt_gbps(pkg, torch)}
-        if alu:
-            finish_alu_kernel(alu, poseidon_peak(pkg, torch))
+        out = {"roofline": roof, "alu_kernel": alu}
+        if not args.leg_skip_extras:
+            out.update(roofline_isolated=isolated_roofline(pkg, torch), ntt_hbm_gbps=ntt_gbps(pkg, torch))
+            if alu:
+                finish_alu_kernel(alu, poseidon_peak(pkg, torch))
         print(json.dumps(out), flush=True)
         return
 
