@@ -128,6 +128,17 @@ void bp_tune_poseidon_mx_sets(int sets);
  * int8 MFMAs on their bytes) is recombined per round, the twelve words once per group (csrc/poseidon_mx.cuh, grp;
  * tools/poseidon_group_model.py).  0: every round by itself.  Results are identical either way. */
 void bp_tune_poseidon_grouped(int on);
+/* The load-dependent choices -- Poseidon sets per wave by launch size, K5 and the FRI alpha-combination in one pass
+ * without partial sums -- follow the number of bp_generate_*_proof calls at work on the device (six or more =
+ * loaded): -1 (default).  0 / 1: stated by a caller that drives the L0 / L0.5 entry points from its own threads (the
+ * library cannot see that load), or by a test that pins both paths.  Results are identical. */
+void bp_tune_assume_loaded(int mode);
+/* Host only: the operand images of one group of K partial rounds starting at round r0 as the device gets them
+ * (csrc/poseidon_group.hpp); tests/test_mx_tables.py pins them to tools/poseidon_group_model.py.
+ * out_ops: bp_debug_poseidon_group_ops(K) x 1024 bytes, out_cform: 64 i32, out_cmain: 96 i32. */
+uint32_t bp_debug_poseidon_group_ops(uint32_t K);
+int bp_debug_poseidon_group_tables(uint32_t K, uint32_t r0, uint8_t* out_ops, int32_t* out_cform, int32_t* out_cmain,
+                                   int32_t* out_max_plane_sum);
 
 /* Tuning knob for K2: 0 (default) = automatic, 1 = never, 2 = wherever possible: transform a 2^13 / 2^14-point
  * block with TWO workgroups that each do half of the stage coupling its halves while loading (csrc/ntt.hip).
@@ -314,6 +325,13 @@ uint64_t bp_state_device_bytes(const bp_state* s);
 /* abort_flag: nullable; polled between kernel stages (Option<Arc<AtomicBool>>, proof_gen.rs:42). */
 int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
                           uint8_t** out, size_t* out_len);
+/* generate_txn_proof (proof_gen.rs:39-56) for a transaction whose Keccak table attests GIVEN hashing work: the
+ * IR must carry the Keccak-AIR flag (bp_ir_set_keccak_air) and keccak_inputs are the states that go into the
+ * table's permutations (n_perms x 25 lanes; at most 2^log_n / 24 rounded up; the rest of the table is permutations
+ * of the all-zero state).  The decoder side derives them from GenerationInputs with bp_keccak256_permutation_inputs
+ * over signed_txn and contract_code (decoding.rs:131-145; block_driver.irs_from_generation_inputs). */
+int bp_generate_txn_proof_keccak(const bp_state* s, const uint8_t* ir, size_t ir_len, const uint64_t* keccak_inputs,
+                                 size_t n_perms, const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len);
 /* the same call taking the reference's own flag: Arc<AtomicBool> is ONE byte, `flag.as_ptr()` binds here directly */
 int bp_generate_txn_proof_u8(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile uint8_t* abort_flag,
                              uint8_t** out, size_t* out_len);
@@ -379,6 +397,11 @@ int bp_compact_decode_full(const uint8_t* witness, size_t len, uint8_t** out, si
 /* one instruction per text line; release with bp_free_buffer */
 int bp_compact_instructions(const uint8_t* witness, size_t len, uint8_t** text_out, size_t* text_len);
 void bp_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
+/* Keccak-256 of `data` and the 25-lane state (lane index x + 5y) that goes into each of its permutations
+ * (len / 136 + 1 of them): the rows the Keccak table of a transaction that hashes `data` has to contain.
+ * states_out (room for max_perms x 25 words) and digest_out may be NULL; *n_perms_out is always set.  Host only. */
+int bp_keccak256_permutation_inputs(const uint8_t* data, size_t len, uint8_t digest_out[32], uint64_t* states_out,
+                                    size_t max_perms, size_t* n_perms_out);
 
 /* ------------------------------------------------------------------------------------------
  * Next row: the txn IR producer, BlockTrace::into_txn_proof_gen_ir

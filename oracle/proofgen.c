@@ -129,7 +129,17 @@ int orc_pg_preprocess(orc_pg_state* s, const uint64_t* I) {
 }
 
 /* generate_txn_proof (proof_gen.rs:39-56) on the synthetic workload */
-int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) {
+static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inputs, size_t n_perms, gl_t** out,
+                  size_t* out_words);
+int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) { return pg_txn(s, I, NULL, 0, out, out_words); }
+/* the same with the Keccak table's permutation inputs given (n_perms x 25 lanes; the rest of the table: zero states) */
+int orc_pg_txn_keccak(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inputs, size_t n_perms, gl_t** out,
+                      size_t* out_words) {
+  static const uint64_t none = 0;
+  return pg_txn(s, I, keccak_inputs ? keccak_inputs : &none, n_perms, out, out_words);
+}
+static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inputs, size_t n_perms, gl_t** out,
+                  size_t* out_words) {
   const orc_pg_config* cfg = &s->cfg;
   /* version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520: "Txn numbers before/after",
    * "Gas used before/after" equal, tries unchanged) -- same tables proven, public values do not advance */
@@ -148,6 +158,7 @@ int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words
     if (tcfg[3].n_cols != ORC_KECCAK_COLS) return -2;
     tcfg[3].air_id = ORC_AIR_KECCAK_F;
   }
+  if (keccak_inputs && (!keccak_air || n_perms > (((size_t)1 << tcfg[3].log_n) + 23) / 24)) return -3;
   gl_t pv[PV_WORDS];
   pv[0] = I[3]; pv[1] = I[3] + (dummy ? 0 : 1); pv[2] = I[4]; pv[3] = I[5];
   memcpy(pv + 4, I + 6, 32);
@@ -164,7 +175,13 @@ int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words
   for (int t = 0; t < NUM_TABLES; t++) {
     size_t n = (size_t)1 << tcfg[t].log_n;
     trace[t] = (gl_t*)malloc(tcfg[t].n_cols * n * sizeof(gl_t));
-    if (tcfg[t].air_id == ORC_AIR_KECCAK_F) orc_keccak_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
+    if (tcfg[t].air_id == ORC_AIR_KECCAK_F && keccak_inputs) {
+      size_t need = (n + 23) / 24;
+      uint64_t* in = (uint64_t*)calloc(need * 25, 8);
+      memcpy(in, keccak_inputs, n_perms * 25 * 8);
+      orc_keccak_trace(0, in, tcfg[t].log_n, trace[t]);
+      free(in);
+    } else if (tcfg[t].air_id == ORC_AIR_KECCAK_F) orc_keccak_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
     tc[t] = orc_commit_values(trace[t], tcfg[t].log_n, tcfg[t].n_cols, tcfg[t].rate_bits, tcfg[t].cap_height);
     orc_ch_observe_many(&ch, orc_committed_cap(tc[t]), (size_t)4 << tcfg[t].cap_height);

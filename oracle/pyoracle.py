@@ -107,6 +107,7 @@ def lib():
     L.orc_pg_state_build.restype = vp
     L.orc_pg_state_free.argtypes = [vp]
     L.orc_pg_txn.argtypes = [vp, u64p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_pg_txn_keccak.argtypes = [vp, u64p, vp, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_preprocess.argtypes = [vp, u64p]
     L.orc_pg_agg.argtypes = [vp, u64p, sz, i, u64p, sz, i, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_block.argtypes = [vp, vp, sz, u64p, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
@@ -347,9 +348,15 @@ class PgState:
         if rc:
             raise RuntimeError("orc_pg_preprocess failed: %d" % rc)
 
-    def txn(self, ir_words):
+    def txn(self, ir_words, keccak_inputs=None):
+        """keccak_inputs: [n_perms, 25] permutation inputs of the txn's Keccak table (needs the IR's 0x100 flag)"""
         ptr, n = C.POINTER(C.c_uint64)(), C.c_size_t()
-        rc = lib().orc_pg_txn(self.h, arr(ir_words), C.byref(ptr), C.byref(n))
+        if keccak_inputs is None:
+            rc = lib().orc_pg_txn(self.h, arr(ir_words), C.byref(ptr), C.byref(n))
+        else:
+            k = np.ascontiguousarray(keccak_inputs, dtype=np.uint64).reshape(-1, 25)
+            rc = lib().orc_pg_txn_keccak(self.h, arr(ir_words), k.ctypes.data if k.size else None, k.shape[0], C.byref(ptr),
+                                         C.byref(n))
         if rc:
             raise RuntimeError("orc_pg_txn failed: %d" % rc)
         return self._take(ptr, n)

@@ -267,7 +267,23 @@ def irs_from_block_trace(block_trace, block_number, table_log_n, table_width, ha
     return pad_with_dummy_irs(irs, block_number, root0, table_log_n, table_width, has_withdrawals)[0]
 
 
-def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width):
+def keccak_inputs_of_generation_inputs(g):
+    """The Keccak-f permutations a transaction's own data asks for: Keccak-256 of `signed_txn` (the transaction hash)
+    and of every `contract_code` entry (the code hashes the decoder keys them by, decoding.rs:131-145), as the states
+    that go into the permutations, in that order (code in ascending hash order).  The zkEVM's Keccak table holds more
+    (trie nodes, KECCAK256 opcodes): those come from executing the transaction, which is upstream-only."""
+    states = []
+    if g.signed_txn:
+        states += pg.keccak256_permutation_inputs(bytes(g.signed_txn))[1]
+    for h in sorted(g.contract_code):
+        digest, st = pg.keccak256_permutation_inputs(bytes(g.contract_code[h]))
+        if digest != bytes(h):
+            raise ValueError("contract_code is keyed by a hash that is not the Keccak-256 of its bytes")
+        states += st
+    return states
+
+
+def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width, keccak_air=False):
     """`Vec<TxnProofGenIR>` as produced by `decoding.into_txn_proof_gen_ir` (the reference's
     BlockTrace::into_txn_proof_gen_ir: minimal tries, delta replay, dummy padding, withdrawals) -> the IRs this
     library's prover takes.  The zkEVM that would consume the partial tries is upstream-only, so
@@ -276,23 +292,36 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     number and gas come from the decoded entries; the state-root public value starts at the decoded pre-state
     root (folded into four field elements) and chains entry to entry.  Entries without a transaction (dummy
     padding, the withdrawal carrier) become dummy IRs: proven, counters do not advance (decoding.rs:484-520) --
-    a prepended dummy is renumbered to its position, as pad_with_dummy_irs documents."""
+    a prepended dummy is renumbered to its position, as pad_with_dummy_irs documents.
+    keccak_air: every entry's Keccak table (index 3) becomes a real Keccak-f[1600] trace (AIR 1, 2430 columns) whose
+    permutations are the entry's OWN hashing work (keccak_inputs_of_generation_inputs): the table then attests data of
+    the decoded transaction, not only a seed; its height grows to hold them (24 rows per permutation)."""
     from . import compact
     P = 0xFFFFFFFF00000001
     first = gen_inputs[0].tries.state_trie.hash()
     root = tuple(int.from_bytes(first[8 * i:8 * i + 8], "little") % P for i in range(4))
     irs, txn_no, gas = [], 0, 0
+    if keccak_air:
+        table_width = tuple(2430 if t == 3 else w for t, w in enumerate(table_width))
+    base_log_n = tuple(table_log_n)
     for k, g in enumerate(gen_inputs):
+        kw = {}
+        table_log_n = base_log_n
+        if keccak_air:
+            states = keccak_inputs_of_generation_inputs(g)
+            need = max(24 * len(states), 1)
+            table_log_n = tuple(max(l, (need - 1).bit_length()) if t == 3 else l for t, l in enumerate(base_log_n))
+            kw = dict(keccak_air=True, keccak_inputs=tuple(tuple(s) for s in states))
         r = g.trie_roots_after
         blob = (g.signed_txn or b"") + r.state_root + r.transactions_root + r.receipts_root
         blob += b"".join(bytes(a) + int(v).to_bytes(32, "big") for a, v in g.withdrawals)
         seed = int.from_bytes(compact.keccak256(blob)[:8], "little")
         if g.signed_txn is None:
             irs.append(pg.TxnProofGenIR(block_number, txn_no, gas, gas, root, seed, tuple(table_log_n), tuple(table_width),
-                                        dummy=True))
+                                        dummy=True, **kw))
             continue
         used = g.gas_used_after - g.gas_used_before
         irs.append(pg.TxnProofGenIR(block_number, txn_no, gas, gas + used, root, seed, tuple(table_log_n),
-                                    tuple(table_width)))
+                                    tuple(table_width), **kw))
         root, txn_no, gas = pg.state_root_after(root, seed, txn_no), txn_no + 1, gas + used
     return irs

@@ -388,6 +388,24 @@ void bp_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
   std::memcpy(out, h.data(), 32);
 }
 
+// Keccak-256 of `data` together with the state that goes into each of its permutations (len / 136 + 1 of them, 25
+// lanes each, lane index x + 5y): what the Keccak table of a transaction that hashes `data` has to contain
+// (bp_generate_txn_proof_keccak, bp_keccak_trace).  states_out may be NULL to count.
+int bp_keccak256_permutation_inputs(const uint8_t* data, size_t len, uint8_t digest_out[32], uint64_t* states_out,
+                                    size_t max_perms, size_t* n_perms_out) try {
+  if ((!data && len) || !n_perms_out) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_keccak256_permutation_inputs: null argument");
+  std::vector<uint64_t> st;
+  const H256 h = mpt::keccak256_traced(data, len, &st);
+  *n_perms_out = st.size() / 25;
+  if (digest_out) std::memcpy(digest_out, h.data(), 32);
+  if (states_out) {
+    if (st.size() / 25 > max_perms) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_keccak256_permutation_inputs: %zu permutations, room for %zu", st.size() / 25, max_perms);
+    std::memcpy(states_out, st.data(), st.size() * 8);
+  }
+  return BP_OK;
+}
+BPG_ABI_CATCH("bp_keccak256_permutation_inputs")
+
 // process_compact_prestate (compact_prestate_processing.rs:1240-1281): header version, state root,
 // and the sizes of what was extracted.  Any pointer but `witness` may be NULL.
 int bp_compact_decode(const uint8_t* witness, size_t len, uint8_t* header_version, uint8_t state_root[32],

@@ -461,11 +461,15 @@ static std::atomic<uint64_t> g_quad_threshold{0};
 static bool g_poseidon_mx_on();
 static std::atomic<int> g_active_provers{0};
 void prover_active(int delta) { g_active_provers.fetch_add(delta, std::memory_order_relaxed); }
-bool device_loaded() { return g_active_provers.load(std::memory_order_relaxed) >= 6; }  // several provers share the chip
+static std::atomic<int> g_assume_loaded{-1};  // -1: by the count of provers at work; 0 / 1: stated by the caller
+bool device_loaded() {  // several provers share the chip
+  const int a = g_assume_loaded.load(std::memory_order_relaxed);
+  return a < 0 ? g_active_provers.load(std::memory_order_relaxed) >= 6 : a != 0;
+}
 uint64_t quad_threshold() {
   const uint64_t t = g_quad_threshold.load(std::memory_order_relaxed);
   if (t) return t;
-  const bool loaded = g_active_provers.load(std::memory_order_relaxed) >= 6;
+  const bool loaded = device_loaded();
   // with the matrix-core forms the small-launch form (one set per wave) costs 0.65x the quad form's instructions
   // and wins alone up to 2^18 items (tools/kernel_bench.py: 2^17 rows 1.8-2.0 against 1.5-1.8 Gperm/s for four sets)
   if (g_poseidon_mx_on()) return (uint64_t)1 << (loaded ? 13 : 19);
@@ -653,6 +657,10 @@ int bp_debug_poseidon_mx_cin(uint32_t* out) {
 }
 /* 1 (default): the four-set matrix-core kernels take the partial rounds 4..19 in two groups of eight
  * (csrc/poseidon_mx.cuh, grp); 0: every round by itself.  Results are identical. */
+/* The load-dependent choices (kernel forms, one-pass K5 / FRI combination): -1 (default) = by the number of
+ * bp_generate_*_proof calls at work on the device (six or more = loaded); 0 / 1 = stated by a caller that drives the
+ * L0 / L0.5 entry points from its own threads, or by a test that pins both paths. */
+void bp_tune_assume_loaded(int mode) { bpg::g_assume_loaded.store(mode < 0 ? -1 : (mode != 0)); }
 void bp_tune_poseidon_grouped(int on) { bpg::g_poseidon_grouped.store(on != 0); }
 
 // Host only: the operand images of one group as the device gets them (tests/test_mx_tables.py pins them to the

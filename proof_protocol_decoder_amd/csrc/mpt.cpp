@@ -41,7 +41,11 @@ static void keccak_f(uint64_t st[25]) {
     st[0] ^= RC[r];
   }
 }
-H256 keccak256(const uint8_t* data, size_t len) {
+H256 keccak256(const uint8_t* data, size_t len) { return keccak256_traced(data, len, nullptr); }
+
+// The same sponge; every state that goes INTO a permutation (25 lanes, index x + 5y) is appended to `perm_inputs`:
+// the rows a Keccak-f table needs to attest this hash (one permutation per 136-byte block, padding included).
+H256 keccak256_traced(const uint8_t* data, size_t len, std::vector<uint64_t>* perm_inputs) {
   uint64_t st[25] = {0};
   const size_t rate = 136;
   uint8_t block[136];
@@ -51,6 +55,7 @@ H256 keccak256(const uint8_t* data, size_t len) {
       std::memcpy(&w, data + 8 * i, 8);
       st[i] ^= w;
     }
+    if (perm_inputs) perm_inputs->insert(perm_inputs->end(), st, st + 25);
     keccak_f(st);
     data += rate;
     len -= rate;
@@ -64,6 +69,7 @@ H256 keccak256(const uint8_t* data, size_t len) {
     std::memcpy(&w, block + 8 * i, 8);
     st[i] ^= w;
   }
+  if (perm_inputs) perm_inputs->insert(perm_inputs->end(), st, st + 25);
   keccak_f(st);
   H256 out;
   std::memcpy(out.data(), st, 32);

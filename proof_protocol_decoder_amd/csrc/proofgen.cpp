@@ -416,8 +416,11 @@ int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_
 }
 BPG_ABI_CATCH("bp_proof_public_values")
 
+// keccak_inputs (nullable): the permutation inputs of the transaction's Keccak table, n_perms x 25 lanes; needs the
+// IR's Keccak-AIR flag.  Permutations beyond n_perms are of the all-zero state (as upstream pads its table).
 static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
-                          const volatile uint8_t* abort_flag_u8, uint8_t** out, size_t* out_len) {
+                          const volatile uint8_t* abort_flag_u8, uint8_t** out, size_t* out_len,
+                          const uint64_t* keccak_inputs = nullptr, size_t n_perms = 0) {
   if (!s || !ir || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof: null argument");
   if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
   const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
@@ -428,6 +431,11 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
   if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 1) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
   const bool dummy = ver == 2, keccak_air = (flags & 1) != 0;
+  if (keccak_inputs && !keccak_air)
+    return fail(BP_ERR_INVALID_INPUT, "Keccak permutation inputs need an IR whose Keccak table is the Keccak-f AIR (bp_ir_set_keccak_air)");
+  if (keccak_inputs && n_perms > (((size_t)1 << I[11 + 3]) + 23) / 24)
+    return fail(BP_ERR_RANGE, "%zu Keccak permutations do not fit a table of 2^%llu rows (24 rows each)", n_perms,
+                (unsigned long long)I[11 + 3]);
   if (I[5] < I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: gas_used_after < gas_used_before");
   if (dummy && I[5] != I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: a dummy entry must not use gas (decoding.rs:503-506)");
   const bp_config& cfg = s->cfg;
@@ -468,9 +476,22 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
     const uint64_t N = (uint64_t)1 << tcfg[t].log_n;
     d_trace[t] = w.arena.alloc_words((size_t)tcfg[t].n_cols * N);
     if (!d_trace[t]) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) for table %s", w.arena.capacity() >> 20, TABLE_NAMES[t]);
-    r = tcfg[t].air_id == air::KECCAK_F
-            ? launch_keccak_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
-            : launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, I[10] ^ splitmix64(t + 1), w.stream);
+    if (tcfg[t].air_id == air::KECCAK_F && keccak_inputs) {
+      // the caller's permutations, then all-zero states up to the table's height, staged through the pinned buffer
+      const size_t need = (N + 23) / 24;
+      uint64_t* d_in = w.arena.alloc_words(need * 25);
+      if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the Keccak inputs");
+      if (need * 25 > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "Keccak table too tall for the input staging buffer");
+      std::memcpy(w.pinned, keccak_inputs, n_perms * 25 * 8);
+      std::memset(w.pinned + n_perms * 25, 0, (need - n_perms) * 25 * 8);
+      BPG_HIP(hipMemcpyAsync(d_in, w.pinned, need * 25 * 8, hipMemcpyHostToDevice, w.stream));
+      r = launch_keccak_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream);
+      if (r == BP_OK) r = w.wait();  // the staging buffer is reused by the commitments below
+    } else {
+      r = tcfg[t].air_id == air::KECCAK_F
+              ? launch_keccak_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
+              : launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, I[10] ^ splitmix64(t + 1), w.stream);
+    }
     if (r) return r;
     if ((r = commit(w, d_trace[t], tcfg[t].n_cols, tcfg[t].log_n, tcfg[t].rate_bits, tcfg[t].cap_height, false, &trace[t]))) return r;
     ch.observe(trace[t].cap.data(), trace[t].cap.size());
@@ -565,6 +586,16 @@ int bp_generate_txn_proof_u8(const bp_state* s, const uint8_t* ir, size_t ir_len
   return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len);
 }
 BPG_ABI_CATCH("bp_generate_txn_proof_u8")
+// generate_txn_proof where the transaction's Keccak table attests GIVEN hashing work: keccak_inputs = the states that
+// go into its Keccak-f permutations (n_perms x 25 lanes, e.g. from bp_keccak256_permutation_inputs over the signed
+// transaction and the contract code of its GenerationInputs).  abort_flag as in bp_generate_txn_proof_u8.
+int bp_generate_txn_proof_keccak(const bp_state* s, const uint8_t* ir, size_t ir_len, const uint64_t* keccak_inputs,
+                                 size_t n_perms, const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len) try {
+  if (!keccak_inputs && n_perms) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof_keccak: null inputs");
+  static const uint64_t none = 0;
+  return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len, keccak_inputs ? keccak_inputs : &none, n_perms);
+}
+BPG_ABI_CATCH("bp_generate_txn_proof_keccak")
 
 int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
                           const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len) try {

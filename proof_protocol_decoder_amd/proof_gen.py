@@ -61,6 +61,10 @@ def _bind():
     L.bp_ir_encode_dummy.argtypes = [C.c_uint64] * 3 + [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32),
                                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.bp_ir_set_keccak_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.bp_keccak256_permutation_inputs.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t,
+                                                  C.POINTER(C.c_size_t)]
+    L.bp_generate_txn_proof_keccak.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t,
+                                               C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.bp_proof_public_values.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L._pg_bound = True
     return L
@@ -113,6 +117,8 @@ class TxnProofGenIR:
     table_width: tuple
     dummy: bool = False   # a padding entry (decoding.rs:484-520): proven, but txn number / gas / state root stay
     keccak_air: bool = False   # the Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1, 2430 columns)
+    keccak_inputs: tuple = None   # ... attesting THESE permutations ([n][25] lanes) instead of seeded ones; not part of
+                                  # the 25-word IR: handed to bp_generate_txn_proof_keccak beside it
 
     def to_bytes(self):
         L = _bind()
@@ -238,14 +244,35 @@ def _out():
     return C.POINTER(C.c_uint8)(), C.c_size_t()
 
 
-def generate_txn_proof(p_state, gen_inputs, abort_signal=None):
+def keccak256_permutation_inputs(data: bytes):
+    """bp_keccak256_permutation_inputs: -> (digest, [n_perms][25] lanes): the states that go into the Keccak-f
+    permutations of Keccak-256(data) -- what a Keccak table attesting this hash contains."""
+    L = _bind()
+    n = C.c_size_t()
+    check(L.bp_keccak256_permutation_inputs(data, len(data), None, None, 0, C.byref(n)))
+    states, digest = (C.c_uint64 * (25 * n.value))(), C.create_string_buffer(32)
+    check(L.bp_keccak256_permutation_inputs(data, len(data), digest, states, n.value, C.byref(n)))
+    return digest.raw, [list(states[25 * i:25 * i + 25]) for i in range(n.value)]
+
+
+def generate_txn_proof(p_state, gen_inputs, abort_signal=None, keccak_inputs=None):
     """proof_gen.rs:39-56.  abort_signal: optional shared flag (the reference's Option<Arc<AtomicBool>>): a
-    ctypes.c_uint8 / c_bool (one byte, what AtomicBool is: bp_generate_txn_proof_u8) or a ctypes.c_int32."""
+    ctypes.c_uint8 / c_bool (one byte, what AtomicBool is: bp_generate_txn_proof_u8) or a ctypes.c_int32.
+    keccak_inputs: the permutation inputs ([n][25] lanes) of the transaction's Keccak table, for an IR with
+    keccak_air=True (bp_generate_txn_proof_keccak); default: gen_inputs.keccak_inputs if it has any."""
     L = _bind()
     ir = gen_inputs.to_bytes() if isinstance(gen_inputs, TxnProofGenIR) else bytes(gen_inputs)
     out, n = _out()
     flag = C.byref(abort_signal) if abort_signal is not None else None
-    if abort_signal is not None and C.sizeof(abort_signal) == 1:
+    if keccak_inputs is None:
+        keccak_inputs = getattr(gen_inputs, "keccak_inputs", None)
+    if keccak_inputs is not None:
+        flat = [int(x) for st in keccak_inputs for x in st]
+        arr = (C.c_uint64 * max(len(flat), 1))(*flat)
+        if abort_signal is not None and C.sizeof(abort_signal) != 1:
+            raise ValueError("bp_generate_txn_proof_keccak takes the one-byte abort flag")
+        check(L.bp_generate_txn_proof_keccak(p_state._h, ir, len(ir), arr, len(flat) // 25, flag, C.byref(out), C.byref(n)))
+    elif abort_signal is not None and C.sizeof(abort_signal) == 1:
         L.bp_generate_txn_proof_u8.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p,
                                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         check(L.bp_generate_txn_proof_u8(p_state._h, ir, len(ir), flag, C.byref(out), C.byref(n)))

@@ -480,3 +480,32 @@ def test_golden_witnesses_as_pre_images_of_an_empty_block(i):
         assert ir.trie_roots_after.transactions_root == pt.EMPTY_TRIE_HASH and ir.contract_code == {}
         assert {h for h, _ in ir.tries.storage_tries} == set(full.storage)
         assert all(t.hash() == full.storage[h].hash() for h, t in ir.tries.storage_tries)
+
+
+def test_keccak_work_of_a_decoded_transaction():
+    """block_driver.keccak_inputs_of_generation_inputs: the permutation inputs of Keccak-256(signed_txn) and of every
+    contract code, checked by running the sponge again in Python on top of the oracle's permutation (host only)."""
+    import numpy as np
+    from oracle import pyoracle
+    from proof_protocol_decoder_amd import compact
+    from proof_protocol_decoder_amd.block_driver import irs_from_generation_inputs, keccak_inputs_of_generation_inputs
+    pyoracle.build()
+    m = fresh_model()
+    infos = [t for t, _ in block(m)]
+    other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", []), b"\x22" * 32)
+    gis = decoding.into_txn_proof_gen_ir(make_trace(m, infos), other)
+    seen_code = False
+    for g in gis:
+        states = keccak_inputs_of_generation_inputs(g)
+        msgs = ([bytes(g.signed_txn)] if g.signed_txn else []) + [bytes(g.contract_code[h]) for h in sorted(g.contract_code)]
+        seen_code |= bool(g.contract_code)
+        assert len(states) == sum(len(x) // 136 + 1 for x in msgs)
+        k = 0
+        for msg in msgs:
+            n = len(msg) // 136 + 1
+            out = pyoracle.keccak_f(np.array(states[k + n - 1], dtype=np.uint64))     # the last permutation's output
+            assert out[:4].astype("<u8").tobytes() == compact.keccak256(msg)
+            k += n
+    irs = irs_from_generation_inputs(gis, 17, (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8), keccak_air=True)
+    assert all(ir.keccak_air and ir.table_width[3] == 2430 and ir.table_log_n[3] >= 7 for ir in irs)
+    assert all(24 * len(ir.keccak_inputs) <= (1 << ir.table_log_n[3]) for ir in irs)

@@ -67,13 +67,18 @@ def product_verify(bpg, pc, proof):
     return bpg.lib().bp_stark_verify_air(1, C.byref(pc), None, raw, len(raw))
 
 
-@pytest.mark.parametrize("log_n,nq,pb", [(5, 6, 6), (8, 20, 10), (11, 84, 16), (14, 84, 16)])
-def test_table_proof_bit_exact(bpg, oracle, log_n, nq, pb):
+@pytest.mark.parametrize("log_n,nq,pb,loaded", [(5, 6, 6, 0), (8, 20, 10, 1), (11, 84, 16, 0), (11, 84, 16, 1), (14, 84, 16, 0)])
+def test_table_proof_bit_exact(bpg, oracle, log_n, nq, pb, loaded):
     """prove -> verify, bit-flip rejection, HIP bytes == oracle bytes.  2^14 rows is the S1 Keccak table height
-    (constants.rs:12: the range starts at 14)."""
+    (constants.rs:12: the range starts at 14).  loaded: K5 in ONE pass (all six units and the CTL part by one
+    workgroup row), as the library runs it while several provers share the device."""
     cfg, want, ctl, chv = oracle_proof(oracle, log_n, nq, pb, SEED)
     pc = bpg.ops.stark_cfg(log_n, 2430, num_queries=nq, pow_bits=pb)
-    got = bpg.ops.stark_prove_air(1, pc, SEED)
+    bpg.lib().bp_tune_assume_loaded(loaded)
+    try:
+        got = bpg.ops.stark_prove_air(1, pc, SEED)
+    finally:
+        bpg.lib().bp_tune_assume_loaded(-1)
     assert got.shape == want.shape and int(got[14]) == 1
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, "first mismatch at word %d of %d" % (bad[0], want.size)

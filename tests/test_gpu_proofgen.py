@@ -214,6 +214,58 @@ def test_decoded_block_trace_to_block_proof(bpg, pg, p_state):
     assert pv.gas_used_after == 161000 and tuple(pv.state_root_before) == irs[0].state_root_before
 
 
+def test_decoded_transactions_prove_their_own_keccak_work(bpg, pg, p_state, o_state):
+    """GenerationInputs -> the prover, with data instead of a seed for one table: every decoded entry's Keccak table is
+    a Keccak-f[1600] trace (AIR 1) of the entry's OWN hashing work -- Keccak-256 of its signed_txn and of its contract
+    code (decoding.rs:131-145) -- through bp_generate_txn_proof_keccak.  The witness really is that work (the last
+    permutation of the signed transaction ends in its hash), the proofs equal the oracle's byte for byte, the block
+    proof verifies."""
+    import test_decoding as td
+    from proof_protocol_decoder_amd import compact, decoding
+    from proof_protocol_decoder_amd.block_driver import (BlockDriver, irs_from_generation_inputs,
+                                                         keccak_inputs_of_generation_inputs)
+    m = td.fresh_model()
+    infos = [t for t, _ in td.block(m)]
+    other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", [(td.B, 100)]), b"\x22" * 32)
+    gis = decoding.into_txn_proof_gen_ir(td.make_trace(m, infos, hash_out_storage_of=(td.E,)), other)
+    irs = irs_from_generation_inputs(gis, 22, LOG_N, WIDTH, keccak_air=True)
+    real = [(g, ir) for g, ir in zip(gis, irs) if g.signed_txn]
+    assert real and all(ir.keccak_air and ir.table_width[3] == 2430 for ir in irs)
+    g, ir = real[0]
+    states = keccak_inputs_of_generation_inputs(g)
+    assert [list(x) for x in ir.keccak_inputs] == states and len(states) >= 1
+    # the witness is the hashing work: row 24 k + 23 of the trace holds the output of permutation k
+    n_txn_perms = len(g.signed_txn) // 136 + 1
+    log_n = ir.table_log_n[3]
+    inp = np.zeros((((1 << log_n) + 23) // 24, 25), dtype=np.uint64)
+    inp[:len(states)] = np.array(states, dtype=np.uint64)
+    import torch
+    tr = bpg.ops.keccak_trace(log_n, inputs=torch.from_numpy(inp.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
+    r = 24 * (n_txn_perms - 1) + 23
+    out = [int(tr[2428, r]) | (int(tr[2429, r]) << 32)] + [int(tr[2314 + 2 * l, r]) | (int(tr[2315 + 2 * l, r]) << 32) for l in (1, 2, 3)]
+    assert b"".join(x.to_bytes(8, "little") for x in out) == compact.keccak256(bytes(g.signed_txn))
+    # byte parity with the oracle, entry by entry
+    for _, e in zip(gis, irs):
+        got = pg.generate_txn_proof(p_state, e)
+        want = o_state.txn(list(struct.unpack("<25Q", e.to_bytes())), keccak_inputs=np.array(e.keccak_inputs, dtype=np.uint64).reshape(-1, 25))
+        assert (words(got.intern) == want).all()
+    assert pg.generate_txn_proof(p_state, irs[0], keccak_inputs=()).intern != pg.generate_txn_proof(p_state, irs[0]).intern \
+        or not irs[0].keccak_inputs                      # other permutations, another proof
+    drv = BlockDriver(p_state, n_threads=2)
+    try:
+        blk = drv.prove_block_distributed(irs)
+    finally:
+        drv.close()
+    pg.VerifierState.from_prover_state(p_state).verify(blk)
+    assert o_state.verify(words(blk.intern)) == 0
+    # inputs without the flag, or more permutations than the table has rows for, are refused
+    plain = pg.TxnProofGenIR(22, 0, 0, 1, (1, 2, 3, 4), 9, tuple(LOG_N), tuple(WIDTH))
+    with pytest.raises(pg.ProofGenError, match="Keccak-f AIR"):
+        pg.generate_txn_proof(p_state, plain, keccak_inputs=states)
+    with pytest.raises(pg.ProofGenError, match="do not fit"):
+        pg.generate_txn_proof(p_state, irs[0], keccak_inputs=[[0] * 25] * 200)
+
+
 def test_dummy_entries_and_short_blocks(bpg, pg, p_state, o_state):
     """Padding entries (decoding.rs:304-347, 484-520): the dummy IR is proven byte-for-byte like the oracle's, and
     blocks of 0 and 1 transactions -- padded the way the reference pads them -- yield verifying block proofs."""

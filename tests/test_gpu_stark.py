@@ -35,13 +35,20 @@ def oracle_proof(oracle, cfg_tuple, seed, const_seed):
     return cfg, proof, ctl, chv, (cc.cap() if K else None)
 
 
+@pytest.mark.parametrize("loaded", [0, 1], ids=["alone", "loaded"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "logn%d_C%d_K%d_e%d" % c[:4])
-def test_table_proof_bit_exact(bpg, oracle, case):
+def test_table_proof_bit_exact(bpg, oracle, case, loaded):
+    """loaded: the forms the library takes while several provers share the device (four-set Poseidon from 2^13 items,
+    K5 and the FRI combination in one pass without partial sums) -- the same bytes."""
     log_n, C, K, e, r, nq, pb = case
     seed, const_seed = 0x5EED000000000000 + log_n, 77
     cfg, want, ctl, chv, const_cap = oracle_proof(oracle, case, seed, const_seed)
-    got = bpg.ops.stark_prove_synthetic(
-        bpg.ops.stark_cfg(log_n, C, n_const=K, deg_pow=e, rate_bits=r, num_queries=nq, pow_bits=pb), seed, const_seed)
+    bpg.lib().bp_tune_assume_loaded(loaded)
+    try:
+        got = bpg.ops.stark_prove_synthetic(
+            bpg.ops.stark_cfg(log_n, C, n_const=K, deg_pow=e, rate_bits=r, num_queries=nq, pow_bits=pb), seed, const_seed)
+    finally:
+        bpg.lib().bp_tune_assume_loaded(-1)
     assert got.shape == want.shape
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, "first mismatch at word %d of %d" % (bad[0], want.size)
