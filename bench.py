@@ -5,21 +5,23 @@ per GPU.
 A step = one whole 256-txn block: every rank proves its contiguous slice of the block's txns and
 its local aggregation subtree; the N sub-block proofs are gathered to rank 0 over RCCL, which
 finishes the tree and makes the block proof (strong scaling: the block is fixed, the slice shrinks
-with N).  value = 256 * steps / wall time, inputs (the IRs) resident before the clock starts; the
+with N).  value = txns * steps / wall time, inputs (the IRs) resident before the clock starts; the
 witness of each txn is generated on the GPU inside generate_txn_proof, as generate_traces runs
-inside the reference's call (proof_gen.rs:44-52).
+inside the reference's call (proof_gen.rs:44-52).  `python3 bench.py --gpus N` without a launcher
+starts its own N ranks (torch.distributed.run) before it touches the GPU.
 
-Extra objects on the JSON line:
+The timed region runs first.  Everything that is measured ALONE on the chip runs afterwards in a
+fresh child process (`--leg-only`) and is merged into the one JSON line:
   roofline      -- the coset-LDE NTT kernel family (the HBM-roofline kernel the metric names): HIP events on the
-                   kernel's own stream over a single-stream leg run before the block (2 txn proofs, nothing else on
-                   the chip); traffic = algorithmic bytes x the PMC-measured ratio of a tracked profiles/ summary;
-  roofline_in_situ  -- (only with --in-situ-profile: the event records cost 2.4 % of the rate) the same launches inside
-                       the timed region (24 streams share the chip: not the kernel's cost);
+                   kernel's own stream over a single-stream leg (2 txn proofs, nothing else on the chip); traffic =
+                   algorithmic bytes x the PMC-measured ratio of a tracked profiles/ summary;
   roofline_isolated -- the same kernel alone on the chip at the widest table shape;
   ntt_hbm_gbps  -- BASELINE's second figure: the batched inverse NTT alone at four shapes;
-  alu_kernel    -- Merkle leaf hashing (Poseidon; the time-dominant kernels, VALU-issue-bound) over the same leg, against
-                   the rate the same kernels reach with the chip full, measured in this run (poseidon_peak), and what
-                   that rate asks of the int8 matrix cores;
+  alu_kernel    -- Merkle leaf hashing (Poseidon; the time-dominant kernels, VALU-issue-bound) over the same leg, as
+                   a fraction of the hardware's VALU issue ceiling (SIMDs x clock / 4; instructions per permutation
+                   from a tracked SQ-counter summary), next to the same kernels with the chip full, measured live;
+  roofline_in_situ  -- (only with --in-situ-profile: the event records cost 2.4 % of the rate) the LDE launches inside
+                       the timed region (20 streams share the chip: not the kernel's cost);
   cpu_baseline  -- the oracle (CPU restatement, OpenMP) proving ONE txn of the same block on a warm state.
 """
 import argparse

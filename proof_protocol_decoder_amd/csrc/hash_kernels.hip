@@ -505,7 +505,7 @@ int mx_sets(uint64_t n) {
 static std::atomic<int> g_poseidon_grouped{1};
 static std::mutex g_group_mu;
 static const uint32_t* g_group_dev[16] = {};
-static int g_group_state[16] = {};  // 0 not tried, 1 ready, -1 failed
+static std::atomic<int> g_group_state[16];  // 0 not tried, 1 ready, -1 failed
 static std::vector<uint32_t>* g_group_image = nullptr;
 
 static bool build_group_image() {
@@ -540,17 +540,18 @@ const uint32_t* group_tables() {
   if (!g_poseidon_grouped.load(std::memory_order_relaxed)) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (g_group_state[dev] > 0) return g_group_dev[dev];  // set last, after the pointer (mutex release below)
+  if (g_group_state[dev].load(std::memory_order_acquire) > 0) return g_group_dev[dev];  // the state is set after the pointer
   std::lock_guard<std::mutex> lk(g_group_mu);
-  if (g_group_state[dev] != 0) return g_group_state[dev] > 0 ? g_group_dev[dev] : nullptr;
+  if (const int st = g_group_state[dev].load(std::memory_order_acquire)) return st > 0 ? g_group_dev[dev] : nullptr;
   void* d = nullptr;
   if (!build_group_image() || hipMalloc(&d, poseidon::mx::grp::TABLE_WORDS * 4) != hipSuccess ||
       hipMemcpy(d, g_group_image->data(), poseidon::mx::grp::TABLE_WORDS * 4, hipMemcpyHostToDevice) != hipSuccess) {
-    g_group_state[dev] = -1;
+    if (d) (void)hipFree(d);
+    g_group_state[dev].store(-1, std::memory_order_release);
     return nullptr;
   }
   g_group_dev[dev] = static_cast<const uint32_t*>(d);
-  __atomic_store_n(&g_group_state[dev], 1, __ATOMIC_RELEASE);
+  g_group_state[dev].store(1, std::memory_order_release);
   return g_group_dev[dev];
 }
 

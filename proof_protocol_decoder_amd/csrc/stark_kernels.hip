@@ -686,6 +686,7 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
 // Smallest witness w >= base with leading pow_bits zero in state[7] after the duplex
 // (fri_proof_of_work; upstream takes any winner, we take the minimum so results are reproducible).
 __global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned long long* result) {
+  if (__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.base) return;  // see pow_grind_mx_kernel
   const uint64_t cand = a.base + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t s[12];
 #pragma unroll
@@ -701,6 +702,10 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned
 template <bool GR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 pow_grind_mx_kernel(bpg::PowArgs a, unsigned long long* result, const uint32_t* __restrict__ gtab) {
+  // A witness below this batch is already known (an earlier batch of the same speculative group found it: batches
+  // run one after the other on the stream, so the value is stable and the same for every thread): nothing here can
+  // be smaller, the whole grid leaves before it loads a table.
+  if (__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.base) return;
   __shared__ __attribute__((aligned(16))) uint32_t cin[GR ? poseidon::mx::CIN_GROUPED_WORDS : poseidon::mx::CIN_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t gt[GR ? poseidon::mx::grp::TABLE_WORDS : 4];
   if constexpr (GR) {
