@@ -81,6 +81,7 @@ def main():
                          "to them (ends of shards, small blocks)")
     ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
     ap.add_argument("--merkle-fused", type=int, default=None, help="0: one launch per Merkle level")
+    ap.add_argument("--merkle-wide", type=int, default=None, help="bp_tune_merkle_wide (measurement knob)")
     ap.add_argument("--ntt-split", type=int, default=None, help="bp_tune_ntt_split mode (measurement knob)")
     ap.add_argument("--ntt-mx", type=int, default=None, help="bp_tune_ntt_mx mode (measurement knob)")
     ap.add_argument("--poseidon-mx", type=int, default=None, help="bp_tune_poseidon_mx (measurement knob)")
@@ -159,6 +160,8 @@ def main():
         L.bp_tune_merkle_fused(args.merkle_fused)
     if args.quad_threshold_log2 is not None:
         L.bp_tune_quad_threshold(1 << args.quad_threshold_log2)
+    if args.merkle_wide is not None:
+        L.bp_tune_merkle_wide(args.merkle_wide)
     if args.ntt_split is not None:
         L.bp_tune_ntt_split(args.ntt_split)
     if args.ntt_mx is not None:

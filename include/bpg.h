@@ -116,6 +116,10 @@ void bp_tune_quad_threshold(uint64_t n_perms);
  * proof's critical path); 0 = one launch per level; -1 = fused only while fewer than 6 provers are at work on the
  * device.  Results are identical. */
 void bp_tune_merkle_fused(int mode);
+/* With the fused tail on: levels of up to 2^k parents (k = 8..24; 0 = none) also go nine at a time through
+ * merkle_subtree_wide_kernel (256 parents per workgroup, four-set waves while a level has 64 or more of them).
+ * Results are identical. */
+void bp_tune_merkle_wide(int log2_parents);
 /* 1 (default): hashing launches at or above the quad threshold use the matrix-core form of the permutation
  * (csrc/poseidon_mx.cuh: the MDS layer as int8 MFMAs on the byte planes of the state); 0: one lane per state.
  * Results are identical either way. */

@@ -374,6 +374,79 @@ merkle_subtree_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restric
   }
 }
 
+// The same hand-down for the levels ABOVE that: a workgroup takes 256 parents of its first level and reduces them nine
+// levels (256 -> 1, or until the cap).  While a level has 64 or more parents in the workgroup its waves carry four
+// sets of 16 states each (the throughput form: 256 / 128 / 64 parents = 4 / 2 / 1 waves at work), below that one set
+// per wave as in merkle_subtree_mx_kernel.  A 2^16-leaf tree is then three launches -- the widest level by itself,
+// this kernel from 2^14 nodes, the cap's last levels -- instead of six.
+__global__ void __launch_bounds__(256)
+merkle_subtree_wide_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ out, uint64_t n_parents,
+                           uint32_t levels, uint64_t* __restrict__ mirror) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+  __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
+  __shared__ uint64_t sm[2][256 * 4];
+  poseidon::mx::build_cin(cin);
+  __syncthreads();
+  const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
+  const uint32_t wave = threadIdx.x >> 6, n = threadIdx.x & 15;
+  uint64_t level_parents = n_parents;
+  uint32_t wg_parents = n_parents < 256 ? (uint32_t)n_parents : 256u;
+  uint64_t wg_first = (uint64_t)blockIdx.x * 256;
+  uint64_t* dst = out;
+  for (uint32_t l = 0; l < levels; l++) {
+    const uint64_t* prev = sm[(l - 1) & 1];
+    if (wg_parents >= 64) {
+      if (wave * 64 < wg_parents) {  // whole waves only
+        uint64_t e[4][3];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const uint32_t q = wave * 64 + 16 * m + n;  // < wg_parents: it is a multiple of 64 here
+          if (l == 0) {
+            e[m][0] = child[(wg_first + q) * 8 + c.kb];
+            e[m][1] = child[(wg_first + q) * 8 + 4 + c.kb];
+          } else {
+            e[m][0] = prev[(2 * q) * 4 + c.kb];
+            e[m][1] = prev[(2 * q + 1) * 4 + c.kb];
+          }
+          e[m][2] = 0;
+        }
+        poseidon::mx::permute<4>(e, c);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const uint32_t q = wave * 64 + 16 * m + n;
+          const uint64_t d = gl::canon(e[m][0]);
+          dst[(wg_first + q) * 4 + c.kb] = d;
+          if (mirror && l + 1 == levels) mirror[(wg_first + q) * 4 + c.kb] = d;
+          sm[l & 1][q * 4 + c.kb] = d;
+        }
+      }
+    } else if (wave * 16 < wg_parents) {
+      const uint32_t q = wave * 16 + n, qc = q < wg_parents ? q : wg_parents - 1;
+      uint64_t e[1][3];
+      if (l == 0) {
+        e[0][0] = child[(wg_first + qc) * 8 + c.kb];
+        e[0][1] = child[(wg_first + qc) * 8 + 4 + c.kb];
+      } else {
+        e[0][0] = prev[(2 * qc) * 4 + c.kb];
+        e[0][1] = prev[(2 * qc + 1) * 4 + c.kb];
+      }
+      e[0][2] = 0;
+      poseidon::mx::permute<1>(e, c);
+      if (q < wg_parents) {
+        const uint64_t d = gl::canon(e[0][0]);
+        dst[(wg_first + q) * 4 + c.kb] = d;
+        if (mirror && l + 1 == levels) mirror[(wg_first + q) * 4 + c.kb] = d;
+        sm[l & 1][q * 4 + c.kb] = d;
+      }
+    }
+    __syncthreads();
+    dst += level_parents * 4;
+    level_parents >>= 1;
+    wg_parents >>= 1;
+    wg_first >>= 1;
+  }
+}
+
 // 8-byte-per-lane streaming copy: calibrates the rocprofv3 FETCH_SIZE / WRITE_SIZE counters for the
 // access width every field kernel here uses (MI355X_MICROARCH.md, HBM section).
 __global__ void __launch_bounds__(256)
@@ -485,6 +558,7 @@ uint64_t quad_threshold() {
 // off -- the fused form lost 0-4 %: ~12 us per level cost what the launch gaps saved.)
 // 1 = fused (default), 0 = one launch per level, -1 = fused only while fewer than six provers are at work.
 static std::atomic<int> g_merkle_fused{1};
+static std::atomic<int> g_merkle_wide_log2{0};  // levels of up to 2^k parents go to merkle_subtree_wide_kernel (0: none)
 // launches at or above the quad threshold: 1 = matrix-core form (poseidon_mx.cuh), 0 = one lane per state
 static std::atomic<int> g_poseidon_mx{1};
 bool poseidon_mx() { return g_poseidon_mx.load(std::memory_order_relaxed) != 0; }
@@ -584,6 +658,21 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     // levels are throughput work for the four-set kernels); modes 8..20 of the knob = fuse from 2^mode nodes down
     const uint64_t flimit = fmode >= 8 ? (uint64_t)1 << fmode : 2048;
     const bool fused = parents <= flimit && (parents < quad_threshold() || fmode >= 8) && (fmode > 0 || (fmode < 0 && !device_loaded()));
+    // the levels above the one-set fused tail, 256 parents per workgroup, nine levels per launch (knob: wide limit)
+    const uint64_t wlimit = (uint64_t)1 << g_merkle_wide_log2.load(std::memory_order_relaxed);
+    if (!fused && fmode > 0 && poseidon_mx() && parents >= 256 && parents <= wlimit && parents % 256 == 0) {
+      uint32_t levels = l - cap_height;
+      if (levels > 9) levels = 9;
+      uint64_t* mir = (l - levels == cap_height) ? mirror : nullptr;
+      merkle_subtree_wide_kernel<<<(uint32_t)(parents / 256), 256, 0, st>>>(lvl, nxt, parents, levels, mir);
+      BPG_LAUNCH_CHECK();
+      if (mir && mirrored) *mirrored = true;
+      for (uint32_t k = 0; k < levels; k++) {
+        lvl += ((uint64_t)1 << l) * 4;
+        l--;
+      }
+      continue;
+    }
     if (!fused) {
       uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;
       if (const int ns = mx_sets(parents)) {
@@ -661,6 +750,7 @@ int bp_debug_poseidon_mx_cin(uint32_t* out) {
 /* The load-dependent choices (kernel forms, one-pass K5 / FRI combination): -1 (default) = by the number of
  * bp_generate_*_proof calls at work on the device (six or more = loaded); 0 / 1 = stated by a caller that drives the
  * L0 / L0.5 entry points from its own threads, or by a test that pins both paths. */
+void bp_tune_merkle_wide(int log2_parents) { bpg::g_merkle_wide_log2.store(log2_parents < 8 || log2_parents > 24 ? 0 : log2_parents); }
 void bp_tune_assume_loaded(int mode) { bpg::g_assume_loaded.store(mode < 0 ? -1 : (mode != 0)); }
 void bp_tune_poseidon_grouped(int on) { bpg::g_poseidon_grouped.store(on != 0); }
 

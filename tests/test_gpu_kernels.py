@@ -185,7 +185,8 @@ def test_poseidon_byte_plane_extremes(bpg, oracle, perm_form):
         assert (got == oracle.poseidon(s % np.uint64(P))).all(), n
 
 
-@pytest.mark.parametrize("quad", ["quad", "lane", "mx4", "mx2", "mx1", "mx", "mx+fused", "quad+fused", "mx4-ungrouped"])
+@pytest.mark.parametrize("quad", ["quad", "lane", "mx4", "mx2", "mx1", "mx", "mx+fused", "mx+fused+wide", "quad+fused",
+                                  "mx4-ungrouped"])
 @pytest.mark.parametrize("log_n,rate_bits,n_cols,cap_h", [(3, 1, 3, 4), (4, 1, 4, 0), (6, 1, 8, 4), (7, 3, 19, 4),
                                                           (10, 1, 135, 4), (12, 1, 33, 2), (9, 3, 2, 4), (5, 1, 9, 1),
                                                           (6, 1, 13, 3)])
@@ -197,9 +198,10 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     bpg.lib().bp_tune_quad_threshold((1 << 40) if quad.startswith("quad") else 1)  # 1: never quad; 0 would be automatic
     bpg.lib().bp_tune_poseidon_mx(1 if quad.startswith("mx") else 0)
     bpg.lib().bp_tune_poseidon_mx_sets(int(quad[2:3]) if quad[:3] in ("mx4", "mx2", "mx1") else 0)  # "mx": sets by launch size
-    bpg.lib().bp_tune_merkle_fused(1 if quad.endswith("+fused") else 0)
+    bpg.lib().bp_tune_merkle_fused(1 if "+fused" in quad else 0)
+    bpg.lib().bp_tune_merkle_wide(14 if quad.endswith("+wide") else 0)   # nine levels per launch from 256 parents up
     bpg.lib().bp_tune_poseidon_grouped(0 if quad.endswith("-ungrouped") else 1)
-    if quad in ("mx", "mx+fused"):
+    if quad in ("mx", "mx+fused", "mx+fused+wide"):
         bpg.lib().bp_tune_quad_threshold(1 << (log_n + rate_bits))  # leaves with 4 sets, then 2, then 1 up the tree
     rng = np.random.default_rng(300 + log_n)
     rows = 1 << (log_n + rate_bits)
@@ -212,6 +214,7 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     bpg.lib().bp_tune_poseidon_mx(1)
     bpg.lib().bp_tune_poseidon_mx_sets(0)
     bpg.lib().bp_tune_merkle_fused(0)
+    bpg.lib().bp_tune_merkle_wide(0)
     bpg.lib().bp_tune_poseidon_grouped(1)
     assert (dig == want_dig).all()
     assert (dig[-(1 << cap_h):] == want_cap).all()
