@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--keccak-air", action="store_true",
                     help="every transaction's Keccak table is a real Keccak-f[1600] trace (AIR 1, 2430 columns) instead "
                          "of the 2432-column synthetic table BASELINE's metric is quoted on")
-    ap.add_argument("--poseidon-grouped", type=int, default=None, help="bp_tune_poseidon_grouped (measurement knob)")
+    ap.add_argument("--poseidon-grouped", type=int, default=None, help="bp_tune_poseidon_grouped: 0 / 2 / 3 groups of partial rounds (measurement knob)")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
                     help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
     ap.add_argument("--leg-only", action="store_true",
@@ -311,6 +311,9 @@ def main():
     if rank == 0:
         # acceptance: the block proof verifies (VerifierState::verify, verifier_state.rs:56-71)
         pg.VerifierState.from_prover_state(state).verify(last)
+    L.bp_host_wait_mode.restype = C.c_int
+    host_waits = {1: "sleep (hipDeviceScheduleBlockingSync)", 2: "device already in use: mode left alone"}.get(
+        L.bp_host_wait_mode(local_rank), "undecided")
     t_build_info = {"state_build_s": round(t_build, 2), "state_device_gib": round(state.device_bytes / 2**30, 2)}
     driver.close()
     state.close()
@@ -332,7 +335,7 @@ def main():
                    "keccak_table": "Keccak-f[1600] AIR, 2430 columns" if args.keccak_air else "synthetic AIR, 2432 columns",
                    "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
                    "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
-                   "ms_of_each_step_rank0": step_ms, **t_build_info},
+                   "ms_of_each_step_rank0": step_ms, "host_waits": host_waits, **t_build_info},
     }
     alone = {}
     if not args.no_profile:
@@ -391,7 +394,7 @@ def valu_insts_per_perm():
     import re
     try:
         txt = open(os.path.join(ROOT, SQ_FILE)).read()
-        blk = txt[txt.index("leaf_hash_mx_kernel<4, grouped>"):]
+        blk = txt[txt.index("leaf_hash_mx_kernel<4, three groups>"):]
         insts = float(re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+)", blk).group(1))
         mfma = float(re.search(r"SQ_INSTS_MFMA\s+([0-9.e+]+)", blk).group(1))
         m = re.search(r"= ([0-9]+) permutations", txt)

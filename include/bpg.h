@@ -50,10 +50,15 @@ int bp_device_count(void);
  * spinning.  A prover stream per host thread needs this to use more streams than the host has cores.
  * The mode is decided ONCE per device, by whoever comes first -- this call, or the first worker the
  * library creates on the device (bp_state_build, bp_stark_prove_air) -- and is never changed
- * afterwards: later calls return BP_OK and do nothing (switching the mode while one of the library's
- * streams is alive makes a later hipFree hang).  A process that creates the device context through
- * another library should call it first thing. */
+ * afterwards: later calls return BP_OK and do nothing.  The mode can only be switched on a device the
+ * PROCESS has not used yet (switching it under queues that already carried work makes a later hipFree or
+ * hipDeviceSynchronize hang on this ROCm): on a device that is already in use the call leaves the mode
+ * alone -- everything works, host waits spin.  A process that uses the device through another library
+ * (PyTorch, ...) should call this first thing. */
 int bp_use_blocking_sync(int device);
+/* What was decided for the device: 0 nothing yet, 1 host waits sleep, 2 the device was already in use (or
+ * configured otherwise) and keeps its mode. */
+int bp_host_wait_mode(int device);
 
 /* ------------------------------------------------------------------------------------------
  * L0 -- kernel-shaped operations on device buffers.
@@ -127,11 +132,12 @@ void bp_tune_poseidon_mx(int on);
 /* Sets of 16 states a wave of the matrix-core form carries: 4, 2 or 1 (fewer sets = more waves for the same launch);
  * 0 (default) = by launch size: 4 from the quad threshold up, 2 from half of it, else 1.  Results are identical. */
 void bp_tune_poseidon_mx_sets(int sets);
-/* 1 (default): the four-set matrix-core kernels take 16 of the 22 partial rounds in two groups of eight: within a
- * group only the next S-box input (an affine form of the untouched words and the earlier S-box outputs, evaluated by
- * int8 MFMAs on their bytes) is recombined per round, the twelve words once per group (csrc/poseidon_mx.cuh, grp;
- * tools/poseidon_group_model.py).  0: every round by itself.  Results are identical either way. */
-void bp_tune_poseidon_grouped(int on);
+/* The four-set matrix-core kernels take the partial rounds in groups: within a group only the next S-box input (an
+ * affine form of the untouched words and the earlier S-box outputs, evaluated by int8 MFMAs on their bytes) is
+ * recombined per round, the twelve words once per group (csrc/poseidon_mx.cuh, grp; tools/poseidon_group_model.py).
+ * 3 (default; any other non-zero value means 3): all 22 partial rounds, as 8 + 8 + 6; 2: rounds 4..19 as 8 + 8, rounds
+ * 20..25 one by one; 0: every round by itself.  Results are identical in every mode. */
+void bp_tune_poseidon_grouped(int mode);
 /* The load-dependent choices -- Poseidon sets per wave by launch size, K5 and the FRI alpha-combination in one pass
  * without partial sums -- follow the number of bp_generate_*_proof calls at work on the device (six or more =
  * loaded): -1 (default).  0 / 1: stated by a caller that drives the L0 / L0.5 entry points from its own threads (the

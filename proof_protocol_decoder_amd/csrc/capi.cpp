@@ -143,24 +143,46 @@ int bp_device_count(void) {
   return n;
 }
 
+// 0 undecided, 1 interrupt-driven host waits (hipDeviceScheduleBlockingSync), 2 left as the process had it
+static std::atomic<int> g_wait_mode[64];
+
 int bp_use_blocking_sync(int device) {
   // On this ROCm every host wait (hipStreamSynchronize, hipEventSynchronize -- even on an event made
   // with hipEventBlockingSync) spins at 100 % of a core unless the device was given
   // hipDeviceScheduleBlockingSync (tools/wait_probe.hip: 100 % -> 1 %).  With one prover thread per
   // stream the spinning threads fill the box's cores and more streams than cores lose throughput.
   // Decided once per device, by the first caller -- an explicit call (bench.py, before torch creates the context) or
-  // the first worker this library creates (Worker::init) -- and never changed afterwards: switching the mode while
-  // one of our streams is alive hangs a later hipFree (tools/hang_probe.py).
-  static std::atomic<int> decided[64];
+  // the first worker this library creates (Worker::init) -- and never changed afterwards.  The mode can only be
+  // switched while the process has not used the device yet: switching it under queues that already carried work
+  // (the application's null stream, a parked worker's stream) makes a later device-wide wait -- hipFree,
+  // hipDeviceSynchronize -- never return (tools/hang_probe.py; tests/test_gpu_proofgen.py).  A device the process
+  // has already used therefore keeps the mode it has: everything works, host waits spin.
   if (device < 0 || device >= 64) return bpg::fail(BP_ERR_DEVICE, "device %d out of range", device);
-  if (decided[device].exchange(1)) return BP_OK;
+  int expected = 0;
+  if (!g_wait_mode[device].compare_exchange_strong(expected, 2)) return BP_OK;
+  unsigned int flags = 0;
+  int active = 0;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wdeprecated-declarations"
+  // (deprecated as a CUDA driver-API equivalent; it is the one call that tells whether the process has used the device)
+  hipError_t e = hipDevicePrimaryCtxGetState(device, &flags, &active);
+#pragma clang diagnostic pop
+  if (e != hipSuccess) return bpg::fail(BP_ERR_DEVICE, "hipDevicePrimaryCtxGetState(%d): %s", device, hipGetErrorString(e));
+  if ((flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync) {
+    g_wait_mode[device].store(1);
+    return BP_OK;
+  }
+  if (active) return BP_OK;  // in use already: not ours to switch
   int prev = 0;
   (void)hipGetDevice(&prev);
-  hipError_t e = hipSetDevice(device);
+  e = hipSetDevice(device);
   if (e == hipSuccess) e = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
   (void)hipSetDevice(prev);
   if (e != hipSuccess) return bpg::fail(BP_ERR_DEVICE, "hipSetDeviceFlags(blocking sync) on device %d: %s", device, hipGetErrorString(e));
+  g_wait_mode[device].store(1);
   return BP_OK;
 }
+
+int bp_host_wait_mode(int device) { return device >= 0 && device < 64 ? g_wait_mode[device].load() : 0; }
 
 }  // extern "C"

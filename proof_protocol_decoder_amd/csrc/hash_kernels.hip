@@ -206,27 +206,30 @@ merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ p
 // instructions) the one for launches that cannot fill the chip.
 // At least three waves per SIMD (<= 168 VGPRs): with the grouped rounds' operands the four-set kernels otherwise take
 // 172..192 VGPRs, two waves per SIMD, and lose more to the exposed MFMA / LDS latency than the groups save.
-#define BPG_MX_OCC __attribute__((amdgpu_waves_per_eu(3)))
-// GR (NS = 4 only): the partial rounds 4..19 in two groups of eight; gtab = the device image of the operand tables
-// (poseidon_mx.cuh, grp), copied into LDS.  GR = false: every round by itself (NS = 1, 2; the knob; no tables).
+// Larger workgroups do not pay: four waves per SIMD (512 threads, 128 VGPRs, ~25 registers in scratch) hash 2.92
+// instead of 2.98 Gperm/s and gain nothing under load (profiles/r3_poseidon_occ4_ab.txt); six- and twelve-wave
+// workgroups (to share a 67 KB table image) lose a quarter of their resident waves (r3_poseidon_three_groups.txt).
+#define BPG_MX_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+// GR (NS = 4 only): 0 = every round by itself; 2 = the partial rounds 4..19 in two groups of eight; 3 = all 22 partial
+// rounds in groups (8 + 8 + 6).  gtab = the device image of the operand tables (poseidon_mx.cuh, grp), copied into LDS.
 #define BPG_MX_TABLES(NS, GR, gtab)                                                                           \
   static_assert(!(GR) || (NS) == 4, "groups exist for four sets per wave");                                   \
   __shared__ __attribute__((aligned(16)))                                                                     \
-      uint32_t cin[(GR) ? poseidon::mx::CIN_GROUPED_WORDS : poseidon::mx::CIN_WORDS];                         \
-  __shared__ __attribute__((aligned(16))) uint32_t gt[(GR) ? poseidon::mx::grp::TABLE_WORDS : 4];            \
-  if constexpr (GR) {                                                                                         \
-    poseidon::mx::build_cin_grouped(cin);                                                                     \
-    poseidon::mx::grp::load_tables(gt, gtab);                                                                 \
+      uint32_t cin[(GR) ? poseidon::mx::CIN_GROUPED_WORDS<(GR) ? (GR) : 2> : poseidon::mx::CIN_WORDS];        \
+  __shared__ __attribute__((aligned(16))) uint32_t gt[(GR) ? poseidon::mx::grp::TABLE_WORDS<(GR) ? (GR) : 2> : 4]; \
+  if constexpr ((GR) != 0) {                                                                                  \
+    poseidon::mx::build_cin_grouped<(GR) ? (GR) : 2>(cin);                                                    \
+    poseidon::mx::grp::load_tables<(GR) ? (GR) : 2>(gt, gtab);                                                \
   } else {                                                                                                    \
     poseidon::mx::build_cin(cin);                                                                             \
   }                                                                                                           \
   __syncthreads();
-#define BPG_MX_PERMUTE(NS, GR, e, c)                                      \
-  if constexpr (GR) poseidon::mx::permute_grouped(e, c, gt);              \
+#define BPG_MX_PERMUTE(NS, GR, e, c, gtab)                                                      \
+  if constexpr ((GR) != 0) poseidon::mx::permute_grouped<(GR) ? (GR) : 2>(e, c, gt, gtab);  \
   else poseidon::mx::permute<NS>(e, c);
 
-template <int NS, bool GR>
-__global__ void __launch_bounds__(256) BPG_MX_OCC perm_batch_mx_kernel(uint64_t* __restrict__ states, uint64_t n,
+template <int NS, int GR>
+__global__ void BPG_MX_BOUNDS perm_batch_mx_kernel(uint64_t* __restrict__ states, uint64_t n,
                                                             const uint32_t* __restrict__ gtab) {
   BPG_MX_TABLES(NS, GR, gtab)
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(256) BPG_MX_OCC perm_batch_mx_kernel(uint64_t*
 #pragma unroll
     for (int a = 0; a < 3; a++) e[m][a] = states[i * 12 + c.kb + 4 * a];
   }
-  BPG_MX_PERMUTE(NS, GR, e, c)
+  BPG_MX_PERMUTE(NS, GR, e, c, gtab)
 #pragma unroll
   for (int m = 0; m < NS; m++) {
     const uint64_t i = base + 16 * m;
@@ -249,8 +252,8 @@ __global__ void __launch_bounds__(256) BPG_MX_OCC perm_batch_mx_kernel(uint64_t*
   }
 }
 
-template <int NS, bool GR>
-__global__ void __launch_bounds__(256) BPG_MX_OCC
+template <int NS, int GR>
+__global__ void BPG_MX_BOUNDS
 leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
                     uint32_t rate_bits, uint64_t* __restrict__ digests, const uint32_t* __restrict__ gtab) {
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
@@ -284,7 +287,7 @@ leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t 
 #pragma unroll
         for (int m = 0; m < NS; m++) e[m][1] = p[m][(uint64_t)(col + 4 + kb) * stride];
       }
-      BPG_MX_PERMUTE(NS, GR, e, c)
+      BPG_MX_PERMUTE(NS, GR, e, c, gtab)
     }
   }
 #pragma unroll
@@ -298,8 +301,8 @@ leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t 
   }
 }
 
-template <int NS, bool GR>
-__global__ void __launch_bounds__(256) BPG_MX_OCC
+template <int NS, int GR>
+__global__ void BPG_MX_BOUNDS
 merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
                        uint64_t* __restrict__ mirror, const uint32_t* __restrict__ gtab) {
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
@@ -314,7 +317,7 @@ merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict_
     e[m][1] = child[i * 8 + 4 + c.kb];
     e[m][2] = 0;
   }
-  BPG_MX_PERMUTE(NS, GR, e, c)
+  BPG_MX_PERMUTE(NS, GR, e, c, gtab)
 #pragma unroll
   for (int m = 0; m < NS; m++) {
     const uint64_t i = base + 16 * m;
@@ -576,69 +579,99 @@ int mx_sets(uint64_t n) {
 }
 // ---- operand tables of the grouped partial rounds (poseidon_group.hpp): built once per process on the host,
 // uploaded once per device; the four-set kernels copy them into LDS.  nullptr = per-round form (knob, or no tables).
-static std::atomic<int> g_poseidon_grouped{1};
+static std::atomic<int> g_poseidon_grouped{3};  // 0, 2 or 3 groups (bp_tune_poseidon_grouped)
 static std::mutex g_group_mu;
-static const uint32_t* g_group_dev[16] = {};
-static std::atomic<int> g_group_state[16];  // 0 not tried, 1 ready, -1 failed
-static std::vector<uint32_t>* g_group_image = nullptr;
+static const uint32_t* g_group_dev[2][16] = {};
+static std::atomic<int> g_group_state[2][16];  // [n_groups - 2][device]: 0 not tried, 1 ready, -1 failed
+static std::vector<uint32_t>* g_group_image[2] = {nullptr, nullptr};
 
+template <int NG>
 static bool build_group_image() {
   namespace pg = poseidon::group;
   namespace gx = poseidon::mx::grp;
-  if (g_group_image) return true;
-  auto img = std::make_unique<std::vector<uint32_t>>(gx::TABLE_WORDS, 0);
-  for (int g = 0; g < gx::N_GROUPS; g++) {
+  if (g_group_image[NG - 2]) return true;
+  auto img = std::make_unique<std::vector<uint32_t>>(gx::IMAGE_WORDS<NG>, 0);
+  for (int g = 0; g < NG; g++) {
     pg::Tables t;
-    if (!pg::build(gx::K, 4 + gx::K * g, &t) || (int)t.ops.size() != gx::OPS_WORDS * 4) return false;
-    if (g == 0) std::memcpy(img->data(), t.ops.data(), t.ops.size());
-    else if (std::memcmp(img->data(), t.ops.data(), t.ops.size()) != 0) return false;  // the A operands do not depend on r0
     uint32_t* c = img->data() + gx::OPS_WORDS + g * gx::C_WORDS;
+    if (g < 2) {
+      if (!pg::build(gx::K, 4 + gx::K * g, &t) || (int)t.ops.size() != gx::LAY.n_ops * 1024) return false;
+      if (g == 0) std::memcpy(img->data(), t.ops.data(), t.ops.size());
+      else if (std::memcmp(img->data(), t.ops.data(), t.ops.size()) != 0) return false;  // the A operands do not depend on r0
+    } else {
+      // the short group (rounds 20..25): the form operands are the eight-round group's -- a six-round group's are
+      // the same rows with forms 6 and 7 blank, checked here --, its MAIN operands and C tables are its own
+      constexpr pg::Layout L6 = pg::layout(gx::SHORT_K);
+      if (!pg::build(gx::SHORT_K, 20, &t) || (int)t.ops.size() != L6.n_ops * 1024) return false;
+      const uint8_t* o8 = reinterpret_cast<const uint8_t*>(img->data());
+      // operand (pair 0: identical; pair 1: W and the delta of sigma_4) of the short layout -> of the long one
+      for (int i = 0; i < L6.main_base; i++) {
+        const int j = i < L6.d_base[1] ? i : gx::LAY.d_base[1] + (i - L6.d_base[1]);
+        for (int b = 0; b < 1024; b++) {
+          const uint8_t v6 = t.ops[(size_t)i * 1024 + b], v8 = o8[(size_t)j * 1024 + b];
+          const int row = (b >> 4) & 15;  // lane = b >> 4, row = lane & 15: rows 8..15 of pair 1 are forms 6 and 7
+          const bool blank = i >= L6.w_base[1] && row >= 8;
+          if (blank ? v6 != 0 : v6 != v8) return false;
+        }
+      }
+      std::memcpy(img->data() + gx::TABLE_WORDS<NG>, t.ops.data() + (size_t)L6.main_base * 1024, 18 * 1024);
+    }
     std::memcpy(c, t.cform.data(), pg::CFORM_WORDS * 4);
     std::memcpy(c + pg::CFORM_WORDS, t.cmain.data(), pg::CMAIN_WORDS * 4);
   }
   // the per-round MDS layer's A operands as poseidon::mx::make_ctx builds them: lane (r, kb), dword a =
   // M[(r >> 2) + 4g][kb + 4a] << 8 (r & 3)
   static const uint32_t MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-  uint32_t* am = img->data() + gx::OPS_WORDS + gx::N_GROUPS * gx::C_WORDS;
+  uint32_t* am = img->data() + gx::OPS_WORDS + NG * gx::C_WORDS;
   for (uint32_t g = 0; g < 3; g++)
     for (uint32_t lane = 0; lane < 64; lane++)
       for (uint32_t a = 0; a < 3; a++) {
         const uint32_t r = lane & 15, kb = lane >> 4, i = (r >> 2) + 4 * g, k = kb + 4 * a;
         am[(g * 64 + lane) * 4 + a] = (MC[(k + 12 - i) % 12] + ((i | k) == 0 ? 8u : 0u)) << (8 * (r & 3));
       }
-  g_group_image = img.release();
+  g_group_image[NG - 2] = img.release();
   return true;
 }
-// the current device's copy of the image (uploaded on first use), or nullptr
-const uint32_t* group_tables() {
-  if (!g_poseidon_grouped.load(std::memory_order_relaxed)) return nullptr;
+// the current device's copy of the image (uploaded on first use) and the number of groups it serves, or nullptr
+const uint32_t* group_tables(int* n_groups) {
+  const int ng = g_poseidon_grouped.load(std::memory_order_relaxed);
+  if (n_groups) *n_groups = ng;
+  if (ng != 2 && ng != 3) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (g_group_state[dev].load(std::memory_order_acquire) > 0) return g_group_dev[dev];  // the state is set after the pointer
+  std::atomic<int>& state = g_group_state[ng - 2][dev];
+  const uint32_t*& slot = g_group_dev[ng - 2][dev];
+  if (state.load(std::memory_order_acquire) > 0) return slot;  // the state is set after the pointer
   std::lock_guard<std::mutex> lk(g_group_mu);
-  if (const int st = g_group_state[dev].load(std::memory_order_acquire)) return st > 0 ? g_group_dev[dev] : nullptr;
+  if (const int st = state.load(std::memory_order_acquire)) return st > 0 ? slot : nullptr;
   void* d = nullptr;
-  if (!build_group_image() || hipMalloc(&d, poseidon::mx::grp::TABLE_WORDS * 4) != hipSuccess ||
-      hipMemcpy(d, g_group_image->data(), poseidon::mx::grp::TABLE_WORDS * 4, hipMemcpyHostToDevice) != hipSuccess) {
+  const size_t bytes = (size_t)(ng == 3 ? poseidon::mx::grp::IMAGE_WORDS<3> : poseidon::mx::grp::IMAGE_WORDS<2>) * 4;
+  if (!(ng == 3 ? build_group_image<3>() : build_group_image<2>()) || hipMalloc(&d, bytes) != hipSuccess ||
+      hipMemcpy(d, g_group_image[ng - 2]->data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
     if (d) (void)hipFree(d);
-    g_group_state[dev].store(-1, std::memory_order_release);
+    state.store(-1, std::memory_order_release);
     return nullptr;
   }
-  g_group_dev[dev] = static_cast<const uint32_t*>(d);
-  g_group_state[dev].store(1, std::memory_order_release);
-  return g_group_dev[dev];
+  slot = static_cast<const uint32_t*>(d);
+  state.store(1, std::memory_order_release);
+  return slot;
 }
 
 #define BPG_MX_DISPATCH(NS_EXPR, KERNEL, ITEMS, ...)                                                        \
   switch (NS_EXPR) {                                                                                       \
-    case 4:                                                                                                \
-      if (const uint32_t* gtab_ = bpg::group_tables())                                                     \
-        KERNEL<4, true><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, gtab_);                      \
+    case 4: {                                                                                              \
+      int ng_ = 0;                                                                                         \
+      const uint32_t* gtab_ = bpg::group_tables(&ng_);                                                     \
+      if (gtab_ && ng_ == 3)                                                                               \
+        KERNEL<4, 3><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, gtab_);                    \
+      else if (gtab_)                                                                                      \
+        KERNEL<4, 2><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, gtab_);                    \
       else                                                                                                 \
-        KERNEL<4, false><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, nullptr);                   \
+        KERNEL<4, 0><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, nullptr);                  \
       break;                                                                                               \
-    case 2: KERNEL<2, false><<<ceil_div((ITEMS), 128), 256, 0, st>>>(__VA_ARGS__, nullptr); break;        \
-    default: KERNEL<1, false><<<ceil_div((ITEMS), 64), 256, 0, st>>>(__VA_ARGS__, nullptr); break;        \
+    }                                                                                                      \
+    case 2: KERNEL<2, 0><<<ceil_div((ITEMS), 128), 256, 0, st>>>(__VA_ARGS__, nullptr); break;       \
+    default: KERNEL<1, 0><<<ceil_div((ITEMS), 64), 256, 0, st>>>(__VA_ARGS__, nullptr); break;       \
   }
 
 // `mirror` (nullable): host-visible buffer that receives the 2^cap_height cap digests directly from
@@ -752,7 +785,8 @@ int bp_debug_poseidon_mx_cin(uint32_t* out) {
  * L0 / L0.5 entry points from its own threads, or by a test that pins both paths. */
 void bp_tune_merkle_wide(int log2_parents) { bpg::g_merkle_wide_log2.store(log2_parents < 8 || log2_parents > 24 ? 0 : log2_parents); }
 void bp_tune_assume_loaded(int mode) { bpg::g_assume_loaded.store(mode < 0 ? -1 : (mode != 0)); }
-void bp_tune_poseidon_grouped(int on) { bpg::g_poseidon_grouped.store(on != 0); }
+// 0: every round by itself; 2: rounds 4..19 in two groups; 3 (or 1, the default): all 22 partial rounds in three
+void bp_tune_poseidon_grouped(int mode) { bpg::g_poseidon_grouped.store(mode == 0 ? 0 : (mode == 2 ? 2 : 3)); }
 
 // Host only: the operand images of one group as the device gets them (tests/test_mx_tables.py pins them to the
 // integer model tools/poseidon_group_model.py).  out_ops: bp_debug_poseidon_group_ops(K) x 1024 bytes, out_cform: 64

@@ -187,31 +187,41 @@ __device__ __forceinline__ void sbox_full(uint64_t (&e)[NS][3]) {
 }
 
 // ---- grouped partial rounds (four sets per wave only) -----------------------------------------------------------
-// K = 8 partial rounds at a time (poseidon_group.hpp; integer model tools/poseidon_group_model.py): within a group
-// only ONE word per state and round -- the next S-box input, an affine form of the eleven untouched words and the
+// Up to K = 8 partial rounds at a time (poseidon_group.hpp; integer model tools/poseidon_group_model.py): within a
+// group only ONE word per state and round -- the next S-box input, an affine form of the eleven untouched words and the
 // earlier S-box outputs -- comes out of the matrix cores and is recombined; the twelve words are recombined once per
-// group.  228 -> ~140 VALU instructions per round and 64 states, 6 -> 5 MFMAs per set and round.
-//   operands (LDS, 1 KiB each, shared by the four sets): W = forms over the bytes of w, D = one more sigma into the
-//   forms still to come, MAIN = the new state over (w, sigma_0..7); C tables per group hold the round constants.
+// group.  228 -> ~140 VALU instructions per round and 64 states, 6 -> 5 MFMAs per set and round.  The 22 partial
+// rounds are 8 + 8 + 6: the third group runs steps 0..5 on the same form operands.
+//   operands (1 KiB each, shared by the four sets): W = forms over the bytes of w, D = one more sigma into the
+//   forms still to come, MAIN = the new state over (w, sigma_0..7) -- 40 operands in LDS, identical for the two long
+//   groups --, and 18 MAIN operands of the short group in global memory; C tables per group hold the round constants.
 //   B operands: blo / bhi = the state's byte planes as in mds(); bsig: lane group g holds sigma_g and sigma_{g+4}.
 //   Form f of a pair comes out in lane group f % 4 (rows 4(f%4)..+3 of the tile), so the gather into the dense
 //   S-box register and the way back come in four variants of the same three permlane swaps.
 namespace grp {
 constexpr int K = 8;
 constexpr poseidon::group::Layout LAY = poseidon::group::layout(K);
-constexpr int N_GROUPS = 2;                       // partial rounds 4..11 and 12..19; 20..25 take the per-round form
+// NG = number of groups: 2 = partial rounds 4..11 and 12..19, rounds 20..25 in the per-round form;
+//      3 = also rounds 20..25, as a SHORT group: steps 0..5 on the same form operands (the rows of forms 6 and 7 are
+//          garbage nobody reads), the new state from the MAIN operands of a six-round group (18 more operands,
+//          read from global memory).
+constexpr int SHORT_K = 6;
 constexpr int OPS_WORDS = LAY.n_ops * 256;        // 40 KiB
 constexpr int C_WORDS = poseidon::group::CFORM_WORDS + poseidon::group::CMAIN_WORDS;
 constexpr int MDS_A_WORDS = 3 * 256;              // the per-round MDS layer's three A operands (Ctx::A), read from LDS
                                                   // per round instead of living in 12 VGPRs through the groups
-// device image: group operands, per group cform + cmain, the MDS layer's A operands
-constexpr int TABLE_WORDS = OPS_WORDS + N_GROUPS * C_WORDS + MDS_A_WORDS;
+// device image: group operands, per group cform + cmain, the MDS layer's A operands -- this much goes to LDS --, then
+// (NG = 3) the short group's 18 MAIN operands, which stay in global memory (L2): with them in LDS a workgroup needs
+// 67 KB, two per CU, and the kernels lose a quarter of their resident waves (profiles/r3_poseidon_three_groups.txt)
+template <int NG> constexpr int TABLE_WORDS = OPS_WORDS + NG * C_WORDS + MDS_A_WORDS;
+template <int NG> constexpr int IMAGE_WORDS = TABLE_WORDS<NG> + (NG == 3 ? 18 * 256 : 0);
 
 // the whole workgroup copies the image into LDS, 16 bytes per lane and step (call once, then __syncthreads)
+template <int NG>
 __device__ __forceinline__ void load_tables(uint32_t* __restrict__ lds, const uint32_t* __restrict__ glob) {
   const uint4* src = (const uint4*)glob;
   uint4* dst = (uint4*)lds;
-  for (uint32_t i = threadIdx.x; i < (uint32_t)TABLE_WORDS / 4; i += blockDim.x) dst[i] = src[i];
+  for (uint32_t i = threadIdx.x; i < (uint32_t)TABLE_WORDS<NG> / 4; i += blockDim.x) dst[i] = src[i];
 }
 
 // gather<F>: x[m] holds set m's value in lane group F; afterwards x[F] holds set j's value in lane group j.
@@ -258,8 +268,10 @@ struct State {
 };
 
 // step J of a group: S-box input J -> sigma_J into bsig and into the forms still to come
+// (full = false: the short group, whose last step is 5: no later form takes sigma_5)
 template <int J>
-__device__ __forceinline__ void step(State& s, uint64_t (&e)[4][3], const v4i* ops, const int* cform, uint32_t lane) {
+__device__ __forceinline__ void step(State& s, uint64_t (&e)[4][3], const v4i* ops, const int* cform, uint32_t lane,
+                                     bool full = true) {
   constexpr int P = J / 4, F = J % 4;
   const uint32_t kb = lane >> 4;
   if constexpr (F == 0) {  // start pair P: constants + the forms over w (+ the sigmas known so far)
@@ -303,6 +315,7 @@ __device__ __forceinline__ void step(State& s, uint64_t (&e)[4][3], const v4i* o
     s.bsig[m][2 * (J / 4) + 1] = __builtin_amdgcn_update_dpp(s.bsig[m][2 * (J / 4) + 1], (int)h[m], 0xE4, 1 << F, 0xF, false);
   }
   if constexpr (J >= LAY.d_first[P] && J < LAY.d_first[P] + LAY.d_count[P]) {  // a later form of the pair needs sigma_J
+    if (J == SHORT_K - 1 && !full) return;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const v4i a = ops[(LAY.d_base[P] + 2 * (J - LAY.d_first[P]) + half) * 64 + lane];
@@ -312,9 +325,12 @@ __device__ __forceinline__ void step(State& s, uint64_t (&e)[4][3], const v4i* o
   }
 }
 
-// rounds r0 .. r0 + 7 of the partial rounds: e = t(r0) in, t(r0 + 8) out (S-box-input form, constants included)
-__device__ __forceinline__ void partial_group(uint64_t (&e)[4][3], const uint32_t* tab, int grp) {
+// rounds r0 .. r0 + 7 of the partial rounds: e = t(r0) in, t(r0 + 8) out (S-box-input form, constants included);
+// the third group of NG = 3 is short: rounds 20..25, t(26) out
+template <int NG>
+__device__ __forceinline__ void partial_group(uint64_t (&e)[4][3], const uint32_t* tab, const uint32_t* __restrict__ gtab, int grp) {
   const uint32_t lane = threadIdx.x & 63, kb = lane >> 4;
+  const bool full = NG == 2 || grp < 2;   // wave-uniform
   const v4i* ops = (const v4i*)tab;
   const int* cform = (const int*)(tab + OPS_WORDS + grp * C_WORDS);
   const int* cmain = cform + poseidon::group::CFORM_WORDS;
@@ -335,23 +351,36 @@ __device__ __forceinline__ void partial_group(uint64_t (&e)[4][3], const uint32_
   step<2>(s, e, ops, cform, lane);
   step<3>(s, e, ops, cform, lane);
   step<4>(s, e, ops, cform, lane);
-  step<5>(s, e, ops, cform, lane);
-  step<6>(s, e, ops, cform, lane);
-  step<7>(s, e, ops, cform, lane);
-  // the new state: twelve words over (w, sigma_0 .. sigma_7), recombined as in mds()
+  step<5>(s, e, ops, cform, lane, full);
+  if (full) {
+    step<6>(s, e, ops, cform, lane);
+    step<7>(s, e, ops, cform, lane);
+  }
+  // the new state: twelve words over (w, sigma_0 .. sigma_7 / sigma_5), recombined as in mds()
+  const v4i* lops = ops + LAY.main_base * 64 + lane;
+  const v4i* gops = (const v4i*)(gtab + TABLE_WORDS<NG>) + lane;
 #pragma unroll
   for (int g = 0; g < 3; g++) {
-    v4i d[4][2];
+    v4i d[4][2], A[2][3];
+    if (full) {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[h][c] = lops[((g * 2 + h) * 3 + c) * 64];
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[h][c] = gops[((g * 2 + h) * 3 + c) * 64];
+    }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const v4i c0 = ((const v4i*)(cmain + (g * 2 + h) * 16))[kb];
-      const v4i a_lo = ops[(LAY.main_base + (g * 2 + h) * 3) * 64 + lane], a_hi = ops[(LAY.main_base + (g * 2 + h) * 3 + 1) * 64 + lane],
-                a_sg = ops[(LAY.main_base + (g * 2 + h) * 3 + 2) * 64 + lane];
 #pragma unroll
       for (int m = 0; m < 4; m++) {
-        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_lo, s.blo[m], c0, 0, 0, 0);
-        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hi, s.bhi[m], d[m][h], 0, 0, 0);
-        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_sg, s.bsig[m], d[m][h], 0, 0, 0);
+        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[h][0], s.blo[m], c0, 0, 0, 0);
+        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[h][1], s.bhi[m], d[m][h], 0, 0, 0);
+        d[m][h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[h][2], s.bsig[m], d[m][h], 0, 0, 0);
       }
     }
     uint64_t L[4], H[4], x[4];
@@ -365,21 +394,24 @@ __device__ __forceinline__ void partial_group(uint64_t (&e)[4][3], const uint32_
 }  // namespace grp
 
 // The grouped kernels keep the C table of the per-round MDS layer only for the rounds that still use it: 0..3 and
-// 20..29 (14 x 384 bytes instead of 30 x 384: with the 45 KiB of group operands three workgroups still fit a CU's LDS)
-constexpr int CIN_GROUPED_ROUNDS = 14;
-constexpr int CIN_GROUPED_WORDS = CIN_GROUPED_ROUNDS * CIN_PER_ROUND;
-__device__ __forceinline__ int cin_slot(int rnd) { return rnd < 4 ? rnd : rnd - 16; }
+// 20..29 (NG = 2: 14 x 384 bytes instead of 30 x 384: with the 45 KiB of group operands three workgroups still fit a
+// CU's LDS) or 0..3 and 26..29 (NG = 3)
+template <int NG> constexpr int CIN_GROUPED_ROUNDS = NG == 3 ? 8 : 14;
+template <int NG> constexpr int CIN_GROUPED_WORDS = CIN_GROUPED_ROUNDS<NG> * CIN_PER_ROUND;
+template <int NG> __device__ __forceinline__ int cin_slot(int rnd) { return rnd < 4 ? rnd : rnd - (30 - CIN_GROUPED_ROUNDS<NG>); }
+template <int NG>
 __device__ __forceinline__ void build_cin_grouped(uint32_t* __restrict__ cin) {
   const uint4* src = (const uint4*)CIN_TABLE.v;
   uint4* dst = (uint4*)cin;
-  for (uint32_t i = threadIdx.x; i < (uint32_t)CIN_GROUPED_WORDS / 4; i += blockDim.x)
-    dst[i] = src[i < 4 * CIN_PER_ROUND / 4 ? i : i + 16 * CIN_PER_ROUND / 4];
+  for (uint32_t i = threadIdx.x; i < (uint32_t)CIN_GROUPED_WORDS<NG> / 4; i += blockDim.x)
+    dst[i] = src[i < 4 * CIN_PER_ROUND / 4 ? i : i + (30 - CIN_GROUPED_ROUNDS<NG>) * CIN_PER_ROUND / 4];
 }
 
 // mds<4> with the A operands read from the LDS image (one ds_read_b128 each per round, shared by the four sets)
+template <int NG>
 __device__ __forceinline__ void mds4_lds(uint64_t (&e)[4][3], const Ctx& c, int rnd, const uint32_t* tab) {
-  const v4i* cr = (const v4i*)(c.cin + cin_slot(rnd) * CIN_PER_ROUND);
-  const v4i* am = (const v4i*)(tab + grp::OPS_WORDS + grp::N_GROUPS * grp::C_WORDS) + (threadIdx.x & 63);
+  const v4i* cr = (const v4i*)(c.cin + cin_slot<NG>(rnd) * CIN_PER_ROUND);
+  const v4i* am = (const v4i*)(tab + grp::OPS_WORDS + NG * grp::C_WORDS) + (threadIdx.x & 63);
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     v4i blo, bhi;
@@ -403,8 +435,11 @@ __device__ __forceinline__ void mds4_lds(uint64_t (&e)[4][3], const Ctx& c, int 
   }
 }
 
-// The permutation with the partial rounds 4..19 grouped (four sets per wave; tab = the LDS image of grp::load_tables)
-__device__ __forceinline__ void permute_grouped(uint64_t (&e)[4][3], const Ctx& c, const uint32_t* tab) {
+// The permutation with the partial rounds grouped (four sets per wave; tab = the LDS image of grp::load_tables<NG>):
+// NG = 2: rounds 4..19 in two groups, 20..25 one by one; NG = 3: all 22 partial rounds in groups (8 + 8 + 6)
+template <int NG>
+__device__ __forceinline__ void permute_grouped(uint64_t (&e)[4][3], const Ctx& c, const uint32_t* tab,
+                                                const uint32_t* __restrict__ gtab) {
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const uint64_t k = RC[c.kb + 4 * a];
@@ -415,19 +450,22 @@ __device__ __forceinline__ void permute_grouped(uint64_t (&e)[4][3], const Ctx& 
 #pragma unroll 1
   for (int k = 0; k < 4; k++, rnd++) {
     sbox_full<4>(e);
-    mds4_lds(e, c, rnd, tab);
+    mds4_lds<NG>(e, c, rnd, tab);
   }
 #pragma unroll 1
-  for (int g = 0; g < grp::N_GROUPS; g++, rnd += grp::K) grp::partial_group(e, tab, g);
+  for (int g = 0; g < NG; g++) grp::partial_group<NG>(e, tab, gtab, g);
+  rnd = NG == 3 ? 26 : 20;
+  if constexpr (NG == 2) {
 #pragma unroll 1
-  for (; rnd < 26; rnd++) {
-    sbox_word0<4>(e, c);
-    mds4_lds(e, c, rnd, tab);
+    for (; rnd < 26; rnd++) {
+      sbox_word0<4>(e, c);
+      mds4_lds<NG>(e, c, rnd, tab);
+    }
   }
 #pragma unroll 1
   for (int k = 0; k < 4; k++, rnd++) {
     sbox_full<4>(e);
-    mds4_lds(e, c, rnd, tab);
+    mds4_lds<NG>(e, c, rnd, tab);
   }
 }
 

@@ -697,20 +697,21 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned
 }
 // The same search with the MDS layer on the matrix cores (poseidon_mx.cuh): a wave takes 64 consecutive candidates
 // as four sets of 16, lane (n, kb) holds words kb, kb + 4, kb + 8 of candidate 16m + n; word 7 is slot 1 of lanes kb = 3.
-// GR: the partial rounds 4..19 in two groups of eight (gtab = the device image of the operand tables, as in
-// hash_kernels.hip); otherwise every round by itself.
-template <bool GR>
+// GR: 0 = every round by itself; 2 / 3 = the partial rounds in groups (gtab = the device image of the operand tables,
+// as in hash_kernels.hip).
+template <int GR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 pow_grind_mx_kernel(bpg::PowArgs a, unsigned long long* result, const uint32_t* __restrict__ gtab) {
   // A witness below this batch is already known (an earlier batch of the same speculative group found it: batches
   // run one after the other on the stream, so the value is stable and the same for every thread): nothing here can
   // be smaller, the whole grid leaves before it loads a table.
   if (__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.base) return;
-  __shared__ __attribute__((aligned(16))) uint32_t cin[GR ? poseidon::mx::CIN_GROUPED_WORDS : poseidon::mx::CIN_WORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t gt[GR ? poseidon::mx::grp::TABLE_WORDS : 4];
-  if constexpr (GR) {
-    poseidon::mx::build_cin_grouped(cin);
-    poseidon::mx::grp::load_tables(gt, gtab);
+  constexpr int NG = GR ? GR : 2;
+  __shared__ __attribute__((aligned(16))) uint32_t cin[GR ? poseidon::mx::CIN_GROUPED_WORDS<NG> : poseidon::mx::CIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t gt[GR ? poseidon::mx::grp::TABLE_WORDS<NG> : 4];
+  if constexpr (GR != 0) {
+    poseidon::mx::build_cin_grouped<NG>(cin);
+    poseidon::mx::grp::load_tables<NG>(gt, gtab);
   } else {
     poseidon::mx::build_cin(cin);
   }
@@ -727,7 +728,7 @@ pow_grind_mx_kernel(bpg::PowArgs a, unsigned long long* result, const uint32_t* 
 #pragma unroll
     for (int m = 0; m < 4; m++) e[m][s] = mine ? cand0 + 16 * m : w;
   }
-  if constexpr (GR) poseidon::mx::permute_grouped(e, c, gt);
+  if constexpr (GR != 0) poseidon::mx::permute_grouped<NG>(e, c, gt, gtab);
   else poseidon::mx::permute<4>(e, c);
   if (c.kb == 3) {
 #pragma unroll
@@ -924,8 +925,11 @@ int launch_fri_fold(const FriLayerArgs& a, hipStream_t st) {
 }
 int launch_pow(const PowArgs& a, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st) {
   if (poseidon_mx()) {
-    if (const uint32_t* gtab = group_tables()) pow_grind_mx_kernel<true><<<n_candidates / 256, 256, 0, st>>>(a, d_result, gtab);
-    else pow_grind_mx_kernel<false><<<n_candidates / 256, 256, 0, st>>>(a, d_result, nullptr);
+    int ng = 0;
+    const uint32_t* gtab = group_tables(&ng);
+    if (gtab && ng == 3) pow_grind_mx_kernel<3><<<n_candidates / 256, 256, 0, st>>>(a, d_result, gtab);
+    else if (gtab) pow_grind_mx_kernel<2><<<n_candidates / 256, 256, 0, st>>>(a, d_result, gtab);
+    else pow_grind_mx_kernel<0><<<n_candidates / 256, 256, 0, st>>>(a, d_result, nullptr);
   } else
     pow_grind_kernel<<<n_candidates / 256, 256, 0, st>>>(a, d_result);
   BPG_LAUNCH_CHECK();

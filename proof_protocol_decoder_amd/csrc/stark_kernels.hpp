@@ -140,7 +140,9 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
                uint32_t log_n, uint32_t n_cols, uint32_t n_cosets, const uint64_t* scale, bool inverse,
                hipStream_t st);
 // hash_kernels.hip
-const uint32_t* group_tables();  // the current device's image of the grouped-Poseidon operand tables, or nullptr (knob off)
+// the current device's image of the grouped-Poseidon operand tables and the number of groups (2 or 3) it is laid out
+// for, or nullptr (knob off)
+const uint32_t* group_tables(int* n_groups);
 int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st,
                         uint64_t* mirror, bool* mirrored);
 int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,

@@ -18,10 +18,23 @@ def pytest_configure(config):
 # start of every test (module fixtures are torn down inside the last test's window).  BPG_TEST_WATCHDOG=0 disables.
 _WATCHDOG_S = int(os.environ.get("BPG_TEST_WATCHDOG", "360"))
 _WATCHDOG_FILE = None
+# BPG_TEST_WATCHDOG_ABORT=<seconds>: additionally raise SIGABRT in the process that long into a test -- for a run under
+# a debugger (`rocgdb -batch -ex run -ex "thread apply all bt" --args python -m pytest ...`), which then prints the
+# NATIVE stacks of the hang.
+_ABORT_S = int(os.environ.get("BPG_TEST_WATCHDOG_ABORT", "0"))
+_ABORT_TIMER = None
 
 
 def pytest_runtest_logstart(nodeid, location):
-    global _WATCHDOG_FILE
+    global _WATCHDOG_FILE, _ABORT_TIMER
+    if _ABORT_S > 0:
+        import signal
+        import threading
+        if _ABORT_TIMER is not None:
+            _ABORT_TIMER.cancel()
+        _ABORT_TIMER = threading.Timer(_ABORT_S, lambda: os.kill(os.getpid(), signal.SIGABRT))
+        _ABORT_TIMER.daemon = True
+        _ABORT_TIMER.start()
     if _WATCHDOG_S > 0:
         import faulthandler
         if _WATCHDOG_FILE is None:  # pytest captures fd 2 while a test runs: the dump goes to a file of its own
@@ -37,6 +50,8 @@ def pytest_runtest_logstart(nodeid, location):
 def pytest_sessionfinish(session, exitstatus):
     import faulthandler
     faulthandler.cancel_dump_traceback_later()
+    if _ABORT_TIMER is not None:
+        _ABORT_TIMER.cancel()
 
 
 @pytest.fixture(scope="session")

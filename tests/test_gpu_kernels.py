@@ -134,17 +134,18 @@ def test_field_ops_against_big_integers(bpg):
         assert got[13][i] == x % P and got[14][i] == y % P, (i, hex(x), hex(y))
 
 
-@pytest.fixture(params=["mx4", "mx4-ungrouped", "mx2", "mx1", "lane"])
+@pytest.fixture(params=["mx4", "mx4-ungrouped", "mx4-2groups", "mx2", "mx1", "lane"])
 def perm_form(request, bpg):
     """the forms of the batch permutation: MDS on the matrix cores with 4 / 2 / 1 sets of 16 states per wave (four
-    sets: partial rounds 4..19 in two groups of eight, or every round by itself), and one lane per state"""
+    sets: all 22 partial rounds in three groups, rounds 4..19 in two groups of eight, or every round by itself), and
+    one lane per state"""
     bpg.lib().bp_tune_poseidon_mx(0 if request.param == "lane" else 1)
     bpg.lib().bp_tune_poseidon_mx_sets(int(request.param[2:3]) if request.param != "lane" else 0)
-    bpg.lib().bp_tune_poseidon_grouped(0 if request.param.endswith("-ungrouped") else 1)
+    bpg.lib().bp_tune_poseidon_grouped(0 if request.param.endswith("-ungrouped") else 2 if request.param.endswith("-2groups") else 3)
     yield request.param
     bpg.lib().bp_tune_poseidon_mx(1)
     bpg.lib().bp_tune_poseidon_mx_sets(0)
-    bpg.lib().bp_tune_poseidon_grouped(1)
+    bpg.lib().bp_tune_poseidon_grouped(3)
 
 
 def test_poseidon_kat_and_random(bpg, oracle, perm_form):
@@ -186,7 +187,7 @@ def test_poseidon_byte_plane_extremes(bpg, oracle, perm_form):
 
 
 @pytest.mark.parametrize("quad", ["quad", "lane", "mx4", "mx2", "mx1", "mx", "mx+fused", "mx+fused+wide", "quad+fused",
-                                  "mx4-ungrouped"])
+                                  "mx4-ungrouped", "mx4-2groups"])
 @pytest.mark.parametrize("log_n,rate_bits,n_cols,cap_h", [(3, 1, 3, 4), (4, 1, 4, 0), (6, 1, 8, 4), (7, 3, 19, 4),
                                                           (10, 1, 135, 4), (12, 1, 33, 2), (9, 3, 2, 4), (5, 1, 9, 1),
                                                           (6, 1, 13, 3)])
@@ -194,13 +195,14 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     # the three Poseidon kernel families: 4 lanes per state with DPP exchange / one lane per state / MDS on the
     # matrix cores (four sets of 16 states per wave)
     # "+fused": up to seven levels of at most 4096 nodes per launch (LDS hand-down), in the matrix-core one-set form or
-    # the quad form; "mx4-ungrouped": four sets per wave with every partial round by itself (the default groups them)
+    # the quad form; "mx4-ungrouped" / "mx4-2groups": four sets per wave with every partial round by itself / only rounds
+    # 4..19 grouped (the default groups all 22)
     bpg.lib().bp_tune_quad_threshold((1 << 40) if quad.startswith("quad") else 1)  # 1: never quad; 0 would be automatic
     bpg.lib().bp_tune_poseidon_mx(1 if quad.startswith("mx") else 0)
     bpg.lib().bp_tune_poseidon_mx_sets(int(quad[2:3]) if quad[:3] in ("mx4", "mx2", "mx1") else 0)  # "mx": sets by launch size
     bpg.lib().bp_tune_merkle_fused(1 if "+fused" in quad else 0)
     bpg.lib().bp_tune_merkle_wide(14 if quad.endswith("+wide") else 0)   # nine levels per launch from 256 parents up
-    bpg.lib().bp_tune_poseidon_grouped(0 if quad.endswith("-ungrouped") else 1)
+    bpg.lib().bp_tune_poseidon_grouped(0 if quad.endswith("-ungrouped") else 2 if quad.endswith("-2groups") else 3)
     if quad in ("mx", "mx+fused", "mx+fused+wide"):
         bpg.lib().bp_tune_quad_threshold(1 << (log_n + rate_bits))  # leaves with 4 sets, then 2, then 1 up the tree
     rng = np.random.default_rng(300 + log_n)
@@ -215,7 +217,7 @@ def test_merkle_commit_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, cap
     bpg.lib().bp_tune_poseidon_mx_sets(0)
     bpg.lib().bp_tune_merkle_fused(0)
     bpg.lib().bp_tune_merkle_wide(0)
-    bpg.lib().bp_tune_poseidon_grouped(1)
+    bpg.lib().bp_tune_poseidon_grouped(3)
     assert (dig == want_dig).all()
     assert (dig[-(1 << cap_h):] == want_cap).all()
 

@@ -426,6 +426,22 @@ def test_closing_a_state_after_a_table_proof_parked_a_worker_does_not_hang():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "hang_probe.py"), "s"], capture_output=True, text=True,
                        timeout=300, cwd=root, env=dict(os.environ, WD="120"))
     assert r.returncode == 0 and "state closed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "host wait mode 1" in r.stdout   # the library came first: host waits sleep
+
+
+def test_a_device_the_process_already_used_keeps_its_wait_mode():
+    """Found in round 3 (tests/test_gpu_kernels.py followed directly by tests/test_gpu_stark.py): when the process
+    had already run kernels on the device (torch, L0 entry points on the null stream) before the library's first
+    worker, switching the device to blocking host waits made the first hipFree after it wait forever
+    (hip::Device::SyncAllStreams on the older queues).  bp_use_blocking_sync now leaves a device in use alone."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "hang_probe.py"), "ts"], capture_output=True, text=True,
+                       timeout=300, cwd=root, env=dict(os.environ, WD="120"))
+    assert r.returncode == 0 and "state closed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "host wait mode 2" in r.stdout
 
 
 RCCL_CHILD = r'''

@@ -194,3 +194,22 @@ def test_poseidon_group_operands_do_not_depend_on_the_round():
     import poseidon_group_model as model
     a, b = model.device_images(model.build_group(8, 4)), model.device_images(model.build_group(8, 12))
     assert a[0] == b[0] and a[1] != b[1] and a[2] != b[2]
+
+
+def test_poseidon_short_group_runs_on_the_long_groups_form_operands():
+    """The third group of the kernels (rounds 20..25): steps 0..5 on the EIGHT-round group's form operands, the new
+    state from a six-round group's MAIN operands and C tables -- the kernel's sequence on exact integers against the
+    plain rounds (the library checks while it builds the image that the six-round group's form operands are the
+    eight-round group's with the rows of forms 6 and 7 blank)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import poseidon_group_model as model
+    assert model.check_short(n=4)
+    # the same blank-row relation on the model's images
+    ops8, ops6 = model.device_images(model.build_group(8, 4))[0], model.device_images(model.build_group(6, 20))[0]
+    L6 = model.layout(6)
+    for i in range(L6["main_base"]):
+        for b in range(1024):
+            blank = i >= L6["w_base"][1] and ((b >> 4) & 15) >= 8
+            assert ops6[i * 1024 + b] == (0 if blank else ops8[i * 1024 + b]), (i, b)

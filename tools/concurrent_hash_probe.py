@@ -13,7 +13,7 @@ torch.cuda.set_device(0)
 log_n, r, C = 13, 3, 135
 rows = 1 << (log_n + r)
 perms = rows * ((C + 7) // 8) + rows
-grouped = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+grouped = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 bpg.lib().bp_tune_poseidon_grouped(grouped)
 print("bp_tune_poseidon_grouped(%d)" % grouped, flush=True)
 for n_streams in (1, 2, 4, 8, 16, 24):

@@ -4,6 +4,8 @@ it), the next hipFree -- a device-wide wait, e.g. in bp_state_free -- never retu
 mode before it creates its first stream and never changes it (capi.cpp, Worker::init).  Steps (argv[1], any of):
   s / S  a small / large table proof first (parks a worker)     c / n  a child process using the GPU / RCCL
   r      bp_release_cached_memory before closing the state       G / F  knobs: per-round Poseidon / unfused Merkle tail
+  t      the process uses the device through torch FIRST (kernels on the null stream): the library must then leave the
+         wait mode alone (bp_host_wait_mode == 2) -- switching it under used queues hung the first hipFree
 A watchdog thread dumps the Python stacks and ends the process after $WD seconds (a native hang cannot be interrupted).
 tests/test_gpu_proofgen.py runs `s` in a fresh process."""
 import faulthandler, os, subprocess, sys, time
@@ -25,6 +27,11 @@ if "G" in steps: L.bp_tune_poseidon_grouped(0)
 if "F" in steps: L.bp_tune_merkle_fused(0)
 t0 = time.time()
 def say(x): print("%.1f %s" % (time.time() - t0, x), flush=True)
+if "t" in steps:
+    x = torch.randint(0, 2**62, (16, 1 << 12), dtype=torch.int64, device="cuda")
+    for _ in range(20):
+        pkg.ops.merkle_commit(x, 11, 1, 4)
+    torch.cuda.synchronize(); say("torch + L0 work on the null stream")
 if "s" in steps:
     pkg.ops.stark_prove_synthetic(pkg.ops.stark_cfg(13, 135, n_const=82, deg_pow=3, rate_bits=3, num_queries=28), 1, 2); say("stark proof (parked worker)")
 if "S" in steps:
@@ -39,3 +46,6 @@ if "n" in steps:
 if "r" in steps:
     L.bp_release_cached_memory(); say("released parked worker")
 st.close(); say("state closed")
+torch.cuda.synchronize()
+torch.cuda.empty_cache()
+say("host wait mode %d" % L.bp_host_wait_mode(0))

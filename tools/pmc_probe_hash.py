@@ -7,11 +7,12 @@ import proof_protocol_decoder_amd as bpg
 L = bpg.lib()
 log_n, cols, r = 20, 64, 1
 lde = torch.randint(0, 2**62, (cols, 1 << (log_n + r)), dtype=torch.int64, device="cuda")
-for mx, grouped in ((1, 1), (1, 0), (0, 0)):     # matrix cores + grouped partial rounds / per round / one lane per state
+# matrix cores + three groups (all 22 partial rounds) / two groups (rounds 4..19) / per round; one lane per state
+for mx, grouped in ((1, 3), (1, 2), (1, 0), (0, 0)):
     L.bp_tune_poseidon_mx(mx)
     L.bp_tune_poseidon_grouped(grouped)
     bpg.ops.merkle_commit(lde, log_n, r, 4)
     torch.cuda.synchronize()
 L.bp_tune_poseidon_mx(1)
-L.bp_tune_poseidon_grouped(1)
+L.bp_tune_poseidon_grouped(3)
 print("perms per commit:", (1 << (log_n + r)) * 9)

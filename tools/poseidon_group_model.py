@@ -392,6 +392,71 @@ def run_group_device(K, ops, cform, cmain, t, bound):
     return out, sig
 
 
+def run_short_group_device(ops8, main6, cform6, cmain6, t, bound, K=6):
+    """The kernel's THIRD group (rounds 20..25, poseidon_mx.cuh: partial_group with full = false): the form operands
+    are the eight-round group's (rows of forms 6 and 7 come out as garbage nobody reads; the delta of sigma_5, which
+    only they need, is skipped), the new state comes from the MAIN operands of a six-round group, the C tables are
+    the six-round group's."""
+    L = layout(8)
+    sig = [None] * 8
+    lo, hi = chunk_bytes("LO", t, sig, 8), chunk_bytes("HI", t, sig, 8)
+    acc = [None, None]
+    t0 = t[0]
+    for j in range(K):
+        Pi, f = j // 4, j % 4
+        if f == 0:
+            nw = L["w_per_half"][Pi]
+            sb = chunk_bytes("SIG", t, sig, 8)
+            for half in range(2):
+                base = L["w_base"][Pi] + half * nw
+                d = mfma(image_rows(ops8, base), lo, cform6[(Pi * 2 + half) * 16:(Pi * 2 + half) * 16 + 16])
+                d = mfma(image_rows(ops8, base + 1), hi, d)
+                if Pi:
+                    d = mfma(image_rows(ops8, base + 2), sb, d)
+                acc[half] = d
+        if j:
+            t0 = recombine(acc[0][4 * f:4 * f + 4], acc[1][4 * f:4 * f + 4], bound)
+        sig[j] = sbox(t0)
+        if L["d_first"][Pi] <= j < L["d_first"][Pi] + L["d_count"][Pi] and j != K - 1:
+            sb = chunk_bytes("SIG", t, sig, 8)
+            for half in range(2):
+                acc[half] = mfma(image_rows(ops8, L["d_base"][Pi] + 2 * (j - L["d_first"][Pi]) + half), sb, acc[half])
+    sb = chunk_bytes("SIG", t, sig, 8)
+    out = [0] * 12
+    for g in range(3):
+        res = []
+        for h in range(2):
+            base = (g * 2 + h) * 3
+            d = mfma(image_rows(main6, base), lo, cmain6[(g * 2 + h) * 16:(g * 2 + h) * 16 + 16])
+            d = mfma(image_rows(main6, base + 1), hi, d)
+            d = mfma(image_rows(main6, base + 2), sb, d)
+            res.append(d)
+        for ib in range(4):
+            out[ib + 4 * g] = recombine(res[0][4 * ib:4 * ib + 4], res[1][4 * ib:4 * ib + 4], bound)
+    return out, sig[:K]
+
+
+def short_group_images(r0=20):
+    """-> (ops8, main6, cform6, cmain6, bound): what the three-group kernels hold for their last group"""
+    G8, G6 = build_group(8, 4), build_group(6, r0)
+    ops8 = device_images(G8)[0]
+    ops6, cform6, cmain6 = device_images(G6)
+    mb = layout(6)["main_base"]
+    return ops8, ops6[mb * 1024:(mb + 18) * 1024], cform6, cmain6, max(G8["bound"], G6["bound"])
+
+
+def check_short(n=6, seed=2, r0=20):
+    ops8, main6, cform6, cmain6, bound = short_group_images(r0)
+    rng = random.Random(seed)
+    cases = [[rng.randrange(P) for _ in range(12)] for _ in range(n)]
+    cases += [[0] * 12, [P - 1] * 12, [0xFFFFFFFF00000000] * 12, [0x00000000FFFFFFFF] * 12]
+    for t in cases:
+        want, ws = plain_rounds(list(t), r0, 6)
+        got, gs = run_short_group_device(ops8, main6, cform6, cmain6, list(t), bound)
+        assert gs == ws and got == want, ("short group", r0)
+    return True
+
+
 def plain_rounds(t, r0, K):
     sig = []
     for r in range(r0, r0 + K):
@@ -422,3 +487,5 @@ if __name__ == "__main__":
         G = check(K, r0)
         print("K=%d r0=%d: grouped rounds == plain rounds (tile form and the device's operand images, %d operands); "
               "largest plane sum %d (< 2^23 = %d)" % (K, r0, layout(K)["n_ops"], G["bound"], 1 << 23))
+    check_short()
+    print("rounds 20..25 on the eight-round group's form operands + a six-round group's MAIN operands == plain rounds")

@@ -14,7 +14,7 @@ L.bp_tune_poseidon_mx_sets(4)
 def gperm(log_n, r, cols, reps=5):
     lde = torch.randint(0, 2**62, (cols, 1 << (log_n + r)), dtype=torch.int64, device="cuda")
     out = {}
-    for on in (0, 1, 0, 1):
+    for on in (0, 2, 3, 0, 2, 3):
         L.bp_tune_poseidon_grouped(on)
         d = bpg.ops.merkle_commit(lde, log_n, r, 4)
         torch.cuda.synchronize()
@@ -29,8 +29,9 @@ def gperm(log_n, r, cols, reps=5):
         perms = (1 << (log_n + r)) * ((cols + 7) // 8) + (1 << (log_n + r))
         out.setdefault(on, []).append((perms / (best * 1e-3) / 1e9, d.clone()))
     same = all((x[1] == out[0][0][1]).all().item() for v in out.values() for x in v)
-    print("2^%d x %d rate %d: per-round %s Gperm/s, grouped %s Gperm/s, digests identical: %s" % (
-        log_n, cols, 1 << r, ["%.3f" % x[0] for x in out[0]], ["%.3f" % x[0] for x in out[1]], same), flush=True)
+    print("2^%d x %d rate %d: per-round %s Gperm/s, two groups %s, three groups %s, digests identical: %s" % (
+        log_n, cols, 1 << r, ["%.3f" % x[0] for x in out[0]], ["%.3f" % x[0] for x in out[2]],
+        ["%.3f" % x[0] for x in out[3]], same), flush=True)
 
 
 for shape in ((20, 1, 64), (16, 3, 135), (14, 1, 2432), (17, 1, 16)):

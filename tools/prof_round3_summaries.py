@@ -3,6 +3,7 @@
   r3_hash_sq_counters.txt     leaf hashing 2^21 rows x 8 permutations alone on the chip, per kernel form
 """
 import collections
+import re
 import csv
 import glob
 import os
@@ -49,7 +50,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in rows(("r3_hash_sq1", "r3_hash_sq2")):
     k = r["Kernel_Name"]
     if "leaf_hash" in k:
-        name = ("leaf_hash_mx_kernel<4, grouped>" if "Lb1" in k or "true" in k else "leaf_hash_mx_kernel<4, per round>") if "mx" in k \
+        m = re.search(r"leaf_hash_mx_kernel<(\d+), (\d+)>", k) or re.search(r"leaf_hash_mx_kernelILi(\d+)ELi(\d+)E", k)
+        name = ("leaf_hash_mx_kernel<4, %s>" % {"0": "per round", "2": "two groups", "3": "three groups"}[m.group(2)]) if m \
             else "leaf_hash_kernel (one lane per state)"
         acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
 with open(os.path.join(O, "r3_hash_sq_counters.txt"), "w") as out:
