@@ -187,7 +187,8 @@ struct bp_stark_cfg;
  * (eval_packed_generic / eval_ext, evaluated by plonky2_evm's compute_quotient_polys, reached from
  * proof_gen.rs:44-52; the seven zkEVM tables of prover_state.rs:85-93, Keccak range constants.rs:12) is here an
  * air_id: 0 = the synthetic AIR of DESIGN.md section 4 (any width), 1 = keccak_f, one round of Keccak-f[1600] per
- * row on 2430 columns, written from FIPS 202 (not upstream's column layout).  bp_air_describe returns the shape and
+ * row on 2430 columns, written from FIPS 202 (not upstream's column layout), 2 = logic, one AND / OR / XOR of two
+ * 256-bit words per row on 523 columns (likewise its own layout).  bp_air_describe returns the shape and
  * the constraint list of an AIR as families (first index, count, kind, degree); the list is followed, for every
  * air_id, by the two constraints of each cross-table-lookup-like auxiliary column (n_cols / 8 of them). */
 typedef struct bp_air_family {
@@ -228,6 +229,11 @@ int bp_quotient_eval(uint32_t air_id, const struct bp_stark_cfg* shape, const ui
  * columns, column-major, row r = round r % 24 of permutation r / 24.  d_inputs: [ceil(n / 24)][25] input lanes
  * (any u64; lane x + 5y), or NULL to draw them from `seed` (splitmix64(seed ^ (lane << 32) ^ permutation)). */
 int bp_keccak_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
+/* Witness of AIR 2 (the logic table: one AND / OR / XOR of two 256-bit words per row): n = 2^log_n rows x 523 columns,
+ * column-major.  d_inputs: [n][9] = operation code (0 none = a padding row, 1 and, 2 or, 3 xor), then the four 64-bit
+ * words of operand 0 and of operand 1, least significant first; or NULL to draw them from `seed`
+ * (code = splitmix64(seed ^ (0xFF << 32) ^ row) & 3, word w of operand j = splitmix64(seed ^ ((1 + 4 j + w) << 32) ^ row)). */
+int bp_logic_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
 /* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
  * folded domain), done in the evaluation domain.  d_values: the layer's n_l << rate_bits extension values
@@ -264,8 +270,8 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
-/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1: n_cols = 2430, n_const = 0,
- * deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
+/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 / 2: n_cols = 2430 / 523,
+ * n_const = 0, deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
 int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                        uint8_t** out, size_t* out_len);
 /* The CPU verifier (csrc/verifier.cpp, what VerifierState::verify runs per proof, verifier_state.rs:56-71) on one
@@ -378,6 +384,9 @@ int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_
  * order of prover_state.rs:85-93 -- is proven with the Keccak-f[1600] AIR (air_id 1: 2430 columns, the witness is
  * ceil(2^log_n / 24) permutations drawn from the seed) instead of the synthetic AIR.  The table's width must be 2430. */
 int bp_ir_set_keccak_air(uint64_t ir[BP_IR_WORDS], int on);
+/* The same for the logic table (flag 0x200; table index 5): proven with the logic AIR (air_id 2: 523 columns, one
+ * operation per row drawn from the seed).  The table's width must be 523. */
+int bp_ir_set_logic_air(uint64_t ir[BP_IR_WORDS], int on);
 /* public values of a proof container: txn_before, txn_after, gas_before, gas_after, root_before[4],
  * root_after[4], block_number */
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out);

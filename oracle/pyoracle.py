@@ -16,7 +16,8 @@ u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("core.c", "stark.c", "proofgen.c", "gl.h", "oracle.h",
+    srcs = [os.path.join(_HERE, f) for f in ("core.c", "stark.c", "proofgen.c", "keccak_air.c", "keccak_air_body.inc",
+                                              "logic_air.c", "logic_air_body.inc", "gl.h", "oracle.h",
                                               "poseidon_rc.inc", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
@@ -91,6 +92,7 @@ def lib():
     L.orc_synth_trace.argtypes = [u6, cfgp, vp, u64p]
     L.orc_keccak_f.argtypes = [u64p]
     L.orc_keccak_trace.argtypes = [u6, vp, u, u64p]
+    L.orc_logic_trace.argtypes = [u6, vp, u, u64p]
     L.orc_commit_values.argtypes = [u64p, u, sz, u, u]
     L.orc_commit_values.restype = vp
     L.orc_commit_coeffs.argtypes = [u64p, u, sz, u, u]
@@ -222,8 +224,9 @@ class PyChallenger:
         return o
 
 
-AIR_SYNTHETIC, AIR_KECCAK_F = 0, 1
+AIR_SYNTHETIC, AIR_KECCAK_F, AIR_LOGIC = 0, 1, 2
 KECCAK_COLS = 2430
+LOGIC_COLS = 523
 
 
 def make_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, num_queries=84, pow_bits=16,
@@ -246,6 +249,16 @@ def keccak_trace(log_n, seed=0, inputs=None):
     if inp is not None:
         assert inp.shape == (((1 << log_n) + 23) // 24, 25)
     lib().orc_keccak_trace(seed, inp.ctypes.data if inp is not None else None, log_n, out)
+    return out
+
+
+def logic_trace(log_n, seed=0, inputs=None):
+    """orc_logic_trace: the AIR-2 witness [523, 2^log_n]; inputs [2^log_n, 9] (code, operand 0, operand 1) or seeded."""
+    out = np.zeros((LOGIC_COLS, 1 << log_n), dtype=np.uint64)
+    inp = np.ascontiguousarray(inputs, dtype=np.uint64) if inputs is not None else None
+    if inp is not None:
+        assert inp.shape == (1 << log_n, 9)
+    lib().orc_logic_trace(seed, inp.ctypes.data if inp is not None else None, log_n, out)
     return out
 
 

@@ -20,6 +20,9 @@
 //                      written from the public specification (FIPS 202 / the Keccak reference), in the style of
 //                      upstream's keccak table (~2.4 k columns, constants.rs:12) but NOT upstream's column layout,
 //                      which nothing under /root/reference shows [UPSTREAM-UNVERIFIED].
+// AIR 2  logic         bitwise AND / OR / XOR of two 256-bit words per row (the zkEVM's logic table, prover_state.rs:85-93
+//                      "logic"), 523 columns, degree 3; written from the definition of the three operations, NOT
+//                      upstream's column layout [UPSTREAM-UNVERIFIED].
 // The cross-table-lookup-like auxiliary columns (running products over trace columns 8k, 8k+1) are a property of
 // the protocol, not of an AIR (as upstream's CTL checks sit beside Stark::eval): their constraints follow the AIR's
 // in the list for every air_id.
@@ -30,7 +33,7 @@
 namespace bpg {
 namespace air {
 
-constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, COUNT = 2;
+constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, COUNT = 3;
 
 struct Shape {
   uint32_t air_id, n_cols, n_const, deg_pow;
@@ -358,14 +361,79 @@ GL_HD void round(const uint64_t a[25], uint32_t rnd, Round& o) {
 }
 }  // namespace keccak
 
+// ------------------------------------------------------------------------------------------ AIR 2: logic
+// One operation per row on two 256-bit words given as bits; the result as eight 32-bit limbs (the form in which the
+// other tables of a zkEVM would look it up).  A row whose three flags are all zero is padding: its result is zero.
+// Columns:
+//   0 .. 2       is_and, is_or, is_xor
+//   3 .. 258     input 0 bits: 3 + 32 k + z   (limb k, bit z)
+//   259 .. 514   input 1 bits: 259 + 32 k + z
+//   515 .. 522   result limbs
+// Constraints (all rows):
+//   L0  0 .. 2       f (f - 1) for the three flags                                               deg 2
+//   L1  3            s (s - 1), s = is_and + is_or + is_xor: at most one operation               deg 2
+//   L2  4 .. 515     b (b - 1) for the input bits: 4 + 256 j + 32 k + z                          deg 2
+//   L3  516 .. 523   result_k - sum_z 2^z (p (a_z + b_z) + q a_z b_z),  p = is_or + is_xor,      deg 3
+//                    q = is_and - is_or - 2 is_xor   (and: ab, or: a + b - ab, xor: a + b - 2ab)
+// Units: unit k = the bits of limb k of both inputs (L2) and L3 + k; unit 0 also takes L0 and L1.
+namespace logic {
+constexpr uint32_t N_COLS = 523, N_CONSTRAINTS = 524, N_UNITS = 8;
+constexpr uint32_t COL_OP = 0, COL_IN0 = 3, COL_IN1 = 259, COL_RES = 515;
+constexpr uint32_t L0 = 0, L1 = 3, L2 = 4, L3 = 516;
+constexpr uint32_t OP_NONE = 0, OP_AND = 1, OP_OR = 2, OP_XOR = 3;
+GL_HD uint32_t apply(uint32_t op, uint32_t a, uint32_t b) {
+  return op == OP_AND ? (a & b) : op == OP_OR ? (a | b) : op == OP_XOR ? (a ^ b) : 0u;
+}
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(uint32_t k, const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const T f_and = row.loc(COL_OP), f_or = row.loc(COL_OP + 1), f_xor = row.loc(COL_OP + 2);
+  if (k == 0) {
+    const T s = F::add(F::add(f_and, f_or), f_xor);
+    const T x4[4] = {f_and, f_or, f_xor, s};
+    T xx[4];
+    F::mul4(x4, x4, xx);
+#pragma unroll
+    for (uint32_t i = 0; i < 3; i++) out.all(L0 + i, F::sub(xx[i], x4[i]));
+    out.all(L1, F::sub(xx[3], s));
+  }
+  T sum = F::k(0), prod = F::k(0);  // sum_z 2^z (a_z + b_z) and sum_z 2^z a_z b_z, Horner from the top bit down
+#pragma unroll 1
+  for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
+    T a[4], b[4], aa[4], bb[4], ab[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      a[i] = row.loc(COL_IN0 + 32 * k + z0 - 1 - i);
+      b[i] = row.loc(COL_IN1 + 32 * k + z0 - 1 - i);
+    }
+    F::mul4(a, a, aa);
+    F::mul4(b, b, bb);
+    F::mul4(a, b, ab);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      const uint32_t z = z0 - 1 - i;
+      out.all(L2 + 32 * k + z, F::sub(aa[i], a[i]));
+      out.all(L2 + 256 + 32 * k + z, F::sub(bb[i], b[i]));
+      sum = F::add(F::dbl(sum), F::add(a[i], b[i]));
+      prod = F::add(F::dbl(prod), ab[i]);
+    }
+  }
+  const T p = F::add(f_or, f_xor), q = F::sub(F::sub(f_and, f_or), F::dbl(f_xor));
+  out.all(L3 + k, F::sub(row.loc(COL_RES + k), F::add(F::mul(p, sum), F::mul(q, prod))));
+}
+}  // namespace logic
+
 // ------------------------------------------------------------------------------------------ registry
 GL_HD uint32_t n_constraints(const Shape& s) {
-  return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS : synthetic::n_constraints(s);
+  return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS : s.air_id == LOGIC ? logic::N_CONSTRAINTS : synthetic::n_constraints(s);
 }
-GL_HD uint32_t n_units(const Shape& s) { return s.air_id == KECCAK_F ? keccak::N_UNITS : synthetic::n_units(s); }
+GL_HD uint32_t n_units(const Shape& s) {
+  return s.air_id == KECCAK_F ? keccak::N_UNITS : s.air_id == LOGIC ? logic::N_UNITS : synthetic::n_units(s);
+}
 template <class T, class Row, class Emit>
 GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   if (s.air_id == KECCAK_F) keccak::eval_unit<T>(unit, row, out);
+  else if (s.air_id == LOGIC) logic::eval_unit<T>(unit, row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
@@ -397,6 +465,7 @@ inline const Info* info(uint32_t air_id) {
   static const Info table[COUNT] = {
       {SYNTHETIC, "synthetic", 0, 4096, 3},
       {KECCAK_F, "keccak_f", keccak::N_COLS, 0, 3},
+      {LOGIC, "logic", logic::N_COLS, 0, 3},
   };
   return air_id < COUNT ? &table[air_id] : nullptr;
 }

@@ -97,6 +97,11 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
   Worker* wp = take_worker(device, bytes, &rc);
   if (!wp) return rc;
   Worker& w = *wp;
+  // parked again (or freed) on every way out, an exception included: the worker holds the arena
+  struct Parker {
+    Worker* w;
+    ~Parker() { park_worker(w); }
+  } parker{wp};
   auto body = [&]() -> int {
     Challenger ch;
     Committed consts, trace;
@@ -112,6 +117,7 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
     uint64_t* d_trace = w.arena.alloc_words((size_t)c.n_cols * N);
     if (!d_trace) return fail(BP_ERR_DEVICE, "arena exhausted");
     int r2 = c.air_id == air::KECCAK_F ? launch_keccak_trace(d_trace, nullptr, c.log_n, seed, w.stream)
+             : c.air_id == air::LOGIC  ? launch_logic_trace(d_trace, nullptr, c.log_n, seed, w.stream)
                                        : launch_synth_trace(d_trace, d_consts, c.log_n, c.n_cols, c.n_const, c.deg_pow, seed, w.stream);
     if (r2) return r2;
     if ((r2 = commit(w, d_trace, c.n_cols, c.log_n, c.rate_bits, c.cap_height, false, &trace))) return r2;
@@ -127,8 +133,9 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
     return BP_OK;
   };
   rc = body();
-  if (rc == BP_OK) rc = w.wait();  // nothing of this call is still in flight when the worker is parked
-  park_worker(wp);
+  // nothing of this call is still in flight when the worker is parked (a failed call keeps its own message)
+  if (rc) (void)hipStreamSynchronize(w.stream);
+  else rc = w.wait();
   return rc;
 }
 BPG_ABI_CATCH("bp_stark_prove_air")
@@ -190,6 +197,9 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
     namespace kk = air::keccak;
     fam(kk::F0, 24, 2, 1); fam(kk::F1, 24, 1, 1); fam(kk::F2, 1984, 0, 2); fam(kk::F3, 320, 0, 3); fam(kk::F4, 320, 0, 3);
     fam(kk::F5, 50, 0, 3); fam(kk::F6, 50, 0, 3); fam(kk::F7, 2, 0, 1); fam(kk::F8, 2, 0, 2); fam(kk::F9, 50, 1, 2);
+  } else if (air_id == air::LOGIC) {
+    namespace lg = air::logic;
+    fam(lg::L0, 3, 0, 2); fam(lg::L1, 1, 0, 2); fam(lg::L2, 512, 0, 2); fam(lg::L3, 8, 0, 3);
   } else {
     // interleaved per group of four columns: 3g all rows, 3g + 1 transition, 3g + 2 first row
     fam(0, C / 4, 0, 2); fam(1, C / 4, 1, 3 * dp); fam(2, C / 4, 2, 1);
@@ -206,6 +216,13 @@ int bp_keccak_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uin
   return launch_keccak_trace(d_trace_out, d_inputs, log_n, seed, as_stream(stream));
 }
 BPG_ABI_CATCH("bp_keccak_trace")
+
+int bp_logic_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream) try {
+  if (!d_trace_out) return fail(BP_ERR_INVALID_INPUT, "bp_logic_trace: null output");
+  if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_logic_trace: log_n out of range");
+  return launch_logic_trace(d_trace_out, d_inputs, log_n, seed, as_stream(stream));
+}
+BPG_ABI_CATCH("bp_logic_trace")
 
 // ---- L0: the remaining per-stage entry points of SURVEY.md section 8(b) -------------------------------
 

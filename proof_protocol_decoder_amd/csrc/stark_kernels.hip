@@ -123,6 +123,37 @@ keccak_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ input
   }
 }
 
+// ---------------------------------------------------------------- logic witness (AIR 2, air.hpp)
+// One operation per row.  `inputs` ([row][9]: operation code 0 none / 1 and / 2 or / 3 xor, then the four 64-bit words
+// of each operand, least significant first) or, when null, drawn from the seed -- the same stream the oracle draws:
+// code = splitmix64(seed ^ (0xFF << 32) ^ row) & 3, word w of operand j = splitmix64(seed ^ ((1 + 4 j + w) << 32) ^ row).
+// grid.y = 0: flags, result limbs and the bits of operand 0; 1: the bits of operand 1.  Stores coalesce across rows.
+__global__ void __launch_bounds__(256)
+logic_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  namespace lg = bpg::air::logic;
+  const uint32_t n = 1u << log_n;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t op = (uint32_t)(inputs ? inputs[(uint64_t)i * 9] : splitmix64(seed ^ (0xFFull << 32) ^ i)) & 3u;
+  uint64_t w[2][4];
+  for (uint32_t j = 0; j < 2; j++)
+    for (uint32_t k = 0; k < 4; k++)
+      w[j][k] = inputs ? inputs[(uint64_t)i * 9 + 1 + 4 * j + k] : splitmix64(seed ^ ((uint64_t)(1 + 4 * j + k) << 32) ^ i);
+  auto put = [&](uint32_t col, uint64_t v) { t[(uint64_t)col * n + i] = v; };
+  const uint32_t j = blockIdx.y;
+  if (j == 0) {
+    put(lg::COL_OP, op == lg::OP_AND);
+    put(lg::COL_OP + 1, op == lg::OP_OR);
+    put(lg::COL_OP + 2, op == lg::OP_XOR);
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t a = (uint32_t)(w[0][k >> 1] >> (32 * (k & 1))), b = (uint32_t)(w[1][k >> 1] >> (32 * (k & 1)));
+      put(lg::COL_RES + k, lg::apply(op, a, b));
+    }
+  }
+  for (uint32_t z = 0; z < 256; z++) put((j ? lg::COL_IN1 : lg::COL_IN0) + z, (w[j][z >> 6] >> (z & 63)) & 1);
+}
+
 // ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
 // z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
 // One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
@@ -274,6 +305,7 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
   for (uint32_t u = u0; u < u1; u++) {
     if (u < q.n_air_units) {
       if constexpr (AIR == bpg::air::KECCAK_F) bpg::air::keccak::eval_unit<uint64_t>(u, row, out);
+      else if constexpr (AIR == bpg::air::LOGIC) bpg::air::logic::eval_unit<uint64_t>(u, row, out);
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -811,6 +843,12 @@ int launch_keccak_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t lo
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_logic_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 2);
+  logic_trace_kernel<<<grid, 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
                hipStream_t st) {
   if (!n_aux) return BP_OK;
@@ -831,6 +869,7 @@ int launch_quotient(const QuotArgs& q, hipStream_t st) {
   const uint32_t n_units = q.n_air_units + q.n_ctl_units, wg_rows = ceil_div(n_units, q.units_per_wg);
   dim3 g1(ceil_div(rows, 256), wg_rows);
   if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(q);
+  else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(q);
   else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(q);
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {

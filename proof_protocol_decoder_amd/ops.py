@@ -74,6 +74,7 @@ def field_ops(a, b):
 
 AIR_SYNTHETIC, AIR_KECCAK_F = 0, 1
 KECCAK_COLS = 2430
+LOGIC_COLS = 523
 
 
 def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
@@ -82,6 +83,17 @@ def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
     d = AirDesc()
     check(lib().bp_air_describe(air_id, n_cols, n_const, deg_pow, C.byref(d)))
     return d
+
+
+def logic_trace(log_n, seed=0, inputs=None, device="cuda"):
+    """bp_logic_trace: the AIR-2 witness [523, 2^log_n]; inputs [2^log_n, 9] int64 on the device (operation code, the
+    four words of operand 0, of operand 1), or drawn from `seed`."""
+    out = torch.empty((LOGIC_COLS, 1 << log_n), dtype=torch.int64, device=device)
+    if inputs is not None:
+        _require_cuda(inputs)
+        assert inputs.shape == (1 << log_n, 9)
+    check(lib().bp_logic_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
+    return out
 
 
 def keccak_trace(log_n, seed=0, inputs=None, device="cuda"):

@@ -61,6 +61,7 @@ def _bind():
     L.bp_ir_encode_dummy.argtypes = [C.c_uint64] * 3 + [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint32),
                                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.bp_ir_set_keccak_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.bp_ir_set_logic_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_keccak256_permutation_inputs.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t,
                                                   C.POINTER(C.c_size_t)]
     L.bp_generate_txn_proof_keccak.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t,
@@ -119,6 +120,7 @@ class TxnProofGenIR:
     keccak_air: bool = False   # the Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1, 2430 columns)
     keccak_inputs: tuple = None   # ... attesting THESE permutations ([n][25] lanes) instead of seeded ones; not part of
                                   # the 25-word IR: handed to bp_generate_txn_proof_keccak beside it
+    logic_air: bool = False    # the logic table (index 5) is proven with the logic AIR (AIR 2, 523 columns)
 
     def to_bytes(self):
         L = _bind()
@@ -135,6 +137,8 @@ class TxnProofGenIR:
                                  root, self.seed, logs, widths, out))
         if self.keccak_air:
             check(L.bp_ir_set_keccak_air(out, 1))
+        if self.logic_air:
+            check(L.bp_ir_set_logic_air(out, 1))
         return struct.pack("<%dQ" % IR_WORDS, *out)
 
 
