@@ -66,8 +66,8 @@ void orc_fri_fold(const gl2_t* in, gl2_t* out, unsigned log_m, unsigned arity_bi
 typedef struct {
   uint32_t log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits,
       arity_bits, final_poly_bits;
-  uint32_t air_id; /* 0: the synthetic AIR (stark.c), 1: Keccak-f[1600] (keccak_air.c), 2: logic (logic_air.c); header
-                      word 14 of a proof */
+  uint32_t air_id; /* 0: the synthetic AIR (stark.c), 1: Keccak-f[1600] (keccak_air.c), 2: logic (logic_air.c), 3: memory
+                      (memory_air.c); header word 14 of a proof */
 } orc_stark_cfg;
 #define ORC_AIR_SYNTHETIC 0u
 #define ORC_AIR_KECCAK_F 1u
@@ -76,6 +76,9 @@ typedef struct {
 #define ORC_AIR_LOGIC 2u
 #define ORC_LOGIC_COLS 523u
 #define ORC_LOGIC_CONSTRAINTS 524u
+#define ORC_AIR_MEMORY 3u
+#define ORC_MEMORY_COLS 44u
+#define ORC_MEMORY_CONSTRAINTS 60u
 
 /* starky ConstraintConsumer: acc_j = acc_j * alpha_j + constraint, in list order; base field (the LDE coset)
  * and extension field (the verifier at zeta; the alphas stay in the base field). */
@@ -105,6 +108,10 @@ void orc_keccak_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer
 void orc_logic_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
 void orc_logic_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
 void orc_logic_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
+/* memory_air.c */
+void orc_memory_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
+void orc_memory_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
+void orc_memory_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
 
 uint32_t orc_cfg_n_aux(const orc_stark_cfg* c);
 uint32_t orc_cfg_n_quot(const orc_stark_cfg* c);

@@ -23,6 +23,11 @@
 // AIR 2  logic         bitwise AND / OR / XOR of two 256-bit words per row (the zkEVM's logic table, prover_state.rs:85-93
 //                      "logic"), 523 columns, degree 3; written from the definition of the three operations, NOT
 //                      upstream's column layout [UPSTREAM-UNVERIFIED].
+// AIR 3  memory        a memory log sorted by (address, timestamp), one operation per row, 44 columns, degree 3: a read
+//                      returns what the previous operation on the address left there (zero for a first access);
+//                      the ordering is enforced by a 32-bit decomposition of the gap to the next row.  In the style
+//                      of the zkEVM's memory table (prover_state.rs:85-93 "memory"), its own layout
+//                      [UPSTREAM-UNVERIFIED].
 // The cross-table-lookup-like auxiliary columns (running products over trace columns 8k, 8k+1) are a property of
 // the protocol, not of an AIR (as upstream's CTL checks sit beside Stark::eval): their constraints follow the AIR's
 // in the list for every air_id.
@@ -33,7 +38,7 @@
 namespace bpg {
 namespace air {
 
-constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, COUNT = 3;
+constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, COUNT = 4;
 
 struct Shape {
   uint32_t air_id, n_cols, n_const, deg_pow;
@@ -423,17 +428,107 @@ GL_HD void eval_unit(uint32_t k, const Row& row, Emit& out) {
 }
 }  // namespace logic
 
+// ------------------------------------------------------------------------------------------ AIR 3: memory
+// Rows are the operations of a memory log sorted by (address, timestamp); addresses and timestamps are below 2^32.
+// Columns:
+//   0          is_read (0 = write)
+//   1          address
+//   2          timestamp
+//   3 .. 10    value, eight 32-bit limbs (their range is the business of the table that looks the value up)
+//   11         address_changed: the NEXT row is on another address
+//   12 .. 43   bits of the gap to the next row: address' - address - 1 if address_changed, else timestamp' - timestamp - 1
+// Constraints:
+//   M0  0          all rows    is_read (is_read - 1)                                             deg 2
+//   M1  1          all rows    address_changed (address_changed - 1)                             deg 2
+//   M2  2 .. 33    all rows    g (g - 1) for the gap bits                                        deg 2
+//   M3  34         transition  (1 - address_changed) (address' - address)                        deg 2
+//   M4  35         transition  address_changed (address' - address - 1 - G)
+//                              + (1 - address_changed) (timestamp' - timestamp - 1 - G), G = sum_z 2^z g_z   deg 2
+//                              (a gap of 32 bits: addresses strictly increase across changes, timestamps within)
+//   M5  36 .. 43   transition  (1 - address_changed) is_read' (value'_k - value_k)              deg 3
+//   M6  44 .. 51   transition  address_changed is_read' value'_k       (memory starts as zeros)  deg 3
+//   M7  52 .. 59   first row   is_read value_k                                                   deg 2
+// One unit.
+namespace memory {
+constexpr uint32_t N_COLS = 44, N_CONSTRAINTS = 60, N_UNITS = 1;
+constexpr uint32_t COL_READ = 0, COL_ADDR = 1, COL_TS = 2, COL_VAL = 3, COL_CHG = 11, COL_GAP = 12;
+constexpr uint32_t M0 = 0, M1 = 1, M2 = 2, M3 = 34, M4 = 35, M5 = 36, M6 = 44, M7 = 52;
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const T rd = row.loc(COL_READ), chg = row.loc(COL_CHG), rdn = row.nxt(COL_READ);
+  const T same = F::sub(F::k(1), chg);
+  {
+    const T x4[4] = {rd, chg, same, chg}, y4[4] = {rd, chg, rdn, rdn};
+    T p4[4];
+    F::mul4(x4, y4, p4);
+    out.all(M0, F::sub(p4[0], rd));
+    out.all(M1, F::sub(p4[1], chg));
+    T gap = F::k(0);
+#pragma unroll 1
+    for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
+      T g[4], gg[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) g[i] = row.loc(COL_GAP + z0 - 1 - i);
+      F::mul4(g, g, gg);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        out.all(M2 + z0 - 1 - i, F::sub(gg[i], g[i]));
+        gap = F::add(F::dbl(gap), g[i]);
+      }
+    }
+    const T da = F::sub(row.nxt(COL_ADDR), row.loc(COL_ADDR)), dt = F::sub(row.nxt(COL_TS), row.loc(COL_TS));
+    const T g1 = F::add(gap, F::k(1));
+    const T a4[4] = {same, chg, same, same}, b4[4] = {da, F::sub(da, g1), F::sub(dt, g1), same};
+    T q4[4];
+    F::mul4(a4, b4, q4);
+    out.transition(M3, q4[0]);
+    out.transition(M4, F::add(q4[1], q4[2]));
+    const T same_read = p4[2], new_read = p4[3];  // (1 - changed) is_read', changed is_read'
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < 8; k0 += 4) {
+      T v[4], vn[4], dv[4], sr[4], nr[4], r1[4], r2[4], r3[4], rr[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        v[i] = row.loc(COL_VAL + k0 + i);
+        vn[i] = row.nxt(COL_VAL + k0 + i);
+        dv[i] = F::sub(vn[i], v[i]);
+        sr[i] = same_read;
+        nr[i] = new_read;
+        rr[i] = rd;
+      }
+      F::mul4(sr, dv, r1);
+      F::mul4(nr, vn, r2);
+      F::mul4(rr, v, r3);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        out.transition(M5 + k0 + i, r1[i]);
+        out.transition(M6 + k0 + i, r2[i]);
+        out.first(M7 + k0 + i, r3[i]);
+      }
+    }
+  }
+}
+}  // namespace memory
+
 // ------------------------------------------------------------------------------------------ registry
 GL_HD uint32_t n_constraints(const Shape& s) {
-  return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS : s.air_id == LOGIC ? logic::N_CONSTRAINTS : synthetic::n_constraints(s);
+  return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS
+         : s.air_id == LOGIC  ? logic::N_CONSTRAINTS
+         : s.air_id == MEMORY ? memory::N_CONSTRAINTS
+                              : synthetic::n_constraints(s);
 }
 GL_HD uint32_t n_units(const Shape& s) {
-  return s.air_id == KECCAK_F ? keccak::N_UNITS : s.air_id == LOGIC ? logic::N_UNITS : synthetic::n_units(s);
+  return s.air_id == KECCAK_F ? keccak::N_UNITS
+         : s.air_id == LOGIC  ? logic::N_UNITS
+         : s.air_id == MEMORY ? memory::N_UNITS
+                              : synthetic::n_units(s);
 }
 template <class T, class Row, class Emit>
 GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   if (s.air_id == KECCAK_F) keccak::eval_unit<T>(unit, row, out);
   else if (s.air_id == LOGIC) logic::eval_unit<T>(unit, row, out);
+  else if (s.air_id == MEMORY) memory::eval_unit<T>(row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
@@ -466,6 +561,7 @@ inline const Info* info(uint32_t air_id) {
       {SYNTHETIC, "synthetic", 0, 4096, 3},
       {KECCAK_F, "keccak_f", keccak::N_COLS, 0, 3},
       {LOGIC, "logic", logic::N_COLS, 0, 3},
+      {MEMORY, "memory", memory::N_COLS, 0, 3},
   };
   return air_id < COUNT ? &table[air_id] : nullptr;
 }

@@ -154,6 +154,52 @@ logic_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs
   for (uint32_t z = 0; z < 256; z++) put((j ? lg::COL_IN1 : lg::COL_IN0) + z, (w[j][z >> 6] >> (z & 63)) & 1);
 }
 
+// ---------------------------------------------------------------- memory witness (AIR 3, air.hpp)
+// One operation per row, rows sorted by (address, timestamp).  `inputs` ([row][11]: is_read, address, timestamp, eight
+// value limbs; already sorted -- an unsorted log yields a witness the verifier rejects) or, when null, a log drawn
+// from the seed, four operations per address, the same the oracle draws (h(c, i) = splitmix64(seed ^ (c << 32) ^ i)):
+//   address of group g = 4 g + (h(0xA0, g) & 3), timestamp of row i = 8 i + (h(0xA1, i) & 7), is_read = h(0xA2, i) & 1,
+//   a write stores limbs h(0xB0 + k, i) & 0xFFFFFFFF, a read returns what the group's previous operation left (0 first).
+__global__ void __launch_bounds__(256)
+memory_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  namespace mm = bpg::air::memory;
+  const uint32_t n = 1u << log_n;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto h = [&](uint64_t c, uint64_t x) { return splitmix64(seed ^ (c << 32) ^ x); };
+  uint64_t rd, addr, ts, v[8], addr_n = 0, ts_n = 0;
+  if (inputs) {
+    const uint64_t* r = inputs + (uint64_t)i * 11;
+    rd = r[0] & 1; addr = r[1]; ts = r[2];
+    for (uint32_t k = 0; k < 8; k++) v[k] = r[3 + k];
+    if (i + 1 < n) { addr_n = r[11 + 1]; ts_n = r[11 + 2]; }
+  } else {
+    const uint32_t g = i >> 2, j = i & 3;
+    addr = 4ull * g + (h(0xA0, g) & 3);
+    addr_n = j == 3 ? 4ull * (g + 1) + (h(0xA0, g + 1) & 3) : addr;
+    ts = 8ull * i + (h(0xA1, i) & 7);
+    ts_n = 8ull * (i + 1) + (h(0xA1, i + 1) & 7);
+    for (uint32_t k = 0; k < 8; k++) v[k] = 0;
+    rd = 0;
+    for (uint32_t jj = 0; jj <= j; jj++) {  // replay the group up to this row
+      const uint32_t ii = 4 * g + jj;
+      rd = h(0xA2, ii) & 1;
+      if (!rd)
+        for (uint32_t k = 0; k < 8; k++) v[k] = h(0xB0 + k, ii) & 0xFFFFFFFFull;
+    }
+  }
+  const bool last = i + 1 == n, chg = !last && addr_n != addr;
+  const uint32_t gap = last ? 0u : (uint32_t)(chg ? addr_n - addr - 1 : ts_n - ts - 1);
+  auto put = [&](uint32_t col, uint64_t x) { t[(uint64_t)col * n + i] = x; };
+  put(mm::COL_READ, rd);
+  put(mm::COL_ADDR, gl::canon(addr));
+  put(mm::COL_TS, gl::canon(ts));
+  for (uint32_t k = 0; k < 8; k++) put(mm::COL_VAL + k, gl::canon(v[k]));
+  put(mm::COL_CHG, chg);
+  for (uint32_t z = 0; z < 32; z++) put(mm::COL_GAP + z, (gap >> z) & 1);
+}
+
 // ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
 // z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
 // One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
@@ -306,6 +352,7 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
     if (u < q.n_air_units) {
       if constexpr (AIR == bpg::air::KECCAK_F) bpg::air::keccak::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::LOGIC) bpg::air::logic::eval_unit<uint64_t>(u, row, out);
+      else if constexpr (AIR == bpg::air::MEMORY) bpg::air::memory::eval_unit<uint64_t>(row, out);
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -849,6 +896,11 @@ int launch_logic_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_memory_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
+  memory_trace_kernel<<<ceil_div((uint64_t)1 << log_n, 256), 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
                hipStream_t st) {
   if (!n_aux) return BP_OK;
@@ -870,6 +922,7 @@ int launch_quotient(const QuotArgs& q, hipStream_t st) {
   dim3 g1(ceil_div(rows, 256), wg_rows);
   if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(q);
+  else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(q);
   else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(q);
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {

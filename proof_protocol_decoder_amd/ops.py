@@ -75,6 +75,7 @@ def field_ops(a, b):
 AIR_SYNTHETIC, AIR_KECCAK_F = 0, 1
 KECCAK_COLS = 2430
 LOGIC_COLS = 523
+MEMORY_COLS = 44
 
 
 def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
@@ -93,6 +94,17 @@ def logic_trace(log_n, seed=0, inputs=None, device="cuda"):
         _require_cuda(inputs)
         assert inputs.shape == (1 << log_n, 9)
     check(lib().bp_logic_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
+    return out
+
+
+def memory_trace(log_n, seed=0, inputs=None, device="cuda"):
+    """bp_memory_trace: the AIR-3 witness [44, 2^log_n]; inputs [2^log_n, 11] int64 on the device (is_read, address,
+    timestamp, eight value limbs; sorted by address then timestamp), or a log drawn from `seed`."""
+    out = torch.empty((MEMORY_COLS, 1 << log_n), dtype=torch.int64, device=device)
+    if inputs is not None:
+        _require_cuda(inputs)
+        assert inputs.shape == (1 << log_n, 11)
+    check(lib().bp_memory_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
     return out
 
 
