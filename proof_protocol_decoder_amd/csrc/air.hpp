@@ -453,60 +453,39 @@ namespace memory {
 constexpr uint32_t N_COLS = 44, N_CONSTRAINTS = 60, N_UNITS = 1;
 constexpr uint32_t COL_READ = 0, COL_ADDR = 1, COL_TS = 2, COL_VAL = 3, COL_CHG = 11, COL_GAP = 12;
 constexpr uint32_t M0 = 0, M1 = 1, M2 = 2, M3 = 34, M4 = 35, M5 = 36, M6 = 44, M7 = 52;
+// (Sixty constraints on 44 columns: the plain multiply is used outside the bit loop -- the carry-chain groups of four
+// would hold three sets of masks next to the column offsets and spill scalars for nothing.)
 template <class T, class Row, class Emit>
 GL_HD void eval_unit(const Row& row, Emit& out) {
   typedef Ops<T> F;
   const T rd = row.loc(COL_READ), chg = row.loc(COL_CHG), rdn = row.nxt(COL_READ);
   const T same = F::sub(F::k(1), chg);
-  {
-    const T x4[4] = {rd, chg, same, chg}, y4[4] = {rd, chg, rdn, rdn};
-    T p4[4];
-    F::mul4(x4, y4, p4);
-    out.all(M0, F::sub(p4[0], rd));
-    out.all(M1, F::sub(p4[1], chg));
-    T gap = F::k(0);
+  out.all(M0, F::sub(F::mul(rd, rd), rd));
+  out.all(M1, F::sub(F::mul(chg, chg), chg));
+  T gap = F::k(0);
 #pragma unroll 1
-    for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
-      T g[4], gg[4];
+  for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
+    T g[4], gg[4];
 #pragma unroll
-      for (uint32_t i = 0; i < 4; i++) g[i] = row.loc(COL_GAP + z0 - 1 - i);
-      F::mul4(g, g, gg);
+    for (uint32_t i = 0; i < 4; i++) g[i] = row.loc(COL_GAP + z0 - 1 - i);
+    F::mul4(g, g, gg);
 #pragma unroll
-      for (uint32_t i = 0; i < 4; i++) {
-        out.all(M2 + z0 - 1 - i, F::sub(gg[i], g[i]));
-        gap = F::add(F::dbl(gap), g[i]);
-      }
+    for (uint32_t i = 0; i < 4; i++) {
+      out.all(M2 + z0 - 1 - i, F::sub(gg[i], g[i]));
+      gap = F::add(F::dbl(gap), g[i]);
     }
-    const T da = F::sub(row.nxt(COL_ADDR), row.loc(COL_ADDR)), dt = F::sub(row.nxt(COL_TS), row.loc(COL_TS));
-    const T g1 = F::add(gap, F::k(1));
-    const T a4[4] = {same, chg, same, same}, b4[4] = {da, F::sub(da, g1), F::sub(dt, g1), same};
-    T q4[4];
-    F::mul4(a4, b4, q4);
-    out.transition(M3, q4[0]);
-    out.transition(M4, F::add(q4[1], q4[2]));
-    const T same_read = p4[2], new_read = p4[3];  // (1 - changed) is_read', changed is_read'
+  }
+  const T da = F::sub(row.nxt(COL_ADDR), row.loc(COL_ADDR)), dt = F::sub(row.nxt(COL_TS), row.loc(COL_TS));
+  const T g1 = F::add(gap, F::k(1));
+  out.transition(M3, F::mul(same, da));
+  out.transition(M4, F::add(F::mul(chg, F::sub(da, g1)), F::mul(same, F::sub(dt, g1))));
+  const T same_read = F::mul(same, rdn), new_read = F::mul(chg, rdn);
 #pragma unroll 1
-    for (uint32_t k0 = 0; k0 < 8; k0 += 4) {
-      T v[4], vn[4], dv[4], sr[4], nr[4], r1[4], r2[4], r3[4], rr[4];
-#pragma unroll
-      for (uint32_t i = 0; i < 4; i++) {
-        v[i] = row.loc(COL_VAL + k0 + i);
-        vn[i] = row.nxt(COL_VAL + k0 + i);
-        dv[i] = F::sub(vn[i], v[i]);
-        sr[i] = same_read;
-        nr[i] = new_read;
-        rr[i] = rd;
-      }
-      F::mul4(sr, dv, r1);
-      F::mul4(nr, vn, r2);
-      F::mul4(rr, v, r3);
-#pragma unroll
-      for (uint32_t i = 0; i < 4; i++) {
-        out.transition(M5 + k0 + i, r1[i]);
-        out.transition(M6 + k0 + i, r2[i]);
-        out.first(M7 + k0 + i, r3[i]);
-      }
-    }
+  for (uint32_t k = 0; k < 8; k++) {
+    const T v = row.loc(COL_VAL + k), vn = row.nxt(COL_VAL + k);
+    out.transition(M5 + k, F::mul(same_read, F::sub(vn, v)));
+    out.transition(M6 + k, F::mul(new_read, vn));
+    out.first(M7 + k, F::mul(rd, v));
   }
 }
 }  // namespace memory
