@@ -273,11 +273,15 @@ def irs_from_block_trace(block_trace, block_number, table_log_n, table_width, ha
     return pad_with_dummy_irs(irs, block_number, root0, table_log_n, table_width, has_withdrawals)[0]
 
 
-def keccak_inputs_of_generation_inputs(g):
+def keccak_inputs_of_generation_inputs(g, trie_nodes=False):
     """The Keccak-f permutations a transaction's own data asks for: Keccak-256 of `signed_txn` (the transaction hash)
     and of every `contract_code` entry (the code hashes the decoder keys them by, decoding.rs:131-145), as the states
-    that go into the permutations, in that order (code in ascending hash order).  The zkEVM's Keccak table holds more
-    (trie nodes, KECCAK256 opcodes): those come from executing the transaction, which is upstream-only."""
+    that go into the permutations, in that order (code in ascending hash order).
+    trie_nodes: then also the hashing of the entry's partial tries (decoding.rs:179-217: state, transactions, receipts,
+    storage tries in their order) -- every node that is referenced by hash, children before parents, which is the bulk
+    of what a zkEVM's Keccak table holds; each trie's last digest is checked against its root.  What remains
+    upstream-only is the hashing done WHILE executing (KECCAK256 opcodes, the tries after the transaction)."""
+    from .partial_trie import hashed_node_preimages
     states = []
     if g.signed_txn:
         states += pg.keccak256_permutation_inputs(bytes(g.signed_txn))[1]
@@ -286,10 +290,20 @@ def keccak_inputs_of_generation_inputs(g):
         if digest != bytes(h):
             raise ValueError("contract_code is keyed by a hash that is not the Keccak-256 of its bytes")
         states += st
+    if trie_nodes:
+        tries = [g.tries.state_trie, g.tries.transactions_trie, g.tries.receipts_trie] + [t for _, t in g.tries.storage_tries]
+        for trie in tries:
+            digest = None
+            for enc in hashed_node_preimages(trie.root):
+                digest, st = pg.keccak256_permutation_inputs(enc)
+                states += st
+            if digest is not None and digest != trie.hash():
+                raise ValueError("a partial trie's node hashes do not end in its root")
     return states
 
 
-def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width, keccak_air=False):
+def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width, keccak_air=False,
+                               keccak_trie_nodes=False):
     """`Vec<TxnProofGenIR>` as produced by `decoding.into_txn_proof_gen_ir` (the reference's
     BlockTrace::into_txn_proof_gen_ir: minimal tries, delta replay, dummy padding, withdrawals) -> the IRs this
     library's prover takes.  The zkEVM that would consume the partial tries is upstream-only, so
@@ -301,7 +315,9 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     a prepended dummy is renumbered to its position, as pad_with_dummy_irs documents.
     keccak_air: every entry's Keccak table (index 3) becomes a real Keccak-f[1600] trace (AIR 1, 2430 columns) whose
     permutations are the entry's OWN hashing work (keccak_inputs_of_generation_inputs): the table then attests data of
-    the decoded transaction, not only a seed; its height grows to hold them (24 rows per permutation)."""
+    the decoded transaction, not only a seed; its height grows to hold them (24 rows per permutation).
+    keccak_trie_nodes: the hashing of the entry's partial tries is part of that work (the prover state's Keccak range
+    must then reach the taller tables)."""
     from . import compact
     P = 0xFFFFFFFF00000001
     first = gen_inputs[0].tries.state_trie.hash()
@@ -314,7 +330,7 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
         kw = {}
         table_log_n = base_log_n
         if keccak_air:
-            states = keccak_inputs_of_generation_inputs(g)
+            states = keccak_inputs_of_generation_inputs(g, trie_nodes=keccak_trie_nodes)
             need = max(24 * len(states), 1)
             table_log_n = tuple(max(l, (need - 1).bit_length()) if t == 3 else l for t, l in enumerate(base_log_n))
             kw = dict(keccak_air=True, keccak_inputs=tuple(tuple(s) for s in states))

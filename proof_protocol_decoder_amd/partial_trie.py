@@ -101,6 +101,24 @@ def _ref(n: Optional[Node]) -> bytes:
     return enc if len(enc) < 32 else rlp_bytes(keccak256(enc))
 
 
+def hashed_node_preimages(root: Optional[Node]) -> List[bytes]:
+    """The RLP encodings a hasher of the (partial) trie runs Keccak-256 over: every node that its parent references by
+    hash (an encoding of 32 bytes or more) and the root whatever its length; children before parents.  Hashed-out
+    subtrees contribute nothing (their hash is already there)."""
+    out: List[bytes] = []
+
+    def walk(n, is_root):
+        if n is None or n.kind in ("empty", "hash"):
+            return
+        for c in n.children:
+            walk(c, False)
+        enc = n.encode()
+        if is_root or len(enc) >= 32:
+            out.append(enc)
+    walk(root, True)
+    return out
+
+
 @dataclass
 class PartialTrie:
     root: Node

@@ -509,3 +509,43 @@ def test_keccak_work_of_a_decoded_transaction():
     irs = irs_from_generation_inputs(gis, 17, (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8), keccak_air=True)
     assert all(ir.keccak_air and ir.table_width[3] == 2430 and ir.table_log_n[3] >= 7 for ir in irs)
     assert all(24 * len(ir.keccak_inputs) <= (1 << ir.table_log_n[3]) for ir in irs)
+
+
+def test_keccak_work_includes_the_hashing_of_the_partial_tries():
+    """keccak_inputs_of_generation_inputs(trie_nodes=True): after the transaction and the code come the nodes of the
+    entry's partial tries, children before parents; replaying the sponge over the listed permutations reproduces
+    every node hash, and each trie's last digest is its root (host only)."""
+    import numpy as np
+    from oracle import pyoracle
+    from proof_protocol_decoder_amd import compact
+    from proof_protocol_decoder_amd.block_driver import irs_from_generation_inputs, keccak_inputs_of_generation_inputs
+    from proof_protocol_decoder_amd.partial_trie import hashed_node_preimages
+    pyoracle.build()
+    m = fresh_model()
+    infos = [t for t, _ in block(m)]
+    other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", []), b"\x22" * 32)
+    gis = decoding.into_txn_proof_gen_ir(make_trace(m, infos), other)
+    grew = False
+    for g in gis:
+        base = keccak_inputs_of_generation_inputs(g)
+        states = keccak_inputs_of_generation_inputs(g, trie_nodes=True)
+        assert states[:len(base)] == base
+        tries = [g.tries.state_trie, g.tries.transactions_trie, g.tries.receipts_trie] + [t for _, t in g.tries.storage_tries]
+        k = len(base)
+        for trie in tries:
+            pre = hashed_node_preimages(trie.root)
+            assert all(len(e) >= 32 for e in pre[:-1])          # only the root may be shorter
+            for enc in pre:
+                n = len(enc) // 136 + 1
+                out = pyoracle.keccak_f(np.array(states[k + n - 1], dtype=np.uint64))
+                assert out[:4].astype("<u8").tobytes() == compact.keccak256(enc)
+                k += n
+            if pre:
+                assert compact.keccak256(pre[-1]) == trie.hash()
+        assert k == len(states)
+        grew |= len(states) > len(base)
+    assert grew
+    irs = irs_from_generation_inputs(gis, 17, (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8), keccak_air=True,
+                                     keccak_trie_nodes=True)
+    assert all(24 * len(ir.keccak_inputs) <= (1 << ir.table_log_n[3]) for ir in irs)
+    assert max(ir.table_log_n[3] for ir in irs) > 7           # the tables grew to hold the trie hashing

@@ -336,6 +336,54 @@ def test_agg_and_block_refuse_children_that_do_not_verify(pg, p_state, chain):
     assert e.value.code == -5 and "parent" in e.value.message
 
 
+def test_decoded_transactions_prove_the_hashing_of_their_partial_tries(bpg, pg, oracle):
+    """keccak_trie_nodes=True: the Keccak table of a decoded entry also holds the hashing of its partial tries (state,
+    transactions, receipts, storage), node by node -- so the table is taller than the small state's range and this test
+    builds a state whose Keccak range reaches 2^10 rows.  The device witness ends the state trie's hashing in the
+    entry's pre-state root; proofs equal the oracle's byte for byte; the block verifies."""
+    import test_decoding as td
+    from proof_protocol_decoder_amd import compact, decoding
+    from proof_protocol_decoder_amd.block_driver import BlockDriver, irs_from_generation_inputs
+    from proof_protocol_decoder_amd.partial_trie import hashed_node_preimages
+    cfg = dict(SMALL, table_log_hi=[*SMALL["table_log_hi"][:3], 11, *SMALL["table_log_hi"][4:]])
+    b = pg.ProverStateBuilder()
+    for t, name in enumerate(pg.TABLES):
+        getattr(b, "set_%s_circuit_size" % name)(range(cfg["table_log_lo"][t], cfg["table_log_hi"][t]))
+    b.set(**{k: v for k, v in cfg.items() if not k.startswith("table_")}, n_workers=2, arena_bytes=256 << 20)
+    st, ost = b.build(), oracle.PgState(**cfg)
+    try:
+        m = td.fresh_model()
+        infos = [t for t, _ in td.block(m)]
+        other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", [(td.B, 100)]), b"\x22" * 32)
+        gis = decoding.into_txn_proof_gen_ir(td.make_trace(m, infos, hash_out_storage_of=(td.E,)), other)
+        irs = irs_from_generation_inputs(gis, 23, LOG_N, WIDTH, keccak_air=True, keccak_trie_nodes=True)
+        assert max(ir.table_log_n[3] for ir in irs) >= 9
+        g, ir = next((g, ir) for g, ir in zip(gis, irs) if g.signed_txn)
+        # the permutation that ends the state trie's hashing leaves the pre-state root in the witness
+        n_before = len(g.signed_txn) // 136 + 1 + sum(len(c) // 136 + 1 for c in g.contract_code.values())
+        k = n_before + sum(len(e) // 136 + 1 for e in hashed_node_preimages(g.tries.state_trie.root)) - 1
+        log_n = ir.table_log_n[3]
+        inp = np.zeros((((1 << log_n) + 23) // 24, 25), dtype=np.uint64)
+        inp[:len(ir.keccak_inputs)] = np.array(ir.keccak_inputs, dtype=np.uint64)
+        import torch
+        tr = bpg.ops.keccak_trace(log_n, inputs=torch.from_numpy(inp.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
+        r = 24 * k + 23
+        out = [int(tr[2428, r]) | (int(tr[2429, r]) << 32)] + [int(tr[2314 + 2 * l, r]) | (int(tr[2315 + 2 * l, r]) << 32) for l in (1, 2, 3)]
+        assert b"".join(x.to_bytes(8, "little") for x in out) == g.tries.state_trie.hash()
+        for e in irs:
+            got = pg.generate_txn_proof(st, e)
+            want = ost.txn(list(struct.unpack("<25Q", e.to_bytes())), keccak_inputs=np.array(e.keccak_inputs, dtype=np.uint64).reshape(-1, 25))
+            assert (words(got.intern) == want).all()
+        drv = BlockDriver(st, n_threads=2)
+        try:
+            blk = drv.prove_block_distributed(irs)
+        finally:
+            drv.close()
+        pg.VerifierState.from_prover_state(st).verify(blk)
+    finally:
+        st.close()
+
+
 def test_txn_with_a_real_keccak_table_matches_the_oracle(pg, p_state, o_state):
     """IR flag 0x100: the Keccak table of the transaction (index 3, prover_state.rs:85-93) is a real Keccak-f[1600]
     trace proven with AIR 1 (2430 columns, witness drawn from the seed) next to six synthetic tables.  Byte parity of
