@@ -17,7 +17,7 @@ u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("core.c", "stark.c", "proofgen.c", "keccak_air.c", "keccak_air_body.inc",
-                                              "logic_air.c", "logic_air_body.inc", "memory_air.c", "memory_air_body.inc", "gl.h", "oracle.h",
+                                              "logic_air.c", "logic_air_body.inc", "memory_air.c", "memory_air_body.inc", "arithmetic_air.c", "arithmetic_air_body.inc", "gl.h", "oracle.h",
                                               "poseidon_rc.inc", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
@@ -94,6 +94,7 @@ def lib():
     L.orc_keccak_trace.argtypes = [u6, vp, u, u64p]
     L.orc_logic_trace.argtypes = [u6, vp, u, u64p]
     L.orc_memory_trace.argtypes = [u6, vp, u, u64p]
+    L.orc_arithmetic_trace.argtypes = [u6, vp, u, u64p]
     L.orc_commit_values.argtypes = [u64p, u, sz, u, u]
     L.orc_commit_values.restype = vp
     L.orc_commit_coeffs.argtypes = [u64p, u, sz, u, u]
@@ -225,10 +226,11 @@ class PyChallenger:
         return o
 
 
-AIR_SYNTHETIC, AIR_KECCAK_F, AIR_LOGIC, AIR_MEMORY = 0, 1, 2, 3
+AIR_SYNTHETIC, AIR_KECCAK_F, AIR_LOGIC, AIR_MEMORY, AIR_ARITHMETIC = 0, 1, 2, 3, 4
 KECCAK_COLS = 2430
 LOGIC_COLS = 523
 MEMORY_COLS = 44
+ARITHMETIC_COLS = 309
 
 
 def make_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, num_queries=84, pow_bits=16,
@@ -272,6 +274,17 @@ def memory_trace(log_n, seed=0, inputs=None):
     if inp is not None:
         assert inp.shape == (1 << log_n, 11)
     lib().orc_memory_trace(seed, inp.ctypes.data if inp is not None else None, log_n, out)
+    return out
+
+
+def arithmetic_trace(log_n, seed=0, inputs=None):
+    """orc_arithmetic_trace: the AIR-4 witness [309, 2^log_n]; inputs [2^log_n, 9] (code 0 none / 1 add / 2 sub / 3 lt /
+    4 gt, x, y as four u64 each) or seeded."""
+    out = np.zeros((ARITHMETIC_COLS, 1 << log_n), dtype=np.uint64)
+    inp = np.ascontiguousarray(inputs, dtype=np.uint64) if inputs is not None else None
+    if inp is not None:
+        assert inp.shape == (1 << log_n, 9)
+    lib().orc_arithmetic_trace(seed, inp.ctypes.data if inp is not None else None, log_n, out)
     return out
 
 

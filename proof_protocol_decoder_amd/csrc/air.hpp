@@ -28,6 +28,9 @@
 //                      the ordering is enforced by a 32-bit decomposition of the gap to the next row.  In the style
 //                      of the zkEVM's memory table (prover_state.rs:85-93 "memory"), its own layout
 //                      [UPSTREAM-UNVERIFIED].
+// AIR 4  arithmetic    ADD / SUB / LT / GT on 256-bit words as sixteen 16-bit limbs with a carry chain, 309 columns,
+//                      degree 2; the additive part of the zkEVM's arithmetic table (prover_state.rs:85-93
+//                      "arithmetic"), its own layout [UPSTREAM-UNVERIFIED].
 // The cross-table-lookup-like auxiliary columns (running products over trace columns 8k, 8k+1) are a property of
 // the protocol, not of an AIR (as upstream's CTL checks sit beside Stark::eval): their constraints follow the AIR's
 // in the list for every air_id.
@@ -38,7 +41,7 @@
 namespace bpg {
 namespace air {
 
-constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, COUNT = 4;
+constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, COUNT = 5;
 
 struct Shape {
   uint32_t air_id, n_cols, n_const, deg_pow;
@@ -490,17 +493,88 @@ GL_HD void eval_unit(const Row& row, Emit& out) {
 }
 }  // namespace memory
 
+// ------------------------------------------------------------------------------------------ AIR 4: arithmetic
+// One operation per row on 256-bit words x, y given as sixteen 16-bit limbs; a third word z is given by its BITS (so
+// its limbs are range-checked here; the range of x and y is the business of the table that supplies them) and every
+// operation is one carry chain  U + V = W + 2^256 c_15  over the limbs, with (U, V, W) chosen by the flag:
+//   add  x + y = z              (x, y, z)          sub  x - y = z  <=>  z + y = x       (z, y, x)
+//   lt   x < y  <=>  x - y borrows: z + y = x + 2^256 result      (z, y, x), result = c_15
+//   gt   x > y  <=>  y - x borrows: z + x = y + 2^256 result      (z, x, y), result = c_15
+// A row without a flag is padding (its carries are forced to zero).
+// Columns:
+//   0 .. 3       is_add, is_sub, is_lt, is_gt
+//   4 .. 19      x limbs        20 .. 35   y limbs
+//   36 .. 291    z bits: 36 + 16 k + j (limb k, bit j)
+//   292 .. 307   carry out of limb k
+//   308          result (the comparison bit for lt / gt, else 0)
+// Constraints (all rows):
+//   A0  0 .. 3      f (f - 1)                          A1  4          s (s - 1), s = sum of the flags      deg 2
+//   A2  5 .. 260    z bits are bits                    A3  261 .. 276 carries are bits                     deg 2
+//   A4  277 .. 292  U_k + V_k + c_(k-1) - W_k - 2^16 c_k   (c_(-1) = 0)                                    deg 2
+//   A5  293         result - (is_lt + is_gt) c_15                                                          deg 2
+// Units: unit u = limbs 4u .. 4u + 3; unit 0 also takes A0, A1, A5.
+namespace arithmetic {
+constexpr uint32_t N_COLS = 309, N_CONSTRAINTS = 294, N_UNITS = 4;
+constexpr uint32_t COL_OP = 0, COL_X = 4, COL_Y = 20, COL_Z = 36, COL_CARRY = 292, COL_RES = 308;
+constexpr uint32_t A0 = 0, A1 = 4, A2 = 5, A3 = 261, A4 = 277, A5 = 293;
+constexpr uint32_t OP_NONE = 0, OP_ADD = 1, OP_SUB = 2, OP_LT = 3, OP_GT = 4;
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const T f_add = row.loc(COL_OP), f_sub = row.loc(COL_OP + 1), f_lt = row.loc(COL_OP + 2), f_gt = row.loc(COL_OP + 3);
+  if (u == 0) {
+    const T s = F::add(F::add(f_add, f_sub), F::add(f_lt, f_gt));
+    const T x4[4] = {f_add, f_sub, f_lt, f_gt};
+    T xx[4];
+    F::mul4(x4, x4, xx);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) out.all(A0 + i, F::sub(xx[i], x4[i]));
+    out.all(A1, F::sub(F::mul(s, s), s));
+    out.all(A5, F::sub(row.loc(COL_RES), F::mul(F::add(f_lt, f_gt), row.loc(COL_CARRY + 15))));
+  }
+  // the flag sums that select (U, V, W): U = f_add x + fz z,  V = fy y + f_gt x,  W = f_add z + fx x + f_gt y
+  const T fz = F::add(F::add(f_sub, f_lt), f_gt), fy = F::add(F::add(f_add, f_sub), f_lt), fx = F::add(f_sub, f_lt);
+#pragma unroll 1
+  for (uint32_t k = 4 * u; k < 4 * u + 4; k++) {
+    T z = F::k(0);
+#pragma unroll 1
+    for (uint32_t j0 = 16; j0 > 0; j0 -= 4) {
+      T b[4], bb[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) b[i] = row.loc(COL_Z + 16 * k + j0 - 1 - i);
+      F::mul4(b, b, bb);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        out.all(A2 + 16 * k + j0 - 1 - i, F::sub(bb[i], b[i]));
+        z = F::add(F::dbl(z), b[i]);
+      }
+    }
+    const T x = row.loc(COL_X + k), y = row.loc(COL_Y + k), c = row.loc(COL_CARRY + k);
+    // (f_add + f_gt - fx) x + (fy - f_gt) y + (fz - f_add) z  =  U + V - W   (x, y, z each appear on both sides)
+    const T a4[4] = {F::sub(F::add(f_add, f_gt), fx), F::sub(fy, f_gt), F::sub(fz, f_add), c}, b4[4] = {x, y, z, c};
+    T p4[4];
+    F::mul4(a4, b4, p4);
+    out.all(A3 + k, F::sub(p4[3], c));
+    T e = F::add(F::add(p4[0], p4[1]), p4[2]);
+    if (k) e = F::add(e, row.loc(COL_CARRY + k - 1));
+    out.all(A4 + k, F::sub(e, F::mul(F::k(65536), c)));
+  }
+}
+}  // namespace arithmetic
+
 // ------------------------------------------------------------------------------------------ registry
 GL_HD uint32_t n_constraints(const Shape& s) {
   return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS
          : s.air_id == LOGIC  ? logic::N_CONSTRAINTS
          : s.air_id == MEMORY ? memory::N_CONSTRAINTS
+         : s.air_id == ARITHMETIC ? arithmetic::N_CONSTRAINTS
                               : synthetic::n_constraints(s);
 }
 GL_HD uint32_t n_units(const Shape& s) {
   return s.air_id == KECCAK_F ? keccak::N_UNITS
          : s.air_id == LOGIC  ? logic::N_UNITS
          : s.air_id == MEMORY ? memory::N_UNITS
+         : s.air_id == ARITHMETIC ? arithmetic::N_UNITS
                               : synthetic::n_units(s);
 }
 template <class T, class Row, class Emit>
@@ -508,6 +582,7 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   if (s.air_id == KECCAK_F) keccak::eval_unit<T>(unit, row, out);
   else if (s.air_id == LOGIC) logic::eval_unit<T>(unit, row, out);
   else if (s.air_id == MEMORY) memory::eval_unit<T>(row, out);
+  else if (s.air_id == ARITHMETIC) arithmetic::eval_unit<T>(unit, row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
@@ -541,6 +616,7 @@ inline const Info* info(uint32_t air_id) {
       {KECCAK_F, "keccak_f", keccak::N_COLS, 0, 3},
       {LOGIC, "logic", logic::N_COLS, 0, 3},
       {MEMORY, "memory", memory::N_COLS, 0, 3},
+      {ARITHMETIC, "arithmetic", arithmetic::N_COLS, 0, 2},
   };
   return air_id < COUNT ? &table[air_id] : nullptr;
 }

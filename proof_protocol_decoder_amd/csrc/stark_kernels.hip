@@ -200,6 +200,54 @@ memory_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ input
   for (uint32_t z = 0; z < 32; z++) put(mm::COL_GAP + z, (gap >> z) & 1);
 }
 
+// ---------------------------------------------------------------- arithmetic witness (AIR 4, air.hpp)
+// One operation per row.  `inputs` ([row][9]: operation code 0 none / 1 add / 2 sub / 3 lt / 4 gt (anything else:
+// none), then the four 64-bit words of x and of y, least significant first) or, when null, drawn from the seed like the
+// oracle: code = splitmix64(seed ^ (0xFE << 32) ^ row) % 5, word w of operand j = splitmix64(seed ^ ((1 + 4 j + w) << 32) ^ row).
+__global__ void __launch_bounds__(256)
+arithmetic_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  namespace ar = bpg::air::arithmetic;
+  const uint32_t n = 1u << log_n;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t code = inputs ? inputs[(uint64_t)i * 9] : splitmix64(seed ^ (0xFEull << 32) ^ i) % 5;
+  const uint32_t op = code <= 4 ? (uint32_t)code : 0u;
+  uint64_t x[4], y[4];
+  for (uint32_t k = 0; k < 4; k++) {
+    x[k] = inputs ? inputs[(uint64_t)i * 9 + 1 + k] : splitmix64(seed ^ ((uint64_t)(1 + k) << 32) ^ i);
+    y[k] = inputs ? inputs[(uint64_t)i * 9 + 5 + k] : splitmix64(seed ^ ((uint64_t)(5 + k) << 32) ^ i);
+  }
+  auto limb = [](const uint64_t (&w)[4], uint32_t k) { return (uint32_t)(w[k >> 2] >> (16 * (k & 3))) & 0xFFFFu; };
+  auto put = [&](uint32_t col, uint64_t v) { t[(uint64_t)col * n + i] = v; };
+  put(ar::COL_OP, op == ar::OP_ADD);
+  put(ar::COL_OP + 1, op == ar::OP_SUB);
+  put(ar::COL_OP + 2, op == ar::OP_LT);
+  put(ar::COL_OP + 3, op == ar::OP_GT);
+  // the chain U + V = W + 2^256 c: add: z = x + y; sub / lt: z = x - y (z + y = x); gt: z = y - x (z + x = y)
+  uint32_t carry = 0;
+  for (uint32_t k = 0; k < 16; k++) {
+    const uint32_t xk = limb(x, k), yk = limb(y, k);
+    uint32_t zk, ck;
+    if (op == ar::OP_ADD) {
+      const uint32_t s = xk + yk + carry;
+      zk = s & 0xFFFFu; ck = s >> 16;
+    } else if (op == ar::OP_NONE) {
+      zk = 0; ck = 0;
+    } else {  // z = w - v with borrow; the chain's carry out of limb k is that borrow
+      const uint32_t w = op == ar::OP_GT ? yk : xk, v = op == ar::OP_GT ? xk : yk;
+      const uint32_t d = w - v - carry;
+      zk = d & 0xFFFFu; ck = (d >> 16) & 1u;
+    }
+    put(ar::COL_X + k, xk);
+    put(ar::COL_Y + k, yk);
+    for (uint32_t j = 0; j < 16; j++) put(ar::COL_Z + 16 * k + j, (zk >> j) & 1);
+    put(ar::COL_CARRY + k, ck);
+    carry = ck;
+  }
+  put(ar::COL_RES, (op == ar::OP_LT || op == ar::OP_GT) ? carry : 0);
+}
+
 // ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
 // z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
 // One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
@@ -353,6 +401,7 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
       if constexpr (AIR == bpg::air::KECCAK_F) bpg::air::keccak::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::LOGIC) bpg::air::logic::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::MEMORY) bpg::air::memory::eval_unit<uint64_t>(row, out);
+      else if constexpr (AIR == bpg::air::ARITHMETIC) bpg::air::arithmetic::eval_unit<uint64_t>(u, row, out);
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -901,6 +950,11 @@ int launch_memory_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t lo
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_arithmetic_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
+  arithmetic_trace_kernel<<<ceil_div((uint64_t)1 << log_n, 256), 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
                hipStream_t st) {
   if (!n_aux) return BP_OK;
@@ -923,6 +977,7 @@ int launch_quotient(const QuotArgs& q, hipStream_t st) {
   if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(q);
+  else if (q.air_id == bpg::air::ARITHMETIC) quotient_air_kernel<bpg::air::ARITHMETIC><<<g1, 256, 0, st>>>(q);
   else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(q);
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {

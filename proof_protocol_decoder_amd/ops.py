@@ -76,6 +76,7 @@ AIR_SYNTHETIC, AIR_KECCAK_F = 0, 1
 KECCAK_COLS = 2430
 LOGIC_COLS = 523
 MEMORY_COLS = 44
+ARITHMETIC_COLS = 309
 
 
 def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
@@ -105,6 +106,17 @@ def memory_trace(log_n, seed=0, inputs=None, device="cuda"):
         _require_cuda(inputs)
         assert inputs.shape == (1 << log_n, 11)
     check(lib().bp_memory_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
+    return out
+
+
+def arithmetic_trace(log_n, seed=0, inputs=None, device="cuda"):
+    """bp_arithmetic_trace: the AIR-4 witness [309, 2^log_n]; inputs [2^log_n, 9] int64 on the device (operation code
+    0 none / 1 add / 2 sub / 3 lt / 4 gt, the four words of x, of y), or drawn from `seed`."""
+    out = torch.empty((ARITHMETIC_COLS, 1 << log_n), dtype=torch.int64, device=device)
+    if inputs is not None:
+        _require_cuda(inputs)
+        assert inputs.shape == (1 << log_n, 9)
+    check(lib().bp_arithmetic_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
     return out
 
 

@@ -63,6 +63,7 @@ def _bind():
     L.bp_ir_set_keccak_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_logic_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_memory_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.bp_ir_set_arithmetic_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_keccak256_permutation_inputs.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t,
                                                   C.POINTER(C.c_size_t)]
     L.bp_generate_txn_proof_keccak.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t,
@@ -123,6 +124,7 @@ class TxnProofGenIR:
                                   # the 25-word IR: handed to bp_generate_txn_proof_keccak beside it
     logic_air: bool = False    # the logic table (index 5) is proven with the logic AIR (AIR 2, 523 columns)
     memory_air: bool = False   # the memory table (index 6) with the memory AIR (AIR 3, 44 columns)
+    arithmetic_air: bool = False   # the arithmetic table (index 0) with the arithmetic AIR (AIR 4, 309 columns)
 
     def to_bytes(self):
         L = _bind()
@@ -143,6 +145,8 @@ class TxnProofGenIR:
             check(L.bp_ir_set_logic_air(out, 1))
         if self.memory_air:
             check(L.bp_ir_set_memory_air(out, 1))
+        if self.arithmetic_air:
+            check(L.bp_ir_set_arithmetic_air(out, 1))
         return struct.pack("<%dQ" % IR_WORDS, *out)
 
 
