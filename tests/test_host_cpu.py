@@ -281,3 +281,43 @@ def test_bench_spawns_its_own_ranks_when_started_without_a_launcher(monkeypatch)
     monkeypatch.setattr(_sys, "argv", ["bench.py", "--txns", "0"])
     with pytest.raises(SystemExit, match="--txns must be >= 2"):
         bench.main()
+
+
+def test_witness_entry_points_check_their_arguments_before_any_device_work():
+    """bp_keccak_trace / bp_logic_trace / bp_memory_trace / bp_arithmetic_trace and the IR flag setters: null outputs,
+    heights out of range and tables of the wrong width are refused with BP_ERR_INVALID_INPUT (-2) and a message, without a
+    GPU."""
+    import ctypes as C
+    import proof_protocol_decoder_amd as pkg
+    from proof_protocol_decoder_amd import proof_gen as pg
+    L = pkg.lib()
+    L.bp_last_error.restype = C.c_char_p
+    for name in ("bp_keccak_trace", "bp_logic_trace", "bp_memory_trace", "bp_arithmetic_trace"):
+        f = getattr(L, name)
+        f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        assert f(None, 1, 8, None, None) == -2 and name.encode() in L.bp_last_error()
+        assert f(None, 1, 2, C.c_void_p(8), None) == -2 and b"log_n" in L.bp_last_error()
+        assert f(None, 1, 40, C.c_void_p(8), None) == -2
+    pg._bind()
+    ir = (C.c_uint64 * 25)(*struct_ir())
+    for setter, width in (("bp_ir_set_keccak_air", b"2430"), ("bp_ir_set_logic_air", b"523"), ("bp_ir_set_memory_air", b"44"),
+                          ("bp_ir_set_arithmetic_air", b"309")):
+        f = getattr(L, setter)
+        f.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+        assert f(ir, 1) == -2 and width in L.bp_last_error()       # the synthetic widths do not fit the AIR
+        assert f(ir, 0) == 0 and ir[1] == 1                        # switching it off is always possible
+        junk = (C.c_uint64 * 25)()
+        assert f(junk, 1) == -2 and b"not an IR" in L.bp_last_error()
+    # all four flags together, each on a table of the right width
+    w = list(struct_ir())
+    w[18 + 0], w[18 + 3], w[18 + 5], w[18 + 6] = 309, 2430, 523, 44
+    ir = (C.c_uint64 * 25)(*w)
+    for setter in ("bp_ir_set_arithmetic_air", "bp_ir_set_keccak_air", "bp_ir_set_logic_air", "bp_ir_set_memory_air"):
+        assert getattr(L, setter)(ir, 1) == 0
+    assert ir[1] == 0xF01
+    assert L.bp_ir_set_logic_air(ir, 0) == 0 and ir[1] == 0xD01
+
+
+def struct_ir():
+    from pg_common import IR_MAGIC, LOG_N, WIDTH
+    return [IR_MAGIC, 1, 7, 0, 100, 121, 1, 2, 3, 4, 0x5EED, *LOG_N, *WIDTH]
