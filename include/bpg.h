@@ -189,8 +189,8 @@ struct bp_stark_cfg;
  * air_id: 0 = the synthetic AIR of DESIGN.md section 4 (any width), 1 = keccak_f, one round of Keccak-f[1600] per
  * row on 2430 columns, written from FIPS 202 (not upstream's column layout), 2 = logic, one AND / OR / XOR of two
  * 256-bit words per row on 523 columns, 3 = memory, a log of reads and writes sorted by (address, timestamp) on 44
- * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns (likewise their own
- * layouts).  bp_air_describe returns the shape and
+ * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns, 5 = byte_packing,
+ * a big-endian byte sequence and the word it spells on 297 columns (likewise their own layouts).  bp_air_describe returns the shape and
  * the constraint list of an AIR as families (first index, count, kind, degree); the list is followed, for every
  * air_id, by the two constraints of each cross-table-lookup-like auxiliary column (n_cols / 8 of them). */
 typedef struct bp_air_family {
@@ -247,6 +247,11 @@ int bp_memory_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uin
  * 1 add, 2 sub, 3 lt, 4 gt), then the four 64-bit words of x and of y, least significant first; or NULL to draw them
  * from `seed` (code = splitmix64(seed ^ (0xFE << 32) ^ row) % 5, words as in bp_logic_trace). */
 int bp_arithmetic_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
+/* Witness of AIR 5 (the byte-packing table: a big-endian sequence of 1..32 bytes and the 256-bit word it spells, what
+ * MLOAD_32BYTES / MSTORE_32BYTES move): n = 2^log_n rows x 297 columns, column-major.  d_inputs: [n][6] = is_read, len
+ * (0 = a padding row; above 32: 32), the 32 byte slots as four 64-bit words (slot i = byte i % 8 of word i / 8; slots
+ * from len on are ignored); or NULL to draw them from `seed`. */
+int bp_byte_packing_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
 /* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
  * folded domain), done in the evaluation domain.  d_values: the layer's n_l << rate_bits extension values
@@ -283,7 +288,7 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
-/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 / 2 / 3 / 4: n_cols = 2430 / 523 / 44 / 309,
+/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 / 2 / 3 / 4 / 5: n_cols = 2430 / 523 / 44 / 309 / 297,
  * n_const = 0, deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
 int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                        uint8_t** out, size_t* out_len);
@@ -405,6 +410,8 @@ int bp_ir_set_logic_air(uint64_t ir[BP_IR_WORDS], int on);
 int bp_ir_set_memory_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the arithmetic table (flag 0x800; table index 0): the arithmetic AIR (air_id 4: 309 columns). */
 int bp_ir_set_arithmetic_air(uint64_t ir[BP_IR_WORDS], int on);
+/* ... and for the byte-packing table (flag 0x1000; table index 1): the byte-packing AIR (air_id 5: 297 columns). */
+int bp_ir_set_byte_packing_air(uint64_t ir[BP_IR_WORDS], int on);
 /* public values of a proof container: txn_before, txn_after, gas_before, gas_after, root_before[4],
  * root_after[4], block_number */
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out);

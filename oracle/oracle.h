@@ -67,7 +67,8 @@ typedef struct {
   uint32_t log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits,
       arity_bits, final_poly_bits;
   uint32_t air_id; /* 0: the synthetic AIR (stark.c), 1: Keccak-f[1600] (keccak_air.c), 2: logic (logic_air.c), 3: memory
-                      (memory_air.c), 4: arithmetic (arithmetic_air.c); header word 14 of a proof */
+                      (memory_air.c), 4: arithmetic (arithmetic_air.c), 5: byte packing
+                      (byte_packing_air.c); header word 14 of a proof */
 } orc_stark_cfg;
 #define ORC_AIR_SYNTHETIC 0u
 #define ORC_AIR_KECCAK_F 1u
@@ -82,6 +83,9 @@ typedef struct {
 #define ORC_AIR_ARITHMETIC 4u
 #define ORC_ARITHMETIC_COLS 309u
 #define ORC_ARITHMETIC_CONSTRAINTS 294u
+#define ORC_AIR_BYTE_PACKING 5u
+#define ORC_BYTE_PACKING_COLS 297u
+#define ORC_BYTE_PACKING_CONSTRAINTS 330u
 
 /* starky ConstraintConsumer: acc_j = acc_j * alpha_j + constraint, in list order; base field (the LDE coset)
  * and extension field (the verifier at zeta; the alphas stay in the base field). */
@@ -119,6 +123,10 @@ void orc_memory_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer
 void orc_arithmetic_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
 void orc_arithmetic_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
 void orc_arithmetic_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
+/* byte_packing_air.c */
+void orc_byte_packing_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
+void orc_byte_packing_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
+void orc_byte_packing_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
 
 uint32_t orc_cfg_n_aux(const orc_stark_cfg* c);
 uint32_t orc_cfg_n_quot(const orc_stark_cfg* c);

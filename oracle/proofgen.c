@@ -147,11 +147,12 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inp
    * Keccak-f AIR (keccak_air.c) instead of the synthetic one: 2430 columns, witness drawn from the seed;
    * 0x200 = the logic table (index 5) is proven with the logic AIR (logic_air.c): 523 columns;
    * 0x400 = the memory table (index 6) with the memory AIR (memory_air.c): 44 columns;
-   * 0x800 = the arithmetic table (index 0) with the arithmetic AIR (arithmetic_air.c): 309 columns */
+   * 0x800 = the arithmetic table (index 0) with the arithmetic AIR (arithmetic_air.c): 309 columns;
+   * 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (byte_packing_air.c): 297 columns */
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
-  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 15) return -2;
+  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 31) return -2;
   const int dummy = ver == 2, keccak_air = (int)(flags & 1), logic_air = (int)((flags >> 1) & 1), memory_air = (int)((flags >> 2) & 1),
-            arithmetic_air = (int)((flags >> 3) & 1);
+            arithmetic_air = (int)((flags >> 3) & 1), byte_packing_air = (int)((flags >> 4) & 1);
   if (dummy && I[4] != I[5]) return -2;
   orc_stark_cfg tcfg[NUM_TABLES];
   for (int t = 0; t < NUM_TABLES; t++) {
@@ -173,6 +174,10 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inp
   if (arithmetic_air) {
     if (tcfg[0].n_cols != ORC_ARITHMETIC_COLS) return -2;
     tcfg[0].air_id = ORC_AIR_ARITHMETIC;
+  }
+  if (byte_packing_air) {
+    if (tcfg[1].n_cols != ORC_BYTE_PACKING_COLS) return -2;
+    tcfg[1].air_id = ORC_AIR_BYTE_PACKING;
   }
   if (keccak_inputs && (!keccak_air || n_perms > (((size_t)1 << tcfg[3].log_n) + 23) / 24)) return -3;
   gl_t pv[PV_WORDS];
@@ -201,6 +206,7 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inp
     else if (tcfg[t].air_id == ORC_AIR_LOGIC) orc_logic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_MEMORY) orc_memory_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_ARITHMETIC) orc_arithmetic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
+    else if (tcfg[t].air_id == ORC_AIR_BYTE_PACKING) orc_byte_packing_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
     tc[t] = orc_commit_values(trace[t], tcfg[t].log_n, tcfg[t].n_cols, tcfg[t].rate_bits, tcfg[t].cap_height);
     orc_ch_observe_many(&ch, orc_committed_cap(tc[t]), (size_t)4 << tcfg[t].cap_height);

@@ -190,13 +190,14 @@ class BlockDriver:
 
 
 def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_base=0x5EED000000000000,
-                        root0=(1, 2, 3, 4), keccak_air=False, logic_air=False, memory_air=False, arithmetic_air=False):
+                        root0=(1, 2, 3, 4), keccak_air=False, logic_air=False, memory_air=False, arithmetic_air=False,
+                        byte_packing_air=False):
     """The synthetic block of SURVEY.md section 8(d): n_txns txns with distinct seeds whose public
     values chain (state root, txn number, gas) like decoding.rs:106-154 chains GenerationInputs.
     keccak_air: every transaction's Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1; the table's width
     becomes 2430).  logic_air / memory_air: likewise the logic table (index 5) with the logic AIR (AIR 2; width 523) and
     the memory table (index 6) with the memory AIR (AIR 3; width 44); arithmetic_air: the arithmetic table (index 0)
-    with the arithmetic AIR (AIR 4; width 309)."""
+    with the arithmetic AIR (AIR 4; width 309); byte_packing_air: the byte-packing table (index 1) with AIR 5 (width 297)."""
     if keccak_air:
         table_width = tuple(2430 if t == 3 else w for t, w in enumerate(table_width))
     if logic_air:
@@ -205,6 +206,8 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
         table_width = tuple(44 if t == 6 else w for t, w in enumerate(table_width))
     if arithmetic_air:
         table_width = tuple(309 if t == 0 else w for t, w in enumerate(table_width))
+    if byte_packing_air:
+        table_width = tuple(297 if t == 1 else w for t, w in enumerate(table_width))
     import ctypes as C
     L = pg._bind()
     L.bp_state_root_after.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -213,7 +216,8 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
         seed = seed_base + (block_number << 20) + i
         irs.append(pg.TxnProofGenIR(block_number, i, gas, gas + 21000, root, seed, tuple(table_log_n),
                                     tuple(table_width), keccak_air=keccak_air, logic_air=logic_air,
-                                    memory_air=memory_air, arithmetic_air=arithmetic_air))
+                                    memory_air=memory_air, arithmetic_air=arithmetic_air,
+                                    byte_packing_air=byte_packing_air))
         out = (C.c_uint64 * 4)()
         pg.check(L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out))
         root, gas = tuple(out), gas + 21000

@@ -31,6 +31,9 @@
 // AIR 4  arithmetic    ADD / SUB / LT / GT on 256-bit words as sixteen 16-bit limbs with a carry chain, 309 columns,
 //                      degree 2; the additive part of the zkEVM's arithmetic table (prover_state.rs:85-93
 //                      "arithmetic"), its own layout [UPSTREAM-UNVERIFIED].
+// AIR 5  byte_packing  a big-endian sequence of up to 32 bytes <-> one 256-bit word per row (the zkEVM's byte-packing
+//                      table, prover_state.rs:85-93 "byte_packing"), 297 columns, degree 2; its own layout
+//                      [UPSTREAM-UNVERIFIED].
 // The cross-table-lookup-like auxiliary columns (running products over trace columns 8k, 8k+1) are a property of
 // the protocol, not of an AIR (as upstream's CTL checks sit beside Stark::eval): their constraints follow the AIR's
 // in the list for every air_id.
@@ -41,7 +44,7 @@
 namespace bpg {
 namespace air {
 
-constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, COUNT = 5;
+constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, BYTE_PACKING = 5, COUNT = 6;
 
 struct Shape {
   uint32_t air_id, n_cols, n_const, deg_pow;
@@ -562,12 +565,92 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 }
 }  // namespace arithmetic
 
+// ------------------------------------------------------------------------------------------ AIR 5: byte packing
+// One sequence per row: `len` bytes (1..32) read from or written to memory, most significant first, and the 256-bit
+// word they are the big-endian form of (what MLOAD_32BYTES / MSTORE_32BYTES move), as eight 32-bit limbs, least
+// significant limb first.  A row without a length flag is padding.
+// Columns:
+//   0            is_read
+//   1 .. 32      length flags: column j is 1 when len = j
+//   33 .. 288    the bits of the 32 byte slots: 33 + 8 i + b  (slot i = the i-th byte of the sequence)
+//   289 .. 296   value limbs
+// Constraints (all rows):
+//   P0  0          is_read is a bit                         P1  1 .. 32    length flags are bits           deg 2
+//   P2  33         at most one length flag                  P3  34 .. 289  slot bits are bits              deg 2
+//   P4  290 .. 321 slot i is zero unless i < len:  byte_i (1 - sum_{j > i} flag_j)                         deg 2
+//   P5  322 .. 329 value limb k = sum_j flag_j sum_{i < j, 4k <= j-1-i < 4k+4} byte_i 256^(j-1-i-4k)       deg 2
+// Units: unit 0 = P0 .. P2; units 1 .. 8 = slots 4(u-1) .. 4(u-1)+3 (P3, P4) and value limb u - 1 (P5).
+namespace byte_packing {
+constexpr uint32_t N_COLS = 297, N_CONSTRAINTS = 330, N_UNITS = 9;
+constexpr uint32_t COL_READ = 0, COL_LEN = 1, COL_BITS = 33, COL_VAL = 289;
+constexpr uint32_t P0 = 0, P1 = 1, P2 = 33, P3 = 34, P4 = 290, P5 = 322;
+// byte slot i from its bits (Horner)
+template <class T, class Row>
+GL_HD T slot(const Row& row, uint32_t i) {
+  typedef Ops<T> F;
+  T v = F::k(0);
+#pragma unroll 1
+  for (uint32_t b = 8; b > 0; b--) v = F::add(F::dbl(v), row.loc(COL_BITS + 8 * i + b - 1));
+  return v;
+}
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  if (u == 0) {
+    const T rd = row.loc(COL_READ);
+    out.all(P0, F::sub(F::mul(rd, rd), rd));
+    T s = F::k(0);
+#pragma unroll 1
+    for (uint32_t j = 0; j < 32; j++) {
+      const T f = row.loc(COL_LEN + j);
+      out.all(P1 + j, F::sub(F::mul(f, f), f));
+      s = F::add(s, f);
+    }
+    out.all(P2, F::sub(F::mul(s, s), s));
+    return;
+  }
+  const uint32_t k = u - 1;
+  // slots 4k .. 4k + 3: bits, and "zero unless inside the sequence"
+#pragma unroll 1
+  for (uint32_t i = 4 * k; i < 4 * k + 4; i++) {
+    T v = F::k(0);
+#pragma unroll 1
+    for (uint32_t b0 = 8; b0 > 0; b0--) {
+      const T g = row.loc(COL_BITS + 8 * i + b0 - 1);
+      out.all(P3 + 8 * i + b0 - 1, F::sub(F::mul(g, g), g));
+      v = F::add(F::dbl(v), g);
+    }
+    T longer = F::k(0);  // sum of the flags of the lengths that contain slot i: len > i, i.e. flag columns j = i+1 .. 32
+#pragma unroll 1
+    for (uint32_t j = i + 1; j <= 32; j++) longer = F::add(longer, row.loc(COL_LEN + j - 1));
+    out.all(P4 + i, F::mul(v, F::sub(F::k(1), longer)));
+  }
+  // value limb k = sum_j flag_j sum_{p = 4k .. 4k+3, p < j} slot_(j-1-p) 256^(p-4k), regrouped by slot: slot i meets
+  // weight 256^q of limb k under the length j = i + 1 + 4k + q, so
+  //   limb k = sum_i slot_i (flag_(i+1+4k) + 256 flag_(i+2+4k) + 256^2 flag_(i+3+4k) + 256^3 flag_(i+4+4k))
+  T acc = F::k(0);
+#pragma unroll 1
+  for (uint32_t i = 0; i + 1 + 4 * k <= 32; i++) {
+    T sel = F::k(0);
+#pragma unroll
+    for (uint32_t q = 4; q > 0; q--) {  // Horner in 256 over the (up to) four lengths, largest weight first
+      const uint32_t j = i + 4 * k + q;
+      sel = F::mul(sel, F::k(256));
+      if (j <= 32) sel = F::add(sel, row.loc(COL_LEN + j - 1));
+    }
+    acc = F::add(acc, F::mul(slot<T>(row, i), sel));
+  }
+  out.all(P5 + k, F::sub(row.loc(COL_VAL + k), acc));
+}
+}  // namespace byte_packing
+
 // ------------------------------------------------------------------------------------------ registry
 GL_HD uint32_t n_constraints(const Shape& s) {
   return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS
          : s.air_id == LOGIC  ? logic::N_CONSTRAINTS
          : s.air_id == MEMORY ? memory::N_CONSTRAINTS
          : s.air_id == ARITHMETIC ? arithmetic::N_CONSTRAINTS
+         : s.air_id == BYTE_PACKING ? byte_packing::N_CONSTRAINTS
                               : synthetic::n_constraints(s);
 }
 GL_HD uint32_t n_units(const Shape& s) {
@@ -575,6 +658,7 @@ GL_HD uint32_t n_units(const Shape& s) {
          : s.air_id == LOGIC  ? logic::N_UNITS
          : s.air_id == MEMORY ? memory::N_UNITS
          : s.air_id == ARITHMETIC ? arithmetic::N_UNITS
+         : s.air_id == BYTE_PACKING ? byte_packing::N_UNITS
                               : synthetic::n_units(s);
 }
 template <class T, class Row, class Emit>
@@ -583,6 +667,7 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   else if (s.air_id == LOGIC) logic::eval_unit<T>(unit, row, out);
   else if (s.air_id == MEMORY) memory::eval_unit<T>(row, out);
   else if (s.air_id == ARITHMETIC) arithmetic::eval_unit<T>(unit, row, out);
+  else if (s.air_id == BYTE_PACKING) byte_packing::eval_unit<T>(unit, row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
@@ -617,6 +702,7 @@ inline const Info* info(uint32_t air_id) {
       {LOGIC, "logic", logic::N_COLS, 0, 3},
       {MEMORY, "memory", memory::N_COLS, 0, 3},
       {ARITHMETIC, "arithmetic", arithmetic::N_COLS, 0, 2},
+      {BYTE_PACKING, "byte_packing", byte_packing::N_COLS, 0, 2},
   };
   return air_id < COUNT ? &table[air_id] : nullptr;
 }

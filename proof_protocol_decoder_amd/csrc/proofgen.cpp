@@ -415,6 +415,15 @@ int bp_ir_set_arithmetic_air(uint64_t ir[BP_IR_WORDS], int on) {
   return BP_OK;
 }
 
+int bp_ir_set_byte_packing_air(uint64_t ir[BP_IR_WORDS], int on) {
+  if (!ir || ir[0] != IR_MAGIC) return fail(BP_ERR_INVALID_INPUT, "bp_ir_set_byte_packing_air: not an IR");
+  if (on && ir[18 + 1] != air::byte_packing::N_COLS)
+    return fail(BP_ERR_INVALID_INPUT, "the byte-packing AIR has %u columns: the IR gives table byte_packing %llu",
+                air::byte_packing::N_COLS, (unsigned long long)ir[18 + 1]);
+  ir[1] = (ir[1] & ~(uint64_t)0x1000) | (on ? 0x1000 : 0);
+  return BP_OK;
+}
+
 int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_used, const uint64_t state_root[4],
                        uint64_t seed, const uint32_t table_log_n[BP_NUM_TABLES], const uint32_t table_width[BP_NUM_TABLES],
                        uint64_t o[BP_IR_WORDS]) {
@@ -457,11 +466,12 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   // Keccak-f AIR (air.hpp, AIR 1) instead of the synthetic one: 2430 columns, witness drawn from the seed;
   // 0x200 = the logic table (index 5) is proven with the logic AIR (AIR 2): 523 columns, operations drawn from the seed;
   // 0x400 = the memory table (index 6) with the memory AIR (AIR 3): 44 columns, a sorted log drawn from the seed;
-  // 0x800 = the arithmetic table (index 0) with the arithmetic AIR (AIR 4): 309 columns
+  // 0x800 = the arithmetic table (index 0) with the arithmetic AIR (AIR 4): 309 columns;
+  // 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (AIR 5): 297 columns
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
-  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 15) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
+  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 31) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
   const bool dummy = ver == 2, keccak_air = (flags & 1) != 0, logic_air = (flags & 2) != 0, memory_air = (flags & 4) != 0,
-             arithmetic_air = (flags & 8) != 0;
+             arithmetic_air = (flags & 8) != 0, byte_packing_air = (flags & 16) != 0;
   if (keccak_inputs && !keccak_air)
     return fail(BP_ERR_INVALID_INPUT, "Keccak permutation inputs need an IR whose Keccak table is the Keccak-f AIR (bp_ir_set_keccak_air)");
   if (keccak_inputs && n_perms > (((size_t)1 << I[11 + 3]) + 23) / 24)
@@ -482,6 +492,7 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
     if (logic_air && t == 5) tcfg[t].air_id = air::LOGIC;       // ... and on its 523
     if (memory_air && t == 6) tcfg[t].air_id = air::MEMORY;     // ... 44
     if (arithmetic_air && t == 0) tcfg[t].air_id = air::ARITHMETIC;  // ... 309
+    if (byte_packing_air && t == 1) tcfg[t].air_id = air::BYTE_PACKING;  // ... 297
     int r = check_cfg(tcfg[t]);
     if (r) return r;
   }
@@ -530,6 +541,8 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
               ? launch_memory_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
           : tcfg[t].air_id == air::ARITHMETIC
               ? launch_arithmetic_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
+          : tcfg[t].air_id == air::BYTE_PACKING
+              ? launch_byte_packing_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
               : launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, I[10] ^ splitmix64(t + 1), w.stream);
     }
     if (r) return r;

@@ -248,6 +248,39 @@ arithmetic_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ i
   put(ar::COL_RES, (op == ar::OP_LT || op == ar::OP_GT) ? carry : 0);
 }
 
+// ---------------------------------------------------------------- byte-packing witness (AIR 5, air.hpp)
+// One sequence per row.  `inputs` ([row][6]: is_read, len (0 = a padding row, else 1..32; larger values: 32), then the
+// 32 byte slots as four 64-bit words, slot i = byte i % 8 of word i / 8; slots at or beyond len are ignored) or, when
+// null, drawn from the seed like the oracle: is_read = h(0xC0) & 1, len = h(0xC1) % 33, word w = h(0xC2 + w),
+// h(c) = splitmix64(seed ^ (c << 32) ^ row).
+__global__ void __launch_bounds__(256)
+byte_packing_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  namespace bp = bpg::air::byte_packing;
+  const uint32_t n = 1u << log_n;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto h = [&](uint64_t c) { return splitmix64(seed ^ (c << 32) ^ i); };
+  const uint64_t rd = (inputs ? inputs[(uint64_t)i * 6] : h(0xC0)) & 1;
+  uint64_t len = inputs ? inputs[(uint64_t)i * 6 + 1] : h(0xC1) % 33;
+  if (len > 32) len = 32;
+  uint64_t w[4];
+  for (uint32_t k = 0; k < 4; k++) w[k] = inputs ? inputs[(uint64_t)i * 6 + 2 + k] : h(0xC2 + k);
+  auto put = [&](uint32_t col, uint64_t v) { t[(uint64_t)col * n + i] = v; };
+  put(bp::COL_READ, rd);
+  for (uint32_t j = 1; j <= 32; j++) put(bp::COL_LEN + j - 1, len == j);
+  uint32_t limb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t s = 0; s < 32; s++) {
+    const uint32_t byte = s < len ? (uint32_t)(w[s >> 3] >> (8 * (s & 7))) & 0xFFu : 0u;
+    for (uint32_t b = 0; b < 8; b++) put(bp::COL_BITS + 8 * s + b, (byte >> b) & 1);
+    if (s < len) {
+      const uint32_t p = (uint32_t)len - 1 - s;  // weight 256^p of the big-endian value
+      limb[p >> 2] |= byte << (8 * (p & 3));
+    }
+  }
+  for (uint32_t k = 0; k < 8; k++) put(bp::COL_VAL + k, limb[k]);
+}
+
 // ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
 // z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
 // One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
@@ -402,6 +435,7 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
       else if constexpr (AIR == bpg::air::LOGIC) bpg::air::logic::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::MEMORY) bpg::air::memory::eval_unit<uint64_t>(row, out);
       else if constexpr (AIR == bpg::air::ARITHMETIC) bpg::air::arithmetic::eval_unit<uint64_t>(u, row, out);
+      else if constexpr (AIR == bpg::air::BYTE_PACKING) bpg::air::byte_packing::eval_unit<uint64_t>(u, row, out);
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -955,6 +989,11 @@ int launch_arithmetic_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_byte_packing_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
+  byte_packing_trace_kernel<<<ceil_div((uint64_t)1 << log_n, 256), 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
                hipStream_t st) {
   if (!n_aux) return BP_OK;
@@ -978,6 +1017,7 @@ int launch_quotient(const QuotArgs& q, hipStream_t st) {
   else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::ARITHMETIC) quotient_air_kernel<bpg::air::ARITHMETIC><<<g1, 256, 0, st>>>(q);
+  else if (q.air_id == bpg::air::BYTE_PACKING) quotient_air_kernel<bpg::air::BYTE_PACKING><<<g1, 256, 0, st>>>(q);
   else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(q);
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {

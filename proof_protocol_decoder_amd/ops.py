@@ -77,6 +77,7 @@ KECCAK_COLS = 2430
 LOGIC_COLS = 523
 MEMORY_COLS = 44
 ARITHMETIC_COLS = 309
+BYTE_PACKING_COLS = 297
 
 
 def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
@@ -117,6 +118,17 @@ def arithmetic_trace(log_n, seed=0, inputs=None, device="cuda"):
         _require_cuda(inputs)
         assert inputs.shape == (1 << log_n, 9)
     check(lib().bp_arithmetic_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
+    return out
+
+
+def byte_packing_trace(log_n, seed=0, inputs=None, device="cuda"):
+    """bp_byte_packing_trace: the AIR-5 witness [297, 2^log_n]; inputs [2^log_n, 6] int64 on the device (is_read, len,
+    the 32 byte slots as four words), or drawn from `seed`."""
+    out = torch.empty((BYTE_PACKING_COLS, 1 << log_n), dtype=torch.int64, device=device)
+    if inputs is not None:
+        _require_cuda(inputs)
+        assert inputs.shape == (1 << log_n, 6)
+    check(lib().bp_byte_packing_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
     return out
 
 

@@ -64,6 +64,7 @@ def _bind():
     L.bp_ir_set_logic_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_memory_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_arithmetic_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.bp_ir_set_byte_packing_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_keccak256_permutation_inputs.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t,
                                                   C.POINTER(C.c_size_t)]
     L.bp_generate_txn_proof_keccak.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t,
@@ -125,6 +126,7 @@ class TxnProofGenIR:
     logic_air: bool = False    # the logic table (index 5) is proven with the logic AIR (AIR 2, 523 columns)
     memory_air: bool = False   # the memory table (index 6) with the memory AIR (AIR 3, 44 columns)
     arithmetic_air: bool = False   # the arithmetic table (index 0) with the arithmetic AIR (AIR 4, 309 columns)
+    byte_packing_air: bool = False   # the byte-packing table (index 1) with the byte-packing AIR (AIR 5, 297 columns)
 
     def to_bytes(self):
         L = _bind()
@@ -147,6 +149,8 @@ class TxnProofGenIR:
             check(L.bp_ir_set_memory_air(out, 1))
         if self.arithmetic_air:
             check(L.bp_ir_set_arithmetic_air(out, 1))
+        if self.byte_packing_air:
+            check(L.bp_ir_set_byte_packing_air(out, 1))
         return struct.pack("<%dQ" % IR_WORDS, *out)
 
 

@@ -406,17 +406,17 @@ def test_txn_with_a_real_keccak_table_matches_the_oracle(pg, p_state, o_state):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), keccak_air=True).to_bytes()
 
 
-def test_txn_with_real_arithmetic_keccak_logic_and_memory_tables_matches_the_oracle(pg, p_state, o_state):
-    """IR flags 0x800 | 0x100 | 0x200 | 0x400: the arithmetic (index 0), Keccak (3), logic (5) and memory (6) tables of
-    the transaction are proven with AIR 4, 1, 2 and 3 next to three synthetic tables.  Byte parity with the oracle; the
-    block verifies."""
+def test_txn_with_five_real_tables_matches_the_oracle(pg, p_state, o_state):
+    """IR flags 0x800 | 0x1000 | 0x100 | 0x200 | 0x400: the arithmetic (index 0), byte-packing (1), Keccak (3), logic (5)
+    and memory (6) tables of the transaction are proven with AIR 4, 5, 1, 2 and 3 next to two synthetic tables (CPU and
+    Keccak sponge).  Byte parity with the oracle; the block verifies."""
     width = list(WIDTH)
-    width[0], width[3], width[5], width[6] = 309, 2430, 523, 44
+    width[0], width[1], width[3], width[5], width[6] = 309, 297, 2430, 523, 44
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
-                           memory_air=True, arithmetic_air=True)
+                           memory_air=True, arithmetic_air=True, byte_packing_air=True)
     t0 = pg.generate_txn_proof(p_state, ir0)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))
-    assert iw[1] == 0xF01 and iw[18 + 0] == 309 and iw[18 + 5] == 523 and iw[18 + 6] == 44
+    assert iw[1] == 0x1F01 and iw[18 + 0] == 309 and iw[18 + 1] == 297 and iw[18 + 5] == 523 and iw[18 + 6] == 44
     assert (words(t0.intern) == o_state.txn(iw)).all()
     only_logic = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), (*WIDTH[:5], 523, WIDTH[6]), logic_air=True)
     t_l = pg.generate_txn_proof(p_state, only_logic)
@@ -432,6 +432,8 @@ def test_txn_with_real_arithmetic_keccak_logic_and_memory_tables_matches_the_ora
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), memory_air=True).to_bytes()
     with pytest.raises(pg.ProofGenError, match="309"):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), arithmetic_air=True).to_bytes()
+    with pytest.raises(pg.ProofGenError, match="297"):
+        pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), byte_packing_air=True).to_bytes()
 
 
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
