@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "lib", "libbpg.so")
+# BPG_LIBBPG: another build of the same library (a host-sanitizer build, csrc/Makefile with OUT= / CXXFLAGS=)
+_PATH = os.environ.get("BPG_LIBBPG") or os.path.join(_HERE, "lib", "libbpg.so")
 
 BP_OK = 0
 STATUS_NAMES = {0: "BP_OK", -1: "BP_ERR_ABORTED", -2: "BP_ERR_INVALID_INPUT", -3: "BP_ERR_RANGE",
