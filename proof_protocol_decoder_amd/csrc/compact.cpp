@@ -293,9 +293,9 @@ bool build_tree(const std::vector<Instr>& ins, bpg::CompactOut* d, NodeP* root, 
           NodeP s;
           if (!pop(&s, "AccountLeaf (storage)")) return false;
           if (s->kind == Kind::Code) return fail_msg(err, "Invalid block witness entries: a code node cannot be a storage root");
-          mpt::Trie st(to_trie_node(s));
-          storage_root = st.hash();
-          d->storage_by_root[storage_root] = st;  // keyed by root first (compact_prestate_processing.rs:617-619)
+          mpt::Trie storage(to_trie_node(s));
+          storage_root = storage.hash();
+          d->storage_by_root[storage_root] = storage;  // keyed by root first (compact_prestate_processing.rs:617-619)
           collect_code(s, &d->code);
         }
         if (in.has_code) {     // then the code (bytes or hash)
