@@ -366,6 +366,21 @@ int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, c
  * over signed_txn and contract_code (decoding.rs:131-145; block_driver.irs_from_generation_inputs). */
 int bp_generate_txn_proof_keccak(const bp_state* s, const uint8_t* ir, size_t ir_len, const uint64_t* keccak_inputs,
                                  size_t n_perms, const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len);
+/* The general form: witness data for any table that has an AIR, instead of a witness drawn from the seed (the decoder
+ * side derives it from GenerationInputs: proof_protocol_decoder_amd/block_driver.py).  A table is given data when its
+ * has_* field is non-zero (n may be 0: a table of padding only) and its IR flag is set (bp_ir_set_*_air).  Items beyond
+ * n are padding: Keccak permutations of the all-zero state, rows without an operation, and for the memory log reads of
+ * the last address at later and later times.  Layouts as for the bp_*_trace entry points: keccak_inputs [n][25],
+ * logic_ops / arithmetic_ops [n][9], memory_log [n][11] sorted by (address, timestamp), byte_sequences [n][6]. */
+typedef struct bp_txn_witness {
+  const uint64_t* keccak_inputs;   size_t n_perms;           int has_keccak;
+  const uint64_t* logic_ops;       size_t n_logic_ops;       int has_logic;
+  const uint64_t* memory_log;      size_t n_memory_ops;      int has_memory;
+  const uint64_t* arithmetic_ops;  size_t n_arithmetic_ops;  int has_arithmetic;
+  const uint64_t* byte_sequences;  size_t n_byte_sequences;  int has_byte_packing;
+} bp_txn_witness;
+int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
+                                  const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len);
 /* the same call taking the reference's own flag: Arc<AtomicBool> is ONE byte, `flag.as_ptr()` binds here directly */
 int bp_generate_txn_proof_u8(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile uint8_t* abort_flag,
                              uint8_t** out, size_t* out_len);

@@ -129,17 +129,53 @@ int orc_pg_preprocess(orc_pg_state* s, const uint64_t* I) {
 }
 
 /* generate_txn_proof (proof_gen.rs:39-56) on the synthetic workload */
-static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inputs, size_t n_perms, gl_t** out,
-                  size_t* out_words);
-int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) { return pg_txn(s, I, NULL, 0, out, out_words); }
+/* witness data per table (NULL: drawn from the seed): items[t] x n[t], WIT_WORDS[t] words each */
+typedef struct { const uint64_t* items[NUM_TABLES]; size_t n[NUM_TABLES]; } pg_witness;
+static const unsigned WIT_WORDS[NUM_TABLES] = {9, 6, 0, 25, 0, 9, 11};
+static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_t** out, size_t* out_words);
+int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) { return pg_txn(s, I, NULL, out, out_words); }
 /* the same with the Keccak table's permutation inputs given (n_perms x 25 lanes; the rest of the table: zero states) */
 int orc_pg_txn_keccak(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inputs, size_t n_perms, gl_t** out,
                       size_t* out_words) {
   static const uint64_t none = 0;
-  return pg_txn(s, I, keccak_inputs ? keccak_inputs : &none, n_perms, out, out_words);
+  pg_witness w;
+  memset(&w, 0, sizeof(w));
+  w.items[3] = keccak_inputs ? keccak_inputs : &none;
+  w.n[3] = n_perms;
+  return pg_txn(s, I, &w, out, out_words);
 }
-static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inputs, size_t n_perms, gl_t** out,
-                  size_t* out_words) {
+/* the general form: data for the tables with an AIR, by table index (0 arithmetic [n][9], 1 byte packing [n][6],
+ * 3 Keccak [n][25], 5 logic [n][9], 6 memory [n][11] sorted); given[t] != 0 selects a table (n may be 0) */
+int orc_pg_txn_witness(orc_pg_state* s, const uint64_t* I, const uint64_t* const items[NUM_TABLES], const size_t n[NUM_TABLES],
+                       const int given[NUM_TABLES], gl_t** out, size_t* out_words) {
+  static const uint64_t none = 0;
+  pg_witness w;
+  memset(&w, 0, sizeof(w));
+  for (int t = 0; t < NUM_TABLES; t++)
+    if (given[t] && WIT_WORDS[t]) {
+      w.items[t] = items[t] ? items[t] : &none;
+      w.n[t] = n[t];
+    }
+  return pg_txn(s, I, &w, out, out_words);
+}
+/* the table's whole input list: the given items, then padding (zero states / rows without an operation; the memory
+ * log goes on reading its last cell, one tick later each row) */
+static uint64_t* padded_items(int t, size_t rows, const uint64_t* items, size_t n) {
+  const size_t cap = t == 3 ? (rows + 23) / 24 : rows, wds = WIT_WORDS[t];
+  uint64_t* in = (uint64_t*)calloc(cap * wds, 8);
+  memcpy(in, items, n * wds * 8);
+  if (t == 6) {
+    uint64_t last[11] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (n) memcpy(last, items + (n - 1) * 11, sizeof(last));
+    last[0] = 1;
+    for (size_t i = n; i < cap; i++) {
+      last[2]++;
+      memcpy(in + i * 11, last, sizeof(last));
+    }
+  }
+  return in;
+}
+static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_t** out, size_t* out_words) {
   const orc_pg_config* cfg = &s->cfg;
   /* version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520: "Txn numbers before/after",
    * "Gas used before/after" equal, tries unchanged) -- same tables proven, public values do not advance */
@@ -179,7 +215,14 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inp
     if (tcfg[1].n_cols != ORC_BYTE_PACKING_COLS) return -2;
     tcfg[1].air_id = ORC_AIR_BYTE_PACKING;
   }
-  if (keccak_inputs && (!keccak_air || n_perms > (((size_t)1 << tcfg[3].log_n) + 23) / 24)) return -3;
+  if (wit) {
+    const int has_air[NUM_TABLES] = {arithmetic_air, byte_packing_air, 0, keccak_air, 0, logic_air, memory_air};
+    for (int t = 0; t < NUM_TABLES; t++) {
+      if (!wit->items[t]) continue;
+      const size_t rows = (size_t)1 << tcfg[t].log_n;
+      if (!has_air[t] || wit->n[t] > (t == 3 ? (rows + 23) / 24 : rows)) return -3;
+    }
+  }
   gl_t pv[PV_WORDS];
   pv[0] = I[3]; pv[1] = I[3] + (dummy ? 0 : 1); pv[2] = I[4]; pv[3] = I[5];
   memcpy(pv + 4, I + 6, 32);
@@ -196,11 +239,13 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const uint64_t* keccak_inp
   for (int t = 0; t < NUM_TABLES; t++) {
     size_t n = (size_t)1 << tcfg[t].log_n;
     trace[t] = (gl_t*)malloc(tcfg[t].n_cols * n * sizeof(gl_t));
-    if (tcfg[t].air_id == ORC_AIR_KECCAK_F && keccak_inputs) {
-      size_t need = (n + 23) / 24;
-      uint64_t* in = (uint64_t*)calloc(need * 25, 8);
-      memcpy(in, keccak_inputs, n_perms * 25 * 8);
-      orc_keccak_trace(0, in, tcfg[t].log_n, trace[t]);
+    if (wit && wit->items[t] && tcfg[t].air_id != ORC_AIR_SYNTHETIC) {
+      uint64_t* in = padded_items(t, n, wit->items[t], wit->n[t]);
+      if (t == 3) orc_keccak_trace(0, in, tcfg[t].log_n, trace[t]);
+      else if (t == 5) orc_logic_trace(0, in, tcfg[t].log_n, trace[t]);
+      else if (t == 6) orc_memory_trace(0, in, tcfg[t].log_n, trace[t]);
+      else if (t == 0) orc_arithmetic_trace(0, in, tcfg[t].log_n, trace[t]);
+      else orc_byte_packing_trace(0, in, tcfg[t].log_n, trace[t]);
       free(in);
     } else if (tcfg[t].air_id == ORC_AIR_KECCAK_F) orc_keccak_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_LOGIC) orc_logic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);

@@ -113,6 +113,8 @@ def lib():
     L.orc_pg_state_free.argtypes = [vp]
     L.orc_pg_txn.argtypes = [vp, u64p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_txn_keccak.argtypes = [vp, u64p, vp, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_pg_txn_witness.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
+                                     C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_preprocess.argtypes = [vp, u64p]
     L.orc_pg_agg.argtypes = [vp, u64p, sz, i, u64p, sz, i, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_block.argtypes = [vp, vp, sz, u64p, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
@@ -400,10 +402,22 @@ class PgState:
         if rc:
             raise RuntimeError("orc_pg_preprocess failed: %d" % rc)
 
-    def txn(self, ir_words, keccak_inputs=None):
-        """keccak_inputs: [n_perms, 25] permutation inputs of the txn's Keccak table (needs the IR's 0x100 flag)"""
+    WITNESS_WORDS = {0: 9, 1: 6, 3: 25, 5: 9, 6: 11}   # table index -> words per item (arithmetic, byte packing, keccak, logic, memory)
+
+    def txn(self, ir_words, keccak_inputs=None, witness=None):
+        """keccak_inputs: [n_perms, 25] permutation inputs of the txn's Keccak table (needs the IR's 0x100 flag).
+        witness: {table index: [n, words] array} for any of the tables with an AIR (orc_pg_txn_witness)."""
         ptr, n = C.POINTER(C.c_uint64)(), C.c_size_t()
-        if keccak_inputs is None:
+        if witness is not None:
+            if keccak_inputs is not None:
+                witness = {**witness, 3: keccak_inputs}
+            keep, items, counts, given = [], (C.c_void_p * 7)(), (C.c_size_t * 7)(), (C.c_int * 7)()
+            for t, data in witness.items():
+                a = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, self.WITNESS_WORDS[t])
+                keep.append(a)
+                items[t], counts[t], given[t] = (a.ctypes.data if a.size else None), a.shape[0], 1
+            rc = lib().orc_pg_txn_witness(self.h, arr(ir_words), items, counts, given, C.byref(ptr), C.byref(n))
+        elif keccak_inputs is None:
             rc = lib().orc_pg_txn(self.h, arr(ir_words), C.byref(ptr), C.byref(n))
         else:
             k = np.ascontiguousarray(keccak_inputs, dtype=np.uint64).reshape(-1, 25)

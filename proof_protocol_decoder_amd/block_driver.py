@@ -309,8 +309,39 @@ def keccak_inputs_of_generation_inputs(g, trie_nodes=False):
     return states
 
 
+def hashed_preimages_of_generation_inputs(g, trie_nodes=False):
+    """The byte strings keccak_inputs_of_generation_inputs hashes, in its order: signed_txn, the contract codes in
+    ascending hash order and, with trie_nodes, the hash-referenced nodes of the entry's partial tries."""
+    from .partial_trie import hashed_node_preimages
+    out = [bytes(g.signed_txn)] if g.signed_txn else []
+    out += [bytes(g.contract_code[h]) for h in sorted(g.contract_code)]
+    if trie_nodes:
+        for trie in [g.tries.state_trie, g.tries.transactions_trie, g.tries.receipts_trie] + [t for _, t in g.tries.storage_tries]:
+            out += hashed_node_preimages(trie.root)
+    return out
+
+
+def memory_and_byte_packing_work_of_preimages(preimages):
+    """What moving those byte strings to the hasher looks like in a zkEVM, as witness data for the memory table (AIR 3)
+    and the byte-packing table (AIR 5): every byte lives at its own address (the strings laid end to end), is written
+    once and read once -- the log is returned sorted by (address, timestamp), [is_read, address, timestamp, value limbs]
+    -- and the hasher takes them 32 at a time: one byte-packing sequence [is_read = 1, len, four words of byte slots]
+    per chunk (the last chunk of a string may be shorter)."""
+    log, seqs, addr = [], [], 0
+    for m in preimages:
+        for b in m:
+            log.append([0, addr, 2 * addr + 1, b, 0, 0, 0, 0, 0, 0, 0])      # the byte is stored ...
+            log.append([1, addr, 2 * addr + 2, b, 0, 0, 0, 0, 0, 0, 0])      # ... and read back by the packer
+            addr += 1
+        for off in range(0, len(m), 32):
+            chunk = m[off:off + 32]
+            padded = chunk + bytes(32 - len(chunk))
+            seqs.append([1, len(chunk)] + [int.from_bytes(padded[8 * w:8 * w + 8], "little") for w in range(4)])
+    return log, seqs
+
+
 def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width, keccak_air=False,
-                               keccak_trie_nodes=False):
+                               keccak_trie_nodes=False, memory_air=False, byte_packing_air=False):
     """`Vec<TxnProofGenIR>` as produced by `decoding.into_txn_proof_gen_ir` (the reference's
     BlockTrace::into_txn_proof_gen_ir: minimal tries, delta replay, dummy padding, withdrawals) -> the IRs this
     library's prover takes.  The zkEVM that would consume the partial tries is upstream-only, so
@@ -324,7 +355,10 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     permutations are the entry's OWN hashing work (keccak_inputs_of_generation_inputs): the table then attests data of
     the decoded transaction, not only a seed; its height grows to hold them (24 rows per permutation).
     keccak_trie_nodes: the hashing of the entry's partial tries is part of that work (the prover state's Keccak range
-    must then reach the taller tables)."""
+    must then reach the taller tables).
+    memory_air / byte_packing_air (with keccak_air): the memory table (AIR 3) and the byte-packing table (AIR 5) of
+    every entry hold the traffic of the SAME bytes on their way to the hasher
+    (memory_and_byte_packing_work_of_preimages) instead of a seeded witness; their heights grow to hold it."""
     from . import compact
     P = 0xFFFFFFFF00000001
     first = gen_inputs[0].tries.state_trie.hash()
@@ -332,6 +366,12 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     irs, txn_no, gas = [], 0, 0
     if keccak_air:
         table_width = tuple(2430 if t == 3 else w for t, w in enumerate(table_width))
+    if (memory_air or byte_packing_air) and not keccak_air:
+        raise ValueError("the memory / byte-packing work is that of the hashed bytes: it needs keccak_air")
+    if memory_air:
+        table_width = tuple(44 if t == 6 else w for t, w in enumerate(table_width))
+    if byte_packing_air:
+        table_width = tuple(297 if t == 1 else w for t, w in enumerate(table_width))
     base_log_n = tuple(table_log_n)
     for k, g in enumerate(gen_inputs):
         kw = {}
@@ -341,6 +381,18 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
             need = max(24 * len(states), 1)
             table_log_n = tuple(max(l, (need - 1).bit_length()) if t == 3 else l for t, l in enumerate(base_log_n))
             kw = dict(keccak_air=True, keccak_inputs=tuple(tuple(s) for s in states))
+            if memory_air or byte_packing_air:
+                log, seqs = memory_and_byte_packing_work_of_preimages(
+                    hashed_preimages_of_generation_inputs(g, trie_nodes=keccak_trie_nodes))
+                wit, ln = [], list(table_log_n)
+                if memory_air:
+                    ln[6] = max(ln[6], (max(len(log), 1) - 1).bit_length())
+                    wit.append((6, tuple(tuple(r) for r in log)))
+                if byte_packing_air:
+                    ln[1] = max(ln[1], (max(len(seqs), 1) - 1).bit_length())
+                    wit.append((1, tuple(tuple(r) for r in seqs)))
+                table_log_n = tuple(ln)
+                kw.update(memory_air=memory_air, byte_packing_air=byte_packing_air, witness=tuple(wit))
         r = g.trie_roots_after
         blob = (g.signed_txn or b"") + r.state_root + r.transactions_root + r.receipts_root
         blob += b"".join(bytes(a) + int(v).to_bytes(32, "big") for a, v in g.withdrawals)

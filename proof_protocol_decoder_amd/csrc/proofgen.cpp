@@ -452,11 +452,36 @@ int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_
 }
 BPG_ABI_CATCH("bp_proof_public_values")
 
-// keccak_inputs (nullable): the permutation inputs of the transaction's Keccak table, n_perms x 25 lanes; needs the
-// IR's Keccak-AIR flag.  Permutations beyond n_perms are of the all-zero state (as upstream pads its table).
+// Witness data given by the caller instead of drawn from the seed, per table (bp_txn_witness): in[t] nullable, n[t]
+// items of WITNESS_WORDS[t] words; the table must carry its AIR flag.  The rest of the table is padding: permutations
+// of the all-zero state (as upstream pads its Keccak table), rows without an operation, and for the memory log reads
+// of the last address at later and later times (a memory that is left alone).
+struct TxnWitness {
+  const uint64_t* in[BP_NUM_TABLES] = {};
+  size_t n[BP_NUM_TABLES] = {};
+};
+static const uint32_t WITNESS_WORDS[BP_NUM_TABLES] = {9, 6, 0, 25, 0, 9, 11};  // arithmetic, byte packing, -, keccak, -, logic, memory
+static const uint32_t WITNESS_AIR[BP_NUM_TABLES] = {air::ARITHMETIC, air::BYTE_PACKING, ~0u, air::KECCAK_F, ~0u, air::LOGIC, air::MEMORY};
+// items a table of N rows holds: one permutation per 24 rows for Keccak (the last one may be cut), else one per row
+static size_t witness_capacity(int t, uint64_t N) { return t == 3 ? (size_t)((N + 23) / 24) : (size_t)N; }
+// the table's full input array (capacity x words), the caller's items first, then padding
+static void fill_table_inputs(int t, uint64_t N, const uint64_t* in, size_t n, uint64_t* dst) {
+  const size_t cap = witness_capacity(t, N), wds = WITNESS_WORDS[t];
+  std::memcpy(dst, in, n * wds * 8);
+  std::memset(dst + n * wds, 0, (cap - n) * wds * 8);
+  if (t == 6) {  // memory: keep reading the last cell (a first-row read of zero memory when the log is empty)
+    uint64_t last[11] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (n) std::memcpy(last, in + (n - 1) * 11, sizeof(last));
+    last[0] = 1;
+    for (size_t i = n; i < cap; i++) {
+      last[2] += 1;
+      std::memcpy(dst + i * 11, last, sizeof(last));
+    }
+  }
+}
 static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
                           const volatile uint8_t* abort_flag_u8, uint8_t** out, size_t* out_len,
-                          const uint64_t* keccak_inputs = nullptr, size_t n_perms = 0) {
+                          const TxnWitness* wit = nullptr) {
   if (!s || !ir || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof: null argument");
   if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
   const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
@@ -472,11 +497,18 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 31) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
   const bool dummy = ver == 2, keccak_air = (flags & 1) != 0, logic_air = (flags & 2) != 0, memory_air = (flags & 4) != 0,
              arithmetic_air = (flags & 8) != 0, byte_packing_air = (flags & 16) != 0;
-  if (keccak_inputs && !keccak_air)
-    return fail(BP_ERR_INVALID_INPUT, "Keccak permutation inputs need an IR whose Keccak table is the Keccak-f AIR (bp_ir_set_keccak_air)");
-  if (keccak_inputs && n_perms > (((size_t)1 << I[11 + 3]) + 23) / 24)
-    return fail(BP_ERR_RANGE, "%zu Keccak permutations do not fit a table of 2^%llu rows (24 rows each)", n_perms,
-                (unsigned long long)I[11 + 3]);
+  if (wit) {
+    const bool has_air[BP_NUM_TABLES] = {arithmetic_air, byte_packing_air, false, keccak_air, false, logic_air, memory_air};
+    for (int t = 0; t < BP_NUM_TABLES; t++) {
+      if (!wit->in[t]) continue;
+      if (!has_air[t])
+        return fail(BP_ERR_INVALID_INPUT, "witness data for table %s needs an IR whose %s table is proven with its AIR (bp_ir_set_*_air)",
+                    TABLE_NAMES[t], TABLE_NAMES[t]);
+      if (I[11 + t] < 40 && wit->n[t] > witness_capacity(t, (uint64_t)1 << I[11 + t]))
+        return fail(BP_ERR_RANGE, "%zu witness items do not fit table %s of 2^%llu rows%s", wit->n[t], TABLE_NAMES[t],
+                    (unsigned long long)I[11 + t], t == 3 ? " (24 rows per Keccak permutation)" : "");
+    }
+  }
   if (I[5] < I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: gas_used_after < gas_used_before");
   if (dummy && I[5] != I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: a dummy entry must not use gas (decoding.rs:503-506)");
   const bp_config& cfg = s->cfg;
@@ -521,17 +553,20 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
     const uint64_t N = (uint64_t)1 << tcfg[t].log_n;
     d_trace[t] = w.arena.alloc_words((size_t)tcfg[t].n_cols * N);
     if (!d_trace[t]) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) for table %s", w.arena.capacity() >> 20, TABLE_NAMES[t]);
-    if (tcfg[t].air_id == air::KECCAK_F && keccak_inputs) {
-      // the caller's permutations, then all-zero states up to the table's height, staged through the pinned buffer
-      const size_t need = (N + 23) / 24;
-      uint64_t* d_in = w.arena.alloc_words(need * 25);
-      if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the Keccak inputs");
-      if (need * 25 > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "Keccak table too tall for the input staging buffer");
-      std::memcpy(w.pinned, keccak_inputs, n_perms * 25 * 8);
-      std::memset(w.pinned + n_perms * 25, 0, (need - n_perms) * 25 * 8);
-      BPG_HIP(hipMemcpyAsync(d_in, w.pinned, need * 25 * 8, hipMemcpyHostToDevice, w.stream));
-      r = launch_keccak_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream);
-      if (r == BP_OK) r = w.wait();  // the staging buffer is reused by the commitments below
+    if (wit && wit->in[t] && tcfg[t].air_id == WITNESS_AIR[t]) {
+      // the caller's items, then padding up to the table's height, staged through the pinned buffer
+      const size_t words = witness_capacity(t, N) * WITNESS_WORDS[t];
+      uint64_t* d_in = w.arena.alloc_words(words);
+      if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the witness data of table %s", TABLE_NAMES[t]);
+      if (words > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "table %s too tall for the input staging buffer", TABLE_NAMES[t]);
+      fill_table_inputs(t, N, wit->in[t], wit->n[t], w.pinned);
+      BPG_HIP(hipMemcpyAsync(d_in, w.pinned, words * 8, hipMemcpyHostToDevice, w.stream));
+      r = t == 3   ? launch_keccak_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
+          : t == 5 ? launch_logic_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
+          : t == 6 ? launch_memory_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
+          : t == 0 ? launch_arithmetic_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
+                   : launch_byte_packing_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream);
+      if (r == BP_OK) r = w.wait();  // the staging buffer is reused by the next table and the commitments below
     } else {
       r = tcfg[t].air_id == air::KECCAK_F
               ? launch_keccak_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
@@ -646,9 +681,31 @@ int bp_generate_txn_proof_keccak(const bp_state* s, const uint8_t* ir, size_t ir
                                  size_t n_perms, const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len) try {
   if (!keccak_inputs && n_perms) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof_keccak: null inputs");
   static const uint64_t none = 0;
-  return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len, keccak_inputs ? keccak_inputs : &none, n_perms);
+  TxnWitness wit;
+  wit.in[3] = keccak_inputs ? keccak_inputs : &none;
+  wit.n[3] = n_perms;
+  return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len, &wit);
 }
 BPG_ABI_CATCH("bp_generate_txn_proof_keccak")
+// The general form: witness data for any of the tables that have an AIR (bp_txn_witness, include/bpg.h).
+int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
+                                  const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len) try {
+  if (!data) return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len);
+  static const uint64_t none = 0;
+  TxnWitness wit;
+  const struct { int t; const uint64_t* p; size_t n; int given; } f[5] = {
+      {3, data->keccak_inputs, data->n_perms, data->has_keccak}, {5, data->logic_ops, data->n_logic_ops, data->has_logic},
+      {6, data->memory_log, data->n_memory_ops, data->has_memory}, {0, data->arithmetic_ops, data->n_arithmetic_ops, data->has_arithmetic},
+      {1, data->byte_sequences, data->n_byte_sequences, data->has_byte_packing}};
+  for (const auto& x : f) {
+    if (!x.given) continue;
+    if (!x.p && x.n) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof_witness: null data for table %s", TABLE_NAMES[x.t]);
+    wit.in[x.t] = x.p ? x.p : &none;
+    wit.n[x.t] = x.n;
+  }
+  return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len, &wit);
+}
+BPG_ABI_CATCH("bp_generate_txn_proof_witness")
 
 int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
                           const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len) try {

@@ -67,6 +67,8 @@ def _bind():
     L.bp_ir_set_byte_packing_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_keccak256_permutation_inputs.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t,
                                                   C.POINTER(C.c_size_t)]
+    L.bp_generate_txn_proof_witness.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.bp_generate_txn_proof_keccak.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t,
                                                C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.bp_proof_public_values.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
@@ -127,6 +129,8 @@ class TxnProofGenIR:
     memory_air: bool = False   # the memory table (index 6) with the memory AIR (AIR 3, 44 columns)
     arithmetic_air: bool = False   # the arithmetic table (index 0) with the arithmetic AIR (AIR 4, 309 columns)
     byte_packing_air: bool = False   # the byte-packing table (index 1) with the byte-packing AIR (AIR 5, 297 columns)
+    witness: tuple = None   # ((table index, ((words of an item), ...)), ...): data for tables with an AIR instead of a
+                            # seeded witness (bp_generate_txn_proof_witness); like keccak_inputs not part of the 25-word IR
 
     def to_bytes(self):
         L = _bind()
@@ -271,18 +275,52 @@ def keccak256_permutation_inputs(data: bytes):
     return digest.raw, [list(states[25 * i:25 * i + 25]) for i in range(n.value)]
 
 
-def generate_txn_proof(p_state, gen_inputs, abort_signal=None, keccak_inputs=None):
+class TxnWitness(C.Structure):
+    """bp_txn_witness (include/bpg.h)"""
+    _fields_ = [(n, t) for name in ("keccak_inputs:n_perms:has_keccak", "logic_ops:n_logic_ops:has_logic",
+                                    "memory_log:n_memory_ops:has_memory", "arithmetic_ops:n_arithmetic_ops:has_arithmetic",
+                                    "byte_sequences:n_byte_sequences:has_byte_packing")
+                for n, t in zip(name.split(":"), (C.c_void_p, C.c_size_t, C.c_int))]
+
+
+WITNESS_FIELDS = {3: ("keccak_inputs", "n_perms", "has_keccak", 25), 5: ("logic_ops", "n_logic_ops", "has_logic", 9),
+                  6: ("memory_log", "n_memory_ops", "has_memory", 11), 0: ("arithmetic_ops", "n_arithmetic_ops", "has_arithmetic", 9),
+                  1: ("byte_sequences", "n_byte_sequences", "has_byte_packing", 6)}
+
+
+def generate_txn_proof(p_state, gen_inputs, abort_signal=None, keccak_inputs=None, witness=None):
     """proof_gen.rs:39-56.  abort_signal: optional shared flag (the reference's Option<Arc<AtomicBool>>): a
     ctypes.c_uint8 / c_bool (one byte, what AtomicBool is: bp_generate_txn_proof_u8) or a ctypes.c_int32.
     keccak_inputs: the permutation inputs ([n][25] lanes) of the transaction's Keccak table, for an IR with
-    keccak_air=True (bp_generate_txn_proof_keccak); default: gen_inputs.keccak_inputs if it has any."""
+    keccak_air=True (bp_generate_txn_proof_keccak); default: gen_inputs.keccak_inputs if it has any.
+    witness: {table index: [[words of an item], ...]} for the tables proven with an AIR (0 arithmetic [9], 1 byte packing
+    [6], 3 Keccak [25], 5 logic [9], 6 memory [11]; bp_generate_txn_proof_witness); default: gen_inputs.witness."""
     L = _bind()
     ir = gen_inputs.to_bytes() if isinstance(gen_inputs, TxnProofGenIR) else bytes(gen_inputs)
     out, n = _out()
     flag = C.byref(abort_signal) if abort_signal is not None else None
     if keccak_inputs is None:
         keccak_inputs = getattr(gen_inputs, "keccak_inputs", None)
-    if keccak_inputs is not None:
+    if witness is None and getattr(gen_inputs, "witness", None) is not None:
+        witness = dict(gen_inputs.witness)
+    if witness is not None:
+        if keccak_inputs is not None and 3 not in witness:
+            witness = {**witness, 3: keccak_inputs}
+        if abort_signal is not None and C.sizeof(abort_signal) != 1:
+            raise ValueError("bp_generate_txn_proof_witness takes the one-byte abort flag")
+        w, keep = TxnWitness(), []
+        for t, items in witness.items():
+            ptr_f, n_f, has_f, words = WITNESS_FIELDS[t]
+            flat = [int(x) for it in items for x in it]
+            if len(flat) % words:
+                raise ValueError("witness items of table %d have %d words each" % (t, words))
+            a = (C.c_uint64 * max(len(flat), 1))(*flat)
+            keep.append(a)
+            setattr(w, ptr_f, C.cast(a, C.c_void_p))
+            setattr(w, n_f, len(flat) // words)
+            setattr(w, has_f, 1)
+        check(L.bp_generate_txn_proof_witness(p_state._h, ir, len(ir), C.byref(w), flag, C.byref(out), C.byref(n)))
+    elif keccak_inputs is not None:
         flat = [int(x) for st in keccak_inputs for x in st]
         arr = (C.c_uint64 * max(len(flat), 1))(*flat)
         if abort_signal is not None and C.sizeof(abort_signal) != 1:

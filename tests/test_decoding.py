@@ -549,3 +549,61 @@ def test_keccak_work_includes_the_hashing_of_the_partial_tries():
                                      keccak_trie_nodes=True)
     assert all(24 * len(ir.keccak_inputs) <= (1 << ir.table_log_n[3]) for ir in irs)
     assert max(ir.table_log_n[3] for ir in irs) > 7           # the tables grew to hold the trie hashing
+
+
+def test_memory_and_byte_packing_work_of_a_decoded_transaction():
+    """irs_from_generation_inputs(..., memory_air=True, byte_packing_air=True): the memory log and the byte-packing
+    sequences of an entry are the traffic of exactly the bytes its Keccak table hashes -- the log replays as a memory
+    whose reads return those bytes in order, the sequences spell the 32-byte chunks big-endian, and the oracle's
+    witnesses of both (padded to the table heights the IR asks for) satisfy what tests/test_memory_air.py and
+    tests/test_byte_packing_air.py check (host only)."""
+    import numpy as np
+    from oracle import pyoracle
+    from proof_protocol_decoder_amd.block_driver import (hashed_preimages_of_generation_inputs, irs_from_generation_inputs,
+                                                         memory_and_byte_packing_work_of_preimages)
+    import test_memory_air as tm
+    pyoracle.build()
+    m = fresh_model()
+    infos = [t for t, _ in block(m)]
+    other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", []), b"\x22" * 32)
+    gis = decoding.into_txn_proof_gen_ir(make_trace(m, infos), other)
+    irs = irs_from_generation_inputs(gis, 17, (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8), keccak_air=True,
+                                     keccak_trie_nodes=True, memory_air=True, byte_packing_air=True)
+    busy = 0
+    for g, ir in zip(gis, irs):
+        assert ir.memory_air and ir.byte_packing_air and ir.table_width[6] == 44 and ir.table_width[1] == 297
+        pre = hashed_preimages_of_generation_inputs(g, trie_nodes=True)
+        blob = b"".join(pre)
+        wit = dict(ir.witness)
+        log, seqs = np.array(wit[6], dtype=np.uint64).reshape(-1, 11), np.array(wit[1], dtype=np.uint64).reshape(-1, 6)
+        assert len(log) == 2 * len(blob) <= (1 << ir.table_log_n[6]) and len(seqs) <= (1 << ir.table_log_n[1])
+        if not len(blob):
+            continue
+        busy += 1
+        # sorted by (address, timestamp); the reads, in address order, are the hashed bytes
+        keys = [(int(r[1]), int(r[2])) for r in log]
+        assert keys == sorted(keys) and len(set(keys)) == len(keys)
+        assert bytes(int(r[3]) for r in log if r[0] == 1) == blob
+        # the sequences are the strings cut into 32-byte chunks
+        chunks = [p[o:o + 32] for p in pre for o in range(0, len(p), 32)]
+        assert len(seqs) == len(chunks)
+        for s, c in zip(seqs, chunks):
+            assert int(s[0]) == 1 and int(s[1]) == len(c)
+            assert b"".join(int(w).to_bytes(8, "little") for w in s[2:])[:len(c)] == c
+        # the oracle's witnesses of the padded inputs are a memory / spell the chunks
+        n_rows = 1 << ir.table_log_n[6]
+        padded = np.zeros((n_rows, 11), dtype=np.uint64)
+        padded[:len(log)] = log
+        last = log[-1].copy()
+        last[0] = 1
+        for i in range(len(log), n_rows):
+            last[2] += np.uint64(1)
+            padded[i] = last
+        tm.check_trace_is_a_memory(pyoracle.memory_trace(ir.table_log_n[6], inputs=padded))
+        bp_rows = 1 << ir.table_log_n[1]
+        bp = np.zeros((bp_rows, 6), dtype=np.uint64)
+        bp[:len(seqs)] = seqs
+        t = pyoracle.byte_packing_trace(ir.table_log_n[1], inputs=bp)
+        for r, c in enumerate(chunks):
+            assert sum(int(t[289 + k, r]) << (32 * k) for k in range(8)) == int.from_bytes(c, "big")
+    assert busy >= 2

@@ -260,7 +260,7 @@ def test_decoded_transactions_prove_their_own_keccak_work(bpg, pg, p_state, o_st
     assert o_state.verify(words(blk.intern)) == 0
     # inputs without the flag, or more permutations than the table has rows for, are refused
     plain = pg.TxnProofGenIR(22, 0, 0, 1, (1, 2, 3, 4), 9, tuple(LOG_N), tuple(WIDTH))
-    with pytest.raises(pg.ProofGenError, match="Keccak-f AIR"):
+    with pytest.raises(pg.ProofGenError, match="table keccak needs an IR"):
         pg.generate_txn_proof(p_state, plain, keccak_inputs=states)
     with pytest.raises(pg.ProofGenError, match="do not fit"):
         pg.generate_txn_proof(p_state, irs[0], keccak_inputs=[[0] * 25] * 200)
@@ -380,6 +380,77 @@ def test_decoded_transactions_prove_the_hashing_of_their_partial_tries(bpg, pg, 
         finally:
             drv.close()
         pg.VerifierState.from_prover_state(st).verify(blk)
+    finally:
+        st.close()
+
+
+def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, oracle):
+    """memory_air / byte_packing_air with keccak_air: three tables of a decoded entry hold data of the entry, not a seed
+    -- the Keccak table the hashing of its signed transaction, code and partial tries, the memory table the log of
+    those bytes (written once, read once), the byte-packing table the same bytes taken 32 at a time
+    (bp_generate_txn_proof_witness).  The device witnesses contain the bytes; proofs equal the oracle's byte for byte
+    (orc_pg_txn_witness); the block verifies."""
+    import test_decoding as td
+    from proof_protocol_decoder_amd import decoding
+    from proof_protocol_decoder_amd.block_driver import (BlockDriver, hashed_preimages_of_generation_inputs,
+                                                         irs_from_generation_inputs)
+    hi = list(SMALL["table_log_hi"])
+    hi[1], hi[3], hi[6] = 8, 11, 13
+    cfg = dict(SMALL, table_log_hi=hi)
+    b = pg.ProverStateBuilder()
+    for t, name in enumerate(pg.TABLES):
+        getattr(b, "set_%s_circuit_size" % name)(range(cfg["table_log_lo"][t], cfg["table_log_hi"][t]))
+    b.set(**{k: v for k, v in cfg.items() if not k.startswith("table_")}, n_workers=2, arena_bytes=256 << 20)
+    st, ost = b.build(), oracle.PgState(**cfg)
+    try:
+        m = td.fresh_model()
+        infos = [t for t, _ in td.block(m)]
+        other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", [(td.B, 100)]), b"\x22" * 32)
+        gis = decoding.into_txn_proof_gen_ir(td.make_trace(m, infos, hash_out_storage_of=(td.E,)), other)
+        irs = irs_from_generation_inputs(gis, 24, LOG_N, WIDTH, keccak_air=True, keccak_trie_nodes=True, memory_air=True,
+                                         byte_packing_air=True)
+        g, ir = next((g, ir) for g, ir in zip(gis, irs) if g.signed_txn)
+        pre = hashed_preimages_of_generation_inputs(g, trie_nodes=True)
+        blob = b"".join(pre)
+        wit = dict(ir.witness)
+        # the device's memory witness of the entry's log holds the hashed bytes (value limb 0 of the reads) ...
+        import torch
+        log_n = ir.table_log_n[6]
+        log = np.array(wit[6], dtype=np.uint64).reshape(-1, 11)
+        padded = np.zeros((1 << log_n, 11), dtype=np.uint64)
+        padded[:len(log)] = log
+        last = log[-1].copy()
+        last[0] = 1
+        for i in range(len(log), 1 << log_n):
+            last[2] += np.uint64(1)
+            padded[i] = last
+        tr = bpg.ops.memory_trace(log_n, inputs=torch.from_numpy(padded.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
+        reads = tr[0, :len(log)] == 1
+        assert bytes(int(x) for x in tr[3, :len(log)][reads]) == blob
+        # ... and the byte-packing witness spells the first chunk of the first string (the signed transaction)
+        seqs = np.array(wit[1], dtype=np.uint64).reshape(-1, 6)
+        bp = np.zeros((1 << ir.table_log_n[1], 6), dtype=np.uint64)
+        bp[:len(seqs)] = seqs
+        tb = bpg.ops.byte_packing_trace(ir.table_log_n[1], inputs=torch.from_numpy(bp.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
+        assert sum(int(tb[289 + k, 0]) << (32 * k) for k in range(8)) == int.from_bytes(pre[0][:32], "big")
+        assert pre[0] == bytes(g.signed_txn)
+        for e in irs:
+            got = pg.generate_txn_proof(st, e)
+            w = {t: np.array(items, dtype=np.uint64) for t, items in e.witness}
+            want = ost.txn(list(struct.unpack("<25Q", e.to_bytes())), keccak_inputs=np.array(e.keccak_inputs, dtype=np.uint64).reshape(-1, 25),
+                           witness=w)
+            assert (words(got.intern) == want).all()
+        assert pg.generate_txn_proof(st, irs[0], witness={6: (), 1: ()}).intern != pg.generate_txn_proof(st, irs[0]).intern
+        drv = BlockDriver(st, n_threads=2)
+        try:
+            blk = drv.prove_block_distributed(irs)
+        finally:
+            drv.close()
+        pg.VerifierState.from_prover_state(st).verify(blk)
+        # data for a table whose IR flag is not set is refused
+        plain = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 5, tuple(LOG_N), tuple(WIDTH))
+        with pytest.raises(pg.ProofGenError, match="memory"):
+            pg.generate_txn_proof(st, plain, witness={6: ()})
     finally:
         st.close()
 
