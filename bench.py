@@ -89,8 +89,9 @@ def main():
                     help="every transaction's Keccak table is a real Keccak-f[1600] trace (AIR 1, 2430 columns) instead "
                          "of the 2432-column synthetic table BASELINE's metric is quoted on")
     ap.add_argument("--real-airs", action="store_true",
-                    help="the arithmetic, byte-packing, Keccak, logic and memory tables of every transaction are proven with the "
-                         "AIRs written from their public definitions (AIR 4, 5, 1, 2, 3: 309 / 297 / 2430 / 523 / 44 columns) instead of synthetic tables of "
+                    help="the arithmetic, byte-packing, Keccak, Keccak-sponge, logic and memory tables of every transaction are "
+                         "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / "
+                         "2414 / 523 / 44 columns) instead of synthetic tables of "
                          "BASELINE's widths -- another workload than the metric's, reported as such")
     ap.add_argument("--poseidon-grouped", type=int, default=None, help="bp_tune_poseidon_grouped: 0 / 2 / 3 groups of partial rounds (measurement knob)")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
@@ -281,7 +282,7 @@ def main():
 
     blocks = [synthetic_block_irs(b, args.txns, S1_LOG_N, S1_WIDTH, keccak_air=args.keccak_air or args.real_airs,
                                   logic_air=args.real_airs, memory_air=args.real_airs, arithmetic_air=args.real_airs,
-                                  byte_packing_air=args.real_airs)
+                                  byte_packing_air=args.real_airs, keccak_sponge_air=args.real_airs)
               for b in range(args.warmup + args.steps)]
     last = None
     phase("warmup")
@@ -342,7 +343,8 @@ def main():
                                    else "synthetic AIR, 2432 columns",
                    **({"logic_table": "logic AIR, 523 columns", "memory_table": "memory AIR, 44 columns",
                        "arithmetic_table": "arithmetic AIR, 309 columns",
-                       "byte_packing_table": "byte-packing AIR, 297 columns"} if args.real_airs else {}),
+                       "byte_packing_table": "byte-packing AIR, 297 columns",
+                       "keccak_sponge_table": "Keccak sponge AIR, 2414 columns"} if args.real_airs else {}),
                    "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
                    "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
                    "ms_of_each_step_rank0": step_ms, "host_waits": host_waits, **t_build_info},

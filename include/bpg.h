@@ -190,7 +190,8 @@ struct bp_stark_cfg;
  * row on 2430 columns, written from FIPS 202 (not upstream's column layout), 2 = logic, one AND / OR / XOR of two
  * 256-bit words per row on 523 columns, 3 = memory, a log of reads and writes sorted by (address, timestamp) on 44
  * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns, 5 = byte_packing,
- * a big-endian byte sequence and the word it spells on 297 columns (likewise their own layouts).  bp_air_describe returns the shape and
+ * a big-endian byte sequence and the word it spells on 297 columns, 6 = keccak_sponge, the absorbing side of
+ * Keccak-256 (XOR into the rate, chaining, pad10*1) on 2414 columns (likewise their own layouts).  bp_air_describe returns the shape and
  * the constraint list of an AIR as families (first index, count, kind, degree); the list is followed, for every
  * air_id, by the two constraints of each cross-table-lookup-like auxiliary column (n_cols / 8 of them). */
 typedef struct bp_air_family {
@@ -252,6 +253,12 @@ int bp_arithmetic_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n,
  * (0 = a padding row; above 32: 32), the 32 byte slots as four 64-bit words (slot i = byte i % 8 of word i / 8; slots
  * from len on are ignored); or NULL to draw them from `seed`. */
 int bp_byte_packing_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
+/* Witness of AIR 6 (the Keccak sponge table: the absorbing side of Keccak-256, one 136-byte block per row): n =
+ * 2^log_n rows x 2414 columns, column-major.  d_inputs: [n][44] = flags (1 full block, 2 final block, 0 padding row),
+ * message bytes in the block, the block as absorbed (17 words, pad10*1 included), the 25 lanes of the state before the
+ * block -- bp_keccak256_sponge_rows makes them for a message; or NULL for one single-block message per row drawn from
+ * `seed`.  The kernel computes the XOR and the permutation of every row. */
+int bp_keccak_sponge_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
 /* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
  * folded domain), done in the evaluation domain.  d_values: the layer's n_l << rate_bits extension values
@@ -288,7 +295,7 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
-/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 / 2 / 3 / 4 / 5: n_cols = 2430 / 523 / 44 / 309 / 297,
+/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 / 2 / 3 / 4 / 5 / 6: n_cols = 2430 / 523 / 44 / 309 / 297 / 2414,
  * n_const = 0, deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
 int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                        uint8_t** out, size_t* out_len);
@@ -378,6 +385,7 @@ typedef struct bp_txn_witness {
   const uint64_t* memory_log;      size_t n_memory_ops;      int has_memory;
   const uint64_t* arithmetic_ops;  size_t n_arithmetic_ops;  int has_arithmetic;
   const uint64_t* byte_sequences;  size_t n_byte_sequences;  int has_byte_packing;
+  const uint64_t* sponge_rows;     size_t n_sponge_rows;     int has_keccak_sponge;  /* [n][44], bp_keccak256_sponge_rows */
 } bp_txn_witness;
 int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
                                   const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len);
@@ -427,6 +435,8 @@ int bp_ir_set_memory_air(uint64_t ir[BP_IR_WORDS], int on);
 int bp_ir_set_arithmetic_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the byte-packing table (flag 0x1000; table index 1): the byte-packing AIR (air_id 5: 297 columns). */
 int bp_ir_set_byte_packing_air(uint64_t ir[BP_IR_WORDS], int on);
+/* ... and for the Keccak sponge table (flag 0x2000; table index 4): the Keccak sponge AIR (air_id 6: 2414 columns). */
+int bp_ir_set_keccak_sponge_air(uint64_t ir[BP_IR_WORDS], int on);
 /* public values of a proof container: txn_before, txn_after, gas_before, gas_after, root_before[4],
  * root_after[4], block_number */
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out);
@@ -461,6 +471,10 @@ void bp_keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
  * states_out (room for max_perms x 25 words) and digest_out may be NULL; *n_perms_out is always set.  Host only. */
 int bp_keccak256_permutation_inputs(const uint8_t* data, size_t len, uint8_t digest_out[32], uint64_t* states_out,
                                     size_t max_perms, size_t* n_perms_out);
+/* The same hash as rows of the Keccak sponge table (bp_keccak_sponge_trace): 44 words per 136-byte block.  rows_out
+ * may be NULL to count. */
+int bp_keccak256_sponge_rows(const uint8_t* data, size_t len, uint8_t digest_out[32], uint64_t* rows_out, size_t max_rows,
+                             size_t* n_rows_out);
 
 /* ------------------------------------------------------------------------------------------
  * Next row: the txn IR producer, BlockTrace::into_txn_proof_gen_ir

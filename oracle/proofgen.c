@@ -131,7 +131,7 @@ int orc_pg_preprocess(orc_pg_state* s, const uint64_t* I) {
 /* generate_txn_proof (proof_gen.rs:39-56) on the synthetic workload */
 /* witness data per table (NULL: drawn from the seed): items[t] x n[t], WIT_WORDS[t] words each */
 typedef struct { const uint64_t* items[NUM_TABLES]; size_t n[NUM_TABLES]; } pg_witness;
-static const unsigned WIT_WORDS[NUM_TABLES] = {9, 6, 0, 25, 0, 9, 11};
+static const unsigned WIT_WORDS[NUM_TABLES] = {9, 6, 0, 25, 44, 9, 11};
 static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_t** out, size_t* out_words);
 int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) { return pg_txn(s, I, NULL, out, out_words); }
 /* the same with the Keccak table's permutation inputs given (n_perms x 25 lanes; the rest of the table: zero states) */
@@ -184,11 +184,13 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
    * 0x200 = the logic table (index 5) is proven with the logic AIR (logic_air.c): 523 columns;
    * 0x400 = the memory table (index 6) with the memory AIR (memory_air.c): 44 columns;
    * 0x800 = the arithmetic table (index 0) with the arithmetic AIR (arithmetic_air.c): 309 columns;
-   * 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (byte_packing_air.c): 297 columns */
+   * 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (byte_packing_air.c): 297 columns;
+   * 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (keccak_sponge_air.c): 2414 columns */
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
-  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 31) return -2;
+  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 63) return -2;
   const int dummy = ver == 2, keccak_air = (int)(flags & 1), logic_air = (int)((flags >> 1) & 1), memory_air = (int)((flags >> 2) & 1),
-            arithmetic_air = (int)((flags >> 3) & 1), byte_packing_air = (int)((flags >> 4) & 1);
+            arithmetic_air = (int)((flags >> 3) & 1), byte_packing_air = (int)((flags >> 4) & 1),
+            sponge_air = (int)((flags >> 5) & 1);
   if (dummy && I[4] != I[5]) return -2;
   orc_stark_cfg tcfg[NUM_TABLES];
   for (int t = 0; t < NUM_TABLES; t++) {
@@ -215,8 +217,12 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
     if (tcfg[1].n_cols != ORC_BYTE_PACKING_COLS) return -2;
     tcfg[1].air_id = ORC_AIR_BYTE_PACKING;
   }
+  if (sponge_air) {
+    if (tcfg[4].n_cols != ORC_KECCAK_SPONGE_COLS) return -2;
+    tcfg[4].air_id = ORC_AIR_KECCAK_SPONGE;
+  }
   if (wit) {
-    const int has_air[NUM_TABLES] = {arithmetic_air, byte_packing_air, 0, keccak_air, 0, logic_air, memory_air};
+    const int has_air[NUM_TABLES] = {arithmetic_air, byte_packing_air, 0, keccak_air, sponge_air, logic_air, memory_air};
     for (int t = 0; t < NUM_TABLES; t++) {
       if (!wit->items[t]) continue;
       const size_t rows = (size_t)1 << tcfg[t].log_n;
@@ -245,6 +251,7 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
       else if (t == 5) orc_logic_trace(0, in, tcfg[t].log_n, trace[t]);
       else if (t == 6) orc_memory_trace(0, in, tcfg[t].log_n, trace[t]);
       else if (t == 0) orc_arithmetic_trace(0, in, tcfg[t].log_n, trace[t]);
+      else if (t == 4) orc_keccak_sponge_trace(0, in, tcfg[t].log_n, trace[t]);
       else orc_byte_packing_trace(0, in, tcfg[t].log_n, trace[t]);
       free(in);
     } else if (tcfg[t].air_id == ORC_AIR_KECCAK_F) orc_keccak_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
@@ -252,6 +259,7 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
     else if (tcfg[t].air_id == ORC_AIR_MEMORY) orc_memory_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_ARITHMETIC) orc_arithmetic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_BYTE_PACKING) orc_byte_packing_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
+    else if (tcfg[t].air_id == ORC_AIR_KECCAK_SPONGE) orc_keccak_sponge_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
     tc[t] = orc_commit_values(trace[t], tcfg[t].log_n, tcfg[t].n_cols, tcfg[t].rate_bits, tcfg[t].cap_height);
     orc_ch_observe_many(&ch, orc_committed_cap(tc[t]), (size_t)4 << tcfg[t].cap_height);

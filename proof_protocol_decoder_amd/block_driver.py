@@ -191,13 +191,14 @@ class BlockDriver:
 
 def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_base=0x5EED000000000000,
                         root0=(1, 2, 3, 4), keccak_air=False, logic_air=False, memory_air=False, arithmetic_air=False,
-                        byte_packing_air=False):
+                        byte_packing_air=False, keccak_sponge_air=False):
     """The synthetic block of SURVEY.md section 8(d): n_txns txns with distinct seeds whose public
     values chain (state root, txn number, gas) like decoding.rs:106-154 chains GenerationInputs.
     keccak_air: every transaction's Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1; the table's width
     becomes 2430).  logic_air / memory_air: likewise the logic table (index 5) with the logic AIR (AIR 2; width 523) and
     the memory table (index 6) with the memory AIR (AIR 3; width 44); arithmetic_air: the arithmetic table (index 0)
-    with the arithmetic AIR (AIR 4; width 309); byte_packing_air: the byte-packing table (index 1) with AIR 5 (width 297)."""
+    with the arithmetic AIR (AIR 4; width 309); byte_packing_air: the byte-packing table (index 1) with AIR 5 (width 297);
+    keccak_sponge_air: the Keccak sponge table (index 4) with AIR 6 (width 2414)."""
     if keccak_air:
         table_width = tuple(2430 if t == 3 else w for t, w in enumerate(table_width))
     if logic_air:
@@ -208,6 +209,8 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
         table_width = tuple(309 if t == 0 else w for t, w in enumerate(table_width))
     if byte_packing_air:
         table_width = tuple(297 if t == 1 else w for t, w in enumerate(table_width))
+    if keccak_sponge_air:
+        table_width = tuple(2414 if t == 4 else w for t, w in enumerate(table_width))
     import ctypes as C
     L = pg._bind()
     L.bp_state_root_after.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -217,7 +220,7 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
         irs.append(pg.TxnProofGenIR(block_number, i, gas, gas + 21000, root, seed, tuple(table_log_n),
                                     tuple(table_width), keccak_air=keccak_air, logic_air=logic_air,
                                     memory_air=memory_air, arithmetic_air=arithmetic_air,
-                                    byte_packing_air=byte_packing_air))
+                                    byte_packing_air=byte_packing_air, keccak_sponge_air=keccak_sponge_air))
         out = (C.c_uint64 * 4)()
         pg.check(L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out))
         root, gas = tuple(out), gas + 21000
@@ -341,7 +344,7 @@ def memory_and_byte_packing_work_of_preimages(preimages):
 
 
 def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width, keccak_air=False,
-                               keccak_trie_nodes=False, memory_air=False, byte_packing_air=False):
+                               keccak_trie_nodes=False, memory_air=False, byte_packing_air=False, keccak_sponge_air=False):
     """`Vec<TxnProofGenIR>` as produced by `decoding.into_txn_proof_gen_ir` (the reference's
     BlockTrace::into_txn_proof_gen_ir: minimal tries, delta replay, dummy padding, withdrawals) -> the IRs this
     library's prover takes.  The zkEVM that would consume the partial tries is upstream-only, so
@@ -358,7 +361,10 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     must then reach the taller tables).
     memory_air / byte_packing_air (with keccak_air): the memory table (AIR 3) and the byte-packing table (AIR 5) of
     every entry hold the traffic of the SAME bytes on their way to the hasher
-    (memory_and_byte_packing_work_of_preimages) instead of a seeded witness; their heights grow to hold it."""
+    (memory_and_byte_packing_work_of_preimages) instead of a seeded witness; their heights grow to hold it.
+    keccak_sponge_air (with keccak_air): the Keccak sponge table (AIR 6) absorbs the same strings block by block
+    (pg.keccak256_sponge_rows): its (xored rate, capacity) -> updated state pairs are, row for row, the inputs and
+    outputs of the Keccak table's permutations."""
     from . import compact
     P = 0xFFFFFFFF00000001
     first = gen_inputs[0].tries.state_trie.hash()
@@ -366,8 +372,10 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     irs, txn_no, gas = [], 0, 0
     if keccak_air:
         table_width = tuple(2430 if t == 3 else w for t, w in enumerate(table_width))
-    if (memory_air or byte_packing_air) and not keccak_air:
-        raise ValueError("the memory / byte-packing work is that of the hashed bytes: it needs keccak_air")
+    if (memory_air or byte_packing_air or keccak_sponge_air) and not keccak_air:
+        raise ValueError("the memory / byte-packing / sponge work is that of the hashed bytes: it needs keccak_air")
+    if keccak_sponge_air:
+        table_width = tuple(2414 if t == 4 else w for t, w in enumerate(table_width))
     if memory_air:
         table_width = tuple(44 if t == 6 else w for t, w in enumerate(table_width))
     if byte_packing_air:
@@ -381,10 +389,14 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
             need = max(24 * len(states), 1)
             table_log_n = tuple(max(l, (need - 1).bit_length()) if t == 3 else l for t, l in enumerate(base_log_n))
             kw = dict(keccak_air=True, keccak_inputs=tuple(tuple(s) for s in states))
-            if memory_air or byte_packing_air:
-                log, seqs = memory_and_byte_packing_work_of_preimages(
-                    hashed_preimages_of_generation_inputs(g, trie_nodes=keccak_trie_nodes))
+            if memory_air or byte_packing_air or keccak_sponge_air:
+                pre = hashed_preimages_of_generation_inputs(g, trie_nodes=keccak_trie_nodes)
+                log, seqs = memory_and_byte_packing_work_of_preimages(pre)
                 wit, ln = [], list(table_log_n)
+                if keccak_sponge_air:
+                    rows = [r for m in pre for r in pg.keccak256_sponge_rows(m)[1]]
+                    ln[4] = max(ln[4], (max(len(rows), 1) - 1).bit_length())
+                    wit.append((4, tuple(tuple(r) for r in rows)))
                 if memory_air:
                     ln[6] = max(ln[6], (max(len(log), 1) - 1).bit_length())
                     wit.append((6, tuple(tuple(r) for r in log)))
@@ -392,7 +404,8 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
                     ln[1] = max(ln[1], (max(len(seqs), 1) - 1).bit_length())
                     wit.append((1, tuple(tuple(r) for r in seqs)))
                 table_log_n = tuple(ln)
-                kw.update(memory_air=memory_air, byte_packing_air=byte_packing_air, witness=tuple(wit))
+                kw.update(memory_air=memory_air, byte_packing_air=byte_packing_air, keccak_sponge_air=keccak_sponge_air,
+                          witness=tuple(wit))
         r = g.trie_roots_after
         blob = (g.signed_txn or b"") + r.state_root + r.transactions_root + r.receipts_root
         blob += b"".join(bytes(a) + int(v).to_bytes(32, "big") for a, v in g.withdrawals)

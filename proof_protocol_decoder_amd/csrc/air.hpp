@@ -34,6 +34,11 @@
 // AIR 5  byte_packing  a big-endian sequence of up to 32 bytes <-> one 256-bit word per row (the zkEVM's byte-packing
 //                      table, prover_state.rs:85-93 "byte_packing"), 297 columns, degree 2; its own layout
 //                      [UPSTREAM-UNVERIFIED].
+// AIR 6  keccak_sponge the absorbing side of Keccak-256: one 136-byte block per row, XORed into the rate, chained from
+//                      row to row, pad10*1 on a message's last block (the zkEVM's Keccak sponge table,
+//                      prover_state.rs:85-93 "keccak_sponge"), 2414 columns, degree 2; its own layout
+//                      [UPSTREAM-UNVERIFIED].  The permutation itself is the Keccak-f table's (AIR 1): this table
+//                      carries its input (xored rate, capacity) and its output as columns for a cross-table lookup.
 // The cross-table-lookup-like auxiliary columns (running products over trace columns 8k, 8k+1) are a property of
 // the protocol, not of an AIR (as upstream's CTL checks sit beside Stark::eval): their constraints follow the AIR's
 // in the list for every air_id.
@@ -44,7 +49,7 @@
 namespace bpg {
 namespace air {
 
-constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, BYTE_PACKING = 5, COUNT = 6;
+constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, BYTE_PACKING = 5, KECCAK_SPONGE = 6, COUNT = 7;
 
 struct Shape {
   uint32_t air_id, n_cols, n_const, deg_pow;
@@ -644,6 +649,102 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 }
 }  // namespace byte_packing
 
+// ------------------------------------------------------------------------------------------ AIR 6: Keccak sponge
+// One absorbed block per row.  A message is a run of rows: zero or more FULL blocks (136 message bytes) and one FINAL
+// block (0..135 message bytes, then pad10*1: 0x01 after the last byte, 0x80 on byte 135).  The state before the first
+// block of a message is zero; after a full block the next row starts from this row's updated state.  A row with
+// neither flag is padding.
+// Columns ("limb" = 32 bits; state limb 2 l + h = half h of lane l = x + 5y):
+//   0, 1           is_full, is_final
+//   2 .. 137       final-length flags: column 2 + j is 1 when the final block holds j message bytes
+//   138 .. 1225    bits of the block as absorbed: 138 + 8 i + b (byte i, bit b)
+//   1226 .. 2313   bits of the rate part of the state before the block: 1226 + 32 k + z (limb k < 34)
+//   2314 .. 2329   capacity limbs of the state before the block
+//   2330 .. 2363   rate limbs after the XOR (with the capacity: the input of the permutation)
+//   2364 .. 2413   the state after the permutation, 50 limbs -- NOT constrained here: tying (xored rate, capacity) ->
+//                  updated state to a permutation is the cross-table lookup into the Keccak-f table
+// Constraints:
+//   K0  0 .. 1        all rows    flags are bits                K1  2          all rows  at most one flag      deg 2
+//   K2  3 .. 138      all rows    length flags are bits         K3  139        all rows  sum of them = is_final deg 2 / 1
+//   K4  140 .. 1227   all rows    block bits are bits           K5  1228 .. 2315 all rows rate bits are bits    deg 2
+//   K6  2316 .. 2451  all rows    pad10*1: with A_i = sum_{j < i} L_j (byte i lies after the message) and
+//                                 c_i = 0x80 for i = 135, else 0:  A_i (byte_i - c_i) + L_i (byte_i - 1 - c_i)  deg 2
+//   K7  2452 .. 2485  all rows    xored limb k - sum_z 2^z xor(rate bit, block bit)                             deg 2
+//   K8  2486 .. 2535  transition  next row's state before - is_full * updated state (50 limbs)                  deg 2
+//   K9  2536 .. 2585  first row   the state before is zero (50 limbs)                                          deg 1
+//   K10 2586          transition  is_full (1 - is_full' - is_final'): a message does not end on a full block   deg 2
+// Units: 0 = K0 .. K3, K10; 1 + k (k < 34) = rate limb k (bytes 4k .. 4k+3 of the block); 35 = the capacity limbs.
+namespace keccak_sponge {
+constexpr uint32_t N_COLS = 2414, N_CONSTRAINTS = 2587, N_UNITS = 36;
+constexpr uint32_t COL_FULL = 0, COL_FINAL = 1, COL_LEN = 2, COL_BLOCK = 138, COL_RATE = 1226, COL_CAP = 2314, COL_XORED = 2330,
+                   COL_UPDATED = 2364;
+constexpr uint32_t K0 = 0, K1 = 2, K2 = 3, K3 = 139, K4 = 140, K5 = 1228, K6 = 2316, K7 = 2452, K8 = 2486, K9 = 2536, K10 = 2586;
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const T full = row.loc(COL_FULL);
+  if (u == 0) {
+    const T fin = row.loc(COL_FINAL), s = F::add(full, fin);
+    out.all(K0, F::sub(F::mul(full, full), full));
+    out.all(K0 + 1, F::sub(F::mul(fin, fin), fin));
+    out.all(K1, F::sub(F::mul(s, s), s));
+    T n = F::k(0);
+#pragma unroll 1
+    for (uint32_t j = 0; j < 136; j++) {
+      const T l = row.loc(COL_LEN + j);
+      out.all(K2 + j, F::sub(F::mul(l, l), l));
+      n = F::add(n, l);
+    }
+    out.all(K3, F::sub(n, fin));
+    out.transition(K10, F::mul(full, F::sub(F::sub(F::k(1), row.nxt(COL_FULL)), row.nxt(COL_FINAL))));
+    return;
+  }
+  if (u == 35) {
+#pragma unroll 1
+    for (uint32_t k = 0; k < 16; k++) {
+      out.transition(K8 + 34 + k, F::sub(row.nxt(COL_CAP + k), F::mul(full, row.loc(COL_UPDATED + 34 + k))));
+      out.first(K9 + 34 + k, row.loc(COL_CAP + k));
+    }
+    return;
+  }
+  const uint32_t k = u - 1;
+  // (plain multiplies, one bit at a time: the carry-chain groups of four next to five running sums and the rolled
+  // loops' column offsets cost this kernel 177 VGPRs and 35 spilled scalars)
+  {
+    T after = F::k(0);  // A_i: the sum of the length flags below byte i
+#pragma unroll 1
+    for (uint32_t j = 0; j < 4 * k; j++) after = F::add(after, row.loc(COL_LEN + j));
+#pragma unroll 1
+    for (uint32_t i = 4 * k; i < 4 * k + 4; i++) {  // the four bytes of the limb: bits, and pad10*1
+      T byte = F::k(0);
+#pragma unroll 1
+      for (uint32_t b = 8; b > 0; b--) {
+        const T bb = row.loc(COL_BLOCK + 8 * i + b - 1);
+        out.all(K4 + 8 * i + b - 1, F::sub(F::mul(bb, bb), bb));
+        byte = F::add(F::dbl(byte), bb);
+      }
+      const T l_i = row.loc(COL_LEN + i), v = F::sub(byte, F::k(i == 135 ? 0x80 : 0));
+      out.all(K6 + i, F::add(F::mul(after, v), F::mul(l_i, F::sub(v, F::k(1)))));
+      after = F::add(after, l_i);
+    }
+  }
+  T xored = F::k(0), before = F::k(0);
+#pragma unroll 1
+  for (uint32_t z = 32; z > 0; z--) {  // limb bit z - 1 = bit (z - 1) % 8 of byte 4k + (z - 1) / 8
+    const T bb = row.loc(COL_BLOCK + 32 * k + z - 1), rr = row.loc(COL_RATE + 32 * k + z - 1);
+    out.all(K5 + 32 * k + z - 1, F::sub(F::mul(rr, rr), rr));
+    xored = F::add(F::dbl(xored), F::sub(F::add(bb, rr), F::dbl(F::mul(bb, rr))));
+    before = F::add(F::dbl(before), rr);
+  }
+  out.all(K7 + k, F::sub(row.loc(COL_XORED + k), xored));
+  T before_next = F::k(0);
+#pragma unroll 1
+  for (uint32_t z = 32; z > 0; z--) before_next = F::add(F::dbl(before_next), row.nxt(COL_RATE + 32 * k + z - 1));
+  out.transition(K8 + k, F::sub(before_next, F::mul(full, row.loc(COL_UPDATED + k))));
+  out.first(K9 + k, before);
+}
+}  // namespace keccak_sponge
+
 // ------------------------------------------------------------------------------------------ registry
 GL_HD uint32_t n_constraints(const Shape& s) {
   return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS
@@ -651,6 +752,7 @@ GL_HD uint32_t n_constraints(const Shape& s) {
          : s.air_id == MEMORY ? memory::N_CONSTRAINTS
          : s.air_id == ARITHMETIC ? arithmetic::N_CONSTRAINTS
          : s.air_id == BYTE_PACKING ? byte_packing::N_CONSTRAINTS
+         : s.air_id == KECCAK_SPONGE ? keccak_sponge::N_CONSTRAINTS
                               : synthetic::n_constraints(s);
 }
 GL_HD uint32_t n_units(const Shape& s) {
@@ -659,6 +761,7 @@ GL_HD uint32_t n_units(const Shape& s) {
          : s.air_id == MEMORY ? memory::N_UNITS
          : s.air_id == ARITHMETIC ? arithmetic::N_UNITS
          : s.air_id == BYTE_PACKING ? byte_packing::N_UNITS
+         : s.air_id == KECCAK_SPONGE ? keccak_sponge::N_UNITS
                               : synthetic::n_units(s);
 }
 template <class T, class Row, class Emit>
@@ -668,6 +771,7 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   else if (s.air_id == MEMORY) memory::eval_unit<T>(row, out);
   else if (s.air_id == ARITHMETIC) arithmetic::eval_unit<T>(unit, row, out);
   else if (s.air_id == BYTE_PACKING) byte_packing::eval_unit<T>(unit, row, out);
+  else if (s.air_id == KECCAK_SPONGE) keccak_sponge::eval_unit<T>(unit, row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
@@ -703,6 +807,7 @@ inline const Info* info(uint32_t air_id) {
       {MEMORY, "memory", memory::N_COLS, 0, 3},
       {ARITHMETIC, "arithmetic", arithmetic::N_COLS, 0, 2},
       {BYTE_PACKING, "byte_packing", byte_packing::N_COLS, 0, 2},
+      {KECCAK_SPONGE, "keccak_sponge", keccak_sponge::N_COLS, 0, 2},
   };
   return air_id < COUNT ? &table[air_id] : nullptr;
 }

@@ -406,6 +406,24 @@ int bp_keccak256_permutation_inputs(const uint8_t* data, size_t len, uint8_t dig
 }
 BPG_ABI_CATCH("bp_keccak256_permutation_inputs")
 
+// The same hash as rows of the Keccak sponge table (AIR 6; bp_keccak_sponge_trace, bp_generate_txn_proof_witness): one
+// row of 44 words per 136-byte block -- flags (1 full, 2 final), message bytes in the block, the block as absorbed (17
+// words), the 25 lanes of the state before it.  rows_out may be NULL to count.
+int bp_keccak256_sponge_rows(const uint8_t* data, size_t len, uint8_t digest_out[32], uint64_t* rows_out, size_t max_rows,
+                             size_t* n_rows_out) try {
+  if ((!data && len) || !n_rows_out) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_keccak256_sponge_rows: null argument");
+  std::vector<uint64_t> rows;
+  const H256 h = mpt::keccak256_sponge_rows(data, len, &rows);
+  *n_rows_out = rows.size() / 44;
+  if (digest_out) std::memcpy(digest_out, h.data(), 32);
+  if (rows_out) {
+    if (rows.size() / 44 > max_rows) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_keccak256_sponge_rows: %zu rows, room for %zu", rows.size() / 44, max_rows);
+    std::memcpy(rows_out, rows.data(), rows.size() * 8);
+  }
+  return BP_OK;
+}
+BPG_ABI_CATCH("bp_keccak256_sponge_rows")
+
 // process_compact_prestate (compact_prestate_processing.rs:1240-1281): header version, state root,
 // and the sizes of what was extracted.  Any pointer but `witness` may be NULL.
 int bp_compact_decode(const uint8_t* witness, size_t len, uint8_t* header_version, uint8_t state_root[32],

@@ -43,6 +43,41 @@ static void keccak_f(uint64_t st[25]) {
 }
 H256 keccak256(const uint8_t* data, size_t len) { return keccak256_traced(data, len, nullptr); }
 
+// The absorbing side of the same hash, block by block, as rows of the Keccak sponge table (air.hpp, AIR 6): per block
+// 44 words = flags (1 full block, 2 final block), message bytes in the block, the block as absorbed (17 words, pad10*1
+// included on the final one), the 25 lanes of the state BEFORE the block.
+H256 keccak256_sponge_rows(const uint8_t* data, size_t len, std::vector<uint64_t>* rows) {
+  uint64_t st[25] = {0};
+  const size_t rate = 136;
+  for (;;) {
+    const bool final_block = len < rate;
+    uint8_t block[136];
+    std::memset(block, 0, rate);
+    const size_t take = final_block ? len : rate;
+    if (take) std::memcpy(block, data, take);
+    if (final_block) {
+      block[len] ^= 0x01;
+      block[rate - 1] ^= 0x80;
+    }
+    uint64_t w[17];
+    std::memcpy(w, block, rate);
+    if (rows) {
+      rows->push_back(final_block ? 2 : 1);
+      rows->push_back(take);
+      rows->insert(rows->end(), w, w + 17);
+      rows->insert(rows->end(), st, st + 25);
+    }
+    for (size_t i = 0; i < 17; i++) st[i] ^= w[i];
+    keccak_f(st);
+    if (final_block) break;
+    data += rate;
+    len -= rate;
+  }
+  H256 out;
+  std::memcpy(out.data(), st, 32);
+  return out;
+}
+
 // The same sponge; every state that goes INTO a permutation (25 lanes, index x + 5y) is appended to `perm_inputs`:
 // the rows a Keccak-f table needs to attest this hash (one permutation per 136-byte block, padding included).
 H256 keccak256_traced(const uint8_t* data, size_t len, std::vector<uint64_t>* perm_inputs) {

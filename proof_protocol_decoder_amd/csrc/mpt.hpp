@@ -25,6 +25,7 @@ using Nibbles = std::vector<uint8_t>;  // one nibble per element
 
 H256 keccak256(const uint8_t* data, size_t len);
 H256 keccak256_traced(const uint8_t* data, size_t len, std::vector<uint64_t>* perm_inputs);  // + the permutation inputs
+H256 keccak256_sponge_rows(const uint8_t* data, size_t len, std::vector<uint64_t>* rows);     // + the sponge table's rows
 inline H256 keccak256(const Bytes& b) { return keccak256(b.data(), b.size()); }
 
 // protocol_decoder/src/types.rs:25-43

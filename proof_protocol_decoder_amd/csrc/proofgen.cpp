@@ -424,6 +424,15 @@ int bp_ir_set_byte_packing_air(uint64_t ir[BP_IR_WORDS], int on) {
   return BP_OK;
 }
 
+int bp_ir_set_keccak_sponge_air(uint64_t ir[BP_IR_WORDS], int on) {
+  if (!ir || ir[0] != IR_MAGIC) return fail(BP_ERR_INVALID_INPUT, "bp_ir_set_keccak_sponge_air: not an IR");
+  if (on && ir[18 + 4] != air::keccak_sponge::N_COLS)
+    return fail(BP_ERR_INVALID_INPUT, "the Keccak sponge AIR has %u columns: the IR gives table keccak_sponge %llu",
+                air::keccak_sponge::N_COLS, (unsigned long long)ir[18 + 4]);
+  ir[1] = (ir[1] & ~(uint64_t)0x2000) | (on ? 0x2000 : 0);
+  return BP_OK;
+}
+
 int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_used, const uint64_t state_root[4],
                        uint64_t seed, const uint32_t table_log_n[BP_NUM_TABLES], const uint32_t table_width[BP_NUM_TABLES],
                        uint64_t o[BP_IR_WORDS]) {
@@ -460,8 +469,8 @@ struct TxnWitness {
   const uint64_t* in[BP_NUM_TABLES] = {};
   size_t n[BP_NUM_TABLES] = {};
 };
-static const uint32_t WITNESS_WORDS[BP_NUM_TABLES] = {9, 6, 0, 25, 0, 9, 11};  // arithmetic, byte packing, -, keccak, -, logic, memory
-static const uint32_t WITNESS_AIR[BP_NUM_TABLES] = {air::ARITHMETIC, air::BYTE_PACKING, ~0u, air::KECCAK_F, ~0u, air::LOGIC, air::MEMORY};
+static const uint32_t WITNESS_WORDS[BP_NUM_TABLES] = {9, 6, 0, 25, 44, 9, 11};  // arithmetic, byte packing, -, keccak, sponge, logic, memory
+static const uint32_t WITNESS_AIR[BP_NUM_TABLES] = {air::ARITHMETIC, air::BYTE_PACKING, ~0u, air::KECCAK_F, air::KECCAK_SPONGE, air::LOGIC, air::MEMORY};
 // items a table of N rows holds: one permutation per 24 rows for Keccak (the last one may be cut), else one per row
 static size_t witness_capacity(int t, uint64_t N) { return t == 3 ? (size_t)((N + 23) / 24) : (size_t)N; }
 // the table's full input array (capacity x words), the caller's items first, then padding
@@ -492,13 +501,14 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   // 0x200 = the logic table (index 5) is proven with the logic AIR (AIR 2): 523 columns, operations drawn from the seed;
   // 0x400 = the memory table (index 6) with the memory AIR (AIR 3): 44 columns, a sorted log drawn from the seed;
   // 0x800 = the arithmetic table (index 0) with the arithmetic AIR (AIR 4): 309 columns;
-  // 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (AIR 5): 297 columns
+  // 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (AIR 5): 297 columns;
+  // 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6): 2414 columns
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
-  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 31) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
+  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 63) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
   const bool dummy = ver == 2, keccak_air = (flags & 1) != 0, logic_air = (flags & 2) != 0, memory_air = (flags & 4) != 0,
-             arithmetic_air = (flags & 8) != 0, byte_packing_air = (flags & 16) != 0;
+             arithmetic_air = (flags & 8) != 0, byte_packing_air = (flags & 16) != 0, sponge_air = (flags & 32) != 0;
   if (wit) {
-    const bool has_air[BP_NUM_TABLES] = {arithmetic_air, byte_packing_air, false, keccak_air, false, logic_air, memory_air};
+    const bool has_air[BP_NUM_TABLES] = {arithmetic_air, byte_packing_air, false, keccak_air, sponge_air, logic_air, memory_air};
     for (int t = 0; t < BP_NUM_TABLES; t++) {
       if (!wit->in[t]) continue;
       if (!has_air[t])
@@ -525,6 +535,7 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
     if (memory_air && t == 6) tcfg[t].air_id = air::MEMORY;     // ... 44
     if (arithmetic_air && t == 0) tcfg[t].air_id = air::ARITHMETIC;  // ... 309
     if (byte_packing_air && t == 1) tcfg[t].air_id = air::BYTE_PACKING;  // ... 297
+    if (sponge_air && t == 4) tcfg[t].air_id = air::KECCAK_SPONGE;       // ... 2414
     int r = check_cfg(tcfg[t]);
     if (r) return r;
   }
@@ -565,6 +576,7 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
           : t == 5 ? launch_logic_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
           : t == 6 ? launch_memory_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
           : t == 0 ? launch_arithmetic_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
+          : t == 4 ? launch_keccak_sponge_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
                    : launch_byte_packing_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream);
       if (r == BP_OK) r = w.wait();  // the staging buffer is reused by the next table and the commitments below
     } else {
@@ -578,6 +590,8 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
               ? launch_arithmetic_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
           : tcfg[t].air_id == air::BYTE_PACKING
               ? launch_byte_packing_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
+          : tcfg[t].air_id == air::KECCAK_SPONGE
+              ? launch_keccak_sponge_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
               : launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, I[10] ^ splitmix64(t + 1), w.stream);
     }
     if (r) return r;
@@ -693,7 +707,8 @@ int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t i
   if (!data) return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len);
   static const uint64_t none = 0;
   TxnWitness wit;
-  const struct { int t; const uint64_t* p; size_t n; int given; } f[5] = {
+  const struct { int t; const uint64_t* p; size_t n; int given; } f[6] = {
+      {4, data->sponge_rows, data->n_sponge_rows, data->has_keccak_sponge},
       {3, data->keccak_inputs, data->n_perms, data->has_keccak}, {5, data->logic_ops, data->n_logic_ops, data->has_logic},
       {6, data->memory_log, data->n_memory_ops, data->has_memory}, {0, data->arithmetic_ops, data->n_arithmetic_ops, data->has_arithmetic},
       {1, data->byte_sequences, data->n_byte_sequences, data->has_byte_packing}};

@@ -281,6 +281,74 @@ byte_packing_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__
   for (uint32_t k = 0; k < 8; k++) put(bp::COL_VAL + k, limb[k]);
 }
 
+// ---------------------------------------------------------------- Keccak sponge witness (AIR 6, air.hpp)
+// One absorbed block per row.  `inputs` ([row][44]: flags (1 = full block, 2 = final block, 0 = padding row), the number
+// of message bytes in the block, the block as absorbed (17 words, padding included), the 25 lanes of the state before
+// the block) or, when null, one single-block message per row drawn from the seed like the oracle:
+// h(c) = splitmix64(seed ^ (c << 32) ^ row); every eighth row (h(0xD3) % 8 == 0) is a padding row, else len = h(0xD0) % 136,
+// message word w = h(0xD1 + (w << 8)), state before = 0.  The updated state is the permutation of (xored rate, capacity).
+__global__ void __launch_bounds__(256)
+keccak_sponge_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
+  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  namespace sp = bpg::air::keccak_sponge;
+  namespace kk = bpg::air::keccak;
+  const uint32_t n = 1u << log_n;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t flags, len, blk[17], st[25];
+  if (inputs) {
+    const uint64_t* r = inputs + (uint64_t)i * 44;
+    flags = r[0] & 3; len = r[1];
+    for (uint32_t w = 0; w < 17; w++) blk[w] = r[2 + w];
+    for (uint32_t l = 0; l < 25; l++) st[l] = r[19 + l];
+  } else {
+    auto h = [&](uint64_t c) { return splitmix64(seed ^ (c << 32) ^ i); };
+    for (uint32_t l = 0; l < 25; l++) st[l] = 0;
+    if (h(0xD3) % 8 == 0) {
+      flags = 0; len = 0;
+      for (uint32_t w = 0; w < 17; w++) blk[w] = 0;
+    } else {
+      flags = 2; len = h(0xD0) % 136;
+      for (uint32_t w = 0; w < 17; w++) {
+        const uint64_t m = h(0xD1 + ((uint64_t)w << 8));
+        const uint32_t lo = 8 * w;  // bytes lo .. lo + 7 of the block: keep the first len - lo of them
+        blk[w] = len >= lo + 8 ? m : len > lo ? m & ((1ull << (8 * (len - lo))) - 1) : 0;
+      }
+      blk[len >> 3] ^= 1ull << (8 * (len & 7));
+      blk[16] ^= 0x80ull << 56;
+    }
+  }
+  if (flags == 3) flags = 0;
+  uint64_t a[25];
+  for (uint32_t l = 0; l < 25; l++) a[l] = l < 17 ? st[l] ^ blk[l] : st[l];
+  kk::Round R;
+  uint64_t p[25];
+  for (uint32_t l = 0; l < 25; l++) p[l] = a[l];
+  if (flags) {
+    for (uint32_t r = 0; r < 24; r++) {
+      kk::round(p, r, R);
+      for (uint32_t l = 0; l < 25; l++) p[l] = R.app[l];
+      p[0] = R.appp0;
+    }
+  } else {
+    for (uint32_t l = 0; l < 25; l++) p[l] = 0;
+  }
+  auto put = [&](uint32_t col, uint64_t v) { t[(uint64_t)col * n + i] = v; };
+  const uint32_t part = blockIdx.y;  // 0: flags, lengths, limbs; 1: block bits; 2: rate bits
+  if (part == 0) {
+    put(sp::COL_FULL, flags == 1);
+    put(sp::COL_FINAL, flags == 2);
+    for (uint32_t j = 0; j < 136; j++) put(sp::COL_LEN + j, flags == 2 && len == j);
+    for (uint32_t k = 0; k < 16; k++) put(sp::COL_CAP + k, (uint32_t)(st[17 + k / 2] >> (32 * (k & 1))));
+    for (uint32_t k = 0; k < 34; k++) put(sp::COL_XORED + k, (uint32_t)(a[k / 2] >> (32 * (k & 1))));
+    for (uint32_t k = 0; k < 50; k++) put(sp::COL_UPDATED + k, (uint32_t)(p[k / 2] >> (32 * (k & 1))));
+  } else if (part == 1) {
+    for (uint32_t z = 0; z < 1088; z++) put(sp::COL_BLOCK + z, (blk[z >> 6] >> (z & 63)) & 1);
+  } else {
+    for (uint32_t z = 0; z < 1088; z++) put(sp::COL_RATE + z, (st[z >> 6] >> (z & 63)) & 1);
+  }
+}
+
 // ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
 // z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
 // One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
@@ -436,6 +504,7 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
       else if constexpr (AIR == bpg::air::MEMORY) bpg::air::memory::eval_unit<uint64_t>(row, out);
       else if constexpr (AIR == bpg::air::ARITHMETIC) bpg::air::arithmetic::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::BYTE_PACKING) bpg::air::byte_packing::eval_unit<uint64_t>(u, row, out);
+      else if constexpr (AIR == bpg::air::KECCAK_SPONGE) bpg::air::keccak_sponge::eval_unit<uint64_t>(u, row, out);
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -994,6 +1063,12 @@ int launch_byte_packing_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint3
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 3);
+  keccak_sponge_trace_kernel<<<grid, 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
                hipStream_t st) {
   if (!n_aux) return BP_OK;
@@ -1018,6 +1093,7 @@ int launch_quotient(const QuotArgs& q, hipStream_t st) {
   else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::ARITHMETIC) quotient_air_kernel<bpg::air::ARITHMETIC><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::BYTE_PACKING) quotient_air_kernel<bpg::air::BYTE_PACKING><<<g1, 256, 0, st>>>(q);
+  else if (q.air_id == bpg::air::KECCAK_SPONGE) quotient_air_kernel<bpg::air::KECCAK_SPONGE><<<g1, 256, 0, st>>>(q);
   else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(q);
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {

@@ -78,6 +78,7 @@ LOGIC_COLS = 523
 MEMORY_COLS = 44
 ARITHMETIC_COLS = 309
 BYTE_PACKING_COLS = 297
+KECCAK_SPONGE_COLS = 2414
 
 
 def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
@@ -129,6 +130,17 @@ def byte_packing_trace(log_n, seed=0, inputs=None, device="cuda"):
         _require_cuda(inputs)
         assert inputs.shape == (1 << log_n, 6)
     check(lib().bp_byte_packing_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
+    return out
+
+
+def keccak_sponge_trace(log_n, seed=0, inputs=None, device="cuda"):
+    """bp_keccak_sponge_trace: the AIR-6 witness [2414, 2^log_n]; inputs [2^log_n, 44] int64 on the device (flags, message
+    bytes in the block, the block as absorbed, the state before it: proof_gen.keccak256_sponge_rows), or seeded."""
+    out = torch.empty((KECCAK_SPONGE_COLS, 1 << log_n), dtype=torch.int64, device=device)
+    if inputs is not None:
+        _require_cuda(inputs)
+        assert inputs.shape == (1 << log_n, 44)
+    check(lib().bp_keccak_sponge_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
     return out
 
 

@@ -65,6 +65,9 @@ def _bind():
     L.bp_ir_set_memory_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_arithmetic_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_byte_packing_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.bp_ir_set_keccak_sponge_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.bp_keccak256_sponge_rows.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t,
+                                           C.POINTER(C.c_size_t)]
     L.bp_keccak256_permutation_inputs.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t,
                                                   C.POINTER(C.c_size_t)]
     L.bp_generate_txn_proof_witness.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p,
@@ -129,6 +132,7 @@ class TxnProofGenIR:
     memory_air: bool = False   # the memory table (index 6) with the memory AIR (AIR 3, 44 columns)
     arithmetic_air: bool = False   # the arithmetic table (index 0) with the arithmetic AIR (AIR 4, 309 columns)
     byte_packing_air: bool = False   # the byte-packing table (index 1) with the byte-packing AIR (AIR 5, 297 columns)
+    keccak_sponge_air: bool = False  # the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6, 2414 columns)
     witness: tuple = None   # ((table index, ((words of an item), ...)), ...): data for tables with an AIR instead of a
                             # seeded witness (bp_generate_txn_proof_witness); like keccak_inputs not part of the 25-word IR
 
@@ -155,6 +159,8 @@ class TxnProofGenIR:
             check(L.bp_ir_set_arithmetic_air(out, 1))
         if self.byte_packing_air:
             check(L.bp_ir_set_byte_packing_air(out, 1))
+        if self.keccak_sponge_air:
+            check(L.bp_ir_set_keccak_sponge_air(out, 1))
         return struct.pack("<%dQ" % IR_WORDS, *out)
 
 
@@ -279,13 +285,26 @@ class TxnWitness(C.Structure):
     """bp_txn_witness (include/bpg.h)"""
     _fields_ = [(n, t) for name in ("keccak_inputs:n_perms:has_keccak", "logic_ops:n_logic_ops:has_logic",
                                     "memory_log:n_memory_ops:has_memory", "arithmetic_ops:n_arithmetic_ops:has_arithmetic",
-                                    "byte_sequences:n_byte_sequences:has_byte_packing")
+                                    "byte_sequences:n_byte_sequences:has_byte_packing",
+                                    "sponge_rows:n_sponge_rows:has_keccak_sponge")
                 for n, t in zip(name.split(":"), (C.c_void_p, C.c_size_t, C.c_int))]
 
 
 WITNESS_FIELDS = {3: ("keccak_inputs", "n_perms", "has_keccak", 25), 5: ("logic_ops", "n_logic_ops", "has_logic", 9),
                   6: ("memory_log", "n_memory_ops", "has_memory", 11), 0: ("arithmetic_ops", "n_arithmetic_ops", "has_arithmetic", 9),
-                  1: ("byte_sequences", "n_byte_sequences", "has_byte_packing", 6)}
+                  1: ("byte_sequences", "n_byte_sequences", "has_byte_packing", 6),
+                  4: ("sponge_rows", "n_sponge_rows", "has_keccak_sponge", 44)}
+
+
+def keccak256_sponge_rows(data: bytes):
+    """bp_keccak256_sponge_rows: -> (digest, [n_blocks][44] words): the rows a Keccak sponge table (AIR 6) absorbing
+    `data` contains -- flags, message bytes in the block, the block as absorbed, the state before it."""
+    L = _bind()
+    n = C.c_size_t()
+    check(L.bp_keccak256_sponge_rows(data, len(data), None, None, 0, C.byref(n)))
+    rows, digest = (C.c_uint64 * (44 * n.value))(), C.create_string_buffer(32)
+    check(L.bp_keccak256_sponge_rows(data, len(data), digest, rows, n.value, C.byref(n)))
+    return digest.raw, [list(rows[44 * i:44 * i + 44]) for i in range(n.value)]
 
 
 def generate_txn_proof(p_state, gen_inputs, abort_signal=None, keccak_inputs=None, witness=None):
@@ -294,7 +313,8 @@ def generate_txn_proof(p_state, gen_inputs, abort_signal=None, keccak_inputs=Non
     keccak_inputs: the permutation inputs ([n][25] lanes) of the transaction's Keccak table, for an IR with
     keccak_air=True (bp_generate_txn_proof_keccak); default: gen_inputs.keccak_inputs if it has any.
     witness: {table index: [[words of an item], ...]} for the tables proven with an AIR (0 arithmetic [9], 1 byte packing
-    [6], 3 Keccak [25], 5 logic [9], 6 memory [11]; bp_generate_txn_proof_witness); default: gen_inputs.witness."""
+    [6], 3 Keccak [25], 4 Keccak sponge [44], 5 logic [9], 6 memory [11]; bp_generate_txn_proof_witness); default:
+    gen_inputs.witness."""
     L = _bind()
     ir = gen_inputs.to_bytes() if isinstance(gen_inputs, TxnProofGenIR) else bytes(gen_inputs)
     out, n = _out()

@@ -1,0 +1,92 @@
+"""AIR 6 (Keccak sponge, csrc/air.hpp) on the GPU against the oracle's independent statement of it (oracle/keccak_sponge_air.c): the
+witness generator, K5 alone through bp_quotient_eval(air_id = 6, ...), and whole table proofs byte for byte."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import P, coset_major_to_natural, rand_field, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED00000000000A
+
+
+@pytest.mark.parametrize("log_n", [4, 9, 13])
+def test_witness_matches_oracle(bpg, oracle, log_n):
+    want = oracle.keccak_sponge_trace(log_n, seed=SEED + log_n)
+    got = to_host(bpg.ops.keccak_sponge_trace(log_n, seed=SEED + log_n))
+    assert got.shape == want.shape == (2414, 1 << log_n) and (got == want).all()
+    from test_keccak_sponge_air import MESSAGES, rows_of
+    msgs = (MESSAGES * (1 + (1 << log_n) // 16))[:max(1, (1 << log_n) // 3)]
+    rows, k, digests = rows_of(oracle, msgs, log_n)
+    want = oracle.keccak_sponge_trace(log_n, inputs=rows)
+    got = to_host(bpg.ops.keccak_sponge_trace(log_n, inputs=to_dev(rows)))
+    assert (got == want).all()
+    # the first message is empty: its only row's updated state starts with Keccak-256("")
+    out = [int(got[2364 + 2 * l, 0]) | (int(got[2365 + 2 * l, 0]) << 32) for l in range(4)]
+    assert b"".join(x.to_bytes(8, "little") for x in out) == digests[0]
+
+
+@pytest.mark.parametrize("log_n", [5, 9, 12])
+def test_quotient_eval_matches_oracle(bpg, oracle, log_n):
+    """K5 alone on AIR 4: random LDE matrices (on the coset the 'bit' columns are arbitrary field elements), fixed
+    challenges.  2^5 / 2^9 rows spread the 36 units and the CTL part over grid.y, 2^14 is closer to one pass."""
+    rng = np.random.default_rng(900 + log_n)
+    rows = (1 << log_n) << 1
+    trace = rand_field(rng, (2414, rows))
+    aux = rand_field(rng, (301, rows))
+    ctl, alphas = rand_field(rng, (4,)), rand_field(rng, (2,))
+    want = oracle.quotient_values(oracle.make_cfg(log_n, 2414, air_id=6), None, trace, aux, ctl, alphas[0], alphas[1])
+    idx = coset_major_to_natural(log_n, 1)
+
+    def to_cm(mat):
+        cm = np.empty_like(mat)
+        cm[:, idx] = mat
+        return to_dev(cm)
+    got = bpg.ops.quotient_eval(bpg.ops.stark_cfg(log_n, 2414), to_cm(trace), to_cm(aux), None, ctl, alphas, air_id=6)
+    assert (to_host(got)[:, idx] == want).all()
+
+
+def oracle_proof(oracle, log_n, nq, pb, seed):
+    cfg = oracle.make_cfg(log_n, 2414, num_queries=nq, pow_bits=pb, air_id=6)
+    tr = oracle.keccak_sponge_trace(log_n, seed=seed)
+    tc = oracle.Committed.from_values(tr, 1, 4)
+    ch = oracle.PyChallenger()
+    ch.observe(tc.cap())
+    ctl = np.array([ch.challenge() for _ in range(4)], dtype=np.uint64)
+    chv = ch.clone()
+    return cfg, oracle.stark_prove(cfg, tr, ctl, ch, None, tc), ctl, chv
+
+
+def product_verify(bpg, pc, proof):
+    raw = np.ascontiguousarray(proof, dtype="<u8").tobytes()
+    return bpg.lib().bp_stark_verify_air(6, C.byref(pc), None, raw, len(raw))
+
+
+@pytest.mark.parametrize("log_n,nq,pb,loaded", [(5, 6, 6, 0), (9, 84, 16, 1), (9, 84, 16, 0), (12, 84, 16, 1)])
+def test_table_proof_bit_exact(bpg, oracle, log_n, nq, pb, loaded):
+    """prove -> verify, bit-flip rejection, HIP bytes == oracle bytes.  2^9 rows is the S1 Keccak sponge table's height
+    (the reference's range starts there, constants.rs:13).  loaded: K5 in ONE pass, as the library runs it while provers share the device."""
+    cfg, want, ctl, chv = oracle_proof(oracle, log_n, nq, pb, SEED)
+    pc = bpg.ops.stark_cfg(log_n, 2414, num_queries=nq, pow_bits=pb)
+    bpg.lib().bp_tune_assume_loaded(loaded)
+    try:
+        got = bpg.ops.stark_prove_air(6, pc, SEED)
+    finally:
+        bpg.lib().bp_tune_assume_loaded(-1)
+    assert got.shape == want.shape and int(got[14]) == 6
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first mismatch at word %d of %d" % (bad[0], want.size)
+    assert oracle.stark_verify(cfg, got, ctl, chv, None) == 0
+    assert product_verify(bpg, pc, got) == 0
+    flipped = got.copy()
+    flipped[got.size // 2] ^= np.uint64(1 << 21)
+    assert product_verify(bpg, pc, flipped) != 0
+
+
+def test_wrong_shapes_for_the_air_are_refused(bpg):
+    from proof_protocol_decoder_amd._lib import BpgError
+    for kw in (dict(n_cols=2416), dict(n_cols=2414, n_const=2), dict(n_cols=2414, deg_pow=3, rate_bits=3)):
+        cfg = bpg.ops.stark_cfg(6, kw.pop("n_cols"), num_queries=6, pow_bits=6, **kw)
+        with pytest.raises(BpgError, match="keccak_sponge"):
+            bpg.ops.stark_prove_air(6, cfg, 1)

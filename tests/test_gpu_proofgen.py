@@ -385,10 +385,11 @@ def test_decoded_transactions_prove_the_hashing_of_their_partial_tries(bpg, pg, 
 
 
 def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, oracle):
-    """memory_air / byte_packing_air with keccak_air: three tables of a decoded entry hold data of the entry, not a seed
-    -- the Keccak table the hashing of its signed transaction, code and partial tries, the memory table the log of
-    those bytes (written once, read once), the byte-packing table the same bytes taken 32 at a time
-    (bp_generate_txn_proof_witness).  The device witnesses contain the bytes; proofs equal the oracle's byte for byte
+    """memory_air / byte_packing_air / keccak_sponge_air with keccak_air: four tables of a decoded entry hold data of the
+    entry, not a seed -- the Keccak table the hashing of its signed transaction, code and partial tries, the Keccak
+    sponge table the absorption of those strings block by block (its xored states are, row for row, the Keccak table's
+    permutation inputs), the memory table the log of those bytes (written once, read once), the byte-packing table the
+    same bytes taken 32 at a time (bp_generate_txn_proof_witness).  The device witnesses contain the bytes; proofs equal the oracle's byte for byte
     (orc_pg_txn_witness); the block verifies."""
     import test_decoding as td
     from proof_protocol_decoder_amd import decoding
@@ -408,7 +409,7 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
         other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", [(td.B, 100)]), b"\x22" * 32)
         gis = decoding.into_txn_proof_gen_ir(td.make_trace(m, infos, hash_out_storage_of=(td.E,)), other)
         irs = irs_from_generation_inputs(gis, 24, LOG_N, WIDTH, keccak_air=True, keccak_trie_nodes=True, memory_air=True,
-                                         byte_packing_air=True)
+                                         byte_packing_air=True, keccak_sponge_air=True)
         g, ir = next((g, ir) for g, ir in zip(gis, irs) if g.signed_txn)
         pre = hashed_preimages_of_generation_inputs(g, trie_nodes=True)
         blob = b"".join(pre)
@@ -434,6 +435,11 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
         tb = bpg.ops.byte_packing_trace(ir.table_log_n[1], inputs=torch.from_numpy(bp.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
         assert sum(int(tb[289 + k, 0]) << (32 * k) for k in range(8)) == int.from_bytes(pre[0][:32], "big")
         assert pre[0] == bytes(g.signed_txn)
+        # the sponge rows' permutation inputs (state before ^ block, capacity) are the Keccak table's inputs, row for row
+        sp = np.array(wit[4], dtype=np.uint64).reshape(-1, 44)
+        xored = sp[:, 19:].copy()
+        xored[:, :17] ^= sp[:, 2:19]
+        assert (xored == np.array(ir.keccak_inputs, dtype=np.uint64)).all()
         for e in irs:
             got = pg.generate_txn_proof(st, e)
             w = {t: np.array(items, dtype=np.uint64) for t, items in e.witness}
@@ -477,17 +483,17 @@ def test_txn_with_a_real_keccak_table_matches_the_oracle(pg, p_state, o_state):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), keccak_air=True).to_bytes()
 
 
-def test_txn_with_five_real_tables_matches_the_oracle(pg, p_state, o_state):
-    """IR flags 0x800 | 0x1000 | 0x100 | 0x200 | 0x400: the arithmetic (index 0), byte-packing (1), Keccak (3), logic (5)
-    and memory (6) tables of the transaction are proven with AIR 4, 5, 1, 2 and 3 next to two synthetic tables (CPU and
-    Keccak sponge).  Byte parity with the oracle; the block verifies."""
+def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
+    """IR flags 0x800 | 0x1000 | 0x100 | 0x2000 | 0x200 | 0x400: the arithmetic (index 0), byte-packing (1), Keccak (3),
+    Keccak sponge (4), logic (5) and memory (6) tables of the transaction are proven with AIR 4, 5, 1, 6, 2 and 3; only
+    the CPU table (2) stays synthetic.  Byte parity with the oracle; the block verifies."""
     width = list(WIDTH)
-    width[0], width[1], width[3], width[5], width[6] = 309, 297, 2430, 523, 44
+    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 297, 2430, 2414, 523, 44
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
-                           memory_air=True, arithmetic_air=True, byte_packing_air=True)
+                           memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
     t0 = pg.generate_txn_proof(p_state, ir0)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))
-    assert iw[1] == 0x1F01 and iw[18 + 0] == 309 and iw[18 + 1] == 297 and iw[18 + 5] == 523 and iw[18 + 6] == 44
+    assert iw[1] == 0x3F01 and iw[18 + 0] == 309 and iw[18 + 1] == 297 and iw[18 + 4] == 2414 and iw[18 + 5] == 523 and iw[18 + 6] == 44
     assert (words(t0.intern) == o_state.txn(iw)).all()
     only_logic = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), (*WIDTH[:5], 523, WIDTH[6]), logic_air=True)
     t_l = pg.generate_txn_proof(p_state, only_logic)
@@ -505,6 +511,8 @@ def test_txn_with_five_real_tables_matches_the_oracle(pg, p_state, o_state):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), arithmetic_air=True).to_bytes()
     with pytest.raises(pg.ProofGenError, match="297"):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), byte_packing_air=True).to_bytes()
+    with pytest.raises(pg.ProofGenError, match="2414"):
+        pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), keccak_sponge_air=True).to_bytes()
 
 
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)

@@ -292,7 +292,8 @@ def test_witness_entry_points_check_their_arguments_before_any_device_work():
     from proof_protocol_decoder_amd import proof_gen as pg
     L = pkg.lib()
     L.bp_last_error.restype = C.c_char_p
-    for name in ("bp_keccak_trace", "bp_logic_trace", "bp_memory_trace", "bp_arithmetic_trace", "bp_byte_packing_trace"):
+    for name in ("bp_keccak_trace", "bp_logic_trace", "bp_memory_trace", "bp_arithmetic_trace", "bp_byte_packing_trace",
+                 "bp_keccak_sponge_trace"):
         f = getattr(L, name)
         f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         assert f(None, 1, 8, None, None) == -2 and name.encode() in L.bp_last_error()
@@ -301,7 +302,8 @@ def test_witness_entry_points_check_their_arguments_before_any_device_work():
     pg._bind()
     ir = (C.c_uint64 * 25)(*struct_ir())
     for setter, width in (("bp_ir_set_keccak_air", b"2430"), ("bp_ir_set_logic_air", b"523"), ("bp_ir_set_memory_air", b"44"),
-                          ("bp_ir_set_arithmetic_air", b"309"), ("bp_ir_set_byte_packing_air", b"297")):
+                          ("bp_ir_set_arithmetic_air", b"309"), ("bp_ir_set_byte_packing_air", b"297"),
+                          ("bp_ir_set_keccak_sponge_air", b"2414")):
         f = getattr(L, setter)
         f.argtypes = [C.POINTER(C.c_uint64), C.c_int]
         assert f(ir, 1) == -2 and width in L.bp_last_error()       # the synthetic widths do not fit the AIR
@@ -310,13 +312,13 @@ def test_witness_entry_points_check_their_arguments_before_any_device_work():
         assert f(junk, 1) == -2 and b"not an IR" in L.bp_last_error()
     # all four flags together, each on a table of the right width
     w = list(struct_ir())
-    w[18 + 0], w[18 + 1], w[18 + 3], w[18 + 5], w[18 + 6] = 309, 297, 2430, 523, 44
+    w[18 + 0], w[18 + 1], w[18 + 3], w[18 + 4], w[18 + 5], w[18 + 6] = 309, 297, 2430, 2414, 523, 44
     ir = (C.c_uint64 * 25)(*w)
-    for setter in ("bp_ir_set_arithmetic_air", "bp_ir_set_byte_packing_air", "bp_ir_set_keccak_air", "bp_ir_set_logic_air",
-                   "bp_ir_set_memory_air"):
+    for setter in ("bp_ir_set_arithmetic_air", "bp_ir_set_byte_packing_air", "bp_ir_set_keccak_air", "bp_ir_set_keccak_sponge_air",
+                   "bp_ir_set_logic_air", "bp_ir_set_memory_air"):
         assert getattr(L, setter)(ir, 1) == 0
-    assert ir[1] == 0x1F01
-    assert L.bp_ir_set_logic_air(ir, 0) == 0 and ir[1] == 0x1D01
+    assert ir[1] == 0x3F01
+    assert L.bp_ir_set_logic_air(ir, 0) == 0 and ir[1] == 0x3D01
 
 
 def struct_ir():
