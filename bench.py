@@ -93,6 +93,7 @@ def main():
                          "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / "
                          "2414 / 523 / 44 columns) instead of synthetic tables of "
                          "BASELINE's widths -- another workload than the metric's, reported as such")
+    ap.add_argument("--k5-spread", type=int, default=None, help="bp_tune_k5_spread (measurement knob)")
     ap.add_argument("--poseidon-grouped", type=int, default=None, help="bp_tune_poseidon_grouped: 0 / 2 / 3 groups of partial rounds (measurement knob)")
     ap.add_argument("--quad-threshold-log2", type=int, default=None,
                     help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
@@ -175,6 +176,8 @@ def main():
         L.bp_tune_poseidon_mx(args.poseidon_mx)
     if args.poseidon_grouped is not None:
         L.bp_tune_poseidon_grouped(args.poseidon_grouped)
+    if args.k5_spread is not None:
+        L.bp_tune_k5_spread(args.k5_spread)
 
     def read_family(note, leg=True):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()

@@ -143,6 +143,9 @@ void bp_tune_poseidon_grouped(int mode);
  * loaded): -1 (default).  0 / 1: stated by a caller that drives the L0 / L0.5 entry points from its own threads (the
  * library cannot see that load), or by a test that pins both paths.  Results are identical. */
 void bp_tune_assume_loaded(int mode);
+/* Measurement knob: 1 = while the device is loaded the quotient kernel spreads the units of the SYNTHETIC AIR over
+ * workgroup rows until the launch has 256 workgroups, as it does for the AIRs of the real tables; 0 (default): one pass. */
+void bp_tune_k5_spread(int on);
 /* Host only: the operand images of one group of K partial rounds starting at round r0 as the device gets them
  * (csrc/poseidon_group.hpp); tests/test_mx_tables.py pins them to tools/poseidon_group_model.py.
  * out_ops: bp_debug_poseidon_group_ops(K) x 1024 bytes, out_cform: 64 i32, out_cmain: 96 i32. */

@@ -59,6 +59,7 @@ static uint32_t n_fri_layers(const StarkCfg& c) {  // FriReductionStrategy::Cons
   }
   return n;
 }
+std::atomic<int> g_k5_spread_all{0};  // measurement knob (bp_tune_k5_spread): the loaded-device spreading rule for the synthetic AIR too
 int check_cfg(const StarkCfg& c) {
   const air::Info* ai = air::info(c.air_id);
   if (!ai) return fail(BP_ERR_INVALID_INPUT, "unknown air_id %u (bp_air_count() AIRs are built in)", c.air_id);
@@ -251,9 +252,14 @@ int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t
   // One pass (the alpha fold never leaves the registers) once the rows alone fill the chip: 2048 workgroups of
   // 256 lanes = 2 per SIMD.  Shorter tables spread their units over grid.y until the launch has that many.
   // While several provers share the device nothing needs filling: one pass, one launch fewer on the proof's
-  // critical path and no partial sums.
+  // critical path and no partial sums -- for the synthetic AIR, whose row costs little.  The AIRs of the real tables
+  // cost 10^4 .. 10^5 instructions per row: one pass over a SHORT table is then milliseconds of a few workgroups on the
+  // critical path (Keccak sponge, 2^9 rows: 2.6 ms against 0.11 ms spread, profiles/r3_k5_air_probe.txt), so their
+  // units are spread until the launch has 256 workgroups.
   const uint32_t n_units = qa.n_air_units + qa.n_ctl_units, wg_x = (uint32_t)((M + 255) / 256);
-  const uint32_t want_rows = device_loaded() ? 1 : std::min<uint32_t>(n_units, std::max<uint32_t>(1, (2048 + wg_x - 1) / wg_x));
+  const uint32_t loaded_rows = (cfg.air_id == air::SYNTHETIC && !g_k5_spread_all.load(std::memory_order_relaxed))
+                                   ? 1 : std::min<uint32_t>(n_units, std::max<uint32_t>(1, (256 + wg_x - 1) / wg_x));
+  const uint32_t want_rows = device_loaded() ? loaded_rows : std::min<uint32_t>(n_units, std::max<uint32_t>(1, (2048 + wg_x - 1) / wg_x));
   qa.units_per_wg = (n_units + want_rows - 1) / want_rows;
   qa.alpha0 = alpha0; qa.alpha1 = alpha1;
   qa.g = wN; qa.g_inv = gl::inv(wN); qa.n_inv = gl::inv(N);

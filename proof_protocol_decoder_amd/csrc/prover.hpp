@@ -70,6 +70,7 @@ struct ProofLayout {
 };
 constexpr uint64_t PROOF_MAGIC = 0x4B52415453475042ULL;  // "BPGSTARK"
 constexpr size_t PROOF_HDR_WORDS = 16;
+extern std::atomic<int> g_k5_spread_all;
 int check_cfg(const StarkCfg& c);
 ProofLayout proof_layout(const StarkCfg& c);
 void proof_digest(const StarkCfg& c, const uint64_t* proof, uint64_t out[4]);

@@ -69,6 +69,7 @@ void park_worker(Worker* w) {
 extern "C" {
 
 void bp_free_buffer(uint8_t* buf) { std::free(buf); }
+void bp_tune_k5_spread(int on) { bpg::g_k5_spread_all.store(on != 0); }
 
 void bp_release_cached_memory(void) {
   std::vector<Worker*> all;

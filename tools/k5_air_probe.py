@@ -18,6 +18,8 @@ CASES = [  # name, air_id, columns, log_n (the S1 height of the table), n_const
     ("logic (AIR 2)", 2, 523, 12, 0),
     ("logic (AIR 2) at 2^16", 2, 523, 16, 0),
     ("memory (AIR 3)", 3, 44, 17, 0),
+    ("keccak sponge (AIR 6)", 6, 2414, 9, 0),
+    ("keccak sponge (AIR 6) at 2^12", 6, 2414, 12, 0),
 ]
 g = torch.Generator(device="cuda").manual_seed(1)
 for name, air, C_, log_n, K in CASES:
