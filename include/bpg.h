@@ -381,7 +381,11 @@ int bp_generate_txn_proof_keccak(const bp_state* s, const uint8_t* ir, size_t ir
  * has_* field is non-zero (n may be 0: a table of padding only) and its IR flag is set (bp_ir_set_*_air).  Items beyond
  * n are padding: Keccak permutations of the all-zero state, rows without an operation, and for the memory log reads of
  * the last address at later and later times.  Layouts as for the bp_*_trace entry points: keccak_inputs [n][25],
- * logic_ops / arithmetic_ops [n][9], memory_log [n][11] sorted by (address, timestamp), byte_sequences [n][6]. */
+ * logic_ops / arithmetic_ops [n][9], memory_log [n][11] sorted by (address, timestamp), byte_sequences [n][6].
+ * Given data is CHECKED: the prover does not validate a witness and nothing downstream verifies the table proofs (upstream's
+ * root circuit would), so the table proof made from caller-given data is verified on the host before the call goes on;
+ * data that does not satisfy the table's AIR (a log that is not a memory, sponge rows that do not chain, ...) returns
+ * BP_ERR_VERIFY.  (bp_generate_txn_proof_keccak likewise; every set of permutation inputs satisfies the Keccak-f AIR.) */
 typedef struct bp_txn_witness {
   const uint64_t* keccak_inputs;   size_t n_perms;           int has_keccak;
   const uint64_t* logic_ops;       size_t n_logic_ops;       int has_logic;

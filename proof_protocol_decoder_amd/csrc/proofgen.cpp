@@ -607,7 +607,18 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before table %s", TABLE_NAMES[t]);
     const size_t mark = w.arena.mark();
+    const bool given = wit && wit->in[t] && tcfg[t].air_id == WITNESS_AIR[t];
+    Challenger before = ch;  // the transcript as the verifier of this table proof starts from it
     if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, proof))) return r;
+    if (given) {
+      // The prover does not check a witness, and nothing downstream of this call verifies the table proofs (upstream's
+      // root circuit would): data that came from the caller is therefore checked here, by the CPU verifier on the
+      // proof just made -- a log that is not a memory, a block that is not padded, ... ends the call.
+      if (stark_verify(tcfg[t], nullptr, ctl, before, proof.data(), proof.size()) != BP_OK) {
+        const std::string why = bp_last_error();
+        return fail(BP_ERR_VERIFY, "the witness data given for table %s does not satisfy its AIR: %s", TABLE_NAMES[t], why.c_str());
+      }
+    }
     proof_digest(tcfg[t], proof.data(), digest[t]);
     w.arena.release(mark);
   }

@@ -453,6 +453,20 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
         finally:
             drv.close()
         pg.VerifierState.from_prover_state(st).verify(blk)
+        # caller-given data is CHECKED (the CPU verifier runs on the table proof just made): a log whose read returns
+        # something else than what was written, or sponge rows that do not chain, end the call
+        bad_log = [list(r) for r in wit[6]]
+        k = next(i for i, r in enumerate(bad_log) if r[0] == 1)
+        bad_log[k][3] ^= 1
+        with pytest.raises(pg.ProofGenError, match="memory does not satisfy its AIR") as e:
+            pg.generate_txn_proof(st, ir, witness={**wit, 6: bad_log})
+        assert e.value.code == -5
+        if len(wit[4]) >= 2:
+            bad_rows = [list(r) for r in wit[4]]
+            k = next(i for i, r in enumerate(bad_rows) if r[0] == 1)     # a full block: the next row continues from it
+            bad_rows[k + 1][19 + 3] ^= 1
+            with pytest.raises(pg.ProofGenError, match="keccak_sponge does not satisfy its AIR"):
+                pg.generate_txn_proof(st, ir, witness={**wit, 4: bad_rows})
         # data for a table whose IR flag is not set is refused
         plain = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 5, tuple(LOG_N), tuple(WIDTH))
         with pytest.raises(pg.ProofGenError, match="memory"):
