@@ -194,7 +194,8 @@ struct bp_stark_cfg;
  * 256-bit words per row on 523 columns, 3 = memory, a log of reads and writes sorted by (address, timestamp) on 44
  * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns, 5 = byte_packing,
  * a big-endian byte sequence and the word it spells on 297 columns, 6 = keccak_sponge, the absorbing side of
- * Keccak-256 (XOR into the rate, chaining, pad10*1) on 2414 columns (likewise their own layouts).  bp_air_describe returns the shape and
+ * Keccak-256 (XOR into the rate, chaining, pad10*1) on 2414 columns, 7 = arithmetic_mul, x * y = z + 2^256 w on 1217
+ * columns (likewise their own layouts; AIR 7 is not wired to a transaction's table: bp_stark_prove_air only).  bp_air_describe returns the shape and
  * the constraint list of an AIR as families (first index, count, kind, degree); the list is followed, for every
  * air_id, by the two constraints of each cross-table-lookup-like auxiliary column (n_cols / 8 of them). */
 typedef struct bp_air_family {
@@ -262,6 +263,10 @@ int bp_byte_packing_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_
  * block -- bp_keccak256_sponge_rows makes them for a message; or NULL for one single-block message per row drawn from
  * `seed`.  The kernel computes the XOR and the permutation of every row. */
 int bp_keccak_sponge_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
+/* Witness of AIR 7 (the multiplicative half of the arithmetic table, a table of its own here: x * y = z + 2^256 w as a
+ * 32-column schoolbook product over 16-bit limbs with 21-bit carries): n = 2^log_n rows x 1217 columns, column-major.
+ * d_inputs: [n][9] = is_mul (0 = a padding row), the four 64-bit words of x and of y; or NULL to draw them from `seed`. */
+int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
 /* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
  * folded domain), done in the evaluation domain.  d_values: the layer's n_l << rate_bits extension values
@@ -298,7 +303,7 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
-/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 / 2 / 3 / 4 / 5 / 6: n_cols = 2430 / 523 / 44 / 309 / 297 / 2414,
+/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 .. 7: n_cols = 2430 / 523 / 44 / 309 / 297 / 2414 / 1217,
  * n_const = 0, deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
 int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                        uint8_t** out, size_t* out_len);

@@ -68,7 +68,8 @@ typedef struct {
       arity_bits, final_poly_bits;
   uint32_t air_id; /* 0: the synthetic AIR (stark.c), 1: Keccak-f[1600] (keccak_air.c), 2: logic (logic_air.c), 3: memory
                       (memory_air.c), 4: arithmetic (arithmetic_air.c), 5: byte packing
-                      (byte_packing_air.c), 6: Keccak sponge (keccak_sponge_air.c); header word 14 of a proof */
+                      (byte_packing_air.c), 6: Keccak sponge (keccak_sponge_air.c),
+                      7: multiplication (arithmetic_mul_air.c); header word 14 of a proof */
 } orc_stark_cfg;
 #define ORC_AIR_SYNTHETIC 0u
 #define ORC_AIR_KECCAK_F 1u
@@ -89,6 +90,9 @@ typedef struct {
 #define ORC_AIR_KECCAK_SPONGE 6u
 #define ORC_KECCAK_SPONGE_COLS 2414u
 #define ORC_KECCAK_SPONGE_CONSTRAINTS 2587u
+#define ORC_AIR_ARITHMETIC_MUL 7u
+#define ORC_ARITHMETIC_MUL_COLS 1217u
+#define ORC_ARITHMETIC_MUL_CONSTRAINTS 1218u
 
 /* starky ConstraintConsumer: acc_j = acc_j * alpha_j + constraint, in list order; base field (the LDE coset)
  * and extension field (the verifier at zeta; the alphas stay in the base field). */
@@ -135,6 +139,10 @@ size_t orc_keccak_sponge_rows(const uint8_t* msg, size_t len, uint64_t* rows, ui
 void orc_keccak_sponge_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
 void orc_keccak_sponge_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
 void orc_keccak_sponge_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
+/* arithmetic_mul_air.c */
+void orc_arithmetic_mul_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
+void orc_arithmetic_mul_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
+void orc_arithmetic_mul_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
 
 uint32_t orc_cfg_n_aux(const orc_stark_cfg* c);
 uint32_t orc_cfg_n_quot(const orc_stark_cfg* c);

@@ -17,7 +17,7 @@ u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("core.c", "stark.c", "proofgen.c", "keccak_air.c", "keccak_air_body.inc",
-                                              "logic_air.c", "logic_air_body.inc", "memory_air.c", "memory_air_body.inc", "arithmetic_air.c", "arithmetic_air_body.inc", "byte_packing_air.c", "byte_packing_air_body.inc", "keccak_sponge_air.c", "keccak_sponge_air_body.inc", "gl.h", "oracle.h",
+                                              "logic_air.c", "logic_air_body.inc", "memory_air.c", "memory_air_body.inc", "arithmetic_air.c", "arithmetic_air_body.inc", "byte_packing_air.c", "byte_packing_air_body.inc", "keccak_sponge_air.c", "keccak_sponge_air_body.inc", "arithmetic_mul_air.c", "arithmetic_mul_air_body.inc", "gl.h", "oracle.h",
                                               "poseidon_rc.inc", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
@@ -97,6 +97,7 @@ def lib():
     L.orc_arithmetic_trace.argtypes = [u6, vp, u, u64p]
     L.orc_byte_packing_trace.argtypes = [u6, vp, u, u64p]
     L.orc_keccak_sponge_trace.argtypes = [u6, vp, u, u64p]
+    L.orc_arithmetic_mul_trace.argtypes = [u6, vp, u, u64p]
     L.orc_keccak_sponge_rows.argtypes = [C.c_char_p, sz, vp, vp]
     L.orc_keccak_sponge_rows.restype = sz
     L.orc_commit_values.argtypes = [u64p, u, sz, u, u]
@@ -234,12 +235,14 @@ class PyChallenger:
 
 AIR_SYNTHETIC, AIR_KECCAK_F, AIR_LOGIC, AIR_MEMORY, AIR_ARITHMETIC, AIR_BYTE_PACKING = 0, 1, 2, 3, 4, 5
 AIR_KECCAK_SPONGE = 6
+AIR_ARITHMETIC_MUL = 7
 KECCAK_COLS = 2430
 LOGIC_COLS = 523
 MEMORY_COLS = 44
 ARITHMETIC_COLS = 309
 BYTE_PACKING_COLS = 297
 KECCAK_SPONGE_COLS = 2414
+ARITHMETIC_MUL_COLS = 1217
 
 
 def make_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, num_queries=84, pow_bits=16,
@@ -305,6 +308,17 @@ def byte_packing_trace(log_n, seed=0, inputs=None):
     if inp is not None:
         assert inp.shape == (1 << log_n, 6)
     lib().orc_byte_packing_trace(seed, inp.ctypes.data if inp is not None else None, log_n, out)
+    return out
+
+
+def arithmetic_mul_trace(log_n, seed=0, inputs=None):
+    """orc_arithmetic_mul_trace: the AIR-7 witness [1217, 2^log_n]; inputs [2^log_n, 9] (is_mul, x, y as four u64 each)
+    or seeded."""
+    out = np.zeros((ARITHMETIC_MUL_COLS, 1 << log_n), dtype=np.uint64)
+    inp = np.ascontiguousarray(inputs, dtype=np.uint64) if inputs is not None else None
+    if inp is not None:
+        assert inp.shape == (1 << log_n, 9)
+    lib().orc_arithmetic_mul_trace(seed, inp.ctypes.data if inp is not None else None, log_n, out)
     return out
 
 

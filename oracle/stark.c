@@ -180,6 +180,9 @@ static void eval_constraints_base(const orc_stark_cfg* cf, const gl_t* cst, cons
   } else if (cf->air_id == ORC_AIR_KECCAK_SPONGE) {
     orc_keccak_sponge_constraints_base(loc, nxt, k);
     G = 0;
+  } else if (cf->air_id == ORC_AIR_ARITHMETIC_MUL) {
+    orc_arithmetic_mul_constraints_base(loc, nxt, k);
+    G = 0;
   }
   for (size_t g = 0; g < G; g++) {
     gl_t a = loc[4 * g], b = loc[4 * g + 1], c = loc[4 * g + 2], d = loc[4 * g + 3];
@@ -222,6 +225,9 @@ static void eval_constraints_ext(const orc_stark_cfg* cf, const gl2_t* cst, cons
     G = 0;
   } else if (cf->air_id == ORC_AIR_KECCAK_SPONGE) {
     orc_keccak_sponge_constraints_ext(loc, nxt, k);
+    G = 0;
+  } else if (cf->air_id == ORC_AIR_ARITHMETIC_MUL) {
+    orc_arithmetic_mul_constraints_ext(loc, nxt, k);
     G = 0;
   }
   for (size_t g = 0; g < G; g++) {
@@ -334,7 +340,8 @@ int orc_stark_prove(const orc_stark_cfg* cf, const orc_committed* consts, const 
   const size_t N = (size_t)1 << log_n, M = N << r, C = cf->n_cols, K = cf->n_const, A = L.n_aux,
                Q = L.n_quot, qdf = (size_t)1 << r;
   if ((cf->deg_pow != 1 && cf->deg_pow != 3) || qdf != 3 * cf->deg_pow - 1 || C < 8 || log_m < h ||
-      (K && !consts) || cf->air_id > ORC_AIR_KECCAK_SPONGE ||
+      (K && !consts) || cf->air_id > ORC_AIR_ARITHMETIC_MUL ||
+      (cf->air_id == ORC_AIR_ARITHMETIC_MUL && (C != ORC_ARITHMETIC_MUL_COLS || K != 0 || cf->deg_pow != 1)) ||
       (cf->air_id == ORC_AIR_KECCAK_SPONGE && (C != ORC_KECCAK_SPONGE_COLS || K != 0 || cf->deg_pow != 1)) ||
       (cf->air_id == ORC_AIR_BYTE_PACKING && (C != ORC_BYTE_PACKING_COLS || K != 0 || cf->deg_pow != 1)) ||
       (cf->air_id == ORC_AIR_ARITHMETIC && (C != ORC_ARITHMETIC_COLS || K != 0 || cf->deg_pow != 1)) ||

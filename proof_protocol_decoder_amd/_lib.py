@@ -82,6 +82,7 @@ def lib():
     L.bp_arithmetic_trace.argtypes = [vp, u64, u32, vp, vp]
     L.bp_byte_packing_trace.argtypes = [vp, u64, u32, vp, vp]
     L.bp_keccak_sponge_trace.argtypes = [vp, u64, u32, vp, vp]
+    L.bp_arithmetic_mul_trace.argtypes = [vp, u64, u32, vp, vp]
     L.bp_stark_verify_air.argtypes = [u32, C.POINTER(StarkCfg), C.POINTER(u64), C.c_char_p, C.c_size_t]
     L.bp_stark_prove_air.argtypes = [u32, C.POINTER(StarkCfg), u64, u64, i, C.POINTER(C.POINTER(C.c_uint8)),
                                      C.POINTER(C.c_size_t)]

@@ -39,6 +39,9 @@
 //                      prover_state.rs:85-93 "keccak_sponge"), 2414 columns, degree 2; its own layout
 //                      [UPSTREAM-UNVERIFIED].  The permutation itself is the Keccak-f table's (AIR 1): this table
 //                      carries its input (xored rate, capacity) and its output as columns for a cross-table lookup.
+// AIR 7  arithmetic_mul  the multiplicative half of the arithmetic table: x * y = z + 2^256 w on 256-bit words, a 32-column
+//                      schoolbook product over sixteen 16-bit limbs with 21-bit carries, 1217 columns, degree 3.  A
+//                      table of its own here: merged into AIR 4's rows it would add 900 columns to every addition.
 // The cross-table-lookup-like auxiliary columns (running products over trace columns 8k, 8k+1) are a property of
 // the protocol, not of an AIR (as upstream's CTL checks sit beside Stark::eval): their constraints follow the AIR's
 // in the list for every air_id.
@@ -49,7 +52,7 @@
 namespace bpg {
 namespace air {
 
-constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, BYTE_PACKING = 5, KECCAK_SPONGE = 6, COUNT = 7;
+constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, BYTE_PACKING = 5, KECCAK_SPONGE = 6, ARITHMETIC_MUL = 7, COUNT = 8;
 
 struct Shape {
   uint32_t air_id, n_cols, n_const, deg_pow;
@@ -745,6 +748,67 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 }
 }  // namespace keccak_sponge
 
+// ------------------------------------------------------------------------------------------ AIR 7: multiplication
+// One product per row: x * y = z + 2^256 w with x, y as sixteen 16-bit limbs and z, w by their bits.  Product column
+// k (0 .. 31) collects the limb products x_i y_j with i + j = k and the carry of the column below:
+//   is_mul * sum_{i+j=k} x_i y_j + c_(k-1) = p_k + 2^16 c_k,   p = the limbs of z (k < 16) then of w,   c_(-1) = 0 = c_31
+// A column sum is below 16 * 2^32 + 2^21, so a carry fits 21 bits.  A row with is_mul = 0 is padding: the chain then
+// forces every p and c to zero.
+// Columns:
+//   0            is_mul
+//   1 .. 16      x limbs          17 .. 32   y limbs
+//   33 .. 288    z bits: 33 + 16 k + j          289 .. 544   w bits: 289 + 16 k + j
+//   545 .. 1216  carry bits: 545 + 21 k + j (carry out of product column k)
+// Constraints (all rows):
+//   U0  0            is_mul is a bit                                                       deg 2
+//   U1  1 .. 256     z bits      U2  257 .. 512   w bits      U3  513 .. 1184   carry bits  deg 2
+//   U4  1185 .. 1216 is_mul * sum_{i+j=k} x_i y_j + c_(k-1) - p_k - 2^16 c_k               deg 3
+//   U5  1217         c_31 (the product has 512 bits)                                       deg 1
+// Units: unit u = product columns 4u .. 4u + 3 (their p bits, carry bits and U4); unit 0 also U0, unit 7 also U5.
+namespace arithmetic_mul {
+constexpr uint32_t N_COLS = 1217, N_CONSTRAINTS = 1218, N_UNITS = 8;
+constexpr uint32_t COL_MUL = 0, COL_X = 1, COL_Y = 17, COL_Z = 33, COL_W = 289, COL_CARRY = 545;
+constexpr uint32_t U0 = 0, U1 = 1, U2 = 257, U3 = 513, U4 = 1185, U5 = 1217;
+// sum_j 2^j bit_j over `n` bit columns starting at `col`, with their booleanity constraints starting at index `cidx`
+template <class T, class Row, class Emit>
+GL_HD T bits_value(const Row& row, Emit& out, uint32_t col, uint32_t n, uint32_t cidx) {
+  typedef Ops<T> F;
+  T v = F::k(0);
+#pragma unroll 1
+  for (uint32_t j = n; j > 0; j--) {
+    const T b = row.loc(col + j - 1);
+    out.all(cidx + j - 1, F::sub(F::mul(b, b), b));
+    v = F::add(F::dbl(v), b);
+  }
+  return v;
+}
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const T m = row.loc(COL_MUL);
+  if (u == 0) out.all(U0, F::sub(F::mul(m, m), m));
+  // the carry into column 4u is the carry out of column 4u - 1 (its booleanity belongs to the unit below)
+  T cin = F::k(0);
+  if (u) {
+#pragma unroll 1
+    for (uint32_t j = 21; j > 0; j--) cin = F::add(F::dbl(cin), row.loc(COL_CARRY + 21 * (4 * u - 1) + j - 1));
+  }
+#pragma unroll 1
+  for (uint32_t k = 4 * u; k < 4 * u + 4; k++) {
+    const T p = k < 16 ? bits_value<T>(row, out, COL_Z + 16 * k, 16, U1 + 16 * k)
+                       : bits_value<T>(row, out, COL_W + 16 * (k - 16), 16, U2 + 16 * (k - 16));
+    const T c = bits_value<T>(row, out, COL_CARRY + 21 * k, 21, U3 + 21 * k);
+    T conv = F::k(0);  // sum over i + j = k, 0 <= i, j < 16
+    const uint32_t i0 = k < 16 ? 0 : k - 15, i1 = k < 16 ? k : 15;
+#pragma unroll 1
+    for (uint32_t i = i0; i <= i1; i++) conv = F::add(conv, F::mul(row.loc(COL_X + i), row.loc(COL_Y + k - i)));
+    out.all(U4 + k, F::sub(F::add(F::mul(m, conv), cin), F::add(p, F::mul(F::k(65536), c))));
+    cin = c;
+  }
+  if (u == 7) out.all(U5, cin);
+}
+}  // namespace arithmetic_mul
+
 // ------------------------------------------------------------------------------------------ registry
 GL_HD uint32_t n_constraints(const Shape& s) {
   return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS
@@ -753,6 +817,7 @@ GL_HD uint32_t n_constraints(const Shape& s) {
          : s.air_id == ARITHMETIC ? arithmetic::N_CONSTRAINTS
          : s.air_id == BYTE_PACKING ? byte_packing::N_CONSTRAINTS
          : s.air_id == KECCAK_SPONGE ? keccak_sponge::N_CONSTRAINTS
+         : s.air_id == ARITHMETIC_MUL ? arithmetic_mul::N_CONSTRAINTS
                               : synthetic::n_constraints(s);
 }
 GL_HD uint32_t n_units(const Shape& s) {
@@ -762,6 +827,7 @@ GL_HD uint32_t n_units(const Shape& s) {
          : s.air_id == ARITHMETIC ? arithmetic::N_UNITS
          : s.air_id == BYTE_PACKING ? byte_packing::N_UNITS
          : s.air_id == KECCAK_SPONGE ? keccak_sponge::N_UNITS
+         : s.air_id == ARITHMETIC_MUL ? arithmetic_mul::N_UNITS
                               : synthetic::n_units(s);
 }
 template <class T, class Row, class Emit>
@@ -772,6 +838,7 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   else if (s.air_id == ARITHMETIC) arithmetic::eval_unit<T>(unit, row, out);
   else if (s.air_id == BYTE_PACKING) byte_packing::eval_unit<T>(unit, row, out);
   else if (s.air_id == KECCAK_SPONGE) keccak_sponge::eval_unit<T>(unit, row, out);
+  else if (s.air_id == ARITHMETIC_MUL) arithmetic_mul::eval_unit<T>(unit, row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
@@ -808,6 +875,7 @@ inline const Info* info(uint32_t air_id) {
       {ARITHMETIC, "arithmetic", arithmetic::N_COLS, 0, 2},
       {BYTE_PACKING, "byte_packing", byte_packing::N_COLS, 0, 2},
       {KECCAK_SPONGE, "keccak_sponge", keccak_sponge::N_COLS, 0, 2},
+      {ARITHMETIC_MUL, "arithmetic_mul", arithmetic_mul::N_COLS, 0, 3},
   };
   return air_id < COUNT ? &table[air_id] : nullptr;
 }

@@ -123,6 +123,7 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
              : c.air_id == air::ARITHMETIC ? launch_arithmetic_trace(d_trace, nullptr, c.log_n, seed, w.stream)
              : c.air_id == air::BYTE_PACKING ? launch_byte_packing_trace(d_trace, nullptr, c.log_n, seed, w.stream)
              : c.air_id == air::KECCAK_SPONGE ? launch_keccak_sponge_trace(d_trace, nullptr, c.log_n, seed, w.stream)
+             : c.air_id == air::ARITHMETIC_MUL ? launch_arithmetic_mul_trace(d_trace, nullptr, c.log_n, seed, w.stream)
                                        : launch_synth_trace(d_trace, d_consts, c.log_n, c.n_cols, c.n_const, c.deg_pow, seed, w.stream);
     if (r2) return r2;
     if ((r2 = commit(w, d_trace, c.n_cols, c.log_n, c.rate_bits, c.cap_height, false, &trace))) return r2;
@@ -222,6 +223,10 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
     fam(sp::K0, 2, 0, 2); fam(sp::K1, 1, 0, 2); fam(sp::K2, 136, 0, 2); fam(sp::K3, 1, 0, 1); fam(sp::K4, 1088, 0, 2);
     fam(sp::K5, 1088, 0, 2); fam(sp::K6, 136, 0, 2); fam(sp::K7, 34, 0, 2); fam(sp::K8, 50, 1, 2); fam(sp::K9, 50, 2, 1);
     fam(sp::K10, 1, 1, 2);
+  } else if (air_id == air::ARITHMETIC_MUL) {
+    namespace am = air::arithmetic_mul;
+    fam(am::U0, 1, 0, 2); fam(am::U1, 256, 0, 2); fam(am::U2, 256, 0, 2); fam(am::U3, 672, 0, 2); fam(am::U4, 32, 0, 3);
+    fam(am::U5, 1, 0, 1);
   } else {
     // interleaved per group of four columns: 3g all rows, 3g + 1 transition, 3g + 2 first row
     fam(0, C / 4, 0, 2); fam(1, C / 4, 1, 3 * dp); fam(2, C / 4, 2, 1);
@@ -273,6 +278,13 @@ int bp_keccak_sponge_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log
   return launch_keccak_sponge_trace(d_trace_out, d_inputs, log_n, seed, as_stream(stream));
 }
 BPG_ABI_CATCH("bp_keccak_sponge_trace")
+
+int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream) try {
+  if (!d_trace_out) return fail(BP_ERR_INVALID_INPUT, "bp_arithmetic_mul_trace: null output");
+  if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_arithmetic_mul_trace: log_n out of range");
+  return launch_arithmetic_mul_trace(d_trace_out, d_inputs, log_n, seed, as_stream(stream));
+}
+BPG_ABI_CATCH("bp_arithmetic_mul_trace")
 
 // ---- L0: the remaining per-stage entry points of SURVEY.md section 8(b) -------------------------------
 

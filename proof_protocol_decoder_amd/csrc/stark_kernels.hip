@@ -349,6 +349,45 @@ keccak_sponge_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- multiplication witness (AIR 7, air.hpp)
+// One product per row.  `inputs` ([row][9]: is_mul, the four 64-bit words of x and of y, least significant first) or,
+// when null, drawn from the seed like the oracle: is_mul = splitmix64(seed ^ (0xE0 << 32) ^ row) % 4 != 0, words as in
+// bp_logic_trace.  Schoolbook over 16-bit limbs: column sums stay below 2^37.
+__global__ void __launch_bounds__(256)
+arithmetic_mul_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  namespace am = bpg::air::arithmetic_mul;
+  const uint32_t n = 1u << log_n;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool mul = inputs ? (inputs[(uint64_t)i * 9] & 1) != 0 : splitmix64(seed ^ (0xE0ull << 32) ^ i) % 4 != 0;
+  uint64_t x[4], y[4];
+  for (uint32_t k = 0; k < 4; k++) {
+    x[k] = inputs ? inputs[(uint64_t)i * 9 + 1 + k] : splitmix64(seed ^ ((uint64_t)(1 + k) << 32) ^ i);
+    y[k] = inputs ? inputs[(uint64_t)i * 9 + 5 + k] : splitmix64(seed ^ ((uint64_t)(5 + k) << 32) ^ i);
+  }
+  auto limb = [](const uint64_t (&w)[4], uint32_t k) { return (uint64_t)((w[k >> 2] >> (16 * (k & 3))) & 0xFFFFu); };
+  auto put = [&](uint32_t col, uint64_t v) { t[(uint64_t)col * n + i] = v; };
+  put(am::COL_MUL, mul);
+  for (uint32_t k = 0; k < 16; k++) {
+    put(am::COL_X + k, limb(x, k));
+    put(am::COL_Y + k, limb(y, k));
+  }
+  uint64_t carry = 0;
+  for (uint32_t k = 0; k < 32; k++) {
+    uint64_t sum = carry;
+    if (mul) {
+      const uint32_t i0 = k < 16 ? 0 : k - 15, i1 = k < 16 ? k : 15;
+      for (uint32_t a = i0; a <= i1; a++) sum += limb(x, a) * limb(y, k - a);
+    }
+    const uint32_t p = (uint32_t)(sum & 0xFFFFu);
+    carry = sum >> 16;
+    const uint32_t pcol = k < 16 ? am::COL_Z + 16 * k : am::COL_W + 16 * (k - 16);
+    for (uint32_t j = 0; j < 16; j++) put(pcol + j, (p >> j) & 1);
+    for (uint32_t j = 0; j < 21; j++) put(am::COL_CARRY + 21 * k + j, (carry >> j) & 1);
+  }
+}
+
 // ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
 // z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
 // One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
@@ -505,6 +544,7 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
       else if constexpr (AIR == bpg::air::ARITHMETIC) bpg::air::arithmetic::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::BYTE_PACKING) bpg::air::byte_packing::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::KECCAK_SPONGE) bpg::air::keccak_sponge::eval_unit<uint64_t>(u, row, out);
+      else if constexpr (AIR == bpg::air::ARITHMETIC_MUL) bpg::air::arithmetic_mul::eval_unit<uint64_t>(u, row, out);
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -1069,6 +1109,11 @@ int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
+  arithmetic_mul_trace_kernel<<<ceil_div((uint64_t)1 << log_n, 256), 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
                hipStream_t st) {
   if (!n_aux) return BP_OK;
@@ -1094,6 +1139,7 @@ int launch_quotient(const QuotArgs& q, hipStream_t st) {
   else if (q.air_id == bpg::air::ARITHMETIC) quotient_air_kernel<bpg::air::ARITHMETIC><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::BYTE_PACKING) quotient_air_kernel<bpg::air::BYTE_PACKING><<<g1, 256, 0, st>>>(q);
   else if (q.air_id == bpg::air::KECCAK_SPONGE) quotient_air_kernel<bpg::air::KECCAK_SPONGE><<<g1, 256, 0, st>>>(q);
+  else if (q.air_id == bpg::air::ARITHMETIC_MUL) quotient_air_kernel<bpg::air::ARITHMETIC_MUL><<<g1, 256, 0, st>>>(q);
   else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(q);
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {

@@ -79,6 +79,7 @@ MEMORY_COLS = 44
 ARITHMETIC_COLS = 309
 BYTE_PACKING_COLS = 297
 KECCAK_SPONGE_COLS = 2414
+ARITHMETIC_MUL_COLS = 1217
 
 
 def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
@@ -141,6 +142,17 @@ def keccak_sponge_trace(log_n, seed=0, inputs=None, device="cuda"):
         _require_cuda(inputs)
         assert inputs.shape == (1 << log_n, 44)
     check(lib().bp_keccak_sponge_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
+    return out
+
+
+def arithmetic_mul_trace(log_n, seed=0, inputs=None, device="cuda"):
+    """bp_arithmetic_mul_trace: the AIR-7 witness [1217, 2^log_n]; inputs [2^log_n, 9] int64 on the device (is_mul, the
+    four words of x, of y), or drawn from `seed`."""
+    out = torch.empty((ARITHMETIC_MUL_COLS, 1 << log_n), dtype=torch.int64, device=device)
+    if inputs is not None:
+        _require_cuda(inputs)
+        assert inputs.shape == (1 << log_n, 9)
+    check(lib().bp_arithmetic_mul_trace(inputs.data_ptr() if inputs is not None else None, seed, log_n, out.data_ptr(), _stream()))
     return out
 
 

@@ -293,7 +293,7 @@ def test_witness_entry_points_check_their_arguments_before_any_device_work():
     L = pkg.lib()
     L.bp_last_error.restype = C.c_char_p
     for name in ("bp_keccak_trace", "bp_logic_trace", "bp_memory_trace", "bp_arithmetic_trace", "bp_byte_packing_trace",
-                 "bp_keccak_sponge_trace"):
+                 "bp_keccak_sponge_trace", "bp_arithmetic_mul_trace"):
         f = getattr(L, name)
         f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         assert f(None, 1, 8, None, None) == -2 and name.encode() in L.bp_last_error()
