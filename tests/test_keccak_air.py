@@ -152,7 +152,7 @@ def test_air_registry_describes_both_airs():
     assert s.name == b"synthetic" and (s.fixed_n_cols, s.n_cols, s.degree, s.n_air_constraints) == (0, 135, 9, 99)
     from proof_protocol_decoder_amd._lib import BpgError
     with pytest.raises(BpgError):
-        pkg.ops.air_describe(7)
+        pkg.ops.air_describe(99)
 
 
 def test_oracle_txn_with_the_keccak_flag_differs_only_through_table_3(oracle):
