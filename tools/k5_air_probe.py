@@ -20,6 +20,7 @@ CASES = [  # name, air_id, columns, log_n (the S1 height of the table), n_const
     ("memory (AIR 3)", 3, 44, 17, 0),
     ("keccak sponge (AIR 6)", 6, 2414, 9, 0),
     ("keccak sponge (AIR 6) at 2^12", 6, 2414, 12, 0),
+    ("multiplication (AIR 7)", 7, 1217, 14, 0),
 ]
 g = torch.Generator(device="cuda").manual_seed(1)
 for name, air, C_, log_n, K in CASES:
