@@ -45,7 +45,7 @@ for name, air, C_, log_n, K in CASES:
             best = min(best, a.elapsed_time(b))
         out.append(best)
     L.bp_tune_assume_loaded(-1)
-    print("%-42s 2^%d x %d, %4d constraints: %8.1f us spread over workgroup rows, %8.1f us one pass; %6.2f G constraint "
+    print("%-42s 2^%d x %d, %4d constraints: %8.1f us spread over workgroup rows, %8.1f us in the form taken under load (one pass for the synthetic AIR, 256 workgroups for the others); %6.2f G constraint "
           "evaluations/s, %5.1f ns per row" % (name, log_n, C_, n_cons, out[0] * 1e3, out[1] * 1e3,
                                                 n_cons * rows / (min(out) * 1e-3) / 1e9, min(out) * 1e6 / rows), flush=True)
     del tr, aux
