@@ -49,6 +49,22 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join("profiles", "r3_pmc_lde_family.txt")
 
 
+# (flag, bp_tune_* entry, help): every run-time knob of the library that bench.py can set
+TUNE_KNOBS = (
+    ("--merkle-fused", "bp_tune_merkle_fused", "0: one launch per Merkle level"),
+    ("--merkle-wide", "bp_tune_merkle_wide", "levels of up to 2^k parents through the wide fused kernel"),
+    ("--ntt-split", "bp_tune_ntt_split", "split NTT kernels: 0 auto, 1 never, 2 wherever possible"),
+    ("--ntt-mx", "bp_tune_ntt_mx", "matrix-core NTT blocks"),
+    ("--poseidon-mx", "bp_tune_poseidon_mx", "0: Poseidon without the matrix cores"),
+    ("--poseidon-grouped", "bp_tune_poseidon_grouped", "0 / 2 / 3 groups of partial rounds"),
+    ("--k5-spread", "bp_tune_k5_spread", "spread the synthetic AIR's units under load too"),
+    ("--quad-threshold-log2", "bp_tune_quad_threshold",
+     "hash launches with fewer rows than 2^k take the low-latency Poseidon forms"),
+    ("--rec-batch", "bp_tune_rec_batch", "recursion-shaped proofs proved in lock-step per batch (1 = one at a time)"),
+    ("--host-wait", "bp_tune_host_wait", "0 auto, 1 the runtime's wait, 2 the library's poll-and-sleep wait"),
+)
+
+
 def traffic_ratio():
     import re
     try:
@@ -76,15 +92,12 @@ def main():
                     help="also time every LDE launch INSIDE the timed region with HIP events (roofline_in_situ).  Off by "
                          "default: the event records cost 2.4 %% of the block rate (profiles/r3_order_experiment.txt)")
     ap.add_argument("--no-in-situ-profile", action="store_true", help="(accepted for older command lines: the default)")
-    ap.add_argument("--extra-workers", type=int, default=0,
-                    help="prover streams beyond --threads that idle until a txn can fan its seven recursion chains out "
-                         "to them (ends of shards, small blocks)")
     ap.add_argument("--arena-gib", type=float, default=5.0, help="device arena per prover stream")
-    ap.add_argument("--merkle-fused", type=int, default=None, help="0: one launch per Merkle level")
-    ap.add_argument("--merkle-wide", type=int, default=None, help="bp_tune_merkle_wide (measurement knob)")
-    ap.add_argument("--ntt-split", type=int, default=None, help="bp_tune_ntt_split mode (measurement knob)")
-    ap.add_argument("--ntt-mx", type=int, default=None, help="bp_tune_ntt_mx mode (measurement knob)")
-    ap.add_argument("--poseidon-mx", type=int, default=None, help="bp_tune_poseidon_mx (measurement knob)")
+    # measurement knobs: one table, used for the argument parser, for applying them and for handing EVERY one of them
+    # to the --leg-only child, so that the alone-on-the-chip figures of a line come from the configuration its timed
+    # region ran with
+    for flag, _, help_ in TUNE_KNOBS:
+        ap.add_argument(flag, type=int, default=None, help=help_)
     ap.add_argument("--keccak-air", action="store_true",
                     help="every transaction's Keccak table is a real Keccak-f[1600] trace (AIR 1, 2430 columns) instead "
                          "of the 2432-column synthetic table BASELINE's metric is quoted on")
@@ -93,10 +106,6 @@ def main():
                          "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / "
                          "2414 / 523 / 44 columns) instead of synthetic tables of "
                          "BASELINE's widths -- another workload than the metric's, reported as such")
-    ap.add_argument("--k5-spread", type=int, default=None, help="bp_tune_k5_spread (measurement knob)")
-    ap.add_argument("--poseidon-grouped", type=int, default=None, help="bp_tune_poseidon_grouped: 0 / 2 / 3 groups of partial rounds (measurement knob)")
-    ap.add_argument("--quad-threshold-log2", type=int, default=None,
-                    help="hash launches with fewer rows than 2^k use the 4-lanes-per-state Poseidon kernels")
     ap.add_argument("--leg-only", action="store_true",
                     help="(internal) run only the alone-on-the-chip measurements -- single-stream roofline leg, isolated "
                          "LDE, inverse-NTT sweep, Poseidon peak -- and print them as one JSON object; the main run "
@@ -162,22 +171,10 @@ def main():
     from proof_protocol_decoder_amd.block_driver import BlockDriver, TorchGather, shard_bounds, synthetic_block_irs
     L = pkg.lib()
     L.bp_profile_read.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    if args.merkle_fused is not None:
-        L.bp_tune_merkle_fused(args.merkle_fused)
-    if args.quad_threshold_log2 is not None:
-        L.bp_tune_quad_threshold(1 << args.quad_threshold_log2)
-    if args.merkle_wide is not None:
-        L.bp_tune_merkle_wide(args.merkle_wide)
-    if args.ntt_split is not None:
-        L.bp_tune_ntt_split(args.ntt_split)
-    if args.ntt_mx is not None:
-        L.bp_tune_ntt_mx(args.ntt_mx)
-    if args.poseidon_mx is not None:
-        L.bp_tune_poseidon_mx(args.poseidon_mx)
-    if args.poseidon_grouped is not None:
-        L.bp_tune_poseidon_grouped(args.poseidon_grouped)
-    if args.k5_spread is not None:
-        L.bp_tune_k5_spread(args.k5_spread)
+    for flag, fn, _ in TUNE_KNOBS:
+        val = getattr(args, flag[2:].replace("-", "_"))
+        if val is not None:
+            getattr(L, fn)((1 << val) if flag == "--quad-threshold-log2" else val)
 
     def read_family(note, leg=True):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
@@ -218,7 +215,7 @@ def main():
         """The same workload with ONE prover stream and nothing else on the chip, so every launch of the kernel
         has the device to itself and event time == kernel time (this is what the rocprof summary in profiles/ is
         taken from)."""
-        solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=5 << 30).build()
+        solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=int(args.arena_gib * 2**30)).build()
         solo_driver = BlockDriver(solo, n_threads=1)
         irs = synthetic_block_irs(1000, 2, S1_LOG_N, S1_WIDTH)
         solo_driver.prove_shard(irs[:1])
@@ -271,7 +268,7 @@ def main():
 
     t_build = time.time()
     # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
-    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads + args.extra_workers,
+    state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads,
                                          arena_bytes=int(args.arena_gib * 2**30)).build()
     t_build = time.time() - t_build
     driver = BlockDriver(state, n_threads=args.threads)
@@ -371,11 +368,9 @@ def main():
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
             env["BPG_LEG_DEVICE"] = str(local_rank)
-            knobs = []
-            for flag, val in (("--merkle-fused", args.merkle_fused), ("--ntt-split", args.ntt_split),
-                              ("--ntt-mx", args.ntt_mx), ("--poseidon-mx", args.poseidon_mx),
-                              ("--poseidon-grouped", args.poseidon_grouped),
-                              ("--quad-threshold-log2", args.quad_threshold_log2)):
+            knobs = ["--arena-gib", str(args.arena_gib)]
+            for flag, _, _ in TUNE_KNOBS:
+                val = getattr(args, flag[2:].replace("-", "_"))
                 if val is not None:
                     knobs += [flag, str(val)]
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg-only"] + knobs, env=env,

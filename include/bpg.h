@@ -143,6 +143,15 @@ void bp_tune_poseidon_grouped(int mode);
  * loaded): -1 (default).  0 / 1: stated by a caller that drives the L0 / L0.5 entry points from its own threads (the
  * library cannot see that load), or by a test that pins both paths.  Results are identical. */
 void bp_tune_assume_loaded(int mode);
+/* The recursion-shaped proofs of a transaction -- level k of its seven per-table chains (proof_gen.rs:44-52 proves all
+ * tables in one call; upstream shrinks each table's proof through a chain of fixed-shape circuits) -- are proved in
+ * lock-step, up to n (1..8, default 8) proofs per batch: seven transcripts stepped together, every kernel launch and every
+ * host wait shared.  1 = one proof at a time (round 3's behaviour, for A/B runs).  Results are identical. */
+void bp_tune_rec_batch(int n);
+/* How the library's prover threads wait for the device: 0 (default) = the runtime's wait where it sleeps
+ * (bp_host_wait_mode 1), the library's own poll-and-sleep wait where the runtime's would spin (mode 2: a device the
+ * process had already used when the library came to it); 1 = always the runtime's wait; 2 = always poll and sleep. */
+void bp_tune_host_wait(int mode);
 /* Measurement knob: 1 = while the device is loaded the quotient kernel spreads the units of the SYNTHETIC AIR over
  * workgroup rows until the launch has 256 workgroups, as it does for the AIRs of the real tables; 0 (default): one pass. */
 void bp_tune_k5_spread(int on);

@@ -145,6 +145,7 @@ int bp_device_count(void) {
 
 // 0 undecided, 1 interrupt-driven host waits (hipDeviceScheduleBlockingSync), 2 left as the process had it
 static std::atomic<int> g_wait_mode[64];
+static std::mutex g_wait_mu;
 
 int bp_use_blocking_sync(int device) {
   // On this ROCm every host wait (hipStreamSynchronize, hipEventSynchronize -- even on an event made
@@ -156,10 +157,19 @@ int bp_use_blocking_sync(int device) {
   // switched while the process has not used the device yet: switching it under queues that already carried work
   // (the application's null stream, a parked worker's stream) makes a later device-wide wait -- hipFree,
   // hipDeviceSynchronize -- never return (tools/hang_probe.py; tests/test_gpu_proofgen.py).  A device the process
-  // has already used therefore keeps the mode it has: everything works, host waits spin.
+  // has already used therefore keeps the mode it has; the library's own waits then poll and sleep
+  // (Worker::wait, prover.cpp) instead of calling the runtime's spinning wait.
   if (device < 0 || device >= 64) return bpg::fail(BP_ERR_DEVICE, "device %d out of range", device);
-  int expected = 0;
-  if (!g_wait_mode[device].compare_exchange_strong(expected, 2)) return BP_OK;
+  if (g_wait_mode[device].load(std::memory_order_acquire)) return BP_OK;
+  // The whole decision is one critical section: a second thread must not create its stream (Worker::init) between
+  // this thread's "decided" and its hipSetDeviceFlags -- that sequence is the round-3 hipFree hang.
+  std::lock_guard<std::mutex> lk(g_wait_mu);
+  if (g_wait_mode[device].load(std::memory_order_acquire)) return BP_OK;
+  struct Decide {  // the mode is published last, on every way out
+    std::atomic<int>& slot;
+    int mode = 2;
+    ~Decide() { slot.store(mode, std::memory_order_release); }
+  } decide{g_wait_mode[device]};
   unsigned int flags = 0;
   int active = 0;
 #pragma clang diagnostic push
@@ -169,7 +179,7 @@ int bp_use_blocking_sync(int device) {
 #pragma clang diagnostic pop
   if (e != hipSuccess) return bpg::fail(BP_ERR_DEVICE, "hipDevicePrimaryCtxGetState(%d): %s", device, hipGetErrorString(e));
   if ((flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync) {
-    g_wait_mode[device].store(1);
+    decide.mode = 1;
     return BP_OK;
   }
   if (active) return BP_OK;  // in use already: not ours to switch
@@ -179,7 +189,7 @@ int bp_use_blocking_sync(int device) {
   if (e == hipSuccess) e = hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
   (void)hipSetDevice(prev);
   if (e != hipSuccess) return bpg::fail(BP_ERR_DEVICE, "hipSetDeviceFlags(blocking sync) on device %d: %s", device, hipGetErrorString(e));
-  g_wait_mode[device].store(1);
+  decide.mode = 1;
   return BP_OK;
 }
 

@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "poseidon.cuh"
 #include "poseidon_mx.cuh"
+#include "stark_kernels.hpp"
 
 namespace {
 
@@ -32,7 +33,9 @@ __global__ void __launch_bounds__(256) perm_batch_kernel(uint64_t* __restrict__ 
 // >= 5 waves per SIMD: the interleaved S-boxes otherwise balloon to ~190 VGPRs (2 waves), which exposes latency
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 leaf_hash_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
-                 uint32_t rate_bits, uint64_t* __restrict__ digests) {
+                 uint32_t rate_bits, uint64_t* __restrict__ digests, uint64_t lde_bstride, uint64_t dig_bstride) {
+  lde += blockIdx.z * lde_bstride;  // tree blockIdx.z of a batch of equally shaped commitments
+  digests += blockIdx.z * dig_bstride;
   const uint64_t rows = (uint64_t)1 << (log_n + rate_bits);
   uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
@@ -66,7 +69,9 @@ leaf_hash_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_c
 // Quad-cooperative variants (poseidon.cuh): four lanes per row / node.  blockDim = 256 = 64 quads.
 __global__ void __launch_bounds__(256)
 leaf_hash_quad_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
-                      uint32_t rate_bits, uint64_t* __restrict__ digests) {
+                      uint32_t rate_bits, uint64_t* __restrict__ digests, uint64_t lde_bstride, uint64_t dig_bstride) {
+  lde += blockIdx.z * lde_bstride;
+  digests += blockIdx.z * dig_bstride;
   __shared__ uint64_t rc[360];
   for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
   __syncthreads();
@@ -92,8 +97,11 @@ leaf_hash_quad_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_
 }
 __global__ void __launch_bounds__(256)
 merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
-                         uint64_t* __restrict__ mirror) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+                         uint64_t* __restrict__ mirror, uint64_t dig_bstride) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  child += blockIdx.z * dig_bstride;
+  parent += blockIdx.z * dig_bstride;
+  if (mirror) mirror += blockIdx.z * n_parents * 4;  // the mirrored level is the cap: 4 * n_parents words per tree
   __shared__ uint64_t rc[360];
   for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
   __syncthreads();
@@ -113,10 +121,13 @@ merkle_level_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restric
 // seven single-level launches on a proof's critical path.
 __global__ void __launch_bounds__(256)
 merkle_subtree_quad_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ out, uint64_t n_parents,
-                           uint32_t levels, uint64_t* __restrict__ mirror) {
+                           uint32_t levels, uint64_t* __restrict__ mirror, uint64_t dig_bstride) {
   __shared__ uint64_t rc[360];
   __shared__ uint64_t sm[2][64 * 4];
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  child += blockIdx.z * dig_bstride;
+  out += blockIdx.z * dig_bstride;
+  if (mirror) mirror += blockIdx.z * ((n_parents >> (levels - 1)) * 4);  // the last level of the launch is the cap
   for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
   __syncthreads();
   const poseidon::QuadCtx qc = poseidon::quad_ctx();
@@ -180,8 +191,11 @@ leaf_hash_rows_kernel(const uint64_t* __restrict__ leaves, uint32_t leaf_len, ui
 // One lane per parent node of one level.
 __global__ void __launch_bounds__(256)
 merkle_level_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
-                    uint64_t* __restrict__ mirror) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+                    uint64_t* __restrict__ mirror, uint64_t dig_bstride) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  child += blockIdx.z * dig_bstride;
+  parent += blockIdx.z * dig_bstride;
+  if (mirror) mirror += blockIdx.z * n_parents * 4;
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= n_parents) return;
   uint64_t l[4], r[4], o[4];
@@ -255,8 +269,11 @@ __global__ void BPG_MX_BOUNDS perm_batch_mx_kernel(uint64_t* __restrict__ states
 template <int NS, int GR>
 __global__ void BPG_MX_BOUNDS
 leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t n_cols, uint32_t log_n,
-                    uint32_t rate_bits, uint64_t* __restrict__ digests, const uint32_t* __restrict__ gtab) {
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+                    uint32_t rate_bits, uint64_t* __restrict__ digests, uint64_t lde_bstride, uint64_t dig_bstride,
+                    const uint32_t* __restrict__ gtab) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  lde += blockIdx.z * lde_bstride;
+  digests += blockIdx.z * dig_bstride;
   BPG_MX_TABLES(NS, GR, gtab)
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
   const uint64_t rows = (uint64_t)1 << (log_n + rate_bits);
@@ -304,8 +321,11 @@ leaf_hash_mx_kernel(const uint64_t* __restrict__ lde, uint64_t stride, uint32_t 
 template <int NS, int GR>
 __global__ void BPG_MX_BOUNDS
 merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ parent, uint64_t n_parents,
-                       uint64_t* __restrict__ mirror, const uint32_t* __restrict__ gtab) {
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+                       uint64_t* __restrict__ mirror, uint64_t dig_bstride, const uint32_t* __restrict__ gtab) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  child += blockIdx.z * dig_bstride;
+  parent += blockIdx.z * dig_bstride;
+  if (mirror) mirror += blockIdx.z * n_parents * 4;
   BPG_MX_TABLES(NS, GR, gtab)
   const poseidon::mx::Ctx c = poseidon::mx::make_ctx(cin);
   const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * NS) + (threadIdx.x & 15);
@@ -337,8 +357,11 @@ merkle_level_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict_
 // with the quad-cooperative permutation, ~12 us per level against ~8).
 __global__ void __launch_bounds__(256)
 merkle_subtree_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ out, uint64_t n_parents,
-                         uint32_t levels, uint64_t* __restrict__ mirror) {
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+                         uint32_t levels, uint64_t* __restrict__ mirror, uint64_t dig_bstride) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  child += blockIdx.z * dig_bstride;
+  out += blockIdx.z * dig_bstride;
+  if (mirror) mirror += blockIdx.z * ((n_parents >> (levels - 1)) * 4);  // the last level of the launch is the cap
   __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
   __shared__ uint64_t sm[2][64 * 4];
   poseidon::mx::build_cin(cin);
@@ -384,8 +407,11 @@ merkle_subtree_mx_kernel(const uint64_t* __restrict__ child, uint64_t* __restric
 // this kernel from 2^14 nodes, the cap's last levels -- instead of six.
 __global__ void __launch_bounds__(256)
 merkle_subtree_wide_kernel(const uint64_t* __restrict__ child, uint64_t* __restrict__ out, uint64_t n_parents,
-                           uint32_t levels, uint64_t* __restrict__ mirror) {
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+                           uint32_t levels, uint64_t* __restrict__ mirror, uint64_t dig_bstride) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  child += blockIdx.z * dig_bstride;
+  out += blockIdx.z * dig_bstride;
+  if (mirror) mirror += blockIdx.z * ((n_parents >> (levels - 1)) * 4);
   __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
   __shared__ uint64_t sm[2][256 * 4];
   poseidon::mx::build_cin(cin);
@@ -527,7 +553,6 @@ __global__ void __launch_bounds__(256) field_ops_kernel(const uint64_t* __restri
 
 namespace bpg {
 
-int merkle_commit_cols(const uint64_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint64_t*, hipStream_t, uint64_t*, bool*);
 
 // launches with fewer permutations than this use the quad-cooperative kernels (4x the waves)
 // 0 = automatic: the quad form (4x the waves, 1.22x the instructions) pays while the chip is not full, so
@@ -657,31 +682,35 @@ const uint32_t* group_tables(int* n_groups) {
   return slot;
 }
 
-#define BPG_MX_DISPATCH(NS_EXPR, KERNEL, ITEMS, ...)                                                        \
+// ITEMS: rows / nodes / states of ONE tree; BATCH trees (grid.z) of that size in the launch
+#define BPG_MX_DISPATCH(NS_EXPR, KERNEL, ITEMS, BATCH, ...)                                                 \
   switch (NS_EXPR) {                                                                                       \
     case 4: {                                                                                              \
       int ng_ = 0;                                                                                         \
       const uint32_t* gtab_ = bpg::group_tables(&ng_);                                                     \
       if (gtab_ && ng_ == 3)                                                                               \
-        KERNEL<4, 3><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, gtab_);                    \
+        KERNEL<4, 3><<<dim3(ceil_div((ITEMS), 256), 1, (BATCH)), 256, 0, st>>>(__VA_ARGS__, gtab_);       \
       else if (gtab_)                                                                                      \
-        KERNEL<4, 2><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, gtab_);                    \
+        KERNEL<4, 2><<<dim3(ceil_div((ITEMS), 256), 1, (BATCH)), 256, 0, st>>>(__VA_ARGS__, gtab_);       \
       else                                                                                                 \
-        KERNEL<4, 0><<<ceil_div((ITEMS), 256), 256, 0, st>>>(__VA_ARGS__, nullptr);                  \
+        KERNEL<4, 0><<<dim3(ceil_div((ITEMS), 256), 1, (BATCH)), 256, 0, st>>>(__VA_ARGS__, nullptr);     \
       break;                                                                                               \
     }                                                                                                      \
-    case 2: KERNEL<2, 0><<<ceil_div((ITEMS), 128), 256, 0, st>>>(__VA_ARGS__, nullptr); break;       \
-    default: KERNEL<1, 0><<<ceil_div((ITEMS), 64), 256, 0, st>>>(__VA_ARGS__, nullptr); break;       \
+    case 2: KERNEL<2, 0><<<dim3(ceil_div((ITEMS), 128), 1, (BATCH)), 256, 0, st>>>(__VA_ARGS__, nullptr); break; \
+    default: KERNEL<1, 0><<<dim3(ceil_div((ITEMS), 64), 1, (BATCH)), 256, 0, st>>>(__VA_ARGS__, nullptr); break; \
   }
 
 // `mirror` (nullable): host-visible buffer that receives the 2^cap_height cap digests directly from
 // the kernel that produces them, so the caller needs no device->host copy, only a stream wait.
 // Returns with *mirrored = false when there was no level to run (the cap is the leaf level).
 int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st,
-                        uint64_t* mirror, bool* mirrored) {
+                        uint64_t* mirror, bool* mirrored, uint32_t batch, uint64_t dig_bstride) {
   uint64_t* lvl = d_digests;
   uint32_t l = log_leaves;
   if (mirrored) *mirrored = false;
+  if (batch == 0 || batch > MAX_BATCH) return fail(BP_ERR_INVALID_INPUT, "merkle: batch of %u trees", batch);
+  // `batch` trees of this shape are in every launch (grid.z): the choice of kernel form goes by the work of the
+  // whole launch, the fusing limits by one tree (a workgroup never spans two trees)
   while (l > cap_height) {
     const uint64_t cnt = (uint64_t)1 << l, parents = cnt / 2;
     uint64_t* nxt = lvl + cnt * 4;
@@ -697,7 +726,7 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
       uint32_t levels = l - cap_height;
       if (levels > 9) levels = 9;
       uint64_t* mir = (l - levels == cap_height) ? mirror : nullptr;
-      merkle_subtree_wide_kernel<<<(uint32_t)(parents / 256), 256, 0, st>>>(lvl, nxt, parents, levels, mir);
+      merkle_subtree_wide_kernel<<<dim3((uint32_t)(parents / 256), 1, batch), 256, 0, st>>>(lvl, nxt, parents, levels, mir, dig_bstride);
       BPG_LAUNCH_CHECK();
       if (mir && mirrored) *mirrored = true;
       for (uint32_t k = 0; k < levels; k++) {
@@ -708,12 +737,12 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     }
     if (!fused) {
       uint64_t* mir = (l - 1 == cap_height) ? mirror : nullptr;
-      if (const int ns = mx_sets(parents)) {
-        BPG_MX_DISPATCH(ns, merkle_level_mx_kernel, parents, lvl, nxt, parents, mir)
-      } else if (parents >= quad_threshold())  // big level: one lane per node
-        merkle_level_kernel<<<ceil_div(parents, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
+      if (const int ns = mx_sets(parents * batch)) {
+        BPG_MX_DISPATCH(ns, merkle_level_mx_kernel, parents, batch, lvl, nxt, parents, mir, dig_bstride)
+      } else if (parents * batch >= quad_threshold())  // big level: one lane per node
+        merkle_level_kernel<<<dim3(ceil_div(parents, 256), 1, batch), 256, 0, st>>>(lvl, nxt, parents, mir, dig_bstride);
       else
-        merkle_level_quad_kernel<<<ceil_div(cnt * 2, 256), 256, 0, st>>>(lvl, nxt, parents, mir);
+        merkle_level_quad_kernel<<<dim3(ceil_div(cnt * 2, 256), 1, batch), 256, 0, st>>>(lvl, nxt, parents, mir, dig_bstride);
       BPG_LAUNCH_CHECK();
       if (mir && mirrored) *mirrored = true;
       lvl = nxt;
@@ -728,8 +757,8 @@ int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_h
     for (uint64_t p = parents >= 64 ? 64 : parents; p > 1; p >>= 1) max_levels++;
     if (levels > max_levels) levels = max_levels;
     uint64_t* mir = (l - levels == cap_height) ? mirror : nullptr;
-    if (poseidon_mx()) merkle_subtree_mx_kernel<<<wgs, 256, 0, st>>>(lvl, nxt, parents, levels, mir);
-    else merkle_subtree_quad_kernel<<<wgs, 256, 0, st>>>(lvl, nxt, parents, levels, mir);
+    if (poseidon_mx()) merkle_subtree_mx_kernel<<<dim3(wgs, 1, batch), 256, 0, st>>>(lvl, nxt, parents, levels, mir, dig_bstride);
+    else merkle_subtree_quad_kernel<<<dim3(wgs, 1, batch), 256, 0, st>>>(lvl, nxt, parents, levels, mir, dig_bstride);
     BPG_LAUNCH_CHECK();
     if (mir && mirrored) *mirrored = true;
     for (uint32_t k = 0; k < levels; k++) {
@@ -818,7 +847,7 @@ int bp_poseidon_perm_batch(uint64_t* d_states, uint64_t n, void* stream) try {
   hipStream_t st = bpg::as_stream(stream);
   using bpg::ceil_div;
   if (const int ns = bpg::mx_sets(n)) {
-    BPG_MX_DISPATCH(ns, perm_batch_mx_kernel, n, d_states, n)
+    BPG_MX_DISPATCH(ns, perm_batch_mx_kernel, n, 1, d_states, n)
   } else
     perm_batch_kernel<<<bpg::ceil_div(n, 256), 256, 0, st>>>(d_states, n);
   BPG_LAUNCH_CHECK();
@@ -829,7 +858,7 @@ BPG_ABI_CATCH("bp_poseidon_perm_batch")
 int bp_merkle_commit(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n,
                      uint32_t rate_bits, uint32_t cap_height, uint64_t* d_digests, void* stream) try {
   return bpg::merkle_commit_cols(d_lde, lde_stride, n_cols, log_n, rate_bits, cap_height, d_digests,
-                                 bpg::as_stream(stream), nullptr, nullptr);
+                                 bpg::as_stream(stream), nullptr, nullptr, 1, 0, 0);
 }
 BPG_ABI_CATCH("bp_merkle_commit")
 
@@ -838,27 +867,34 @@ BPG_ABI_CATCH("bp_merkle_commit")
 namespace bpg {
 
 int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
-                       uint32_t cap_height, uint64_t* d_digests, hipStream_t st, uint64_t* mirror, bool* mirrored) {
+                       uint32_t cap_height, uint64_t* d_digests, hipStream_t st, uint64_t* mirror, bool* mirrored,
+                       uint32_t batch, uint64_t lde_bstride, uint64_t dig_bstride) {
   const uint32_t log_leaves = log_n + rate_bits;
   if (!d_lde || !d_digests) return fail(BP_ERR_INVALID_INPUT, "bp_merkle_commit: null buffer");
   if (log_leaves > 30 || cap_height > log_leaves || n_cols == 0 || lde_stride < ((uint64_t)1 << log_leaves))
     return fail(BP_ERR_INVALID_INPUT,
                 "bp_merkle_commit: bad shape (log_n=%u rate_bits=%u cap_height=%u n_cols=%u stride=%llu)", log_n,
                 rate_bits, cap_height, n_cols, (unsigned long long)lde_stride);
+  if (batch == 0 || batch > MAX_BATCH) return fail(BP_ERR_INVALID_INPUT, "merkle: batch of %u trees", batch);
   uint64_t rows = (uint64_t)1 << log_leaves;
   {
     // integer-ALU-bound family: the "bytes" slot of the profiler carries permutations
-    KernelTimer kt(PROF_LEAF_HASH, st, n_cols > 4 ? (double)rows * (double)((n_cols + 7) / 8) : 0.0);
-    if (const int ns = mx_sets(rows)) {
-      BPG_MX_DISPATCH(ns, leaf_hash_mx_kernel, rows, d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests)
-    } else if (rows < quad_threshold())
-      leaf_hash_quad_kernel<<<ceil_div(rows * 4, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
-                                                                   d_digests);
+    KernelTimer kt(PROF_LEAF_HASH, st, n_cols > 4 ? (double)batch * (double)rows * (double)((n_cols + 7) / 8) : 0.0);
+    // the matrix-core kernels take whole sets of 16 rows: a tree with fewer rows than a wave's sets takes fewer sets
+    // (a forced set count -- bp_tune_poseidon_mx_sets, a low quad threshold -- must not read past a tiny matrix)
+    int ns = mx_sets(rows * batch);
+    while (ns > 1 && (uint64_t)16 * ns > rows) ns >>= 1;
+    if (ns && rows >= 16) {
+      BPG_MX_DISPATCH(ns, leaf_hash_mx_kernel, rows, batch, d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests, lde_bstride, dig_bstride)
+    } else if (rows * batch < quad_threshold())
+      leaf_hash_quad_kernel<<<dim3(ceil_div(rows * 4, 256), 1, batch), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits,
+                                                                               d_digests, lde_bstride, dig_bstride);
     else
-      leaf_hash_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests);
+      leaf_hash_kernel<<<dim3(ceil_div(rows, 256), 1, batch), 256, 0, st>>>(d_lde, lde_stride, n_cols, log_n, rate_bits, d_digests,
+                                                                      lde_bstride, dig_bstride);
   }
   BPG_LAUNCH_CHECK();
-  return merkle_upper_levels(d_digests, log_leaves, cap_height, st, mirror, mirrored);
+  return merkle_upper_levels(d_digests, log_leaves, cap_height, st, mirror, mirrored, batch, dig_bstride);
 }
 
 }  // namespace bpg

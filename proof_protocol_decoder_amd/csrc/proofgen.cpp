@@ -3,6 +3,8 @@
 // proof_types.rs}.  What each call computes is the synthetic workload of SURVEY.md section 8(d)
 // (DESIGN.md section 5); the control flow, ownership, threading and error behaviour follow the
 // reference (see include/bpg.h).
+#include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <memory>
@@ -98,32 +100,6 @@ struct WorkerLease {
   }
 };
 
-// A worker for a helper thread, only if one is idle right now (never waits).
-struct TryLease {
-  const bp_state* s;
-  Worker* w = nullptr;
-  size_t mark = 0;
-  explicit TryLease(const bp_state* st) : s(st) {
-    std::lock_guard<std::mutex> lk(s->mu);
-    if (s->idle.empty()) return;
-    w = s->idle.back();
-    s->idle.pop_back();
-    mark = w->arena.mark();
-    prover_active(+1);
-  }
-  ~TryLease() {
-    if (!w) return;
-    prover_active(-1);
-    (void)hipStreamSynchronize(w->stream);
-    w->arena.release(mark);
-    w->abort_flag = nullptr;
-    w->abort_flag_u8 = nullptr;
-    std::lock_guard<std::mutex> lk(s->mu);
-    s->idle.push_back(w);
-    s->cv.notify_one();
-  }
-};
-
 StarkCfg rec_cfg_of(const bp_config& c) {
   return StarkCfg{c.rec_log_n, c.rec_n_cols, c.rec_n_const, 3, c.rec_rate_bits, c.stark_cap_height,
                   c.rec_num_queries, c.rec_pow_bits, c.arity_bits, c.final_poly_bits};
@@ -177,29 +153,53 @@ int emit_box(uint64_t kind, uint64_t circuit, const std::vector<uint64_t>& pi, c
   return BP_OK;
 }
 
-// One recursion-shaped proof: transcript = circuit digest, hash of the public inputs, trace cap.
+// Recursion-shaped proofs; transcript of each = circuit digest, hash of the public inputs, trace cap.  `n` proofs of
+// the state's one recursion shape are proved in lock-step, up to g_rec_batch at a time (stark_prove_batch: every
+// launch and every host wait is shared; circuits, public inputs and transcripts are each proof's own).
+std::atomic<uint32_t> g_rec_batch{MAX_BATCH};  // bp_tune_rec_batch: 1 = one proof at a time
+int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* const* circ, const std::vector<uint64_t>* pi,
+                    std::vector<uint64_t>* proofs) {
+  const uint32_t cap = std::min<uint32_t>(std::min<uint32_t>(MAX_BATCH, std::max<uint32_t>(1, g_rec_batch.load(std::memory_order_relaxed))),
+                                          std::max<uint32_t>(1, MAX_BATCH_QUERIES / std::max<uint32_t>(1, rc.num_queries)));
+  const uint64_t N = (uint64_t)1 << rc.log_n;
+  for (uint32_t first = 0; first < n; first += cap) {
+    const uint32_t B = std::min(cap, n - first);
+    const size_t mark = w.arena.mark();
+    uint64_t* d_trace = w.arena.alloc_words((size_t)B * rc.n_cols * N);
+    if (!d_trace) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB)", w.arena.capacity() >> 20);
+    Challenger ch[MAX_BATCH];
+    SynthTraceArgs sa[MAX_BATCH];
+    const uint64_t* d_tv[MAX_BATCH];
+    const Committed* consts[MAX_BATCH];
+    for (uint32_t b = 0; b < B; b++) {
+      const Circuit& c = *circ[first + b];
+      uint64_t pi_hash[4];
+      hash_no_pad_host(pi[first + b].data(), pi[first + b].size(), pi_hash);
+      ch[b].observe(c.digest, 4);
+      ch[b].observe(pi_hash, 4);
+      d_tv[b] = d_trace + (size_t)b * rc.n_cols * N;
+      sa[b] = SynthTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0]};
+      consts[b] = &c.consts;
+    }
+    int r = launch_synth_trace(sa, B, rc.log_n, rc.n_cols, rc.n_const, rc.deg_pow, w.stream);
+    if (r) return r;
+    Committed trace[MAX_BATCH];
+    if ((r = commit_batch(w, d_trace, rc.n_cols, B, rc.log_n, rc.rate_bits, rc.cap_height, false, trace))) return r;
+    Ctl ctl[MAX_BATCH];
+    for (uint32_t b = 0; b < B; b++) {
+      ch[b].observe(trace[b].cap.data(), trace[b].cap.size());
+      for (int i = 0; i < 4; i++) ctl[b].v[i] = ch[b].challenge();
+    }
+    r = stark_prove_batch(w, rc, B, consts, trace, d_tv, ctl, ch, proofs + first);
+    w.arena.release(mark);
+    if (r) return r;
+  }
+  return BP_OK;
+}
 int rec_prove(Worker& w, const StarkCfg& rc, const Circuit& circ, const std::vector<uint64_t>& pi,
               std::vector<uint64_t>& proof) {
-  const size_t mark = w.arena.mark();
-  uint64_t pi_hash[4];
-  hash_no_pad_host(pi.data(), pi.size(), pi_hash);
-  Challenger ch;
-  ch.observe(circ.digest, 4);
-  ch.observe(pi_hash, 4);
-  const uint64_t N = (uint64_t)1 << rc.log_n;
-  uint64_t* d_trace = w.arena.alloc_words((size_t)rc.n_cols * N);
-  if (!d_trace) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB)", w.arena.capacity() >> 20);
-  int r = launch_synth_trace(d_trace, circ.d_const_values, rc.log_n, rc.n_cols, rc.n_const, rc.deg_pow, pi_hash[0],
-                             w.stream);
-  if (r) return r;
-  Committed trace;
-  if ((r = commit(w, d_trace, rc.n_cols, rc.log_n, rc.rate_bits, rc.cap_height, false, &trace))) return r;
-  ch.observe(trace.cap.data(), trace.cap.size());
-  Ctl ctl;
-  for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
-  r = stark_prove(w, rc, &circ.consts, trace, d_trace, ctl, ch, proof);
-  w.arena.release(mark);
-  return r;
+  const Circuit* c = &circ;
+  return rec_prove_batch(w, rc, 1, &c, &pi, &proof);
 }
 int rec_verify(const StarkCfg& rc, const LightCircuit& circ, const Box& b) {
   uint64_t pi_hash[4];
@@ -264,6 +264,8 @@ void root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_numbe
 }  // namespace
 
 extern "C" {
+
+void bp_tune_rec_batch(int n) { g_rec_batch.store(n < 1 ? 1 : (n > (int)MAX_BATCH ? MAX_BATCH : (uint32_t)n)); }
 
 void bp_config_default(bp_config* c) {
   // constants.rs:6-18, positional order of prover_state.rs:85-93
@@ -622,61 +624,25 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
     proof_digest(tcfg[t], proof.data(), digest[t]);
     w.arena.release(mark);
   }
-  BPG_HIP(hipStreamSynchronize(w.stream));
+  if ((r = w.wait())) return r;
   w.arena.release(lease.mark);  // traces are dead; the chains below only need digests
-  // per-table recursion-shaped chains (wrap + shrinks).  The seven chains do not depend on each other:
-  // each one goes to a worker that is idle RIGHT NOW (end of a shard, small blocks, a lone txn), the rest
-  // run here.  Under full load no worker is idle and this is the plain sequential loop.
-  auto run_chain = [&](Worker& cw, int t) -> int {
-    const Circuit& circ = s->table_circuits[s->table_offset[t] + (tcfg[t].log_n - cfg.table_log_lo[t])];
-    std::vector<uint64_t> chain_proof;
-    for (uint32_t depth = 0; depth < cfg.shrink_depth; depth++) {
-      if (cw.aborted()) return fail(BP_ERR_ABORTED, "aborted in recursion chain of table %s", TABLE_NAMES[t]);
-      std::vector<uint64_t> pi = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (uint64_t)t, depth};
-      int rc = rec_prove(cw, s->rec_cfg, circ, pi, chain_proof);
-      if (rc) return rc;
-      proof_digest(s->rec_cfg, chain_proof.data(), digest[t]);
-    }
-    return BP_OK;
-  };
+  // per-table recursion-shaped chains (wrap + shrinks).  The seven chains do not depend on each other and their
+  // proofs have one shape: level k of all seven is ONE batch proved in lock-step (rec_prove_batch) -- seven
+  // transcripts stepped together, every kernel launch and host wait shared --, then level k + 1.  (Until round 4 each
+  // chain was its own sequence of 6..16-column launches: 88 of a transaction's 118 LDE launches and most of its
+  // 1,620 kernel launches.)
   {
-    struct Helper { std::unique_ptr<TryLease> lease; std::thread th; int rc = BP_OK; std::string err; };
-    Helper helpers[BP_NUM_TABLES];
-    bool mine[BP_NUM_TABLES];
-    for (int t = 0; t < BP_NUM_TABLES; t++) {
-      mine[t] = true;
-      if (t == 0 || cfg.shrink_depth == 0) continue;  // this thread always has work of its own
-      std::unique_ptr<TryLease> l(new TryLease(s));
-      if (!l->w) continue;
-      mine[t] = false;
-      Helper& h = helpers[t];
-      h.lease = std::move(l);
-      h.lease->w->abort_flag = abort_flag;
-      h.lease->w->abort_flag_u8 = abort_flag_u8;
-      try {
-        h.th = std::thread([&, t] {
-          Helper& hh = helpers[t];
-          (void)hipSetDevice(cfg.device);
-          hh.rc = run_chain(*hh.lease->w, t);
-          if (hh.rc) hh.err = bp_last_error();
-        });
-      } catch (...) {  // no thread to be had: the chain runs here like the others (nothing may throw across the ABI)
-        h.lease.reset();
-        mine[t] = true;
-      }
-    }
-    int first_rc = BP_OK;
-    std::string first_err;
+    const Circuit* circ[BP_NUM_TABLES];
     for (int t = 0; t < BP_NUM_TABLES; t++)
-      if (mine[t] && first_rc == BP_OK && (first_rc = run_chain(w, t))) first_err = bp_last_error();
-    for (int t = 0; t < BP_NUM_TABLES; t++) {
-      Helper& h = helpers[t];
-      if (!h.th.joinable()) continue;
-      h.th.join();
-      h.lease.reset();
-      if (h.rc && first_rc == BP_OK) { first_rc = h.rc; first_err = h.err; }
+      circ[t] = &s->table_circuits[s->table_offset[t] + (tcfg[t].log_n - cfg.table_log_lo[t])];
+    std::vector<uint64_t> pis[BP_NUM_TABLES], chain_proof[BP_NUM_TABLES];
+    for (uint32_t depth = 0; depth < cfg.shrink_depth; depth++) {
+      if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted in the recursion chains (level %u)", depth);
+      for (int t = 0; t < BP_NUM_TABLES; t++)
+        pis[t] = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (uint64_t)t, depth};
+      if ((r = rec_prove_batch(w, s->rec_cfg, BP_NUM_TABLES, circ, pis, chain_proof))) return r;
+      for (int t = 0; t < BP_NUM_TABLES; t++) proof_digest(s->rec_cfg, chain_proof[t].data(), digest[t]);
     }
-    if (first_rc) return fail(first_rc, "%s", first_err.c_str());
   }
   // root proof
   std::vector<uint64_t> pi;

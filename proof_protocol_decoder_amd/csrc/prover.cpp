@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include "prover.hpp"
 #include <algorithm>
+#include <chrono>
+#include <memory>
+#include <thread>
 
 namespace bpg {
 
@@ -121,6 +124,12 @@ void proof_digest(const StarkCfg& c, const uint64_t* proof, uint64_t out[4]) {
   hash_no_pad_host(buf.data(), buf.size(), out);
 }
 
+#define TRY(expr)        \
+  do {                   \
+    int _rc = (expr);    \
+    if (_rc) return _rc; \
+  } while (0)
+
 // ------------------------------------------------------------------ arena / worker
 int DeviceArena::init(size_t bytes) {
   destroy();
@@ -156,7 +165,7 @@ int Worker::init(int dev, size_t arena_bytes) {
   pinned_words = (size_t)1 << 22;  // 32 MiB staging
   BPG_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), pinned_words * 8, hipHostMallocDefault));
   BPG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&pinned_dev), pinned, 0));
-  BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_pow_result), 8));
+  BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_pow_result), 8 * MAX_BATCH));
   // many prover threads share few host cores: wait on a blocking event (the thread sleeps) rather
   // than spin in hipStreamSynchronize
   BPG_HIP(hipEventCreateWithFlags(&sync_event, hipEventBlockingSync | hipEventDisableTiming));
@@ -174,17 +183,41 @@ void Worker::destroy() {
   d_pow_result = nullptr;
   stream = nullptr;
 }
+// Host waits.  Where the device has interrupt-driven waits (bp_host_wait_mode 1) the runtime's wait sleeps.  On a
+// device the process had already used the library must not switch that mode (capi.cpp), and the runtime's wait spins
+// at 100 % of a core -- twenty prover threads doing that starve the ones that have work (round 2: 18 instead of 25
+// txn-proofs/s).  There the wait is the library's own: poll the event, and once the wait is older than a few
+// microseconds sleep between polls, an eighth of the time waited so far (at most 200 us): the latency added to a
+// stage is bounded by 1/8 of the stage, the CPU time of a waiting thread by the poll rate.
+static std::atomic<int> g_host_wait{0};  // 0: by the device's mode; 1: always the runtime's wait; 2: always poll + sleep
+void tune_host_wait(int mode) { g_host_wait.store(mode < 0 || mode > 2 ? 0 : mode); }
+extern "C" int bp_host_wait_mode(int device);
+int Worker::wait_recorded() {
+  const int knob = g_host_wait.load(std::memory_order_relaxed);
+  if (knob == 1 || (knob == 0 && bp_host_wait_mode(device) == 1)) {
+    BPG_HIP(hipEventSynchronize(sync_event));
+    return BP_OK;
+  }
+  using clock = std::chrono::steady_clock;
+  const clock::time_point t0 = clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(sync_event);
+    if (e == hipSuccess) return BP_OK;
+    if (e != hipErrorNotReady) return fail(BP_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(e));
+    const int64_t waited_us = std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count();
+    if (waited_us < 8) continue;  // the shortest stages (a copy, a tiny launch) finish in one or two polls
+    std::this_thread::sleep_for(std::chrono::microseconds(std::min<int64_t>(200, std::max<int64_t>(5, waited_us / 8))));
+  }
+}
 int Worker::wait() {
   BPG_HIP(hipEventRecord(sync_event, stream));
-  BPG_HIP(hipEventSynchronize(sync_event));
-  return BP_OK;
+  return wait_recorded();
 }
 int Worker::d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words) {
   for (size_t off = 0; off < words; off += pinned_words) {
     size_t k = std::min(pinned_words, words - off);
     BPG_HIP(hipMemcpyAsync(pinned, dev_src + off, k * 8, hipMemcpyDeviceToHost, stream));
-    BPG_HIP(hipEventRecord(sync_event, stream));
-    BPG_HIP(hipEventSynchronize(sync_event));
+    TRY(wait());
     std::memcpy(host_dst + off, pinned, k * 8);
   }
   return BP_OK;
@@ -195,45 +228,62 @@ int Worker::d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words) {
   if (!var)                                                                                             \
     return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) allocating %zu words for " #var,     \
                 w.arena.capacity() >> 20, (size_t)(words))
-#define TRY(expr)        \
-  do {                   \
-    int _rc = (expr);    \
-    if (_rc) return _rc; \
-  } while (0)
 
 extern "C" int bp_lde_batch(const uint64_t*, uint64_t, uint64_t*, uint64_t, uint64_t*, uint64_t, uint32_t, uint32_t,
                             uint32_t, int, void*);
 extern "C" uint64_t bp_merkle_digest_words(uint32_t, uint32_t);
 
-int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
-           uint32_t cap_height, bool from_coeffs, Committed* out) {
+// `batch` commitments of one shape in lock-step: d_in holds the matrices one behind the other ([batch][n_cols][n],
+// column stride n), the outputs are laid out the same way, and every launch -- inverse NTT, coset LDE, leaf hashing,
+// Merkle levels -- covers all of them (the NTTs simply see batch * n_cols columns; the hash kernels take the tree
+// index from grid.z).  out[b] are views into the shared buffers.  One host wait for all caps.
+int commit_batch(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t batch, uint32_t log_n, uint32_t rate_bits,
+                 uint32_t cap_height, bool from_coeffs, Committed* out) {
+  if (batch == 0 || batch > MAX_BATCH) return fail(BP_ERR_INVALID_INPUT, "commit: batch of %u", batch);
   const uint64_t n = (uint64_t)1 << log_n, m = n << rate_bits;
-  out->log_n = log_n; out->n_cols = n_cols; out->rate_bits = rate_bits; out->cap_height = cap_height;
-  ARENA_ALLOC(lde, (size_t)n_cols * m);
+  const size_t all_cols = (size_t)n_cols * batch;
+  ARENA_ALLOC(lde, all_cols * m);
   const size_t dw = bp_merkle_digest_words(log_n + rate_bits, cap_height);
-  ARENA_ALLOC(digests, dw);
+  ARENA_ALLOC(digests, dw * batch);
   uint64_t* coeffs = const_cast<uint64_t*>(d_in);
   if (!from_coeffs) {
-    ARENA_ALLOC(c, (size_t)n_cols * n);
+    ARENA_ALLOC(c, all_cols * n);
     coeffs = c;
   }
-  TRY(bp_lde_batch(d_in, n, from_coeffs ? nullptr : coeffs, n, lde, m, log_n, rate_bits, n_cols, from_coeffs,
+  TRY(bp_lde_batch(d_in, n, from_coeffs ? nullptr : coeffs, n, lde, m, log_n, rate_bits, (uint32_t)all_cols, from_coeffs,
                    w.stream));
   // the kernel that makes the cap level writes it into the pinned mailbox as well: no copy launch
-  bool mirrored = false;
-  TRY(merkle_commit_cols(lde, m, n_cols, log_n, rate_bits, cap_height, digests, w.stream, w.pinned_dev, &mirrored));
-  out->coeffs = coeffs; out->lde = lde; out->digests = digests;
   const size_t cw = (size_t)4 << cap_height;
-  out->cap.resize(cw);
-  if (!mirrored) return w.d2h(out->cap.data(), digests + dw - cw, cw);
-  TRY(w.wait());
-  std::memcpy(out->cap.data(), w.pinned, cw * 8);
+  if (cw * batch > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "caps do not fit the mailbox");
+  bool mirrored = false;
+  TRY(merkle_commit_cols(lde, m, n_cols, log_n, rate_bits, cap_height, digests, w.stream, w.pinned_dev, &mirrored, batch,
+                         (uint64_t)n_cols * m, dw));
+  if (mirrored) {
+    TRY(w.wait());
+  } else {  // the cap is the leaf level: no kernel above it that could have mirrored it
+    for (uint32_t b = 0; b < batch; b++)
+      BPG_HIP(hipMemcpyAsync(w.pinned + b * cw, digests + (b + 1) * dw - cw, cw * 8, hipMemcpyDeviceToHost, w.stream));
+    TRY(w.wait());
+  }
+  for (uint32_t b = 0; b < batch; b++) {
+    Committed& o = out[b];
+    o.log_n = log_n; o.n_cols = n_cols; o.rate_bits = rate_bits; o.cap_height = cap_height;
+    o.coeffs = coeffs + (size_t)b * n_cols * n;
+    o.lde = lde + (size_t)b * n_cols * m;
+    o.digests = digests + (size_t)b * dw;
+    o.cap.assign(w.pinned + b * cw, w.pinned + (b + 1) * cw);
+  }
   return BP_OK;
+}
+int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
+           uint32_t cap_height, bool from_coeffs, Committed* out) {
+  return commit_batch(w, d_in, n_cols, 1, log_n, rate_bits, cap_height, from_coeffs, out);
 }
 
 // Everything of the quotient launch that follows from the table shape and the challenges (the caller
 // sets the three LDE pointers and the two output buffers).  Used by stark_prove and bp_quotient_eval.
-int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out) {
+int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out, QuotCoset* coset,
+                  int loaded, uint32_t batch) {
   QuotArgs& qa = *out;
   const uint32_t log_n = cfg.log_n, r = cfg.rate_bits, R = 1u << r, C = cfg.n_cols, K = cfg.n_const, A = C / 8;
   const uint64_t N = (uint64_t)1 << log_n, M = N << r;
@@ -255,20 +305,22 @@ int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t
   // critical path and no partial sums -- for the synthetic AIR, whose row costs little.  The AIRs of the real tables
   // cost 10^4 .. 10^5 instructions per row: one pass over a SHORT table is then milliseconds of a few workgroups on the
   // critical path (Keccak sponge, 2^9 rows: 2.6 ms against 0.11 ms spread, profiles/r3_k5_air_probe.txt), so their
-  // units are spread until the launch has 256 workgroups.
-  const uint32_t n_units = qa.n_air_units + qa.n_ctl_units, wg_x = (uint32_t)((M + 255) / 256);
+  // units are spread until the launch has 256 workgroups.  The proofs of a batch (grid.z) count as rows of the launch.
+  const uint32_t n_units = qa.n_air_units + qa.n_ctl_units, wg_x = (uint32_t)((M + 255) / 256) * std::max<uint32_t>(1, batch);
   const uint32_t loaded_rows = (cfg.air_id == air::SYNTHETIC && !g_k5_spread_all.load(std::memory_order_relaxed))
                                    ? 1 : std::min<uint32_t>(n_units, std::max<uint32_t>(1, (256 + wg_x - 1) / wg_x));
-  const uint32_t want_rows = device_loaded() ? loaded_rows : std::min<uint32_t>(n_units, std::max<uint32_t>(1, (2048 + wg_x - 1) / wg_x));
+  const bool is_loaded = loaded < 0 ? device_loaded() : loaded != 0;
+  const uint32_t want_rows = is_loaded ? loaded_rows : std::min<uint32_t>(n_units, std::max<uint32_t>(1, (2048 + wg_x - 1) / wg_x));
   qa.units_per_wg = (n_units + want_rows - 1) / want_rows;
   qa.alpha0 = alpha0; qa.alpha1 = alpha1;
   qa.g = wN; qa.g_inv = gl::inv(wN); qa.n_inv = gl::inv(N);
   // per-coset constants: g_t = 7 * w_M^t, Z_H(g_t x) = g_t^n - 1 (constant on a coset)
-  for (uint32_t t = 0; t < R; t++) {
-    qa.g_t[t] = gl::mulc(gl::GENERATOR, gl::pow(wM, t));
-    qa.zh_t[t] = gl::subc(gl::pow(qa.g_t[t], N), 1);
-    qa.zh_inv_t[t] = gl::inv(qa.zh_t[t]);
-  }
+  if (coset)
+    for (uint32_t t = 0; t < R; t++) {
+      coset->g_t[t] = gl::mulc(gl::GENERATOR, gl::pow(wM, t));
+      coset->zh_t[t] = gl::subc(gl::pow(coset->g_t[t], N), 1);
+      coset->zh_inv_t[t] = gl::inv(coset->zh_t[t]);
+    }
   qa.ctl = ctl;
   return BP_OK;
 }
@@ -292,212 +344,278 @@ int fri_layer_args(uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uin
   return BP_OK;
 }
 
-// ------------------------------------------------------------------ one table
+// ------------------------------------------------------------------ one table, or a batch of equally shaped ones
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
                 const uint64_t* d_tv, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof) {
+  return stark_prove_batch(w, cfg, 1, &consts, &trace, &d_tv, &ctl, &ch, &proof);
+}
+
+int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committed* const* consts,
+                      const Committed* trace, const uint64_t* const* d_tv, const Ctl* ctl, Challenger* ch,
+                      std::vector<uint64_t>* proofs) {
   TRY(check_cfg(cfg));
+  if (B == 0 || B > MAX_BATCH || (size_t)B * cfg.num_queries > MAX_BATCH_QUERIES)
+    return fail(BP_ERR_INVALID_INPUT, "stark_prove_batch: %u proofs x %u queries (at most %u proofs, %u queries in all)", B,
+                cfg.num_queries, MAX_BATCH, MAX_BATCH_QUERIES);
   const ProofLayout L = proof_layout(cfg);
   const uint32_t log_n = cfg.log_n, r = cfg.rate_bits, h = cfg.cap_height, R = 1u << r;
   const uint64_t N = (uint64_t)1 << log_n, M = N << r;
   const uint32_t C = cfg.n_cols, K = cfg.n_const, A = L.n_aux, Q = L.n_quot;
-  if (K && !consts) return fail(BP_ERR_INVALID_INPUT, "constants commitment missing");
   hipStream_t st = w.stream;
-  proof.assign(L.total, 0);
-  uint64_t* P = proof.data();
-  P[0] = PROOF_MAGIC; P[1] = log_n; P[2] = C; P[3] = K; P[4] = A; P[5] = Q; P[6] = r; P[7] = h;
-  P[8] = cfg.num_queries; P[9] = L.n_layers; P[10] = L.final_len; P[11] = cfg.deg_pow; P[12] = cfg.pow_bits;
-  P[13] = cfg.arity_bits; P[14] = cfg.air_id;
-  std::memcpy(P + L.trace_cap, trace.cap.data(), L.cap_words * 8);
+  uint64_t* P[MAX_BATCH];
+  for (uint32_t b = 0; b < B; b++) {
+    if (K && !(consts && consts[b])) return fail(BP_ERR_INVALID_INPUT, "constants commitment missing");
+    proofs[b].assign(L.total, 0);
+    uint64_t* p = P[b] = proofs[b].data();
+    p[0] = PROOF_MAGIC; p[1] = log_n; p[2] = C; p[3] = K; p[4] = A; p[5] = Q; p[6] = r; p[7] = h;
+    p[8] = cfg.num_queries; p[9] = L.n_layers; p[10] = L.final_len; p[11] = cfg.deg_pow; p[12] = cfg.pow_bits;
+    p[13] = cfg.arity_bits; p[14] = cfg.air_id;
+    std::memcpy(p + L.trace_cap, trace[b].cap.data(), L.cap_words * 8);
+  }
   if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before auxiliary commitment");
 
   // per-coset constants: g_t = 7 * w_M^t, Z_H(g_t x) = g_t^n - 1 (constant on a coset)
-  const uint64_t wM = gl::root(log_n + r), wN = gl::root(log_n);
-  uint64_t g_t[16], zh_t[16], zh_inv_t[16];
-  for (uint32_t t = 0; t < R; t++) {
-    g_t[t] = gl::mulc(gl::GENERATOR, gl::pow(wM, t));
-    zh_t[t] = gl::subc(gl::pow(g_t[t], N), 1);
-    zh_inv_t[t] = gl::inv(zh_t[t]);
-  }
+  const uint64_t wN = gl::root(log_n);
   const uint64_t *tw_n = nullptr, *coset_scale = nullptr, *coset_scale_inv = nullptr;
   TRY(get_table(0, log_n, 0, &tw_n));
   TRY(get_table(2, log_n, r, &coset_scale));
   TRY(get_table(3, log_n, r, &coset_scale_inv));
 
   // 1. auxiliary columns (suffix products) and their commitment
-  ARENA_ALLOC(d_auxv, (size_t)A * N);
-  TRY(launch_aux(d_tv, d_auxv, log_n, A, ctl, st));
-  Committed aux;
-  TRY(commit(w, d_auxv, A, log_n, r, h, false, &aux));
-  std::memcpy(P + L.aux_cap, aux.cap.data(), L.cap_words * 8);
-  ch.observe(aux.cap.data(), L.cap_words);
-
-  // 2. alphas
-  const uint64_t alpha0 = ch.challenge(), alpha1 = ch.challenge();
-
-  // 3. quotient on the LDE coset -> per-coset iNTT -> chunk coefficients -> commitment
-  QuotArgs qa{};
-  qa.trace_lde = trace.lde; qa.aux_lde = aux.lde; qa.const_lde = K ? consts->lde : nullptr;
-  TRY(quotient_args(cfg, ctl, alpha0, alpha1, &qa));
-  const size_t mark_q = w.arena.mark();
-  ARENA_ALLOC(d_qc, (size_t)Q * N);  // chunk coefficients: live until the end (quotient oracle)
-  const size_t mark_tmp = w.arena.mark();
-  ARENA_ALLOC(d_cpow, 2 * (size_t)qa.n_constraints + 48);
-  ARENA_ALLOC(d_partial, quotient_partial_words(qa) + 1);
-  ARENA_ALLOC(d_qvals, 2 * M);
-  qa.apow = d_cpow; qa.partial = d_partial; qa.qvals = d_qvals;
-  TRY(launch_quotient(qa, st));
-  TRY(intt_nat2br(d_qvals, N, d_qvals, N, log_n, 2 * R, true, st));  // 2 challenges x 2^r cosets, in place
-  ChunkArgs ca{};
-  ca.e = d_qvals; ca.inv_scale = coset_scale_inv; ca.out = d_qc; ca.out_stride = N; ca.log_n = log_n; ca.rate_bits = r;
+  ARENA_ALLOC(d_auxv, (size_t)B * A * N);
   {
-    const uint64_t wr_inv = gl::inv(gl::root(r)), sn_inv = gl::inv(gl::pow(gl::GENERATOR, N)), r_inv = gl::inv(R);
-    for (uint32_t k = 0; k < R; k++) {
-      ca.wr_inv_pow[k] = gl::pow(wr_inv, k);
-      ca.chunk_scale[k] = gl::mulc(gl::pow(sn_inv, k), r_inv);
-    }
+    AuxArgs aa[MAX_BATCH];
+    for (uint32_t b = 0; b < B; b++) aa[b] = AuxArgs{d_tv[b], d_auxv + (size_t)b * A * N, ctl[b]};
+    TRY(launch_aux(aa, B, log_n, A, st));
   }
-  TRY(launch_quotient_chunks(ca, st));
-  (void)mark_q;
+  Committed aux[MAX_BATCH];
+  TRY(commit_batch(w, d_auxv, A, B, log_n, r, h, false, aux));
+  for (uint32_t b = 0; b < B; b++) {
+    std::memcpy(P[b] + L.aux_cap, aux[b].cap.data(), L.cap_words * 8);
+    ch[b].observe(aux[b].cap.data(), L.cap_words);
+  }
+
+  // 2. alphas;  3. quotient on the LDE coset -> per-coset iNTT -> chunk coefficients -> commitment
+  QuotArgs qa[MAX_BATCH] = {};
+  QuotCoset coset{};
+  const int loaded = device_loaded();  // one answer for the whole batch: the proofs share one grid
+  for (uint32_t b = 0; b < B; b++) {
+    const uint64_t alpha0 = ch[b].challenge(), alpha1 = ch[b].challenge();
+    qa[b].trace_lde = trace[b].lde; qa[b].aux_lde = aux[b].lde; qa[b].const_lde = K ? consts[b]->lde : nullptr;
+    TRY(quotient_args(cfg, ctl[b], alpha0, alpha1, &qa[b], &coset, loaded, B));
+  }
+  ARENA_ALLOC(d_qc, (size_t)B * Q * N);  // chunk coefficients: live until the end (quotient oracle)
+  const size_t mark_tmp = w.arena.mark();
+  {
+    const size_t cpow_words = 2 * (size_t)qa[0].n_constraints + 48, part_words = quotient_partial_words(qa[0]) + 1;
+    ARENA_ALLOC(d_cpow, B * cpow_words);
+    ARENA_ALLOC(d_partial, B * part_words);
+    ARENA_ALLOC(d_qvals, (size_t)B * 2 * M);
+    for (uint32_t b = 0; b < B; b++) {
+      qa[b].apow = d_cpow + b * cpow_words; qa[b].partial = d_partial + b * part_words; qa[b].qvals = d_qvals + (size_t)b * 2 * M;
+    }
+    TRY(launch_quotient(qa, B, coset, st));
+    TRY(intt_nat2br(d_qvals, N, d_qvals, N, log_n, B * 2 * R, true, st));  // 2 challenges x 2^r cosets per proof, in place
+    ChunkArgs ca[MAX_BATCH] = {};
+    const uint64_t wr_inv = gl::inv(gl::root(r)), sn_inv = gl::inv(gl::pow(gl::GENERATOR, N)), r_inv = gl::inv(R);
+    for (uint32_t b = 0; b < B; b++) {
+      ChunkArgs& c = ca[b];
+      c.e = d_qvals + (size_t)b * 2 * M; c.inv_scale = coset_scale_inv; c.out = d_qc + (size_t)b * Q * N; c.out_stride = N;
+      c.log_n = log_n; c.rate_bits = r;
+      for (uint32_t k = 0; k < R; k++) {
+        c.wr_inv_pow[k] = gl::pow(wr_inv, k);
+        c.chunk_scale[k] = gl::mulc(gl::pow(sn_inv, k), r_inv);
+      }
+    }
+    TRY(launch_quotient_chunks(ca, B, st));
+  }
   // the temporaries are dead once the chunk kernel has run; stream order makes reuse safe
   w.arena.release(mark_tmp);
-  Committed quot;
-  TRY(commit(w, d_qc, Q, log_n, r, h, true, &quot));
-  std::memcpy(P + L.quot_cap, quot.cap.data(), L.cap_words * 8);
-  ch.observe(quot.cap.data(), L.cap_words);
+  Committed quot[MAX_BATCH];
+  TRY(commit_batch(w, d_qc, Q, B, log_n, r, h, true, quot));
+  for (uint32_t b = 0; b < B; b++) {
+    std::memcpy(P[b] + L.quot_cap, quot[b].cap.data(), L.cap_words * 8);
+    ch[b].observe(quot[b].cap.data(), L.cap_words);
+  }
   if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted after quotient commitment");
 
   // 4. zeta
-  const gl::Ext zeta = ch.challenge_ext();
-  if (gl::eq(gl::pow(zeta, N), gl::ext(1))) return fail(BP_ERR_INVALID_INPUT, "Opening point is in the subgroup.");
-  const gl::Ext zeta_next = gl::scale(zeta, wN);
+  gl::Ext zeta[MAX_BATCH], zeta_next[MAX_BATCH];
+  for (uint32_t b = 0; b < B; b++) {
+    zeta[b] = ch[b].challenge_ext();
+    if (gl::eq(gl::pow(zeta[b], N), gl::ext(1))) return fail(BP_ERR_INVALID_INPUT, "Opening point is in the subgroup.");
+    zeta_next[b] = gl::scale(zeta[b], wN);
+  }
 
   // 5. openings: dot products of bit-reversed coefficient columns with zeta^bitrev(pos)
-  ARENA_ALLOC(d_pw, 6 * N);  // zeta, g zeta and 1 in one launch
-  const uint64_t* d_pw1 = d_pw + 4 * N;
-  TRY(launch_power_vectors(d_pw, log_n, zeta, zeta_next, 3, st, gl::ext(1)));
-  const size_t open_cols = (size_t)K + C + A + Q + A;
-  if (open_cols * 4 > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "too many columns for the opening mailbox");
-  uint64_t* d_open = w.pinned_dev;  // kernels write the openings straight into host-visible memory
+  ARENA_ALLOC(d_pw, (size_t)B * 6 * N);  // zeta, g zeta and 1 of every proof in one launch
   {
-    // one launch for the five opening sets (they used to be five launches in a row on the critical path)
-    OpenMulti om{};
-    om.stride = N; om.log_n = log_n;
-    uint64_t* d_o = d_open;
-    auto seg = [&](const uint64_t* coeffs, uint32_t n_cols, const uint64_t* pw, uint32_t n_points) {
-      if (n_cols) {
-        const uint32_t k = om.n_segs++;
-        om.coeffs[k] = coeffs; om.pw[k] = pw; om.out[k] = d_o; om.n_points[k] = n_points;
-        om.first_col[k + 1] = om.first_col[k] + n_cols;
-      }
-      d_o += (size_t)n_cols * 4;
-    };
-    seg(K ? consts->coeffs : nullptr, K, d_pw, 1);
-    seg(trace.coeffs, C, d_pw, 2);
-    seg(aux.coeffs, A, d_pw, 2);
-    seg(quot.coeffs, Q, d_pw, 1);
-    seg(aux.coeffs, A, d_pw1, 1);
-    TRY(launch_openings_multi(om, st));
+    PowerVecArgs pv[MAX_BATCH];
+    for (uint32_t b = 0; b < B; b++) pv[b] = PowerVecArgs{d_pw + (size_t)b * 6 * N, {zeta[b], zeta_next[b], gl::ext(1)}};
+    TRY(launch_power_vectors(pv, B, log_n, 3, st));
+  }
+  const size_t open_cols = (size_t)K + C + A + Q + A;
+  if (open_cols * 4 * B > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "too many columns for the opening mailbox");
+  {
+    // one launch for the five opening sets of every proof (they used to be five launches in a row on the critical
+    // path); the kernels write the openings straight into host-visible memory
+    OpenMulti om[MAX_BATCH] = {};
+    for (uint32_t b = 0; b < B; b++) {
+      OpenMulti& o = om[b];
+      o.stride = N; o.log_n = log_n;
+      const uint64_t *pw = d_pw + (size_t)b * 6 * N, *pw1 = pw + 4 * N;
+      uint64_t* d_o = w.pinned_dev + (size_t)b * open_cols * 4;
+      auto seg = [&](const uint64_t* coeffs, uint32_t n_cols, const uint64_t* pwv, uint32_t n_points) {
+        if (n_cols) {
+          const uint32_t k = o.n_segs++;
+          o.coeffs[k] = coeffs; o.pw[k] = pwv; o.out[k] = d_o; o.n_points[k] = n_points;
+          o.first_col[k + 1] = o.first_col[k] + n_cols;
+        }
+        d_o += (size_t)n_cols * 4;
+      };
+      seg(K ? consts[b]->coeffs : nullptr, K, pw, 1);
+      seg(trace[b].coeffs, C, pw, 2);
+      seg(aux[b].coeffs, A, pw, 2);
+      seg(quot[b].coeffs, Q, pw, 1);
+      seg(aux[b].coeffs, A, pw1, 1);
+    }
+    TRY(launch_openings_multi(om, B, st));
   }
   TRY(w.wait());
-  std::vector<uint64_t> ho(w.pinned, w.pinned + open_cols * 4);
-  {
-    uint64_t* oz = P + L.open_zeta;
+  for (uint32_t b = 0; b < B; b++) {
+    const uint64_t* ho = w.pinned + (size_t)b * open_cols * 4;
+    uint64_t* oz = P[b] + L.open_zeta;
     for (size_t c = 0; c < (size_t)K + C + A + Q; c++) { oz[2 * c] = ho[4 * c]; oz[2 * c + 1] = ho[4 * c + 1]; }
-    uint64_t* on = P + L.open_next;
+    uint64_t* on = P[b] + L.open_next;
     for (size_t c = 0; c < (size_t)C + A; c++) { on[2 * c] = ho[4 * (K + c) + 2]; on[2 * c + 1] = ho[4 * (K + c) + 3]; }
-    uint64_t* of = P + L.open_first;
+    uint64_t* of = P[b] + L.open_first;
     const size_t base = (size_t)K + C + A + Q;
     for (size_t c = 0; c < A; c++) { of[2 * c] = ho[4 * (base + c)]; of[2 * c + 1] = ho[4 * (base + c) + 1]; }
+    ch[b].observe(P[b] + L.open_zeta, 2 * (size_t)L.n_zeta);
+    ch[b].observe(P[b] + L.open_next, 2 * (size_t)L.n_next);
+    ch[b].observe(P[b] + L.open_first, 2 * (size_t)A);
   }
-  ch.observe(P + L.open_zeta, 2 * (size_t)L.n_zeta);
-  ch.observe(P + L.open_next, 2 * (size_t)L.n_next);
-  ch.observe(P + L.open_first, 2 * (size_t)A);
 
   // 6. FRI.  Batches: (zeta: all), (g*zeta: trace, aux), (1: aux);  final = ((q0*a^k1 + q1)*a^k2 + q2)
-  const gl::Ext alpha = ch.challenge_ext();
+  gl::Ext alpha[MAX_BATCH];
+  for (uint32_t b = 0; b < B; b++) alpha[b] = ch[b].challenge_ext();
   const uint32_t k0 = L.n_zeta, k1 = L.n_next, k2 = A;
-  ARENA_ALLOC(d_apow, 2 * (size_t)k0);
-  TRY(launch_alpha_pows(d_apow, k0, alpha, st));
+  ARENA_ALLOC(d_apow, (size_t)B * 2 * k0);
+  {
+    AlphaPowArgs ap[MAX_BATCH];
+    for (uint32_t b = 0; b < B; b++) ap[b] = AlphaPowArgs{d_apow + (size_t)b * 2 * k0, alpha[b]};
+    TRY(launch_alpha_pows(ap, B, k0, st));
+  }
   struct OracleRef { const Committed* c; int32_t e[3]; };
-  OracleRef refs[4];
+  OracleRef refs[MAX_BATCH][4];
   int n_or = 0;
-  if (K) refs[n_or++] = {consts, {0, -1, -1}};
-  refs[n_or++] = {&trace, {(int32_t)K, 0, -1}};
-  refs[n_or++] = {&aux, {(int32_t)(K + C), (int32_t)C, 0}};
-  refs[n_or++] = {&quot, {(int32_t)(K + C + A), -1, -1}};
+  for (uint32_t b = 0; b < B; b++) {
+    n_or = 0;
+    if (K) refs[b][n_or++] = {consts[b], {0, -1, -1}};
+    refs[b][n_or++] = {&trace[b], {(int32_t)K, 0, -1}};
+    refs[b][n_or++] = {&aux[b], {(int32_t)(K + C), (int32_t)C, 0}};
+    refs[b][n_or++] = {&quot[b], {(int32_t)(K + C + A), -1, -1}};
+  }
   const uint32_t cols_per_chunk = 64;
   uint32_t total_chunks = 0;
-  for (int o = 0; o < n_or; o++) total_chunks += (refs[o].c->n_cols + cols_per_chunk - 1) / cols_per_chunk;
-  ARENA_ALLOC(d_cpart, (size_t)total_chunks * 6 * N);
-  uint32_t chunk_base = 0;
-  CombineMulti cm{};
-  for (int o = 0; o < n_or; o++) {  // one launch over the chunks of all oracles
-    CombineArgs& cb = cm.a[cm.n_oracles++];
-    cb.coeffs = refs[o].c->coeffs; cb.stride = N; cb.log_n = log_n; cb.n_cols = refs[o].c->n_cols;
-    cb.cols_per_chunk = cols_per_chunk; cb.chunk_base = chunk_base;
-    for (int b = 0; b < 3; b++) cb.exp_base[b] = refs[o].e[b];
-    cb.alpha_pows = d_apow; cb.partial = d_cpart;
-    chunk_base += (cb.n_cols + cols_per_chunk - 1) / cols_per_chunk;
-  }
-  ARENA_ALLOC(d_g, 6 * N);
-  if (device_loaded()) {  // several provers share the device: one pass, no partial sums, one launch instead of two
-    TRY(launch_combine_all(cm, d_g, st));
-  } else {
-    TRY(launch_combine_partial_multi(cm, total_chunks, st));
-    TRY(launch_combine_reduce(d_cpart, total_chunks, log_n, d_g, st));
-  }
-  ARENA_ALLOC(d_glde, 6 * M);
-  TRY(ntt_br2nat(d_g, N, d_glde, M, N, log_n, 6, R, coset_scale, false, st));
-  FriInitArgs fi{};
-  fi.glde = d_glde; fi.tw_n = tw_n; fi.log_n = log_n; fi.rate_bits = r;
-  std::memcpy(fi.g_t, g_t, sizeof(g_t));
+  for (int o = 0; o < n_or; o++) total_chunks += (refs[0][o].c->n_cols + cols_per_chunk - 1) / cols_per_chunk;
+  ARENA_ALLOC(d_g, (size_t)B * 6 * N);
   {
-    const uint64_t* opens[3] = {P + L.open_zeta, P + L.open_next, P + L.open_first};
-    const uint32_t kk[3] = {k0, k1, k2};
-    for (int b = 0; b < 3; b++) {  // PrecomputedReducedOpenings: sum_j alpha^j opening_j
-      gl::Ext acc = gl::ext(0);
-      for (size_t j = kk[b]; j-- > 0;) acc = gl::add(gl::mul(acc, alpha), gl::Ext{opens[b][2 * j], opens[b][2 * j + 1]});
-      fi.y[b] = acc;
+    const bool one_pass = loaded != 0;  // several provers share the device: one pass, no partial sums, one launch instead of two
+    uint64_t* d_cpart = nullptr;
+    if (!one_pass) {
+      ARENA_ALLOC(cp, (size_t)B * total_chunks * 6 * N);
+      d_cpart = cp;
     }
-    fi.z[0] = zeta; fi.z[1] = zeta_next; fi.z[2] = gl::ext(1);
-    fi.alpha_shift[0] = gl::pow(alpha, (uint64_t)k1 + k2);
-    fi.alpha_shift[1] = gl::pow(alpha, k2);
-    fi.alpha_shift[2] = gl::ext(1);
+    CombineMulti cm[MAX_BATCH] = {};
+    uint64_t* gp[MAX_BATCH];
+    CombineReduceArgs cr[MAX_BATCH];
+    for (uint32_t b = 0; b < B; b++) {
+      uint32_t chunk_base = 0;
+      uint64_t* part = d_cpart ? d_cpart + (size_t)b * total_chunks * 6 * N : nullptr;
+      for (int o = 0; o < n_or; o++) {  // one launch over the chunks of all oracles
+        CombineArgs& cb = cm[b].a[cm[b].n_oracles++];
+        cb.coeffs = refs[b][o].c->coeffs; cb.stride = N; cb.log_n = log_n; cb.n_cols = refs[b][o].c->n_cols;
+        cb.cols_per_chunk = cols_per_chunk; cb.chunk_base = chunk_base;
+        for (int k = 0; k < 3; k++) cb.exp_base[k] = refs[b][o].e[k];
+        cb.alpha_pows = d_apow + (size_t)b * 2 * k0; cb.partial = part;
+        chunk_base += (cb.n_cols + cols_per_chunk - 1) / cols_per_chunk;
+      }
+      gp[b] = d_g + (size_t)b * 6 * N;
+      cr[b] = CombineReduceArgs{part, gp[b]};
+    }
+    if (one_pass) {
+      TRY(launch_combine_all(cm, B, gp, st));
+    } else {
+      TRY(launch_combine_partial_multi(cm, B, total_chunks, st));
+      TRY(launch_combine_reduce(cr, B, total_chunks, log_n, st));
+    }
   }
-  ARENA_ALLOC(d_v0, 2 * M);
-  fi.out = d_v0;
-  TRY(launch_fri_init(fi, st));
+  ARENA_ALLOC(d_glde, (size_t)B * 6 * M);
+  TRY(ntt_br2nat(d_g, N, d_glde, M, N, log_n, 6 * B, R, coset_scale, false, st));
+  ARENA_ALLOC(d_v0, (size_t)B * 2 * M);
+  {
+    FriInitArgs fi[MAX_BATCH] = {};
+    for (uint32_t b = 0; b < B; b++) {
+      FriInitArgs& f = fi[b];
+      f.glde = d_glde + (size_t)b * 6 * M; f.tw_n = tw_n; f.log_n = log_n; f.rate_bits = r;
+      std::memcpy(f.g_t, coset.g_t, sizeof(f.g_t));
+      const uint64_t* opens[3] = {P[b] + L.open_zeta, P[b] + L.open_next, P[b] + L.open_first};
+      const uint32_t kk[3] = {k0, k1, k2};
+      for (int k = 0; k < 3; k++) {  // PrecomputedReducedOpenings: sum_j alpha^j opening_j
+        gl::Ext acc = gl::ext(0);
+        for (size_t j = kk[k]; j-- > 0;) acc = gl::add(gl::mul(acc, alpha[b]), gl::Ext{opens[k][2 * j], opens[k][2 * j + 1]});
+        f.y[k] = acc;
+      }
+      f.z[0] = zeta[b]; f.z[1] = zeta_next[b]; f.z[2] = gl::ext(1);
+      f.alpha_shift[0] = gl::pow(alpha[b], (uint64_t)k1 + k2);
+      f.alpha_shift[1] = gl::pow(alpha[b], k2);
+      f.alpha_shift[2] = gl::ext(1);
+      f.out = d_v0 + (size_t)b * 2 * M;
+    }
+    TRY(launch_fri_init(fi, B, st));
+  }
 
   // commit phase (fri_committed_trees), folding in the evaluation domain
   const uint32_t ab = cfg.arity_bits, arity = 1u << ab;
+  // per layer: the values and digests of proof b sit b * (stride) words behind those of proof 0
   const uint64_t *layer_values[9], *layer_digests[9];
+  size_t layer_vstride[9], layer_dstride[9];
   uint32_t layer_log_nl[9];
   uint64_t* cur = d_v0;
+  size_t cur_stride = 2 * M;
   uint32_t log_nl = log_n;
   uint64_t shift = gl::GENERATOR;
   for (uint32_t l = 0; l < L.n_layers; l++) {
     const uint32_t log_leaves = log_nl - ab + r;
-    const size_t dw = bp_merkle_digest_words(log_leaves, h);
-    ARENA_ALLOC(d_dig, dw);
-    ARENA_ALLOC(d_next, (size_t)2 << log_leaves);
-    FriLayerArgs fa{};
-    TRY(fri_layer_args(log_nl, r, ab, shift, &fa));
-    fa.values = cur; fa.out = d_next; fa.digests = d_dig;
-    TRY(launch_fri_layer_leaves(fa, st));
-    bool mirrored = false;
-    TRY(merkle_upper_levels(d_dig, log_leaves, h, st, w.pinned_dev, &mirrored));
-    uint64_t* cap = P + L.fri_caps + l * L.cap_words;
-    if (mirrored) {
-      TRY(w.wait());
-      std::memcpy(cap, w.pinned, L.cap_words * 8);
-    } else {
-      TRY(w.d2h(cap, d_dig + dw - L.cap_words, L.cap_words));
+    const size_t dw = bp_merkle_digest_words(log_leaves, h), next_words = (size_t)2 << log_leaves;
+    ARENA_ALLOC(d_dig, dw * B);
+    ARENA_ALLOC(d_next, next_words * B);
+    FriLayerArgs fa[MAX_BATCH] = {};
+    TRY(fri_layer_args(log_nl, r, ab, shift, &fa[0]));
+    for (uint32_t b = 0; b < B; b++) {
+      if (b) fa[b] = fa[0];
+      fa[b].values = cur + b * cur_stride; fa[b].out = d_next + b * next_words; fa[b].digests = d_dig + b * dw;
     }
-    ch.observe(cap, L.cap_words);
-    fa.beta = ch.challenge_ext();
-    TRY(launch_fri_fold(fa, st));
-    layer_values[l] = cur; layer_digests[l] = d_dig; layer_log_nl[l] = log_nl;
+    TRY(launch_fri_layer_leaves(fa, B, st));
+    bool mirrored = false;
+    TRY(merkle_upper_levels(d_dig, log_leaves, h, st, w.pinned_dev, &mirrored, B, dw));
+    if (!mirrored)
+      for (uint32_t b = 0; b < B; b++)
+        BPG_HIP(hipMemcpyAsync(w.pinned + b * L.cap_words, d_dig + (b + 1) * dw - L.cap_words, L.cap_words * 8,
+                               hipMemcpyDeviceToHost, st));
+    TRY(w.wait());
+    for (uint32_t b = 0; b < B; b++) {
+      uint64_t* cap = P[b] + L.fri_caps + l * L.cap_words;
+      std::memcpy(cap, w.pinned + b * L.cap_words, L.cap_words * 8);
+      ch[b].observe(cap, L.cap_words);
+      fa[b].beta = ch[b].challenge_ext();
+    }
+    TRY(launch_fri_fold(fa, B, st));
+    layer_values[l] = cur; layer_vstride[l] = cur_stride; layer_digests[l] = d_dig; layer_dstride[l] = dw;
+    layer_log_nl[l] = log_nl;
     cur = d_next;
+    cur_stride = next_words;
     log_nl -= ab;
     shift = gl::pow(shift, arity);
   }
@@ -505,41 +623,49 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
   {
     const uint32_t log_ml = log_nl + r;
     const uint64_t ml = (uint64_t)1 << log_ml, nl = (uint64_t)1 << log_nl;
-    std::vector<uint64_t> hv(2 * ml);
-    TRY(w.d2h(hv.data(), cur, hv.size()));
+    if (2 * ml * B > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "final FRI layer does not fit the mailbox");
+    for (uint32_t b = 0; b < B; b++)
+      BPG_HIP(hipMemcpyAsync(w.pinned + b * 2 * ml, cur + b * cur_stride, 2 * ml * 8, hipMemcpyDeviceToHost, st));
+    TRY(w.wait());
     const uint64_t w_inv = gl::inv(gl::root(log_ml)), s_inv = gl::inv(shift), ml_inv = gl::inv(ml);
     std::vector<uint64_t> wp(ml);  // w^-k
     wp[0] = 1;
     for (uint64_t k = 1; k < ml; k++) wp[k] = gl::mulc(wp[k - 1], w_inv);
-    uint64_t sk = ml_inv;  // s^-k / m
-    for (uint64_t k = 0; k < ml; k++) {
-      uint64_t c0 = 0, c1 = 0;
-      for (uint64_t i = 0; i < ml; i++) {  // natural index i = t + 2^r * m  <->  coset-major t*n_l + m
-        const uint64_t pos = (i & (R - 1)) * nl + (i >> r);
-        const uint64_t tw = wp[(i * k) & (ml - 1)];
-        c0 = gl::addc(c0, gl::mulc(hv[2 * pos], tw));
-        c1 = gl::addc(c1, gl::mulc(hv[2 * pos + 1], tw));
+    for (uint32_t b = 0; b < B; b++) {
+      const uint64_t* hv = w.pinned + b * 2 * ml;
+      uint64_t sk = ml_inv;  // s^-k / m
+      for (uint64_t k = 0; k < ml; k++) {
+        uint64_t c0 = 0, c1 = 0;
+        for (uint64_t i = 0; i < ml; i++) {  // natural index i = t + 2^r * m  <->  coset-major t*n_l + m
+          const uint64_t pos = (i & (R - 1)) * nl + (i >> r);
+          const uint64_t tw = wp[(i * k) & (ml - 1)];
+          c0 = gl::addc(c0, gl::mulc(hv[2 * pos], tw));
+          c1 = gl::addc(c1, gl::mulc(hv[2 * pos + 1], tw));
+        }
+        c0 = gl::mulc(c0, sk);
+        c1 = gl::mulc(c1, sk);
+        sk = gl::mulc(sk, s_inv);
+        if (k < L.final_len) {
+          P[b][L.final_poly + 2 * k] = c0;
+          P[b][L.final_poly + 2 * k + 1] = c1;
+        } else if (c0 || c1) {
+          return fail(BP_ERR_INVALID_INPUT, "FRI final polynomial has a non-zero tail: the witness violates the AIR");
+        }
       }
-      c0 = gl::mulc(c0, sk);
-      c1 = gl::mulc(c1, sk);
-      sk = gl::mulc(sk, s_inv);
-      if (k < L.final_len) {
-        P[L.final_poly + 2 * k] = c0;
-        P[L.final_poly + 2 * k + 1] = c1;
-      } else if (c0 || c1) {
-        return fail(BP_ERR_INVALID_INPUT, "FRI final polynomial has a non-zero tail: the witness violates the AIR");
-      }
+      ch[b].observe(P[b] + L.final_poly, 2 * (size_t)L.final_len);
     }
   }
-  ch.observe(P + L.final_poly, 2 * (size_t)L.final_len);
   if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before proof of work");
 
   // proof of work: smallest witness
   {
-    PowArgs pa{};
-    ch.pow_state(pa.state, &pa.pos);
-    pa.bits = cfg.pow_bits;
-    uint64_t nonce = 0;
+    PowArgs pa[MAX_BATCH] = {};
+    for (uint32_t b = 0; b < B; b++) {
+      ch[b].pow_state(pa[b].state, &pa[b].pos);
+      pa[b].bits = cfg.pow_bits;
+    }
+    unsigned long long res[MAX_BATCH];
+    for (uint32_t b = 0; b < B; b++) res[b] = 0;
     if (cfg.pow_bits) {
       // The smallest witness is geometric with mean 2^pow_bits and every candidate costs a whole permutation, so
       // the batch size decides how many permutations are wasted past the winner: batches of 2^(pow_bits-1) stop
@@ -548,62 +674,76 @@ int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const C
       // extra launches are latency on one of 24 streams.  After 8 misses the batch grows (tiny bit counts, bad luck).
       const uint32_t batch0 = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 12, (uint64_t)1 << (cfg.pow_bits ? cfg.pow_bits - 1 : 0)));
       uint32_t batch = batch0, n_batches = 0;
-      unsigned long long res = ~0ULL;
-      BPG_HIP(hipMemsetAsync(w.d_pow_result, 0xFF, 8, st));
+      BPG_HIP(hipMemsetAsync(w.d_pow_result, 0xFF, 8 * MAX_BATCH, st));
       // Batches are launched four at a time before the host looks: a batch whose predecessors already found a
       // witness leaves at once (pow_grind_mx_kernel), so the speculation costs four tiny launches and saves the
-      // device->host round trip after every batch (2.5 -> 1.2 round trips per proof at 16 bits).
+      // device->host round trip after every batch (2.5 -> 1.2 round trips per proof at 16 bits).  The proofs of a
+      // batch search side by side (grid.z), each for its own witness: a proof that has found its own leaves at once.
       for (uint64_t base = 0;;) {
         for (int k = 0; k < 4; k++) {
           if (++n_batches > 8) batch = std::min<uint32_t>(1u << 20, batch * 2);
-          pa.base = base;
-          TRY(launch_pow(pa, batch, w.d_pow_result, st));
+          for (uint32_t b = 0; b < B; b++) pa[b].base = base;
+          TRY(launch_pow(pa, B, batch, w.d_pow_result, st));
           base += batch;
         }
-        TRY(w.d2h(reinterpret_cast<uint64_t*>(&res), reinterpret_cast<uint64_t*>(w.d_pow_result), 1));
-        if (res != ~0ULL) break;
+        BPG_HIP(hipMemcpyAsync(w.pinned, w.d_pow_result, 8 * B, hipMemcpyDeviceToHost, st));
+        TRY(w.wait());
+        bool all = true;
+        for (uint32_t b = 0; b < B; b++) {
+          res[b] = reinterpret_cast<const unsigned long long*>(w.pinned)[b];
+          all = all && res[b] != ~0ULL;
+        }
+        if (all) break;
         if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted during proof of work");
         if (base > ((uint64_t)1 << 44)) return fail(BP_ERR_DEVICE, "proof of work search exhausted");
       }
-      nonce = res;
     }
-    P[L.pow] = nonce;
-    ch.observe(nonce);
-    const uint64_t resp = ch.challenge();
-    if (cfg.pow_bits && (resp >> (64 - cfg.pow_bits)) != 0)
-      return fail(BP_ERR_DEVICE, "proof-of-work witness failed the host re-check");
+    for (uint32_t b = 0; b < B; b++) {
+      const uint64_t nonce = res[b];
+      P[b][L.pow] = nonce;
+      ch[b].observe(nonce);
+      const uint64_t resp = ch[b].challenge();
+      if (cfg.pow_bits && (resp >> (64 - cfg.pow_bits)) != 0)
+        return fail(BP_ERR_DEVICE, "proof-of-work witness failed the host re-check");
+    }
   }
 
   // query phase: indices from the transcript, rows + Merkle paths gathered on the device
   {
-    QueryArgs qa2{};
-    QueryLayerArgs ql{};
-    for (uint32_t q = 0; q < cfg.num_queries; q++) qa2.x_index[q] = ql.x_index[q] = ch.challenge() & (M - 1);
+    // (heap: the two argument blocks are 3 KiB each)
+    std::unique_ptr<QueryArgs> qa2(new QueryArgs());
+    std::unique_ptr<QueryLayerArgs> ql(new QueryLayerArgs());
     const size_t q_words = (size_t)cfg.num_queries * L.query_words;
-    const bool q_direct = q_words <= w.pinned_words;  // gather straight into host-visible memory when it fits
-    uint64_t* d_q = q_direct ? w.pinned_dev : w.arena.alloc_words(q_words);
+    const bool q_direct = q_words * B <= w.pinned_words;  // gather straight into host-visible memory when it fits
+    uint64_t* d_q = q_direct ? w.pinned_dev : w.arena.alloc_words(q_words * B);
     if (!d_q) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) allocating the query buffer", w.arena.capacity() >> 20);
-    qa2.out = ql.out = d_q;
-    qa2.query_words = ql.query_words = L.query_words;
-    qa2.log_n = log_n; qa2.rate_bits = r; qa2.cap_height = h;
-    uint32_t off = 1;
-    for (int o = 0; o < n_or; o++) {
-      const Committed* c = refs[o].c;
-      qa2.oracle[o] = QueryOracle{c->lde, c->digests, M, c->n_cols, off};
-      off += c->n_cols + L.depth0 * 4;
+    qa2->query_words = ql->query_words = L.query_words;
+    qa2->n_queries = ql->n_queries = cfg.num_queries;
+    qa2->log_n = log_n; qa2->rate_bits = r; qa2->cap_height = h;
+    ql->rate_bits = r; ql->cap_height = h; ql->arity_bits = ab;
+    for (uint32_t b = 0; b < B; b++) {
+      for (uint32_t q = 0; q < cfg.num_queries; q++)
+        qa2->x_index[b * cfg.num_queries + q] = ql->x_index[b * cfg.num_queries + q] = ch[b].challenge() & (M - 1);
+      qa2->proof[b].out = ql->proof[b].out = d_q + b * q_words;
+      uint32_t off = 1;
+      for (int o = 0; o < n_or; o++) {
+        const Committed* c = refs[b][o].c;
+        qa2->proof[b].oracle[o] = QueryOracle{c->lde, c->digests, M, c->n_cols, off};
+        off += c->n_cols + L.depth0 * 4;
+      }
+      for (uint32_t l = 0; l < L.n_layers; l++) {
+        ql->proof[b].layer[l] = QueryLayer{layer_values[l] + b * layer_vstride[l], layer_digests[l] + b * layer_dstride[l],
+                                          layer_log_nl[l], off};
+        off += 2 * arity + (layer_log_nl[l] - ab + r - h) * 4;
+      }
     }
-    TRY(launch_query_initial(qa2, cfg.num_queries, n_or, st));
-    ql.rate_bits = r; ql.cap_height = h; ql.arity_bits = ab;
-    for (uint32_t l = 0; l < L.n_layers; l++) {
-      ql.layer[l] = QueryLayer{layer_values[l], layer_digests[l], layer_log_nl[l], off};
-      off += 2 * arity + (layer_log_nl[l] - ab + r - h) * 4;
-    }
-    TRY(launch_query_layers(ql, cfg.num_queries, L.n_layers, st));
+    TRY(launch_query_initial(*qa2, B, n_or, st));
+    TRY(launch_query_layers(*ql, B, L.n_layers, st));
     if (q_direct) {
       TRY(w.wait());
-      std::memcpy(P + L.queries, w.pinned, q_words * 8);
+      for (uint32_t b = 0; b < B; b++) std::memcpy(P[b] + L.queries, w.pinned + b * q_words, q_words * 8);
     } else {
-      TRY(w.d2h(P + L.queries, d_q, q_words));
+      for (uint32_t b = 0; b < B; b++) TRY(w.d2h(P[b] + L.queries, d_q + b * q_words, q_words));
     }
   }
   return BP_OK;

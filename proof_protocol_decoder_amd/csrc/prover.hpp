@@ -105,7 +105,7 @@ struct Worker {
   uint64_t* pinned = nullptr;      // host staging / mailbox (kernels may write it directly)
   uint64_t* pinned_dev = nullptr;  // the same memory as seen from the device
   size_t pinned_words = 0;
-  unsigned long long* d_pow_result = nullptr;
+  unsigned long long* d_pow_result = nullptr;  // MAX_BATCH words: one witness per proof of a batch
   hipEvent_t sync_event = nullptr;  // blocking-sync event: waiting threads sleep instead of spinning
   const volatile int32_t* abort_flag = nullptr;
   const volatile uint8_t* abort_flag_u8 = nullptr;  // AtomicBool::as_ptr() of the reference's Arc<AtomicBool>
@@ -114,7 +114,8 @@ struct Worker {
   int init(int device, size_t arena_bytes);
   void destroy();
   int d2h(uint64_t* host_dst, const uint64_t* dev_src, size_t words);  // async copy + stream sync
-  int wait();  // everything queued on the stream has completed (blocking event)
+  int wait();  // everything queued on the stream has completed; the thread sleeps meanwhile (prover.cpp, "Host waits")
+  int wait_recorded();  // the same for a sync_event the caller has recorded already
   bool aborted() const { return (abort_flag && *abort_flag) || (abort_flag_u8 && *abort_flag_u8); }
 };
 
@@ -122,19 +123,34 @@ struct Worker {
 // bit-reversed coefficients when from_coeffs; then the commitment aliases d_in as its coefficients).
 int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
            uint32_t cap_height, bool from_coeffs, Committed* out);
+// `batch` (<= MAX_BATCH) commitments of one shape, every launch covering all of them: d_in = [batch][n_cols][n]
+int commit_batch(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t batch, uint32_t log_n, uint32_t rate_bits,
+                 uint32_t cap_height, bool from_coeffs, Committed* out);
 
 // prove_single_table on the synthetic AIR.  The caller has already observed the trace cap(s) and
 // drawn ctl (plonky2_evm prover order).  Fills `proof` (proof_layout(cfg).total words).
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
                 const uint64_t* d_trace_values, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof);
+// The same for `batch` (<= MAX_BATCH, batch * num_queries <= MAX_BATCH_QUERIES) proofs of ONE shape in lock-step:
+// independent transcripts, every kernel launch and every host wait shared (the seven per-table recursion chains of
+// a transaction, proofgen.cpp).  Proof b's bytes are those stark_prove would give for (consts[b], trace[b], ...).
+// consts: per proof, may be null when the shape has no constant columns.
+int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t batch, const Committed* const* consts,
+                      const Committed* trace, const uint64_t* const* d_trace_values, const Ctl* ctl, Challenger* ch,
+                      std::vector<uint64_t>* proofs);
 
+void tune_host_wait(int mode);  // bp_tune_host_wait
 // hash_kernels.hip: +1 / -1 as a prover starts / finishes (the Poseidon kernel choice follows the load)
 void prover_active(int delta);
 bool device_loaded();  // six or more provers at work on the device
 
 // launch-argument builders shared by the prover and the L0 entry points (stark_api.cpp)
-// fills everything but the matrix pointers, apow (2 * n_constraints words) and partial (quotient_partial_words)
-int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out);
+// fills everything but the matrix pointers, apow (2 * n_constraints words) and partial (quotient_partial_words).
+// loaded: how the units are spread over workgroup rows -- -1 by the device's load right now, 0 / 1 stated (a caller
+// that sizes a buffer in one call and launches in another must not depend on a state that can flip in between)
+// coset (nullable): the per-coset constants launch_quotient needs; batch: proofs of this shape in the launch
+int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out, QuotCoset* coset,
+                  int loaded = -1, uint32_t batch = 1);
 size_t quotient_partial_words(const QuotArgs& qa);  // 0 when the table takes one pass
 int fri_layer_args(uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uint64_t shift, FriLayerArgs* out);
 

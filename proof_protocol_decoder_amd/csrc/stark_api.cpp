@@ -1,4 +1,5 @@
 // stark_api.cpp -- C ABI entry for one synthetic-AIR table proof (include/bpg.h, L0.5).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -70,6 +71,7 @@ extern "C" {
 
 void bp_free_buffer(uint8_t* buf) { std::free(buf); }
 void bp_tune_k5_spread(int on) { bpg::g_k5_spread_all.store(on != 0); }
+void bp_tune_host_wait(int mode) { bpg::tune_host_wait(mode); }
 
 void bp_release_cached_memory(void) {
   std::vector<Worker*> all;
@@ -298,10 +300,18 @@ static int quot_cfg(uint32_t air_id, const bp_stark_cfg* shape, StarkCfg* c) {
 uint64_t bp_quotient_scratch_words(uint32_t air_id, const bp_stark_cfg* shape) {
   StarkCfg c;
   if (quot_cfg(air_id, shape, &c)) return 0;
+  // The spreading of the units over workgroup rows follows the device's load, which bp_generate_* calls on other
+  // threads change at any moment: the scratch is sized for the larger of the two forms (the unloaded one spreads
+  // furthest), so a launch that finds another load state than this call did still fits.
   QuotArgs qa{};
   Ctl ctl{};
-  if (init_ntt_kernels() || quotient_args(c, ctl, 1, 1, &qa)) return 0;
-  return 2 * (uint64_t)qa.n_constraints + 48 + quotient_partial_words(qa);
+  if (init_ntt_kernels()) return 0;
+  uint64_t words = 0;
+  for (int loaded = 0; loaded < 2; loaded++) {
+    if (quotient_args(c, ctl, 1, 1, &qa, nullptr, loaded)) return 0;
+    words = std::max<uint64_t>(words, 2 * (uint64_t)qa.n_constraints + 48 + quotient_partial_words(qa));
+  }
+  return words;
 }
 
 int bp_quotient_eval(uint32_t air_id, const bp_stark_cfg* shape, const uint64_t* d_trace_lde, const uint64_t* d_aux_lde,
@@ -319,10 +329,11 @@ int bp_quotient_eval(uint32_t air_id, const bp_stark_cfg* shape, const uint64_t*
   Ctl ctl;
   for (int i = 0; i < 4; i++) ctl.v[i] = ctl_in[i];
   QuotArgs qa{};
+  QuotCoset coset{};
   qa.trace_lde = d_trace_lde; qa.aux_lde = d_aux_lde; qa.const_lde = c.n_const ? d_const_lde : nullptr;
-  if ((rc = quotient_args(c, ctl, alphas[0], alphas[1], &qa))) return rc;
+  if ((rc = quotient_args(c, ctl, alphas[0], alphas[1], &qa, &coset))) return rc;
   qa.apow = d_scratch; qa.partial = d_scratch + 2 * (size_t)qa.n_constraints + 48; qa.qvals = d_qvals_out;
-  return launch_quotient(qa, as_stream(stream));
+  return launch_quotient(qa, coset, as_stream(stream));
 }
 BPG_ABI_CATCH("bp_quotient_eval")
 

@@ -48,11 +48,14 @@ synth_const_kernel(uint64_t* out, uint32_t log_n, uint32_t n_const, uint64_t see
   if (i >= ((uint64_t)n_const << log_n)) return;
   out[i] = rnd(seed ^ 0xC0115700C0115700ULL, i >> log_n, i & ((1ull << log_n) - 1));
 }
-// grid = (rows/256, groups + 1): group g < G fills columns 4g..4g+3; blockIdx.y == G fills the tail.
+// grid = (rows/256, groups + 1, proofs): group g < G fills columns 4g..4g+3; blockIdx.y == G fills the tail.
 __global__ void __launch_bounds__(256)
-synth_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ consts, uint32_t log_n, uint32_t n_cols,
-                   uint32_t n_const, uint32_t deg_pow, uint64_t seed) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+synth_trace_kernel(bpg::BatchOf<bpg::SynthTraceArgs> batch, uint32_t log_n, uint32_t n_cols, uint32_t n_const,
+                   uint32_t deg_pow) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  uint64_t* __restrict__ t = batch.a[blockIdx.z].trace;
+  const uint64_t* __restrict__ consts = batch.a[blockIdx.z].consts;
+  const uint64_t seed = batch.a[blockIdx.z].seed;
   const uint32_t n = 1u << log_n, G = n_cols / 4;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -81,7 +84,7 @@ synth_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ consts
 // splitmix64(seed ^ (lane << 32) ^ permutation) -- the same stream the oracle draws.
 __global__ void __launch_bounds__(256)
 keccak_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   namespace kk = bpg::air::keccak;
   const uint32_t n = 1u << log_n;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,7 +133,7 @@ keccak_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ input
 // grid.y = 0: flags, result limbs and the bits of operand 0; 1: the bits of operand 1.  Stores coalesce across rows.
 __global__ void __launch_bounds__(256)
 logic_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   namespace lg = bpg::air::logic;
   const uint32_t n = 1u << log_n;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -289,7 +292,7 @@ byte_packing_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__
 // message word w = h(0xD1 + (w << 8)), state before = 0.  The updated state is the permutation of (xored rate, capacity).
 __global__ void __launch_bounds__(256)
 keccak_sponge_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   namespace sp = bpg::air::keccak_sponge;
   namespace kk = bpg::air::keccak;
   const uint32_t n = 1u << log_n;
@@ -397,9 +400,11 @@ arithmetic_mul_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict
 // (The first version gave each lane one n/T-element chunk: lanes n/T*8 bytes apart, every access a
 // different cache line, 16x the algorithmic HBM reads on the 2^14..2^17-row tables by PMC.)
 __global__ void __launch_bounds__(1024)
-aux_suffix_product_kernel(const uint64_t* __restrict__ trace, uint64_t* __restrict__ aux, uint32_t log_n,
-                          bpg::Ctl ctl) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+aux_suffix_product_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const uint64_t* __restrict__ trace = batch.a[blockIdx.z].trace;
+  uint64_t* __restrict__ aux = batch.a[blockIdx.z].aux;
+  const bpg::Ctl& ctl = batch.a[blockIdx.z].ctl;
   __shared__ uint64_t part[1024];
   const uint32_t n = 1u << log_n, k = blockIdx.x, T = blockDim.x, t = threadIdx.x;
   const uint64_t *a = trace + (uint64_t)(8 * k) * n, *b = a + n;
@@ -521,8 +526,9 @@ struct DevEmit {  // the constraint consumer: two constraints (x two challenges)
 // grid = (rows / 256, workgroup rows); workgroup row y evaluates units [y * units_per_wg, ...) of the list
 // "AIR units, then CTL units".
 template <uint32_t AIR>
-__global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) quotient_air_kernel(bpg::BatchOf<bpg::QuotArgs> batch) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::QuotArgs& q = batch.a[blockIdx.z];
   const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
   const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
@@ -562,8 +568,9 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::QuotArgs q) {
   }
 }
 // qvals = (sum of the workgroup rows' partial sums) / Z_H.   grid = (rows / 256, 2 challenges)
-__global__ void __launch_bounds__(256) quotient_sum_kernel(bpg::QuotArgs q, uint32_t n_wg_rows) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) quotient_sum_kernel(bpg::BatchOf<bpg::QuotArgs> batch, uint32_t n_wg_rows) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::QuotArgs& q = batch.a[blockIdx.z];
   const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
   const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
@@ -576,9 +583,15 @@ __global__ void __launch_bounds__(256) quotient_sum_kernel(bpg::QuotArgs q, uint
 struct CosetTab {
   uint64_t v[48];
 };
+struct AlphaTabArgs {
+  uint64_t* out;
+  uint64_t a0, a1;
+};
 __global__ void __launch_bounds__(256)
-alpha_table_kernel(uint64_t* __restrict__ out, uint32_t T, uint64_t a0, uint64_t a1, CosetTab ct) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+alpha_table_kernel(bpg::BatchOf<AlphaTabArgs> batch, uint32_t T, CosetTab ct) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  uint64_t* __restrict__ out = batch.a[blockIdx.z].out;
+  const uint64_t a0 = batch.a[blockIdx.z].a0, a1 = batch.a[blockIdx.z].a1;
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.y == 0 && e < 48) out[2 * (uint64_t)T + e] = ct.v[e];
   if (e >= T) return;
@@ -586,8 +599,9 @@ alpha_table_kernel(uint64_t* __restrict__ out, uint32_t T, uint64_t a0, uint64_t
 }
 // After the per-coset inverse NTT: E_t[pos] (bit-reversed n0).  c_{n0 + n*n1} =
 // (s^n)^(-n1) / 2^r * sum_t w_{2^r}^(-t n1) * E_t[pos] * g_t^(-n0).   grid = (n/256, 2 challenges)
-__global__ void __launch_bounds__(256) quotient_chunks_kernel(bpg::ChunkArgs c) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) quotient_chunks_kernel(bpg::BatchOf<bpg::ChunkArgs> batch) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::ChunkArgs& c = batch.a[blockIdx.z];
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << c.log_n;
   if (pos >= n) return;
   const uint32_t j = blockIdx.y, R = 1u << c.rate_bits;
@@ -604,19 +618,21 @@ __global__ void __launch_bounds__(256) quotient_chunks_kernel(bpg::ChunkArgs c) 
 // ---------------------------------------------------------------- K8 openings
 // pw[0..n) = zeta^bitrev(pos) (c0 plane), pw[n..2n) c1 plane; same for the second point at 2n.
 __global__ void __launch_bounds__(256)
-power_vector_kernel(uint64_t* __restrict__ out, uint32_t log_n, Ext z0, Ext z1, Ext z2) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+power_vector_kernel(bpg::BatchOf<bpg::PowerVecArgs> batch, uint32_t log_n) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << log_n;
   if (pos >= n) return;
   const uint32_t e = gl::bitrev(pos, log_n);
-  const Ext z = blockIdx.y == 0 ? z0 : (blockIdx.y == 1 ? z1 : z2);
+  const Ext z = batch.a[blockIdx.z].z[blockIdx.y];
   const Ext r = gl::pow(z, e);
-  uint64_t* o = out + (uint64_t)blockIdx.y * 2 * n;
+  uint64_t* o = batch.a[blockIdx.z].out + (uint64_t)blockIdx.y * 2 * n;
   o[pos] = r.c0;
   o[n + pos] = r.c1;
 }
-__global__ void __launch_bounds__(256) alpha_pows_kernel(uint64_t* __restrict__ out, uint32_t count, Ext alpha) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) alpha_pows_kernel(bpg::BatchOf<bpg::AlphaPowArgs> batch, uint32_t count) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  uint64_t* __restrict__ out = batch.a[blockIdx.z].out;
+  const Ext alpha = batch.a[blockIdx.z].alpha;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
   const Ext r = gl::pow(alpha, j);
@@ -656,13 +672,14 @@ openings_column(const uint64_t* __restrict__ c, uint32_t log_n, const uint64_t* 
 __global__ void __launch_bounds__(256)
 openings_kernel(const uint64_t* __restrict__ coeffs, uint64_t stride, uint32_t log_n,
                 const uint64_t* __restrict__ pw, uint32_t n_points, uint64_t* __restrict__ out) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   openings_column(coeffs + blockIdx.x * stride, log_n, pw, n_points, out + (uint64_t)blockIdx.x * 4);
 }
 // every opening set of a proof (constants, trace, aux, quotient at zeta [/ g zeta], aux at 1) in ONE launch: the
 // five launches it replaces sat one behind the other on the proof's critical path
-__global__ void __launch_bounds__(256) openings_multi_kernel(bpg::OpenMulti m) {
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+__global__ void __launch_bounds__(256) openings_multi_kernel(bpg::BatchOf<bpg::OpenMulti> batch) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  const bpg::OpenMulti& m = batch.a[blockIdx.z];
   uint32_t s = 0;
 #pragma unroll
   for (int k = 1; k < 5; k++)
@@ -723,8 +740,13 @@ __device__ __forceinline__ void fri_combine_partial_body(const bpg::CombineArgs&
 }
 // Every column of every oracle in one pass, straight into g[6][n]: no partial sums, no reduce launch.  For a
 // device that several provers share (nothing needs filling); the sums are exact, so the bytes are the same.
-__global__ void __launch_bounds__(256) fri_combine_all_kernel(bpg::CombineMulti m, uint64_t* __restrict__ g) {
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
+struct GPtrs {
+  uint64_t* g[bpg::MAX_BATCH];
+};
+__global__ void __launch_bounds__(256) fri_combine_all_kernel(bpg::BatchOf<bpg::CombineMulti> batch, GPtrs gp) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  const bpg::CombineMulti& m = batch.a[blockIdx.z];
+  uint64_t* __restrict__ g = gp.g[blockIdx.z];
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << m.a[0].log_n;
   if (pos >= n) return;
   gl::DotAcc d01[4] = {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()};
@@ -733,12 +755,13 @@ __global__ void __launch_bounds__(256) fri_combine_all_kernel(bpg::CombineMulti 
   fri_combine_store(d01, d2, g, n, pos);
 }
 __global__ void __launch_bounds__(256) fri_combine_partial_kernel(bpg::CombineArgs a) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   fri_combine_partial_body(a, blockIdx.y);
 }
 // all oracles of a proof (constants, trace, aux, quotient) in one launch: grid.y runs over the chunks of all of them
-__global__ void __launch_bounds__(256) fri_combine_partial_multi_kernel(bpg::CombineMulti m) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);
+__global__ void __launch_bounds__(256) fri_combine_partial_multi_kernel(bpg::BatchOf<bpg::CombineMulti> batch) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  const bpg::CombineMulti& m = batch.a[blockIdx.z];
   uint32_t o = 0;
 #pragma unroll
   for (int k = 1; k < 4; k++)
@@ -747,9 +770,10 @@ __global__ void __launch_bounds__(256) fri_combine_partial_multi_kernel(bpg::Com
 }
 // g[6][n] = sum over chunks.  grid = (n/256, 6)
 __global__ void __launch_bounds__(256)
-fri_combine_reduce_kernel(const uint64_t* __restrict__ partial, uint32_t n_chunks, uint32_t log_n,
-                          uint64_t* __restrict__ g) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+fri_combine_reduce_kernel(bpg::BatchOf<bpg::CombineReduceArgs> batch, uint32_t n_chunks, uint32_t log_n) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const uint64_t* __restrict__ partial = batch.a[blockIdx.z].partial;
+  uint64_t* __restrict__ g = batch.a[blockIdx.z].g;
   const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << log_n;
   if (pos >= n) return;
   uint64_t acc = 0;
@@ -758,8 +782,9 @@ fri_combine_reduce_kernel(const uint64_t* __restrict__ partial, uint32_t n_chunk
 }
 // Layer-0 FRI values: V(x) = sum_b alpha^(e_b) * (G_b(x) - y_b) / (x - z_b), x on the LDE coset.
 // glde: [6][rows] coset-major; out: AoS ext [rows].
-__global__ void __launch_bounds__(256) fri_quotient_values_kernel(bpg::FriInitArgs a) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) fri_quotient_values_kernel(bpg::BatchOf<bpg::FriInitArgs> batch) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::FriInitArgs& a = batch.a[blockIdx.z];
   const uint64_t rows = (uint64_t)1 << (a.log_n + a.rate_bits);
   const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (pos >= rows) return;
@@ -788,8 +813,9 @@ __global__ void __launch_bounds__(256) fri_quotient_values_kernel(bpg::FriInitAr
 // x0 * w_a^j', j' = 0..a-1 at positions t*n_l + m0 + j'*(n_l/a).  Its Merkle leaf (upstream:
 // bit-reversed values chunked by arity) is those values in bitrev_a(j) order, leaf index
 // bitrev(t + 2^r*m0).
-__global__ void __launch_bounds__(256) fri_layer_leaf_kernel(bpg::FriLayerArgs a) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) fri_layer_leaf_kernel(bpg::BatchOf<bpg::FriLayerArgs> batch) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::FriLayerArgs& a = batch.a[blockIdx.z];
   const uint32_t log_q = a.log_nl - a.arity_bits;  // log2(n_l / arity)
   const uint64_t n_leaves = (uint64_t)1 << (log_q + a.rate_bits);
   const uint64_t id = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -816,8 +842,9 @@ __global__ void __launch_bounds__(256) fri_layer_leaf_kernel(bpg::FriLayerArgs a
 }
 // Quad-cooperative form of the same leaf hash: lane q of a quad carries state words q and q+4, i.e.
 // component (q & 1) of ext elements (q >> 1) and 2 + (q >> 1) of every 4-element absorb.
-__global__ void __launch_bounds__(256) fri_layer_leaf_quad_kernel(bpg::FriLayerArgs a) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) fri_layer_leaf_quad_kernel(bpg::BatchOf<bpg::FriLayerArgs> batch) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::FriLayerArgs& a = batch.a[blockIdx.z];
   __shared__ uint64_t rc[360];
   for (uint32_t i = threadIdx.x; i < 360; i += blockDim.x) rc[i] = poseidon::RC[i];
   __syncthreads();
@@ -843,8 +870,9 @@ __global__ void __launch_bounds__(256) fri_layer_leaf_quad_kernel(bpg::FriLayerA
 // Matrix-core form (poseidon_mx.cuh): a wave takes 16 * NS leaves; lane (n, kb) of set m carries state words kb and
 // kb + 4 of leaf 16m + n, i.e. component (kb & 1) of ext elements (kb >> 1) and 2 + (kb >> 1) of every absorb.
 template <int NS>
-__global__ void __launch_bounds__(256) fri_layer_leaf_mx_kernel(bpg::FriLayerArgs a) {
-  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) fri_layer_leaf_mx_kernel(bpg::BatchOf<bpg::FriLayerArgs> batch) {
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::FriLayerArgs& a = batch.a[blockIdx.z];
   __shared__ __attribute__((aligned(16))) uint32_t cin[poseidon::mx::CIN_WORDS];
   poseidon::mx::build_cin(cin);
   __syncthreads();
@@ -882,8 +910,9 @@ __global__ void __launch_bounds__(256) fri_layer_leaf_mx_kernel(bpg::FriLayerArg
   }
 }
 // P'(x0^a) = sum_i (beta/x0)^i u_i,  u_i = 1/a * sum_j' w_a^(-i j') P(x0 w_a^j')
-__global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+__global__ void __launch_bounds__(256) fri_fold_kernel(bpg::BatchOf<bpg::FriLayerArgs> batch) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::FriLayerArgs& a = batch.a[blockIdx.z];
   const uint32_t log_q = a.log_nl - a.arity_bits;
   const uint64_t n_out = (uint64_t)1 << (log_q + a.rate_bits);
   const uint64_t id = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -956,7 +985,9 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(bpg::FriLayerArgs a) {
 // ---------------------------------------------------------------- K9 proof of work
 // Smallest witness w >= base with leading pow_bits zero in state[7] after the duplex
 // (fri_proof_of_work; upstream takes any winner, we take the minimum so results are reproducible).
-__global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned long long* result) {
+__global__ void __launch_bounds__(256) pow_grind_kernel(bpg::BatchOf<bpg::PowArgs> batch, unsigned long long* result) {
+  const bpg::PowArgs& a = batch.a[blockIdx.z];
+  result += blockIdx.z;
   if (__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.base) return;  // see pow_grind_mx_kernel
   const uint64_t cand = a.base + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t s[12];
@@ -972,7 +1003,9 @@ __global__ void __launch_bounds__(256) pow_grind_kernel(bpg::PowArgs a, unsigned
 // as in hash_kernels.hip).
 template <int GR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
-pow_grind_mx_kernel(bpg::PowArgs a, unsigned long long* result, const uint32_t* __restrict__ gtab) {
+pow_grind_mx_kernel(bpg::BatchOf<bpg::PowArgs> batch, unsigned long long* result, const uint32_t* __restrict__ gtab) {
+  const bpg::PowArgs& a = batch.a[blockIdx.z];
+  result += blockIdx.z;  // one witness word per proof of the batch
   // A witness below this batch is already known (an earlier batch of the same speculative group found it: batches
   // run one after the other on the stream, so the value is stable and the same for every thread): nothing here can
   // be smaller, the whole grid leaves before it loads a table.
@@ -1009,19 +1042,20 @@ pow_grind_mx_kernel(bpg::PowArgs a, unsigned long long* result, const uint32_t* 
 }
 
 // ---------------------------------------------------------------- query openings
-// grid = (num_queries, n_oracles).  Writes row values and the Merkle path of leaf x into the
+// grid = (num_queries x proofs, n_oracles).  Writes row values and the Merkle path of leaf x into the
 // query record (layout: DESIGN.md section 6).
 __global__ void __launch_bounds__(256) query_initial_kernel(bpg::QueryArgs a) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
-  const uint32_t q = blockIdx.x, o = blockIdx.y;
-  const uint64_t x = a.x_index[q];
-  const bpg::QueryOracle& orc = a.oracle[o];
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const uint32_t b = blockIdx.x / a.n_queries, q = blockIdx.x % a.n_queries, o = blockIdx.y;
+  const uint64_t x = a.x_index[blockIdx.x];
+  const bpg::QueryOracle& orc = a.proof[b].oracle[o];
   const uint32_t log_rows = a.log_n + a.rate_bits;
   // leaf x = row bitrev: natural i = bitrev(x) = t + 2^r*m  ->  coset-major t*n + m
   const uint32_t i = gl::bitrev((uint32_t)x, log_rows);
   const uint64_t pos = ((uint64_t)(i & ((1u << a.rate_bits) - 1)) << a.log_n) + (i >> a.rate_bits);
-  if (o == 0 && threadIdx.x == 0) a.out[(uint64_t)q * a.query_words] = x;
-  uint64_t* w = a.out + (uint64_t)q * a.query_words + orc.out_offset;
+  uint64_t* out = a.proof[b].out;
+  if (o == 0 && threadIdx.x == 0) out[(uint64_t)q * a.query_words] = x;
+  uint64_t* w = out + (uint64_t)q * a.query_words + orc.out_offset;
   for (uint32_t c = threadIdx.x; c < orc.n_cols; c += blockDim.x) w[c] = orc.lde[(uint64_t)c * orc.stride + pos];
   w += orc.n_cols;
   const uint32_t depth = log_rows - a.cap_height;
@@ -1032,18 +1066,18 @@ __global__ void __launch_bounds__(256) query_initial_kernel(bpg::QueryArgs a) {
     w[k] = orc.digests[(off + ((x >> lvl) ^ 1)) * 4 + (k & 3)];
   }
 }
-// grid = (num_queries, n_layers)
+// grid = (num_queries x proofs, n_layers)
 __global__ void __launch_bounds__(64) query_layers_kernel(bpg::QueryLayerArgs a) {
-  if (gridDim.x * gridDim.y <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
-  const uint32_t q = blockIdx.x, l = blockIdx.y;
-  const bpg::QueryLayer& L = a.layer[l];
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const uint32_t b = blockIdx.x / a.n_queries, q = blockIdx.x % a.n_queries, l = blockIdx.y;
+  const bpg::QueryLayer& L = a.proof[b].layer[l];
   const uint32_t arity = 1u << a.arity_bits;
-  const uint64_t leaf = a.x_index[q] >> (a.arity_bits * (l + 1));
+  const uint64_t leaf = a.x_index[blockIdx.x] >> (a.arity_bits * (l + 1));
   const uint32_t log_q = L.log_nl - a.arity_bits, log_leaves = log_q + a.rate_bits;
   const uint32_t c = gl::bitrev((uint32_t)leaf, log_leaves);  // = t + 2^r * m0
   const uint32_t t = c & ((1u << a.rate_bits) - 1), m0 = c >> a.rate_bits;
   const uint64_t base = ((uint64_t)t << L.log_nl) + m0;
-  uint64_t* w = a.out + (uint64_t)q * a.query_words + L.out_offset;
+  uint64_t* w = a.proof[b].out + (uint64_t)q * a.query_words + L.out_offset;
   for (uint32_t k = threadIdx.x; k < 2 * arity; k += blockDim.x) {
     const uint32_t jj = gl::bitrev(k >> 1, a.arity_bits);
     w[k] = L.values[2 * (base + ((uint64_t)jj << log_q)) + (k & 1)];
@@ -1069,10 +1103,14 @@ int launch_synth_constants(uint64_t* d_out, uint32_t log_n, uint32_t n_const, ui
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_synth_trace(uint64_t* d_trace, const uint64_t* d_consts, uint32_t log_n, uint32_t n_cols,
-                       uint32_t n_const, uint32_t deg_pow, uint64_t seed, hipStream_t st) {
-  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), n_cols / 4 + 1);
-  synth_trace_kernel<<<grid, 256, 0, st>>>(d_trace, d_consts, log_n, n_cols, n_const, deg_pow, seed);
+static int check_batch(uint32_t batch) {
+  return batch >= 1 && batch <= MAX_BATCH ? BP_OK : fail(BP_ERR_INVALID_INPUT, "batch of %u proofs: 1..%u can be proved in lock-step", batch, MAX_BATCH);
+}
+int launch_synth_trace(const SynthTraceArgs* a, uint32_t batch, uint32_t log_n, uint32_t n_cols, uint32_t n_const,
+                       uint32_t deg_pow, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), n_cols / 4 + 1, batch);
+  synth_trace_kernel<<<grid, 256, 0, st>>>(batch_of(a, batch), log_n, n_cols, n_const, deg_pow);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -1114,55 +1152,62 @@ int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uin
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
-               hipStream_t st) {
+int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t log_n, uint32_t n_aux, hipStream_t st) {
   if (!n_aux) return BP_OK;
+  if (int rc = check_batch(batch)) return rc;
   uint32_t threads = (1u << log_n) < 1024 ? (1u << log_n) : 1024;
   if (threads < 64) threads = 64;
-  aux_suffix_product_kernel<<<n_aux, threads, 0, st>>>(d_trace, d_aux, log_n, ctl);
+  aux_suffix_product_kernel<<<dim3(n_aux, 1, batch), threads, 0, st>>>(batch_of(a, batch), log_n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_quotient(const QuotArgs& q, hipStream_t st) {
+int launch_quotient(const QuotArgs* qs, uint32_t batch, const QuotCoset& coset, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  const QuotArgs& q = qs[0];
   const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
-  // the alpha-power table of this proof's two challenges (a few thousand words, read wave-uniformly)
+  // the alpha-power table of every proof's two challenges (a few thousand words, read wave-uniformly)
   CosetTab ct;
-  for (int t = 0; t < 16; t++) { ct.v[t] = q.g_t[t]; ct.v[16 + t] = q.zh_t[t]; ct.v[32 + t] = q.zh_inv_t[t]; }
-  alpha_table_kernel<<<dim3(ceil_div(q.n_constraints, 256), 2), 256, 0, st>>>(const_cast<uint64_t*>(q.apow), q.n_constraints,
-                                                                             q.alpha0, q.alpha1, ct);
+  for (int t = 0; t < 16; t++) { ct.v[t] = coset.g_t[t]; ct.v[16 + t] = coset.zh_t[t]; ct.v[32 + t] = coset.zh_inv_t[t]; }
+  BatchOf<AlphaTabArgs> at{};
+  for (uint32_t b = 0; b < batch; b++) at.a[b] = AlphaTabArgs{const_cast<uint64_t*>(qs[b].apow), qs[b].alpha0, qs[b].alpha1};
+  alpha_table_kernel<<<dim3(ceil_div(q.n_constraints, 256), 2, batch), 256, 0, st>>>(at, q.n_constraints, ct);
   BPG_LAUNCH_CHECK();
   const uint32_t n_units = q.n_air_units + q.n_ctl_units, wg_rows = ceil_div(n_units, q.units_per_wg);
-  dim3 g1(ceil_div(rows, 256), wg_rows);
-  if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(q);
-  else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(q);
-  else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(q);
-  else if (q.air_id == bpg::air::ARITHMETIC) quotient_air_kernel<bpg::air::ARITHMETIC><<<g1, 256, 0, st>>>(q);
-  else if (q.air_id == bpg::air::BYTE_PACKING) quotient_air_kernel<bpg::air::BYTE_PACKING><<<g1, 256, 0, st>>>(q);
-  else if (q.air_id == bpg::air::KECCAK_SPONGE) quotient_air_kernel<bpg::air::KECCAK_SPONGE><<<g1, 256, 0, st>>>(q);
-  else if (q.air_id == bpg::air::ARITHMETIC_MUL) quotient_air_kernel<bpg::air::ARITHMETIC_MUL><<<g1, 256, 0, st>>>(q);
-  else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(q);
+  const BatchOf<QuotArgs> qb = batch_of(qs, batch);
+  dim3 g1(ceil_div(rows, 256), wg_rows, batch);
+  if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(qb);
+  else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(qb);
+  else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(qb);
+  else if (q.air_id == bpg::air::ARITHMETIC) quotient_air_kernel<bpg::air::ARITHMETIC><<<g1, 256, 0, st>>>(qb);
+  else if (q.air_id == bpg::air::BYTE_PACKING) quotient_air_kernel<bpg::air::BYTE_PACKING><<<g1, 256, 0, st>>>(qb);
+  else if (q.air_id == bpg::air::KECCAK_SPONGE) quotient_air_kernel<bpg::air::KECCAK_SPONGE><<<g1, 256, 0, st>>>(qb);
+  else if (q.air_id == bpg::air::ARITHMETIC_MUL) quotient_air_kernel<bpg::air::ARITHMETIC_MUL><<<g1, 256, 0, st>>>(qb);
+  else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(qb);
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {
-    quotient_sum_kernel<<<dim3(ceil_div(rows, 256), 2), 256, 0, st>>>(q, wg_rows);
+    quotient_sum_kernel<<<dim3(ceil_div(rows, 256), 2, batch), 256, 0, st>>>(qb, wg_rows);
     BPG_LAUNCH_CHECK();
   }
   return BP_OK;
 }
-int launch_quotient_chunks(const ChunkArgs& c, hipStream_t st) {
-  dim3 grid(ceil_div((uint64_t)1 << c.log_n, 256), 2);
-  quotient_chunks_kernel<<<grid, 256, 0, st>>>(c);
+int launch_quotient_chunks(const ChunkArgs* c, uint32_t batch, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  dim3 grid(ceil_div((uint64_t)1 << c[0].log_n, 256), 2, batch);
+  quotient_chunks_kernel<<<grid, 256, 0, st>>>(batch_of(c, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_power_vectors(uint64_t* d_out, uint32_t log_n, gl::Ext z0, gl::Ext z1, uint32_t n_points,
-                         hipStream_t st, gl::Ext z2) {
-  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), n_points);
-  power_vector_kernel<<<grid, 256, 0, st>>>(d_out, log_n, z0, z1, z2);
+int launch_power_vectors(const PowerVecArgs* a, uint32_t batch, uint32_t log_n, uint32_t n_points, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  if (n_points < 1 || n_points > 3) return fail(BP_ERR_INVALID_INPUT, "launch_power_vectors: 1..3 points");
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), n_points, batch);
+  power_vector_kernel<<<grid, 256, 0, st>>>(batch_of(a, batch), log_n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_alpha_pows(uint64_t* d_out, uint32_t count, gl::Ext alpha, hipStream_t st) {
-  alpha_pows_kernel<<<ceil_div(count, 256), 256, 0, st>>>(d_out, count, alpha);
+int launch_alpha_pows(const AlphaPowArgs* a, uint32_t batch, uint32_t count, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  alpha_pows_kernel<<<dim3(ceil_div(count, 256), 1, batch), 256, 0, st>>>(batch_of(a, batch), count);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -1173,86 +1218,98 @@ int launch_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, u
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_openings_multi(const OpenMulti& m, hipStream_t st) {
-  const uint32_t total = m.first_col[m.n_segs];
+int launch_openings_multi(const OpenMulti* m, uint32_t batch, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  const uint32_t total = m[0].first_col[m[0].n_segs];  // the proofs of a batch have one shape
   if (!total) return BP_OK;
-  openings_multi_kernel<<<total, 256, 0, st>>>(m);
+  openings_multi_kernel<<<dim3(total, 1, batch), 256, 0, st>>>(batch_of(m, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_combine_partial(const CombineArgs& a, uint32_t n_chunks, hipStream_t st) {
-  if (!a.n_cols) return BP_OK;
-  dim3 grid(ceil_div((uint64_t)1 << a.log_n, 256), n_chunks);
-  fri_combine_partial_kernel<<<grid, 256, 0, st>>>(a);
-  BPG_LAUNCH_CHECK();
-  return BP_OK;
-}
-int launch_combine_partial_multi(const CombineMulti& m, uint32_t total_chunks, hipStream_t st) {
+int launch_combine_partial_multi(const CombineMulti* m, uint32_t batch, uint32_t total_chunks, hipStream_t st) {
   if (!total_chunks) return BP_OK;
-  dim3 grid(ceil_div((uint64_t)1 << m.a[0].log_n, 256), total_chunks);
-  fri_combine_partial_multi_kernel<<<grid, 256, 0, st>>>(m);
+  if (int rc = check_batch(batch)) return rc;
+  dim3 grid(ceil_div((uint64_t)1 << m[0].a[0].log_n, 256), total_chunks, batch);
+  fri_combine_partial_multi_kernel<<<grid, 256, 0, st>>>(batch_of(m, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_combine_all(const CombineMulti& m, uint64_t* d_g, hipStream_t st) {
-  fri_combine_all_kernel<<<ceil_div((uint64_t)1 << m.a[0].log_n, 256), 256, 0, st>>>(m, d_g);
+int launch_combine_all(const CombineMulti* m, uint32_t batch, uint64_t* const* d_g, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  GPtrs gp{};
+  for (uint32_t b = 0; b < batch; b++) gp.g[b] = d_g[b];
+  fri_combine_all_kernel<<<dim3(ceil_div((uint64_t)1 << m[0].a[0].log_n, 256), 1, batch), 256, 0, st>>>(batch_of(m, batch), gp);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_combine_reduce(const uint64_t* d_partial, uint32_t n_chunks, uint32_t log_n, uint64_t* d_g,
-                          hipStream_t st) {
-  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 6);
-  fri_combine_reduce_kernel<<<grid, 256, 0, st>>>(d_partial, n_chunks, log_n, d_g);
+int launch_combine_reduce(const CombineReduceArgs* a, uint32_t batch, uint32_t n_chunks, uint32_t log_n, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 6, batch);
+  fri_combine_reduce_kernel<<<grid, 256, 0, st>>>(batch_of(a, batch), n_chunks, log_n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_fri_init(const FriInitArgs& a, hipStream_t st) {
-  uint64_t rows = (uint64_t)1 << (a.log_n + a.rate_bits);
-  fri_quotient_values_kernel<<<ceil_div(rows, 256), 256, 0, st>>>(a);
+int launch_fri_init(const FriInitArgs* a, uint32_t batch, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  uint64_t rows = (uint64_t)1 << (a[0].log_n + a[0].rate_bits);
+  fri_quotient_values_kernel<<<dim3(ceil_div(rows, 256), 1, batch), 256, 0, st>>>(batch_of(a, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
 uint64_t quad_threshold();  // hash_kernels.hip
 bool poseidon_mx();         // hash_kernels.hip
 int mx_sets(uint64_t n);    // hash_kernels.hip
-int launch_fri_layer_leaves(const FriLayerArgs& a, hipStream_t st) {
+int launch_fri_layer_leaves(const FriLayerArgs* as, uint32_t batch, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  const FriLayerArgs& a = as[0];
   uint64_t n = (uint64_t)1 << (a.log_nl - a.arity_bits + a.rate_bits);
-  if (const int ns = mx_sets(n)) {
-    if (ns == 4) fri_layer_leaf_mx_kernel<4><<<ceil_div(n, 256), 256, 0, st>>>(a);
-    else if (ns == 2) fri_layer_leaf_mx_kernel<2><<<ceil_div(n, 128), 256, 0, st>>>(a);
-    else fri_layer_leaf_mx_kernel<1><<<ceil_div(n, 64), 256, 0, st>>>(a);
-  } else if (n < quad_threshold()) fri_layer_leaf_quad_kernel<<<ceil_div(n * 4, 256), 256, 0, st>>>(a);
-  else fri_layer_leaf_kernel<<<ceil_div(n, 256), 256, 0, st>>>(a);
+  const BatchOf<FriLayerArgs> ab = batch_of(as, batch);
+  // the form follows the work of the whole launch (every proof has its own grid.z slice: no wave spans two proofs)
+  if (const int ns = mx_sets(n * batch)) {
+    if (ns == 4) fri_layer_leaf_mx_kernel<4><<<dim3(ceil_div(n, 256), 1, batch), 256, 0, st>>>(ab);
+    else if (ns == 2) fri_layer_leaf_mx_kernel<2><<<dim3(ceil_div(n, 128), 1, batch), 256, 0, st>>>(ab);
+    else fri_layer_leaf_mx_kernel<1><<<dim3(ceil_div(n, 64), 1, batch), 256, 0, st>>>(ab);
+  } else if (n * batch < quad_threshold()) fri_layer_leaf_quad_kernel<<<dim3(ceil_div(n * 4, 256), 1, batch), 256, 0, st>>>(ab);
+  else fri_layer_leaf_kernel<<<dim3(ceil_div(n, 256), 1, batch), 256, 0, st>>>(ab);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_fri_fold(const FriLayerArgs& a, hipStream_t st) {
-  uint64_t n = (uint64_t)1 << (a.log_nl - a.arity_bits + a.rate_bits);
-  fri_fold_kernel<<<ceil_div(n, 256), 256, 0, st>>>(a);
+int launch_fri_fold(const FriLayerArgs* a, uint32_t batch, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  uint64_t n = (uint64_t)1 << (a[0].log_nl - a[0].arity_bits + a[0].rate_bits);
+  fri_fold_kernel<<<dim3(ceil_div(n, 256), 1, batch), 256, 0, st>>>(batch_of(a, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_pow(const PowArgs& a, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st) {
+int launch_pow(const PowArgs* a, uint32_t batch, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  const BatchOf<PowArgs> ab = batch_of(a, batch);
+  const dim3 grid(n_candidates / 256, 1, batch);
   if (poseidon_mx()) {
     int ng = 0;
     const uint32_t* gtab = group_tables(&ng);
-    if (gtab && ng == 3) pow_grind_mx_kernel<3><<<n_candidates / 256, 256, 0, st>>>(a, d_result, gtab);
-    else if (gtab) pow_grind_mx_kernel<2><<<n_candidates / 256, 256, 0, st>>>(a, d_result, gtab);
-    else pow_grind_mx_kernel<0><<<n_candidates / 256, 256, 0, st>>>(a, d_result, nullptr);
+    if (gtab && ng == 3) pow_grind_mx_kernel<3><<<grid, 256, 0, st>>>(ab, d_result, gtab);
+    else if (gtab) pow_grind_mx_kernel<2><<<grid, 256, 0, st>>>(ab, d_result, gtab);
+    else pow_grind_mx_kernel<0><<<grid, 256, 0, st>>>(ab, d_result, nullptr);
   } else
-    pow_grind_kernel<<<n_candidates / 256, 256, 0, st>>>(a, d_result);
+    pow_grind_kernel<<<grid, 256, 0, st>>>(ab, d_result);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_query_initial(const QueryArgs& a, uint32_t n_queries, uint32_t n_oracles, hipStream_t st) {
-  dim3 grid(n_queries, n_oracles);
+int launch_query_initial(const QueryArgs& a, uint32_t batch, uint32_t n_oracles, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  if (!a.n_queries || a.n_queries * batch > MAX_BATCH_QUERIES) return fail(BP_ERR_INVALID_INPUT, "query launch: %u x %u indices, at most %u", a.n_queries, batch, MAX_BATCH_QUERIES);
+  dim3 grid(a.n_queries * batch, n_oracles);
   query_initial_kernel<<<grid, 256, 0, st>>>(a);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_query_layers(const QueryLayerArgs& a, uint32_t n_queries, uint32_t n_layers, hipStream_t st) {
+int launch_query_layers(const QueryLayerArgs& a, uint32_t batch, uint32_t n_layers, hipStream_t st) {
   if (!n_layers) return BP_OK;
-  dim3 grid(n_queries, n_layers);
+  if (int rc = check_batch(batch)) return rc;
+  if (!a.n_queries || a.n_queries * batch > MAX_BATCH_QUERIES || n_layers > MAX_FRI_LAYERS)
+    return fail(BP_ERR_INVALID_INPUT, "query launch: %u x %u indices, %u layers", a.n_queries, batch, n_layers);
+  dim3 grid(a.n_queries * batch, n_layers);
   query_layers_kernel<<<grid, 64, 0, st>>>(a);
   BPG_LAUNCH_CHECK();
   return BP_OK;

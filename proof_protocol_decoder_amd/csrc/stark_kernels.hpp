@@ -12,6 +12,21 @@ struct Ctl {
   uint64_t v[4];  // beta0, gamma0, beta1, gamma1 (grand-product challenge sets)
 };
 
+// Proofs of ONE shape proved in lock-step (the seven per-table recursion chains of a transaction,
+// proofgen.cpp): every kernel below takes the argument blocks of up to MAX_BATCH proofs and runs proof
+// blockIdx.z of them; a lone proof is a batch of one.  The blocks travel as kernel arguments (<= 4 KiB).
+constexpr uint32_t MAX_BATCH = 8;
+template <class A>
+struct BatchOf {
+  A a[MAX_BATCH];
+};
+template <class A>
+inline BatchOf<A> batch_of(const A* a, uint32_t n) {
+  BatchOf<A> b{};
+  for (uint32_t i = 0; i < n && i < MAX_BATCH; i++) b.a[i] = a[i];
+  return b;
+}
+
 struct QuotArgs {
   const uint64_t *trace_lde, *aux_lde, *const_lde;
   uint64_t trace_stride, aux_stride, const_stride;
@@ -22,8 +37,32 @@ struct QuotArgs {
   // the constraint list (air.hpp): AIR constraints, then two per aux column; units = AIR units, then CTL units
   uint32_t n_air_constraints, n_constraints, n_air_units, n_ctl_units, aux_per_unit, units_per_wg;
   uint64_t alpha0, alpha1, g, g_inv, n_inv;
-  uint64_t g_t[16], zh_t[16], zh_inv_t[16];  // per coset: 7*w_M^t, g_t^n - 1 and its inverse
   Ctl ctl;
+};
+struct QuotCoset {  // per coset: 7*w_M^t, g_t^n - 1 and its inverse (the same for every proof of a shape)
+  uint64_t g_t[16], zh_t[16], zh_inv_t[16];
+};
+struct SynthTraceArgs {
+  uint64_t* trace;
+  const uint64_t* consts;
+  uint64_t seed;
+};
+struct AuxArgs {
+  const uint64_t* trace;
+  uint64_t* aux;
+  Ctl ctl;
+};
+struct PowerVecArgs {
+  uint64_t* out;  // n_points vectors of 2n words each: point y at out + y * 2n
+  gl::Ext z[3];
+};
+struct AlphaPowArgs {
+  uint64_t* out;
+  gl::Ext alpha;
+};
+struct CombineReduceArgs {
+  const uint64_t* partial;
+  uint64_t* g;
 };
 struct ChunkArgs {
   const uint64_t* e;          // [2][2^r][n] per-coset inverse NTT output (bit-reversed)
@@ -83,29 +122,43 @@ struct QueryOracle {
   uint64_t stride;
   uint32_t n_cols, out_offset;
 };
-struct QueryArgs {
-  uint64_t x_index[128];
+// Query openings of a batch: query q of the launch belongs to proof q / n_queries (MAX_BATCH_QUERIES indices in all)
+constexpr uint32_t MAX_BATCH_QUERIES = 256;
+struct QueryProof {
   uint64_t* out;
-  uint64_t query_words;
-  uint32_t log_n, rate_bits, cap_height;
   QueryOracle oracle[4];
+};
+struct QueryArgs {
+  uint64_t x_index[MAX_BATCH_QUERIES];
+  uint64_t query_words;
+  uint32_t log_n, rate_bits, cap_height, n_queries;  // n_queries: per proof
+  QueryProof proof[MAX_BATCH];
 };
 struct QueryLayer {
   const uint64_t *values, *digests;
   uint32_t log_nl, out_offset;
 };
-struct QueryLayerArgs {
-  uint64_t x_index[128];
+constexpr uint32_t MAX_FRI_LAYERS = 8;  // check_cfg (prover.cpp)
+struct QueryLayerProof {
   uint64_t* out;
+  QueryLayer layer[MAX_FRI_LAYERS];
+};
+struct QueryLayerArgs {
+  uint64_t x_index[MAX_BATCH_QUERIES];
   uint64_t query_words;
-  uint32_t rate_bits, cap_height, arity_bits;
-  QueryLayer layer[8];
+  uint32_t rate_bits, cap_height, arity_bits, n_queries;
+  QueryLayerProof proof[MAX_BATCH];
 };
 
-// stark_kernels.hip
+// stark_kernels.hip.  Launchers that take `const X* a, uint32_t batch` run `batch` proofs of one shape in one launch.
 int launch_synth_constants(uint64_t* d_out, uint32_t log_n, uint32_t n_const, uint64_t seed, hipStream_t st);
-int launch_synth_trace(uint64_t* d_trace, const uint64_t* d_consts, uint32_t log_n, uint32_t n_cols,
-                       uint32_t n_const, uint32_t deg_pow, uint64_t seed, hipStream_t st);
+int launch_synth_trace(const SynthTraceArgs* a, uint32_t batch, uint32_t log_n, uint32_t n_cols, uint32_t n_const,
+                       uint32_t deg_pow, hipStream_t st);
+inline int launch_synth_trace(uint64_t* d_trace, const uint64_t* d_consts, uint32_t log_n, uint32_t n_cols,
+                              uint32_t n_const, uint32_t deg_pow, uint64_t seed, hipStream_t st) {
+  const SynthTraceArgs a{d_trace, d_consts, seed};
+  return launch_synth_trace(&a, 1, log_n, n_cols, n_const, deg_pow, st);
+}
 // AIR 1 witness: n rows x 2430 columns; d_inputs [ceil(n / 24)][25] lanes or null (then drawn from seed)
 int launch_keccak_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_logic_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
@@ -114,28 +167,36 @@ int launch_arithmetic_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_
 int launch_byte_packing_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
-int launch_aux(const uint64_t* d_trace, uint64_t* d_aux, uint32_t log_n, uint32_t n_aux, const Ctl& ctl,
-               hipStream_t st);
-int launch_quotient(const QuotArgs& q, hipStream_t st);
-int launch_quotient_chunks(const ChunkArgs& c, hipStream_t st);
+int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t log_n, uint32_t n_aux, hipStream_t st);
+// every proof of the batch has the shape and the unit spreading of q[0]
+int launch_quotient(const QuotArgs* q, uint32_t batch, const QuotCoset& coset, hipStream_t st);
+inline int launch_quotient(const QuotArgs& q, const QuotCoset& coset, hipStream_t st) { return launch_quotient(&q, 1, coset, st); }
+int launch_quotient_chunks(const ChunkArgs* c, uint32_t batch, hipStream_t st);
+int launch_power_vectors(const PowerVecArgs* a, uint32_t batch, uint32_t log_n, uint32_t n_points, hipStream_t st);
 // d_out: n_points (<= 3) vectors of 2n words each: point y at d_out + y * 2n
-int launch_power_vectors(uint64_t* d_out, uint32_t log_n, gl::Ext z0, gl::Ext z1, uint32_t n_points,
-                         hipStream_t st, gl::Ext z2 = gl::Ext{1, 0});
-int launch_alpha_pows(uint64_t* d_out, uint32_t count, gl::Ext alpha, hipStream_t st);
+inline int launch_power_vectors(uint64_t* d_out, uint32_t log_n, gl::Ext z0, gl::Ext z1, uint32_t n_points,
+                                hipStream_t st, gl::Ext z2 = gl::Ext{1, 0}) {
+  const PowerVecArgs a{d_out, {z0, z1, z2}};
+  return launch_power_vectors(&a, 1, log_n, n_points, st);
+}
+int launch_alpha_pows(const AlphaPowArgs* a, uint32_t batch, uint32_t count, hipStream_t st);
 int launch_openings(const uint64_t* d_coeffs, uint64_t stride, uint32_t log_n, uint32_t n_cols,
                     const uint64_t* d_pw, uint32_t n_points, uint64_t* d_out, hipStream_t st);
-int launch_openings_multi(const OpenMulti& m, hipStream_t st);
-int launch_combine_partial_multi(const CombineMulti& m, uint32_t total_chunks, hipStream_t st);
-int launch_combine_all(const CombineMulti& m, uint64_t* d_g, hipStream_t st);  // one pass, straight into g[6][n]
-int launch_combine_partial(const CombineArgs& a, uint32_t n_chunks, hipStream_t st);
-int launch_combine_reduce(const uint64_t* d_partial, uint32_t n_chunks, uint32_t log_n, uint64_t* d_g,
-                          hipStream_t st);
-int launch_fri_init(const FriInitArgs& a, hipStream_t st);
-int launch_fri_layer_leaves(const FriLayerArgs& a, hipStream_t st);
-int launch_fri_fold(const FriLayerArgs& a, hipStream_t st);
-int launch_pow(const PowArgs& a, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st);
-int launch_query_initial(const QueryArgs& a, uint32_t n_queries, uint32_t n_oracles, hipStream_t st);
-int launch_query_layers(const QueryLayerArgs& a, uint32_t n_queries, uint32_t n_layers, hipStream_t st);
+int launch_openings_multi(const OpenMulti* m, uint32_t batch, hipStream_t st);
+int launch_combine_partial_multi(const CombineMulti* m, uint32_t batch, uint32_t total_chunks, hipStream_t st);
+int launch_combine_all(const CombineMulti* m, uint32_t batch, uint64_t* const* d_g, hipStream_t st);  // one pass, straight into g[6][n]
+int launch_combine_reduce(const CombineReduceArgs* a, uint32_t batch, uint32_t n_chunks, uint32_t log_n, hipStream_t st);
+int launch_fri_init(const FriInitArgs* a, uint32_t batch, hipStream_t st);
+int launch_fri_layer_leaves(const FriLayerArgs* a, uint32_t batch, hipStream_t st);
+int launch_fri_fold(const FriLayerArgs* a, uint32_t batch, hipStream_t st);
+inline int launch_fri_fold(const FriLayerArgs& a, hipStream_t st) { return launch_fri_fold(&a, 1, st); }
+// d_result: one word per proof of the batch (all ones = no witness yet)
+int launch_pow(const PowArgs* a, uint32_t batch, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st);
+inline int launch_pow(const PowArgs& a, uint32_t n_candidates, unsigned long long* d_result, hipStream_t st) {
+  return launch_pow(&a, 1, n_candidates, d_result, st);
+}
+int launch_query_initial(const QueryArgs& a, uint32_t batch, uint32_t n_oracles, hipStream_t st);
+int launch_query_layers(const QueryLayerArgs& a, uint32_t batch, uint32_t n_layers, hipStream_t st);
 
 // ntt.hip
 int init_ntt_kernels();
@@ -149,9 +210,12 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
 // the current device's image of the grouped-Poseidon operand tables and the number of groups (2 or 3) it is laid out
 // for, or nullptr (knob off)
 const uint32_t* group_tables(int* n_groups);
+// batch > 1: `batch` trees of one shape in every launch; tree b's matrix / digest buffer / cap mirror sits
+// b * lde_bstride / b * dig_bstride / b * (4 << cap_height) words behind the first one's
 int merkle_upper_levels(uint64_t* d_digests, uint32_t log_leaves, uint32_t cap_height, hipStream_t st,
-                        uint64_t* mirror, bool* mirrored);
+                        uint64_t* mirror, bool* mirrored, uint32_t batch = 1, uint64_t dig_bstride = 0);
 int merkle_commit_cols(const uint64_t* d_lde, uint64_t lde_stride, uint32_t n_cols, uint32_t log_n, uint32_t rate_bits,
-                       uint32_t cap_height, uint64_t* d_digests, hipStream_t st, uint64_t* mirror, bool* mirrored);
+                       uint32_t cap_height, uint64_t* d_digests, hipStream_t st, uint64_t* mirror, bool* mirrored,
+                       uint32_t batch = 1, uint64_t lde_bstride = 0, uint64_t dig_bstride = 0);
 
 }  // namespace bpg
