@@ -249,6 +249,61 @@ def test_quotient_eval_matches_oracle(bpg, oracle, log_n, n_cols, n_const, deg_p
     assert (to_host(got)[:, idx] == want).all()
 
 
+def test_quotient_scratch_fits_whatever_the_load_state_is_at_launch(bpg, oracle):
+    """bp_quotient_scratch_words and bp_quotient_eval are two calls, and the unit spreading (hence the size of the
+    partial sums) follows the device's load, which other threads change in between: the scratch size must cover both
+    states.  The buffer is allocated at exactly the size returned and followed by a guard that must stay untouched."""
+    import ctypes as C
+    import torch
+    log_n, n_cols, rate_bits = 9, 128, 1
+    rng = np.random.default_rng(77)
+    rows = (1 << log_n) << rate_bits
+    trace, aux = rand_field(rng, (n_cols, rows)), rand_field(rng, (n_cols // 8, rows))
+    ctl, alphas = rand_field(rng, (4,)), rand_field(rng, (2,))
+    cfg = bpg.ops.stark_cfg(log_n, n_cols, rate_bits=rate_bits)
+    L = bpg.lib()
+    want = None
+    try:
+        for at_size, at_launch in ((1, 0), (0, 1), (0, 0), (1, 1)):
+            L.bp_tune_assume_loaded(at_size)
+            words = int(L.bp_quotient_scratch_words(0, C.byref(cfg)))
+            guard = 4096
+            buf = torch.full((words + guard,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda")
+            out = torch.empty((2, rows), dtype=torch.int64, device="cuda")
+            L.bp_tune_assume_loaded(at_launch)
+            t, a = to_dev(trace), to_dev(aux)
+            bpg._lib.check(L.bp_quotient_eval(0, C.byref(cfg), t.data_ptr(), a.data_ptr(), None,
+                                              (C.c_uint64 * 4)(*[int(x) for x in ctl]), (C.c_uint64 * 2)(*[int(x) for x in alphas]),
+                                              buf.data_ptr(), out.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert (buf[words:] == 0x5A5A5A5A5A5A5A5A).all(), "the launch wrote past the scratch it was sized"
+            got = to_host(out)
+            if want is None:
+                want = got
+            assert (got == want).all()
+    finally:
+        L.bp_tune_assume_loaded(-1)
+
+
+def test_merkle_commit_of_a_tiny_matrix_with_forced_sets(bpg, oracle):
+    """bp_tune_poseidon_mx_sets(4) on a 16-row matrix: the four-set kernel would read 48 rows past the last column;
+    the launcher takes fewer sets for trees smaller than a wave's sets.  Same digests in every form."""
+    rng = np.random.default_rng(78)
+    L = bpg.lib()
+    for log_n, r in ((3, 1), (4, 0), (5, 0)):
+        rows = (1 << log_n) << r
+        lde = rand_field(rng, (9, rows))
+        ref = None
+        try:
+            for sets in (0, 1, 2, 4):
+                L.bp_tune_poseidon_mx_sets(sets)
+                got = to_host(bpg.ops.merkle_commit(to_dev(lde), log_n, r, 2))
+                ref = got if ref is None else ref
+                assert (got == ref).all()
+        finally:
+            L.bp_tune_poseidon_mx_sets(0)
+
+
 @pytest.mark.parametrize("log_nl,rate_bits", [(4, 1), (6, 1), (9, 3), (13, 3), (16, 1)])
 def test_fri_fold_matches_oracle(bpg, oracle, log_nl, rate_bits):
     """K6 alone: one arity-16 fold of random extension values, device coset-major vs oracle bit-reversed."""

@@ -73,6 +73,23 @@ def test_txn_agg_block_bytes_match_oracle(pg, p_state, o_state, chain):
     v.verify_any(oa.tobytes())
 
 
+def test_lock_step_batches_do_not_change_a_byte(pg, p_state, bpg, chain):
+    """The seven per-table recursion chains are proved as batches (bp_tune_rec_batch, default 8): whatever the batch
+    size -- one proof at a time, uneven splits, all seven at once -- and whichever way the host waits, the txn proof is
+    the same bytes (which test_txn_agg_block_bytes_match_oracle pins to the oracle)."""
+    t0 = chain[0]
+    L = bpg.lib()
+    try:
+        for n, wait in ((1, 0), (2, 0), (3, 2), (5, 0), (7, 2), (8, 1)):
+            L.bp_tune_rec_batch(n)
+            L.bp_tune_host_wait(wait)
+            again = pg.generate_txn_proof(p_state, make_ir(pg, 7, 0, 0x5EED0001))
+            assert again.intern == t0.intern, "batch size %d, host wait mode %d" % (n, wait)
+    finally:
+        L.bp_tune_rec_batch(8)
+        L.bp_tune_host_wait(0)
+
+
 def test_public_values_chain(chain):
     t0, t1, t2, a01, a012, blk = chain
     assert (t0.p_vals.txn_number_before, t0.p_vals.txn_number_after) == (0, 1)
