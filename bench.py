@@ -319,9 +319,11 @@ def main():
         # acceptance: the block proof verifies (VerifierState::verify, verifier_state.rs:56-71)
         pg.VerifierState.from_prover_state(state).verify(last)
     L.bp_host_wait_mode.restype = C.c_int
-    host_waits = {1: "sleep (hipDeviceScheduleBlockingSync)", 2: "device already in use: mode left alone"}.get(
+    host_waits = {1: "sleep (hipDeviceScheduleBlockingSync)",
+                  2: "device already in use: mode left alone, the library's poll-and-sleep wait"}.get(
         L.bp_host_wait_mode(local_rank), "undecided")
-    t_build_info = {"state_build_s": round(t_build, 2), "state_device_gib": round(state.device_bytes / 2**30, 2)}
+    t_build_info = {"state_build_s": round(t_build, 2), "state_device_gib": round(state.device_bytes / 2**30, 2),
+                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "state_warnings": state.warnings or None}
     driver.close()
     state.close()
     if world > 1:

@@ -53,8 +53,11 @@ int bp_device_count(void);
  * afterwards: later calls return BP_OK and do nothing.  The mode can only be switched on a device the
  * PROCESS has not used yet (switching it under queues that already carried work makes a later hipFree or
  * hipDeviceSynchronize hang on this ROCm): on a device that is already in use the call leaves the mode
- * alone -- everything works, host waits spin.  A process that uses the device through another library
- * (PyTorch, ...) should call this first thing. */
+ * alone, and the library's prover threads then wait with a loop of their own -- poll the event, sleep an
+ * eighth of the time waited so far between polls -- instead of the runtime's spinning wait (measured on
+ * 16 streams: within 1 % of the interrupt-driven rate at 10 % of a core per thread; the runtime's wait
+ * keeps every thread at 100 %).  A process that uses the device through another library (PyTorch, ...)
+ * may still call this first thing to get interrupt-driven waits. */
 int bp_use_blocking_sync(int device);
 /* What was decided for the device: 0 nothing yet, 1 host waits sleep, 2 the device was already in use (or
  * configured otherwise) and keeps its mode. */
@@ -379,6 +382,13 @@ void bp_config_default(bp_config* cfg);
 int bp_state_build(const bp_config* cfg, bp_state** out); /* "very expensive call" in the reference */
 void bp_state_free(bp_state* s);
 uint64_t bp_state_device_bytes(const bp_state* s);
+/* What bp_state_build found about the environment the state runs in, as text ("" when there is nothing to say; valid
+ * until bp_state_free).  Two things are reported.  (1) RUN-TIME PREREQUISITE: one prover = one HIP stream, and ROCm
+ * multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 unless the environment variable says
+ * otherwise, read once when the HIP runtime starts.  With fewer queues than n_workers the provers share queues and
+ * serialise; export GPU_MAX_HW_QUEUES >= n_workers (bench.py: 32) before the process's first HIP call.  (2) The
+ * host-wait mode the device was left in (bp_host_wait_mode 2: the library's own poll-and-sleep wait is in use). */
+const char* bp_state_warnings(const bp_state* s);
 
 /* abort_flag: nullable; polled between kernel stages (Option<Arc<AtomicBool>>, proof_gen.rs:42). */
 int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,

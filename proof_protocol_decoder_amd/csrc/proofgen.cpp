@@ -19,6 +19,7 @@
 
 using namespace bpg;
 extern "C" int bp_use_blocking_sync(int device);
+extern "C" int bp_host_wait_mode(int device);
 
 namespace {
 
@@ -68,6 +69,7 @@ struct bp_state {
   mutable std::mutex seen_mu;
   mutable std::set<mpt::H256> seen;
   mutable std::deque<mpt::H256> seen_order;
+  std::string warnings;  // bp_state_warnings: what bp_state_build found about the environment it runs in
 };
 struct bp_verifier_state {
   StarkCfg rec_cfg;
@@ -348,10 +350,36 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
     s->idle.push_back(w.get());
     s->workers.push_back(std::move(w));
   }
+  {
+    // One prover = one HIP stream, and ROCm multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues
+    // (4 when unset), read once when the HIP runtime starts: provers beyond that number share a queue and run one
+    // after the other -- the state works, at a fraction of its rate.  The library cannot raise the limit after the
+    // runtime has started, so it says so.
+    const char* env = std::getenv("GPU_MAX_HW_QUEUES");
+    const long queues = env && *env ? std::strtol(env, nullptr, 10) : 4;
+    if (queues < (long)cfg->n_workers) {
+      char buf[512];
+      std::snprintf(buf, sizeof(buf),
+                    "GPU_MAX_HW_QUEUES is %s%ld but this state has %u prover streams: HIP maps a process's streams onto that many "
+                    "hardware queues, so concurrent bp_generate_* calls beyond it serialise (measured: 16 streams on 4 queues run at "
+                    "about half the rate).  Set GPU_MAX_HW_QUEUES >= n_workers (bench.py uses 32) in the environment BEFORE the process "
+                    "makes its first HIP call.",
+                    env && *env ? "" : "unset = ", queues, cfg->n_workers);
+      s->warnings = buf;
+    }
+    if (bp_host_wait_mode(cfg->device) == 2) {
+      if (!s->warnings.empty()) s->warnings += "\n";
+      s->warnings += "The process had used this device before the library's first call, so the device's host-wait mode was left alone "
+                     "(bp_use_blocking_sync); the library's prover threads wait with their own poll-and-sleep loop instead of the "
+                     "runtime's spinning wait.  Nothing to do; call bp_use_blocking_sync(device) first thing for interrupt-driven waits.";
+    }
+  }
   *out = s.release();
   return BP_OK;
 }
 BPG_ABI_CATCH("bp_state_build")
+
+const char* bp_state_warnings(const bp_state* s) { return s ? s->warnings.c_str() : ""; }
 
 void bp_state_free(bp_state* s) {
   if (!s) return;

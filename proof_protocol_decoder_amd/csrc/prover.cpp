@@ -193,12 +193,25 @@ static std::atomic<int> g_host_wait{0};  // 0: by the device's mode; 1: always t
 void tune_host_wait(int mode) { g_host_wait.store(mode < 0 || mode > 2 ? 0 : mode); }
 extern "C" int bp_host_wait_mode(int device);
 int Worker::wait_recorded() {
+  using clock = std::chrono::steady_clock;
   const int knob = g_host_wait.load(std::memory_order_relaxed);
+  // While few provers are at work on the device (a lone transaction, the end of a shard, the aggregation tree's last
+  // levels) every host wait is on the proof's critical path and there are cores to spare: poll without sleeping for
+  // a while first -- an interrupt-driven wake-up costs 50..100 us, a poll sees the event within a few --, then wait
+  // the usual way.  Under load (six or more provers) nobody spins: the cores belong to the threads that have work.
+  if (knob != 1 && !device_loaded()) {
+    const clock::time_point t0 = clock::now();
+    for (;;) {
+      const hipError_t e = hipEventQuery(sync_event);
+      if (e == hipSuccess) return BP_OK;
+      if (e != hipErrorNotReady) return fail(BP_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(e));
+      if (clock::now() - t0 > std::chrono::microseconds(1500)) break;
+    }
+  }
   if (knob == 1 || (knob == 0 && bp_host_wait_mode(device) == 1)) {
     BPG_HIP(hipEventSynchronize(sync_event));
     return BP_OK;
   }
-  using clock = std::chrono::steady_clock;
   const clock::time_point t0 = clock::now();
   for (;;) {
     const hipError_t e = hipEventQuery(sync_event);

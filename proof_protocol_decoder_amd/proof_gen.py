@@ -44,6 +44,8 @@ def _bind():
     L.bp_state_free.restype = None
     L.bp_state_device_bytes.argtypes = [vp]
     L.bp_state_device_bytes.restype = C.c_uint64
+    L.bp_state_warnings.argtypes = [vp]
+    L.bp_state_warnings.restype = C.c_char_p
     L.bp_generate_txn_proof.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(u8p), szp]
     L.bp_generate_agg_proof.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.c_int,
                                         C.POINTER(u8p), szp]
@@ -214,6 +216,12 @@ class ProverState:
     @property
     def device_bytes(self):
         return _bind().bp_state_device_bytes(self._h)
+
+    @property
+    def warnings(self):
+        """What bp_state_build found about its environment (GPU_MAX_HW_QUEUES below n_workers, the host-wait mode
+        the device was left in); "" when there is nothing to say."""
+        return _bind().bp_state_warnings(self._h).decode("utf-8", "replace") if self._h else ""
 
     def close(self):
         if self._h:

@@ -632,6 +632,31 @@ def test_a_device_the_process_already_used_keeps_its_wait_mode():
     assert "host wait mode 2" in r.stdout
 
 
+def test_state_build_reports_too_few_hardware_queues_and_the_wait_mode():
+    """bp_state_warnings: the one run-time prerequisite of a multi-stream state that the library cannot set itself
+    (GPU_MAX_HW_QUEUES is read when the HIP runtime starts) is checked at bp_state_build and reported as text; so is
+    the host-wait mode of a device the process used first.  Fresh processes: both are per-process facts."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(steps, queues):
+        env = dict(os.environ, WD="120")
+        env.pop("GPU_MAX_HW_QUEUES", None)
+        if queues:
+            env["GPU_MAX_HW_QUEUES"] = queues
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "hang_probe.py"), steps], capture_output=True,
+                           text=True, timeout=300, cwd=root, env=env)
+        assert r.returncode == 0 and "state closed" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+        return [l for l in r.stdout.splitlines() if "state warnings:" in l][0]
+    low = run("x", "1")          # the probe's state has two prover streams
+    assert "GPU_MAX_HW_QUEUES is 1 but this state has 2 prover streams" in low and "poll-and-sleep" not in low
+    assert run("x", "8").endswith("state warnings: none")
+    used = run("t", "8")         # torch first: mode 2, reported; enough queues: not reported
+    assert "GPU_MAX_HW_QUEUES" not in used and "poll-and-sleep" in used
+
+
 RCCL_CHILD = r'''
 import os, sys
 sys.path.insert(0, {root!r})

@@ -37,6 +37,7 @@ if "s" in steps:
 if "S" in steps:
     pkg.ops.stark_prove_synthetic(pkg.ops.stark_cfg(17, 16), 1, 2); say("big stark proof")
 st = state(); say("state built")
+say("state warnings: " + (st.warnings.replace("\n", " | ") or "none"))
 p = pg.generate_txn_proof(st, pg.TxnProofGenIR(7, 0, 100, 121, (1, 2, 3, 4), 5, LOG_N, WIDTH)); say("txn proof")
 if "c" in steps:
     r = subprocess.run([sys.executable, "-c", "import torch; x=torch.zeros(10,device='cuda'); torch.cuda.synchronize(); print('child ok')"], capture_output=True, text=True); say("child: " + r.stdout.strip())
