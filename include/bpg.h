@@ -208,8 +208,11 @@ struct bp_stark_cfg;
  * a big-endian byte sequence and the word it spells on 297 columns, 6 = keccak_sponge, the absorbing side of
  * Keccak-256 (XOR into the rate, chaining, pad10*1) on 2414 columns, 7 = arithmetic_mul, x * y = z + 2^256 w on 1217
  * columns (likewise their own layouts; AIR 7 is not wired to a transaction's table: bp_stark_prove_air only).  bp_air_describe returns the shape and
- * the constraint list of an AIR as families (first index, count, kind, degree); the list is followed, for every
- * air_id, by the two constraints of each cross-table-lookup-like auxiliary column (n_cols / 8 of them). */
+ * the constraint list of an AIR as families (first index, count, kind, degree); the list is followed by the constraints
+ * of the table's auxiliary columns, its cross-table lookups (csrc/air.hpp, namespace ctl): n_cols / 8 unfiltered running
+ * products for the synthetic AIR (a load placeholder), filter + carried input + two filtered running products for
+ * keccak_f (the looked side of keccak_sponge -> keccak_f), two filtered running products for keccak_sponge (the looking
+ * side), one constant product for the tables no lookup is built for. */
 typedef struct bp_air_family {
   uint32_t first_index, count;
   uint32_t kind;   /* 0 all rows, 1 transition (x (X - g^(n-1))), 2 first row (x L_0), 3 last row (x L_(n-1)) */
@@ -225,7 +228,7 @@ typedef struct bp_air_desc {
   uint32_t n_air_constraints, n_ctl_constraints;
   uint32_t n_units;           /* independently evaluable slices of the list (the kernel's grid.y granularity) */
   uint32_t n_families;
-  bp_air_family families[16]; /* interleaved families (synthetic AIR, CTL) list the index of their first member */
+  bp_air_family families[24]; /* interleaved families (synthetic AIR, CTL) list the index of their first member */
 } bp_air_desc;
 uint32_t bp_air_count(void);
 int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t deg_pow, bp_air_desc* out);
@@ -233,7 +236,7 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
 /* K5.  Constraint / quotient evaluation on the extended domain: what compute_quotient_polys does for one table.
  * shape: log_n, n_cols, n_const, deg_pow, rate_bits of the table (the other fields must make a valid
  * configuration: use the values of the proof the quotient belongs to).  The three LDE matrices are
- * column-major and coset-major with column stride n << rate_bits (d_aux_lde: n_cols/8 columns; d_const_lde may
+ * column-major and coset-major with column stride n << rate_bits (d_aux_lde: bp_air_desc.n_aux columns; d_const_lde may
  * be NULL when n_const == 0).  ctl = beta0, gamma0, beta1, gamma1; alphas = the two constraint challenges.
  * d_scratch: bp_quotient_scratch_words(air_id, shape) words.  d_qvals_out: [2][n << rate_bits], coset-major:
  * position t*n + m = quotient value at 7 * w_{n 2^r}^(t + 2^r m), already divided by Z_H.
@@ -420,6 +423,20 @@ typedef struct bp_txn_witness {
 } bp_txn_witness;
 int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
                                   const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len);
+/* What upstream's `prove` yields before the recursion starts (its AllProof; reached from proof_gen.rs:44-52): the seven
+ * table proofs of the transaction on their ONE transcript, with the public values and the lookup challenges -- the part of
+ * bp_generate_txn_proof that the recursion-shaped proofs then digest.  data: nullable, as for
+ * bp_generate_txn_proof_witness.  Bytes (little-endian u64 words): "BPGTABLS", 7, the 13 public values, the four lookup
+ * challenges, then per table: air_id, log_n, n_cols, n_words and the table's STARK proof.
+ * bp_verify_txn_table_proofs is upstream's verify_proof(all_stark, all_proof, config) on the CPU: every table proof against
+ * the shared transcript AND the cross-table lookups between the tables that are proven with their AIRs (csrc/air.hpp,
+ * namespace ctl: keccak_sponge -> keccak_f -- what the sponge table hashes is what the Keccak-f table permutes): for both
+ * challenge sets the looking and the looked running products agree at the first row.  cfg: the STARK parameters only.
+ * The same lookup check runs inside every bp_generate_txn_proof* call (upstream's root circuit does it in-circuit): tables
+ * that do not form one statement end the call with BP_ERR_VERIFY. */
+int bp_generate_txn_table_proofs(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
+                                 const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len);
+int bp_verify_txn_table_proofs(const bp_config* cfg, const uint8_t* table_proofs, size_t len);
 /* the same call taking the reference's own flag: Arc<AtomicBool> is ONE byte, `flag.as_ptr()` binds here directly */
 int bp_generate_txn_proof_u8(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile uint8_t* abort_flag,
                              uint8_t** out, size_t* out_len);

@@ -1,0 +1,131 @@
+/* oracle/ctl.c -- cross-table lookups (CPU restatement).  TEST INFRASTRUCTURE ONLY; "parity unpinned" by the
+ * reference (see gl.h): upstream proves the seven tables of a transaction as ONE statement (one prove_root call,
+ * plonky_block_proof_gen/src/proof_gen.rs:44-52; tables prover_state.rs:85-93) and ties them with plonky2_evm's
+ * cross-table lookups, which are not under /root/reference.  The lookups here are this repository's own, written for
+ * its own column layouts:
+ *
+ *   keccak_sponge -> keccak_f: every row of the sponge table that absorbs a block claims "the permutation of (xored
+ *   rate, capacity) is (updated state)"; the Keccak-f table exposes (input, output) of the permutations it is asked for.
+ *
+ * A lookup is a pair of filtered running products z[i] = prod_{i' >= i} factor[i'], factor = (gamma + sum_j beta^j
+ * tuple_j) on the rows that take part and 1 on the others; the statement holds when the first-row values agree, for
+ * both challenge sets (beta_0, gamma_0), (beta_1, gamma_1).  Auxiliary columns per table:
+ *   synthetic  n_cols / 8   unfiltered products over trace columns 8k, 8k + 1 (a load placeholder; stark.c)
+ *   keccak_f   5            g (row takes part: last round of an exposed permutation), h_0, h_1 (the permutation's 50
+ *                           input limbs compressed by beta_c, the same value on all its rows), z_0, z_1
+ *   sponge     2            z_0, z_1
+ *   others     1            the constant 1
+ * This file computes the columns by their meaning (if / else per row, explicit powers) and states the constraints as
+ * polynomials; the product (csrc/air.hpp, namespace ctl) evaluates the same polynomials by Horner's rule. */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+enum { KCOL_STEP = 0, KCOL_A = 24, KCOL_APP = 2314, KCOL_APPP = 2428 };
+enum { SCOL_FULL = 0, SCOL_FINAL = 1, SCOL_CAP = 2314, SCOL_XORED = 2330, SCOL_UPDATED = 2364 };
+
+uint32_t orc_ctl_n_aux(uint32_t air_id, uint32_t n_cols) {
+  return air_id == ORC_AIR_SYNTHETIC ? n_cols / 8 : air_id == ORC_AIR_KECCAK_F ? 5 : air_id == ORC_AIR_KECCAK_SPONGE ? 2 : 1;
+}
+
+/* The auxiliary columns of a table with a real AIR, from its trace values tv ([n_cols][N], column-major).
+ * exposed (Keccak-f only, nullable): exposed[p] != 0 when permutation p is asked for, n_exposed entries. */
+void orc_ctl_aux_columns(uint32_t air_id, const gl_t* tv, unsigned log_n, const gl_t ctl[4], const uint8_t* exposed,
+                         size_t n_exposed, gl_t* aux) {
+  const size_t N = (size_t)1 << log_n;
+  if (air_id == ORC_AIR_KECCAK_F) {
+    gl_t *g = aux, *h[2] = {aux + N, aux + 2 * N}, *z[2] = {aux + 3 * N, aux + 4 * N};
+    for (size_t i = 0; i < N; i++) g[i] = (i % 24 == 23 && exposed && i / 24 < n_exposed && exposed[i / 24]) ? 1 : 0;
+    for (int c = 0; c < 2; c++) {
+      const gl_t beta = ctl[2 * c], gamma = ctl[2 * c + 1];
+      gl_t pw[100];
+      pw[0] = 1;
+      for (int j = 1; j < 100; j++) pw[j] = gl_mul(pw[j - 1], beta);
+#pragma omp parallel for schedule(static)
+      for (size_t p = 0; p < (N + 23) / 24; p++) { /* the compressed input, on every row of the permutation */
+        gl_t acc = 0;
+        for (int j = 0; j < 50; j++) acc = gl_add(acc, gl_mul(pw[j], tv[(size_t)(KCOL_A + j) * N + 24 * p]));
+        for (size_t i = 24 * p; i < 24 * p + 24 && i < N; i++) h[c][i] = acc;
+      }
+      gl_t run = 1;
+      for (size_t i = N; i-- > 0;) {
+        if (g[i]) {
+          gl_t tuple = h[c][i];
+          for (int j = 0; j < 50; j++) {
+            const size_t col = j < 2 ? KCOL_APPP + j : KCOL_APP + j;
+            tuple = gl_add(tuple, gl_mul(pw[50 + j], tv[col * N + i]));
+          }
+          run = gl_mul(run, gl_add(gamma, tuple));
+        }
+        z[c][i] = run;
+      }
+    }
+    return;
+  }
+  if (air_id == ORC_AIR_KECCAK_SPONGE) {
+    for (int c = 0; c < 2; c++) {
+      const gl_t beta = ctl[2 * c], gamma = ctl[2 * c + 1];
+      gl_t pw[100], *z = aux + (size_t)c * N, run = 1;
+      pw[0] = 1;
+      for (int j = 1; j < 100; j++) pw[j] = gl_mul(pw[j - 1], beta);
+      for (size_t i = N; i-- > 0;) {
+        if (tv[(size_t)SCOL_FULL * N + i] || tv[(size_t)SCOL_FINAL * N + i]) {
+          gl_t tuple = 0;
+          for (int j = 0; j < 34; j++) tuple = gl_add(tuple, gl_mul(pw[j], tv[(size_t)(SCOL_XORED + j) * N + i]));
+          for (int j = 0; j < 16; j++) tuple = gl_add(tuple, gl_mul(pw[34 + j], tv[(size_t)(SCOL_CAP + j) * N + i]));
+          for (int j = 0; j < 50; j++) tuple = gl_add(tuple, gl_mul(pw[50 + j], tv[(size_t)(SCOL_UPDATED + j) * N + i]));
+          run = gl_mul(run, gl_add(gamma, tuple));
+        }
+        z[i] = run;
+      }
+    }
+    return;
+  }
+  for (size_t i = 0; i < N; i++) aux[i] = 1;
+}
+
+/* ---- constraints, base field ---- */
+#define FT gl_t
+#define FK(c) ((gl_t)(c))
+#define FADD gl_add
+#define FSUB gl_sub
+#define FMUL gl_mul
+#define FSCALE(a, s) gl_mul(a, s)
+#define FNAME(n) cb_##n
+#define CONS_T orc_consumer
+#define CONS_ALL(k, c) orc_cons(k, c)
+#define CONS_TRANS(k, c) orc_cons(k, gl_mul(c, (k)->z_last))
+#define CONS_LAST(k, c) orc_cons(k, gl_mul(c, (k)->l_last))
+#include "ctl_body.inc"
+#undef FT
+#undef FK
+#undef FADD
+#undef FSUB
+#undef FMUL
+#undef FSCALE
+#undef FNAME
+#undef CONS_T
+#undef CONS_ALL
+#undef CONS_TRANS
+#undef CONS_LAST
+void orc_ctl_constraints_base(uint32_t air_id, const gl_t* loc, const gl_t* aux, const gl_t* aux_nxt, const gl_t ctl[4],
+                              orc_consumer* k) {
+  cb_ctl_constraints(air_id, loc, aux, aux_nxt, ctl, k);
+}
+/* ---- the same over the extension ---- */
+#define FT gl2_t
+#define FK(c) gl2_from((gl_t)(c))
+#define FADD gl2_add
+#define FSUB gl2_sub
+#define FMUL gl2_mul
+#define FSCALE(a, s) gl2_scale(a, s)
+#define FNAME(n) ce_##n
+#define CONS_T orc_consumer2
+#define CONS_ALL(k, c) orc_cons2(k, c)
+#define CONS_TRANS(k, c) orc_cons2(k, gl2_mul(c, (k)->z_last))
+#define CONS_LAST(k, c) orc_cons2(k, gl2_mul(c, (k)->l_last))
+#include "ctl_body.inc"
+void orc_ctl_constraints_ext(uint32_t air_id, const gl2_t* loc, const gl2_t* aux, const gl2_t* aux_nxt, const gl_t ctl[4],
+                             orc_consumer2* k) {
+  ce_ctl_constraints(air_id, loc, aux, aux_nxt, ctl, k);
+}

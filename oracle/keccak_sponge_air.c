@@ -60,6 +60,11 @@ size_t orc_keccak_sponge_rows(const uint8_t* msg, size_t len, uint64_t* rows, ui
  * row r is a single-block message drawn from the seed -- h(c) = smix(seed ^ (c << 32) ^ r); h(0xD3) % 8 == 0: padding
  * row; else len = h(0xD0) % 136, message word w = h(0xD1 + (w << 8)), state before = 0. */
 void orc_keccak_sponge_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* t) {
+  orc_keccak_sponge_trace_limit(seed, inputs, log_n, (size_t)-1, t);
+}
+/* row_limit: a seeded table asks for no more permutations than the transaction's Keccak-f table holds in full (ctl.c):
+ * seeded rows from row_limit on are padding rows */
+void orc_keccak_sponge_trace_limit(uint64_t seed, const uint64_t* inputs, unsigned log_n, size_t row_limit, gl_t* t) {
   const size_t n = (size_t)1 << log_n;
 #pragma omp parallel for schedule(static)
   for (size_t r = 0; r < n; r++) {
@@ -72,7 +77,7 @@ void orc_keccak_sponge_trace(uint64_t seed, const uint64_t* inputs, unsigned log
     } else {
       memset(st, 0, sizeof(st));
       memset(blk, 0, sizeof(blk));
-      if (smix(seed ^ (0xD3ULL << 32) ^ r) % 8 == 0) { flags = 0; len = 0; }
+      if (smix(seed ^ (0xD3ULL << 32) ^ r) % 8 == 0 || r >= row_limit) { flags = 0; len = 0; }
       else {
         flags = 2; len = smix(seed ^ (0xD0ULL << 32) ^ r) % 136;
         uint8_t* b = (uint8_t*)blk;

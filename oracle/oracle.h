@@ -137,12 +137,23 @@ void orc_byte_packing_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_co
 /* keccak_sponge_air.c */
 size_t orc_keccak_sponge_rows(const uint8_t* msg, size_t len, uint64_t* rows, uint8_t* digest);
 void orc_keccak_sponge_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
+/* the same; rows of a SEEDED table from row_limit on are padding rows */
+void orc_keccak_sponge_trace_limit(uint64_t seed, const uint64_t* inputs, unsigned log_n, size_t row_limit, gl_t* trace);
 void orc_keccak_sponge_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
 void orc_keccak_sponge_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
 /* arithmetic_mul_air.c */
 void orc_arithmetic_mul_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
 void orc_arithmetic_mul_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
 void orc_arithmetic_mul_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
+
+/* ctl.c: the cross-table lookups (auxiliary columns) of the tables with a real AIR */
+uint32_t orc_ctl_n_aux(uint32_t air_id, uint32_t n_cols);
+void orc_ctl_aux_columns(uint32_t air_id, const gl_t* trace_values, unsigned log_n, const gl_t ctl[4], const uint8_t* exposed,
+                         size_t n_exposed, gl_t* aux);
+void orc_ctl_constraints_base(uint32_t air_id, const gl_t* loc, const gl_t* aux, const gl_t* aux_nxt, const gl_t ctl[4],
+                              orc_consumer* k);
+void orc_ctl_constraints_ext(uint32_t air_id, const gl2_t* loc, const gl2_t* aux, const gl2_t* aux_nxt, const gl_t ctl[4],
+                             orc_consumer2* k);
 
 uint32_t orc_cfg_n_aux(const orc_stark_cfg* c);
 uint32_t orc_cfg_n_quot(const orc_stark_cfg* c);
@@ -176,6 +187,11 @@ void orc_committed_free(orc_committed* c);
  * Returns 0 on success. proof_out has orc_proof_words(cfg) words. */
 int orc_stark_prove(const orc_stark_cfg* cfg, const orc_committed* consts, const orc_committed* trace,
                     const gl_t* trace_values, const gl_t ctl[4], orc_challenger* ch, gl_t* proof_out);
+/* The same for a LOOKED table: exposed[p] != 0 when permutation p of a Keccak-f table is asked for by the transaction's
+ * sponge table (ctl.c); n_exposed entries, NULL: nothing is exposed. */
+int orc_stark_prove_lookup(const orc_stark_cfg* cfg, const orc_committed* consts, const orc_committed* trace,
+                           const gl_t* trace_values, const gl_t ctl[4], orc_challenger* ch, gl_t* proof_out,
+                           const uint8_t* exposed, size_t n_exposed);
 /* Verify; the caller must have driven `ch` identically (caps observed etc.). 0 = accept. */
 int orc_stark_verify(const orc_stark_cfg* cfg, const gl_t* const_cap, const gl_t ctl[4],
                      orc_challenger* ch, const gl_t* proof);

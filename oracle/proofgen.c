@@ -132,6 +132,7 @@ int orc_pg_preprocess(orc_pg_state* s, const uint64_t* I) {
 /* witness data per table (NULL: drawn from the seed): items[t] x n[t], WIT_WORDS[t] words each */
 typedef struct { const uint64_t* items[NUM_TABLES]; size_t n[NUM_TABLES]; } pg_witness;
 static const unsigned WIT_WORDS[NUM_TABLES] = {9, 6, 0, 25, 44, 9, 11};
+int orc_pg_check_lookups(const orc_stark_cfg tcfg[NUM_TABLES], const gl_t* const proofs[NUM_TABLES]);
 static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_t** out, size_t* out_words);
 int orc_pg_txn(orc_pg_state* s, const uint64_t* I, gl_t** out, size_t* out_words) { return pg_txn(s, I, NULL, out, out_words); }
 /* the same with the Keccak table's permutation inputs given (n_perms x 25 lanes; the rest of the table: zero states) */
@@ -175,7 +176,15 @@ static uint64_t* padded_items(int t, size_t rows, const uint64_t* items, size_t 
   }
   return in;
 }
-static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_t** out, size_t* out_words) {
+/* Test hook: 0 makes the PROVER skip its own lookup check, so that tests can hand table proofs that do not form one
+ * statement to the verifiers (which always check). */
+static int g_prover_checks_lookups = 1;
+void orc_pg_set_prover_lookup_check(int on) { g_prover_checks_lookups = on != 0; }
+
+/* The seven table proofs of a transaction on their one transcript (upstream's `prove`: AllProof), their shapes, the
+ * public values and the lookup challenges.  proofs[t] is malloc'ed. */
+static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, orc_stark_cfg tcfg[NUM_TABLES],
+                     gl_t pv[PV_WORDS], gl_t ctl[4], gl_t* proofs[NUM_TABLES]) {
   const orc_pg_config* cfg = &s->cfg;
   /* version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520: "Txn numbers before/after",
    * "Gas used before/after" equal, tries unchanged) -- same tables proven, public values do not advance */
@@ -192,7 +201,6 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
             arithmetic_air = (int)((flags >> 3) & 1), byte_packing_air = (int)((flags >> 4) & 1),
             sponge_air = (int)((flags >> 5) & 1);
   if (dummy && I[4] != I[5]) return -2;
-  orc_stark_cfg tcfg[NUM_TABLES];
   for (int t = 0; t < NUM_TABLES; t++) {
     if (I[11 + t] < cfg->table_log_lo[t] || I[11 + t] >= cfg->table_log_hi[t]) return -3;
     tcfg[t] = table_cfg_of(cfg, (uint32_t)I[11 + t], (uint32_t)I[18 + t]);
@@ -229,7 +237,6 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
       if (!has_air[t] || wit->n[t] > (t == 3 ? (rows + 23) / 24 : rows)) return -3;
     }
   }
-  gl_t pv[PV_WORDS];
   pv[0] = I[3]; pv[1] = I[3] + (dummy ? 0 : 1); pv[2] = I[4]; pv[3] = I[5];
   memcpy(pv + 4, I + 6, 32);
   gl_t in6[6] = {I[6], I[7], I[8], I[9], gl_canon(I[10]), gl_canon(I[3])};
@@ -242,7 +249,15 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
   orc_committed* tc[NUM_TABLES];
   orc_challenger ch;
   orc_ch_init(&ch);
-  for (int t = 0; t < NUM_TABLES; t++) {
+  /* The lookup keccak_sponge -> keccak_f (ctl.c) makes two real tables one statement.  Seeded tables are drawn so that
+   * it holds: the sponge table absorbs blocks only in rows whose permutation the Keccak-f table holds in full, and
+   * permutation p of the Keccak-f table is the one sponge row p asks for.  Tables given by the caller are taken as
+   * they are (and refused below if they disagree). */
+  const int lookup_kf = keccak_air && sponge_air;
+  const size_t kf_full_perms = ((size_t)1 << tcfg[3].log_n) / 24;
+  static const int order[NUM_TABLES] = {4, 0, 1, 2, 3, 5, 6}; /* the sponge table first: the Keccak-f table reads it */
+  for (int oi = 0; oi < NUM_TABLES; oi++) {
+    const int t = order[oi];
     size_t n = (size_t)1 << tcfg[t].log_n;
     trace[t] = (gl_t*)malloc(tcfg[t].n_cols * n * sizeof(gl_t));
     if (wit && wit->items[t] && tcfg[t].air_id != ORC_AIR_SYNTHETIC) {
@@ -254,29 +269,162 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
       else if (t == 4) orc_keccak_sponge_trace(0, in, tcfg[t].log_n, trace[t]);
       else orc_byte_packing_trace(0, in, tcfg[t].log_n, trace[t]);
       free(in);
+    } else if (tcfg[t].air_id == ORC_AIR_KECCAK_F && lookup_kf) {
+      /* permutation p: what sponge row p asks for, if it absorbs a block; else drawn from the seed as usual */
+      const uint64_t seed = I[10] ^ splitmix64(t + 1);
+      const size_t n_perm = (n + 23) / 24, ns = (size_t)1 << tcfg[4].log_n;
+      uint64_t* in = (uint64_t*)malloc(n_perm * 25 * 8);
+      for (size_t p = 0; p < n_perm; p++) {
+        const int asked = p < ns && (trace[4][0 * ns + p] || trace[4][1 * ns + p]);
+        for (int l = 0; l < 25; l++) {
+          if (asked) {
+            const size_t col = l < 17 ? 2330 + 2 * (size_t)l : 2314 + 2 * (size_t)(l - 17); /* xored rate | capacity limbs */
+            in[p * 25 + l] = trace[4][col * ns + p] | (trace[4][(col + 1) * ns + p] << 32);
+          } else {
+            in[p * 25 + l] = splitmix64(seed ^ ((uint64_t)l << 32) ^ p);
+          }
+        }
+      }
+      orc_keccak_trace(0, in, tcfg[t].log_n, trace[t]);
+      free(in);
     } else if (tcfg[t].air_id == ORC_AIR_KECCAK_F) orc_keccak_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_LOGIC) orc_logic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_MEMORY) orc_memory_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_ARITHMETIC) orc_arithmetic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_BYTE_PACKING) orc_byte_packing_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
-    else if (tcfg[t].air_id == ORC_AIR_KECCAK_SPONGE) orc_keccak_sponge_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
+    else if (tcfg[t].air_id == ORC_AIR_KECCAK_SPONGE)
+      orc_keccak_sponge_trace_limit(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, lookup_kf ? kf_full_perms : (size_t)-1, trace[t]);
     else orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
+  }
+  for (int t = 0; t < NUM_TABLES; t++) {
     tc[t] = orc_commit_values(trace[t], tcfg[t].log_n, tcfg[t].n_cols, tcfg[t].rate_bits, tcfg[t].cap_height);
     orc_ch_observe_many(&ch, orc_committed_cap(tc[t]), (size_t)4 << tcfg[t].cap_height);
   }
   orc_ch_observe_many(&ch, pv, PV_WORDS);
-  gl_t ctl[4];
   for (int i = 0; i < 4; i++) ctl[i] = orc_ch_challenge(&ch);
-  gl_t digest[NUM_TABLES][4];
   int rc = 0;
+  for (int t = 0; t < NUM_TABLES; t++) proofs[t] = NULL;
   for (int t = 0; t < NUM_TABLES && !rc; t++) {
-    gl_t* proof = (gl_t*)malloc(orc_proof_words(&tcfg[t]) * sizeof(gl_t));
-    rc = orc_stark_prove(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proof);
-    if (!rc) orc_proof_digest(&tcfg[t], proof, digest[t]);
-    free(proof);
+    proofs[t] = (gl_t*)malloc(orc_proof_words(&tcfg[t]) * sizeof(gl_t));
+    if (t == 3 && lookup_kf) { /* the Keccak-f table exposes the permutations the sponge rows ask for, row p <-> permutation p */
+      const size_t ns = (size_t)1 << tcfg[4].log_n;
+      uint8_t* exposed = (uint8_t*)malloc(ns);
+      for (size_t p = 0; p < ns; p++) exposed[p] = trace[4][p] || trace[4][ns + p];
+      rc = orc_stark_prove_lookup(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t], exposed, ns);
+      free(exposed);
+    } else {
+      rc = orc_stark_prove(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t]);
+    }
   }
   for (int t = 0; t < NUM_TABLES; t++) { orc_committed_free(tc[t]); free(trace[t]); }
+  if (!rc && g_prover_checks_lookups) rc = orc_pg_check_lookups(tcfg, (const gl_t* const*)proofs);
+  if (rc) for (int t = 0; t < NUM_TABLES; t++) { free(proofs[t]); proofs[t] = NULL; }
+  return rc;
+}
+
+/* Offsets of the first-row openings of the auxiliary columns inside a table proof (stark.c layout): after the 16-word
+ * header, three caps, the openings at zeta (all columns + quotient chunks) and at g*zeta (trace + aux). */
+static size_t open_first_offset(const orc_stark_cfg* c) {
+  const size_t cap = (size_t)4 << c->cap_height, A = orc_cfg_n_aux(c), Q = orc_cfg_n_quot(c);
+  return 16 + 3 * cap + 2 * ((size_t)c->n_const + c->n_cols + A + Q) + 2 * ((size_t)c->n_cols + A);
+}
+/* The lookups between the tables of one transaction (ctl.c): the sponge table's running product and the Keccak-f
+ * table's agree at the first row, for both challenge sets.  -11: they do not. */
+int orc_pg_check_lookups(const orc_stark_cfg tcfg[NUM_TABLES], const gl_t* const proofs[NUM_TABLES]) {
+  if (tcfg[3].air_id == ORC_AIR_KECCAK_F && tcfg[4].air_id == ORC_AIR_KECCAK_SPONGE) {
+    const gl_t* looking = proofs[4] + open_first_offset(&tcfg[4]); /* z_0, z_1 are its aux columns 0, 1 */
+    const gl_t* looked = proofs[3] + open_first_offset(&tcfg[3]);  /* ... and columns 3, 4 here */
+    for (int c = 0; c < 2; c++)
+      if (looking[2 * c] != looked[2 * (3 + c)] || looking[2 * c + 1] != looked[2 * (3 + c) + 1]) return -11;
+  }
+  return 0;
+}
+
+#define TABLES_MAGIC 0x534C424154475042ULL /* "BPGTABLS" */
+/* the table proofs alone, as libbpg's bp_generate_txn_table_proofs emits them */
+static int pg_txn_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_t** out, size_t* out_words) {
+  orc_stark_cfg tcfg[NUM_TABLES];
+  gl_t pv[PV_WORDS], ctl[4], *proofs[NUM_TABLES];
+  int rc = pg_tables(s, I, wit, tcfg, pv, ctl, proofs);
   if (rc) return rc;
+  size_t words = 2 + PV_WORDS + 4;
+  for (int t = 0; t < NUM_TABLES; t++) words += 4 + orc_proof_words(&tcfg[t]);
+  gl_t* o = (gl_t*)malloc(words * sizeof(gl_t));
+  size_t off = 0;
+  o[off++] = TABLES_MAGIC; o[off++] = NUM_TABLES;
+  memcpy(o + off, pv, sizeof(pv)); off += PV_WORDS;
+  memcpy(o + off, ctl, 32); off += 4;
+  for (int t = 0; t < NUM_TABLES; t++) {
+    const size_t pw = orc_proof_words(&tcfg[t]);
+    o[off++] = tcfg[t].air_id; o[off++] = tcfg[t].log_n; o[off++] = tcfg[t].n_cols; o[off++] = pw;
+    memcpy(o + off, proofs[t], pw * 8); off += pw;
+    free(proofs[t]);
+  }
+  *out = o; *out_words = words;
+  return 0;
+}
+int orc_pg_txn_tables(orc_pg_state* s, const uint64_t* I, const uint64_t* const items[NUM_TABLES], const size_t n[NUM_TABLES],
+                      const int given[NUM_TABLES], gl_t** out, size_t* out_words) {
+  static const uint64_t none = 0;
+  pg_witness w;
+  memset(&w, 0, sizeof(w));
+  int any = 0;
+  for (int t = 0; t < NUM_TABLES; t++)
+    if (given && given[t] && WIT_WORDS[t]) {
+      w.items[t] = items[t] ? items[t] : &none;
+      w.n[t] = n[t];
+      any = 1;
+    }
+  return pg_txn_tables(s, I, any ? &w : NULL, out, out_words);
+}
+/* upstream's verify_proof(all_stark, all_proof, config): every table proof against the shared transcript, then the
+ * lookups between the tables.  0 = accept; the first failing table t gives -(100 + 20 t) + (the table verifier's code). */
+int orc_pg_verify_tables(const orc_pg_config* cfg, const gl_t* w, size_t words) {
+  if (words < 2 + PV_WORDS + 4 || w[0] != TABLES_MAGIC || w[1] != NUM_TABLES) return -2;
+  const gl_t *pv = w + 2, *ctl_in = pv + PV_WORDS;
+  orc_stark_cfg tcfg[NUM_TABLES];
+  const gl_t* proofs[NUM_TABLES];
+  size_t off = 2 + PV_WORDS + 4;
+  static const uint32_t table_air[NUM_TABLES] = {ORC_AIR_ARITHMETIC, ORC_AIR_BYTE_PACKING, 0xFFFFFFFFu, ORC_AIR_KECCAK_F,
+                                                 ORC_AIR_KECCAK_SPONGE, ORC_AIR_LOGIC, ORC_AIR_MEMORY};
+  for (int t = 0; t < NUM_TABLES; t++) {
+    if (off + 4 > words) return -2;
+    if (w[off] != ORC_AIR_SYNTHETIC && w[off] != table_air[t]) return -5;
+    if (w[off + 1] > 30 || w[off + 2] > 65536) return -2;
+    tcfg[t] = table_cfg_of(cfg, (uint32_t)w[off + 1], (uint32_t)w[off + 2]);
+    tcfg[t].air_id = (uint32_t)w[off];
+    if (w[off + 3] != orc_proof_words(&tcfg[t]) || off + 4 + w[off + 3] > words) return -2;
+    proofs[t] = w + off + 4;
+    off += 4 + w[off + 3];
+  }
+  if (off != words) return -2;
+  orc_challenger ch;
+  orc_ch_init(&ch);
+  for (int t = 0; t < NUM_TABLES; t++) orc_ch_observe_many(&ch, proofs[t] + 16, (size_t)4 << tcfg[t].cap_height);
+  orc_ch_observe_many(&ch, pv, PV_WORDS);
+  gl_t ctl[4];
+  for (int i = 0; i < 4; i++) {
+    ctl[i] = orc_ch_challenge(&ch);
+    if (ctl[i] != ctl_in[i]) return -6;
+  }
+  for (int t = 0; t < NUM_TABLES; t++) {
+    int rc = orc_stark_verify(&tcfg[t], NULL, ctl, &ch, proofs[t]);
+    if (rc) return -(100 + 20 * t) + rc;
+  }
+  return orc_pg_check_lookups(tcfg, proofs);
+}
+
+static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_t** out, size_t* out_words) {
+  const orc_pg_config* cfg = &s->cfg;
+  orc_stark_cfg tcfg[NUM_TABLES];
+  gl_t pv[PV_WORDS], ctl[4], *tproofs[NUM_TABLES];
+  int rc = pg_tables(s, I, wit, tcfg, pv, ctl, tproofs);
+  if (rc) return rc;
+  gl_t digest[NUM_TABLES][4];
+  for (int t = 0; t < NUM_TABLES; t++) {
+    orc_proof_digest(&tcfg[t], tproofs[t], digest[t]);
+    free(tproofs[t]);
+  }
   size_t sw = orc_proof_words(&s->rec);
   gl_t* proof = (gl_t*)malloc(sw * sizeof(gl_t));
   for (int t = 0; t < NUM_TABLES && !rc; t++) {

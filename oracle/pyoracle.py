@@ -119,6 +119,11 @@ def lib():
     L.orc_pg_txn_keccak.argtypes = [vp, u64p, vp, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_txn_witness.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                      C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_pg_txn_tables.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
+                                    C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_pg_verify_tables.argtypes = [C.POINTER(PgConfig), u64p, sz]
+    L.orc_ctl_n_aux.argtypes = [u, u]
+    L.orc_ctl_n_aux.restype = C.c_uint32
     L.orc_pg_preprocess.argtypes = [vp, u64p]
     L.orc_pg_agg.argtypes = [vp, u64p, sz, i, u64p, sz, i, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_block.argtypes = [vp, vp, sz, u64p, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
@@ -464,6 +469,26 @@ class PgState:
         if rc:
             raise RuntimeError("orc_pg_txn failed: %d" % rc)
         return self._take(ptr, n)
+
+    def txn_tables(self, ir_words, witness=None):
+        """The seven table proofs of the transaction alone (upstream's AllProof; orc_pg_txn_tables), in the byte form of
+        libbpg's bp_generate_txn_table_proofs.  witness as for txn()."""
+        ptr, n = C.POINTER(C.c_uint64)(), C.c_size_t()
+        keep, items, counts, given = [], (C.c_void_p * 7)(), (C.c_size_t * 7)(), (C.c_int * 7)()
+        for t, data in (witness or {}).items():
+            a = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, self.WITNESS_WORDS[t])
+            keep.append(a)
+            items[t], counts[t], given[t] = (a.ctypes.data if a.size else None), a.shape[0], 1
+        rc = lib().orc_pg_txn_tables(self.h, arr(ir_words), items, counts, given, C.byref(ptr), C.byref(n))
+        if rc:
+            raise RuntimeError("orc_pg_txn_tables failed: %d" % rc)
+        return self._take(ptr, n)
+
+    def verify_tables(self, table_proofs):
+        """upstream's verify_proof on the table proofs: each table against the shared transcript, then the cross-table
+        lookups (oracle/ctl.c).  0 = accept."""
+        w = arr(table_proofs)
+        return lib().orc_pg_verify_tables(C.byref(self.cfg), w, w.size)
 
     def agg(self, lhs, lhs_is_agg, rhs, rhs_is_agg):
         ptr, n = C.POINTER(C.c_uint64)(), C.c_size_t()

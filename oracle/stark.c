@@ -31,7 +31,7 @@ static void* xmalloc(size_t n) {
 }
 
 /* ------------------------------------------------------------------ shape helpers */
-uint32_t orc_cfg_n_aux(const orc_stark_cfg* c) { return c->n_cols / 8; }
+uint32_t orc_cfg_n_aux(const orc_stark_cfg* c) { return orc_ctl_n_aux(c->air_id, c->n_cols); } /* ctl.c */
 uint32_t orc_cfg_n_quot(const orc_stark_cfg* c) { return 2u << c->rate_bits; } /* 2 challenges x qdf */
 /* FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) */
 uint32_t orc_cfg_n_layers(const orc_stark_cfg* c) {
@@ -162,7 +162,7 @@ static void eval_constraints_base(const orc_stark_cfg* cf, const gl_t* cst, cons
                                   const gl_t* nxt, const gl_t* aux, const gl_t* aux_nxt,
                                   const gl_t ctl[4], consumer_t* k) {
   size_t G = cf->n_cols / 4, A = cf->n_cols / 8;
-  if (cf->air_id == ORC_AIR_KECCAK_F) { /* the AIR's own list (keccak_air.c), then the CTL part below */
+  if (cf->air_id == ORC_AIR_KECCAK_F) { /* the AIR's own list (keccak_air.c), then the table's lookups (ctl.c) */
     orc_keccak_constraints_base(loc, nxt, k);
     G = 0;
   } else if (cf->air_id == ORC_AIR_LOGIC) {
@@ -193,6 +193,7 @@ static void eval_constraints_base(const orc_stark_cfg* cf, const gl_t* cst, cons
     cons(k, gl_mul(gl_sub(gl_sub(nxt[4 * g + 3], t), b), k->z_last));
     cons(k, gl_mul(gl_sub(gl_sub(d, a), b), k->l_first));
   }
+  if (cf->air_id != ORC_AIR_SYNTHETIC) { orc_ctl_constraints_base(cf->air_id, loc, aux, aux_nxt, ctl, k); return; }
   for (size_t j = 0; j < A; j++) {
     gl_t beta = ctl[2 * (j & 1)], gamma = ctl[2 * (j & 1) + 1];
     gl_t term = gl_add(gl_add(gamma, loc[8 * j]), gl_mul(beta, loc[8 * j + 1]));
@@ -239,6 +240,7 @@ static void eval_constraints_ext(const orc_stark_cfg* cf, const gl2_t* cst, cons
     cons2(k, gl2_mul(gl2_sub(gl2_sub(nxt[4 * g + 3], t), b), k->z_last));
     cons2(k, gl2_mul(gl2_sub(gl2_sub(d, a), b), k->l_first));
   }
+  if (cf->air_id != ORC_AIR_SYNTHETIC) { orc_ctl_constraints_ext(cf->air_id, loc, aux, aux_nxt, ctl, k); return; }
   for (size_t j = 0; j < A; j++) {
     gl_t beta = ctl[2 * (j & 1)], gamma = ctl[2 * (j & 1) + 1];
     gl2_t term = gl2_add(gl2_add(gl2_from(gamma), loc[8 * j]), gl2_scale(loc[8 * j + 1], beta));
@@ -335,6 +337,12 @@ void orc_quotient_values(const orc_stark_cfg* cf, const gl_t* const_lde, const g
 
 int orc_stark_prove(const orc_stark_cfg* cf, const orc_committed* consts, const orc_committed* trace,
                     const gl_t* tv, const gl_t ctl[4], orc_challenger* ch, gl_t* proof) {
+  return orc_stark_prove_lookup(cf, consts, trace, tv, ctl, ch, proof, NULL, 0);
+}
+/* exposed (nullable; Keccak-f table only): which permutations a looking table asks for (ctl.c) */
+int orc_stark_prove_lookup(const orc_stark_cfg* cf, const orc_committed* consts, const orc_committed* trace,
+                           const gl_t* tv, const gl_t ctl[4], orc_challenger* ch, gl_t* proof, const uint8_t* exposed,
+                           size_t n_exposed) {
   layout_t L = layout(cf);
   const unsigned log_n = cf->log_n, r = cf->rate_bits, h = cf->cap_height, log_m = log_n + r;
   const size_t N = (size_t)1 << log_n, M = N << r, C = cf->n_cols, K = cf->n_const, A = L.n_aux,
@@ -356,15 +364,20 @@ int orc_stark_prove(const orc_stark_cfg* cf, const orc_committed* consts, const 
   proof[14] = cf->air_id;
   memcpy(proof + L.trace_cap, orc_committed_cap(trace), L.cap_words * 8);
 
-  /* 1. auxiliary (CTL-Z-like) columns: suffix products of term = gamma + a + beta*b */
+  /* 1. auxiliary columns.  Synthetic table: suffix products of term = gamma + a + beta*b; a table with a real AIR:
+   * its lookups (ctl.c) */
   gl_t* auxv = (gl_t*)xmalloc(A * N * sizeof(gl_t));
+  if (cf->air_id != ORC_AIR_SYNTHETIC) {
+    orc_ctl_aux_columns(cf->air_id, tv, log_n, ctl, exposed, n_exposed, auxv);
+  } else {
 #pragma omp parallel for
-  for (size_t k = 0; k < A; k++) {
-    const gl_t *a = tv + (8 * k) * N, *b = a + N;
-    gl_t beta = ctl[2 * (k & 1)], gamma = ctl[2 * (k & 1) + 1], *z = auxv + k * N;
-    z[N - 1] = gl_add(gl_add(gamma, a[N - 1]), gl_mul(beta, b[N - 1]));
-    for (size_t i = N - 1; i-- > 0;)
-      z[i] = gl_mul(z[i + 1], gl_add(gl_add(gamma, a[i]), gl_mul(beta, b[i])));
+    for (size_t k = 0; k < A; k++) {
+      const gl_t *a = tv + (8 * k) * N, *b = a + N;
+      gl_t beta = ctl[2 * (k & 1)], gamma = ctl[2 * (k & 1) + 1], *z = auxv + k * N;
+      z[N - 1] = gl_add(gl_add(gamma, a[N - 1]), gl_mul(beta, b[N - 1]));
+      for (size_t i = N - 1; i-- > 0;)
+        z[i] = gl_mul(z[i + 1], gl_add(gl_add(gamma, a[i]), gl_mul(beta, b[i])));
+    }
   }
   orc_committed* aux = orc_commit_values(auxv, log_n, A, r, h);
   free(auxv);

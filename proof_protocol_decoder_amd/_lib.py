@@ -36,7 +36,7 @@ class AirDesc(C.Structure):
     _fields_ = ([("air_id", C.c_uint32), ("name", C.c_char * 24)]
                 + [(n, C.c_uint32) for n in ("fixed_n_cols", "n_const_max", "degree", "n_cols", "n_aux",
                                              "n_air_constraints", "n_ctl_constraints", "n_units", "n_families")]
-                + [("families", AirFamily * 16)])
+                + [("families", AirFamily * 24)])
 
 
 def take_buffer(ptr, length):

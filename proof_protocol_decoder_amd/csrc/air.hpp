@@ -42,9 +42,8 @@
 // AIR 7  arithmetic_mul  the multiplicative half of the arithmetic table: x * y = z + 2^256 w on 256-bit words, a 32-column
 //                      schoolbook product over sixteen 16-bit limbs with 21-bit carries, 1217 columns, degree 3.  A
 //                      table of its own here: merged into AIR 4's rows it would add 900 columns to every addition.
-// The cross-table-lookup-like auxiliary columns (running products over trace columns 8k, 8k+1) are a property of
-// the protocol, not of an AIR (as upstream's CTL checks sit beside Stark::eval): their constraints follow the AIR's
-// in the list for every air_id.
+// The auxiliary columns of a table are its cross-table lookups (namespace ctl below; upstream's CTL checks sit beside
+// Stark::eval the same way): their constraints follow the AIR's in the list.
 #pragma once
 #include <cstdint>
 #include "gl.hpp"
@@ -842,22 +841,146 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
-// Cross-table-lookup-like running products (protocol level, every air_id): aux column k over trace columns 8k, 8k+1
-// with the challenge set (beta, gamma) = ctl[k mod 2]:  term = gamma + a + beta * b
-//   index base + 2k     transition  z - z' * term
-//   index base + 2k+1   last row    z - term
-template <class T, class Row, class Emit>
-GL_HD void eval_ctl(uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ctl[4], const Row& row, Emit& out) {
+// ------------------------------------------------------------------------------------------ cross-table lookups
+// The auxiliary columns of a table (committed after the four lookup challenges beta_0, gamma_0, beta_1, gamma_1 are
+// known; upstream: plonky2_evm's cross_table_lookup, whose Z columns sit beside Stark::eval -- reached from
+// proof_gen.rs:44-52, where ONE call proves the seven tables of prover_state.rs:85-93 as one statement).  Their
+// constraints follow the AIR's in the constraint list (index base = the AIR's count).
+//
+// A lookup is a filtered running product.  With a filter f (0 / 1 on every row) and a tuple of column values
+// compressed by a challenge set c = (beta_c, gamma_c), v_c = sum_j beta_c^j t_j,
+//     z_c[i] = prod_{i' >= i} term_c[i'],   term_c = 1 + f (gamma_c + v_c - 1)
+// (rows the filter leaves out contribute a factor 1).  Constraints per product column:  transition  z - z' term,
+// last row  z - term.  z_c opened at the first row (every aux column is, proof layout "open_first") is the product
+// over the table's filtered tuples; the statement "the tuples the looking tables send are the tuples the looked table
+// exposes" is the equality of those first-row values (ctl::pairs() below), checked for both challenge sets by whoever
+// verifies a transaction's table proofs (bp_verify_txn_table_proofs; upstream's root circuit does it in-circuit).
+// Every lookup exists twice, once per challenge set (upstream repeats its CTLs num_challenges = 2 times).
+//
+// AIR 0  synthetic   n_cols / 8 columns: the running product over trace columns 8k, 8k+1 with challenge set k mod 2,
+//                    no filter.  A load placeholder from before the real tables existed:
+//                    nothing looks these products up.
+// AIR 1  keccak_f    5 columns: g | h_0 h_1 | z_0 z_1.  LOOKED table of "keccak_sponge -> keccak_f": the tuple is a
+//                    whole permutation (50 input limbs, 50 output limbs).  Input and output live 23 rows apart, so
+//                    h_c carries the compressed input along the permutation's rows -- s_0 (h_c - sum_j beta_c^j A_j) = 0
+//                    on every row, (1 - s_23)(h_c' - h_c) = 0 on transitions -- and the tuple is read on the last
+//                    round's row: v_c = h_c + beta_c^50 sum_j beta_c^j out_j, out = the iota output for lane 0, else
+//                    the chi output.  g is the filter: which permutations the table exposes (g (g - 1) = 0,
+//                    g (1 - s_23) = 0: only last-round rows).  A table holds padding permutations nobody asks for;
+//                    exposing a subset is sound because every row of the table is a valid permutation by the AIR.
+// AIR 6  keccak_sponge  2 columns: z_0 z_1.  LOOKING side of the same lookup: filter is_full + is_final (every row
+//                    that absorbs a block), tuple = (xored rate limbs, capacity limbs | updated state limbs).
+// AIR 2, 3, 4, 5, 7  1 column: no lookup is built for these tables (upstream's go through the CPU table, which needs
+//                    the EVM interpreter, and through memory addresses these layouts do not carry): a constant running
+//                    product z = 1 keeps the oracle set of every table the same.
+namespace ctl {
+constexpr uint32_t KECCAK_G = 0, KECCAK_H = 1, KECCAK_Z = 3, KECCAK_N_AUX = 5, KECCAK_N_CONSTRAINTS = 10;
+constexpr uint32_t SPONGE_Z = 0, SPONGE_N_AUX = 2, SPONGE_N_CONSTRAINTS = 4;
+constexpr uint32_t TUPLE_LIMBS = 50;  // a Keccak state as 32-bit limbs
+
+GL_HD uint32_t n_aux(const Shape& s) {
+  return s.air_id == SYNTHETIC ? s.n_cols / 8 : s.air_id == KECCAK_F ? KECCAK_N_AUX : s.air_id == KECCAK_SPONGE ? SPONGE_N_AUX : 1;
+}
+GL_HD uint32_t n_constraints(const Shape& s) {
+  return s.air_id == SYNTHETIC ? 2 * (s.n_cols / 8)
+         : s.air_id == KECCAK_F ? KECCAK_N_CONSTRAINTS
+         : s.air_id == KECCAK_SPONGE ? SPONGE_N_CONSTRAINTS
+                                     : 2;
+}
+// the first aux column that is a running product (the columns before it are helpers); products run to the last column
+GL_HD uint32_t first_product(uint32_t air_id) { return air_id == KECCAK_F ? KECCAK_Z : 0; }
+
+// sum_{j < n} beta^j col(j) by Horner from the top
+template <class T, class Col>
+GL_HD T compress(const Col& col, uint32_t n, T beta) {
   typedef Ops<T> F;
+  T acc = col(n - 1);
 #pragma unroll 1
-  for (uint32_t k = k0; k < k1; k++) {
-    const T beta = F::k(ctl[2 * (k & 1)]), gamma = F::k(ctl[2 * (k & 1) + 1]);
-    const T a = row.loc(8 * k), b = row.loc(8 * k + 1), z = row.aux(k), zn = row.aux_nxt(k);
-    const T term = F::add(F::add(gamma, a), F::mul(beta, b));
-    out.transition(base + 2 * k, F::sub(z, F::mul(zn, term)));
-    out.last(base + 2 * k + 1, F::sub(z, term));
+  for (uint32_t j = n - 1; j-- > 0;) acc = F::add(F::mul(acc, beta), col(j));
+  return acc;
+}
+// term of product column `col` (an aux column index) of the table: 1 + f (gamma + v - 1)
+template <class T, class Row>
+GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const Row& row) {
+  typedef Ops<T> F;
+  if (s.air_id == SYNTHETIC) {
+    const T beta = F::k(ctl[2 * (col & 1)]), gamma = F::k(ctl[2 * (col & 1) + 1]);
+    return F::add(F::add(gamma, row.loc(8 * col)), F::mul(beta, row.loc(8 * col + 1)));
+  }
+  if (s.air_id == KECCAK_F) {
+    const uint32_t c = col - KECCAK_Z;
+    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]), b50 = F::k(gl::pow(ctl[2 * c], TUPLE_LIMBS));
+    // output limb j of the row: the iota output for lane 0, else the chi output (what constraint family F9 hands on)
+    const T out = compress<T>([&](uint32_t j) { return j < 2 ? row.loc(keccak::COL_APPP + j) : row.loc(keccak::COL_APP + j); },
+                              TUPLE_LIMBS, beta);
+    const T v = F::add(row.aux(KECCAK_H + c), F::mul(b50, out));
+    return F::add(F::k(1), F::mul(row.aux(KECCAK_G), F::sub(F::add(gamma, v), F::k(1))));
+  }
+  if (s.air_id == KECCAK_SPONGE) {
+    const uint32_t c = col - SPONGE_Z;
+    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
+    // tuple order: xored rate (34 limbs), capacity (16), updated state (50)
+    const T v = compress<T>([&](uint32_t j) {
+      return j < 34 ? row.loc(keccak_sponge::COL_XORED + j)
+             : j < 50 ? row.loc(keccak_sponge::COL_CAP + j - 34)
+                      : row.loc(keccak_sponge::COL_UPDATED + j - 50);
+    }, 2 * TUPLE_LIMBS, beta);
+    const T f = F::add(row.loc(keccak_sponge::COL_FULL), row.loc(keccak_sponge::COL_FINAL));
+    return F::add(F::k(1), F::mul(f, F::sub(F::add(gamma, v), F::k(1))));
+  }
+  return F::k(1);
+}
+// The lookup part of the constraint list.  Synthetic tables: products [k0, k1) (their unit slicing); every other
+// table: everything (one unit).
+template <class T, class Row, class Emit>
+GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ctl[4], const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  if (s.air_id == SYNTHETIC) {
+#pragma unroll 1
+    for (uint32_t k = k0; k < k1; k++) {
+      const T z = row.aux(k), zn = row.aux_nxt(k), term = product_term<T>(s, k, ctl, row);
+      out.transition(base + 2 * k, F::sub(z, F::mul(zn, term)));
+      out.last(base + 2 * k + 1, F::sub(z, term));
+    }
+    return;
+  }
+  uint32_t idx = base;
+  if (s.air_id == KECCAK_F) {
+    const T g = row.aux(KECCAK_G), s0 = row.loc(keccak::COL_STEP), s23 = row.loc(keccak::COL_STEP + 23);
+    out.all(idx++, F::sub(F::mul(g, g), g));
+    out.all(idx++, F::mul(g, F::sub(F::k(1), s23)));
+#pragma unroll 1
+    for (uint32_t c = 0; c < 2; c++) {
+      const T beta = F::k(ctl[2 * c]), h = row.aux(KECCAK_H + c);
+      const T in = compress<T>([&](uint32_t j) { return row.loc(keccak::COL_A + j); }, TUPLE_LIMBS, beta);
+      out.all(idx++, F::mul(s0, F::sub(h, in)));
+      out.transition(idx++, F::mul(F::sub(F::k(1), s23), F::sub(row.aux_nxt(KECCAK_H + c), h)));
+    }
+  }
+  const uint32_t p0 = first_product(s.air_id), p1 = n_aux(s);
+#pragma unroll 1
+  for (uint32_t k = p0; k < p1; k++) {
+    const T z = row.aux(k), zn = row.aux_nxt(k), term = product_term<T>(s, k, ctl, row);
+    out.transition(idx++, F::sub(z, F::mul(zn, term)));
+    out.last(idx++, F::sub(z, term));
   }
 }
+
+// The lookups between tables: the product of the first-row values of the looking columns equals that of the looked
+// columns, for challenge set c.  Tables by their position in a transaction (prover_state.rs:85-93).
+struct Pair {
+  const char* name;
+  uint32_t looking_table, looking_air, looking_col;  // aux column of challenge set 0; set c is column + c
+  uint32_t looked_table, looked_air, looked_col;
+};
+constexpr uint32_t N_PAIRS = 1;
+inline const Pair* pairs() {
+  static const Pair P[N_PAIRS] = {
+      {"keccak_sponge -> keccak_f", 4, KECCAK_SPONGE, SPONGE_Z, 3, KECCAK_F, KECCAK_Z},
+  };
+  return P;
+}
+}  // namespace ctl
 
 struct Info {
   uint32_t air_id;

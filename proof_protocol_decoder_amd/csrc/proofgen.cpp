@@ -25,6 +25,7 @@ namespace {
 
 constexpr uint64_t IR_MAGIC = 0x52494E5854475042ULL;     // "BPGTXNIR"
 constexpr uint64_t PROOF_BOX_MAGIC = 0x464F4F5250475042ULL;  // "BPGPROOF"
+constexpr uint64_t TABLES_MAGIC = 0x534C424154475042ULL;     // "BPGTABLS"
 constexpr uint32_t CIRCUIT_ROOT = 7, CIRCUIT_AGG = 8, CIRCUIT_BLOCK = 9;
 constexpr size_t BOX_HDR = 4;
 const char* TABLE_NAMES[BP_NUM_TABLES] = {"arithmetic", "byte_packing", "cpu", "keccak", "keccak_sponge", "logic", "memory"};
@@ -518,12 +519,16 @@ static void fill_table_inputs(int t, uint64_t N, const uint64_t* in, size_t n, u
     }
   }
 }
-static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
-                          const volatile uint8_t* abort_flag_u8, uint8_t** out, size_t* out_len,
-                          const TxnWitness* wit = nullptr) {
-  if (!s || !ir || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof: null argument");
-  if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
-  const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
+// What upstream's `prove` returns before the recursion starts (AllProof: the seven table proofs, the lookup
+// challenges, the public values) -- kept by bp_generate_txn_table_proofs, digested by bp_generate_txn_proof.
+struct TableProofs {
+  StarkCfg tcfg[BP_NUM_TABLES];
+  std::vector<uint64_t> pv;
+  Ctl ctl;
+  std::vector<uint64_t> proof[BP_NUM_TABLES];
+};
+static int parse_ir(const bp_state* s, const uint64_t* I, const TxnWitness* wit, StarkCfg tcfg[BP_NUM_TABLES],
+                    std::vector<uint64_t>* pv_out) {
   // version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520): txn number, gas and state
   // root do not advance, the same tables are proven
   // flags above the version byte: 0x100 = the Keccak table (index 3, prover_state.rs:85-93) is proven with the
@@ -535,13 +540,13 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   // 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6): 2414 columns
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
   if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 63) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
-  const bool dummy = ver == 2, keccak_air = (flags & 1) != 0, logic_air = (flags & 2) != 0, memory_air = (flags & 4) != 0,
-             arithmetic_air = (flags & 8) != 0, byte_packing_air = (flags & 16) != 0, sponge_air = (flags & 32) != 0;
+  const bool dummy = ver == 2;
+  // table index -> the AIR its flag selects (bit t' of flags; WITNESS_AIR lists them by table)
+  static const uint32_t FLAG_OF_TABLE[BP_NUM_TABLES] = {8, 16, 0, 1, 32, 2, 4};
   if (wit) {
-    const bool has_air[BP_NUM_TABLES] = {arithmetic_air, byte_packing_air, false, keccak_air, sponge_air, logic_air, memory_air};
     for (int t = 0; t < BP_NUM_TABLES; t++) {
       if (!wit->in[t]) continue;
-      if (!has_air[t])
+      if (!(flags & FLAG_OF_TABLE[t]))
         return fail(BP_ERR_INVALID_INPUT, "witness data for table %s needs an IR whose %s table is proven with its AIR (bp_ir_set_*_air)",
                     TABLE_NAMES[t], TABLE_NAMES[t]);
       if (I[11 + t] < 40 && wit->n[t] > witness_capacity(t, (uint64_t)1 << I[11 + t]))
@@ -552,7 +557,6 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   if (I[5] < I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: gas_used_after < gas_used_before");
   if (dummy && I[5] != I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: a dummy entry must not use gas (decoding.rs:503-506)");
   const bp_config& cfg = s->cfg;
-  StarkCfg tcfg[BP_NUM_TABLES];
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     const uint64_t ln = I[11 + t], wd = I[18 + t];
     if (ln < cfg.table_log_lo[t] || ln >= cfg.table_log_hi[t])
@@ -560,24 +564,147 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
                   (unsigned long long)ln, cfg.table_log_lo[t], cfg.table_log_hi[t]);
     if (wd > 65536) return fail(BP_ERR_INVALID_INPUT, "table %s: width out of range", TABLE_NAMES[t]);
     tcfg[t] = table_cfg_of(cfg, (uint32_t)ln, (uint32_t)wd);
-    if (keccak_air && t == 3) tcfg[t].air_id = air::KECCAK_F;  // check_cfg insists on its 2430 columns
-    if (logic_air && t == 5) tcfg[t].air_id = air::LOGIC;       // ... and on its 523
-    if (memory_air && t == 6) tcfg[t].air_id = air::MEMORY;     // ... 44
-    if (arithmetic_air && t == 0) tcfg[t].air_id = air::ARITHMETIC;  // ... 309
-    if (byte_packing_air && t == 1) tcfg[t].air_id = air::BYTE_PACKING;  // ... 297
-    if (sponge_air && t == 4) tcfg[t].air_id = air::KECCAK_SPONGE;       // ... 2414
+    if (flags & FLAG_OF_TABLE[t]) tcfg[t].air_id = WITNESS_AIR[t];  // check_cfg insists on the AIR's own width
     int r = check_cfg(tcfg[t]);
     if (r) return r;
   }
   for (int i = 0; i < 4; i++) if (I[6 + i] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "IR: non-canonical state root");
   // PublicValues
-  std::vector<uint64_t> pv(BP_PV_WORDS);
+  std::vector<uint64_t>& pv = *pv_out;
+  pv.assign(BP_PV_WORDS, 0);
   pv[0] = I[3]; pv[1] = I[3] + (dummy ? 0 : 1); pv[2] = I[4]; pv[3] = I[5];
   std::memcpy(&pv[4], I + 6, 32);
   if (dummy) std::memcpy(&pv[8], I + 6, 32);
   else root_after(I + 6, I[10], I[3], &pv[8]);
   pv[12] = I[2];
   for (auto& v : pv) v = gl::canon(v);
+  return BP_OK;
+}
+
+// The cross-table lookups of a transaction's table proofs (air::ctl::pairs): for both challenge sets the first-row
+// value of the looking running product equals that of the looked one.  Only pairs whose two tables are proven with
+// their AIRs exist (a synthetic table has nothing to look up).  Shared by the prover (which refuses to go on with
+// tables that do not form one statement: upstream's root circuit checks this in-circuit) and bp_verify_txn_table_proofs.
+static int check_lookups(const StarkCfg tcfg[BP_NUM_TABLES], const std::vector<uint64_t> proof[BP_NUM_TABLES]) {
+  const air::ctl::Pair* P = air::ctl::pairs();
+  for (uint32_t i = 0; i < air::ctl::N_PAIRS; i++) {
+    const air::ctl::Pair& p = P[i];
+    if (tcfg[p.looking_table].air_id != p.looking_air || tcfg[p.looked_table].air_id != p.looked_air) continue;
+    const ProofLayout La = proof_layout(tcfg[p.looking_table]), Lb = proof_layout(tcfg[p.looked_table]);
+    for (uint32_t c = 0; c < 2; c++) {
+      const uint64_t* a = proof[p.looking_table].data() + La.open_first + 2 * (p.looking_col + c);
+      const uint64_t* b = proof[p.looked_table].data() + Lb.open_first + 2 * (p.looked_col + c);
+      if (a[0] != b[0] || a[1] != b[1])
+        return fail(BP_ERR_VERIFY, "cross-table lookup %s does not hold (challenge set %u): the %s table asks for tuples the %s table "
+                    "does not expose", p.name, c, TABLE_NAMES[p.looking_table], TABLE_NAMES[p.looked_table]);
+    }
+  }
+  return BP_OK;
+}
+
+// generate_traces + the seven table proofs on one transcript (plonky2_evm `prove`), on the leased worker
+static int prove_tables(Worker& w, const uint64_t* I, const TxnWitness* wit, TableProofs* tp) {
+  StarkCfg* tcfg = tp->tcfg;
+  int r;
+  // generate_traces + trace commitments for all tables, then the shared transcript prologue
+  uint64_t* d_trace[BP_NUM_TABLES];
+  Committed trace[BP_NUM_TABLES];
+  Challenger ch;
+  auto given = [&](int t) { return wit && wit->in[t] && tcfg[t].air_id == WITNESS_AIR[t]; };
+  // Two seeded tables that a lookup ties together are ONE statement: the seeded sponge table asks for no more
+  // permutations than the Keccak-f table holds in full, and the seeded Keccak-f table's first permutations are the
+  // ones the sponge rows ask for (air::ctl, keccak_sponge -> keccak_f).  Tables given by the caller are taken as they are.
+  const bool lookup_kf = tcfg[3].air_id == air::KECCAK_F && tcfg[4].air_id == air::KECCAK_SPONGE;
+  const uint32_t sponge_row_limit = lookup_kf ? (uint32_t)(((uint64_t)1 << tcfg[3].log_n) / 24) : ~0u;
+  static const int GEN_ORDER[BP_NUM_TABLES] = {4, 0, 1, 2, 3, 5, 6};  // the sponge table before the Keccak-f table that reads it
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    const uint64_t N = (uint64_t)1 << tcfg[t].log_n;
+    d_trace[t] = w.arena.alloc_words((size_t)tcfg[t].n_cols * N);
+    if (!d_trace[t]) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) for table %s", w.arena.capacity() >> 20, TABLE_NAMES[t]);
+  }
+  for (int gi = 0; gi < BP_NUM_TABLES; gi++) {
+    const int t = GEN_ORDER[gi];
+    const uint64_t N = (uint64_t)1 << tcfg[t].log_n, seed = I[10] ^ splitmix64(t + 1);
+    const size_t mark = w.arena.mark();
+    uint64_t* d_in = nullptr;
+    if (given(t)) {
+      // the caller's items, then padding up to the table's height, staged through the pinned buffer
+      const size_t words = witness_capacity(t, N) * WITNESS_WORDS[t];
+      d_in = w.arena.alloc_words(words);
+      if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the witness data of table %s", TABLE_NAMES[t]);
+      if (words > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "table %s too tall for the input staging buffer", TABLE_NAMES[t]);
+      fill_table_inputs(t, N, wit->in[t], wit->n[t], w.pinned);
+      BPG_HIP(hipMemcpyAsync(d_in, w.pinned, words * 8, hipMemcpyHostToDevice, w.stream));
+    } else if (t == 3 && lookup_kf) {
+      const uint32_t n_perms = (uint32_t)witness_capacity(3, N);
+      d_in = w.arena.alloc_words((size_t)n_perms * 25);
+      if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the Keccak-f table's inputs");
+      if ((r = launch_keccak_inputs_from_sponge(d_trace[4], tcfg[4].log_n, d_in, n_perms, seed, w.stream))) return r;
+    }
+    switch (tcfg[t].air_id) {
+      case air::KECCAK_F: r = launch_keccak_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
+      case air::LOGIC: r = launch_logic_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
+      case air::MEMORY: r = launch_memory_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
+      case air::ARITHMETIC: r = launch_arithmetic_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
+      case air::BYTE_PACKING: r = launch_byte_packing_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
+      case air::KECCAK_SPONGE:
+        r = launch_keccak_sponge_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream, sponge_row_limit);
+        break;
+      default: r = launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, seed, w.stream); break;
+    }
+    if (r) return r;
+    if (d_in) {  // the staging buffer and the input words are reused by the next table
+      if ((r = w.wait())) return r;
+      w.arena.release(mark);
+    }
+  }
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    if ((r = commit(w, d_trace[t], tcfg[t].n_cols, tcfg[t].log_n, tcfg[t].rate_bits, tcfg[t].cap_height, false, &trace[t]))) return r;
+    ch.observe(trace[t].cap.data(), trace[t].cap.size());
+  }
+  ch.observe(tp->pv.data(), tp->pv.size());
+  Ctl& ctl = tp->ctl;
+  for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
+  // table proofs: sequential, one transcript threaded through all of them (plonky2_evm prover)
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before table %s", TABLE_NAMES[t]);
+    const size_t mark = w.arena.mark();
+    Challenger before = ch;  // the transcript as the verifier of this table proof starts from it
+    LookupHint hint;
+    if (t == 3 && lookup_kf) {  // the permutations the sponge table asks for: its flag columns, row p <-> permutation p
+      const uint64_t N4 = (uint64_t)1 << tcfg[4].log_n;
+      hint.flag_a = d_trace[4] + (size_t)air::keccak_sponge::COL_FULL * N4;
+      hint.flag_b = d_trace[4] + (size_t)air::keccak_sponge::COL_FINAL * N4;
+      hint.n_flags = (uint32_t)N4;
+    }
+    if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, tp->proof[t], &hint))) return r;
+    if (given(t)) {
+      // The prover does not check a witness, and nothing downstream of this call verifies the table proofs (upstream's
+      // root circuit would): data that came from the caller is therefore checked here, by the CPU verifier on the
+      // proof just made -- a log that is not a memory, a block that is not padded, ... ends the call.
+      if (stark_verify(tcfg[t], nullptr, ctl, before, tp->proof[t].data(), tp->proof[t].size()) != BP_OK) {
+        const std::string why = bp_last_error();
+        return fail(BP_ERR_VERIFY, "the witness data given for table %s does not satisfy its AIR: %s", TABLE_NAMES[t], why.c_str());
+      }
+    }
+    w.arena.release(mark);
+  }
+  // the tables must be ONE statement: what the sponge table hashes is what the Keccak-f table permutes
+  return check_lookups(tcfg, tp->proof);
+}
+
+static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
+                          const volatile uint8_t* abort_flag_u8, uint8_t** out, size_t* out_len,
+                          const TxnWitness* wit = nullptr, bool tables_only = false) {
+  if (!s || !ir || !out || !out_len) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof: null argument");
+  if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
+  const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
+  const bp_config& cfg = s->cfg;
+  TableProofs tp;
+  int r = parse_ir(s, I, wit, tp.tcfg, &tp.pv);
+  if (r) return r;
+  const StarkCfg* tcfg = tp.tcfg;
+  const std::vector<uint64_t>& pv = tp.pv;
 
   (void)hipSetDevice(cfg.device);
   WorkerLease lease(s);
@@ -585,73 +712,30 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   w.abort_flag = abort_flag;
   w.abort_flag_u8 = abort_flag_u8;
   if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before start");
-  int r;
-  // generate_traces + trace commitments for all tables, then the shared transcript prologue
-  uint64_t* d_trace[BP_NUM_TABLES];
-  Committed trace[BP_NUM_TABLES];
-  Challenger ch;
-  for (int t = 0; t < BP_NUM_TABLES; t++) {
-    const uint64_t N = (uint64_t)1 << tcfg[t].log_n;
-    d_trace[t] = w.arena.alloc_words((size_t)tcfg[t].n_cols * N);
-    if (!d_trace[t]) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) for table %s", w.arena.capacity() >> 20, TABLE_NAMES[t]);
-    if (wit && wit->in[t] && tcfg[t].air_id == WITNESS_AIR[t]) {
-      // the caller's items, then padding up to the table's height, staged through the pinned buffer
-      const size_t words = witness_capacity(t, N) * WITNESS_WORDS[t];
-      uint64_t* d_in = w.arena.alloc_words(words);
-      if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the witness data of table %s", TABLE_NAMES[t]);
-      if (words > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "table %s too tall for the input staging buffer", TABLE_NAMES[t]);
-      fill_table_inputs(t, N, wit->in[t], wit->n[t], w.pinned);
-      BPG_HIP(hipMemcpyAsync(d_in, w.pinned, words * 8, hipMemcpyHostToDevice, w.stream));
-      r = t == 3   ? launch_keccak_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
-          : t == 5 ? launch_logic_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
-          : t == 6 ? launch_memory_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
-          : t == 0 ? launch_arithmetic_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
-          : t == 4 ? launch_keccak_sponge_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream)
-                   : launch_byte_packing_trace(d_trace[t], d_in, tcfg[t].log_n, 0, w.stream);
-      if (r == BP_OK) r = w.wait();  // the staging buffer is reused by the next table and the commitments below
-    } else {
-      r = tcfg[t].air_id == air::KECCAK_F
-              ? launch_keccak_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
-          : tcfg[t].air_id == air::LOGIC
-              ? launch_logic_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
-          : tcfg[t].air_id == air::MEMORY
-              ? launch_memory_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
-          : tcfg[t].air_id == air::ARITHMETIC
-              ? launch_arithmetic_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
-          : tcfg[t].air_id == air::BYTE_PACKING
-              ? launch_byte_packing_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
-          : tcfg[t].air_id == air::KECCAK_SPONGE
-              ? launch_keccak_sponge_trace(d_trace[t], nullptr, tcfg[t].log_n, I[10] ^ splitmix64(t + 1), w.stream)
-              : launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, I[10] ^ splitmix64(t + 1), w.stream);
+  if ((r = prove_tables(w, I, wit, &tp))) return r;
+  if (tables_only) {
+    // "BPGTABLS" | n_tables | public values | lookup challenges | per table: air_id, log_n, n_cols, n_words, proof words
+    std::vector<uint64_t> o = {TABLES_MAGIC, BP_NUM_TABLES};
+    o.insert(o.end(), pv.begin(), pv.end());
+    o.insert(o.end(), tp.ctl.v, tp.ctl.v + 4);
+    for (int t = 0; t < BP_NUM_TABLES; t++) {
+      const uint64_t hdr[4] = {tcfg[t].air_id, tcfg[t].log_n, tcfg[t].n_cols, tp.proof[t].size()};
+      o.insert(o.end(), hdr, hdr + 4);
+      o.insert(o.end(), tp.proof[t].begin(), tp.proof[t].end());
     }
-    if (r) return r;
-    if ((r = commit(w, d_trace[t], tcfg[t].n_cols, tcfg[t].log_n, tcfg[t].rate_bits, tcfg[t].cap_height, false, &trace[t]))) return r;
-    ch.observe(trace[t].cap.data(), trace[t].cap.size());
+    uint64_t* buf = static_cast<uint64_t*>(std::malloc(o.size() * 8));
+    if (!buf) return fail(BP_ERR_DEVICE, "host allocation failed");
+    std::memcpy(buf, o.data(), o.size() * 8);
+    *out = reinterpret_cast<uint8_t*>(buf);
+    *out_len = o.size() * 8;
+    return BP_OK;
   }
-  ch.observe(pv.data(), pv.size());
-  Ctl ctl;
-  for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
-  // table proofs: sequential, one transcript threaded through all of them (plonky2_evm prover)
   uint64_t digest[BP_NUM_TABLES][4];
-  std::vector<uint64_t> proof;
   for (int t = 0; t < BP_NUM_TABLES; t++) {
-    if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before table %s", TABLE_NAMES[t]);
-    const size_t mark = w.arena.mark();
-    const bool given = wit && wit->in[t] && tcfg[t].air_id == WITNESS_AIR[t];
-    Challenger before = ch;  // the transcript as the verifier of this table proof starts from it
-    if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, proof))) return r;
-    if (given) {
-      // The prover does not check a witness, and nothing downstream of this call verifies the table proofs (upstream's
-      // root circuit would): data that came from the caller is therefore checked here, by the CPU verifier on the
-      // proof just made -- a log that is not a memory, a block that is not padded, ... ends the call.
-      if (stark_verify(tcfg[t], nullptr, ctl, before, proof.data(), proof.size()) != BP_OK) {
-        const std::string why = bp_last_error();
-        return fail(BP_ERR_VERIFY, "the witness data given for table %s does not satisfy its AIR: %s", TABLE_NAMES[t], why.c_str());
-      }
-    }
-    proof_digest(tcfg[t], proof.data(), digest[t]);
-    w.arena.release(mark);
+    proof_digest(tcfg[t], tp.proof[t].data(), digest[t]);
+    std::vector<uint64_t>().swap(tp.proof[t]);
   }
+  std::vector<uint64_t> proof;
   if ((r = w.wait())) return r;
   w.arena.release(lease.mark);  // traces are dead; the chains below only need digests
   // per-table recursion-shaped chains (wrap + shrinks).  The seven chains do not depend on each other and their
@@ -706,12 +790,9 @@ int bp_generate_txn_proof_keccak(const bp_state* s, const uint8_t* ir, size_t ir
   return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len, &wit);
 }
 BPG_ABI_CATCH("bp_generate_txn_proof_keccak")
-// The general form: witness data for any of the tables that have an AIR (bp_txn_witness, include/bpg.h).
-int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
-                                  const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len) try {
-  if (!data) return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len);
+// bp_txn_witness (include/bpg.h) -> the per-table form
+static int witness_of(const bp_txn_witness* data, TxnWitness* wit) {
   static const uint64_t none = 0;
-  TxnWitness wit;
   const struct { int t; const uint64_t* p; size_t n; int given; } f[6] = {
       {4, data->sponge_rows, data->n_sponge_rows, data->has_keccak_sponge},
       {3, data->keccak_inputs, data->n_perms, data->has_keccak}, {5, data->logic_ops, data->n_logic_ops, data->has_logic},
@@ -720,12 +801,86 @@ int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t i
   for (const auto& x : f) {
     if (!x.given) continue;
     if (!x.p && x.n) return fail(BP_ERR_INVALID_INPUT, "bp_generate_txn_proof_witness: null data for table %s", TABLE_NAMES[x.t]);
-    wit.in[x.t] = x.p ? x.p : &none;
-    wit.n[x.t] = x.n;
+    wit->in[x.t] = x.p ? x.p : &none;
+    wit->n[x.t] = x.n;
   }
+  return BP_OK;
+}
+// The general form: witness data for any of the tables that have an AIR (bp_txn_witness, include/bpg.h).
+int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
+                                  const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len) try {
+  if (!data) return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len);
+  TxnWitness wit;
+  int r = witness_of(data, &wit);
+  if (r) return r;
   return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len, &wit);
 }
 BPG_ABI_CATCH("bp_generate_txn_proof_witness")
+
+// What upstream's `prove` yields before the recursion (AllProof): the seven table proofs of a transaction on their one
+// transcript, with the public values and the lookup challenges.  data as for bp_generate_txn_proof_witness (nullable).
+int bp_generate_txn_table_proofs(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
+                                 const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len) try {
+  if (!data) return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len, nullptr, true);
+  TxnWitness wit;
+  int r = witness_of(data, &wit);
+  if (r) return r;
+  return txn_proof_impl(s, ir, ir_len, nullptr, abort_flag, out, out_len, &wit, true);
+}
+BPG_ABI_CATCH("bp_generate_txn_table_proofs")
+
+// verify_proof(all_stark, all_proof, config) of upstream, on the CPU: every table proof against the shared transcript
+// (trace caps and public values observed, four lookup challenges drawn, then table after table), and the cross-table
+// lookups between the tables that are proven with their AIRs (air::ctl).  cfg supplies the STARK parameters only.
+int bp_verify_txn_table_proofs(const bp_config* cfg, const uint8_t* bytes, size_t len) try {
+  if (!cfg || !bytes) return fail(BP_ERR_INVALID_INPUT, "bp_verify_txn_table_proofs: null argument");
+  if (len % 8 || len < (2 + BP_PV_WORDS + 4) * 8) return fail(BP_ERR_INVALID_INPUT, "table proofs: truncated");
+  const uint64_t* W = reinterpret_cast<const uint64_t*>(bytes);
+  const size_t n_words = len / 8;
+  if (W[0] != TABLES_MAGIC || W[1] != BP_NUM_TABLES) return fail(BP_ERR_INVALID_INPUT, "table proofs: bad magic");
+  const uint64_t* pv = W + 2;
+  const uint64_t* ctl_in = pv + BP_PV_WORDS;
+  for (size_t i = 0; i < BP_PV_WORDS + 4; i++) if (pv[i] >= gl::P) return fail(BP_ERR_VERIFY, "non-canonical public value or challenge");
+  StarkCfg tcfg[BP_NUM_TABLES];
+  std::vector<uint64_t> proof[BP_NUM_TABLES];
+  size_t off = 2 + BP_PV_WORDS + 4;
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    if (off + 4 > n_words) return fail(BP_ERR_INVALID_INPUT, "table proofs: truncated at table %s", TABLE_NAMES[t]);
+    const uint64_t air_id = W[off], log_n = W[off + 1], n_cols = W[off + 2], pw = W[off + 3];
+    off += 4;
+    if (air_id >= air::COUNT || log_n > 30 || n_cols > 65536) return fail(BP_ERR_INVALID_INPUT, "table proofs: bad header of table %s", TABLE_NAMES[t]);
+    if (air_id != air::SYNTHETIC && air_id != WITNESS_AIR[t])
+      return fail(BP_ERR_VERIFY, "table %s is proven with AIR %llu, which is not that table's", TABLE_NAMES[t], (unsigned long long)air_id);
+    tcfg[t] = table_cfg_of(*cfg, (uint32_t)log_n, (uint32_t)n_cols);
+    tcfg[t].air_id = (uint32_t)air_id;
+    int r = check_cfg(tcfg[t]);
+    if (r) return r;
+    if (pw != proof_layout(tcfg[t]).total || off + pw > n_words) return fail(BP_ERR_INVALID_INPUT, "table proofs: wrong length of table %s", TABLE_NAMES[t]);
+    proof[t].assign(W + off, W + off + pw);
+    off += pw;
+  }
+  if (off != n_words) return fail(BP_ERR_INVALID_INPUT, "table proofs: trailing words");
+  Challenger ch;
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    const ProofLayout L = proof_layout(tcfg[t]);
+    ch.observe(proof[t].data() + L.trace_cap, L.cap_words);
+  }
+  ch.observe(pv, BP_PV_WORDS);
+  Ctl ctl;
+  for (int i = 0; i < 4; i++) {
+    ctl.v[i] = ch.challenge();
+    if (ctl.v[i] != ctl_in[i]) return fail(BP_ERR_VERIFY, "the lookup challenges do not follow from the trace commitments");
+  }
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    int r = stark_verify(tcfg[t], nullptr, ctl, ch, proof[t].data(), proof[t].size());
+    if (r) {
+      const std::string why = bp_last_error();
+      return fail(r, "table %s: %s", TABLE_NAMES[t], why.c_str());
+    }
+  }
+  return check_lookups(tcfg, proof);
+}
+BPG_ABI_CATCH("bp_verify_txn_table_proofs")
 
 int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
                           const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len) try {

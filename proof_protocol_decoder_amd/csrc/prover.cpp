@@ -86,7 +86,7 @@ int check_cfg(const StarkCfg& c) {
 }
 ProofLayout proof_layout(const StarkCfg& c) {
   ProofLayout L{};
-  L.n_aux = c.n_cols / 8;
+  L.n_aux = air::ctl::n_aux(air::Shape{c.air_id, c.n_cols, c.n_const, c.deg_pow});
   L.n_quot = 2u << c.rate_bits;
   L.n_layers = n_fri_layers(c);
   L.final_len = 1u << (c.log_n - L.n_layers * c.arity_bits);
@@ -298,19 +298,21 @@ int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uin
 int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t alpha1, QuotArgs* out, QuotCoset* coset,
                   int loaded, uint32_t batch) {
   QuotArgs& qa = *out;
-  const uint32_t log_n = cfg.log_n, r = cfg.rate_bits, R = 1u << r, C = cfg.n_cols, K = cfg.n_const, A = C / 8;
+  const uint32_t log_n = cfg.log_n, r = cfg.rate_bits, R = 1u << r, C = cfg.n_cols, K = cfg.n_const;
+  const air::Shape shape{cfg.air_id, C, K, cfg.deg_pow};
+  const uint32_t A = air::ctl::n_aux(shape);
   const uint64_t N = (uint64_t)1 << log_n, M = N << r;
   const uint64_t wM = gl::root(log_n + r), wN = gl::root(log_n);
   qa.trace_stride = qa.aux_stride = qa.const_stride = M;
   TRY(get_table(0, log_n, 0, &qa.tw_n));
   qa.air_id = cfg.air_id;
   qa.log_n = log_n; qa.rate_bits = r; qa.n_cols = C; qa.n_const = K; qa.n_aux = A; qa.deg_pow = cfg.deg_pow;
-  // the constraint list and its units (air.hpp)
-  const air::Shape shape{cfg.air_id, C, K, cfg.deg_pow};
+  // the constraint list and its units (air.hpp): the AIR's, then the table's lookups (air::ctl).  The synthetic
+  // table's many product columns are sliced into units; a real table's few lookup columns are one unit.
   qa.n_air_constraints = air::n_constraints(shape);
-  qa.n_constraints = qa.n_air_constraints + 2 * A;
+  qa.n_constraints = qa.n_air_constraints + air::ctl::n_constraints(shape);
   qa.n_air_units = air::n_units(shape);
-  qa.aux_per_unit = std::max<uint32_t>(16, (A + 15) / 16);
+  qa.aux_per_unit = cfg.air_id == air::SYNTHETIC ? std::max<uint32_t>(16, (A + 15) / 16) : A;
   qa.n_ctl_units = (A + qa.aux_per_unit - 1) / qa.aux_per_unit;
   // One pass (the alpha fold never leaves the registers) once the rows alone fill the chip: 2048 workgroups of
   // 256 lanes = 2 per SIMD.  Shorter tables spread their units over grid.y until the launch has that many.
@@ -359,13 +361,13 @@ int fri_layer_args(uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uin
 
 // ------------------------------------------------------------------ one table, or a batch of equally shaped ones
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
-                const uint64_t* d_tv, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof) {
-  return stark_prove_batch(w, cfg, 1, &consts, &trace, &d_tv, &ctl, &ch, &proof);
+                const uint64_t* d_tv, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof, const LookupHint* hint) {
+  return stark_prove_batch(w, cfg, 1, &consts, &trace, &d_tv, &ctl, &ch, &proof, hint);
 }
 
 int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committed* const* consts,
                       const Committed* trace, const uint64_t* const* d_tv, const Ctl* ctl, Challenger* ch,
-                      std::vector<uint64_t>* proofs) {
+                      std::vector<uint64_t>* proofs, const LookupHint* hints) {
   TRY(check_cfg(cfg));
   if (B == 0 || B > MAX_BATCH || (size_t)B * cfg.num_queries > MAX_BATCH_QUERIES)
     return fail(BP_ERR_INVALID_INPUT, "stark_prove_batch: %u proofs x %u queries (at most %u proofs, %u queries in all)", B,
@@ -394,12 +396,15 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committe
   TRY(get_table(2, log_n, r, &coset_scale));
   TRY(get_table(3, log_n, r, &coset_scale_inv));
 
-  // 1. auxiliary columns (suffix products) and their commitment
+  // 1. auxiliary columns -- the table's lookups (air::ctl): helper columns and running products -- and their commitment
   ARENA_ALLOC(d_auxv, (size_t)B * A * N);
   {
     AuxArgs aa[MAX_BATCH];
-    for (uint32_t b = 0; b < B; b++) aa[b] = AuxArgs{d_tv[b], d_auxv + (size_t)b * A * N, ctl[b]};
-    TRY(launch_aux(aa, B, log_n, A, st));
+    for (uint32_t b = 0; b < B; b++) {
+      aa[b] = AuxArgs{d_tv[b], d_auxv + (size_t)b * A * N, ctl[b]};
+      if (hints) { aa[b].flag_a = hints[b].flag_a; aa[b].flag_b = hints[b].flag_b; aa[b].n_flags = hints[b].n_flags; }
+    }
+    TRY(launch_aux(aa, B, cfg.air_id, C, log_n, st));
   }
   Committed aux[MAX_BATCH];
   TRY(commit_batch(w, d_auxv, A, B, log_n, r, h, false, aux));

@@ -192,14 +192,14 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
   const air::Shape shape{air_id, C, ai->n_cols ? 0 : n_const, dp};
   out->degree = ai->degree * dp;
   out->n_cols = C;
-  out->n_aux = C / 8;
+  out->n_aux = air::ctl::n_aux(shape);
   out->n_air_constraints = air::n_constraints(shape);
-  out->n_ctl_constraints = 2 * (C / 8);
+  out->n_ctl_constraints = air::ctl::n_constraints(shape);
   out->n_units = air::n_units(shape);
   // families: (first index, count, kind, degree); kinds: 0 all rows, 1 transition, 2 first row, 3 last row
   uint32_t n = 0;
   auto fam = [&](uint32_t first, uint32_t count, uint32_t kind, uint32_t degree) {
-    if (n < 16) out->families[n++] = bp_air_family{first, count, kind, degree};
+    if (n < 24) out->families[n++] = bp_air_family{first, count, kind, degree};
   };
   if (air_id == air::KECCAK_F) {
     namespace kk = air::keccak;
@@ -233,7 +233,22 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
     // interleaved per group of four columns: 3g all rows, 3g + 1 transition, 3g + 2 first row
     fam(0, C / 4, 0, 2); fam(1, C / 4, 1, 3 * dp); fam(2, C / 4, 2, 1);
   }
-  fam(out->n_air_constraints, C / 8, 1, 2); fam(out->n_air_constraints + 1, C / 8, 3, 1);  // CTL: interleaved 2k, 2k + 1
+  // the table's lookups (air::ctl), in list order after the AIR's own constraints
+  const uint32_t b = out->n_air_constraints;
+  if (air_id == air::SYNTHETIC) {
+    fam(b, C / 8, 1, 2); fam(b + 1, C / 8, 3, 1);  // running products, interleaved 2k (transition), 2k + 1 (last row)
+  } else {
+    uint32_t i = b;
+    if (air_id == air::KECCAK_F) {
+      fam(i, 2, 0, 2); i += 2;           // the filter g: a bit, set on last-round rows only
+      for (int c = 0; c < 2; c++) {      // h_c: the compressed input, fixed on first-round rows, carried along
+        fam(i, 1, 0, 2); fam(i + 1, 1, 1, 2); i += 2;
+      }
+    }
+    for (uint32_t k = air::ctl::first_product(air_id); k < out->n_aux; k++) {  // filtered running products
+      fam(i, 1, 1, 3); fam(i + 1, 1, 3, 2); i += 2;
+    }
+  }
   out->n_families = n;
   return BP_OK;
 }

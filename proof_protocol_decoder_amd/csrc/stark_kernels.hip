@@ -289,9 +289,11 @@ byte_packing_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__
 // of message bytes in the block, the block as absorbed (17 words, padding included), the 25 lanes of the state before
 // the block) or, when null, one single-block message per row drawn from the seed like the oracle:
 // h(c) = splitmix64(seed ^ (c << 32) ^ row); every eighth row (h(0xD3) % 8 == 0) is a padding row, else len = h(0xD0) % 136,
-// message word w = h(0xD1 + (w << 8)), state before = 0.  The updated state is the permutation of (xored rate, capacity).
+// message word w = h(0xD1 + (w << 8)), state before = 0; rows from row_limit on are padding rows (seeded tables only).
+// The updated state is the permutation of (xored rate, capacity).
 __global__ void __launch_bounds__(256)
-keccak_sponge_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
+keccak_sponge_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed,
+                           uint32_t row_limit) {
   if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   namespace sp = bpg::air::keccak_sponge;
   namespace kk = bpg::air::keccak;
@@ -307,7 +309,7 @@ keccak_sponge_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict_
   } else {
     auto h = [&](uint64_t c) { return splitmix64(seed ^ (c << 32) ^ i); };
     for (uint32_t l = 0; l < 25; l++) st[l] = 0;
-    if (h(0xD3) % 8 == 0) {
+    if (h(0xD3) % 8 == 0 || i >= row_limit) {  // row_limit: a seeded table asks for no more permutations than its Keccak-f table holds
       flags = 0; len = 0;
       for (uint32_t w = 0; w < 17; w++) blk[w] = 0;
     } else {
@@ -352,6 +354,29 @@ keccak_sponge_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict_
   }
 }
 
+// The permutations a transaction's SEEDED Keccak-f table holds when its sponge table is real too: permutation p is the
+// one sponge row p asks for -- input = that row's (xored rate, capacity) -- wherever row p absorbs a block; every other
+// permutation is drawn from the seed as keccak_trace_kernel would.  inputs: [n_perms][25] lanes.  This is what makes the
+// two seeded tables one statement for the lookup keccak_sponge -> keccak_f (air::ctl).
+__global__ void __launch_bounds__(256)
+keccak_inputs_from_sponge_kernel(const uint64_t* __restrict__ sponge, uint32_t sponge_log_n, uint64_t* __restrict__ inputs,
+                                 uint32_t n_perms, uint64_t seed) {
+  namespace sp = bpg::air::keccak_sponge;
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << sponge_log_n;
+  if (p >= n_perms) return;
+  const bool asked = p < n && (sponge[(uint64_t)sp::COL_FULL * n + p] + sponge[(uint64_t)sp::COL_FINAL * n + p]) != 0;
+  for (uint32_t l = 0; l < 25; l++) {
+    uint64_t v;
+    if (asked) {
+      const uint32_t c = l < 17 ? sp::COL_XORED + 2 * l : sp::COL_CAP + 2 * (l - 17);
+      v = sponge[(uint64_t)c * n + p] | (sponge[(uint64_t)(c + 1) * n + p] << 32);
+    } else {
+      v = splitmix64(seed ^ ((uint64_t)l << 32) ^ p);
+    }
+    inputs[(uint64_t)p * 25 + l] = v;
+  }
+}
+
 // ---------------------------------------------------------------- multiplication witness (AIR 7, air.hpp)
 // One product per row.  `inputs` ([row][9]: is_mul, the four 64-bit words of x and of y, least significant first) or,
 // when null, drawn from the seed like the oracle: is_mul = splitmix64(seed ^ (0xE0 << 32) ^ row) % 4 != 0, words as in
@@ -391,24 +416,32 @@ arithmetic_mul_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict
   }
 }
 
-// ---------------------------------------------------------------- auxiliary (CTL-Z-like) columns
-// z_k[i] = prod_{i' >= i} (gamma + a[i'] + beta*b[i']), a/b = trace columns 8k, 8k+1.
-// One workgroup per aux column.  The column is walked back to front in tiles of 8*T elements; inside a
+// ---------------------------------------------------------------- auxiliary columns: the table's lookups (air::ctl)
+// A row of the trace as the lookup terms read it (values on the trace domain, column-major).
+struct TraceRow {
+  const uint64_t *trace, *aux_;
+  uint64_t n, i;
+  __device__ __forceinline__ uint64_t loc(uint32_t c) const { return trace[(uint64_t)c * n + i]; }
+  __device__ __forceinline__ uint64_t aux(uint32_t k) const { return aux_[(uint64_t)k * n + i]; }
+};
+// Running products  z_k[i] = prod_{i' >= i} term_k[i'],  term = air::ctl::product_term (synthetic tables: gamma + a +
+// beta * b over trace columns 8k, 8k + 1; real tables: 1 + filter * (gamma + compressed tuple - 1)).
+// One workgroup per product column.  The column is walked back to front in tiles of 8*T elements; inside a
 // tile lane t owns the 8 consecutive elements [8t, 8t+8) (one 64-byte piece: a wave covers 4 KiB of
 // each input per tile, read and written once with 16-byte accesses), the per-lane products are
 // suffix-scanned through LDS and multiplied by the product of the tiles already done.
 // (The first version gave each lane one n/T-element chunk: lanes n/T*8 bytes apart, every access a
 // different cache line, 16x the algorithmic HBM reads on the 2^14..2^17-row tables by PMC.)
+template <uint32_t AIR>
 __global__ void __launch_bounds__(1024)
-aux_suffix_product_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
+aux_suffix_product_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n, uint32_t n_cols) {
   if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
   const uint64_t* __restrict__ trace = batch.a[blockIdx.z].trace;
   uint64_t* __restrict__ aux = batch.a[blockIdx.z].aux;
   const bpg::Ctl& ctl = batch.a[blockIdx.z].ctl;
   __shared__ uint64_t part[1024];
-  const uint32_t n = 1u << log_n, k = blockIdx.x, T = blockDim.x, t = threadIdx.x;
-  const uint64_t *a = trace + (uint64_t)(8 * k) * n, *b = a + n;
-  const uint64_t beta = ctl.v[2 * (k & 1)], gamma = ctl.v[2 * (k & 1) + 1];
+  const bpg::air::Shape shape{AIR, n_cols, 0, 1};
+  const uint32_t n = 1u << log_n, k = bpg::air::ctl::first_product(AIR) + blockIdx.x, T = blockDim.x, t = threadIdx.x;
   uint64_t* z = aux + (uint64_t)k * n;
   // elements per lane per tile (n and T are powers of two; the launcher never uses fewer than 64
   // lanes, so T may exceed n: the surplus lanes then hold the neutral element)
@@ -423,7 +456,7 @@ aux_suffix_product_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
 #pragma unroll
     for (int j = 7; j >= 0; j--) {
       if ((uint32_t)j < per) {
-        f[j] = gl::addc(gl::addc(gamma, a[lo + j]), gl::mulc(beta, b[lo + j]));
+        f[j] = bpg::air::ctl::product_term<uint64_t>(shape, k, ctl.v, TraceRow{trace, aux, n, lo + (uint32_t)j});
         p = gl::mulc(p, f[j]);
       }
     }
@@ -451,6 +484,30 @@ aux_suffix_product_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
     for (int j = 0; j < 8; j++)
       if ((uint32_t)j < per) z[lo + j] = f[j];
     done = gl::mulc(done, whole);
+  }
+}
+// The helper columns of the Keccak-f table's lookup (air::ctl): g, the filter -- 1 on the last-round row of every
+// permutation the table exposes, i.e. permutation p when the looking table's row p absorbs a block (flag_a + flag_b of
+// the sponge table's trace, null: none) --, and h_0 / h_1, the permutation's input compressed by beta_0 / beta_1 and
+// carried along its rows.  A lane owns a row; it reads the 50 input limbs of its permutation's first row.
+__global__ void __launch_bounds__(256)
+keccak_ctl_helpers_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  namespace kk = bpg::air::keccak;
+  namespace ct = bpg::air::ctl;
+  const bpg::AuxArgs& a = batch.a[blockIdx.z];
+  const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t perm = i / 24, first = perm * 24;
+  const bool used = i % 24 == 23 && a.flag_a && perm < a.n_flags && (a.flag_a[perm] + a.flag_b[perm]) != 0;
+  a.aux[(uint64_t)ct::KECCAK_G * n + i] = used;
+#pragma unroll 1
+  for (uint32_t c = 0; c < 2; c++) {
+    const uint64_t beta = a.ctl.v[2 * c];
+    uint64_t acc = a.trace[(uint64_t)(kk::COL_A + ct::TUPLE_LIMBS - 1) * n + first];
+#pragma unroll 1
+    for (uint32_t j = ct::TUPLE_LIMBS - 1; j-- > 0;) acc = gl::addc(gl::mulc(acc, beta), a.trace[(uint64_t)(kk::COL_A + j) * n + first]);
+    a.aux[(uint64_t)(ct::KECCAK_H + c) * n + i] = acc;
   }
 }
 
@@ -554,7 +611,8 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::BatchOf<bpg::Quo
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
-      bpg::air::eval_ctl<uint64_t>(q.n_air_constraints, k0, k1, q.ctl.v, row, out);
+      const bpg::air::Shape cs{AIR, q.n_cols, q.n_const, q.deg_pow};  // AIR as a constant: the other tables' lookups fold away
+      bpg::air::ctl::eval<uint64_t>(cs, q.n_air_constraints, k0, k1, q.ctl.v, row, out);
     }
   }
   const uint64_t r0 = out.result(0), r1 = out.result(1);
@@ -1141,9 +1199,17 @@ int launch_byte_packing_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint3
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
+int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st,
+                               uint32_t row_limit) {
   dim3 grid(ceil_div((uint64_t)1 << log_n, 256), 3);
-  keccak_sponge_trace_kernel<<<grid, 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
+  keccak_sponge_trace_kernel<<<grid, 256, 0, st>>>(d_trace, d_inputs, log_n, seed, row_limit);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_keccak_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sponge_log_n, uint64_t* d_inputs, uint32_t n_perms,
+                                     uint64_t seed, hipStream_t st) {
+  if (!n_perms) return BP_OK;
+  keccak_inputs_from_sponge_kernel<<<ceil_div(n_perms, 256), 256, 0, st>>>(d_sponge_trace, sponge_log_n, d_inputs, n_perms, seed);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -1152,12 +1218,25 @@ int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uin
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t log_n, uint32_t n_aux, hipStream_t st) {
+int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_cols, uint32_t log_n, hipStream_t st) {
+  const air::Shape shape{air_id, n_cols, 0, 1};
+  const uint32_t n_aux = air::ctl::n_aux(shape), p0 = air::ctl::first_product(air_id);
   if (!n_aux) return BP_OK;
   if (int rc = check_batch(batch)) return rc;
+  const BatchOf<AuxArgs> ab = batch_of(a, batch);
+  if (air_id == air::KECCAK_F) {  // the helper columns first: the products read them
+    keccak_ctl_helpers_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), 1, batch), 256, 0, st>>>(ab, log_n);
+    BPG_LAUNCH_CHECK();
+  }
   uint32_t threads = (1u << log_n) < 1024 ? (1u << log_n) : 1024;
   if (threads < 64) threads = 64;
-  aux_suffix_product_kernel<<<dim3(n_aux, 1, batch), threads, 0, st>>>(batch_of(a, batch), log_n);
+  const dim3 grid(n_aux - p0, 1, batch);
+  switch (air_id) {
+    case air::SYNTHETIC: aux_suffix_product_kernel<air::SYNTHETIC><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
+    case air::KECCAK_F: aux_suffix_product_kernel<air::KECCAK_F><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
+    case air::KECCAK_SPONGE: aux_suffix_product_kernel<air::KECCAK_SPONGE><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
+    default: aux_suffix_product_kernel<air::LOGIC><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;  // no lookup: z = 1
+  }
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }

@@ -51,6 +51,10 @@ struct AuxArgs {
   const uint64_t* trace;
   uint64_t* aux;
   Ctl ctl;
+  // Keccak-f table only (air::ctl): permutation p is exposed to the lookup when flag_a[p] + flag_b[p] != 0 -- the two
+  // flag columns of the looking (sponge) table's trace, n_flags rows of it; null: nothing is exposed
+  const uint64_t *flag_a = nullptr, *flag_b = nullptr;
+  uint32_t n_flags = 0;
 };
 struct PowerVecArgs {
   uint64_t* out;  // n_points vectors of 2n words each: point y at out + y * 2n
@@ -165,9 +169,14 @@ int launch_logic_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log
 int launch_memory_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_arithmetic_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_byte_packing_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
-int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
+// row_limit: rows of a SEEDED table from this one on are padding rows (a table given by the caller is taken as it is)
+int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st,
+                               uint32_t row_limit = ~0u);
+// [n_perms][25] input lanes for a seeded Keccak-f table whose sponge table (trace on the device) is real
+int launch_keccak_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sponge_log_n, uint64_t* d_inputs, uint32_t n_perms,
+                                     uint64_t seed, hipStream_t st);
 int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
-int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t log_n, uint32_t n_aux, hipStream_t st);
+int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_cols, uint32_t log_n, hipStream_t st);
 // every proof of the batch has the shape and the unit spreading of q[0]
 int launch_quotient(const QuotArgs* q, uint32_t batch, const QuotCoset& coset, hipStream_t st);
 inline int launch_quotient(const QuotArgs& q, const QuotCoset& coset, hipStream_t st) { return launch_quotient(&q, 1, coset, st); }

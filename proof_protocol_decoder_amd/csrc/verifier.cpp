@@ -128,13 +128,13 @@ int stark_verify(const StarkCfg& cfg, const uint64_t* const_cap, const Ctl& ctl,
     const Ext zhn = gl::scale(zh, gl::inv(N));
     const air::Shape shape{cfg.air_id, C, K, cfg.deg_pow};
     const uint32_t n_air = air::n_constraints(shape);
-    Consumer k(n_air + 2 * A, alpha0, alpha1);
+    Consumer k(n_air + air::ctl::n_constraints(shape), alpha0, alpha1);
     k.z_last = gl::sub(zeta, gl::ext(gl::inv(g)));
     k.l_first = gl::mul(zhn, gl::inv(gl::sub(zeta, gl::ext(1))));
     k.l_last = gl::mul(zhn, gl::inv(gl::sub(gl::scale(zeta, g), gl::ext(1))));
     const OpenedRow row{oz, oz + 2 * (size_t)K, on, oz + 2 * (size_t)(K + C), on + 2 * (size_t)C};
     for (uint32_t u = 0; u < air::n_units(shape); u++) air::eval_unit<Ext>(shape, u, row, k);
-    air::eval_ctl<Ext>(n_air, 0, A, ctl.v, row, k);
+    air::ctl::eval<Ext>(shape, n_air, 0, A, ctl.v, row, k);
     const uint64_t* oq = oz + 2 * (size_t)(K + C + A);
     for (int j = 0; j < 2; j++) {
       Ext acc = gl::ext(0);

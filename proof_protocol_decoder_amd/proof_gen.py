@@ -364,6 +364,57 @@ def generate_txn_proof(p_state, gen_inputs, abort_signal=None, keccak_inputs=Non
     return GeneratedTxnProof(public_values_of(intern)[0], intern)
 
 
+def _witness_struct(gen_inputs, keccak_inputs, witness):
+    """(TxnWitness or None, the ctypes arrays it points into) from the forms generate_txn_proof accepts."""
+    if keccak_inputs is None:
+        keccak_inputs = getattr(gen_inputs, "keccak_inputs", None)
+    if witness is None and getattr(gen_inputs, "witness", None) is not None:
+        witness = dict(gen_inputs.witness)
+    if witness is None and keccak_inputs is None:
+        return None, []
+    witness = dict(witness or {})
+    if keccak_inputs is not None and 3 not in witness:
+        witness[3] = keccak_inputs
+    w, keep = TxnWitness(), []
+    for t, items in witness.items():
+        ptr_f, n_f, has_f, words = WITNESS_FIELDS[t]
+        flat = [int(x) for it in items for x in it]
+        if len(flat) % words:
+            raise ValueError("witness items of table %d have %d words each" % (t, words))
+        a = (C.c_uint64 * max(len(flat), 1))(*flat)
+        keep.append(a)
+        setattr(w, ptr_f, C.cast(a, C.c_void_p))
+        setattr(w, n_f, len(flat) // words)
+        setattr(w, has_f, 1)
+    return w, keep
+
+
+def generate_txn_table_proofs(p_state, gen_inputs, keccak_inputs=None, witness=None):
+    """What upstream's `prove` yields before the recursion (its AllProof; reached from proof_gen.rs:44-52): the seven
+    table proofs of the transaction on their one transcript, with the public values and the lookup challenges, as
+    bytes (bp_generate_txn_table_proofs).  Arguments as for generate_txn_proof."""
+    L = _bind()
+    ir = gen_inputs.to_bytes() if isinstance(gen_inputs, TxnProofGenIR) else bytes(gen_inputs)
+    out, n = _out()
+    w, keep = _witness_struct(gen_inputs, keccak_inputs, witness)
+    L.bp_generate_txn_table_proofs.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    check(L.bp_generate_txn_table_proofs(p_state._h, ir, len(ir), C.byref(w) if w is not None else None, None,
+                                         C.byref(out), C.byref(n)))
+    del keep
+    return take_buffer(out, n)
+
+
+def verify_txn_table_proofs(cfg, table_proofs):
+    """upstream's verify_proof(all_stark, all_proof, config) on the CPU (bp_verify_txn_table_proofs): every table proof
+    against the shared transcript and the cross-table lookups between the tables proven with their AIRs.  cfg: a
+    BpConfig (ProverState.cfg).  Raises ProofGenError when rejected."""
+    L = _bind()
+    L.bp_verify_txn_table_proofs.argtypes = [C.POINTER(BpConfig), C.c_char_p, C.c_size_t]
+    b = bytes(table_proofs)
+    check(L.bp_verify_txn_table_proofs(C.byref(cfg), b, len(b)))
+
+
 def generate_agg_proof(p_state, lhs_child, rhs_child):
     """proof_gen.rs:61-79."""
     L = _bind()

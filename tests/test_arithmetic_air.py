@@ -137,7 +137,7 @@ def test_air_registry_describes_the_arithmetic_air():
     L = pkg.lib()
     assert L.bp_air_count() == 8
     d = pkg.ops.air_describe(4)
-    assert d.name == b"arithmetic" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (309, 309, 38, 2)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (294, 76, 4)
+    assert d.name == b"arithmetic" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (309, 309, 1, 2)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (294, 2, 4)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:6]) == 294 and fams[4] == (277, 16, 0, 2)

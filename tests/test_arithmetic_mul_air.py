@@ -119,7 +119,7 @@ def test_air_registry_describes_the_multiplication_air():
     L = pkg.lib()
     assert L.bp_air_count() == 8
     d = pkg.ops.air_describe(7)
-    assert d.name == b"arithmetic_mul" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (1217, 1217, 152, 3)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (1218, 304, 8)
+    assert d.name == b"arithmetic_mul" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (1217, 1217, 1, 3)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (1218, 2, 8)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:6]) == 1218 and fams[4] == (1185, 32, 0, 3)

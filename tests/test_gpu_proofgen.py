@@ -546,6 +546,54 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), keccak_sponge_air=True).to_bytes()
 
 
+def test_table_proofs_and_their_lookups_match_the_oracle(pg, p_state, o_state, oracle):
+    """bp_generate_txn_table_proofs = upstream's `prove` before the recursion (AllProof): the seven table proofs on one
+    transcript.  With six real tables the sponge table's rows look their permutations up in the Keccak-f table
+    (csrc/air.hpp namespace ctl): bytes equal the oracle's (oracle/ctl.c states the lookup columns independently), both
+    verifiers accept both provers' output, and the prover refuses tables that are valid alone but not one statement."""
+    width = list(WIDTH)
+    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 297, 2430, 2414, 523, 44
+    ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0C71, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
+                           memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
+    iw = list(struct.unpack("<25Q", ir0.to_bytes()))
+    got = pg.generate_txn_table_proofs(p_state, ir0)
+    want = o_state.txn_tables(iw)
+    assert (words(got) == want).all()
+    pg.verify_txn_table_proofs(p_state.cfg, got)
+    assert o_state.verify_tables(words(got)) == 0
+    # the lookup is not vacuous (see tests/test_lookups.py for the layout): the sponge table's product is not 1
+    from test_lookups import first_row_openings
+    looking, looked = first_row_openings(oracle, words(got), 4), first_row_openings(oracle, words(got), 3)
+    assert (looking[0] == looked[3]).all() and (looking[1] == looked[4]).all() and tuple(looking[0]) != (1, 0)
+    # caller-given tables: three messages absorbed by the sponge table, their permutations in the Keccak-f table
+    from test_lookups import sponge_and_keccak_work
+    rows, perms = sponge_and_keccak_work(oracle, [b"abc", bytes(range(200)), b""])
+    w2 = list(WIDTH)
+    w2[3], w2[4] = 2430, 2414
+    ir1 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0C72, tuple(LOG_N), tuple(w2), keccak_air=True, keccak_sponge_air=True)
+    iw1 = list(struct.unpack("<25Q", ir1.to_bytes()))
+    got1 = pg.generate_txn_table_proofs(p_state, ir1, witness={3: perms, 4: rows})
+    assert (words(got1) == o_state.txn_tables(iw1, witness={3: perms, 4: rows})).all()
+    assert o_state.verify_tables(words(got1)) == 0
+    assert (words(pg.generate_txn_proof(p_state, ir1, witness={3: perms, 4: rows}).intern)
+            == o_state.txn(iw1, witness={3: np.array(perms, dtype=np.uint64), 4: np.array(rows, dtype=np.uint64)})).all()
+    # one lane of one permutation differs: each table is valid alone, together they are not one statement
+    bad = [list(p) for p in perms]
+    bad[1][7] ^= 1 << 33
+    for call in (pg.generate_txn_table_proofs, pg.generate_txn_proof):
+        with pytest.raises(pg.ProofGenError, match="cross-table lookup keccak_sponge -> keccak_f does not hold") as e:
+            call(p_state, ir1, witness={3: bad, 4: rows})
+        assert e.value.code == -5
+    # the verifier of the one side refuses what the other side's prover made of the bad tables
+    oracle.lib().orc_pg_set_prover_lookup_check(0)
+    try:
+        bad_tp = o_state.txn_tables(iw1, witness={3: bad, 4: rows})
+    finally:
+        oracle.lib().orc_pg_set_prover_lookup_check(1)
+    with pytest.raises(pg.ProofGenError, match="cross-table lookup"):
+        pg.verify_txn_table_proofs(p_state.cfg, bad_tp.tobytes())
+
+
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
 S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
 

@@ -143,11 +143,15 @@ def test_air_registry_describes_both_airs():
     L = pkg.lib()
     assert L.bp_air_count() == 8
     d = pkg.ops.air_describe(1)
-    assert d.name == b"keccak_f" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (2430, 2430, 303, 3)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (2826, 606, 6)
+    assert d.name == b"keccak_f" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (2430, 2430, 5, 3)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (2826, 10, 6)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:10]) == 2826 and fams[0] == (0, 24, 2, 1) and fams[9] == (2776, 50, 1, 2)
     assert max(deg for _, _, _, deg in fams) == 3
+    # the table's lookups follow (csrc/air.hpp, namespace ctl): the filter g (two constraints), the carried input h_c of
+    # both challenge sets (fixed on first-round rows, carried on transitions), two filtered running products
+    assert fams[10:] == [(2826, 2, 0, 2), (2828, 1, 0, 2), (2829, 1, 1, 2), (2830, 1, 0, 2), (2831, 1, 1, 2),
+                         (2832, 1, 1, 3), (2833, 1, 3, 2), (2834, 1, 1, 3), (2835, 1, 3, 2)]
     s = pkg.ops.air_describe(0, n_cols=135, n_const=82, deg_pow=3)
     assert s.name == b"synthetic" and (s.fixed_n_cols, s.n_cols, s.degree, s.n_air_constraints) == (0, 135, 9, 99)
     from proof_protocol_decoder_amd._lib import BpgError

@@ -122,8 +122,8 @@ def test_air_registry_describes_the_logic_air():
     L = pkg.lib()
     assert L.bp_air_count() == 8
     d = pkg.ops.air_describe(2)
-    assert d.name == b"logic" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (523, 523, 65, 3)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (524, 130, 8)
+    assert d.name == b"logic" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (523, 523, 1, 3)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (524, 2, 8)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert fams[:4] == [(0, 3, 0, 2), (3, 1, 0, 2), (4, 512, 0, 2), (516, 8, 0, 3)]
     # a table of the wrong width is refused

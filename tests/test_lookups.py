@@ -1,0 +1,140 @@
+"""Cross-table lookups (CPU): the tables of a transaction that are proven with their AIRs form ONE statement
+(proof_gen.rs:44-52 proves all tables in one call; upstream ties them with plonky2_evm's cross-table lookups).  Built
+here: keccak_sponge -> keccak_f (csrc/air.hpp namespace ctl, oracle/ctl.c).  The oracle proves a
+transaction's seven tables; its own verifier and the product's CPU verifier (independent statements of the lookup
+constraints) both accept; tables that are each valid alone but disagree with each other are rejected by both."""
+import numpy as np
+import pytest
+
+from pg_common import LOG_N, SMALL, WIDTH, ir_words
+
+REAL_WIDTH = {0: 309, 1: 297, 3: 2430, 4: 2414, 5: 523, 6: 44}
+REAL_FLAG = {3: 0x100, 5: 0x200, 6: 0x400, 0: 0x800, 1: 0x1000, 4: 0x2000}
+
+
+def real_ir(tables, seed=0x5EED0C71, log_n=LOG_N):
+    w = [REAL_WIDTH[t] if t in tables else WIDTH[t] for t in range(7)]
+    ir = ir_words(9, 0, seed, log_n=log_n, width=tuple(w))
+    for t in tables:
+        ir[1] |= REAL_FLAG[t]
+    return ir
+
+
+@pytest.fixture(scope="module")
+def o_state(oracle):
+    return oracle.PgState(**SMALL)
+
+
+@pytest.fixture(scope="module")
+def product_cfg():
+    from proof_protocol_decoder_amd import proof_gen as pg
+    b = pg.ProverStateBuilder()
+    for t, name in enumerate(pg.TABLES):
+        getattr(b, "set_%s_circuit_size" % name)(range(SMALL["table_log_lo"][t], SMALL["table_log_hi"][t]))
+    b.set(**{k: v for k, v in SMALL.items() if not k.startswith("table_")})
+    return pg, b.cfg
+
+
+def table_slices(tp):
+    """[(air_id, log_n, n_cols, first word, n words)] of a "BPGTABLS" container."""
+    out, off = [], 2 + 13 + 4
+    for _ in range(7):
+        air, log_n, n_cols, pw = (int(x) for x in tp[off:off + 4])
+        out.append((air, log_n, n_cols, off + 4, pw))
+        off += 4 + pw
+    assert off == tp.size
+    return out
+
+
+def first_row_openings(oracle, tp, t):
+    """the auxiliary columns of table t opened at the first row, as (c0, c1) pairs"""
+    air, log_n, n_cols, first, _ = table_slices(tp)[t]
+    a = int(oracle.lib().orc_ctl_n_aux(air, n_cols))
+    q, cap = 4, 4 << SMALL["stark_cap_height"]
+    off = first + 16 + 3 * cap + 2 * (n_cols + a + q) + 2 * (n_cols + a)
+    return tp[off:off + 2 * a].reshape(a, 2)
+
+
+def test_seeded_tables_of_a_transaction_are_one_statement(oracle, o_state, product_cfg):
+    pg, cfg = product_cfg
+    tp = o_state.txn_tables(real_ir({0, 1, 3, 4, 5, 6}))
+    assert o_state.verify_tables(tp) == 0
+    pg.verify_txn_table_proofs(cfg, tp.tobytes())
+    # the lookup is not vacuous: the sponge table asks for permutations (its product is not 1) and the Keccak-f table's
+    # exposed product is the same value, for both challenge sets
+    looking, looked = first_row_openings(oracle, tp, 4), first_row_openings(oracle, tp, 3)
+    assert (looking[0] == looked[3]).all() and (looking[1] == looked[4]).all()
+    assert tuple(looking[0]) != (1, 0) and tuple(looking[0]) != tuple(looking[1])
+    # a table no lookup is built for carries the constant product
+    assert (first_row_openings(oracle, tp, 5) == [[1, 0]]).all()
+    # without a real sponge table the Keccak-f table exposes nothing, and nothing is compared
+    tp2 = o_state.txn_tables(real_ir({3}))
+    assert o_state.verify_tables(tp2) == 0
+    pg.verify_txn_table_proofs(cfg, tp2.tobytes())
+    assert (first_row_openings(oracle, tp2, 3)[3:] == [[1, 0], [1, 0]]).all()
+
+
+def sponge_and_keccak_work(oracle, messages):
+    rows, perms = [], []
+    for m in messages:   # (the rows against Keccak-256 itself: tests/test_keccak_sponge_air.py)
+        _, r = oracle.keccak_sponge_rows(m)
+        rows += [[int(w) for w in x] for x in r]
+    for r in rows:   # permutation input = (state before) xor (block as absorbed), capacity untouched
+        blk, st = r[2:19], r[19:44]
+        perms.append([st[l] ^ blk[l] if l < 17 else st[l] for l in range(25)])
+    return rows, perms
+
+
+def test_given_tables_that_disagree_are_rejected_by_both_verifiers(oracle, o_state, product_cfg):
+    pg, cfg = product_cfg
+    msgs = [b"abc", bytes(range(200)), b""]
+    rows, perms = sponge_and_keccak_work(oracle, msgs)
+    ir = real_ir({3, 4})
+    good = o_state.txn_tables(ir, witness={3: perms, 4: rows})
+    assert o_state.verify_tables(good) == 0
+    pg.verify_txn_table_proofs(cfg, good.tobytes())
+    # one lane of one permutation's input differs: the Keccak-f table is still a table of valid permutations, the sponge
+    # table still a valid absorption -- but what the one hashes is no longer what the other permutes
+    bad_perms = [list(p) for p in perms]
+    bad_perms[1][7] ^= 1 << 33
+    with pytest.raises(RuntimeError, match="-11"):          # the prover refuses to go on
+        o_state.txn_tables(ir, witness={3: bad_perms, 4: rows})
+    oracle.lib().orc_pg_set_prover_lookup_check(0)
+    try:
+        bad = o_state.txn_tables(ir, witness={3: bad_perms, 4: rows})
+    finally:
+        oracle.lib().orc_pg_set_prover_lookup_check(1)
+    assert o_state.verify_tables(bad) == -11
+    with pytest.raises(pg.ProofGenError, match="cross-table lookup keccak_sponge -> keccak_f does not hold") as e:
+        pg.verify_txn_table_proofs(cfg, bad.tobytes())
+    assert e.value.code == -5
+    # a sponge row the Keccak-f table has no permutation for (one message more than it permutes)
+    rows2, _ = sponge_and_keccak_work(oracle, msgs + [b"one more"])
+    oracle.lib().orc_pg_set_prover_lookup_check(0)
+    try:
+        bad2 = o_state.txn_tables(ir, witness={3: perms, 4: rows2})
+    finally:
+        oracle.lib().orc_pg_set_prover_lookup_check(1)
+    assert o_state.verify_tables(bad2) == -11
+    with pytest.raises(pg.ProofGenError, match="cross-table lookup"):
+        pg.verify_txn_table_proofs(cfg, bad2.tobytes())
+
+
+def test_table_proof_containers_are_bound_to_their_transcript(oracle, o_state, product_cfg):
+    pg, cfg = product_cfg
+    tp = o_state.txn_tables(real_ir({3, 4}))
+    rng = np.random.default_rng(11)
+    spots = [2 + 3, 2 + 13 + 1]                      # a public value, a lookup challenge
+    for air, _, _, first, pw in table_slices(tp):    # and words of every table proof
+        spots += [first + 16 + 1, first + int(rng.integers(16, pw))]
+    for i in spots:
+        bad = tp.copy()
+        bad[i] ^= np.uint64(1 << int(rng.integers(0, 60)))
+        assert o_state.verify_tables(bad) != 0
+        with pytest.raises(pg.ProofGenError):
+            pg.verify_txn_table_proofs(cfg, bad.tobytes())
+    # the looked product moved to another value together with its looking partner is still refused (the running products
+    # are tied to the committed columns by the table proofs)
+    air, log_n, n_cols, first, pw = table_slices(tp)[4]
+    with pytest.raises(pg.ProofGenError):
+        pg.verify_txn_table_proofs(cfg, tp[:-1].tobytes())
