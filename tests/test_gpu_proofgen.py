@@ -463,7 +463,10 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
             want = ost.txn(list(struct.unpack("<25Q", e.to_bytes())), keccak_inputs=np.array(e.keccak_inputs, dtype=np.uint64).reshape(-1, 25),
                            witness=w)
             assert (words(got.intern) == want).all()
-        assert pg.generate_txn_proof(st, irs[0], witness={6: (), 1: ()}).intern != pg.generate_txn_proof(st, irs[0]).intern
+        # other data, another proof (the sponge rows stay: they and the Keccak-f table are one statement, air::ctl)
+        assert pg.generate_txn_proof(st, irs[0], witness={**dict(irs[0].witness), 6: (), 1: ()}).intern != pg.generate_txn_proof(st, irs[0]).intern
+        with pytest.raises(pg.ProofGenError, match="cross-table lookup keccak_sponge -> keccak_f does not hold"):
+            pg.generate_txn_proof(st, ir, witness={6: (), 1: ()})   # a seeded sponge table next to the entry's own Keccak-f table
         drv = BlockDriver(st, n_threads=2)
         try:
             blk = drv.prove_block_distributed(irs)
