@@ -211,6 +211,33 @@ def main():
                 "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                 "perms_per_launch": round(perms.value / n.value)}
 
+    HBM_KERNELS = ((3, "fri_fold_kernel", "16 M (1 + 1/16) per layer of M extension values"),
+                   (4, "openings_multi_kernel", "8 n C: every coefficient column once"),
+                   (5, "fri_combine_*_kernel", "8 n C: every coefficient column once + six result columns"),
+                   (6, "aux_suffix_product_kernel", "8 n per column read or written (24 n per product of a synthetic table)"))
+    AIR_NAMES = ("synthetic", "keccak_f", "logic", "memory", "arithmetic", "byte_packing", "keccak_sponge", "arithmetic_mul")
+
+    def read_hbm_family(fam, kernel, formula):
+        n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
+        pkg._lib.check(L.bp_profile_read(fam, C.byref(n), C.byref(ms), C.byref(by)))
+        if not n.value:
+            return None
+        ach = by.value / (ms.value * 1e-3) / 1e9
+        return {"kernel": kernel, "bound": "hbm", "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                "alg_bytes_per_launch": round(by.value / n.value), "alg_bytes": formula, "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4)}
+
+    def read_k5(only):
+        out = {}
+        for air in only:
+            name = AIR_NAMES[air]
+            r = read_hbm_family(7 + air, "quotient_air_kernel<%s>" % name,
+                                "8 M (C + A + K + 2): the three LDE matrices read once, two quotient columns written")
+            if r:
+                r.update(k5_counters().get(name, {}))
+                out[name] = r
+        return out
+
     def single_stream_leg():
         """The same workload with ONE prover stream and nothing else on the chip, so every launch of the kernel
         has the device to itself and event time == kernel time (this is what the rocprof summary in profiles/ is
@@ -232,18 +259,55 @@ def main():
         L.bp_profile_enable(0)
         L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
         torch.cuda.synchronize()
-        roof = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one "
-                           "stream (no co-running kernels); all 29 proofs x 3 commitments x tables per txn")
+        roof = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one stream (no "
+                           "co-running kernels); per txn 7 table proofs, 3 lock-step batches of 7 recursion-shaped proofs, a root proof")
         alu = read_leaf_hash()
+        # the other HBM-class kernels SURVEY.md section 8(d) names, over the same leg, and K5 on the synthetic tables
+        others = {name: r for fam, name, formula in HBM_KERNELS for r in [read_hbm_family(fam, name, formula)] if r}
+        k5 = read_k5((0,))
+        if not args.leg_skip_extras:
+            # the same leg with the six tables that have an AIR proven with it: K5 per air_id
+            irs_r = synthetic_block_irs(1001, 2, S1_LOG_N, S1_WIDTH, **REAL_AIRS)
+            solo_driver.prove_shard(irs_r[:1])
+            L.bp_profile_reset()
+            L.bp_profile_enable(1)
+            solo_driver.prove_shard(irs_r)
+            torch.cuda.synchronize()
+            L.bp_profile_enable(0)
+            k5.update(read_k5((1, 2, 3, 4, 5, 6)))
         solo_driver.close()
         solo.close()
-        return roof, alu
+        return roof, alu, others, k5
+
+    def real_airs_block():
+        """The driver's one command never touches AIR 1..6 outside pytest: a 64-txn block whose six tables with an AIR
+        are proven with it (the sponge table's rows look their permutations up in the Keccak-f table), 16 prover
+        streams, here in the child process."""
+        n, thr = 64, 16
+        st = pg.ProverStateBuilder().set(device=local_rank, n_workers=thr, arena_bytes=int(args.arena_gib * 2**30)).build()
+        drv = BlockDriver(st, n_threads=thr)
+        blocks = [synthetic_block_irs(3000 + b, n, S1_LOG_N, S1_WIDTH, **REAL_AIRS) for b in range(3)]
+        last = drv.prove_block_distributed(blocks[0], 0, 1, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in blocks[1:]:
+            last = drv.prove_block_distributed(b, 0, 1, None)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pg.VerifierState.from_prover_state(st).verify(last)
+        drv.close()
+        st.close()
+        return {"value": round(n * 2 / dt, 3), "unit": "txn-proofs/s", "steps": 2, "warmup": 1, "prover_streams": thr,
+                "workload": "64-txn block, the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / "
+                            "2414 / 523 / 44 columns), the CPU table synthetic; cross-table lookup keccak_sponge -> keccak_f "
+                            "checked in every txn; another workload than the metric's"}
 
     if args.leg_only:
         # child mode: everything that is measured alone on the chip, in a process of its own
-        roof, alu = single_stream_leg()
-        out = {"roofline": roof, "alu_kernel": alu}
+        roof, alu, others, k5 = single_stream_leg()
+        out = {"roofline": roof, "alu_kernel": alu, "hbm_kernels": others, "k5": k5}
         if not args.leg_skip_extras:
+            out.update(real_airs=real_airs_block())
             out.update(roofline_isolated=isolated_roofline(pkg, torch), ntt_hbm_gbps=ntt_gbps(pkg, torch))
             if alu:
                 finish_alu_kernel(alu, poseidon_peak(pkg, torch))
@@ -263,7 +327,7 @@ def main():
     roofline = alu_kernel = None
     if args.leg_first and not args.no_profile and rank == 0:
         phase("single-stream leg")
-        roofline, alu_kernel = single_stream_leg()
+        roofline, alu_kernel, _, _ = single_stream_leg()
     phase("state build")
 
     t_build = time.time()
@@ -384,7 +448,7 @@ def main():
     out["roofline"] = alone.get("roofline")
     out["roofline_in_situ"] = roofline_in_situ
     out["alu_kernel"] = alone.get("alu_kernel")
-    for k in ("roofline_isolated", "ntt_hbm_gbps"):
+    for k in ("hbm_kernels", "k5", "real_airs", "roofline_isolated", "ntt_hbm_gbps"):
         if k in alone:
             out[k] = alone[k]
     if world == 1 and not args.no_cpu_baseline:
@@ -414,6 +478,27 @@ def valu_insts_per_perm():
         return insts / perms, mfma / perms
     except (OSError, AttributeError, ValueError):
         return None, None
+
+
+K5_FILE = os.path.join("profiles", "r4_k5_counters.txt")
+REAL_AIRS = dict(keccak_air=True, logic_air=True, memory_air=True, arithmetic_air=True, byte_packing_air=True,
+                 keccak_sponge_air=True)
+
+
+def k5_counters():
+    """Per AIR, from the tracked counter summary of tools/k5_air_probe.py under rocprofv3 (tools/prof_round4.sh):
+    VALU lane-instructions per constraint evaluation and HBM bytes fetched per algorithmic byte read."""
+    import re
+    out = {}
+    try:
+        for line in open(os.path.join(ROOT, K5_FILE)):
+            m = re.match(r"(\w+)\s+.*valu_per_constraint=([0-9.]+).*fetch_over_algorithmic=([0-9.]+)", line)
+            if m:
+                out[m.group(1)] = {"valu_lane_insts_per_constraint": float(m.group(2)),
+                                   "hbm_fetch_over_algorithmic_read": float(m.group(3)), "counters_source": K5_FILE}
+    except OSError:
+        pass
+    return out
 
 
 def finish_alu_kernel(alu, peak):

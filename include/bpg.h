@@ -553,7 +553,10 @@ int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t t
 /* Optional HIP-event timing of kernel families on their own streams (bench.py roofline leg).
  * family 0: LDE coset NTT (LDS-resident DIT), 1: inverse NTT (DIF); total_alg_bytes uses the
  * algorithmic byte counts of SURVEY.md section 8(d).  family 2: Merkle leaf hashing (integer-ALU
- * bound): the third output counts Poseidon PERMUTATIONS instead of bytes. */
+ * bound): the third output counts Poseidon PERMUTATIONS instead of bytes.  The other HBM-class kernels of
+ * section 8(d): 3 FRI fold (16 M (1 + 1/16)), 4 openings (8 n C), 5 FRI alpha-combination (8 n C), 6 auxiliary
+ * running products (8 n per column read or written), 7 + air_id the quotient kernel K5 of that AIR (every LDE
+ * element read once, two quotient columns written). */
 void bp_profile_enable(int on);
 void bp_profile_reset(void);
 int bp_profile_read(int family, uint64_t* launches, double* total_ms, double* total_alg_bytes);

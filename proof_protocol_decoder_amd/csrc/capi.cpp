@@ -88,13 +88,15 @@ KernelTimer::KernelTimer(int f, hipStream_t s, double b) : family(f), st(s), byt
   if (!e0 || !e1) { e0 = e1 = nullptr; return; }
   (void)hipEventRecord(e0, st);
 }
-KernelTimer::~KernelTimer() {
+KernelTimer::~KernelTimer() { stop(); }
+void KernelTimer::stop() {
   if (!e0) return;
   (void)hipEventRecord(e1, st);
   ThreadProf& tp = thread_prof();
   std::lock_guard<std::mutex> lk(tp.mu);
   tp.pending.push_back(Pending{e0, e1, family, bytes});
   if (tp.pending.size() >= 64) tp.retire(false);
+  e0 = e1 = nullptr;
 }
 // everything recorded so far, summed over threads; `reset` also clears the sums
 static void profile_collect(FamilyStats (&out)[PROF_FAMILIES], bool reset) {

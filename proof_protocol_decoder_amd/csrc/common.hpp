@@ -24,7 +24,9 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
 // Optional per-kernel-family HIP-event timing (bench.py's roofline leg).  Off by default: when off the
 // guard is two branches.  Families: 0 = LDE coset NTT (DIT, LDS-resident), 1 = inverse NTT (DIF).
-enum { PROF_LDE_DIT = 0, PROF_INTT_DIF = 1, PROF_LEAF_HASH = 2, PROF_FAMILIES = 3 };  // family 2 counts permutations, not bytes
+// family 2 counts permutations, not bytes; 3..6: the other HBM-class kernels of SURVEY.md section 8(d); 7 + air_id: K5
+enum { PROF_LDE_DIT = 0, PROF_INTT_DIF = 1, PROF_LEAF_HASH = 2, PROF_FRI_FOLD = 3, PROF_OPENINGS = 4, PROF_FRI_COMBINE = 5,
+       PROF_AUX = 6, PROF_K5 = 7, PROF_FAMILIES = 15 };
 bool profile_on();
 // Function-try-block tail of every allocating extern "C" entry: nothing may unwind across the C ABI
 // (include/bpg.h); an exception becomes BP_ERR_DEVICE with its message.
@@ -35,6 +37,7 @@ bool profile_on();
 struct KernelTimer {
   KernelTimer(int family, hipStream_t st, double alg_bytes);
   ~KernelTimer();
+  void stop();  // record the end now (the destructor then does nothing more)
   int family;
   hipStream_t st;
   double bytes;

@@ -1231,6 +1231,10 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
   uint32_t threads = (1u << log_n) < 1024 ? (1u << log_n) : 1024;
   if (threads < 64) threads = 64;
   const dim3 grid(n_aux - p0, 1, batch);
+  // algorithmic bytes: every column a product reads, once, and the product column written (SURVEY.md section 8(d):
+  // 24 n per column of a synthetic table)
+  const double reads = air_id == air::SYNTHETIC ? 2 : air_id == air::KECCAK_F ? 52 : air_id == air::KECCAK_SPONGE ? 102 : 0;
+  KernelTimer kt(PROF_AUX, st, 8.0 * (double)((uint64_t)1 << log_n) * (reads + 1) * (n_aux - p0) * batch);
   switch (air_id) {
     case air::SYNTHETIC: aux_suffix_product_kernel<air::SYNTHETIC><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
     case air::KECCAK_F: aux_suffix_product_kernel<air::KECCAK_F><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
@@ -1254,6 +1258,8 @@ int launch_quotient(const QuotArgs* qs, uint32_t batch, const QuotCoset& coset, 
   const uint32_t n_units = q.n_air_units + q.n_ctl_units, wg_rows = ceil_div(n_units, q.units_per_wg);
   const BatchOf<QuotArgs> qb = batch_of(qs, batch);
   dim3 g1(ceil_div(rows, 256), wg_rows, batch);
+  // algorithmic bytes: every element of the three LDE matrices read once, the two quotient columns written
+  KernelTimer kt(PROF_K5 + (q.air_id < 8 ? q.air_id : 0), st, 8.0 * (double)rows * ((double)q.n_cols + q.n_aux + q.n_const + 2) * batch);
   if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(qb);
   else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(qb);
   else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(qb);
@@ -1262,6 +1268,7 @@ int launch_quotient(const QuotArgs* qs, uint32_t batch, const QuotCoset& coset, 
   else if (q.air_id == bpg::air::KECCAK_SPONGE) quotient_air_kernel<bpg::air::KECCAK_SPONGE><<<g1, 256, 0, st>>>(qb);
   else if (q.air_id == bpg::air::ARITHMETIC_MUL) quotient_air_kernel<bpg::air::ARITHMETIC_MUL><<<g1, 256, 0, st>>>(qb);
   else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(qb);
+  kt.stop();
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {
     quotient_sum_kernel<<<dim3(ceil_div(rows, 256), 2, batch), 256, 0, st>>>(qb, wg_rows);
@@ -1301,14 +1308,22 @@ int launch_openings_multi(const OpenMulti* m, uint32_t batch, hipStream_t st) {
   if (int rc = check_batch(batch)) return rc;
   const uint32_t total = m[0].first_col[m[0].n_segs];  // the proofs of a batch have one shape
   if (!total) return BP_OK;
+  KernelTimer kt(PROF_OPENINGS, st, 8.0 * (double)((uint64_t)1 << m[0].log_n) * total * batch);  // every coefficient column once
   openings_multi_kernel<<<dim3(total, 1, batch), 256, 0, st>>>(batch_of(m, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
+}
+// algorithmic bytes of the alpha-combination of one proof: every coefficient column read once, six result columns written
+static double combine_bytes(const CombineMulti& m) {
+  double cols = 6;
+  for (uint32_t o = 0; o < m.n_oracles; o++) cols += m.a[o].n_cols;
+  return 8.0 * (double)((uint64_t)1 << m.a[0].log_n) * cols;
 }
 int launch_combine_partial_multi(const CombineMulti* m, uint32_t batch, uint32_t total_chunks, hipStream_t st) {
   if (!total_chunks) return BP_OK;
   if (int rc = check_batch(batch)) return rc;
   dim3 grid(ceil_div((uint64_t)1 << m[0].a[0].log_n, 256), total_chunks, batch);
+  KernelTimer kt(PROF_FRI_COMBINE, st, combine_bytes(m[0]) * batch);
   fri_combine_partial_multi_kernel<<<grid, 256, 0, st>>>(batch_of(m, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
@@ -1317,6 +1332,7 @@ int launch_combine_all(const CombineMulti* m, uint32_t batch, uint64_t* const* d
   if (int rc = check_batch(batch)) return rc;
   GPtrs gp{};
   for (uint32_t b = 0; b < batch; b++) gp.g[b] = d_g[b];
+  KernelTimer kt(PROF_FRI_COMBINE, st, combine_bytes(m[0]) * batch);
   fri_combine_all_kernel<<<dim3(ceil_div((uint64_t)1 << m[0].a[0].log_n, 256), 1, batch), 256, 0, st>>>(batch_of(m, batch), gp);
   BPG_LAUNCH_CHECK();
   return BP_OK;
@@ -1356,6 +1372,8 @@ int launch_fri_layer_leaves(const FriLayerArgs* as, uint32_t batch, hipStream_t 
 int launch_fri_fold(const FriLayerArgs* a, uint32_t batch, hipStream_t st) {
   if (int rc = check_batch(batch)) return rc;
   uint64_t n = (uint64_t)1 << (a[0].log_nl - a[0].arity_bits + a[0].rate_bits);
+  // 16 M (1 + 1/arity): the layer's M extension values read, M / arity written
+  KernelTimer kt(PROF_FRI_FOLD, st, 16.0 * (double)n * ((1 << a[0].arity_bits) + 1) * batch);
   fri_fold_kernel<<<dim3(ceil_div(n, 256), 1, batch), 256, 0, st>>>(batch_of(a, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
