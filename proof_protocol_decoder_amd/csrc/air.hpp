@@ -163,9 +163,10 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
 //   F7  2772 .. 2773  all rows    A''[0][0] limb - sum_z 2^z bit_z                               deg 1
 //   F8  2774 .. 2775  all rows    A''' limb - sum_z 2^z xor(bit_z, sum_i s_i RC_i[z])            deg 2
 //   F9  2776 .. 2825  transition  (1 - s_23) (A'_next limb - output limb), output = A''' for lane 0 else A''  deg 2
-// Units: 0 = F0, F1, F7, F8, F9 and the A''[0][0] bits of F2; 1 + x = the x-slices of F2 .. F6.
+// Units: 0 = F0, F1, F7, F8, F9 and the A''[0][0] bits of F2; 1 + x = the column-x slices of F2 .. F5 (theta); 6 + y = the
+// plane-y slice of F6 (chi).
 namespace keccak {
-constexpr uint32_t N_COLS = 2430, N_CONSTRAINTS = 2826, N_UNITS = 6;
+constexpr uint32_t N_COLS = 2430, N_CONSTRAINTS = 2826, N_UNITS = 11;
 constexpr uint32_t COL_STEP = 0, COL_A = 24, COL_C = 74, COL_CP = 394, COL_AP = 714, COL_APP = 2314, COL_APP0_BITS = 2364,
                    COL_APPP = 2428;
 constexpr uint32_t F0 = 0, F1 = 24, F2 = 48, F3 = 2032, F4 = 2352, F5 = 2672, F6 = 2722, F7 = 2772, F8 = 2774, F9 = 2776;
@@ -248,6 +249,10 @@ GL_HD void eval_control_unit(const Row& row, Emit& out) {
     }
 }
 
+// Units 1..5, one per sheet column x: theta.  F2 (bits of C[x] and of the five A' lanes of the column), F3 (C' from C),
+// F4 (column parity of A'), F5 (the input limbs).  Two passes over the column's A' lanes (parity by group of bits,
+// then one Horner accumulator per lane): merging them keeps five accumulators and twenty column pointers live and
+// takes the kernel from ~128 to 253 VGPRs.
 template <class T, class Row, class Emit>
 GL_HD void eval_column_unit(uint32_t x, const Row& row, Emit& out) {
   typedef Ops<T> F;
@@ -321,9 +326,17 @@ GL_HD void eval_column_unit(uint32_t x, const Row& row, Emit& out) {
       }
       out.all(F5 + 2 * (x + 5 * y) + h, F::sub(row.loc(COL_A + 2 * (x + 5 * y) + h), alimb));
     }
-  // F6: chi on the five output lanes (x, y)
+}
+
+// Units 6..10, one per sheet plane y: chi (F6) on the five output lanes (x, y).  B[.][y] draws on exactly five A'
+// lanes, one from every plane ((x + 3y) mod 5, x), and each of them serves three outputs of THIS plane (as B[x],
+// B[x+1], B[x+2]) -- so the A' bits are fetched by one chi unit and one theta unit, not by the four or five column
+// units that each needed them (round 3: 5.2 x the table's bytes came from HBM, profiles/r4_k5_counters.txt).
+template <class T, class Row, class Emit>
+GL_HD void eval_plane_unit(uint32_t y, const Row& row, Emit& out) {
+  typedef Ops<T> F;
 #pragma unroll 1
-  for (uint32_t y = 0; y < 5; y++) {
+  for (uint32_t x = 0; x < 5; x++) {
     const uint32_t l0 = pi_source(x, y), l1 = pi_source((x + 1) % 5, y), l2 = pi_source((x + 2) % 5, y);
     const uint32_t r0 = rho(l0), r1 = rho(l1), r2 = rho(l2);
 #pragma unroll 1
@@ -352,7 +365,8 @@ GL_HD void eval_column_unit(uint32_t x, const Row& row, Emit& out) {
 template <class T, class Row, class Emit>
 GL_HD void eval_unit(uint32_t unit, const Row& row, Emit& out) {
   if (unit == 0) eval_control_unit<T>(row, out);
-  else eval_column_unit<T>(unit - 1, row, out);
+  else if (unit <= 5) eval_column_unit<T>(unit - 1, row, out);
+  else eval_plane_unit<T>(unit - 6, row, out);
 }
 
 // One round on 25 lanes; optionally the intermediate values a trace row needs.

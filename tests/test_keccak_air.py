@@ -144,7 +144,7 @@ def test_air_registry_describes_both_airs():
     assert L.bp_air_count() == 8
     d = pkg.ops.air_describe(1)
     assert d.name == b"keccak_f" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (2430, 2430, 5, 3)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (2826, 10, 6)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (2826, 10, 11)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:10]) == 2826 and fams[0] == (0, 24, 2, 1) and fams[9] == (2776, 50, 1, 2)
     assert max(deg for _, _, _, deg in fams) == 3
