@@ -250,114 +250,121 @@ GL_HD void eval_control_unit(const Row& row, Emit& out) {
 }
 
 // Units 1..5, one per sheet column x: theta.  F2 (bits of C[x] and of the five A' lanes of the column), F3 (C' from C),
-// F4 (column parity of A'), F5 (the input limbs).  Two passes over the column's A' lanes (parity by group of bits,
-// then one Horner accumulator per lane): merging them keeps five accumulators and twenty column pointers live and
-// takes the kernel from ~128 to 253 VGPRs.
+// F4 (column parity of A'), F5 (the input limbs).  Group of four bits by group; every column of the table the unit
+// needs -- C[x], C[x-1], C[x+1], C'[x], the five A' lanes -- is loaded ONCE and used for everything while it is in
+// registers.  (The reuse distance of a second pass, ~400 KB per workgroup with ~100 workgroups sharing an XCD's
+// 4 MiB L2, is far beyond the cache: round 3's two passes made every load a trip to HBM, 5.2 x the table's bytes,
+// profiles/r4_k5_counters.txt.)  F5 is linear in the bits, so a group's share of the limb sum is handed to the
+// consumer as it is formed (the fold acc = sum_i c_i alpha^(T-1-i) adds the shares of one index up): no limb
+// accumulator lives across groups, and the loop over the five lanes stays rolled.
 template <class T, class Row, class Emit>
 GL_HD void eval_column_unit(uint32_t x, const Row& row, Emit& out) {
   typedef Ops<T> F;
   const uint32_t xm = (x + 4) % 5, xp = (x + 1) % 5;
-  // pass 1, per group of four bits of column x: F2 (C bits), F3 (theta), F4 (column parity of A')
-#pragma unroll 1
-  for (uint32_t zt = 63; zt < 64; zt -= 4) {  // the group is bits zt, zt - 1, zt - 2, zt - 3
-    T c[4], cp[4], cm[4], cq[4], t1[4], t2[4], u[4];
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-      c[i] = row.loc(COL_C + 64 * x + zt - i);
-      cp[i] = row.loc(COL_CP + 64 * x + zt - i);
-      cm[i] = row.loc(COL_C + 64 * xm + zt - i);
-      cq[i] = row.loc(COL_C + 64 * xp + (zt - i + 63) % 64);
-    }
-    // C' = xor3(C, C[x-1], rot(C[x+1], 1)) = u + w - 2uw with u = C ^ C[x-1], w = the rotated bit
-    F::mul4(c, c, t1);
-    F::mul4(c, cm, t2);
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-      out.all(F2 + 64 * x + zt - i, F::sub(t1[i], c[i]));
-      u[i] = xor_from_product<T>(c[i], cm[i], t2[i]);
-    }
-    F::mul4(u, cq, t1);
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-      out.all(F3 + 64 * x + zt - i, F::sub(cp[i], xor_from_product<T>(u[i], cq[i], t1[i])));
-      u[i] = F::sub(F::k(0), cp[i]);  // becomes d = sum_y A'[x][y][z] - C'[x][z]
-    }
-#pragma unroll 1
-    for (uint32_t y = 0; y < 5; y++)
-#pragma unroll
-      for (uint32_t i = 0; i < 4; i++) u[i] = F::add(u[i], row.loc(COL_AP + 64 * (x + 5 * y) + zt - i));
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-      t1[i] = F::sub(u[i], F::k(2));
-      t2[i] = F::sub(u[i], F::k(4));
-    }
-    F::mul4(u, t1, c);
-    F::mul4(c, t2, cp);
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) out.all(F4 + 64 * x + zt - i, cp[i]);
-  }
-  // pass 2, per lane (x, y) and half: F2 (A' bits) and F5, the input limb = sum_z 2^z (A' ^ D), D = C ^ C' (Horner
-  // from the top bit down; D is recomputed per lane so that one accumulator is live, not five)
 #pragma unroll 1
   for (uint32_t y = 0; y < 5; y++)
 #pragma unroll 1
-    for (uint32_t h = 0; h < 2; h++) {
-      T alimb = F::k(0);
+    for (uint32_t h = 0; h < 2; h++) out.all(F5 + 2 * (x + 5 * y) + h, row.loc(COL_A + 2 * (x + 5 * y) + h));
 #pragma unroll 1
-      for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
-        const uint32_t zt = 32 * h + z0 - 1;
-        T c[4], cp[4], ap[4], dd[4], apap[4], apd[4];
+  for (uint32_t zt = 63; zt < 64; zt -= 4) {  // the group is bits zt, zt - 1, zt - 2, zt - 3
+    const uint32_t h = zt >> 5;
+    const T weight = F::k((uint64_t)1 << ((zt - 3) & 31));  // 2^(lowest bit of the group within its limb)
+    T c[4], cp[4], dd[4], u[4];
+    {
+      T cm[4], cq[4], t1[4], t2[4];
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-          c[i] = row.loc(COL_C + 64 * x + zt - i);
-          cp[i] = row.loc(COL_CP + 64 * x + zt - i);
-          ap[i] = row.loc(COL_AP + 64 * (x + 5 * y) + zt - i);
-        }
-        F::mul4(c, cp, dd);
-        F::mul4(ap, ap, apap);
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) dd[i] = xor_from_product<T>(c[i], cp[i], dd[i]);
-        F::mul4(ap, dd, apd);
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-          out.all(F2 + 320 + 64 * (x + 5 * y) + zt - i, F::sub(apap[i], ap[i]));
-          alimb = F::add(F::dbl(alimb), xor_from_product<T>(ap[i], dd[i], apd[i]));
-        }
+      for (uint32_t i = 0; i < 4; i++) {
+        c[i] = row.loc(COL_C + 64 * x + zt - i);
+        cp[i] = row.loc(COL_CP + 64 * x + zt - i);
+        cm[i] = row.loc(COL_C + 64 * xm + zt - i);
+        cq[i] = row.loc(COL_C + 64 * xp + (zt - i + 63) % 64);
       }
-      out.all(F5 + 2 * (x + 5 * y) + h, F::sub(row.loc(COL_A + 2 * (x + 5 * y) + h), alimb));
+      // C' = xor3(C, C[x-1], rot(C[x+1], 1)) = u + w - 2uw with u = C ^ C[x-1], w = the rotated bit
+      F::mul4(c, c, t1);
+      F::mul4(c, cm, t2);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        out.all(F2 + 64 * x + zt - i, F::sub(t1[i], c[i]));
+        u[i] = xor_from_product<T>(c[i], cm[i], t2[i]);
+      }
+      F::mul4(u, cq, t1);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) out.all(F3 + 64 * x + zt - i, F::sub(cp[i], xor_from_product<T>(u[i], cq[i], t1[i])));
+      F::mul4(c, cp, t2);  // D = C ^ C'
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        dd[i] = xor_from_product<T>(c[i], cp[i], t2[i]);
+        u[i] = F::sub(F::k(0), cp[i]);  // becomes d = sum_y A'[x][y][z] - C'[x][z]
+      }
     }
+#pragma unroll 1
+    for (uint32_t y = 0; y < 5; y++) {  // the five lanes of the column: booleanity, parity, A = A' ^ D
+      T ap[4], apap[4], apd[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) ap[i] = row.loc(COL_AP + 64 * (x + 5 * y) + zt - i);
+      F::mul4(ap, ap, apap);
+      F::mul4(ap, dd, apd);
+      T g = F::k(0);  // the group's four bits of A = A' ^ D, bit zt on top
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        out.all(F2 + 320 + 64 * (x + 5 * y) + zt - i, F::sub(apap[i], ap[i]));
+        u[i] = F::add(u[i], ap[i]);
+        g = F::add(F::dbl(g), xor_from_product<T>(ap[i], dd[i], apd[i]));
+      }
+      out.all(F5 + 2 * (x + 5 * y) + h, F::sub(F::k(0), F::mul(g, weight)));
+    }
+    {
+      T t1[4], t2[4], p[4], q[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        t1[i] = F::sub(u[i], F::k(2));
+        t2[i] = F::sub(u[i], F::k(4));
+      }
+      F::mul4(u, t1, p);
+      F::mul4(p, t2, q);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) out.all(F4 + 64 * x + zt - i, q[i]);
+    }
+  }
 }
 
 // Units 6..10, one per sheet plane y: chi (F6) on the five output lanes (x, y).  B[.][y] draws on exactly five A'
-// lanes, one from every plane ((x + 3y) mod 5, x), and each of them serves three outputs of THIS plane (as B[x],
-// B[x+1], B[x+2]) -- so the A' bits are fetched by one chi unit and one theta unit, not by the four or five column
-// units that each needed them (round 3: 5.2 x the table's bytes came from HBM, profiles/r4_k5_counters.txt).
+// lanes, one from every plane ((x + 3y) mod 5, x), each rotated by its own offset.  A group of four bits of all five
+// B lanes is loaded once and serves the five outputs from registers (each B is b0 of one output, b1 of another, b2 of a
+// third); the outputs' limb sums go to the consumer group by group, as in the column units.
 template <class T, class Row, class Emit>
 GL_HD void eval_plane_unit(uint32_t y, const Row& row, Emit& out) {
   typedef Ops<T> F;
-#pragma unroll 1
+  uint32_t src[5], rot[5];
+#pragma unroll
   for (uint32_t x = 0; x < 5; x++) {
-    const uint32_t l0 = pi_source(x, y), l1 = pi_source((x + 1) % 5, y), l2 = pi_source((x + 2) % 5, y);
-    const uint32_t r0 = rho(l0), r1 = rho(l1), r2 = rho(l2);
+    src[x] = pi_source(x, y);
+    rot[x] = rho(src[x]);
+  }
 #pragma unroll 1
-    for (uint32_t h = 0; h < 2; h++) {
-      T acc = F::k(0);
+  for (uint32_t l = 0; l < 5; l++)
 #pragma unroll 1
-      for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
-        T b0[4], nb1[4], b2[4], t[4], bt[4];
+    for (uint32_t h = 0; h < 2; h++) out.all(F6 + 2 * (l + 5 * y) + h, row.loc(COL_APP + 2 * (l + 5 * y) + h));
+#pragma unroll 1
+  for (uint32_t zt = 63; zt < 64; zt -= 4) {
+    const uint32_t h = zt >> 5;
+    const T weight = F::k((uint64_t)1 << ((zt - 3) & 31));
+    T b[5][4];  // B[x][z] = A'[source of x][(z - rho) mod 64] for z = zt - i
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-          const uint32_t z = 32 * h + z0 - 1 - i;  // B[.][z] = A'[source][(z - rho) mod 64]
-          b0[i] = row.loc(COL_AP + 64 * l0 + (z + 64 - r0) % 64);
-          nb1[i] = F::sub(F::k(1), row.loc(COL_AP + 64 * l1 + (z + 64 - r1) % 64));
-          b2[i] = row.loc(COL_AP + 64 * l2 + (z + 64 - r2) % 64);
-        }
-        F::mul4(nb1, b2, t);
-        F::mul4(b0, t, bt);
+    for (uint32_t x = 0; x < 5; x++)
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++) acc = F::add(F::dbl(acc), xor_from_product<T>(b0[i], t[i], bt[i]));
-      }
-      out.all(F6 + 2 * (x + 5 * y) + h, F::sub(row.loc(COL_APP + 2 * (x + 5 * y) + h), acc));
+      for (uint32_t i = 0; i < 4; i++) b[x][i] = row.loc(COL_AP + 64 * src[x] + (zt - i + 64 - rot[x]) % 64);
+#pragma unroll
+    for (uint32_t x = 0; x < 5; x++) {
+      T nb1[4], t[4], bt[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) nb1[i] = F::sub(F::k(1), b[(x + 1) % 5][i]);
+      F::mul4(nb1, b[(x + 2) % 5], t);
+      F::mul4(b[x], t, bt);
+      T g = F::k(0);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) g = F::add(F::dbl(g), xor_from_product<T>(b[x][i], t[i], bt[i]));
+      out.all(F6 + 2 * (x + 5 * y) + h, F::sub(F::k(0), F::mul(g, weight)));
     }
   }
 }
