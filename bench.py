@@ -46,7 +46,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
 # (two rocprofv3 --pmc passes of this same command, tools/pmc_family_traffic.py).  bench.py cannot collect
 # counters itself, so it reads the tracked summary and names it (and the commit it was taken at) beside the
 # number; no file, no number.
-TRAFFIC_FILE = os.path.join("profiles", "r3_pmc_lde_family.txt")
+TRAFFIC_FILE = os.path.join("profiles", "r4_pmc_lde_family.txt")
 
 
 # (flag, bp_tune_* entry, help): every run-time knob of the library that bench.py can set
@@ -460,13 +460,13 @@ def main():
 # 4 cycles (a SIMD has 16 lanes), at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md).
 N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
 VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * PEAK_CLOCK_HZ / 4
-SQ_FILE = os.path.join("profiles", "r3_hash_sq_counters.txt")
+SQ_FILE = os.path.join("profiles", "r4_hash_sq_counters.txt")
 
 
 def valu_insts_per_perm():
     """VALU wave-instructions per Poseidon permutation of the shipped leaf-hash kernel (four sets per wave, grouped
     partial rounds), from the tracked SQ-counter summary (rocprofv3 --pmc SQ_INSTS_VALU over 2^21 rows x 8
-    permutations; tools/prof_round3.sh)."""
+    permutations; tools/prof_round4.sh)."""
     import re
     try:
         txt = open(os.path.join(ROOT, SQ_FILE)).read()

@@ -207,7 +207,11 @@ struct bp_stark_cfg;
  * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns, 5 = byte_packing,
  * a big-endian byte sequence and the word it spells on 297 columns, 6 = keccak_sponge, the absorbing side of
  * Keccak-256 (XOR into the rate, chaining, pad10*1) on 2414 columns, 7 = arithmetic_mul, x * y = z + 2^256 w on 1217
- * columns (likewise their own layouts; AIR 7 is not wired to a transaction's table: bp_stark_prove_air only).  bp_air_describe returns the shape and
+ * columns (likewise their own layouts; AIR 7 is not wired to a transaction's table: bp_stark_prove_air only), 8 = plonk, a
+ * PLONK-shaped circuit as a table: 135 wires (80 routed), 84 preprocessed constant columns (two gate selectors, two gate
+ * constants, 80 sigmas), arithmetic and S-box gates, public inputs bound to the first row and the copy-constraint
+ * permutation argument (Z + nine partial products per challenge set) as its auxiliary columns; degree 9, rate_bits 3 -- the
+ * proof system of upstream's recursion circuits (CircuitData::prove), not their gate set and not a verifier circuit.  bp_air_describe returns the shape and
  * the constraint list of an AIR as families (first index, count, kind, degree); the list is followed by the constraints
  * of the table's auxiliary columns, its cross-table lookups (csrc/air.hpp, namespace ctl): n_cols / 8 unfiltered running
  * products for the synthetic AIR (a load placeholder), filter + carried input + two filtered running products for
@@ -283,6 +287,13 @@ int bp_keccak_sponge_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log
  * d_inputs: [n][9] = is_mul (0 = a padding row), the four 64-bit words of x and of y; or NULL to draw them from `seed`. */
 int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
+/* AIR 8 (plonk): the 84 preprocessed constant columns of the fixed circuit (selectors, gate constants drawn from `seed`,
+ * the 80 sigmas of its copy permutation), n = 2^log_n rows, column-major; and the circuit's witness, 135 wires: free wires
+ * drawn from `seed`, the four public inputs in row 0 and, through a copy constraint, in the first arithmetic row. */
+int bp_plonk_constants(uint64_t seed, uint32_t log_n, uint64_t* d_consts_out, void* stream);
+int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t pub[4], uint32_t log_n, uint64_t* d_trace_out,
+                   void* stream);
+
 /* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
  * folded domain), done in the evaluation domain.  d_values: the layer's n_l << rate_bits extension values
  * (c0, c1 interleaved) on shift * <w_{n_l 2^r}>, coset-major (position t*n_l + m = point index t + 2^r m).
@@ -327,6 +338,11 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
  * constants commitment when n_const > 0, else NULL.  Host only; BP_ERR_VERIFY + bp_last_error() on rejection. */
 int bp_stark_verify_air(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint8_t* proof,
                         size_t len);
+/* AIR 8 (plonk) binds four public inputs to its first row.  A lone table proof (bp_stark_prove_air(8, ...)) takes them from
+ * its seed by bp_stark_public_inputs; its verifier is given them (pub = NULL: four zeros, what every other AIR has). */
+void bp_stark_public_inputs(uint64_t seed, uint64_t out[4]);
+int bp_stark_verify_air_pub(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint64_t* pub,
+                            const uint8_t* proof, size_t len);
 /* bp_stark_prove_synthetic keeps one worker (stream + device arena, up to ~100 GB for a 2^20 x 2432
  * table) parked per device between calls, because re-allocating it costs more than the proof.
  * This frees the parked workers. */

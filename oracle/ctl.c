@@ -25,7 +25,11 @@ enum { KCOL_STEP = 0, KCOL_A = 24, KCOL_APP = 2314, KCOL_APPP = 2428 };
 enum { SCOL_FULL = 0, SCOL_FINAL = 1, SCOL_CAP = 2314, SCOL_XORED = 2330, SCOL_UPDATED = 2364 };
 
 uint32_t orc_ctl_n_aux(uint32_t air_id, uint32_t n_cols) {
-  return air_id == ORC_AIR_SYNTHETIC ? n_cols / 8 : air_id == ORC_AIR_KECCAK_F ? 5 : air_id == ORC_AIR_KECCAK_SPONGE ? 2 : 1;
+  return air_id == ORC_AIR_SYNTHETIC ? n_cols / 8
+         : air_id == ORC_AIR_KECCAK_F ? 5
+         : air_id == ORC_AIR_KECCAK_SPONGE ? 2
+         : air_id == ORC_AIR_PLONK ? 20 /* Z + nine partial products per challenge set (plonk_air.c) */
+                                   : 1;
 }
 
 /* The auxiliary columns of a table with a real AIR, from its trace values tv ([n_cols][N], column-major).

@@ -69,7 +69,8 @@ typedef struct {
   uint32_t air_id; /* 0: the synthetic AIR (stark.c), 1: Keccak-f[1600] (keccak_air.c), 2: logic (logic_air.c), 3: memory
                       (memory_air.c), 4: arithmetic (arithmetic_air.c), 5: byte packing
                       (byte_packing_air.c), 6: Keccak sponge (keccak_sponge_air.c),
-                      7: multiplication (arithmetic_mul_air.c); header word 14 of a proof */
+                      7: multiplication (arithmetic_mul_air.c), 8: plonk (plonk_air.c); header word 14 of a proof */
+  uint64_t pub[4]; /* the table's public inputs (AIR 8 binds them to its first row); zero for the other AIRs */
 } orc_stark_cfg;
 #define ORC_AIR_SYNTHETIC 0u
 #define ORC_AIR_KECCAK_F 1u
@@ -93,6 +94,9 @@ typedef struct {
 #define ORC_AIR_ARITHMETIC_MUL 7u
 #define ORC_ARITHMETIC_MUL_COLS 1217u
 #define ORC_ARITHMETIC_MUL_CONSTRAINTS 1218u
+#define ORC_AIR_PLONK 8u
+#define ORC_PLONK_COLS 135u
+#define ORC_PLONK_CONSTS 84u
 
 /* starky ConstraintConsumer: acc_j = acc_j * alpha_j + constraint, in list order; base field (the LDE coset)
  * and extension field (the verifier at zeta; the alphas stay in the base field). */
@@ -141,6 +145,15 @@ void orc_keccak_sponge_trace(uint64_t seed, const uint64_t* inputs, unsigned log
 void orc_keccak_sponge_trace_limit(uint64_t seed, const uint64_t* inputs, unsigned log_n, size_t row_limit, gl_t* trace);
 void orc_keccak_sponge_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
 void orc_keccak_sponge_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
+/* plonk_air.c */
+void orc_stark_public_inputs(uint64_t seed, gl_t out[4]);
+void orc_plonk_constants(uint64_t seed, unsigned log_n, gl_t* consts);
+void orc_plonk_trace(uint64_t seed, const gl_t pub[4], const gl_t* consts, unsigned log_n, gl_t* trace);
+void orc_plonk_aux_columns(const gl_t* trace_values, const gl_t* consts, unsigned log_n, const gl_t ctl[4], gl_t* aux);
+void orc_plonk_constraints_base(const gl_t* cst, const gl_t* loc, const gl_t* aux, const gl_t* aux_nxt, const gl_t ctl[4],
+                                const gl_t pub[4], gl_t x, orc_consumer* k);
+void orc_plonk_constraints_ext(const gl2_t* cst, const gl2_t* loc, const gl2_t* aux, const gl2_t* aux_nxt, const gl_t ctl[4],
+                               const gl_t pub[4], gl2_t x, orc_consumer2* k);
 /* arithmetic_mul_air.c */
 void orc_arithmetic_mul_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* trace);
 void orc_arithmetic_mul_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);

@@ -48,12 +48,12 @@ static uint64_t circuit_seed(uint32_t kind, uint32_t degree) {
 }
 static orc_stark_cfg rec_cfg_of(const orc_pg_config* c) {
   orc_stark_cfg r = {c->rec_log_n, c->rec_n_cols, c->rec_n_const, 3, c->rec_rate_bits, c->stark_cap_height,
-                     c->rec_num_queries, c->rec_pow_bits, c->arity_bits, c->final_poly_bits, ORC_AIR_SYNTHETIC};
+                     c->rec_num_queries, c->rec_pow_bits, c->arity_bits, c->final_poly_bits, ORC_AIR_SYNTHETIC, {0, 0, 0, 0}};
   return r;
 }
 static orc_stark_cfg table_cfg_of(const orc_pg_config* c, uint32_t log_n, uint32_t width) {
   orc_stark_cfg r = {log_n, width, 0, 1, c->stark_rate_bits, c->stark_cap_height, c->stark_num_queries,
-                     c->stark_pow_bits, c->arity_bits, c->final_poly_bits, ORC_AIR_SYNTHETIC};
+                     c->stark_pow_bits, c->arity_bits, c->final_poly_bits, ORC_AIR_SYNTHETIC, {0, 0, 0, 0}};
   return r;
 }
 

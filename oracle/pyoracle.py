@@ -27,8 +27,9 @@ def build(force=False):
 
 
 class StarkCfg(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("log_n", "n_cols", "n_const", "deg_pow", "rate_bits", "cap_height",
-                                           "num_queries", "pow_bits", "arity_bits", "final_poly_bits", "air_id")]
+    _fields_ = ([(n, C.c_uint32) for n in ("log_n", "n_cols", "n_const", "deg_pow", "rate_bits", "cap_height",
+                                            "num_queries", "pow_bits", "arity_bits", "final_poly_bits", "air_id")]
+                + [("pub", C.c_uint64 * 4)])   # the table's public inputs (AIR 8); zero otherwise
 
 
 class Challenger(C.Structure):
@@ -119,6 +120,9 @@ def lib():
     L.orc_pg_txn_keccak.argtypes = [vp, u64p, vp, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_txn_witness.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                      C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
+    L.orc_stark_public_inputs.argtypes = [u6, u64p]
+    L.orc_plonk_constants.argtypes = [u6, u, u64p]
+    L.orc_plonk_trace.argtypes = [u6, u64p, u64p, u, u64p]
     L.orc_pg_txn_tables.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                     C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_verify_tables.argtypes = [C.POINTER(PgConfig), u64p, sz]
@@ -251,9 +255,35 @@ ARITHMETIC_MUL_COLS = 1217
 
 
 def make_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, num_queries=84, pow_bits=16,
-             arity_bits=4, final_poly_bits=5, air_id=AIR_SYNTHETIC):
+             arity_bits=4, final_poly_bits=5, air_id=AIR_SYNTHETIC, pub=(0, 0, 0, 0)):
     return StarkCfg(log_n, n_cols, n_const, deg_pow, rate_bits, cap_height, num_queries, pow_bits, arity_bits,
-                    final_poly_bits, air_id)
+                    final_poly_bits, air_id, (C.c_uint64 * 4)(*[int(x) for x in pub]))
+
+
+AIR_PLONK, PLONK_COLS, PLONK_CONSTS = 8, 135, 84
+
+
+def plonk_cfg(log_n, pub=(0, 0, 0, 0), **kw):
+    """AIR 8 (plonk_air.c): 135 wires, 84 constant columns, degree 9 -> deg_pow 3, rate_bits 3."""
+    return make_cfg(log_n, PLONK_COLS, n_const=PLONK_CONSTS, deg_pow=3, rate_bits=3, air_id=AIR_PLONK, pub=pub, **kw)
+
+
+def stark_public_inputs(seed):
+    out = np.empty(4, dtype=np.uint64)
+    lib().orc_stark_public_inputs(C.c_uint64(seed), out)
+    return out
+
+
+def plonk_constants(log_n, seed):
+    out = np.zeros((PLONK_CONSTS, 1 << log_n), dtype=np.uint64)
+    lib().orc_plonk_constants(C.c_uint64(seed), log_n, out)
+    return out
+
+
+def plonk_trace(log_n, seed, pub, consts):
+    out = np.zeros((PLONK_COLS, 1 << log_n), dtype=np.uint64)
+    lib().orc_plonk_trace(C.c_uint64(seed), arr(pub), arr(consts), log_n, out)
+    return out
 
 
 def keccak_f(lanes):

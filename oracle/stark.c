@@ -160,8 +160,12 @@ typedef orc_consumer consumer_t;
 #define cons orc_cons
 static void eval_constraints_base(const orc_stark_cfg* cf, const gl_t* cst, const gl_t* loc,
                                   const gl_t* nxt, const gl_t* aux, const gl_t* aux_nxt,
-                                  const gl_t ctl[4], consumer_t* k) {
+                                  const gl_t ctl[4], gl_t x, consumer_t* k) {
   size_t G = cf->n_cols / 4, A = cf->n_cols / 8;
+  if (cf->air_id == ORC_AIR_PLONK) { /* gates and copy constraints in one list (plonk_air.c) */
+    orc_plonk_constraints_base(cst, loc, aux, aux_nxt, ctl, cf->pub, x, k);
+    return;
+  }
   if (cf->air_id == ORC_AIR_KECCAK_F) { /* the AIR's own list (keccak_air.c), then the table's lookups (ctl.c) */
     orc_keccak_constraints_base(loc, nxt, k);
     G = 0;
@@ -207,8 +211,12 @@ typedef orc_consumer2 consumer2_t;
 static inline gl2_t pow_e2(gl2_t t, uint32_t e) { return e == 3 ? gl2_mul(gl2_sqr(t), t) : t; }
 static void eval_constraints_ext(const orc_stark_cfg* cf, const gl2_t* cst, const gl2_t* loc,
                                  const gl2_t* nxt, const gl2_t* aux, const gl2_t* aux_nxt,
-                                 const gl_t ctl[4], consumer2_t* k) {
+                                 const gl_t ctl[4], gl2_t x, consumer2_t* k) {
   size_t G = cf->n_cols / 4, A = cf->n_cols / 8;
+  if (cf->air_id == ORC_AIR_PLONK) {
+    orc_plonk_constraints_ext(cst, loc, aux, aux_nxt, ctl, cf->pub, x, k);
+    return;
+  }
   if (cf->air_id == ORC_AIR_KECCAK_F) {
     orc_keccak_constraints_ext(loc, nxt, k);
     G = 0;
@@ -325,7 +333,7 @@ void orc_quotient_values(const orc_stark_cfg* cf, const gl_t* const_lde, const g
         k.z_last = gl_sub(x, ginv);
         k.l_first = gl_mul(gl_mul(zh, ninv), gl_inv(gl_sub(x, 1)));
         k.l_last = gl_mul(gl_mul(zh, ninv), gl_inv(gl_sub(gl_mul(g, x), 1)));
-        eval_constraints_base(cf, cst, loc, nxt, ax, axn, ctl, &k);
+        eval_constraints_base(cf, cst, loc, nxt, ax, axn, ctl, x, &k);
         gl_t zhi = gl_inv(zh);
         qv[i] = gl_mul(k.acc[0], zhi);
         qv[M + i] = gl_mul(k.acc[1], zhi);
@@ -348,7 +356,8 @@ int orc_stark_prove_lookup(const orc_stark_cfg* cf, const orc_committed* consts,
   const size_t N = (size_t)1 << log_n, M = N << r, C = cf->n_cols, K = cf->n_const, A = L.n_aux,
                Q = L.n_quot, qdf = (size_t)1 << r;
   if ((cf->deg_pow != 1 && cf->deg_pow != 3) || qdf != 3 * cf->deg_pow - 1 || C < 8 || log_m < h ||
-      (K && !consts) || cf->air_id > ORC_AIR_ARITHMETIC_MUL ||
+      (K && !consts) || cf->air_id > ORC_AIR_PLONK ||
+      (cf->air_id == ORC_AIR_PLONK && (C != ORC_PLONK_COLS || K != ORC_PLONK_CONSTS || cf->deg_pow != 3)) ||
       (cf->air_id == ORC_AIR_ARITHMETIC_MUL && (C != ORC_ARITHMETIC_MUL_COLS || K != 0 || cf->deg_pow != 1)) ||
       (cf->air_id == ORC_AIR_KECCAK_SPONGE && (C != ORC_KECCAK_SPONGE_COLS || K != 0 || cf->deg_pow != 1)) ||
       (cf->air_id == ORC_AIR_BYTE_PACKING && (C != ORC_BYTE_PACKING_COLS || K != 0 || cf->deg_pow != 1)) ||
@@ -367,7 +376,13 @@ int orc_stark_prove_lookup(const orc_stark_cfg* cf, const orc_committed* consts,
   /* 1. auxiliary columns.  Synthetic table: suffix products of term = gamma + a + beta*b; a table with a real AIR:
    * its lookups (ctl.c) */
   gl_t* auxv = (gl_t*)xmalloc(A * N * sizeof(gl_t));
-  if (cf->air_id != ORC_AIR_SYNTHETIC) {
+  if (cf->air_id == ORC_AIR_PLONK) { /* the copy products need the sigmas on the trace domain: evaluate the constants */
+    gl_t* cv = (gl_t*)xmalloc(K * N * sizeof(gl_t));
+    memcpy(cv, consts->coeffs, K * N * sizeof(gl_t));
+    for (size_t c = 0; c < K; c++) orc_ntt(cv + c * N, log_n);
+    orc_plonk_aux_columns(tv, cv, log_n, ctl, auxv);
+    free(cv);
+  } else if (cf->air_id != ORC_AIR_SYNTHETIC) {
     orc_ctl_aux_columns(cf->air_id, tv, log_n, ctl, exposed, n_exposed, auxv);
   } else {
 #pragma omp parallel for
@@ -604,7 +619,7 @@ int orc_stark_verify(const orc_stark_cfg* cf, const gl_t* const_cap, const gl_t 
     k.z_last = gl2_sub(zeta, gl2_from(gl_inv(g)));
     k.l_first = gl2_mul(gl2_mul(zh, ninv), gl2_inv(gl2_sub(zeta, gl2_from(1))));
     k.l_last = gl2_mul(gl2_mul(zh, ninv), gl2_inv(gl2_sub(gl2_scale(zeta, g), gl2_from(1))));
-    eval_constraints_ext(cf, oz, oz + K, on, oz + K + C, on + C, ctl, &k);
+    eval_constraints_ext(cf, oz, oz + K, on, oz + K + C, on + C, ctl, zeta, &k);
     for (int j = 0; j < 2; j++) {
       gl2_t acc = gl2_from(0);
       for (size_t t = qdf; t-- > 0;) acc = gl2_add(gl2_mul(acc, zn), oz[K + C + A + j * qdf + t]);

@@ -51,7 +51,7 @@
 namespace bpg {
 namespace air {
 
-constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, BYTE_PACKING = 5, KECCAK_SPONGE = 6, ARITHMETIC_MUL = 7, COUNT = 8;
+constexpr uint32_t SYNTHETIC = 0, KECCAK_F = 1, LOGIC = 2, MEMORY = 3, ARITHMETIC = 4, BYTE_PACKING = 5, KECCAK_SPONGE = 6, ARITHMETIC_MUL = 7, PLONK = 8, COUNT = 9;
 
 struct Shape {
   uint32_t air_id, n_cols, n_const, deg_pow;
@@ -829,6 +829,88 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 }
 }  // namespace arithmetic_mul
 
+// ------------------------------------------------------------------------------------------ AIR 8: plonk
+// A PLONK-shaped circuit as a table: what upstream's recursion circuits are proved with (CircuitData::prove, reached
+// from proof_gen.rs:44-52 for the per-table shrink chains and from :66-75, :97-103 for aggregation and block proofs;
+// CircuitConfig::standard_recursion_config [UPSTREAM-UNVERIFIED]: 135 wires of which 80 are routed, constants and
+// sigmas preprocessed, quotient degree factor 8, two challenges).  NOT upstream's gate set and NOT a verifier circuit
+// (a proof of this AIR does not check a child proof): it is the proof SYSTEM of the recursion layer -- gates selected
+// by preprocessed constants, public inputs bound in-circuit, and the copy-constraint permutation argument with Z and
+// partial products -- on a fixed satisfiable circuit.
+// Wires (135 columns): routed 0..79 = 20 slots (a, b, c, d) = 4s .. 4s+3; advice 80..134 = 11 S-box units
+// (x, x^2, x^4, x^6, x^7) = 80 + 5i ...
+// Preprocessed constants (84 columns): 0 q_arith, 1 q_sbox (gate selectors), 2 c0, 3 c1 (gate constants),
+// 4..83 sigma_j, j < 80: the copy permutation, sigma_j(w^i) = k_j' w^i' for the position (j', i') that wire (j, i) is
+// tied to (k_j = 7^j: 80 disjoint cosets of the row subgroup).
+// Gates (index, kind, degree):
+//   G0  0 .. 19   all rows   q_arith (c0 a_s b_s + c1 c_s - d_s)                     (ArithmeticGate shape: 20 ops per row)  4
+//   G1  20 .. 63  all rows   q_sbox (x2 - x x), (x4 - x2 x2), (x6 - x4 x2), (x7 - x6 x)  per unit (the Poseidon S-box x^7)   3
+//   G2  64 .. 85  all rows   q_sbox (x - a_i), q_sbox (x7 - d_i): the unit's input and output are routed wires            2
+//   G3  86 .. 89  first row  w_j - pub_j, j < 4: the public inputs (the hash of the proof's public-input list)             1
+// The copy constraints are the table's auxiliary columns (namespace ctl below): per challenge set Z and nine partial
+// products.  The fixed circuit (rows in groups of four after a first group that holds the public-input row and no-ops):
+//   row 4g      arithmetic, inputs free             d_s = c0 a_s b_s + c1 c_s
+//   row 4g + 1  arithmetic, a_s := d_s(4g), b_s := d_(s+1)(4g), c_s := c_s(4g)          (3- and 2-cycles)
+//   row 4g + 2  S-box, x_i := d_i(4g + 1) through a_i, d_i = x_i^7                       (2-cycles)
+//   row 4g + 3  arithmetic, a_i := d_i(4g + 2) for i < 11, the rest free               (2-cycles)
+// and c_j(4) := pub_j (row 0), j < 4, ties the computation to the public inputs.
+namespace plonk {
+constexpr uint32_t N_COLS = 135, N_CONST = 84, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 90, N_UNITS = 1;
+constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_SIGMA = 4;
+constexpr uint32_t COL_SBOX = 80;
+constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86;
+// where wire (col, row) points in the copy permutation (the next position of its cycle), n rows
+GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t& col_out, uint32_t& row_out) {
+  col_out = col; row_out = row;
+  if (col >= N_ROUTED || row < 4) {
+    // the public-input row: w_j(0) -> c_j(4) -> c_j(5) -> w_j(0), j < 4 (needs a second group to exist)
+    if (row == 0 && col < 4 && n >= 8) { col_out = 4 * col + 2; row_out = 4; }
+    return;
+  }
+  const uint32_t g = row >> 2, p = row & 3, s = col >> 2, w = col & 3;
+  const uint32_t base = 4 * g;
+  if (p == 0) {
+    if (w == 3) { col_out = 4 * s; row_out = base + 1; }                        // d_s(4g) -> a_s(4g+1)
+    else if (w == 2) { col_out = col; row_out = base + 1; }                     // c_s(4g) -> c_s(4g+1)
+  } else if (p == 1) {
+    if (w == 0) { col_out = 4 * ((s + N_SLOTS - 1) % N_SLOTS) + 1; row_out = base + 1; }  // a_s -> b_(s-1) of the same row
+    else if (w == 1) { col_out = 4 * ((s + 1) % N_SLOTS) + 3; row_out = base; }           // b_s(4g+1) -> d_(s+1)(4g)
+    else if (w == 2) {                                                                   // c_s(4g+1) -> c_s(4g), or the public input
+      if (g == 1 && s < 4) { col_out = s; row_out = 0; }
+      else { col_out = col; row_out = base; }
+    } else if (s < N_SBOX) { col_out = 4 * s; row_out = base + 2; }             // d_i(4g+1) -> a_i(4g+2)
+  } else if (p == 2) {
+    if (s < N_SBOX && w == 0) { col_out = 4 * s + 3; row_out = base + 1; }      // a_i(4g+2) -> d_i(4g+1)
+    else if (s < N_SBOX && w == 3) { col_out = 4 * s; row_out = base + 3; }     // d_i(4g+2) -> a_i(4g+3)
+  } else {
+    if (s < N_SBOX && w == 0) { col_out = 4 * s + 3; row_out = base + 2; }      // a_i(4g+3) -> d_i(4g+2)
+  }
+}
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const T qa = row.cst(CST_ARITH), qs = row.cst(CST_SBOX), c0 = row.cst(CST_C0), c1 = row.cst(CST_C1);
+#pragma unroll 1
+  for (uint32_t s = 0; s < N_SLOTS; s++) {
+    const T a = row.loc(4 * s), b = row.loc(4 * s + 1), c = row.loc(4 * s + 2), d = row.loc(4 * s + 3);
+    out.all(G0 + s, F::mul(qa, F::sub(F::add(F::mul(c0, F::mul(a, b)), F::mul(c1, c)), d)));
+  }
+#pragma unroll 1
+  for (uint32_t i = 0; i < N_SBOX; i++) {
+    const uint32_t u = COL_SBOX + 5 * i;
+    const T x = row.loc(u), x2 = row.loc(u + 1), x4 = row.loc(u + 2), x6 = row.loc(u + 3), x7 = row.loc(u + 4);
+    out.all(G1 + 4 * i, F::mul(qs, F::sub(x2, F::mul(x, x))));
+    out.all(G1 + 4 * i + 1, F::mul(qs, F::sub(x4, F::mul(x2, x2))));
+    out.all(G1 + 4 * i + 2, F::mul(qs, F::sub(x6, F::mul(x4, x2))));
+    out.all(G1 + 4 * i + 3, F::mul(qs, F::sub(x7, F::mul(x6, x))));
+    out.all(G2 + 2 * i, F::mul(qs, F::sub(x, row.loc(4 * i))));
+    out.all(G2 + 2 * i + 1, F::mul(qs, F::sub(x7, row.loc(4 * i + 3))));
+  }
+#pragma unroll 1
+  for (uint32_t j = 0; j < 4; j++) out.first(G3 + j, F::sub(row.loc(j), F::k(row.pub(j))));
+}
+}  // namespace plonk
+
 // ------------------------------------------------------------------------------------------ registry
 GL_HD uint32_t n_constraints(const Shape& s) {
   return s.air_id == KECCAK_F ? keccak::N_CONSTRAINTS
@@ -838,6 +920,7 @@ GL_HD uint32_t n_constraints(const Shape& s) {
          : s.air_id == BYTE_PACKING ? byte_packing::N_CONSTRAINTS
          : s.air_id == KECCAK_SPONGE ? keccak_sponge::N_CONSTRAINTS
          : s.air_id == ARITHMETIC_MUL ? arithmetic_mul::N_CONSTRAINTS
+         : s.air_id == PLONK ? plonk::N_CONSTRAINTS
                               : synthetic::n_constraints(s);
 }
 GL_HD uint32_t n_units(const Shape& s) {
@@ -848,6 +931,7 @@ GL_HD uint32_t n_units(const Shape& s) {
          : s.air_id == BYTE_PACKING ? byte_packing::N_UNITS
          : s.air_id == KECCAK_SPONGE ? keccak_sponge::N_UNITS
          : s.air_id == ARITHMETIC_MUL ? arithmetic_mul::N_UNITS
+         : s.air_id == PLONK ? plonk::N_UNITS
                               : synthetic::n_units(s);
 }
 template <class T, class Row, class Emit>
@@ -859,6 +943,7 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   else if (s.air_id == BYTE_PACKING) byte_packing::eval_unit<T>(unit, row, out);
   else if (s.air_id == KECCAK_SPONGE) keccak_sponge::eval_unit<T>(unit, row, out);
   else if (s.air_id == ARITHMETIC_MUL) arithmetic_mul::eval_unit<T>(unit, row, out);
+  else if (s.air_id == PLONK) plonk::eval_unit<T>(row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
@@ -898,17 +983,25 @@ namespace ctl {
 constexpr uint32_t KECCAK_G = 0, KECCAK_H = 1, KECCAK_Z = 3, KECCAK_N_AUX = 5, KECCAK_N_CONSTRAINTS = 10;
 constexpr uint32_t SPONGE_Z = 0, SPONGE_N_AUX = 2, SPONGE_N_CONSTRAINTS = 4;
 constexpr uint32_t TUPLE_LIMBS = 50;  // a Keccak state as 32-bit limbs
+// AIR 8 (plonk): per challenge set c, column 10 c = Z_c and 10 c + k = the k-th partial product, k = 1..9
+constexpr uint32_t PLONK_N_AUX = 20, PLONK_N_CONSTRAINTS = 22, PLONK_CHUNK = 8, PLONK_CHUNKS = 10;
 
 GL_HD uint32_t n_aux(const Shape& s) {
-  return s.air_id == SYNTHETIC ? s.n_cols / 8 : s.air_id == KECCAK_F ? KECCAK_N_AUX : s.air_id == KECCAK_SPONGE ? SPONGE_N_AUX : 1;
+  return s.air_id == SYNTHETIC ? s.n_cols / 8
+         : s.air_id == KECCAK_F ? KECCAK_N_AUX
+         : s.air_id == KECCAK_SPONGE ? SPONGE_N_AUX
+         : s.air_id == PLONK ? PLONK_N_AUX
+                             : 1;
 }
 GL_HD uint32_t n_constraints(const Shape& s) {
   return s.air_id == SYNTHETIC ? 2 * (s.n_cols / 8)
          : s.air_id == KECCAK_F ? KECCAK_N_CONSTRAINTS
          : s.air_id == KECCAK_SPONGE ? SPONGE_N_CONSTRAINTS
+         : s.air_id == PLONK ? PLONK_N_CONSTRAINTS
                                      : 2;
 }
 // the first aux column that is a running product (the columns before it are helpers); products run to the last column
+// (AIR 8 keeps its two running products, columns 0 and 10, in its own kernels: stark_kernels.hip)
 GL_HD uint32_t first_product(uint32_t air_id) { return air_id == KECCAK_F ? KECCAK_Z : 0; }
 
 // sum_{j < n} beta^j col(j) by Horner from the top
@@ -924,6 +1017,7 @@ GL_HD T compress(const Col& col, uint32_t n, T beta) {
 template <class T, class Row>
 GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const Row& row) {
   typedef Ops<T> F;
+  if (s.air_id == PLONK) return row.aux(col);  // the row's total num / den, left in the column by plonk_chunk_ratios_kernel
   if (s.air_id == SYNTHETIC) {
     const T beta = F::k(ctl[2 * (col & 1)]), gamma = F::k(ctl[2 * (col & 1) + 1]);
     return F::add(F::add(gamma, row.loc(8 * col)), F::mul(beta, row.loc(8 * col + 1)));
@@ -951,11 +1045,53 @@ GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const 
   }
   return F::k(1);
 }
+// AIR 8: the copy constraints of the PLONK-shaped circuit (plonky2's permutation argument: Z and partial products;
+// upstream's vanishing-polynomial terms check_partial_products + L_1 (Z - 1)).  With the routed wires w_j, j < 80, in
+// chunks of eight, per challenge set (beta, gamma):
+//   num_k = prod_{j in chunk k} (w_j + beta k_j x + gamma)      k_j = 7^j, x = the row's point
+//   den_k = prod_{j in chunk k} (w_j + beta sigma_j + gamma)
+// and the running product goes BACKWARDS through the rows (as every running product of this library does): with
+// cur_0 = Z(next row), cur_k = the k-th partial product (k = 1..9), cur_10 = Z(this row):
+//   index base + 11 c + k - 1   all rows (the wrap from the last row to the first included)   cur_k den_k - cur_(k-1) num_k   deg 9
+//   index base + 11 c + 10      first row                                                      Z - 1
+// Z(first) = 1 and the cyclic relation force prod_rows prod_j (numerator / denominator) = 1.
+// Challenge set c is the unit [10 c, 10 c + 10) of the auxiliary columns.
+template <class T, class Row, class Emit>
+GL_HD void eval_plonk(uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ctl[4], const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  const T x = row.x();
+#pragma unroll 1
+  for (uint32_t c = k0 / 10; c < (k1 + 9) / 10; c++) {
+    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
+    T bkx = F::mul(beta, x);  // beta k_j x, j running
+    T prev = row.aux_nxt(10 * c);
+#pragma unroll 1
+    for (uint32_t k = 1; k <= PLONK_CHUNKS; k++) {
+      T num = F::k(1), den = F::k(1);
+#pragma unroll 1
+      for (uint32_t j = PLONK_CHUNK * (k - 1); j < PLONK_CHUNK * k; j++) {
+        const T w = F::add(row.loc(j), gamma);
+        num = F::mul(num, F::add(w, bkx));
+        den = F::mul(den, F::add(w, F::mul(beta, row.cst(plonk::CST_SIGMA + j))));
+        bkx = F::mul(bkx, F::k(7));
+      }
+      const T cur = row.aux(10 * c + (k < PLONK_CHUNKS ? k : 0));
+      out.all(base + 11 * c + k - 1, F::sub(F::mul(cur, den), F::mul(prev, num)));
+      prev = cur;
+    }
+    out.first(base + 11 * c + 10, F::sub(row.aux(10 * c), F::k(1)));
+  }
+}
+
 // The lookup part of the constraint list.  Synthetic tables: products [k0, k1) (their unit slicing); every other
 // table: everything (one unit).
 template <class T, class Row, class Emit>
 GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ctl[4], const Row& row, Emit& out) {
   typedef Ops<T> F;
+  if (s.air_id == PLONK) {
+    eval_plonk<T>(base, k0, k1, ctl, row, out);
+    return;
+  }
   if (s.air_id == SYNTHETIC) {
 #pragma unroll 1
     for (uint32_t k = k0; k < k1; k++) {
@@ -1020,6 +1156,7 @@ inline const Info* info(uint32_t air_id) {
       {BYTE_PACKING, "byte_packing", byte_packing::N_COLS, 0, 2},
       {KECCAK_SPONGE, "keccak_sponge", keccak_sponge::N_COLS, 0, 2},
       {ARITHMETIC_MUL, "arithmetic_mul", arithmetic_mul::N_COLS, 0, 3},
+      {PLONK, "plonk", plonk::N_COLS, plonk::N_CONST, 9},
   };
   return air_id < COUNT ? &table[air_id] : nullptr;
 }

@@ -805,7 +805,7 @@ int get_table(int kind, uint32_t log_n, uint32_t rate_bits, const uint64_t** out
 
 // Matrix-core form of the block kernels (ntt_mx.cuh).  0: never; 1: 2^12- and 2^13-point blocks; 2: 2^14-point blocks
 // too (tests); 3 (default): 2^13-point blocks -- where it wins a little -- while the device is not loaded (fewer than
-// six provers at work).  Measured (tools/ntt_mx_probe.py, bench.py --ntt-mx 1 / 0 back to back on one box):
+// six provers at work).  Measured (bench.py --ntt-mx 1 / 0 back to back on one box; HISTORY.md, round 2):
 //   first version, MFMA constants in 96 VGPRs, 224-240 VGPRs = two waves per SIMD (profiles/r2_ntt_mx_probe.txt,
 //   r2_ntt_mx_block_ab.txt): alone level at 2^12 points, +7 % LDE / +17 % inverse at 2^13 x 135 rate 8, -25 % at 2^14
 //   (spills); under the 24-stream block run 29.8 against 34.1 txn-proofs/s -- its fat waves crowd out the Poseidon

@@ -66,9 +66,10 @@ std::atomic<int> g_k5_spread_all{0};  // measurement knob (bp_tune_k5_spread): t
 int check_cfg(const StarkCfg& c) {
   const air::Info* ai = air::info(c.air_id);
   if (!ai) return fail(BP_ERR_INVALID_INPUT, "unknown air_id %u (bp_air_count() AIRs are built in)", c.air_id);
-  if (ai->n_cols && (c.n_cols != ai->n_cols || c.n_const != 0 || c.deg_pow != 1))
-    return fail(BP_ERR_INVALID_INPUT, "AIR %u (%s) has %u columns, no constant columns and degree %u (deg_pow 1): got n_cols=%u "
-                "n_const=%u deg_pow=%u", c.air_id, ai->name, ai->n_cols, ai->degree, c.n_cols, c.n_const, c.deg_pow);
+  if (ai->n_cols && (c.n_cols != ai->n_cols || c.n_const != ai->n_const_max || c.deg_pow != (ai->degree > 3 ? 3u : 1u)))
+    return fail(BP_ERR_INVALID_INPUT, "AIR %u (%s) has %u columns, %u constant columns and degree %u (deg_pow %u): got n_cols=%u "
+                "n_const=%u deg_pow=%u", c.air_id, ai->name, ai->n_cols, ai->n_const_max, ai->degree, ai->degree > 3 ? 3u : 1u,
+                c.n_cols, c.n_const, c.deg_pow);
   if (c.deg_pow != 1 && c.deg_pow != 3) return fail(BP_ERR_INVALID_INPUT, "deg_pow must be 1 or 3");
   if ((1u << c.rate_bits) != 3 * c.deg_pow - 1)
     return fail(BP_ERR_INVALID_INPUT, "quotient degree factor 3*deg_pow-1 must equal 2^rate_bits");
@@ -284,6 +285,7 @@ int commit_batch(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t batc
     o.coeffs = coeffs + (size_t)b * n_cols * n;
     o.lde = lde + (size_t)b * n_cols * m;
     o.digests = digests + (size_t)b * dw;
+    o.values = from_coeffs ? nullptr : d_in + (size_t)b * n_cols * n;
     o.cap.assign(w.pinned + b * cw, w.pinned + (b + 1) * cw);
   }
   return BP_OK;
@@ -403,6 +405,7 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committe
     for (uint32_t b = 0; b < B; b++) {
       aa[b] = AuxArgs{d_tv[b], d_auxv + (size_t)b * A * N, ctl[b]};
       if (hints) { aa[b].flag_a = hints[b].flag_a; aa[b].flag_b = hints[b].flag_b; aa[b].n_flags = hints[b].n_flags; }
+      if (K) aa[b].consts = consts[b]->values;
     }
     TRY(launch_aux(aa, B, cfg.air_id, C, log_n, st));
   }
@@ -688,7 +691,7 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committe
       // The smallest witness is geometric with mean 2^pow_bits and every candidate costs a whole permutation, so
       // the batch size decides how many permutations are wasted past the winner: batches of 2^(pow_bits-1) stop
       // after 2.5 launches and 83 k permutations on average at 16 bits (one batch of 2 x 2^16 followed by
-      // doubling: 168 k).  Proof of work is 7 % of a txn proof's VALU work (tools/valu_work_breakdown.py), the
+      // doubling: 168 k).  Proof of work is 3.5 % of a txn proof's VALU work (profiles/r3_sq_loaded_by_kernel.txt), the
       // extra launches are latency on one of 24 streams.  After 8 misses the batch grows (tiny bit counts, bad luck).
       const uint32_t batch0 = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 12, (uint64_t)1 << (cfg.pow_bits ? cfg.pow_bits - 1 : 0)));
       uint32_t batch = batch0, n_batches = 0;

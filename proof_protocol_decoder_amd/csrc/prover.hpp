@@ -94,6 +94,7 @@ class DeviceArena {
 
 struct Committed {
   uint64_t *coeffs = nullptr, *lde = nullptr, *digests = nullptr;
+  const uint64_t* values = nullptr;  // the committed values on the trace domain, while the caller keeps them (else null)
   uint32_t log_n = 0, n_cols = 0, rate_bits = 0, cap_height = 0;
   std::vector<uint64_t> cap;  // host copy, 2^cap_height * 4 words
 };

@@ -112,7 +112,8 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
     if (c.n_const) {
       d_consts = w.arena.alloc_words((size_t)c.n_const * N);
       if (!d_consts) return fail(BP_ERR_DEVICE, "arena exhausted");
-      int r2 = launch_synth_constants(d_consts, c.log_n, c.n_const, const_seed, w.stream);
+      int r2 = c.air_id == air::PLONK ? launch_plonk_constants(d_consts, c.log_n, const_seed, w.stream)
+                                      : launch_synth_constants(d_consts, c.log_n, c.n_const, const_seed, w.stream);
       if (r2) return r2;
       if ((r2 = commit(w, d_consts, c.n_const, c.log_n, c.rate_bits, c.cap_height, false, &consts))) return r2;
       ch.observe(consts.cap.data(), consts.cap.size());
@@ -126,11 +127,18 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
              : c.air_id == air::BYTE_PACKING ? launch_byte_packing_trace(d_trace, nullptr, c.log_n, seed, w.stream)
              : c.air_id == air::KECCAK_SPONGE ? launch_keccak_sponge_trace(d_trace, nullptr, c.log_n, seed, w.stream)
              : c.air_id == air::ARITHMETIC_MUL ? launch_arithmetic_mul_trace(d_trace, nullptr, c.log_n, seed, w.stream)
+             : c.air_id == air::PLONK ? BP_OK
                                        : launch_synth_trace(d_trace, d_consts, c.log_n, c.n_cols, c.n_const, c.deg_pow, seed, w.stream);
+    Ctl ctl;
+    if (c.air_id == air::PLONK) {  // the public inputs of a lone table proof follow from the seed (bp_stark_public_inputs)
+      PlonkTraceArgs pa{d_trace, d_consts, seed, {0, 0, 0, 0}};
+      bp_stark_public_inputs(seed, ctl.pub);
+      std::memcpy(pa.pub, ctl.pub, sizeof(pa.pub));
+      r2 = launch_plonk_trace(&pa, 1, c.log_n, w.stream);
+    }
     if (r2) return r2;
     if ((r2 = commit(w, d_trace, c.n_cols, c.log_n, c.rate_bits, c.cap_height, false, &trace))) return r2;
     ch.observe(trace.cap.data(), trace.cap.size());
-    Ctl ctl;
     for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
     std::vector<uint64_t> proof;
     if ((r2 = stark_prove(w, c, c.n_const ? &consts : nullptr, trace, d_trace, ctl, ch, proof))) return r2;
@@ -155,8 +163,23 @@ int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t co
 
 // The CPU verifier for one table proof of bp_stark_prove_air (same transcript prologue: constants cap if any, trace
 // cap, four CTL challenges).  Host only: runs without a GPU.
+// The four public inputs of a lone AIR-8 table proof made from `seed` (in a transaction they are the hash of the proof's
+// public-input list): splitmix64(seed ^ ((0x50 + j) << 32)) reduced mod p.
+void bp_stark_public_inputs(uint64_t seed, uint64_t out[4]) {
+  for (uint64_t j = 0; j < 4; j++) {
+    uint64_t z = (seed ^ ((0x50 + j) << 32)) + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    out[j] = gl::canon(z ^ (z >> 31));
+  }
+}
+
 int bp_stark_verify_air(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint8_t* proof,
-                        size_t len) try {
+                        size_t len) {
+  return bp_stark_verify_air_pub(air_id, cfg, const_cap, nullptr, proof, len);
+}
+int bp_stark_verify_air_pub(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint64_t* pub,
+                            const uint8_t* proof, size_t len) try {
   if (!cfg || !proof) return fail(BP_ERR_INVALID_INPUT, "bp_stark_verify_air: null argument");
   StarkCfg c{cfg->log_n, cfg->n_cols, cfg->n_const, cfg->deg_pow, cfg->rate_bits, cfg->cap_height,
              cfg->num_queries, cfg->pow_bits, cfg->arity_bits, cfg->final_poly_bits, air_id};
@@ -172,9 +195,14 @@ int bp_stark_verify_air(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t
   ch.observe(w.data() + L.trace_cap, L.cap_words);
   Ctl ctl;
   for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
+  if (pub)
+    for (int i = 0; i < 4; i++) {
+      if (pub[i] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "non-canonical public input");
+      ctl.pub[i] = pub[i];
+    }
   return stark_verify(c, c.n_const ? const_cap : nullptr, ctl, ch, w.data(), w.size());
 }
-BPG_ABI_CATCH("bp_stark_verify_air")
+BPG_ABI_CATCH("bp_stark_verify_air_pub")
 
 // ---- the AIR registry (air.hpp) --------------------------------------------------------------------------
 
@@ -188,9 +216,9 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
   std::strncpy(out->name, ai->name, sizeof(out->name) - 1);
   out->fixed_n_cols = ai->n_cols;
   out->n_const_max = ai->n_const_max;
-  const uint32_t C = ai->n_cols ? ai->n_cols : n_cols, dp = ai->n_cols ? 1 : (deg_pow ? deg_pow : 1);
-  const air::Shape shape{air_id, C, ai->n_cols ? 0 : n_const, dp};
-  out->degree = ai->degree * dp;
+  const uint32_t C = ai->n_cols ? ai->n_cols : n_cols, dp = ai->n_cols ? (ai->degree > 3 ? 3 : 1) : (deg_pow ? deg_pow : 1);
+  const air::Shape shape{air_id, C, ai->n_cols ? ai->n_const_max : n_const, dp};
+  out->degree = ai->n_cols ? ai->degree : ai->degree * dp;
   out->n_cols = C;
   out->n_aux = air::ctl::n_aux(shape);
   out->n_air_constraints = air::n_constraints(shape);
@@ -225,6 +253,9 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
     fam(sp::K0, 2, 0, 2); fam(sp::K1, 1, 0, 2); fam(sp::K2, 136, 0, 2); fam(sp::K3, 1, 0, 1); fam(sp::K4, 1088, 0, 2);
     fam(sp::K5, 1088, 0, 2); fam(sp::K6, 136, 0, 2); fam(sp::K7, 34, 0, 2); fam(sp::K8, 50, 1, 2); fam(sp::K9, 50, 2, 1);
     fam(sp::K10, 1, 1, 2);
+  } else if (air_id == air::PLONK) {
+    namespace pk = air::plonk;
+    fam(pk::G0, 20, 0, 4); fam(pk::G1, 44, 0, 3); fam(pk::G2, 22, 0, 2); fam(pk::G3, 4, 2, 1);
   } else if (air_id == air::ARITHMETIC_MUL) {
     namespace am = air::arithmetic_mul;
     fam(am::U0, 1, 0, 2); fam(am::U1, 256, 0, 2); fam(am::U2, 256, 0, 2); fam(am::U3, 672, 0, 2); fam(am::U4, 32, 0, 3);
@@ -237,6 +268,8 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
   const uint32_t b = out->n_air_constraints;
   if (air_id == air::SYNTHETIC) {
     fam(b, C / 8, 1, 2); fam(b + 1, C / 8, 3, 1);  // running products, interleaved 2k (transition), 2k + 1 (last row)
+  } else if (air_id == air::PLONK) {  // the copy constraints: per challenge set ten chunk relations and Z(first) = 1
+    for (uint32_t c = 0; c < 2; c++) { fam(b + 11 * c, 10, 0, 9); fam(b + 11 * c + 10, 1, 2, 1); }
   } else {
     uint32_t i = b;
     if (air_id == air::KECCAK_F) {
@@ -302,6 +335,26 @@ int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t lo
   return launch_arithmetic_mul_trace(d_trace_out, d_inputs, log_n, seed, as_stream(stream));
 }
 BPG_ABI_CATCH("bp_arithmetic_mul_trace")
+
+// AIR 8: the preprocessed constants of the fixed PLONK-shaped circuit (84 columns: selectors, gate constants drawn from
+// `seed`, sigmas) and its witness (135 wires; free wires drawn from `seed`, public inputs pub[4] in row 0).
+int bp_plonk_constants(uint64_t seed, uint32_t log_n, uint64_t* d_consts_out, void* stream) try {
+  if (!d_consts_out) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_constants: null output");
+  if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_constants: log_n out of range");
+  int rc = init_ntt_kernels();
+  if (rc) return rc;
+  return launch_plonk_constants(d_consts_out, log_n, seed, as_stream(stream));
+}
+BPG_ABI_CATCH("bp_plonk_constants")
+int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t pub[4], uint32_t log_n, uint64_t* d_trace_out,
+                   void* stream) try {
+  if (!d_consts || !pub || !d_trace_out) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: null argument");
+  if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: log_n out of range");
+  PlonkTraceArgs a{d_trace_out, d_consts, seed, {pub[0], pub[1], pub[2], pub[3]}};
+  for (int j = 0; j < 4; j++) if (pub[j] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: non-canonical public input");
+  return launch_plonk_trace(&a, 1, log_n, as_stream(stream));
+}
+BPG_ABI_CATCH("bp_plonk_trace")
 
 // ---- L0: the remaining per-stage entry points of SURVEY.md section 8(b) -------------------------------
 

@@ -421,6 +421,8 @@ arithmetic_mul_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict
 struct TraceRow {
   const uint64_t *trace, *aux_;
   uint64_t n, i;
+  __device__ __forceinline__ uint64_t x() const { return 0; }  // (no product term reads the point or the constants)
+  __device__ __forceinline__ uint64_t cst(uint32_t) const { return 0; }
   __device__ __forceinline__ uint64_t loc(uint32_t c) const { return trace[(uint64_t)c * n + i]; }
   __device__ __forceinline__ uint64_t aux(uint32_t k) const { return aux_[(uint64_t)k * n + i]; }
 };
@@ -441,7 +443,8 @@ aux_suffix_product_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n, uint
   const bpg::Ctl& ctl = batch.a[blockIdx.z].ctl;
   __shared__ uint64_t part[1024];
   const bpg::air::Shape shape{AIR, n_cols, 0, 1};
-  const uint32_t n = 1u << log_n, k = bpg::air::ctl::first_product(AIR) + blockIdx.x, T = blockDim.x, t = threadIdx.x;
+  const uint32_t n = 1u << log_n, T = blockDim.x, t = threadIdx.x;
+  const uint32_t k = AIR == bpg::air::PLONK ? 10 * blockIdx.x : bpg::air::ctl::first_product(AIR) + blockIdx.x;  // (plonk: Z_0, Z_1)
   uint64_t* z = aux + (uint64_t)k * n;
   // elements per lane per tile (n and T are powers of two; the launcher never uses fewer than 64
   // lanes, so T may exceed n: the surplus lanes then hold the neutral element)
@@ -511,6 +514,138 @@ keccak_ctl_helpers_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
   }
 }
 
+// ---------------------------------------------------------------- AIR 8 (plonk, air.hpp): constants, witness, copy products
+// The preprocessed columns of the fixed circuit: selectors by the row's place in its group of four, gate constants
+// drawn from the circuit's seed, and the sigmas sigma_j(w^i) = k_j' w^i' by air::plonk::sigma_of.  grid = (rows/256, 84).
+__global__ void __launch_bounds__(256)
+plonk_constants_kernel(uint64_t* __restrict__ out, uint32_t log_n, uint64_t seed, const uint64_t* __restrict__ tw_n) {
+  namespace pk = bpg::air::plonk;
+  const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (i >= n) return;
+  const uint32_t p = i & 3;
+  uint64_t v;
+  if (k == pk::CST_ARITH) v = i >= 4 && p != 2;
+  else if (k == pk::CST_SBOX) v = i >= 4 && p == 2;
+  else if (k < pk::CST_SIGMA) v = rnd(seed ^ 0xC0115700C0115700ULL, k, i);
+  else {
+    uint32_t c2, r2;
+    pk::sigma_of(k - pk::CST_SIGMA, i, n, c2, r2);
+    v = gl::mulc(gl::pow((uint64_t)7, c2), root_pow(tw_n, log_n, r2));
+  }
+  out[(uint64_t)k * n + i] = v;
+}
+// The witness: one lane per group of four rows (the group's rows depend on each other), all 135 wires of its rows.
+// Free wires are rnd(seed, column, row) as in the synthetic witness.
+__global__ void __launch_bounds__(64)
+plonk_trace_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
+  namespace pk = bpg::air::plonk;
+  if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  const bpg::PlonkTraceArgs& a = batch.a[blockIdx.z];
+  const uint32_t n = 1u << log_n, g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * g >= n) return;
+  uint64_t* __restrict__ t = a.trace;
+  const uint64_t seed = a.seed;
+  auto put = [&](uint32_t col, uint32_t row, uint64_t v) { t[(uint64_t)col * n + row] = v; };
+  auto cst = [&](uint32_t k, uint32_t row) { return a.consts[(uint64_t)k * n + row]; };
+  const uint32_t r0 = 4 * g;
+  if (g == 0) {  // the public-input row and three no-op rows: every wire free
+    for (uint32_t r = 0; r < 4; r++)
+      for (uint32_t c = 0; c < pk::N_COLS; c++) put(c, r, r == 0 && c < 4 ? a.pub[c] : rnd(seed, c, r));
+    return;
+  }
+  for (uint32_t r = r0; r < r0 + 4; r++)  // the advice wires of the arithmetic rows are free
+    if (r != r0 + 2)
+      for (uint32_t c = pk::COL_SBOX; c < pk::N_COLS; c++) put(c, r, rnd(seed, c, r));
+  uint64_t d0[pk::N_SLOTS], c_in[pk::N_SLOTS], d1[pk::N_SBOX];
+  for (uint32_t s = 0; s < pk::N_SLOTS; s++) {  // row 4g: inputs free (c_j = the public inputs in the first such row)
+    const uint64_t av = rnd(seed, 4 * s, r0), bv = rnd(seed, 4 * s + 1, r0);
+    const uint64_t cv = g == 1 && s < 4 ? a.pub[s] : rnd(seed, 4 * s + 2, r0);
+    d0[s] = gl::addc(gl::mulc(cst(pk::CST_C0, r0), gl::mulc(av, bv)), gl::mulc(cst(pk::CST_C1, r0), cv));
+    c_in[s] = cv;
+    put(4 * s, r0, av); put(4 * s + 1, r0, bv); put(4 * s + 2, r0, cv); put(4 * s + 3, r0, d0[s]);
+  }
+  for (uint32_t s = 0; s < pk::N_SLOTS; s++) {  // row 4g + 1: a_s = d_s, b_s = d_(s+1), c_s = c_s of the row above
+    const uint64_t av = d0[s], bv = d0[(s + 1) % pk::N_SLOTS], cv = c_in[s];
+    const uint64_t dv = gl::addc(gl::mulc(cst(pk::CST_C0, r0 + 1), gl::mulc(av, bv)), gl::mulc(cst(pk::CST_C1, r0 + 1), cv));
+    if (s < pk::N_SBOX) d1[s] = dv;
+    put(4 * s, r0 + 1, av); put(4 * s + 1, r0 + 1, bv); put(4 * s + 2, r0 + 1, cv); put(4 * s + 3, r0 + 1, dv);
+  }
+  for (uint32_t s = 0; s < pk::N_SLOTS; s++) {  // row 4g + 2: the S-box units take d_i of the row above to the 7th power
+    if (s < pk::N_SBOX) {
+      const uint64_t x = d1[s], x2 = gl::mulc(x, x), x4 = gl::mulc(x2, x2), x6 = gl::mulc(x4, x2), x7 = gl::mulc(x6, x);
+      const uint32_t u = pk::COL_SBOX + 5 * s;
+      put(u, r0 + 2, x); put(u + 1, r0 + 2, x2); put(u + 2, r0 + 2, x4); put(u + 3, r0 + 2, x6); put(u + 4, r0 + 2, x7);
+      put(4 * s, r0 + 2, x); put(4 * s + 3, r0 + 2, x7);
+      d1[s] = x7;
+    } else {
+      put(4 * s, r0 + 2, rnd(seed, 4 * s, r0 + 2)); put(4 * s + 3, r0 + 2, rnd(seed, 4 * s + 3, r0 + 2));
+    }
+    put(4 * s + 1, r0 + 2, rnd(seed, 4 * s + 1, r0 + 2)); put(4 * s + 2, r0 + 2, rnd(seed, 4 * s + 2, r0 + 2));
+  }
+  for (uint32_t s = 0; s < pk::N_SLOTS; s++) {  // row 4g + 3: a_i = the S-box outputs, the rest free
+    const uint64_t av = s < pk::N_SBOX ? d1[s] : rnd(seed, 4 * s, r0 + 3), bv = rnd(seed, 4 * s + 1, r0 + 3), cv = rnd(seed, 4 * s + 2, r0 + 3);
+    const uint64_t dv = gl::addc(gl::mulc(cst(pk::CST_C0, r0 + 3), gl::mulc(av, bv)), gl::mulc(cst(pk::CST_C1, r0 + 3), cv));
+    put(4 * s, r0 + 3, av); put(4 * s + 1, r0 + 3, bv); put(4 * s + 2, r0 + 3, cv); put(4 * s + 3, r0 + 3, dv);
+  }
+}
+// Copy products, step 1 of 3: per row and challenge set the ten chunk ratios num_k / den_k (one inversion per row:
+// the denominators are inverted together) as cumulative products P_k = prod_{k' <= k} num / den: P_1..P_9 into the
+// partial-product columns, the row's total P_10 into the Z column.  grid = (rows/256, 2, proofs).
+__global__ void __launch_bounds__(256)
+plonk_chunk_ratios_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n, const uint64_t* __restrict__ tw_n) {
+  namespace pk = bpg::air::plonk;
+  namespace ct = bpg::air::ctl;
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  const bpg::AuxArgs& a = batch.a[blockIdx.z];
+  const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (i >= n) return;
+  const uint64_t beta = a.ctl.v[2 * c], gamma = a.ctl.v[2 * c + 1];
+  uint64_t bkx = gl::mulc(beta, root_pow(tw_n, log_n, i));
+  uint64_t num[ct::PLONK_CHUNKS], den[ct::PLONK_CHUNKS];
+#pragma unroll 1
+  for (uint32_t k = 0; k < ct::PLONK_CHUNKS; k++) {
+    uint64_t nu = 1, de = 1;
+#pragma unroll 1
+    for (uint32_t j = ct::PLONK_CHUNK * k; j < ct::PLONK_CHUNK * (k + 1); j++) {
+      const uint64_t w = gl::addc(a.trace[(uint64_t)j * n + i], gamma);
+      nu = gl::mulc(nu, gl::addc(w, bkx));
+      de = gl::mulc(de, gl::addc(w, gl::mulc(beta, a.consts[(uint64_t)(pk::CST_SIGMA + j) * n + i])));
+      bkx = gl::mulc(bkx, 7);
+    }
+    num[k] = nu; den[k] = de;
+  }
+  // 1 / den_k for all k with one inversion: prefix products, invert the last, peel backwards
+  uint64_t pre[ct::PLONK_CHUNKS];
+  pre[0] = den[0];
+#pragma unroll
+  for (uint32_t k = 1; k < ct::PLONK_CHUNKS; k++) pre[k] = gl::mulc(pre[k - 1], den[k]);
+  uint64_t inv = gl::inv(pre[ct::PLONK_CHUNKS - 1]);
+#pragma unroll
+  for (uint32_t k = ct::PLONK_CHUNKS; k-- > 0;) {
+    const uint64_t dk_inv = k ? gl::mulc(inv, pre[k - 1]) : inv;
+    inv = gl::mulc(inv, den[k]);
+    num[k] = gl::mulc(num[k], dk_inv);  // the ratio of chunk k
+  }
+  uint64_t P = 1;
+  uint64_t* aux = a.aux + (uint64_t)(10 * c) * n + i;
+#pragma unroll
+  for (uint32_t k = 0; k < ct::PLONK_CHUNKS; k++) {
+    P = gl::mulc(P, num[k]);
+    aux[(uint64_t)(k + 1 < ct::PLONK_CHUNKS ? k + 1 : 0) * n] = P;  // P_(k+1): columns 1..9, the total in column 0
+  }
+}
+// step 3 of 3 (step 2, the suffix products of the row totals in the two Z columns, is aux_suffix_product_kernel):
+// partial product k of row i = Z(i + 1) P_k(i), the wrap from the last row to the first included.  grid = (rows/256, 18, proofs).
+__global__ void __launch_bounds__(256) plonk_partial_products_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
+  const bpg::AuxArgs& a = batch.a[blockIdx.z];
+  const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y / 9, k = 1 + blockIdx.y % 9;
+  if (i >= n) return;
+  const uint64_t z_next = a.aux[(uint64_t)(10 * c) * n + ((i + 1) & (n - 1))];
+  uint64_t* p = a.aux + (uint64_t)(10 * c + k) * n + i;
+  *p = gl::mulc(*p, z_next);
+}
+
 // ---------------------------------------------------------------- K5 quotient
 // One kernel for every AIR (air.hpp): a lane owns one point of the LDE coset, evaluates the units its workgroup
 // row was given and folds the constraints with the alpha powers IN REGISTERS:
@@ -520,7 +655,7 @@ keccak_ctl_helpers_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
 // partial sums ever reach HBM.  Short tables spread their units over grid.y workgroup rows; the partial sums of
 // the rows simply add (every term carries its absolute power), which quotient_sum_kernel does.
 struct RowPoint {
-  uint64_t z_last, l_first, l_last;
+  uint64_t z_last, l_first, l_last, x;
 };
 __device__ __forceinline__ RowPoint row_point(const bpg::QuotArgs& q, uint32_t t, uint32_t m) {
   // per-coset constants from the table alpha_table_kernel left behind the alpha powers (t is a per-lane value:
@@ -529,6 +664,7 @@ __device__ __forceinline__ RowPoint row_point(const bpg::QuotArgs& q, uint32_t t
   const uint64_t x = gl::mulc(coset[t], root_pow(q.tw_n, q.log_n, m));
   const uint64_t zh = coset[16 + t];
   RowPoint p;
+  p.x = x;
   p.z_last = gl::subc(x, q.g_inv);
   const uint64_t zn = gl::mulc(zh, q.n_inv);
   // both Lagrange denominators with one inversion (x is off the subgroup: neither is zero)
@@ -541,6 +677,10 @@ __device__ __forceinline__ RowPoint row_point(const bpg::QuotArgs& q, uint32_t t
 struct DevRow {  // one point of the coset: column-major matrices, lanes = consecutive rows (coalesced)
   const uint64_t *trace, *aux_, *cst_;
   uint64_t ts, as, cs, pos, pos_next;
+  uint64_t xv;          // the point itself
+  const uint64_t* pub_;  // the table's public inputs (kernel arguments)
+  __device__ __forceinline__ uint64_t x() const { return xv; }
+  __device__ __forceinline__ uint64_t pub(uint32_t j) const { return pub_[j]; }
   __device__ __forceinline__ uint64_t loc(uint32_t c) const { return trace[(uint64_t)c * ts + pos]; }
   __device__ __forceinline__ uint64_t nxt(uint32_t c) const { return trace[(uint64_t)c * ts + pos_next]; }
   __device__ __forceinline__ uint64_t cst(uint32_t k) const { return cst_[(uint64_t)k * cs + pos]; }
@@ -591,10 +731,10 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::BatchOf<bpg::Quo
   if (pos >= rows) return;
   const uint32_t n = 1u << q.log_n;
   const uint32_t t = (uint32_t)(pos >> q.log_n), m = (uint32_t)(pos & (n - 1));
-  DevRow row{q.trace_lde, q.aux_lde, q.const_lde, q.trace_stride, q.aux_stride, q.const_stride, pos,
-             ((uint64_t)t << q.log_n) | ((m + 1) & (n - 1))};
   DevEmit out{q.apow, q.n_constraints, row_point(q, t, m),
               {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()}, 0, 0, false};
+  DevRow row{q.trace_lde, q.aux_lde, q.const_lde, q.trace_stride, q.aux_stride, q.const_stride, pos,
+             ((uint64_t)t << q.log_n) | ((m + 1) & (n - 1)), out.rp.x, q.ctl.pub};
   const bpg::air::Shape shape{AIR, q.n_cols, q.n_const, q.deg_pow};
   const uint32_t n_units = q.n_air_units + q.n_ctl_units;
   const uint32_t u0 = blockIdx.y * q.units_per_wg, u1 = min(u0 + q.units_per_wg, n_units);
@@ -608,6 +748,7 @@ __global__ void __launch_bounds__(256) quotient_air_kernel(bpg::BatchOf<bpg::Quo
       else if constexpr (AIR == bpg::air::BYTE_PACKING) bpg::air::byte_packing::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::KECCAK_SPONGE) bpg::air::keccak_sponge::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::ARITHMETIC_MUL) bpg::air::arithmetic_mul::eval_unit<uint64_t>(u, row, out);
+      else if constexpr (AIR == bpg::air::PLONK) bpg::air::plonk::eval_unit<uint64_t>(row, out);
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -1218,6 +1359,19 @@ int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uin
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, hipStream_t st) {
+  const uint64_t* tw_n = nullptr;
+  if (int rc = get_table(0, log_n, 0, &tw_n)) return rc;
+  plonk_constants_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), air::plonk::N_CONST), 256, 0, st>>>(d_out, log_n, seed, tw_n);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
+int launch_plonk_trace(const PlonkTraceArgs* a, uint32_t batch, uint32_t log_n, hipStream_t st) {
+  if (int rc = check_batch(batch)) return rc;
+  plonk_trace_kernel<<<dim3(ceil_div(((uint64_t)1 << log_n) / 4, 64), 1, batch), 64, 0, st>>>(batch_of(a, batch), log_n);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_cols, uint32_t log_n, hipStream_t st) {
   const air::Shape shape{air_id, n_cols, 0, 1};
   const uint32_t n_aux = air::ctl::n_aux(shape), p0 = air::ctl::first_product(air_id);
@@ -1230,6 +1384,20 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
   }
   uint32_t threads = (1u << log_n) < 1024 ? (1u << log_n) : 1024;
   if (threads < 64) threads = 64;
+  if (air_id == air::PLONK) {  // chunk ratios per row, suffix products of the row totals, partial products
+    for (uint32_t b = 0; b < batch; b++)
+      if (!a[b].consts) return fail(BP_ERR_INVALID_INPUT, "the plonk AIR needs the circuit's constant columns (the sigmas) for its copy products");
+    const uint64_t* tw_n = nullptr;
+    if (int rc = get_table(0, log_n, 0, &tw_n)) return rc;
+    const uint32_t gx = ceil_div((uint64_t)1 << log_n, 256);
+    plonk_chunk_ratios_kernel<<<dim3(gx, 2, batch), 256, 0, st>>>(ab, log_n, tw_n);
+    BPG_LAUNCH_CHECK();
+    aux_suffix_product_kernel<air::PLONK><<<dim3(2, 1, batch), threads, 0, st>>>(ab, log_n, n_cols);
+    BPG_LAUNCH_CHECK();
+    plonk_partial_products_kernel<<<dim3(gx, 18, batch), 256, 0, st>>>(ab, log_n);
+    BPG_LAUNCH_CHECK();
+    return BP_OK;
+  }
   const dim3 grid(n_aux - p0, 1, batch);
   // algorithmic bytes: every column a product reads, once, and the product column written (SURVEY.md section 8(d):
   // 24 n per column of a synthetic table)
@@ -1259,6 +1427,7 @@ int launch_quotient(const QuotArgs* qs, uint32_t batch, const QuotCoset& coset, 
   const BatchOf<QuotArgs> qb = batch_of(qs, batch);
   dim3 g1(ceil_div(rows, 256), wg_rows, batch);
   // algorithmic bytes: every element of the three LDE matrices read once, the two quotient columns written
+  // (AIR 8 is counted with the synthetic recursion-shaped proofs it replaces)
   KernelTimer kt(PROF_K5 + (q.air_id < 8 ? q.air_id : 0), st, 8.0 * (double)rows * ((double)q.n_cols + q.n_aux + q.n_const + 2) * batch);
   if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(qb);
   else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(qb);
@@ -1267,6 +1436,7 @@ int launch_quotient(const QuotArgs* qs, uint32_t batch, const QuotCoset& coset, 
   else if (q.air_id == bpg::air::BYTE_PACKING) quotient_air_kernel<bpg::air::BYTE_PACKING><<<g1, 256, 0, st>>>(qb);
   else if (q.air_id == bpg::air::KECCAK_SPONGE) quotient_air_kernel<bpg::air::KECCAK_SPONGE><<<g1, 256, 0, st>>>(qb);
   else if (q.air_id == bpg::air::ARITHMETIC_MUL) quotient_air_kernel<bpg::air::ARITHMETIC_MUL><<<g1, 256, 0, st>>>(qb);
+  else if (q.air_id == bpg::air::PLONK) quotient_air_kernel<bpg::air::PLONK><<<g1, 256, 0, st>>>(qb);
   else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(qb);
   kt.stop();
   BPG_LAUNCH_CHECK();

@@ -10,6 +10,9 @@ namespace bpg {
 
 struct Ctl {
   uint64_t v[4];  // beta0, gamma0, beta1, gamma1 (grand-product challenge sets)
+  // the table's public inputs (AIR 8: the four words of the hash of the proof's public-input list, bound to the first
+  // row in-circuit); zero for the tables that have none
+  uint64_t pub[4] = {0, 0, 0, 0};
 };
 
 // Proofs of ONE shape proved in lock-step (the seven per-table recursion chains of a transaction,
@@ -55,6 +58,7 @@ struct AuxArgs {
   // flag columns of the looking (sponge) table's trace, n_flags rows of it; null: nothing is exposed
   const uint64_t *flag_a = nullptr, *flag_b = nullptr;
   uint32_t n_flags = 0;
+  const uint64_t* consts = nullptr;  // AIR 8: the preprocessed constant columns on the trace domain ([K][n]: the sigmas)
 };
 struct PowerVecArgs {
   uint64_t* out;  // n_points vectors of 2n words each: point y at out + y * 2n
@@ -177,6 +181,14 @@ int launch_keccak_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sp
                                      uint64_t seed, hipStream_t st);
 int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_cols, uint32_t log_n, hipStream_t st);
+// AIR 8 (plonk): the constants (selectors, gate constants, sigmas of the fixed circuit) and the witness
+int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, hipStream_t st);
+struct PlonkTraceArgs {
+  uint64_t* trace;
+  const uint64_t* consts;
+  uint64_t seed, pub[4];
+};
+int launch_plonk_trace(const PlonkTraceArgs* a, uint32_t batch, uint32_t log_n, hipStream_t st);
 // every proof of the batch has the shape and the unit spreading of q[0]
 int launch_quotient(const QuotArgs* q, uint32_t batch, const QuotCoset& coset, hipStream_t st);
 inline int launch_quotient(const QuotArgs& q, const QuotCoset& coset, hipStream_t st) { return launch_quotient(&q, 1, coset, st); }

@@ -42,6 +42,10 @@ Ext rd(const uint64_t* p, size_t i) { return Ext{p[2 * i], p[2 * i + 1]}; }
 // The opened row at zeta / g*zeta as the AIR evaluators (air.hpp) read it.
 struct OpenedRow {
   const uint64_t *cst_, *loc_, *nxt_, *aux_, *aux_nxt_;
+  Ext x_;                // the opening point zeta
+  const uint64_t* pub_;  // the table's public inputs
+  Ext x() const { return x_; }
+  uint64_t pub(uint32_t j) const { return pub_[j]; }
   Ext cst(uint32_t k) const { return rd(cst_, k); }
   Ext loc(uint32_t c) const { return rd(loc_, c); }
   Ext nxt(uint32_t c) const { return rd(nxt_, c); }
@@ -132,7 +136,7 @@ int stark_verify(const StarkCfg& cfg, const uint64_t* const_cap, const Ctl& ctl,
     k.z_last = gl::sub(zeta, gl::ext(gl::inv(g)));
     k.l_first = gl::mul(zhn, gl::inv(gl::sub(zeta, gl::ext(1))));
     k.l_last = gl::mul(zhn, gl::inv(gl::sub(gl::scale(zeta, g), gl::ext(1))));
-    const OpenedRow row{oz, oz + 2 * (size_t)K, on, oz + 2 * (size_t)(K + C), on + 2 * (size_t)C};
+    const OpenedRow row{oz, oz + 2 * (size_t)K, on, oz + 2 * (size_t)(K + C), on + 2 * (size_t)C, zeta, ctl.pub};
     for (uint32_t u = 0; u < air::n_units(shape); u++) air::eval_unit<Ext>(shape, u, row, k);
     air::ctl::eval<Ext>(shape, n_air, 0, A, ctl.v, row, k);
     const uint64_t* oq = oz + 2 * (size_t)(K + C + A);

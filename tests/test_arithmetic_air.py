@@ -135,7 +135,7 @@ def test_a_witness_that_breaks_one_family_yields_a_rejected_proof(oracle, col, r
 def test_air_registry_describes_the_arithmetic_air():
     import proof_protocol_decoder_amd as pkg
     L = pkg.lib()
-    assert L.bp_air_count() == 8
+    assert L.bp_air_count() == 9
     d = pkg.ops.air_describe(4)
     assert d.name == b"arithmetic" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (309, 309, 1, 2)
     assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (294, 2, 4)

@@ -128,7 +128,7 @@ def test_a_witness_that_breaks_one_family_yields_a_rejected_proof(oracle, what, 
 def test_air_registry_describes_the_byte_packing_air():
     import proof_protocol_decoder_amd as pkg
     L = pkg.lib()
-    assert L.bp_air_count() == 8
+    assert L.bp_air_count() == 9
     d = pkg.ops.air_describe(5)
     assert d.name == b"byte_packing" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (297, 297, 1, 2)
     assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (330, 2, 9)

@@ -1,0 +1,113 @@
+"""AIR 8 (plonk, csrc/air.hpp: gates + the copy-constraint permutation argument) on the GPU against the oracle's
+independent statement (oracle/plonk_air.c): the preprocessed constants and the witness of the fixed circuit, K5 alone
+through bp_quotient_eval(air_id = 8, ...), and whole proofs byte for byte -- at 2^13 rows with 28 queries this is the
+shape of upstream's recursion proofs (CircuitConfig::standard_recursion_config)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import P, coset_major_to_natural, rand_field, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+SEED, CSEED = 0x5EED000000000008, 0xC0DE000000000008
+
+
+def dev_constants(bpg, log_n, seed):
+    import torch
+    out = torch.empty((84, 1 << log_n), dtype=torch.int64, device="cuda")
+    bpg._lib.check(bpg.lib().bp_plonk_constants(C.c_uint64(seed), log_n, C.c_void_p(out.data_ptr()), None))
+    return out
+
+
+@pytest.mark.parametrize("log_n", [4, 8, 13])
+def test_constants_and_witness_match_oracle(bpg, oracle, log_n):
+    import torch
+    k = dev_constants(bpg, log_n, CSEED + log_n)
+    want_k = oracle.plonk_constants(log_n, CSEED + log_n)
+    assert (to_host(k) == want_k).all()
+    pub = oracle.stark_public_inputs(SEED + log_n)
+    got_pub = (C.c_uint64 * 4)()
+    bpg.lib().bp_stark_public_inputs(C.c_uint64(SEED + log_n), got_pub)
+    assert [int(x) for x in got_pub] == [int(x) for x in pub]
+    t = torch.empty((135, 1 << log_n), dtype=torch.int64, device="cuda")
+    bpg._lib.check(bpg.lib().bp_plonk_trace(C.c_void_p(k.data_ptr()), C.c_uint64(SEED + log_n), got_pub, log_n, C.c_void_p(t.data_ptr()), None))
+    assert (to_host(t) == oracle.plonk_trace(log_n, SEED + log_n, pub, want_k)).all()
+
+
+@pytest.mark.parametrize("log_n,loaded", [(5, 0), (9, 1), (13, 0)])
+def test_quotient_eval_matches_oracle(bpg, oracle, log_n, loaded):
+    """K5 alone on AIR 8: random LDE matrices (gates, and the chunk relations of the copy products with the row's point
+    x and the sigmas from the constants matrix), fixed challenges, public inputs zero."""
+    rng = np.random.default_rng(800 + log_n)
+    rows = (1 << log_n) << 3
+    trace, aux, consts = rand_field(rng, (135, rows)), rand_field(rng, (20, rows)), rand_field(rng, (84, rows))
+    ctl, alphas = rand_field(rng, (4,)), rand_field(rng, (2,))
+    want = oracle.quotient_values(oracle.plonk_cfg(log_n), consts, trace, aux, ctl, alphas[0], alphas[1])
+    idx = coset_major_to_natural(log_n, 3)
+
+    def to_cm(mat):
+        cm = np.empty_like(mat)
+        cm[:, idx] = mat
+        return to_dev(cm)
+    bpg.lib().bp_tune_assume_loaded(loaded)
+    try:
+        got = bpg.ops.quotient_eval(bpg.ops.stark_cfg(log_n, 135, n_const=84, deg_pow=3, rate_bits=3), to_cm(trace), to_cm(aux),
+                                    to_cm(consts), ctl, alphas, air_id=8)
+    finally:
+        bpg.lib().bp_tune_assume_loaded(-1)
+    assert (to_host(got)[:, idx] == want).all()
+
+
+def oracle_proof(oracle, log_n, nq, pb, seed, cseed):
+    pub = oracle.stark_public_inputs(seed)
+    cfg = oracle.plonk_cfg(log_n, pub=pub, num_queries=nq, pow_bits=pb)
+    k = oracle.plonk_constants(log_n, cseed)
+    tr = oracle.plonk_trace(log_n, seed, pub, k)
+    cc = oracle.Committed.from_values(k, 3, 4)
+    tc = oracle.Committed.from_values(tr, 3, 4)
+    ch = oracle.PyChallenger()
+    ch.observe(cc.cap())
+    ch.observe(tc.cap())
+    ctl = np.array([ch.challenge() for _ in range(4)], dtype=np.uint64)
+    chv = ch.clone()
+    return cfg, oracle.stark_prove(cfg, tr, ctl, ch, cc, tc), ctl, chv, cc.cap().copy(), pub
+
+
+def product_verify(bpg, pc, proof, cap, pub):
+    L = bpg.lib()
+    L.bp_stark_verify_air_pub.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+    raw = np.ascontiguousarray(proof, dtype="<u8").tobytes()
+    capa = np.ascontiguousarray(cap, dtype=np.uint64)
+    return L.bp_stark_verify_air_pub(8, C.byref(pc), capa.ctypes.data_as(C.POINTER(C.c_uint64)), (C.c_uint64 * 4)(*[int(x) for x in pub]), raw, len(raw))
+
+
+@pytest.mark.parametrize("log_n,nq,pb,loaded", [(5, 6, 6, 0), (9, 20, 10, 1), (13, 28, 16, 0), (13, 28, 16, 1)])
+def test_proof_bit_exact(bpg, oracle, log_n, nq, pb, loaded):
+    cfg, want, ctl, chv, cap, pub = oracle_proof(oracle, log_n, nq, pb, SEED, CSEED)
+    pc = bpg.ops.stark_cfg(log_n, 135, n_const=84, deg_pow=3, rate_bits=3, num_queries=nq, pow_bits=pb)
+    bpg.lib().bp_tune_assume_loaded(loaded)
+    try:
+        got = bpg.ops.stark_prove_air(8, pc, SEED, const_seed=CSEED)
+    finally:
+        bpg.lib().bp_tune_assume_loaded(-1)
+    assert got.shape == want.shape and int(got[14]) == 8 and int(got[4]) == 20
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first mismatch at word %d of %d" % (bad[0], want.size)
+    assert oracle.stark_verify(cfg, got, ctl, chv, cap) == 0
+    assert product_verify(bpg, pc, got, cap, pub) == 0
+    flipped = got.copy()
+    flipped[got.size // 2] ^= np.uint64(1 << 21)
+    assert product_verify(bpg, pc, flipped, cap, pub) != 0
+    wrong = [int(x) for x in pub]
+    wrong[0] ^= 2
+    assert product_verify(bpg, pc, got, cap, wrong) != 0
+
+
+def test_wrong_shapes_for_the_air_are_refused(bpg):
+    from proof_protocol_decoder_amd._lib import BpgError
+    for kw in (dict(n_cols=136, n_const=84, deg_pow=3, rate_bits=3), dict(n_cols=135, n_const=82, deg_pow=3, rate_bits=3),
+               dict(n_cols=135, n_const=84)):
+        cfg = bpg.ops.stark_cfg(6, kw.pop("n_cols"), num_queries=6, pow_bits=6, **kw)
+        with pytest.raises(BpgError, match="plonk"):
+            bpg.ops.stark_prove_air(8, cfg, 1)

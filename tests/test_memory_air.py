@@ -152,7 +152,7 @@ def test_a_witness_cell_out_of_range_is_rejected(oracle, col, row, val):
 def test_air_registry_describes_the_memory_air():
     import proof_protocol_decoder_amd as pkg
     L = pkg.lib()
-    assert L.bp_air_count() == 8
+    assert L.bp_air_count() == 9
     d = pkg.ops.air_describe(3)
     assert d.name == b"memory" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (44, 44, 1, 3)
     assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (60, 2, 1)
