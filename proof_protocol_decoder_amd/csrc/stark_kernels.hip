@@ -534,59 +534,69 @@ plonk_constants_kernel(uint64_t* __restrict__ out, uint32_t log_n, uint64_t seed
   }
   out[(uint64_t)k * n + i] = v;
 }
-// The witness: one lane per group of four rows (the group's rows depend on each other), all 135 wires of its rows.
-// Free wires are rnd(seed, column, row) as in the synthetic witness.
-__global__ void __launch_bounds__(64)
+// The witness: one lane per (group of four rows, slot): the slot's four routed wires in the group's rows and, for the
+// first eleven slots, the five advice wires of their S-box unit.  Free wires are rnd(seed, column, row) as in the
+// synthetic witness; what a slot needs of its neighbour (b_s of row 4g + 1 is d_(s+1) of row 4g) it recomputes from the
+// seed.  No lane keeps more than a handful of values: nothing lives in scratch.  grid.x covers (n / 4) x 20 lanes,
+// groups fastest.
+__global__ void __launch_bounds__(256)
 plonk_trace_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
   namespace pk = bpg::air::plonk;
   if (gridDim.x * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
-  const bpg::PlonkTraceArgs& a = batch.a[blockIdx.z];
-  const uint32_t n = 1u << log_n, g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (4 * g >= n) return;
-  uint64_t* __restrict__ t = a.trace;
-  const uint64_t seed = a.seed;
-  auto put = [&](uint32_t col, uint32_t row, uint64_t v) { t[(uint64_t)col * n + row] = v; };
-  auto cst = [&](uint32_t k, uint32_t row) { return a.consts[(uint64_t)k * n + row]; };
-  const uint32_t r0 = 4 * g;
+  const uint32_t n = 1u << log_n, groups = n >> 2, id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= groups * pk::N_SLOTS) return;
+  const uint32_t g = id % groups, s = id / groups, r0 = 4 * g;
+  uint64_t* __restrict__ t = batch.a[blockIdx.z].trace;
+  const uint64_t* __restrict__ cs = batch.a[blockIdx.z].consts;
+  const uint64_t seed = batch.a[blockIdx.z].seed;
+  const uint32_t sn = (s + 1) % pk::N_SLOTS;  // the neighbour slot whose output this slot's b input copies
+  const uint64_t pub_s = s < 4 ? batch.a[blockIdx.z].pub[s] : 0, pub_n = sn < 4 ? batch.a[blockIdx.z].pub[sn] : 0;
+  const bool unit = s < pk::N_SBOX;
+  const uint32_t u = pk::COL_SBOX + 5 * s;  // the slot's S-box unit (slots 0..10)
+#define PUT(col, row, v) t[(uint64_t)(col) * n + (row)] = (v)
+#define CST(k, row) cs[(uint64_t)(k) * n + (row)]
   if (g == 0) {  // the public-input row and three no-op rows: every wire free
-    for (uint32_t r = 0; r < 4; r++)
-      for (uint32_t c = 0; c < pk::N_COLS; c++) put(c, r, r == 0 && c < 4 ? a.pub[c] : rnd(seed, c, r));
+    for (uint32_t r = 0; r < 4; r++) {
+      for (uint32_t w = 0; w < 4; w++) PUT(4 * s + w, r, rnd(seed, 4 * s + w, r));
+      if (unit)
+        for (uint32_t w = 0; w < 5; w++) PUT(u + w, r, rnd(seed, u + w, r));
+    }
+    if (s == 0)
+      for (uint32_t j = 0; j < 4; j++) PUT(j, 0, batch.a[blockIdx.z].pub[j]);
     return;
   }
-  for (uint32_t r = r0; r < r0 + 4; r++)  // the advice wires of the arithmetic rows are free
-    if (r != r0 + 2)
-      for (uint32_t c = pk::COL_SBOX; c < pk::N_COLS; c++) put(c, r, rnd(seed, c, r));
-  uint64_t d0[pk::N_SLOTS], c_in[pk::N_SLOTS], d1[pk::N_SBOX];
-  for (uint32_t s = 0; s < pk::N_SLOTS; s++) {  // row 4g: inputs free (c_j = the public inputs in the first such row)
-    const uint64_t av = rnd(seed, 4 * s, r0), bv = rnd(seed, 4 * s + 1, r0);
-    const uint64_t cv = g == 1 && s < 4 ? a.pub[s] : rnd(seed, 4 * s + 2, r0);
-    d0[s] = gl::addc(gl::mulc(cst(pk::CST_C0, r0), gl::mulc(av, bv)), gl::mulc(cst(pk::CST_C1, r0), cv));
-    c_in[s] = cv;
-    put(4 * s, r0, av); put(4 * s + 1, r0, bv); put(4 * s + 2, r0, cv); put(4 * s + 3, r0, d0[s]);
+  if (unit)  // the advice wires of the three arithmetic rows are free
+    for (uint32_t p = 0; p < 4; p++)
+      if (p != 2)
+        for (uint32_t w = 0; w < 5; w++) PUT(u + w, r0 + p, rnd(seed, u + w, r0 + p));
+  // row 4g: inputs free (c_j of the first computing row = public input j)
+  const uint64_t c0 = CST(pk::CST_C0, r0), c1 = CST(pk::CST_C1, r0);
+  const uint64_t av = rnd(seed, 4 * s, r0), bv = rnd(seed, 4 * s + 1, r0);
+  const uint64_t cv = g == 1 && s < 4 ? pub_s : rnd(seed, 4 * s + 2, r0);
+  const uint64_t d0 = gl::addc(gl::mulc(c0, gl::mulc(av, bv)), gl::mulc(c1, cv));
+  const uint64_t cn = g == 1 && sn < 4 ? pub_n : rnd(seed, 4 * sn + 2, r0);
+  const uint64_t d0n = gl::addc(gl::mulc(c0, gl::mulc(rnd(seed, 4 * sn, r0), rnd(seed, 4 * sn + 1, r0))), gl::mulc(c1, cn));
+  PUT(4 * s, r0, av); PUT(4 * s + 1, r0, bv); PUT(4 * s + 2, r0, cv); PUT(4 * s + 3, r0, d0);
+  // row 4g + 1: a_s = d_s, b_s = d_(s+1), c_s = c_s of the row above
+  const uint64_t d1 = gl::addc(gl::mulc(CST(pk::CST_C0, r0 + 1), gl::mulc(d0, d0n)), gl::mulc(CST(pk::CST_C1, r0 + 1), cv));
+  PUT(4 * s, r0 + 1, d0); PUT(4 * s + 1, r0 + 1, d0n); PUT(4 * s + 2, r0 + 1, cv); PUT(4 * s + 3, r0 + 1, d1);
+  // row 4g + 2: the S-box units take d_i of the row above to the 7th power
+  uint64_t a3 = rnd(seed, 4 * s, r0 + 3);
+  if (unit) {
+    const uint64_t x = d1, x2 = gl::mulc(x, x), x4 = gl::mulc(x2, x2), x6 = gl::mulc(x4, x2), x7 = gl::mulc(x6, x);
+    PUT(u, r0 + 2, x); PUT(u + 1, r0 + 2, x2); PUT(u + 2, r0 + 2, x4); PUT(u + 3, r0 + 2, x6); PUT(u + 4, r0 + 2, x7);
+    PUT(4 * s, r0 + 2, x); PUT(4 * s + 3, r0 + 2, x7);
+    a3 = x7;
+  } else {
+    PUT(4 * s, r0 + 2, rnd(seed, 4 * s, r0 + 2)); PUT(4 * s + 3, r0 + 2, rnd(seed, 4 * s + 3, r0 + 2));
   }
-  for (uint32_t s = 0; s < pk::N_SLOTS; s++) {  // row 4g + 1: a_s = d_s, b_s = d_(s+1), c_s = c_s of the row above
-    const uint64_t av = d0[s], bv = d0[(s + 1) % pk::N_SLOTS], cv = c_in[s];
-    const uint64_t dv = gl::addc(gl::mulc(cst(pk::CST_C0, r0 + 1), gl::mulc(av, bv)), gl::mulc(cst(pk::CST_C1, r0 + 1), cv));
-    if (s < pk::N_SBOX) d1[s] = dv;
-    put(4 * s, r0 + 1, av); put(4 * s + 1, r0 + 1, bv); put(4 * s + 2, r0 + 1, cv); put(4 * s + 3, r0 + 1, dv);
-  }
-  for (uint32_t s = 0; s < pk::N_SLOTS; s++) {  // row 4g + 2: the S-box units take d_i of the row above to the 7th power
-    if (s < pk::N_SBOX) {
-      const uint64_t x = d1[s], x2 = gl::mulc(x, x), x4 = gl::mulc(x2, x2), x6 = gl::mulc(x4, x2), x7 = gl::mulc(x6, x);
-      const uint32_t u = pk::COL_SBOX + 5 * s;
-      put(u, r0 + 2, x); put(u + 1, r0 + 2, x2); put(u + 2, r0 + 2, x4); put(u + 3, r0 + 2, x6); put(u + 4, r0 + 2, x7);
-      put(4 * s, r0 + 2, x); put(4 * s + 3, r0 + 2, x7);
-      d1[s] = x7;
-    } else {
-      put(4 * s, r0 + 2, rnd(seed, 4 * s, r0 + 2)); put(4 * s + 3, r0 + 2, rnd(seed, 4 * s + 3, r0 + 2));
-    }
-    put(4 * s + 1, r0 + 2, rnd(seed, 4 * s + 1, r0 + 2)); put(4 * s + 2, r0 + 2, rnd(seed, 4 * s + 2, r0 + 2));
-  }
-  for (uint32_t s = 0; s < pk::N_SLOTS; s++) {  // row 4g + 3: a_i = the S-box outputs, the rest free
-    const uint64_t av = s < pk::N_SBOX ? d1[s] : rnd(seed, 4 * s, r0 + 3), bv = rnd(seed, 4 * s + 1, r0 + 3), cv = rnd(seed, 4 * s + 2, r0 + 3);
-    const uint64_t dv = gl::addc(gl::mulc(cst(pk::CST_C0, r0 + 3), gl::mulc(av, bv)), gl::mulc(cst(pk::CST_C1, r0 + 3), cv));
-    put(4 * s, r0 + 3, av); put(4 * s + 1, r0 + 3, bv); put(4 * s + 2, r0 + 3, cv); put(4 * s + 3, r0 + 3, dv);
-  }
+  PUT(4 * s + 1, r0 + 2, rnd(seed, 4 * s + 1, r0 + 2)); PUT(4 * s + 2, r0 + 2, rnd(seed, 4 * s + 2, r0 + 2));
+  // row 4g + 3: a_i = the S-box outputs, the rest free
+  const uint64_t b3 = rnd(seed, 4 * s + 1, r0 + 3), c3 = rnd(seed, 4 * s + 2, r0 + 3);
+  const uint64_t d3 = gl::addc(gl::mulc(CST(pk::CST_C0, r0 + 3), gl::mulc(a3, b3)), gl::mulc(CST(pk::CST_C1, r0 + 3), c3));
+  PUT(4 * s, r0 + 3, a3); PUT(4 * s + 1, r0 + 3, b3); PUT(4 * s + 2, r0 + 3, c3); PUT(4 * s + 3, r0 + 3, d3);
+#undef PUT
+#undef CST
 }
 // Copy products, step 1 of 3: per row and challenge set the ten chunk ratios num_k / den_k (one inversion per row:
 // the denominators are inverted together) as cumulative products P_k = prod_{k' <= k} num / den: P_1..P_9 into the
@@ -1368,7 +1378,7 @@ int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, hipSt
 }
 int launch_plonk_trace(const PlonkTraceArgs* a, uint32_t batch, uint32_t log_n, hipStream_t st) {
   if (int rc = check_batch(batch)) return rc;
-  plonk_trace_kernel<<<dim3(ceil_div(((uint64_t)1 << log_n) / 4, 64), 1, batch), 64, 0, st>>>(batch_of(a, batch), log_n);
+  plonk_trace_kernel<<<dim3(ceil_div((((uint64_t)1 << log_n) / 4) * air::plonk::N_SLOTS, 256), 1, batch), 256, 0, st>>>(batch_of(a, batch), log_n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
