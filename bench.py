@@ -106,6 +106,11 @@ def main():
                          "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / "
                          "2414 / 523 / 44 columns) instead of synthetic tables of "
                          "BASELINE's widths -- another workload than the metric's, reported as such")
+    ap.add_argument("--plonk-rec", action="store_true",
+                    help="the recursion-shaped proofs (22 of a txn's 29 proofs, every aggregation and block proof) are proofs of "
+                         "the PLONK-shaped circuit (AIR 8: gates by constants, public inputs in-circuit, the copy-constraint "
+                         "permutation argument; bp_config.rec_air_id = 8, 84 constant columns) instead of the synthetic AIR "
+                         "BASELINE's workload is defined on -- reported as another workload")
     ap.add_argument("--leg-only", action="store_true",
                     help="(internal) run only the alone-on-the-chip measurements -- single-stream roofline leg, isolated "
                          "LDE, inverse-NTT sweep, Poseidon peak -- and print them as one JSON object; the main run "
@@ -242,7 +247,8 @@ def main():
         """The same workload with ONE prover stream and nothing else on the chip, so every launch of the kernel
         has the device to itself and event time == kernel time (this is what the rocprof summary in profiles/ is
         taken from)."""
-        solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=int(args.arena_gib * 2**30)).build()
+        solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=int(args.arena_gib * 2**30),
+                                            **(dict(rec_air_id=8, rec_n_const=84) if args.plonk_rec else {})).build()
         solo_driver = BlockDriver(solo, n_threads=1)
         irs = synthetic_block_irs(1000, 2, S1_LOG_N, S1_WIDTH)
         solo_driver.prove_shard(irs[:1])
@@ -332,8 +338,9 @@ def main():
 
     t_build = time.time()
     # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
+    rec = dict(rec_air_id=8, rec_n_const=84) if args.plonk_rec else {}
     state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads,
-                                         arena_bytes=int(args.arena_gib * 2**30)).build()
+                                         arena_bytes=int(args.arena_gib * 2**30), **rec).build()
     t_build = time.time() - t_build
     driver = BlockDriver(state, n_threads=args.threads)
     gather = TorchGather(torch.device("cpu") if share else torch.device("cuda", local_rank)) if world > 1 else None
@@ -407,6 +414,8 @@ def main():
                                % (args.txns, list(S1_LOG_N), list(S1_WIDTH), args.txns - 1),
                    "keccak_table": "Keccak-f[1600] AIR, 2430 columns" if (args.keccak_air or args.real_airs)
                                    else "synthetic AIR, 2432 columns",
+                   "recursion_proofs": "PLONK-shaped circuit (AIR 8), 135 wires, 84 constants" if args.plonk_rec
+                                       else "synthetic AIR, 135 columns, 82 constants",
                    **({"logic_table": "logic AIR, 523 columns", "memory_table": "memory AIR, 44 columns",
                        "arithmetic_table": "arithmetic AIR, 309 columns",
                        "byte_packing_table": "byte-packing AIR, 297 columns",
@@ -434,7 +443,7 @@ def main():
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
             env["BPG_LEG_DEVICE"] = str(local_rank)
-            knobs = ["--arena-gib", str(args.arena_gib)]
+            knobs = ["--arena-gib", str(args.arena_gib)] + (["--plonk-rec"] if args.plonk_rec else [])
             for flag, _, _ in TUNE_KNOBS:
                 val = getattr(args, flag[2:].replace("-", "_"))
                 if val is not None:
@@ -452,7 +461,7 @@ def main():
         if k in alone:
             out[k] = alone[k]
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0])
+        out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0], plonk_rec=args.plonk_rec)
     print(json.dumps(out), flush=True)
 
 
@@ -606,7 +615,7 @@ def usable_cores():
     return min(n, 64)
 
 
-def cpu_baseline(ir):
+def cpu_baseline(ir, plonk_rec=False):
     """Oracle (CPU restatement, OpenMP over the host cores) proving one txn of the block."""
     from oracle import pyoracle  # checker / baseline only
     pyoracle.build()
@@ -618,8 +627,8 @@ def cpu_baseline(ir):
     lo, hi = list(S1_LOG_N), [x + 1 for x in S1_LOG_N]
     st = pyoracle.PgState(table_log_lo=lo, table_log_hi=hi, stark_rate_bits=1, stark_cap_height=4,
                           stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5, rec_log_n=13,
-                          rec_n_cols=135, rec_n_const=82, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
-                          shrink_depth=3)
+                          rec_n_cols=135, rec_n_const=84 if plonk_rec else 82, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
+                          shrink_depth=3, rec_air_id=8 if plonk_rec else 0)
     import struct
     words = list(struct.unpack("<25Q", ir.to_bytes()))
     # like for like with the GPU figure, which excludes bp_state_build: the eight circuits this txn touches are

@@ -384,6 +384,11 @@ typedef struct bp_config {
    * columns, rate_bits 3, 28 queries */
   uint32_t rec_log_n, rec_n_cols, rec_n_const, rec_rate_bits, rec_num_queries, rec_pow_bits;
   uint32_t shrink_depth; /* recursion-shaped proofs per table before the root (3) */
+  uint32_t rec_air_id;   /* what the recursion-shaped proofs are proofs OF: 0 (default) = the synthetic AIR on rec_n_cols x
+                          * rec_n_const columns; 8 = the PLONK-shaped circuit of AIR 8 (csrc/air.hpp: gates by constants,
+                          * public inputs bound in-circuit, copy constraints by the permutation argument), which needs
+                          * rec_n_cols = 135 and rec_n_const = 84 -- the proof system of upstream's recursion circuits
+                          * (prove_aggregation / prove_block, proof_gen.rs:66-75, 97-103), still not a verifier circuit */
   int32_t device;        /* HIP device index */
   uint32_t n_workers;    /* concurrent provers (one HIP stream + arena each) */
   uint64_t arena_bytes;  /* device arena per worker.  A table height inside its configured range is PROVABLE when

@@ -21,6 +21,7 @@ typedef struct {
   uint32_t stark_rate_bits, stark_cap_height, stark_num_queries, stark_pow_bits, arity_bits, final_poly_bits;
   uint32_t rec_log_n, rec_n_cols, rec_n_const, rec_rate_bits, rec_num_queries, rec_pow_bits;
   uint32_t shrink_depth;
+  uint32_t rec_air_id; /* 0: recursion-shaped proofs on the synthetic AIR; 8: on the PLONK-shaped circuit (plonk_air.c) */
 } orc_pg_config;
 
 typedef struct {
@@ -48,7 +49,7 @@ static uint64_t circuit_seed(uint32_t kind, uint32_t degree) {
 }
 static orc_stark_cfg rec_cfg_of(const orc_pg_config* c) {
   orc_stark_cfg r = {c->rec_log_n, c->rec_n_cols, c->rec_n_const, 3, c->rec_rate_bits, c->stark_cap_height,
-                     c->rec_num_queries, c->rec_pow_bits, c->arity_bits, c->final_poly_bits, ORC_AIR_SYNTHETIC, {0, 0, 0, 0}};
+                     c->rec_num_queries, c->rec_pow_bits, c->arity_bits, c->final_poly_bits, c->rec_air_id, {0, 0, 0, 0}};
   return r;
 }
 static orc_stark_cfg table_cfg_of(const orc_pg_config* c, uint32_t log_n, uint32_t width) {
@@ -77,7 +78,8 @@ static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed) {
   if (!c->built) {
     size_t n = (size_t)1 << s->rec.log_n;
     c->const_values = (gl_t*)malloc(s->rec.n_const * n * sizeof(gl_t));
-    orc_synth_constants(seed, s->rec.log_n, s->rec.n_const, c->const_values);
+    if (s->rec.air_id == ORC_AIR_PLONK) orc_plonk_constants(seed, s->rec.log_n, c->const_values);
+    else orc_synth_constants(seed, s->rec.log_n, s->rec.n_const, c->const_values);
     c->consts = orc_commit_values(c->const_values, s->rec.log_n, s->rec.n_const, s->rec.rate_bits, s->rec.cap_height);
     orc_hash_no_pad(orc_committed_cap(c->consts), (size_t)4 << s->rec.cap_height, c->digest);
     c->built = 1;
@@ -96,12 +98,18 @@ static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_
   orc_ch_observe_many(&ch, pi_hash, 4);
   size_t n = (size_t)1 << s->rec.log_n;
   gl_t* trace = (gl_t*)malloc(s->rec.n_cols * n * sizeof(gl_t));
-  orc_synth_trace(pi_hash[0], &s->rec, circ->const_values, trace);
+  orc_stark_cfg rcfg = s->rec; /* the PLONK-shaped circuit binds the hash of the public inputs to its first row */
+  if (rcfg.air_id == ORC_AIR_PLONK) {
+    memcpy(rcfg.pub, pi_hash, sizeof(rcfg.pub));
+    orc_plonk_trace(pi_hash[0], pi_hash, circ->const_values, rcfg.log_n, trace);
+  } else {
+    orc_synth_trace(pi_hash[0], &s->rec, circ->const_values, trace);
+  }
   orc_committed* tc = orc_commit_values(trace, s->rec.log_n, s->rec.n_cols, s->rec.rate_bits, s->rec.cap_height);
   orc_ch_observe_many(&ch, orc_committed_cap(tc), (size_t)4 << s->rec.cap_height);
   gl_t ctl[4];
   for (int i = 0; i < 4; i++) ctl[i] = orc_ch_challenge(&ch);
-  int rc = orc_stark_prove(&s->rec, circ->consts, tc, trace, ctl, &ch, proof);
+  int rc = orc_stark_prove(&rcfg, circ->consts, tc, trace, ctl, &ch, proof);
   orc_committed_free(tc);
   free(trace);
   return rc;
@@ -516,7 +524,9 @@ int orc_pg_verify(orc_pg_state* s, const gl_t* w, size_t words) {
   orc_ch_observe_many(&ch, b.stark + 16, cap_words); /* trace cap follows the 16-word header */
   gl_t ctl[4];
   for (int i = 0; i < 4; i++) ctl[i] = orc_ch_challenge(&ch);
-  return orc_stark_verify(&s->rec, orc_committed_cap(circ->consts), ctl, &ch, b.stark);
+  orc_stark_cfg rcfg = s->rec;
+  if (rcfg.air_id == ORC_AIR_PLONK) memcpy(rcfg.pub, pi_hash, sizeof(rcfg.pub));
+  return orc_stark_verify(&rcfg, orc_committed_cap(circ->consts), ctl, &ch, b.stark);
 }
 
 /* cap of special circuit k (0 root, 1 agg, 2 block): what a light verifier keeps */

@@ -43,7 +43,7 @@ class PgConfig(C.Structure):
                 + [(n, C.c_uint32) for n in ("stark_rate_bits", "stark_cap_height", "stark_num_queries",
                                              "stark_pow_bits", "arity_bits", "final_poly_bits", "rec_log_n",
                                              "rec_n_cols", "rec_n_const", "rec_rate_bits", "rec_num_queries",
-                                             "rec_pow_bits", "shrink_depth")])
+                                             "rec_pow_bits", "shrink_depth", "rec_air_id")])
 
 
 class Gl2(C.Structure):

@@ -105,7 +105,7 @@ struct WorkerLease {
 
 StarkCfg rec_cfg_of(const bp_config& c) {
   return StarkCfg{c.rec_log_n, c.rec_n_cols, c.rec_n_const, 3, c.rec_rate_bits, c.stark_cap_height,
-                  c.rec_num_queries, c.rec_pow_bits, c.arity_bits, c.final_poly_bits};
+                  c.rec_num_queries, c.rec_pow_bits, c.arity_bits, c.final_poly_bits, c.rec_air_id};
 }
 StarkCfg table_cfg_of(const bp_config& c, uint32_t log_n, uint32_t width) {
   return StarkCfg{log_n, width, 0, 1, c.stark_rate_bits, c.stark_cap_height, c.stark_num_queries,
@@ -116,7 +116,8 @@ int build_circuit(Worker& w, const StarkCfg& rc, uint64_t seed, Circuit* out) {
   const uint64_t N = (uint64_t)1 << rc.log_n;
   out->d_const_values = w.arena.alloc_words((size_t)rc.n_const * N);
   if (!out->d_const_values) return fail(BP_ERR_DEVICE, "state arena exhausted");
-  int rc2 = launch_synth_constants(out->d_const_values, rc.log_n, rc.n_const, seed, w.stream);
+  int rc2 = rc.air_id == air::PLONK ? launch_plonk_constants(out->d_const_values, rc.log_n, seed, w.stream)
+                                    : launch_synth_constants(out->d_const_values, rc.log_n, rc.n_const, seed, w.stream);
   if (rc2) return rc2;
   if ((rc2 = commit(w, out->d_const_values, rc.n_const, rc.log_n, rc.rate_bits, rc.cap_height, false, &out->consts)))
     return rc2;
@@ -172,6 +173,8 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
     if (!d_trace) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB)", w.arena.capacity() >> 20);
     Challenger ch[MAX_BATCH];
     SynthTraceArgs sa[MAX_BATCH];
+    PlonkTraceArgs pa[MAX_BATCH];
+    Ctl ctl[MAX_BATCH];
     const uint64_t* d_tv[MAX_BATCH];
     const Committed* consts[MAX_BATCH];
     for (uint32_t b = 0; b < B; b++) {
@@ -182,13 +185,15 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
       ch[b].observe(pi_hash, 4);
       d_tv[b] = d_trace + (size_t)b * rc.n_cols * N;
       sa[b] = SynthTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0]};
+      pa[b] = PlonkTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0], {pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
+      if (rc.air_id == air::PLONK) std::memcpy(ctl[b].pub, pi_hash, sizeof(pi_hash));  // bound to the circuit's first row
       consts[b] = &c.consts;
     }
-    int r = launch_synth_trace(sa, B, rc.log_n, rc.n_cols, rc.n_const, rc.deg_pow, w.stream);
+    int r = rc.air_id == air::PLONK ? launch_plonk_trace(pa, B, rc.log_n, w.stream)
+                                    : launch_synth_trace(sa, B, rc.log_n, rc.n_cols, rc.n_const, rc.deg_pow, w.stream);
     if (r) return r;
     Committed trace[MAX_BATCH];
     if ((r = commit_batch(w, d_trace, rc.n_cols, B, rc.log_n, rc.rate_bits, rc.cap_height, false, trace))) return r;
-    Ctl ctl[MAX_BATCH];
     for (uint32_t b = 0; b < B; b++) {
       ch[b].observe(trace[b].cap.data(), trace[b].cap.size());
       for (int i = 0; i < 4; i++) ctl[b].v[i] = ch[b].challenge();
@@ -214,6 +219,7 @@ int rec_verify(const StarkCfg& rc, const LightCircuit& circ, const Box& b) {
   ch.observe(b.stark + L.trace_cap, L.cap_words);
   Ctl ctl;
   for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
+  if (rc.air_id == air::PLONK) std::memcpy(ctl.pub, pi_hash, sizeof(pi_hash));
   return stark_verify(rc, circ.cap.data(), ctl, ch, b.stark, b.stark_words);
 }
 

@@ -28,7 +28,7 @@ class BpConfig(C.Structure):
                 + [(n, C.c_uint32) for n in ("stark_rate_bits", "stark_cap_height", "stark_num_queries",
                                              "stark_pow_bits", "arity_bits", "final_poly_bits", "rec_log_n",
                                              "rec_n_cols", "rec_n_const", "rec_rate_bits", "rec_num_queries",
-                                             "rec_pow_bits", "shrink_depth")]
+                                             "rec_pow_bits", "shrink_depth", "rec_air_id")]
                 + [("device", C.c_int32), ("n_workers", C.c_uint32), ("arena_bytes", C.c_uint64)])
 
 

@@ -111,3 +111,39 @@ def test_wrong_shapes_for_the_air_are_refused(bpg):
         cfg = bpg.ops.stark_cfg(6, kw.pop("n_cols"), num_queries=6, pow_bits=6, **kw)
         with pytest.raises(BpgError, match="plonk"):
             bpg.ops.stark_prove_air(8, cfg, 1)
+
+
+def test_recursion_layer_on_the_plonk_circuit_matches_the_oracle(bpg, oracle):
+    """bp_config.rec_air_id = 8: the seven per-table chains (in lock-step batches), the root proof, an aggregation and a
+    block proof are proofs of the PLONK-shaped circuit; containers equal the oracle's byte for byte, both verifiers
+    accept, lock-step batching does not change a byte."""
+    import struct
+    from pg_common import LOG_N, SMALL_PLONK, WIDTH, ir_words
+    pg = bpg.proof_gen
+    b = pg.ProverStateBuilder()
+    for t, name in enumerate(pg.TABLES):
+        getattr(b, "set_%s_circuit_size" % name)(range(SMALL_PLONK["table_log_lo"][t], SMALL_PLONK["table_log_hi"][t]))
+    b.set(**{k: v for k, v in SMALL_PLONK.items() if not k.startswith("table_")}, n_workers=2, arena_bytes=256 << 20)
+    st, ost = b.build(), oracle.PgState(**SMALL_PLONK)
+    try:
+        ir0 = pg.TxnProofGenIR(7, 0, 100, 121, (1, 2, 3, 4), 0x5EED0001, tuple(LOG_N), tuple(WIDTH))
+        t0 = pg.generate_txn_proof(st, ir0)
+        o0 = ost.txn(ir_words(7, 0, 0x5EED0001))
+        got = np.frombuffer(t0.intern, dtype=np.uint64)
+        assert got.shape == o0.shape and (got == o0).all()
+        t1 = pg.generate_txn_proof(st, pg.TxnProofGenIR(7, 1, 121, 150, t0.p_vals.state_root_after, 0x5EED0002, tuple(LOG_N), tuple(WIDTH)))
+        o1 = ost.txn(ir_words(7, 1, 0x5EED0002, root_before=t0.p_vals.state_root_after, gas=(121, 150)))
+        agg = pg.generate_agg_proof(st, t0, t1)
+        oa = ost.agg(o0, False, o1, False)
+        assert (np.frombuffer(agg.intern, dtype=np.uint64) == oa).all()
+        blk = pg.generate_block_proof(st, None, agg)
+        assert (np.frombuffer(blk.intern, dtype=np.uint64) == ost.block(None, oa)).all()
+        pg.VerifierState.from_prover_state(st).verify(blk)
+        assert ost.verify(np.frombuffer(blk.intern, dtype=np.uint64)) == 0
+        bpg.lib().bp_tune_rec_batch(1)
+        try:
+            assert pg.generate_txn_proof(st, ir0).intern == t0.intern
+        finally:
+            bpg.lib().bp_tune_rec_batch(8)
+    finally:
+        st.close()

@@ -136,3 +136,40 @@ def test_air_registry_describes_the_plonk_air():
     assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (90, 22, 1)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert fams == [(0, 20, 0, 4), (20, 44, 0, 3), (64, 22, 0, 2), (86, 4, 2, 1), (90, 10, 0, 9), (100, 1, 2, 1), (101, 10, 0, 9), (111, 1, 2, 1)]
+
+
+def test_recursion_layer_on_the_plonk_circuit_chain_of_proofs(oracle):
+    """bp_config.rec_air_id = 8: every recursion-shaped proof (the per-table chains, the root, aggregation and block
+    proofs: proof_gen.rs:44-52, 66-75, 97-103) is a proof of the PLONK-shaped circuit whose public inputs -- the hash of
+    the proof's public-input list: child digests, flags, public values -- are bound to its first row.  The oracle makes
+    txn / agg / block proofs; the product's CPU verifier, built from the oracle's circuit caps, accepts them and refuses
+    corrupted ones, a changed public value included (it changes the hash the circuit is bound to)."""
+    from pg_common import SMALL_PLONK, ir_words
+    from proof_protocol_decoder_amd import proof_gen as pg
+    st = oracle.PgState(**SMALL_PLONK)
+    t0 = st.txn(ir_words(7, 0, 0x5EED0001))
+    root1 = tuple(int(x) for x in t0[4 + 28 + 8:4 + 28 + 12])
+    t1 = st.txn(ir_words(7, 1, 0x5EED0002, root_before=root1, gas=(121, 150)))
+    agg = st.agg(t0, False, t1, False)
+    blk = st.block(None, agg)
+    for p in (t0, agg, blk):
+        assert st.verify(p) == 0
+    assert int(blk[4 + 22 + 14]) == 8 and int(blk[4 + 22 + 4]) == 20        # header of the block proof's STARK: AIR 8, 20 aux columns
+    b = pg.ProverStateBuilder()
+    for t, name in enumerate(pg.TABLES):
+        getattr(b, "set_%s_circuit_size" % name)(range(SMALL_PLONK["table_log_lo"][t], SMALL_PLONK["table_log_hi"][t]))
+    b.set(**{k: v for k, v in SMALL_PLONK.items() if not k.startswith("table_")})
+    v = pg.VerifierState.from_caps(b.cfg, st.circuit_caps().reshape(-1))
+    v.verify(blk.tobytes())
+    v.verify_any(t0.tobytes())
+    v.verify_any(agg.tobytes())
+    rng = np.random.default_rng(12)
+    for i in list(rng.integers(4, blk.size, size=10)) + [4 + 9 + 3, 4 + 22 + 16]:   # a public value; the trace cap
+        bad = blk.copy()
+        bad[i] ^= np.uint64(1 << int(rng.integers(0, 60)))
+        with pytest.raises(pg.ProofGenError):
+            v.verify(bad.tobytes())
+        assert st.verify(bad) != 0
+    # the synthetic recursion layer's verifier does not take these proofs, nor the other way round
+    from pg_common import SMALL
+    assert oracle.PgState(**SMALL).verify(blk) != 0
