@@ -285,14 +285,16 @@ def main():
         solo.close()
         return roof, alu, others, k5
 
-    def real_airs_block():
-        """The driver's one command never touches AIR 1..6 outside pytest: a 64-txn block whose six tables with an AIR
-        are proven with it (the sponge table's rows look their permutations up in the Keccak-f table), 16 prover
-        streams, here in the child process."""
+    def side_block(real_airs, plonk_rec):
+        """The driver's one command never touches AIR 1..6 and AIR 8 outside pytest: a 64-txn block of another
+        workload than the metric's, 16 prover streams, here in the child process.  real_airs: the six tables with an
+        AIR are proven with it (the sponge table's rows look their permutations up in the Keccak-f table); plonk_rec:
+        the recursion-shaped proofs are proofs of the PLONK-shaped circuit (bp_config.rec_air_id = 8)."""
         n, thr = 64, 16
-        st = pg.ProverStateBuilder().set(device=local_rank, n_workers=thr, arena_bytes=int(args.arena_gib * 2**30)).build()
+        rec = dict(rec_air_id=8, rec_n_const=84) if plonk_rec else {}
+        st = pg.ProverStateBuilder().set(device=local_rank, n_workers=thr, arena_bytes=int(args.arena_gib * 2**30), **rec).build()
         drv = BlockDriver(st, n_threads=thr)
-        blocks = [synthetic_block_irs(3000 + b, n, S1_LOG_N, S1_WIDTH, **REAL_AIRS) for b in range(3)]
+        blocks = [synthetic_block_irs(3000 + b, n, S1_LOG_N, S1_WIDTH, **(REAL_AIRS if real_airs else {})) for b in range(3)]
         last = drv.prove_block_distributed(blocks[0], 0, 1, None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -303,17 +305,23 @@ def main():
         pg.VerifierState.from_prover_state(st).verify(last)
         drv.close()
         st.close()
+        what = []
+        if real_airs:
+            what.append("the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / 2414 / 523 / 44 "
+                        "columns), the CPU table synthetic; cross-table lookup keccak_sponge -> keccak_f checked in every txn")
+        if plonk_rec:
+            what.append("every recursion-shaped proof a proof of the PLONK-shaped circuit (AIR 8: 135 wires, 84 constant "
+                        "columns, copy-constraint permutation argument, public inputs bound in-circuit)")
         return {"value": round(n * 2 / dt, 3), "unit": "txn-proofs/s", "steps": 2, "warmup": 1, "prover_streams": thr,
-                "workload": "64-txn block, the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / "
-                            "2414 / 523 / 44 columns), the CPU table synthetic; cross-table lookup keccak_sponge -> keccak_f "
-                            "checked in every txn; another workload than the metric's"}
+                "workload": "64-txn block, " + "; ".join(what) + "; another workload than the metric's"}
 
     if args.leg_only:
         # child mode: everything that is measured alone on the chip, in a process of its own
         roof, alu, others, k5 = single_stream_leg()
         out = {"roofline": roof, "alu_kernel": alu, "hbm_kernels": others, "k5": k5}
         if not args.leg_skip_extras:
-            out.update(real_airs=real_airs_block())
+            out.update(real_airs=side_block(True, False), plonk_rec=side_block(False, True),
+                       real_airs_plonk_rec=side_block(True, True))
             out.update(roofline_isolated=isolated_roofline(pkg, torch), ntt_hbm_gbps=ntt_gbps(pkg, torch))
             if alu:
                 finish_alu_kernel(alu, poseidon_peak(pkg, torch))
@@ -457,7 +465,7 @@ def main():
     out["roofline"] = alone.get("roofline")
     out["roofline_in_situ"] = roofline_in_situ
     out["alu_kernel"] = alone.get("alu_kernel")
-    for k in ("hbm_kernels", "k5", "real_airs", "roofline_isolated", "ntt_hbm_gbps"):
+    for k in ("hbm_kernels", "k5", "real_airs", "plonk_rec", "real_airs_plonk_rec", "roofline_isolated", "ntt_hbm_gbps"):
         if k in alone:
             out[k] = alone[k]
     if world == 1 and not args.no_cpu_baseline:
