@@ -41,6 +41,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 # SURVEY.md section 8(d) S1 "transfer-txn": range minima of constants.rs:6-18, placeholder widths
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
 S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
+SYNTHETIC_REC = dict(rec_air_id=0, rec_n_const=82)   # the recursion-shaped proofs of rounds 1-3 (--synthetic-rec)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
 # HBM traffic / algorithmic bytes of the roofline leg's launches comes from a PMC measurement kept under profiles/
 # (two rocprofv3 --pmc passes of this same command, tools/pmc_family_traffic.py).  bench.py cannot collect
@@ -106,11 +107,12 @@ def main():
                          "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / "
                          "2414 / 523 / 44 columns) instead of synthetic tables of "
                          "BASELINE's widths -- another workload than the metric's, reported as such")
-    ap.add_argument("--plonk-rec", action="store_true",
+    ap.add_argument("--synthetic-rec", action="store_true",
                     help="the recursion-shaped proofs (22 of a txn's 29 proofs, every aggregation and block proof) are proofs of "
-                         "the PLONK-shaped circuit (AIR 8: gates by constants, public inputs in-circuit, the copy-constraint "
-                         "permutation argument; bp_config.rec_air_id = 8, 84 constant columns) instead of the synthetic AIR "
-                         "BASELINE's workload is defined on -- reported as another workload")
+                         "the synthetic AIR on 135 x 82 columns, as in rounds 1-3 (bp_config.rec_air_id = 0), instead of the "
+                         "PLONK-shaped circuit that is the default since round 4 (AIR 8: gates by constants, public inputs "
+                         "in-circuit, the copy-constraint permutation argument; 84 constant columns, 20 instead of 16 "
+                         "auxiliary columns)")
     ap.add_argument("--leg-only", action="store_true",
                     help="(internal) run only the alone-on-the-chip measurements -- single-stream roofline leg, isolated "
                          "LDE, inverse-NTT sweep, Poseidon peak -- and print them as one JSON object; the main run "
@@ -248,7 +250,7 @@ def main():
         has the device to itself and event time == kernel time (this is what the rocprof summary in profiles/ is
         taken from)."""
         solo = pg.ProverStateBuilder().set(device=local_rank, n_workers=1, arena_bytes=int(args.arena_gib * 2**30),
-                                            **(dict(rec_air_id=8, rec_n_const=84) if args.plonk_rec else {})).build()
+                                            **(SYNTHETIC_REC if args.synthetic_rec else {})).build()
         solo_driver = BlockDriver(solo, n_threads=1)
         irs = synthetic_block_irs(1000, 2, S1_LOG_N, S1_WIDTH)
         solo_driver.prove_shard(irs[:1])
@@ -285,13 +287,13 @@ def main():
         solo.close()
         return roof, alu, others, k5
 
-    def side_block(real_airs, plonk_rec):
-        """The driver's one command never touches AIR 1..6 and AIR 8 outside pytest: a 64-txn block of another
-        workload than the metric's, 16 prover streams, here in the child process.  real_airs: the six tables with an
-        AIR are proven with it (the sponge table's rows look their permutations up in the Keccak-f table); plonk_rec:
-        the recursion-shaped proofs are proofs of the PLONK-shaped circuit (bp_config.rec_air_id = 8)."""
+    def side_block(real_airs, synthetic_rec):
+        """The driver's one command never touches AIR 1..6 outside pytest: a 64-txn block of another workload than the
+        metric's, 16 prover streams, here in the child process.  real_airs: the six tables with an AIR are proven with
+        it (the sponge table's rows look their permutations up in the Keccak-f table); synthetic_rec: the
+        recursion-shaped proofs are proofs of the synthetic AIR (bp_config.rec_air_id = 0, the workload of rounds 1-3)."""
         n, thr = 64, 16
-        rec = dict(rec_air_id=8, rec_n_const=84) if plonk_rec else {}
+        rec = SYNTHETIC_REC if synthetic_rec else {}
         st = pg.ProverStateBuilder().set(device=local_rank, n_workers=thr, arena_bytes=int(args.arena_gib * 2**30), **rec).build()
         drv = BlockDriver(st, n_threads=thr)
         blocks = [synthetic_block_irs(3000 + b, n, S1_LOG_N, S1_WIDTH, **(REAL_AIRS if real_airs else {})) for b in range(3)]
@@ -309,9 +311,11 @@ def main():
         if real_airs:
             what.append("the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / 2414 / 523 / 44 "
                         "columns), the CPU table synthetic; cross-table lookup keccak_sponge -> keccak_f checked in every txn")
-        if plonk_rec:
-            what.append("every recursion-shaped proof a proof of the PLONK-shaped circuit (AIR 8: 135 wires, 84 constant "
-                        "columns, copy-constraint permutation argument, public inputs bound in-circuit)")
+        if synthetic_rec:
+            what.append("every recursion-shaped proof a proof of the synthetic AIR (135 x 82 columns, 16 auxiliary columns) "
+                        "instead of the PLONK-shaped circuit: the recursion workload of rounds 1-3")
+        else:
+            what.append("recursion-shaped proofs on the PLONK-shaped circuit (AIR 8), as in the metric's run")
         return {"value": round(n * 2 / dt, 3), "unit": "txn-proofs/s", "steps": 2, "warmup": 1, "prover_streams": thr,
                 "workload": "64-txn block, " + "; ".join(what) + "; another workload than the metric's"}
 
@@ -320,8 +324,7 @@ def main():
         roof, alu, others, k5 = single_stream_leg()
         out = {"roofline": roof, "alu_kernel": alu, "hbm_kernels": others, "k5": k5}
         if not args.leg_skip_extras:
-            out.update(real_airs=side_block(True, False), plonk_rec=side_block(False, True),
-                       real_airs_plonk_rec=side_block(True, True))
+            out.update(real_airs=side_block(True, False), synthetic_rec=side_block(False, True))
             out.update(roofline_isolated=isolated_roofline(pkg, torch), ntt_hbm_gbps=ntt_gbps(pkg, torch))
             if alu:
                 finish_alu_kernel(alu, poseidon_peak(pkg, torch))
@@ -346,7 +349,7 @@ def main():
 
     t_build = time.time()
     # ProverStateBuilder::default() ranges (constants.rs:6-18), as the reference builds them
-    rec = dict(rec_air_id=8, rec_n_const=84) if args.plonk_rec else {}
+    rec = SYNTHETIC_REC if args.synthetic_rec else {}
     state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads,
                                          arena_bytes=int(args.arena_gib * 2**30), **rec).build()
     t_build = time.time() - t_build
@@ -422,8 +425,8 @@ def main():
                                % (args.txns, list(S1_LOG_N), list(S1_WIDTH), args.txns - 1),
                    "keccak_table": "Keccak-f[1600] AIR, 2430 columns" if (args.keccak_air or args.real_airs)
                                    else "synthetic AIR, 2432 columns",
-                   "recursion_proofs": "PLONK-shaped circuit (AIR 8), 135 wires, 84 constants" if args.plonk_rec
-                                       else "synthetic AIR, 135 columns, 82 constants",
+                   "recursion_proofs": "synthetic AIR, 135 columns, 82 constants" if args.synthetic_rec
+                                       else "PLONK-shaped circuit (AIR 8), 135 wires, 84 constants, 20 auxiliary columns",
                    **({"logic_table": "logic AIR, 523 columns", "memory_table": "memory AIR, 44 columns",
                        "arithmetic_table": "arithmetic AIR, 309 columns",
                        "byte_packing_table": "byte-packing AIR, 297 columns",
@@ -451,7 +454,7 @@ def main():
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                 "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
             env["BPG_LEG_DEVICE"] = str(local_rank)
-            knobs = ["--arena-gib", str(args.arena_gib)] + (["--plonk-rec"] if args.plonk_rec else [])
+            knobs = ["--arena-gib", str(args.arena_gib)] + (["--synthetic-rec"] if args.synthetic_rec else [])
             for flag, _, _ in TUNE_KNOBS:
                 val = getattr(args, flag[2:].replace("-", "_"))
                 if val is not None:
@@ -465,11 +468,11 @@ def main():
     out["roofline"] = alone.get("roofline")
     out["roofline_in_situ"] = roofline_in_situ
     out["alu_kernel"] = alone.get("alu_kernel")
-    for k in ("hbm_kernels", "k5", "real_airs", "plonk_rec", "real_airs_plonk_rec", "roofline_isolated", "ntt_hbm_gbps"):
+    for k in ("hbm_kernels", "k5", "real_airs", "synthetic_rec", "roofline_isolated", "ntt_hbm_gbps"):
         if k in alone:
             out[k] = alone[k]
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0], plonk_rec=args.plonk_rec)
+        out["cpu_baseline"] = cpu_baseline(blocks[args.warmup][0], synthetic_rec=args.synthetic_rec)
     print(json.dumps(out), flush=True)
 
 
@@ -623,7 +626,7 @@ def usable_cores():
     return min(n, 64)
 
 
-def cpu_baseline(ir, plonk_rec=False):
+def cpu_baseline(ir, synthetic_rec=False):
     """Oracle (CPU restatement, OpenMP over the host cores) proving one txn of the block."""
     from oracle import pyoracle  # checker / baseline only
     pyoracle.build()
@@ -635,8 +638,8 @@ def cpu_baseline(ir, plonk_rec=False):
     lo, hi = list(S1_LOG_N), [x + 1 for x in S1_LOG_N]
     st = pyoracle.PgState(table_log_lo=lo, table_log_hi=hi, stark_rate_bits=1, stark_cap_height=4,
                           stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5, rec_log_n=13,
-                          rec_n_cols=135, rec_n_const=84 if plonk_rec else 82, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
-                          shrink_depth=3, rec_air_id=8 if plonk_rec else 0)
+                          rec_n_cols=135, rec_n_const=82 if synthetic_rec else 84, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
+                          shrink_depth=3, rec_air_id=0 if synthetic_rec else 8)
     import struct
     words = list(struct.unpack("<25Q", ir.to_bytes()))
     # like for like with the GPU figure, which excludes bp_state_build: the eight circuits this txn touches are

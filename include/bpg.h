@@ -380,12 +380,12 @@ typedef struct bp_config {
   /* StarkConfig::standard_fast_config(): rate_bits 1, cap_height 4, 84 queries, 16 PoW bits,
    * ConstantArityBits(4, 5)  [UPSTREAM-UNVERIFIED values, runtime parameters here] */
   uint32_t stark_rate_bits, stark_cap_height, stark_num_queries, stark_pow_bits, arity_bits, final_poly_bits;
-  /* CircuitConfig::standard_recursion_config() shaped proofs: 2^13 rows x 135 wires, 82 constant
-   * columns, rate_bits 3, 28 queries */
+  /* CircuitConfig::standard_recursion_config() shaped proofs: 2^13 rows x 135 wires, rate_bits 3, 28 queries; 84
+   * preprocessed constant columns (4 gate constants + 80 sigmas) for the PLONK-shaped circuit, which is the default */
   uint32_t rec_log_n, rec_n_cols, rec_n_const, rec_rate_bits, rec_num_queries, rec_pow_bits;
   uint32_t shrink_depth; /* recursion-shaped proofs per table before the root (3) */
-  uint32_t rec_air_id;   /* what the recursion-shaped proofs are proofs OF: 0 (default) = the synthetic AIR on rec_n_cols x
-                          * rec_n_const columns; 8 = the PLONK-shaped circuit of AIR 8 (csrc/air.hpp: gates by constants,
+  uint32_t rec_air_id;   /* what the recursion-shaped proofs are proofs OF: 0 = the synthetic AIR on rec_n_cols x rec_n_const
+                          * columns (rounds 1-3; 82 constants); 8 (default) = the PLONK-shaped circuit of AIR 8 (csrc/air.hpp: gates by constants,
                           * public inputs bound in-circuit, copy constraints by the permutation argument), which needs
                           * rec_n_cols = 135 and rec_n_const = 84 -- the proof system of upstream's recursion circuits
                           * (prove_aggregation / prove_block, proof_gen.rs:66-75, 97-103), still not a verifier circuit */

@@ -283,9 +283,11 @@ void bp_config_default(bp_config* c) {
   for (int t = 0; t < BP_NUM_TABLES; t++) { c->table_log_lo[t] = lo[t]; c->table_log_hi[t] = hi[t]; }
   c->stark_rate_bits = 1; c->stark_cap_height = 4; c->stark_num_queries = 84; c->stark_pow_bits = 16;
   c->arity_bits = 4; c->final_poly_bits = 5;
-  c->rec_log_n = 13; c->rec_n_cols = 135; c->rec_n_const = 82; c->rec_rate_bits = 3; c->rec_num_queries = 28;
+  // recursion-shaped proofs: proofs of the PLONK-shaped circuit (AIR 8), 135 wires, 84 preprocessed constant columns
+  c->rec_log_n = 13; c->rec_n_cols = 135; c->rec_n_const = 84; c->rec_rate_bits = 3; c->rec_num_queries = 28;
   c->rec_pow_bits = 16;
   c->shrink_depth = 3;
+  c->rec_air_id = 8;
   c->device = 0; c->n_workers = 4; c->arena_bytes = (uint64_t)6 << 30;
 }
 

@@ -2,7 +2,8 @@
 SMALL = dict(
     table_log_lo=[6, 5, 6, 7, 5, 6, 8], table_log_hi=[8, 7, 8, 9, 7, 8, 10],
     stark_rate_bits=1, stark_cap_height=4, stark_num_queries=10, stark_pow_bits=8, arity_bits=4, final_poly_bits=5,
-    rec_log_n=6, rec_n_cols=19, rec_n_const=5, rec_rate_bits=3, rec_num_queries=6, rec_pow_bits=6, shrink_depth=2)
+    rec_log_n=6, rec_n_cols=19, rec_n_const=5, rec_rate_bits=3, rec_num_queries=6, rec_pow_bits=6, shrink_depth=2,
+    rec_air_id=0)   # recursion-shaped proofs on the synthetic AIR (small: 19 columns); SMALL_PLONK below is the default kind
 LOG_N = (6, 5, 7, 7, 5, 6, 9)
 WIDTH = (16, 8, 24, 40, 16, 24, 8)
 IR_MAGIC = 0x52494E5854475042

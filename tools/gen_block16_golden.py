@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np  # noqa: E402
 
-from gen_hotpath_golden import S1_LOG_N, block_irs  # noqa: E402
+from gen_hotpath_golden import DEFAULT_PG, block_irs  # noqa: E402
 from oracle import pyoracle as orc  # noqa: E402
 
 t00 = time.time()
@@ -52,13 +52,10 @@ try:
     ctypes.CDLL("libgomp.so.1").omp_set_num_threads(CORES)
 except OSError:
     pass
-N_TXN = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+N_TXN = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
 orc.build()
 sha = lambda w: hashlib.sha256(np.ascontiguousarray(w, dtype="<u8").tobytes()).hexdigest()
-st = orc.PgState(table_log_lo=list(S1_LOG_N), table_log_hi=[x + 1 for x in S1_LOG_N], stark_rate_bits=1,
-                 stark_cap_height=4, stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5,
-                 rec_log_n=13, rec_n_cols=135, rec_n_const=82, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
-                 shrink_depth=3)
+st = orc.PgState(**DEFAULT_PG)
 irs = block_irs(16)[:N_TXN]
 level = []
 for i, ir in enumerate(irs):

@@ -27,10 +27,7 @@ def main():
     orc.build()
     g.BLOCK = BLOCK
     irs = g.block_irs(N_TXN)
-    st = orc.PgState(table_log_lo=list(g.S1_LOG_N), table_log_hi=[x + 1 for x in g.S1_LOG_N], stark_rate_bits=1,
-                     stark_cap_height=4, stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5,
-                     rec_log_n=13, rec_n_cols=135, rec_n_const=82, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
-                     shrink_depth=3)
+    st = orc.PgState(**g.DEFAULT_PG)
     out = {"generator": "tools/gen_block256_golden.py", "block_number": BLOCK, "n_txn": N_TXN,
            "ir255": [int(x) for x in irs[255]]}
     for i in PICK:
