@@ -222,7 +222,7 @@ def main():
                    (4, "openings_multi_kernel", "8 n C: every coefficient column once"),
                    (5, "fri_combine_*_kernel", "8 n C: every coefficient column once + six result columns"),
                    (6, "aux_suffix_product_kernel", "8 n per column read or written (24 n per product of a synthetic table)"))
-    AIR_NAMES = ("synthetic", "keccak_f", "logic", "memory", "arithmetic", "byte_packing", "keccak_sponge", "arithmetic_mul")
+    AIR_NAMES = ("synthetic", "keccak_f", "logic", "memory", "arithmetic", "byte_packing", "keccak_sponge", "arithmetic_mul", "plonk")
 
     def read_hbm_family(fam, kernel, formula):
         n, ms, by = C.c_uint64(), C.c_double(), C.c_double()
@@ -272,7 +272,7 @@ def main():
         alu = read_leaf_hash()
         # the other HBM-class kernels SURVEY.md section 8(d) names, over the same leg, and K5 on the synthetic tables
         others = {name: r for fam, name, formula in HBM_KERNELS for r in [read_hbm_family(fam, name, formula)] if r}
-        k5 = read_k5((0,))
+        k5 = read_k5((0, 8))
         if not args.leg_skip_extras:
             # the same leg with the six tables that have an AIR proven with it: K5 per air_id
             irs_r = synthetic_block_irs(1001, 2, S1_LOG_N, S1_WIDTH, **REAL_AIRS)

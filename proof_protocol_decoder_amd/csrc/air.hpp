@@ -80,6 +80,17 @@ struct Ops<uint64_t> {
     gl::canon_n<4>(r);
     __builtin_amdgcn_sched_barrier(0);
   }
+  // The same without canonical results, for products that only feed further products: operands and results are ANY
+  // u64 representative (gl::mul_n takes them); add_lazy(a, b) adds a canonical b to such a value, mul7 multiplies one
+  // by 7.  A value made this way must pass through mul4 / mul (canonical results) before add / sub / out see it.
+  static __device__ __forceinline__ void mul4_lazy(const T (&a)[4], const T (&b)[4], T (&r)[4]) {
+    __builtin_amdgcn_sched_barrier(0);
+    gl::mul_n<4>(a, b, r);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  static __device__ __forceinline__ T add_lazy(T a_any, T b) { return gl::add(a_any, b); }
+  static __device__ __forceinline__ T sub_lazy(T a_any, T b) { return gl::sub(a_any, b); }
+  static __device__ __forceinline__ T mul7(T a_any) { return gl::mul7(a_any); }
 };
 #endif
 template <>
@@ -93,6 +104,10 @@ struct Ops<gl::Ext> {
   static void mul4(const T (&a)[4], const T (&b)[4], T (&r)[4]) {
     for (int i = 0; i < 4; i++) r[i] = gl::mul(a[i], b[i]);
   }
+  static void mul4_lazy(const T (&a)[4], const T (&b)[4], T (&r)[4]) { mul4(a, b, r); }
+  static T add_lazy(T a, T b) { return gl::add(a, b); }
+  static T sub_lazy(T a, T b) { return gl::sub(a, b); }
+  static T mul7(T a) { return gl::scale(a, 7); }
 };
 
 // ------------------------------------------------------------------------------------------ AIR 0: synthetic
@@ -890,21 +905,45 @@ template <class T, class Row, class Emit>
 GL_HD void eval_unit(const Row& row, Emit& out) {
   typedef Ops<T> F;
   const T qa = row.cst(CST_ARITH), qs = row.cst(CST_SBOX), c0 = row.cst(CST_C0), c1 = row.cst(CST_C1);
+  const T qa4[4] = {qa, qa, qa, qa}, qs4[4] = {qs, qs, qs, qs}, c04[4] = {c0, c0, c0, c0}, c14[4] = {c1, c1, c1, c1};
+  // four slots at a time; only what meets an addition or the consumer is made canonical
 #pragma unroll 1
-  for (uint32_t s = 0; s < N_SLOTS; s++) {
-    const T a = row.loc(4 * s), b = row.loc(4 * s + 1), c = row.loc(4 * s + 2), d = row.loc(4 * s + 3);
-    out.all(G0 + s, F::mul(qa, F::sub(F::add(F::mul(c0, F::mul(a, b)), F::mul(c1, c)), d)));
+  for (uint32_t s = 0; s < N_SLOTS; s += 4) {
+    T a[4], b[4], c[4], ab[4], cab[4], cc[4], t[4], g[4];
+    for (uint32_t i = 0; i < 4; i++) { a[i] = row.loc(4 * (s + i)); b[i] = row.loc(4 * (s + i) + 1); c[i] = row.loc(4 * (s + i) + 2); }
+    F::mul4_lazy(a, b, ab);
+    F::mul4_lazy(c04, ab, cab);
+    F::mul4(c14, c, cc);
+    for (uint32_t i = 0; i < 4; i++) t[i] = F::sub_lazy(F::add_lazy(cab[i], cc[i]), row.loc(4 * (s + i) + 3));
+    F::mul4(qa4, t, g);
+    for (uint32_t i = 0; i < 4; i++) out.all(G0 + s + i, g[i]);
   }
+  // an S-box unit: its four products in one group, the selector times its four power relations in another; the
+  // selector times the two wire relations of two units share a third
+  T pend[4] = {F::k(0), F::k(0), F::k(0), F::k(0)};
 #pragma unroll 1
   for (uint32_t i = 0; i < N_SBOX; i++) {
     const uint32_t u = COL_SBOX + 5 * i;
     const T x = row.loc(u), x2 = row.loc(u + 1), x4 = row.loc(u + 2), x6 = row.loc(u + 3), x7 = row.loc(u + 4);
-    out.all(G1 + 4 * i, F::mul(qs, F::sub(x2, F::mul(x, x))));
-    out.all(G1 + 4 * i + 1, F::mul(qs, F::sub(x4, F::mul(x2, x2))));
-    out.all(G1 + 4 * i + 2, F::mul(qs, F::sub(x6, F::mul(x4, x2))));
-    out.all(G1 + 4 * i + 3, F::mul(qs, F::sub(x7, F::mul(x6, x))));
-    out.all(G2 + 2 * i, F::mul(qs, F::sub(x, row.loc(4 * i))));
-    out.all(G2 + 2 * i + 1, F::mul(qs, F::sub(x7, row.loc(4 * i + 3))));
+    const T l4[4] = {x, x2, x4, x6}, r4[4] = {x, x2, x2, x};
+    T p4[4], d4[4], g4[4];
+    F::mul4(l4, r4, p4);
+    d4[0] = F::sub(x2, p4[0]); d4[1] = F::sub(x4, p4[1]); d4[2] = F::sub(x6, p4[2]); d4[3] = F::sub(x7, p4[3]);
+    F::mul4(qs4, d4, g4);
+    for (uint32_t k = 0; k < 4; k++) out.all(G1 + 4 * i + k, g4[k]);
+    pend[2 * (i & 1)] = F::sub(x, row.loc(4 * i));
+    pend[2 * (i & 1) + 1] = F::sub(x7, row.loc(4 * i + 3));
+    if ((i & 1) || i + 1 == N_SBOX) {
+      T w4[4];
+      F::mul4(qs4, pend, w4);
+      const uint32_t i0 = i & ~1u;
+      out.all(G2 + 2 * i0, w4[0]);
+      out.all(G2 + 2 * i0 + 1, w4[1]);
+      if (i & 1) {
+        out.all(G2 + 2 * i0 + 2, w4[2]);
+        out.all(G2 + 2 * i0 + 3, w4[3]);
+      }
+    }
   }
 #pragma unroll 1
   for (uint32_t j = 0; j < 4; j++) out.first(G3 + j, F::sub(row.loc(j), F::k(row.pub(j))));
@@ -1056,6 +1095,9 @@ GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const 
 //   index base + 11 c + 10      first row                                                      Z - 1
 // Z(first) = 1 and the cyclic relation force prod_rows prod_j (numerator / denominator) = 1.
 // Challenge set c is the unit [10 c, 10 c + 10) of the auxiliary columns.
+// The products are taken in groups of four independent multiplications (Ops::mul4 / mul4_lazy: only the last level
+// needs canonical results): beta sigma_j for four wires (beta x k_j is a chain of multiplications by 7), then the pair products of numerator and denominator terms, then the halves; the chunk's last two levels
+// last level (cur den, prev num) rides in the next chunk's last group, so every group is full.
 template <class T, class Row, class Emit>
 GL_HD void eval_plonk(uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ctl[4], const Row& row, Emit& out) {
   typedef Ops<T> F;
@@ -1063,22 +1105,46 @@ GL_HD void eval_plonk(uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ct
 #pragma unroll 1
   for (uint32_t c = k0 / 10; c < (k1 + 9) / 10; c++) {
     const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
-    T bkx = F::mul(beta, x);  // beta k_j x, j running
+    const T bx = F::mul(beta, x);
+    const T b4[4] = {beta, beta, beta, beta};
+    T bkx = bx;  // beta x k_j, k_j = 7^j: a chain of multiplications by 7 (lazy: any representative)
     T prev = row.aux_nxt(10 * c);
+    // the chunk before this one, one level from done: its numerator, denominator and the two running-product values
+    T num_ = F::k(0), den_ = F::k(0), cur_ = F::k(0), prev_ = F::k(0);
 #pragma unroll 1
     for (uint32_t k = 1; k <= PLONK_CHUNKS; k++) {
-      T num = F::k(1), den = F::k(1);
+      T pn[4], pd[4];  // pair products of the chunk's eight numerator / denominator terms
 #pragma unroll 1
-      for (uint32_t j = PLONK_CHUNK * (k - 1); j < PLONK_CHUNK * k; j++) {
-        const T w = F::add(row.loc(j), gamma);
-        num = F::mul(num, F::add(w, bkx));
-        den = F::mul(den, F::add(w, F::mul(beta, row.cst(plonk::CST_SIGMA + j))));
-        bkx = F::mul(bkx, F::k(7));
+      for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t j0 = PLONK_CHUNK * (k - 1) + 4 * h;
+        T sg[4], bs[4];
+        for (uint32_t i = 0; i < 4; i++) sg[i] = row.cst(plonk::CST_SIGMA + j0 + i);
+        F::mul4_lazy(b4, sg, bs);
+        T tn[4], td[4];
+        for (uint32_t i = 0; i < 4; i++) {
+          const T w = F::add(row.loc(j0 + i), gamma);
+          tn[i] = F::add_lazy(bkx, w);
+          td[i] = F::add_lazy(bs[i], w);
+          bkx = F::mul7(bkx);
+        }
+        const T l4[4] = {tn[0], tn[2], td[0], td[2]}, r4[4] = {tn[1], tn[3], td[1], td[3]};
+        T q4[4];
+        F::mul4_lazy(l4, r4, q4);
+        pn[2 * h] = q4[0]; pn[2 * h + 1] = q4[1]; pd[2 * h] = q4[2]; pd[2 * h + 1] = q4[3];
       }
       const T cur = row.aux(10 * c + (k < PLONK_CHUNKS ? k : 0));
-      out.all(base + 11 * c + k - 1, F::sub(F::mul(cur, den), F::mul(prev, num)));
+      const T l4[4] = {pn[0], pn[2], pd[0], pd[2]}, r4[4] = {pn[1], pn[3], pd[1], pd[3]};
+      T hv[4];  // the halves: numerator A, B, denominator A, B
+      F::mul4_lazy(l4, r4, hv);
+      // this chunk's numerator and denominator; the previous chunk's cur den and prev num
+      const T m4[4] = {hv[0], hv[2], cur_, prev_}, n4[4] = {hv[1], hv[3], den_, num_};
+      T g4[4];
+      F::mul4(m4, n4, g4);
+      if (k > 1) out.all(base + 11 * c + k - 2, F::sub(g4[2], g4[3]));
+      num_ = g4[0]; den_ = g4[1]; cur_ = cur; prev_ = prev;
       prev = cur;
     }
+    out.all(base + 11 * c + PLONK_CHUNKS - 1, F::sub(F::mul(cur_, den_), F::mul(prev_, num_)));
     out.first(base + 11 * c + 10, F::sub(row.aux(10 * c), F::k(1)));
   }
 }

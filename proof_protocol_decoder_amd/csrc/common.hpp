@@ -26,7 +26,7 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // guard is two branches.  Families: 0 = LDE coset NTT (DIT, LDS-resident), 1 = inverse NTT (DIF).
 // family 2 counts permutations, not bytes; 3..6: the other HBM-class kernels of SURVEY.md section 8(d); 7 + air_id: K5
 enum { PROF_LDE_DIT = 0, PROF_INTT_DIF = 1, PROF_LEAF_HASH = 2, PROF_FRI_FOLD = 3, PROF_OPENINGS = 4, PROF_FRI_COMBINE = 5,
-       PROF_AUX = 6, PROF_K5 = 7, PROF_FAMILIES = 15 };
+       PROF_AUX = 6, PROF_K5 = 7 /* + air_id, nine AIRs */, PROF_FAMILIES = 16 };
 bool profile_on();
 // Function-try-block tail of every allocating extern "C" entry: nothing may unwind across the C ABI
 // (include/bpg.h); an exception becomes BP_ERR_DEVICE with its message.

@@ -1438,7 +1438,7 @@ int launch_quotient(const QuotArgs* qs, uint32_t batch, const QuotCoset& coset, 
   dim3 g1(ceil_div(rows, 256), wg_rows, batch);
   // algorithmic bytes: every element of the three LDE matrices read once, the two quotient columns written
   // (AIR 8 is counted with the synthetic recursion-shaped proofs it replaces)
-  KernelTimer kt(PROF_K5 + (q.air_id < 8 ? q.air_id : 0), st, 8.0 * (double)rows * ((double)q.n_cols + q.n_aux + q.n_const + 2) * batch);
+  KernelTimer kt(PROF_K5 + (q.air_id < air::COUNT ? q.air_id : 0), st, 8.0 * (double)rows * ((double)q.n_cols + q.n_aux + q.n_const + 2) * batch);
   if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(qb);
   else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(qb);
   else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(qb);

@@ -24,6 +24,7 @@ BLOCK, N_TXN, PICK = 2256, 256, (0, 127, 255)
 
 
 def main():
+    g.use_the_cores_we_may_run_on()
     orc.build()
     g.BLOCK = BLOCK
     irs = g.block_irs(N_TXN)
