@@ -3,7 +3,7 @@ docs/usage_seq_diagrams.md:8-20) -- fan the txns of a block out, aggregate, make
 
 One process per GPU.  Transactions are independent (trace_protocol.rs:18-22), so rank r proves the
 CONTIGUOUS slice [r*n/N, (r+1)*n/N) (aggregation needs contiguous ranges, proof_types.rs:23-24) and
-folds it into one proof with a local balanced tree: no communication.  The only exchange step of
+folds it into one proof with a local aggregation tree (aggregation_plan): no communication.  The only exchange step of
 the whole path is the gather of the N sub-block proofs (a few hundred KB each) to rank 0, which
 finishes the tree (N-1 aggregation proofs) and makes the block proof.  No field data ever crosses
 GPUs, so there is no all-reduce here by construction.
@@ -20,22 +20,66 @@ def shard_bounds(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def tree_reduce(proofs, agg_fn, pool=None):
-    """Fold a contiguous list of aggregatable proofs left-to-right into one, level by level.
-    Every level's aggregations are independent and run concurrently on `pool`."""
-    level = list(proofs)
-    if not level:
+def aggregation_plan(n, shape="pairs_then_chain"):
+    """The aggregation tree over n contiguous leaves (nodes 0 .. n-1): a list of (left, right) node ids, entry k being
+    node n + k; the last entry is the root.  Aggregation needs contiguous ranges (proof_types.rs:23-24) and nothing
+    else, the reference leaves the order to its scheduler (docs/usage_seq_diagrams.md:8-20).
+
+    "balanced": adjacent pairs level by level, an odd tail carried up.  After the LAST leaf exists, log2(n)
+    aggregations still run one after the other, each alone on the chip.
+    "pairs_then_chain" (the shard default): adjacent leaves are paired and the pair results folded left to right,
+    ((p0 p1) p2) p3 ...  Leaves complete roughly in order, so the chain advances while the later transactions are
+    still being proven -- one aggregation per two transactions, far below what it can keep up with -- and after the
+    last leaf only its pair, one chain step and the block proof remain, whatever n is."""
+    if n < 1:
         raise ValueError("nothing to aggregate")
-    while len(level) > 1:
-        pairs = [(level[i], level[i + 1]) for i in range(0, len(level) - 1, 2)]
-        if pool is not None and len(pairs) > 1:
-            nxt = list(pool.map(lambda p: agg_fn(p[0], p[1]), pairs))
+    plan = []
+    if shape == "balanced":
+        level = list(range(n))
+        while len(level) > 1:
+            nxt = []
+            for k in range(0, len(level) - 1, 2):
+                plan.append((level[k], level[k + 1]))
+                nxt.append(n + len(plan) - 1)
+            if len(level) % 2:
+                nxt.append(level[-1])
+            level = nxt
+        return plan
+    if shape != "pairs_then_chain":
+        raise ValueError("unknown tree shape %r" % (shape,))
+    heads = []
+    for k in range(0, n - 1, 2):
+        plan.append((k, k + 1))
+        heads.append(n + len(plan) - 1)
+    if n % 2:
+        heads.append(n - 1)
+    acc = heads[0]
+    for h in heads[1:]:
+        plan.append((acc, h))
+        acc = n + len(plan) - 1
+    return plan
+
+
+def tree_reduce(proofs, agg_fn, pool=None, shape="balanced"):
+    """Fold a contiguous list of aggregatable proofs into one along aggregation_plan(len(proofs), shape).
+    Aggregations whose children exist are independent and run concurrently on `pool`."""
+    nodes = list(proofs)
+    if not nodes:
+        raise ValueError("nothing to aggregate")
+    plan = aggregation_plan(len(nodes), shape)
+    n = len(nodes)
+    nodes += [None] * len(plan)
+    todo = list(range(len(plan)))
+    while todo:
+        ready = [k for k in todo if nodes[plan[k][0]] is not None and nodes[plan[k][1]] is not None]
+        if pool is not None and len(ready) > 1:
+            outs = list(pool.map(lambda k: agg_fn(nodes[plan[k][0]], nodes[plan[k][1]]), ready))
         else:
-            nxt = [agg_fn(a, b) for a, b in pairs]
-        if len(level) % 2:
-            nxt.append(level[-1])
-        level = nxt
-    return level[0]
+            outs = [agg_fn(nodes[plan[k][0]], nodes[plan[k][1]]) for k in ready]
+        for k, o in zip(ready, outs):
+            nodes[n + k] = o
+        todo = [k for k in todo if k not in set(ready)]
+    return nodes[-1]
 
 
 class TorchGather:
@@ -81,6 +125,7 @@ class BlockDriver:
 
     def __init__(self, p_state=None, n_threads=4, prove_txn=None, prove_agg=None, prove_block=None,
                  decode_proof=None):
+        self.n_threads = n_threads
         self.pool = ThreadPoolExecutor(n_threads) if n_threads > 1 else None
         self.prove_txn = prove_txn or (lambda ir: pg.generate_txn_proof(p_state, ir))
         self.prove_agg = prove_agg or (lambda a, b: pg.generate_agg_proof(p_state, a, b))
@@ -92,59 +137,62 @@ class BlockDriver:
         pv, kind = pg.public_values_of(raw)
         return (pg.GeneratedAggProof if kind == 1 else pg.GeneratedTxnProof)(pv, raw)
 
-    def prove_shard(self, irs):
-        """All txn proofs of a contiguous slice and its local aggregation tree.  The tree has the
-        same shape as tree_reduce (adjacent pairs per level, an odd tail is carried up), but every
-        aggregation is submitted the moment both of its children exist, so the tree overlaps with
-        the remaining txn proofs instead of running after them."""
+    def prove_shard(self, irs, shape="pairs_then_chain"):
+        """All txn proofs of a contiguous slice and its local aggregation tree (aggregation_plan).  Every aggregation
+        starts the moment both of its children exist and goes AHEAD of the transactions still waiting for a thread,
+        so the tree advances with the proving instead of piling up behind it."""
         n = len(irs)
         if self.pool is None or n < 2:
             txn_proofs = [self.prove_txn(ir) for ir in irs]
-            return tree_reduce(txn_proofs, self.prove_agg, None), txn_proofs
+            return tree_reduce(txn_proofs, self.prove_agg, None, shape), txn_proofs
+        import heapq
         import threading
-        lock = threading.Lock()
-        done = threading.Event()
-        # plan: levels[l] = list of node ids; a node is ("txn", i) or ("agg", left, right)
-        nodes = [("txn", i) for i in range(n)]
-        level = list(range(n))
+        plan = aggregation_plan(n, shape)
         parent_of = {}
-        while len(level) > 1:
-            nxt = []
-            for k in range(0, len(level) - 1, 2):
-                nodes.append(("agg", level[k], level[k + 1]))
-                nid = len(nodes) - 1
-                parent_of[level[k]] = parent_of[level[k + 1]] = nid
-                nxt.append(nid)
-            if len(level) % 2:
-                nxt.append(level[-1])
-            level = nxt
-        root = level[0]
+        for k, (l, r) in enumerate(plan):
+            parent_of[l] = parent_of[r] = n + k
+        root = n + len(plan) - 1
         results, errors = {}, []
+        cond = threading.Condition()
+        # (priority, node id): aggregations (0) before transactions (1), each kind in index order
+        queue = [(1, i) for i in range(n)]
+        heapq.heapify(queue)
+        state = {"stop": False}
 
         def finish(nid, value):
-            with lock:
+            with cond:
                 results[nid] = value
                 par = parent_of.get(nid)
-                ready = par is not None and nodes[par][1] in results and nodes[par][2] in results
-            if nid == root:
-                done.set()
-            elif ready:
-                self.pool.submit(run, par)
+                if par is not None and plan[par - n][0] in results and plan[par - n][1] in results:
+                    heapq.heappush(queue, (0, par))
+                if nid == root:
+                    state["stop"] = True
+                cond.notify_all()
 
-        def run(nid):
-            try:
-                node = nodes[nid]
-                if node[0] == "txn":
-                    finish(nid, self.prove_txn(irs[node[1]]))
-                else:
-                    finish(nid, self.prove_agg(results[node[1]], results[node[2]]))
-            except BaseException as e:  # surface the first failure to the caller
-                errors.append(e)
-                done.set()
+        def worker():
+            while True:
+                with cond:
+                    while not queue and not state["stop"]:
+                        cond.wait()
+                    if state["stop"]:
+                        return
+                    _, nid = heapq.heappop(queue)
+                try:
+                    if nid < n:
+                        finish(nid, self.prove_txn(irs[nid]))
+                    else:
+                        l, r = plan[nid - n]
+                        finish(nid, self.prove_agg(results[l], results[r]))
+                except BaseException as e:  # surface the first failure to the caller
+                    with cond:
+                        errors.append(e)
+                        state["stop"] = True
+                        cond.notify_all()
+                    return
 
-        for i in range(n):
-            self.pool.submit(run, i)
-        done.wait()
+        futures = [self.pool.submit(worker) for _ in range(min(self.n_threads, n))]
+        for f in futures:
+            f.result()
         if errors:
             raise errors[0]
         return results[root], [results[i] for i in range(n)]

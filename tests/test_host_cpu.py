@@ -108,18 +108,69 @@ def test_shard_bounds_are_contiguous_and_balanced():
 
 def test_tree_reduce_keeps_order_and_counts():
     from concurrent.futures import ThreadPoolExecutor
-    from proof_protocol_decoder_amd.block_driver import tree_reduce
+    from proof_protocol_decoder_amd.block_driver import aggregation_plan, tree_reduce
     calls = []
 
     def agg(a, b):
         assert a[1] == b[0]                 # contiguous ranges only
         calls.append((a, b))
         return (a[0], b[1])
-    for n in (1, 2, 3, 5, 8, 13, 32):
-        calls.clear()
-        with ThreadPoolExecutor(4) as pool:
-            assert tree_reduce([(i, i + 1) for i in range(n)], agg, pool) == (0, n)
-        assert len(calls) == n - 1
+    for shape in ("balanced", "pairs_then_chain"):
+        for n in (1, 2, 3, 5, 8, 13, 32):
+            calls.clear()
+            with ThreadPoolExecutor(4) as pool:
+                assert tree_reduce([(i, i + 1) for i in range(n)], agg, pool, shape) == (0, n)
+            assert len(calls) == n - 1
+            plan = aggregation_plan(n, shape)
+            assert len(plan) == n - 1 and all(l < n + k and r < n + k for k, (l, r) in enumerate(plan))
+    # what is left to do once the LAST leaf exists: log2(n) aggregations one after the other in the balanced tree,
+    # its pair and one chain step in the shard's shape -- whatever n is
+    def tail(n, shape):
+        plan, depth = aggregation_plan(n, shape), {n - 1: 0}
+        for k, (l, r) in enumerate(plan):
+            if l in depth or r in depth:
+                depth[n + k] = 1 + max(depth.get(l, 0), depth.get(r, 0))
+        return depth[n + len(plan) - 1]
+    assert [tail(n, "balanced") for n in (16, 32, 256)] == [4, 5, 8]
+    assert [tail(n, "pairs_then_chain") for n in (16, 32, 256)] == [2, 2, 2]
+
+
+def test_prove_shard_runs_aggregations_ahead_of_waiting_transactions():
+    """The shard's tree is scheduled with the proving: an aggregation whose children exist is taken before any
+    transaction that has not started, and a failure in any task surfaces."""
+    import threading
+    import time
+    from proof_protocol_decoder_amd.block_driver import BlockDriver
+    order, lock = [], threading.Lock()
+
+    def txn(i):
+        time.sleep(0.01)
+        with lock:
+            order.append(("txn", i))
+        return (i, i + 1)
+
+    def agg(a, b):
+        assert a[1] == b[0]
+        with lock:
+            order.append(("agg", a[0], b[1]))
+        return (a[0], b[1])
+    drv = BlockDriver(None, n_threads=2, prove_txn=txn, prove_agg=agg)
+    try:
+        top, leaves = drv.prove_shard(list(range(12)))
+        assert top == (0, 12) and leaves == [(i, i + 1) for i in range(12)]
+        # the pair (0, 1) is aggregated long before the last transactions are proven
+        assert order.index(("agg", 0, 2)) < order.index(("txn", 6))
+        assert sum(1 for o in order if o[0] == "agg") == 11
+
+        def bad(i):
+            if i == 5:
+                raise RuntimeError("txn 5 failed")
+            return txn(i)
+        drv.prove_txn = bad
+        with pytest.raises(RuntimeError, match="txn 5 failed"):
+            drv.prove_shard(list(range(12)))
+    finally:
+        drv.close()
 
 
 DRIVER_SCRIPT = r'''
