@@ -113,6 +113,8 @@ def main():
                          "PLONK-shaped circuit that is the default since round 4 (AIR 8: gates by constants, public inputs "
                          "in-circuit, the copy-constraint permutation argument; 84 constant columns, 20 instead of 16 "
                          "auxiliary columns)")
+    ap.add_argument("--tree-shape", default="balanced", choices=("balanced", "pairs_then_chain"),
+                    help="shape of a shard's aggregation tree (block_driver.aggregation_plan)")
     ap.add_argument("--leg-only", action="store_true",
                     help="(internal) run only the alone-on-the-chip measurements -- single-stream roofline leg, isolated "
                          "LDE, inverse-NTT sweep, Poseidon peak -- and print them as one JSON object; the main run "
@@ -353,7 +355,7 @@ def main():
     state = pg.ProverStateBuilder().set(device=local_rank, n_workers=args.threads,
                                          arena_bytes=int(args.arena_gib * 2**30), **rec).build()
     t_build = time.time() - t_build
-    driver = BlockDriver(state, n_threads=args.threads)
+    driver = BlockDriver(state, n_threads=args.threads, tree_shape=args.tree_shape)
     gather = TorchGather(torch.device("cpu") if share else torch.device("cuda", local_rank)) if world > 1 else None
 
     def barrier():

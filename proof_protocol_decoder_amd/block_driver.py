@@ -20,17 +20,18 @@ def shard_bounds(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def aggregation_plan(n, shape="pairs_then_chain"):
+def aggregation_plan(n, shape="balanced"):
     """The aggregation tree over n contiguous leaves (nodes 0 .. n-1): a list of (left, right) node ids, entry k being
     node n + k; the last entry is the root.  Aggregation needs contiguous ranges (proof_types.rs:23-24) and nothing
     else, the reference leaves the order to its scheduler (docs/usage_seq_diagrams.md:8-20).
 
-    "balanced": adjacent pairs level by level, an odd tail carried up.  After the LAST leaf exists, log2(n)
-    aggregations still run one after the other, each alone on the chip.
-    "pairs_then_chain" (the shard default): adjacent leaves are paired and the pair results folded left to right,
-    ((p0 p1) p2) p3 ...  Leaves complete roughly in order, so the chain advances while the later transactions are
-    still being proven -- one aggregation per two transactions, far below what it can keep up with -- and after the
-    last leaf only its pair, one chain step and the block proof remain, whatever n is."""
+    "balanced" (the default): adjacent pairs level by level, an odd tail carried up.
+    "pairs_then_chain": adjacent leaves are paired and the pair results folded left to right, ((p0 p1) p2) p3 ...
+    After the LAST leaf only its pair, one chain step and the block proof remain instead of log2(n) levels -- but the
+    leaves of a shard do not finish one by one: the last wave of transactions (one per prover stream) ends together,
+    and the chain then serialises what the balanced tree does in log2(streams) concurrent levels.  Measured on the
+    32-txn shard: 36.9 against 37.3 txn-proofs/s for the balanced tree, level on the 256-txn block; kept as an option
+    (bench.py --tree-shape)."""
     if n < 1:
         raise ValueError("nothing to aggregate")
     plan = []
@@ -124,8 +125,9 @@ class BlockDriver:
     prove_block(parent_or_None, agg) -> GeneratedBlockProof.  The defaults bind the HIP library."""
 
     def __init__(self, p_state=None, n_threads=4, prove_txn=None, prove_agg=None, prove_block=None,
-                 decode_proof=None):
+                 decode_proof=None, tree_shape="balanced"):
         self.n_threads = n_threads
+        self.tree_shape = tree_shape   # of a shard's local tree (aggregation_plan)
         self.pool = ThreadPoolExecutor(n_threads) if n_threads > 1 else None
         self.prove_txn = prove_txn or (lambda ir: pg.generate_txn_proof(p_state, ir))
         self.prove_agg = prove_agg or (lambda a, b: pg.generate_agg_proof(p_state, a, b))
@@ -137,11 +139,12 @@ class BlockDriver:
         pv, kind = pg.public_values_of(raw)
         return (pg.GeneratedAggProof if kind == 1 else pg.GeneratedTxnProof)(pv, raw)
 
-    def prove_shard(self, irs, shape="pairs_then_chain"):
+    def prove_shard(self, irs, shape=None):
         """All txn proofs of a contiguous slice and its local aggregation tree (aggregation_plan).  Every aggregation
         starts the moment both of its children exist and goes AHEAD of the transactions still waiting for a thread,
         so the tree advances with the proving instead of piling up behind it."""
         n = len(irs)
+        shape = shape or self.tree_shape
         if self.pool is None or n < 2:
             txn_proofs = [self.prove_txn(ir) for ir in irs]
             return tree_reduce(txn_proofs, self.prove_agg, None, shape), txn_proofs

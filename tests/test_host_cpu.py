@@ -124,7 +124,7 @@ def test_tree_reduce_keeps_order_and_counts():
             plan = aggregation_plan(n, shape)
             assert len(plan) == n - 1 and all(l < n + k and r < n + k for k, (l, r) in enumerate(plan))
     # what is left to do once the LAST leaf exists: log2(n) aggregations one after the other in the balanced tree,
-    # its pair and one chain step in the shard's shape -- whatever n is
+    # its pair and one chain step in the other shape -- whatever n is
     def tail(n, shape):
         plan, depth = aggregation_plan(n, shape), {n - 1: 0}
         for k, (l, r) in enumerate(plan):

@@ -1,6 +1,6 @@
 """Digest of the ORACLE's block proof of BASELINE configs[1]: the 16-txn synthetic S1 block (block number 2000) at
-bp_config_default parameters -- all 16 txn proofs, the aggregation tree in the shape of block_driver.aggregation_plan
-(pairs, then a chain), the block proof.  ~6 minutes on the GPU box's 16 host cores (CPU oracle only, nothing
+bp_config_default parameters -- all 16 txn proofs, the aggregation tree in the shape of block_driver.tree_reduce
+(adjacent pairs per level), the block proof.  ~6 minutes on the GPU box's 16 host cores (CPU oracle only, nothing
 touches the GPU); merge the printed object into tests/golden/hotpath_golden.json under "block16_full".
 
     gpurun --timeout 1200 -- 'python tools/gen_block16_golden.py > gpurun_out/block16_full.json'
@@ -62,24 +62,16 @@ for i, ir in enumerate(irs):
     t0 = time.time()
     level.append((st.txn(ir), False))
     print("txn %d: %.1f s (%d threads)" % (i, time.time() - t0, CORES), file=sys.stderr, flush=True)
-out = {"txn_sha256": [sha(p) for p, _ in level], "agg_sha256": [], "tree": "pairs_then_chain"}
-# the shard's aggregation tree: block_driver.aggregation_plan(n, "pairs_then_chain"), restated -- adjacent leaves are
-# paired, the pair results folded left to right; node ids: leaves 0..n-1, then the aggregations in plan order
-n = len(level)
-nodes = list(level)
-heads = []
-for k in range(0, n - 1, 2):
-    nodes.append((st.agg(nodes[k][0], nodes[k][1], nodes[k + 1][0], nodes[k + 1][1]), True))
-    out["agg_sha256"].append(sha(nodes[-1][0]))
-    heads.append(len(nodes) - 1)
-if n % 2:
-    heads.append(n - 1)
-acc = heads[0]
-for h in heads[1:]:
-    nodes.append((st.agg(nodes[acc][0], nodes[acc][1], nodes[h][0], nodes[h][1]), True))
-    out["agg_sha256"].append(sha(nodes[-1][0]))
-    acc = len(nodes) - 1
-level = [nodes[acc]]
+out = {"txn_sha256": [sha(p) for p, _ in level], "agg_sha256": []}
+while len(level) > 1:
+    nxt = []
+    for k in range(0, len(level) - 1, 2):
+        a = st.agg(level[k][0], level[k][1], level[k + 1][0], level[k + 1][1])
+        out["agg_sha256"].append(sha(a))
+        nxt.append((a, True))
+    if len(level) % 2:
+        nxt.append(level[-1])
+    level = nxt
 blk = st.block(None, level[0][0])
 assert st.verify(blk) == 0
 out["block_sha256"] = sha(blk)
