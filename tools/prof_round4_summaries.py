@@ -40,11 +40,11 @@ def k5_summary():
     with open(os.path.join(O, "r4_k5_counters.txt"), "w") as out:
         out.write("# HEAD %s.  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES / FETCH_SIZE / WRITE_SIZE (three passes) -- python "
                   "tools/k5_air_probe.py --counters: ONE quotient_air_kernel<AIR> launch per AIR on random LDE matrices (spread form, "
-                  "rate 2).  valu_per_constraint = SQ_INSTS_VALU x 64 lanes / (rows x constraints); fetch_over_algorithmic = FETCH_SIZE x 2 "
-                  "KiB / (8 x rows x (columns + aux columns)): 1.0 = every LDE element comes from HBM once\n" % HEAD)
+                  "rate 2; rate 8 for AIR 8).  valu_per_constraint = SQ_INSTS_VALU x 64 lanes / (rows x constraints); fetch_over_algorithmic = "
+                  "FETCH_SIZE x 2 KiB / (8 x rows x (columns + aux + constant columns)): 1.0 = every LDE element comes from HBM once\n" % HEAD)
         for air, c in sorted(cases.items()):
             v = acc.get(air, {})
-            read_alg = 8.0 * c["rows"] * (c["cols"] + c["aux"])
+            read_alg = c["alg"] - 16.0 * c["rows"]   # the probe's algorithmic bytes less the two quotient columns written
             fetch = 2 * 1024 * v.get("FETCH_SIZE", 0)
             out.write("%-14s rows=%d cols=%d aux=%d constraints=%d  valu_wave_insts=%.4e valu_per_constraint=%.2f  fetched_MB=%.1f "
                       "algorithmic_read_MB=%.1f fetch_over_algorithmic=%.3f written_MB=%.1f\n"
