@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--txns", type=int, default=256, help="transactions per block")
     ap.add_argument("--threads", type=int, default=0,
                     help="concurrent provers (HIP streams) per GPU; 0 = at most 20, dividing the shard into equally full "
-                         "rounds: measured optimum (profiles/r3_sweep_threads.txt); the waits sleep, so the count is not "
+                         "rounds: measured optimum (profiles/r4_sweep_threads.txt); the waits sleep, so the count is not "
                          "tied to host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing (roofline leg)")
@@ -153,10 +153,10 @@ def main():
     # BPG_SHARE_GPU=1 is a rehearsal mode for a 1-GPU box: all ranks use device 0 and the gather runs
     # over gloo (RCCL needs one device per rank).  The driver's real runs never set it.
     if args.threads <= 0:
-        # at most 20 streams, and as many as divide the shard into equally full rounds.  Round 3 sweep on the 256-txn
-        # block (profiles/r3_sweep_threads.txt): 14 / 16 / 18 / 20 / 22 / 24 / 28 / 32 streams -> 36.3 / 36.7 / 37.6 /
-        # 38.1 / 37.2 / 37.4 / 37.0 / 37.0 txn-proofs/s (with round 2's slower kernels the optimum was 24).  A 32-txn
-        # shard runs 16 + 16, a 16-txn shard all 16 at once (profiles/r2_shard_streams.txt).
+        # at most 20 streams, and as many as divide the shard into equally full rounds.  Sweep on the 256-txn block
+        # (profiles/r4_sweep_threads.txt): 16 / 18 / 20 / 24 streams -> 39.2 / 39.6 / 39.6 / 38.7 txn-proofs/s (flat from 14
+        # to 20 since the recursion chains are lock-step batches).  A 32-txn shard runs 16 + 16, a 16-txn shard all 16
+        # at once (profiles/r2_shard_streams.txt).
         shard = (args.txns + world - 1) // world
         rounds = (shard + 19) // 20
         args.threads = max(4, (shard + rounds - 1) // rounds)
