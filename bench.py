@@ -104,7 +104,7 @@ def main():
                          "of the 2432-column synthetic table BASELINE's metric is quoted on")
     ap.add_argument("--real-airs", action="store_true",
                     help="the arithmetic, byte-packing, Keccak, Keccak-sponge, logic and memory tables of every transaction are "
-                         "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / "
+                         "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 299 / 2430 / "
                          "2414 / 523 / 44 columns) instead of synthetic tables of "
                          "BASELINE's widths -- another workload than the metric's, reported as such")
     ap.add_argument("--synthetic-rec", action="store_true",
@@ -311,7 +311,7 @@ def main():
         st.close()
         what = []
         if real_airs:
-            what.append("the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 297 / 2430 / 2414 / 523 / 44 "
+            what.append("the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 299 / 2430 / 2414 / 523 / 44 "
                         "columns), the CPU table synthetic; cross-table lookup keccak_sponge -> keccak_f checked in every txn")
         if synthetic_rec:
             what.append("every recursion-shaped proof a proof of the synthetic AIR (135 x 82 columns, 16 auxiliary columns) "
@@ -431,7 +431,7 @@ def main():
                                        else "PLONK-shaped circuit (AIR 8), 135 wires, 84 constants, 20 auxiliary columns",
                    **({"logic_table": "logic AIR, 523 columns", "memory_table": "memory AIR, 44 columns",
                        "arithmetic_table": "arithmetic AIR, 309 columns",
-                       "byte_packing_table": "byte-packing AIR, 297 columns",
+                       "byte_packing_table": "byte-packing AIR, 299 columns",
                        "keccak_sponge_table": "Keccak sponge AIR, 2414 columns"} if args.real_airs else {}),
                    "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
                    "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,

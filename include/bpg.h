@@ -205,7 +205,7 @@ struct bp_stark_cfg;
  * row on 2430 columns, written from FIPS 202 (not upstream's column layout), 2 = logic, one AND / OR / XOR of two
  * 256-bit words per row on 523 columns, 3 = memory, a log of reads and writes sorted by (address, timestamp) on 44
  * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns, 5 = byte_packing,
- * a big-endian byte sequence and the word it spells on 297 columns, 6 = keccak_sponge, the absorbing side of
+ * a big-endian byte sequence and the word it spells on 299 columns, 6 = keccak_sponge, the absorbing side of
  * Keccak-256 (XOR into the rate, chaining, pad10*1) on 2414 columns, 7 = arithmetic_mul, x * y = z + 2^256 w on 1217
  * columns (likewise their own layouts; AIR 7 is not wired to a transaction's table: bp_stark_prove_air only), 8 = plonk, a
  * PLONK-shaped circuit as a table: 135 wires (80 routed), 84 preprocessed constant columns (two gate selectors, two gate
@@ -272,9 +272,12 @@ int bp_memory_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uin
  * from `seed` (code = splitmix64(seed ^ (0xFE << 32) ^ row) % 5, words as in bp_logic_trace). */
 int bp_arithmetic_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 /* Witness of AIR 5 (the byte-packing table: a big-endian sequence of 1..32 bytes and the 256-bit word it spells, what
- * MLOAD_32BYTES / MSTORE_32BYTES move): n = 2^log_n rows x 297 columns, column-major.  d_inputs: [n][6] = is_read, len
- * (0 = a padding row; above 32: 32), the 32 byte slots as four 64-bit words (slot i = byte i % 8 of word i / 8; slots
- * from len on are ignored); or NULL to draw them from `seed`. */
+ * MLOAD_32BYTES / MSTORE_32BYTES move): n = 2^log_n rows x 299 columns, column-major.  d_inputs: [n][6] = word 0:
+ * is_read (bit 0) | timestamp << 8; word 1: len (low byte; 0 = a padding row; above 32: 32) | address << 8 -- the 32-bit
+ * address and timestamp of the memory operation that moves the word (the lookup byte_packing -> memory sends
+ * (is_read, address, timestamp, value limbs) to the memory table; zero when the caller does not care) --; then the 32
+ * byte slots as four 64-bit words (slot i = byte i % 8 of word i / 8; slots from len on are ignored); or NULL to draw
+ * them from `seed` (address = row, timestamp = 2 + row). */
 int bp_byte_packing_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 /* Witness of AIR 6 (the Keccak sponge table: the absorbing side of Keccak-256, one 136-byte block per row): n =
  * 2^log_n rows x 2414 columns, column-major.  d_inputs: [n][44] = flags (1 full block, 2 final block, 0 padding row),
@@ -329,7 +332,7 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
-/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 .. 7: n_cols = 2430 / 523 / 44 / 309 / 297 / 2414 / 1217,
+/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 .. 7: n_cols = 2430 / 523 / 44 / 309 / 299 / 2414 / 1217,
  * n_const = 0, deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
 int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                        uint8_t** out, size_t* out_len);
@@ -502,7 +505,7 @@ int bp_ir_set_logic_air(uint64_t ir[BP_IR_WORDS], int on);
 int bp_ir_set_memory_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the arithmetic table (flag 0x800; table index 0): the arithmetic AIR (air_id 4: 309 columns). */
 int bp_ir_set_arithmetic_air(uint64_t ir[BP_IR_WORDS], int on);
-/* ... and for the byte-packing table (flag 0x1000; table index 1): the byte-packing AIR (air_id 5: 297 columns). */
+/* ... and for the byte-packing table (flag 0x1000; table index 1): the byte-packing AIR (air_id 5: 299 columns). */
 int bp_ir_set_byte_packing_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the Keccak sponge table (flag 0x2000; table index 4): the Keccak sponge AIR (air_id 6: 2414 columns). */
 int bp_ir_set_keccak_sponge_air(uint64_t ir[BP_IR_WORDS], int on);

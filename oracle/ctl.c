@@ -2,10 +2,13 @@
  * reference (see gl.h): upstream proves the seven tables of a transaction as ONE statement (one prove_root call,
  * plonky_block_proof_gen/src/proof_gen.rs:44-52; tables prover_state.rs:85-93) and ties them with plonky2_evm's
  * cross-table lookups, which are not under /root/reference.  The lookups here are this repository's own, written for
- * its own column layouts:
+ * its own column layouts (AIRS.md section 3):
  *
  *   keccak_sponge -> keccak_f: every row of the sponge table that absorbs a block claims "the permutation of (xored
  *   rate, capacity) is (updated state)"; the Keccak-f table exposes (input, output) of the permutations it is asked for.
+ *
+ *   byte_packing -> memory: every row of the byte-packing table that moves a word claims "the memory operation
+ *   (is_read, address, timestamp) carries this 256-bit value"; the memory table exposes the operations it is asked for.
  *
  * A lookup is a pair of filtered running products z[i] = prod_{i' >= i} factor[i'], factor = (gamma + sum_j beta^j
  * tuple_j) on the rows that take part and 1 on the others; the statement holds when the first-row values agree, for
@@ -14,6 +17,8 @@
  *   keccak_f   5            g (row takes part: last round of an exposed permutation), h_0, h_1 (the permutation's 50
  *                           input limbs compressed by beta_c, the same value on all its rows), z_0, z_1
  *   sponge     2            z_0, z_1
+ *   byte_packing 2          z_0, z_1
+ *   memory     3            g (the operation is exposed), z_0, z_1
  *   others     1            the constant 1
  * This file computes the columns by their meaning (if / else per row, explicit powers) and states the constraints as
  * polynomials; the product (csrc/air.hpp, namespace ctl) evaluates the same polynomials by Horner's rule. */
@@ -23,17 +28,22 @@
 
 enum { KCOL_STEP = 0, KCOL_A = 24, KCOL_APP = 2314, KCOL_APPP = 2428 };
 enum { SCOL_FULL = 0, SCOL_FINAL = 1, SCOL_CAP = 2314, SCOL_XORED = 2330, SCOL_UPDATED = 2364 };
+enum { PCOL_READ = 0, PCOL_LEN = 1, PCOL_VAL = 289, PCOL_ADDR = 297, PCOL_TS = 298 };
+enum { MCOL_READ = 0, MCOL_ADDR = 1, MCOL_TS = 2, MCOL_VAL = 3 };
 
 uint32_t orc_ctl_n_aux(uint32_t air_id, uint32_t n_cols) {
   return air_id == ORC_AIR_SYNTHETIC ? n_cols / 8
          : air_id == ORC_AIR_KECCAK_F ? 5
          : air_id == ORC_AIR_KECCAK_SPONGE ? 2
+         : air_id == ORC_AIR_BYTE_PACKING ? 2
+         : air_id == ORC_AIR_MEMORY ? 3
          : air_id == ORC_AIR_PLONK ? 20 /* Z + nine partial products per challenge set (plonk_air.c) */
                                    : 1;
 }
 
 /* The auxiliary columns of a table with a real AIR, from its trace values tv ([n_cols][N], column-major).
- * exposed (Keccak-f only, nullable): exposed[p] != 0 when permutation p is asked for, n_exposed entries. */
+ * exposed (nullable): Keccak-f table: exposed[p] != 0 when permutation p is asked for; memory table: exposed[i] != 0 when
+ * the operation in row i is asked for; n_exposed entries. */
 void orc_ctl_aux_columns(uint32_t air_id, const gl_t* tv, unsigned log_n, const gl_t ctl[4], const uint8_t* exposed,
                          size_t n_exposed, gl_t* aux) {
   const size_t N = (size_t)1 << log_n;
@@ -78,6 +88,44 @@ void orc_ctl_aux_columns(uint32_t air_id, const gl_t* tv, unsigned log_n, const 
           for (int j = 0; j < 34; j++) tuple = gl_add(tuple, gl_mul(pw[j], tv[(size_t)(SCOL_XORED + j) * N + i]));
           for (int j = 0; j < 16; j++) tuple = gl_add(tuple, gl_mul(pw[34 + j], tv[(size_t)(SCOL_CAP + j) * N + i]));
           for (int j = 0; j < 50; j++) tuple = gl_add(tuple, gl_mul(pw[50 + j], tv[(size_t)(SCOL_UPDATED + j) * N + i]));
+          run = gl_mul(run, gl_add(gamma, tuple));
+        }
+        z[i] = run;
+      }
+    }
+    return;
+  }
+  if (air_id == ORC_AIR_BYTE_PACKING) { /* a row with a length sends (is_read, address, timestamp, value limbs) */
+    for (int c = 0; c < 2; c++) {
+      const gl_t beta = ctl[2 * c], gamma = ctl[2 * c + 1];
+      gl_t *z = aux + (size_t)c * N, run = 1;
+      for (size_t i = N; i-- > 0;) {
+        int has_len = 0;
+        for (int j = 0; j < 32; j++) has_len |= tv[(size_t)(PCOL_LEN + j) * N + i] != 0;
+        if (has_len) {
+          gl_t tuple = tv[(size_t)PCOL_READ * N + i], pw = beta;
+          tuple = gl_add(tuple, gl_mul(pw, tv[(size_t)PCOL_ADDR * N + i])); pw = gl_mul(pw, beta);
+          tuple = gl_add(tuple, gl_mul(pw, tv[(size_t)PCOL_TS * N + i])); pw = gl_mul(pw, beta);
+          for (int k = 0; k < 8; k++) { tuple = gl_add(tuple, gl_mul(pw, tv[(size_t)(PCOL_VAL + k) * N + i])); pw = gl_mul(pw, beta); }
+          run = gl_mul(run, gl_add(gamma, tuple));
+        }
+        z[i] = run;
+      }
+    }
+    return;
+  }
+  if (air_id == ORC_AIR_MEMORY) { /* an exposed row offers (is_read, address, timestamp, value limbs) */
+    gl_t* g = aux;
+    for (size_t i = 0; i < N; i++) g[i] = (exposed && i < n_exposed && exposed[i]) ? 1 : 0;
+    for (int c = 0; c < 2; c++) {
+      const gl_t beta = ctl[2 * c], gamma = ctl[2 * c + 1];
+      gl_t *z = aux + (size_t)(1 + c) * N, run = 1;
+      for (size_t i = N; i-- > 0;) {
+        if (g[i]) {
+          gl_t tuple = tv[(size_t)MCOL_READ * N + i], pw = beta;
+          tuple = gl_add(tuple, gl_mul(pw, tv[(size_t)MCOL_ADDR * N + i])); pw = gl_mul(pw, beta);
+          tuple = gl_add(tuple, gl_mul(pw, tv[(size_t)MCOL_TS * N + i])); pw = gl_mul(pw, beta);
+          for (int k = 0; k < 8; k++) { tuple = gl_add(tuple, gl_mul(pw, tv[(size_t)(MCOL_VAL + k) * N + i])); pw = gl_mul(pw, beta); }
           run = gl_mul(run, gl_add(gamma, tuple));
         }
         z[i] = run;

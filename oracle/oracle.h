@@ -86,7 +86,7 @@ typedef struct {
 #define ORC_ARITHMETIC_COLS 309u
 #define ORC_ARITHMETIC_CONSTRAINTS 294u
 #define ORC_AIR_BYTE_PACKING 5u
-#define ORC_BYTE_PACKING_COLS 297u
+#define ORC_BYTE_PACKING_COLS 299u
 #define ORC_BYTE_PACKING_CONSTRAINTS 330u
 #define ORC_AIR_KECCAK_SPONGE 6u
 #define ORC_KECCAK_SPONGE_COLS 2414u

@@ -201,7 +201,7 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
    * 0x200 = the logic table (index 5) is proven with the logic AIR (logic_air.c): 523 columns;
    * 0x400 = the memory table (index 6) with the memory AIR (memory_air.c): 44 columns;
    * 0x800 = the arithmetic table (index 0) with the arithmetic AIR (arithmetic_air.c): 309 columns;
-   * 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (byte_packing_air.c): 297 columns;
+   * 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (byte_packing_air.c): 299 columns;
    * 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (keccak_sponge_air.c): 2414 columns */
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
   if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 63) return -2;
@@ -263,6 +263,11 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
    * they are (and refused below if they disagree). */
   const int lookup_kf = keccak_air && sponge_air;
   const size_t kf_full_perms = ((size_t)1 << tcfg[3].log_n) / 24;
+  /* byte_packing -> memory (ctl.c): a memory table that is not given is the log of the byte-packing table's words --
+   * per packing row the write that put the word at its address (timestamp 1) and the operation the row looks up --,
+   * then re-reads of the last address up to the table's height */
+  const int lookup_bm = byte_packing_air && memory_air;
+  if (lookup_bm && !(wit && wit->items[6]) && tcfg[6].log_n < tcfg[1].log_n + 1) return -2;
   static const int order[NUM_TABLES] = {4, 0, 1, 2, 3, 5, 6}; /* the sponge table first: the Keccak-f table reads it */
   for (int oi = 0; oi < NUM_TABLES; oi++) {
     const int t = order[oi];
@@ -295,6 +300,21 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
       }
       orc_keccak_trace(0, in, tcfg[t].log_n, trace[t]);
       free(in);
+    } else if (tcfg[t].air_id == ORC_AIR_MEMORY && lookup_bm) {
+      const size_t np = (size_t)1 << tcfg[1].log_n;
+      const gl_t* pk = trace[1];
+      uint64_t* in = (uint64_t*)malloc(n * 11 * 8);
+      for (size_t i = 0; i < n; i++) {
+        const size_t r = i / 2 < np ? i / 2 : np - 1;
+        uint64_t* o = in + i * 11;
+        o[1] = pk[297 * np + r];
+        for (int k = 0; k < 8; k++) o[3 + k] = pk[(size_t)(289 + k) * np + r];
+        if (i / 2 >= np) { o[0] = 1; o[2] = pk[298 * np + r] + (i - 2 * np + 1); }   /* a re-read of the last address */
+        else if (i % 2 == 0) { o[0] = 0; o[2] = 1; }                                  /* the word is put there */
+        else { o[0] = pk[0 * np + r]; o[2] = pk[298 * np + r]; }                      /* the operation the packing row names */
+      }
+      orc_memory_trace(0, in, tcfg[t].log_n, trace[t]);
+      free(in);
     } else if (tcfg[t].air_id == ORC_AIR_KECCAK_F) orc_keccak_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_LOGIC) orc_logic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_MEMORY) orc_memory_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
@@ -320,6 +340,19 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
       for (size_t p = 0; p < ns; p++) exposed[p] = trace[4][p] || trace[4][ns + p];
       rc = orc_stark_prove_lookup(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t], exposed, ns);
       free(exposed);
+    } else if (t == 6 && lookup_bm) { /* the memory table exposes the operations the byte-packing rows name */
+      const size_t np = (size_t)1 << tcfg[1].log_n, nm = (size_t)1 << tcfg[6].log_n;
+      uint8_t* exposed = (uint8_t*)calloc(nm, 1);
+      for (size_t r = 0; r < np; r++) {
+        int moves = 0;
+        for (int j = 0; j < 32; j++) moves |= trace[1][(size_t)(1 + j) * np + r] != 0;
+        if (!moves) continue;
+        const gl_t a = trace[1][297 * np + r], ts = trace[1][298 * np + r];
+        for (size_t i = 0; i < nm; i++)
+          if (trace[6][1 * nm + i] == a && trace[6][2 * nm + i] == ts) { exposed[i] = 1; break; }
+      }
+      rc = orc_stark_prove_lookup(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t], exposed, nm);
+      free(exposed);
     } else {
       rc = orc_stark_prove(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t]);
     }
@@ -344,6 +377,12 @@ int orc_pg_check_lookups(const orc_stark_cfg tcfg[NUM_TABLES], const gl_t* const
     const gl_t* looked = proofs[3] + open_first_offset(&tcfg[3]);  /* ... and columns 3, 4 here */
     for (int c = 0; c < 2; c++)
       if (looking[2 * c] != looked[2 * (3 + c)] || looking[2 * c + 1] != looked[2 * (3 + c) + 1]) return -11;
+  }
+  if (tcfg[1].air_id == ORC_AIR_BYTE_PACKING && tcfg[6].air_id == ORC_AIR_MEMORY) {
+    const gl_t* looking = proofs[1] + open_first_offset(&tcfg[1]); /* z_0, z_1 are its aux columns 0, 1 */
+    const gl_t* looked = proofs[6] + open_first_offset(&tcfg[6]);  /* ... and columns 1, 2 here (column 0 is the filter) */
+    for (int c = 0; c < 2; c++)
+      if (looking[2 * c] != looked[2 * (1 + c)] || looking[2 * c + 1] != looked[2 * (1 + c) + 1]) return -12;
   }
   return 0;
 }

@@ -249,7 +249,7 @@ KECCAK_COLS = 2430
 LOGIC_COLS = 523
 MEMORY_COLS = 44
 ARITHMETIC_COLS = 309
-BYTE_PACKING_COLS = 297
+BYTE_PACKING_COLS = 299
 KECCAK_SPONGE_COLS = 2414
 ARITHMETIC_MUL_COLS = 1217
 
@@ -336,7 +336,7 @@ def arithmetic_trace(log_n, seed=0, inputs=None):
 
 
 def byte_packing_trace(log_n, seed=0, inputs=None):
-    """orc_byte_packing_trace: the AIR-5 witness [297, 2^log_n]; inputs [2^log_n, 6] (is_read, len, the 32 byte slots as
+    """orc_byte_packing_trace: the AIR-5 witness [299, 2^log_n]; inputs [2^log_n, 6] (is_read, len, the 32 byte slots as
     four u64) or seeded."""
     out = np.zeros((BYTE_PACKING_COLS, 1 << log_n), dtype=np.uint64)
     inp = np.ascontiguousarray(inputs, dtype=np.uint64) if inputs is not None else None

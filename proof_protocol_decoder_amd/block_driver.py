@@ -248,7 +248,7 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
     keccak_air: every transaction's Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1; the table's width
     becomes 2430).  logic_air / memory_air: likewise the logic table (index 5) with the logic AIR (AIR 2; width 523) and
     the memory table (index 6) with the memory AIR (AIR 3; width 44); arithmetic_air: the arithmetic table (index 0)
-    with the arithmetic AIR (AIR 4; width 309); byte_packing_air: the byte-packing table (index 1) with AIR 5 (width 297);
+    with the arithmetic AIR (AIR 4; width 309); byte_packing_air: the byte-packing table (index 1) with AIR 5 (width 299);
     keccak_sponge_air: the Keccak sponge table (index 4) with AIR 6 (width 2414)."""
     if keccak_air:
         table_width = tuple(2430 if t == 3 else w for t, w in enumerate(table_width))
@@ -259,7 +259,7 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
     if arithmetic_air:
         table_width = tuple(309 if t == 0 else w for t, w in enumerate(table_width))
     if byte_packing_air:
-        table_width = tuple(297 if t == 1 else w for t, w in enumerate(table_width))
+        table_width = tuple(299 if t == 1 else w for t, w in enumerate(table_width))
     if keccak_sponge_air:
         table_width = tuple(2414 if t == 4 else w for t, w in enumerate(table_width))
     import ctypes as C
@@ -376,21 +376,26 @@ def hashed_preimages_of_generation_inputs(g, trie_nodes=False):
 
 
 def memory_and_byte_packing_work_of_preimages(preimages):
-    """What moving those byte strings to the hasher looks like in a zkEVM, as witness data for the memory table (AIR 3)
-    and the byte-packing table (AIR 5): every byte lives at its own address (the strings laid end to end), is written
-    once and read once -- the log is returned sorted by (address, timestamp), [is_read, address, timestamp, value limbs]
-    -- and the hasher takes them 32 at a time: one byte-packing sequence [is_read = 1, len, four words of byte slots]
-    per chunk (the last chunk of a string may be shorter)."""
+    """What moving those byte strings to the hasher looks like in a zkEVM, as witness data for the byte-packing table
+    (AIR 5) and the memory table (AIR 3), tied by the lookup byte_packing -> memory (AIRS.md section 3): the hasher
+    takes the bytes 32 at a time -- one byte-packing sequence per chunk (the last chunk of a string may be shorter):
+    [is_read = 1 | timestamp << 8, len | address << 8, four words of byte slots] -- and the 256-bit word a chunk spells
+    lives at its own address (the chunks numbered through the strings), written once and read once by the packer: the
+    memory log [is_read, address, timestamp, eight 32-bit value limbs], sorted by (address, timestamp).  The read is the
+    operation the packing row names."""
     log, seqs, addr = [], [], 0
     for m in preimages:
-        for b in m:
-            log.append([0, addr, 2 * addr + 1, b, 0, 0, 0, 0, 0, 0, 0])      # the byte is stored ...
-            log.append([1, addr, 2 * addr + 2, b, 0, 0, 0, 0, 0, 0, 0])      # ... and read back by the packer
-            addr += 1
         for off in range(0, len(m), 32):
             chunk = m[off:off + 32]
+            word = int.from_bytes(chunk, "big")
+            limbs = [(word >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+            ts = addr + 2
+            log.append([0, addr, 1] + limbs)       # the word is stored ...
+            log.append([1, addr, ts] + limbs)      # ... and read back by the packer
             padded = chunk + bytes(32 - len(chunk))
-            seqs.append([1, len(chunk)] + [int.from_bytes(padded[8 * w:8 * w + 8], "little") for w in range(4)])
+            seqs.append([1 | (ts << 8), len(chunk) | (addr << 8)]
+                        + [int.from_bytes(padded[8 * w:8 * w + 8], "little") for w in range(4)])
+            addr += 1
     return log, seqs
 
 
@@ -430,7 +435,7 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     if memory_air:
         table_width = tuple(44 if t == 6 else w for t, w in enumerate(table_width))
     if byte_packing_air:
-        table_width = tuple(297 if t == 1 else w for t, w in enumerate(table_width))
+        table_width = tuple(299 if t == 1 else w for t, w in enumerate(table_width))
     base_log_n = tuple(table_log_n)
     for k, g in enumerate(gen_inputs):
         kw = {}

@@ -32,7 +32,7 @@
 //                      degree 2; the additive part of the zkEVM's arithmetic table (prover_state.rs:85-93
 //                      "arithmetic"), its own layout [UPSTREAM-UNVERIFIED].
 // AIR 5  byte_packing  a big-endian sequence of up to 32 bytes <-> one 256-bit word per row (the zkEVM's byte-packing
-//                      table, prover_state.rs:85-93 "byte_packing"), 297 columns, degree 2; its own layout
+//                      table, prover_state.rs:85-93 "byte_packing"), 299 columns, degree 2; its own layout
 //                      [UPSTREAM-UNVERIFIED].
 // AIR 6  keccak_sponge the absorbing side of Keccak-256: one 136-byte block per row, XORed into the rate, chained from
 //                      row to row, pad10*1 on a message's last block (the zkEVM's Keccak sponge table,
@@ -617,6 +617,8 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 //   1 .. 32      length flags: column j is 1 when len = j
 //   33 .. 288    the bits of the 32 byte slots: 33 + 8 i + b  (slot i = the i-th byte of the sequence)
 //   289 .. 296   value limbs
+//   297, 298     address, timestamp of the memory operation that moves the word (free columns of the AIR; the lookup
+//                byte_packing -> memory, namespace ctl, sends (is_read, address, timestamp, value limbs) to the memory table)
 // Constraints (all rows):
 //   P0  0          is_read is a bit                         P1  1 .. 32    length flags are bits           deg 2
 //   P2  33         at most one length flag                  P3  34 .. 289  slot bits are bits              deg 2
@@ -624,8 +626,8 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 //   P5  322 .. 329 value limb k = sum_j flag_j sum_{i < j, 4k <= j-1-i < 4k+4} byte_i 256^(j-1-i-4k)       deg 2
 // Units: unit 0 = P0 .. P2; units 1 .. 8 = slots 4(u-1) .. 4(u-1)+3 (P3, P4) and value limb u - 1 (P5).
 namespace byte_packing {
-constexpr uint32_t N_COLS = 297, N_CONSTRAINTS = 330, N_UNITS = 9;
-constexpr uint32_t COL_READ = 0, COL_LEN = 1, COL_BITS = 33, COL_VAL = 289;
+constexpr uint32_t N_COLS = 299, N_CONSTRAINTS = 330, N_UNITS = 9;
+constexpr uint32_t COL_READ = 0, COL_LEN = 1, COL_BITS = 33, COL_VAL = 289, COL_ADDR = 297, COL_TS = 298;
 constexpr uint32_t P0 = 0, P1 = 1, P2 = 33, P3 = 34, P4 = 290, P5 = 322;
 // byte slot i from its bits (Horner)
 template <class T, class Row>
@@ -1015,13 +1017,21 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
 //                    exposing a subset is sound because every row of the table is a valid permutation by the AIR.
 // AIR 6  keccak_sponge  2 columns: z_0 z_1.  LOOKING side of the same lookup: filter is_full + is_final (every row
 //                    that absorbs a block), tuple = (xored rate limbs, capacity limbs | updated state limbs).
-// AIR 2, 3, 4, 5, 7  1 column: no lookup is built for these tables (upstream's go through the CPU table, which needs
-//                    the EVM interpreter, and through memory addresses these layouts do not carry): a constant running
-//                    product z = 1 keeps the oracle set of every table the same.
+// AIR 5  byte_packing  2 columns: z_0 z_1.  LOOKING side of "byte_packing -> memory": filter = the row has a length,
+//                    tuple = (is_read, address, timestamp, the eight value limbs): the word the sequence spells is ONE
+//                    operation of the memory table, whose rows hold 256-bit values.  (Upstream looks every BYTE of the
+//                    sequence up, at consecutive addresses; here the word is the unit, as in this memory table.)
+// AIR 3  memory      3 columns: g | z_0 z_1.  LOOKED side: g is the filter, which operations the table exposes
+//                    (g (g - 1) = 0); tuple = (is_read, address, timestamp, value limbs) of the row.
+// AIR 2, 4, 7        1 column: no lookup is built for these tables (upstream's go through the CPU table, which needs
+//                    the EVM interpreter): a constant running product z = 1 keeps the oracle set of every table the same.
 namespace ctl {
 constexpr uint32_t KECCAK_G = 0, KECCAK_H = 1, KECCAK_Z = 3, KECCAK_N_AUX = 5, KECCAK_N_CONSTRAINTS = 10;
 constexpr uint32_t SPONGE_Z = 0, SPONGE_N_AUX = 2, SPONGE_N_CONSTRAINTS = 4;
 constexpr uint32_t TUPLE_LIMBS = 50;  // a Keccak state as 32-bit limbs
+constexpr uint32_t PACK_Z = 0, PACK_N_AUX = 2, PACK_N_CONSTRAINTS = 4;
+constexpr uint32_t MEM_G = 0, MEM_Z = 1, MEM_N_AUX = 3, MEM_N_CONSTRAINTS = 5;
+constexpr uint32_t WORD_TUPLE = 11;  // is_read, address, timestamp, eight value limbs
 // AIR 8 (plonk): per challenge set c, column 10 c = Z_c and 10 c + k = the k-th partial product, k = 1..9
 constexpr uint32_t PLONK_N_AUX = 20, PLONK_N_CONSTRAINTS = 22, PLONK_CHUNK = 8, PLONK_CHUNKS = 10;
 
@@ -1029,6 +1039,8 @@ GL_HD uint32_t n_aux(const Shape& s) {
   return s.air_id == SYNTHETIC ? s.n_cols / 8
          : s.air_id == KECCAK_F ? KECCAK_N_AUX
          : s.air_id == KECCAK_SPONGE ? SPONGE_N_AUX
+         : s.air_id == BYTE_PACKING ? PACK_N_AUX
+         : s.air_id == MEMORY ? MEM_N_AUX
          : s.air_id == PLONK ? PLONK_N_AUX
                              : 1;
 }
@@ -1036,12 +1048,14 @@ GL_HD uint32_t n_constraints(const Shape& s) {
   return s.air_id == SYNTHETIC ? 2 * (s.n_cols / 8)
          : s.air_id == KECCAK_F ? KECCAK_N_CONSTRAINTS
          : s.air_id == KECCAK_SPONGE ? SPONGE_N_CONSTRAINTS
+         : s.air_id == BYTE_PACKING ? PACK_N_CONSTRAINTS
+         : s.air_id == MEMORY ? MEM_N_CONSTRAINTS
          : s.air_id == PLONK ? PLONK_N_CONSTRAINTS
                                      : 2;
 }
 // the first aux column that is a running product (the columns before it are helpers); products run to the last column
 // (AIR 8 keeps its two running products, columns 0 and 10, in its own kernels: stark_kernels.hip)
-GL_HD uint32_t first_product(uint32_t air_id) { return air_id == KECCAK_F ? KECCAK_Z : 0; }
+GL_HD uint32_t first_product(uint32_t air_id) { return air_id == KECCAK_F ? KECCAK_Z : air_id == MEMORY ? MEM_Z : 0; }
 
 // sum_{j < n} beta^j col(j) by Horner from the top
 template <class T, class Col>
@@ -1081,6 +1095,31 @@ GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const 
     }, 2 * TUPLE_LIMBS, beta);
     const T f = F::add(row.loc(keccak_sponge::COL_FULL), row.loc(keccak_sponge::COL_FINAL));
     return F::add(F::k(1), F::mul(f, F::sub(F::add(gamma, v), F::k(1))));
+  }
+  if (s.air_id == BYTE_PACKING) {
+    const uint32_t c = col - PACK_Z;
+    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
+    const T v = compress<T>([&](uint32_t j) {
+      return j == 0 ? row.loc(byte_packing::COL_READ)
+             : j == 1 ? row.loc(byte_packing::COL_ADDR)
+             : j == 2 ? row.loc(byte_packing::COL_TS)
+                      : row.loc(byte_packing::COL_VAL + j - 3);
+    }, WORD_TUPLE, beta);
+    T f = F::k(0);  // the row has a length: it moves a word
+#pragma unroll 1
+    for (uint32_t j = 0; j < 32; j++) f = F::add(f, row.loc(byte_packing::COL_LEN + j));
+    return F::add(F::k(1), F::mul(f, F::sub(F::add(gamma, v), F::k(1))));
+  }
+  if (s.air_id == MEMORY) {
+    const uint32_t c = col - MEM_Z;
+    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
+    const T v = compress<T>([&](uint32_t j) {
+      return j == 0 ? row.loc(memory::COL_READ)
+             : j == 1 ? row.loc(memory::COL_ADDR)
+             : j == 2 ? row.loc(memory::COL_TS)
+                      : row.loc(memory::COL_VAL + j - 3);
+    }, WORD_TUPLE, beta);
+    return F::add(F::k(1), F::mul(row.aux(MEM_G), F::sub(F::add(gamma, v), F::k(1))));
   }
   return F::k(1);
 }
@@ -1180,6 +1219,10 @@ GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const u
       out.transition(idx++, F::mul(F::sub(F::k(1), s23), F::sub(row.aux_nxt(KECCAK_H + c), h)));
     }
   }
+  if (s.air_id == MEMORY) {
+    const T g = row.aux(MEM_G);
+    out.all(idx++, F::sub(F::mul(g, g), g));
+  }
   const uint32_t p0 = first_product(s.air_id), p1 = n_aux(s);
 #pragma unroll 1
   for (uint32_t k = p0; k < p1; k++) {
@@ -1196,10 +1239,11 @@ struct Pair {
   uint32_t looking_table, looking_air, looking_col;  // aux column of challenge set 0; set c is column + c
   uint32_t looked_table, looked_air, looked_col;
 };
-constexpr uint32_t N_PAIRS = 1;
+constexpr uint32_t N_PAIRS = 2;
 inline const Pair* pairs() {
   static const Pair P[N_PAIRS] = {
       {"keccak_sponge -> keccak_f", 4, KECCAK_SPONGE, SPONGE_Z, 3, KECCAK_F, KECCAK_Z},
+      {"byte_packing -> memory", 1, BYTE_PACKING, PACK_Z, 6, MEMORY, MEM_Z},
   };
   return P;
 }

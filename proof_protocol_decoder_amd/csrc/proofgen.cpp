@@ -544,7 +544,7 @@ static int parse_ir(const bp_state* s, const uint64_t* I, const TxnWitness* wit,
   // 0x200 = the logic table (index 5) is proven with the logic AIR (AIR 2): 523 columns, operations drawn from the seed;
   // 0x400 = the memory table (index 6) with the memory AIR (AIR 3): 44 columns, a sorted log drawn from the seed;
   // 0x800 = the arithmetic table (index 0) with the arithmetic AIR (AIR 4): 309 columns;
-  // 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (AIR 5): 297 columns;
+  // 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (AIR 5): 299 columns;
   // 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6): 2414 columns
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
   if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 63) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
@@ -624,6 +624,12 @@ static int prove_tables(Worker& w, const uint64_t* I, const TxnWitness* wit, Tab
   // ones the sponge rows ask for (air::ctl, keccak_sponge -> keccak_f).  Tables given by the caller are taken as they are.
   const bool lookup_kf = tcfg[3].air_id == air::KECCAK_F && tcfg[4].air_id == air::KECCAK_SPONGE;
   const uint32_t sponge_row_limit = lookup_kf ? (uint32_t)(((uint64_t)1 << tcfg[3].log_n) / 24) : ~0u;
+  // byte_packing -> memory: the memory table that is not given by the caller is the log of the byte-packing table's
+  // words (two operations per packing row); it must be tall enough to hold them
+  const bool lookup_bm = tcfg[1].air_id == air::BYTE_PACKING && tcfg[6].air_id == air::MEMORY;
+  if (lookup_bm && !given(6) && tcfg[6].log_n < tcfg[1].log_n + 1)
+    return fail(BP_ERR_INVALID_INPUT, "the memory table (2^%u rows) cannot hold the operations of the byte-packing table (2^%u rows): "
+                "two per row", tcfg[6].log_n, tcfg[1].log_n);
   static const int GEN_ORDER[BP_NUM_TABLES] = {4, 0, 1, 2, 3, 5, 6};  // the sponge table before the Keccak-f table that reads it
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     const uint64_t N = (uint64_t)1 << tcfg[t].log_n;
@@ -648,6 +654,10 @@ static int prove_tables(Worker& w, const uint64_t* I, const TxnWitness* wit, Tab
       d_in = w.arena.alloc_words((size_t)n_perms * 25);
       if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the Keccak-f table's inputs");
       if ((r = launch_keccak_inputs_from_sponge(d_trace[4], tcfg[4].log_n, d_in, n_perms, seed, w.stream))) return r;
+    } else if (t == 6 && lookup_bm) {
+      d_in = w.arena.alloc_words((size_t)N * 11);
+      if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the memory table's log");
+      if ((r = launch_memory_inputs_from_byte_packing(d_trace[1], tcfg[1].log_n, d_in, (uint32_t)N, w.stream))) return r;
     }
     switch (tcfg[t].air_id) {
       case air::KECCAK_F: r = launch_keccak_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
@@ -684,6 +694,10 @@ static int prove_tables(Worker& w, const uint64_t* I, const TxnWitness* wit, Tab
       hint.flag_a = d_trace[4] + (size_t)air::keccak_sponge::COL_FULL * N4;
       hint.flag_b = d_trace[4] + (size_t)air::keccak_sponge::COL_FINAL * N4;
       hint.n_flags = (uint32_t)N4;
+    }
+    if (t == 6 && lookup_bm) {  // the operations the byte-packing table looks up: its trace (address, timestamp per row)
+      hint.flag_a = d_trace[1];
+      hint.n_flags = (uint32_t)1 << tcfg[1].log_n;
     }
     if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, tp->proof[t], &hint))) return r;
     if (given(t)) {

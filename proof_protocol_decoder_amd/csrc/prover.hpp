@@ -132,7 +132,9 @@ int commit_batch(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t batc
 // drawn ctl (plonky2_evm prover order).  Fills `proof` (proof_layout(cfg).total words).
 // hint (nullable): what the prover of a LOOKED table needs to know about its looking tables (air::ctl) -- for the
 // Keccak-f table, which permutations the sponge table asks for: permutation p when flag_a[p] + flag_b[p] != 0 (the two
-// flag columns of the sponge table's trace on the device).  Without a hint the table exposes nothing.
+// flag columns of the sponge table's trace on the device); for the memory table, which operations the byte-packing
+// table looks up: flag_a = that table's trace on the device (its address and timestamp columns name the operation),
+// n_flags = its rows.  Without a hint the table exposes nothing.
 struct LookupHint {
   const uint64_t *flag_a = nullptr, *flag_b = nullptr;
   uint32_t n_flags = 0;

@@ -278,6 +278,7 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
         fam(i, 1, 0, 2); fam(i + 1, 1, 1, 2); i += 2;
       }
     }
+    if (air_id == air::MEMORY) { fam(i, 1, 0, 2); i += 1; }  // the filter g of byte_packing -> memory: a bit
     for (uint32_t k = air::ctl::first_product(air_id); k < out->n_aux; k++) {  // filtered running products
       fam(i, 1, 1, 3); fam(i + 1, 1, 3, 2); i += 2;
     }

@@ -252,10 +252,12 @@ arithmetic_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ i
 }
 
 // ---------------------------------------------------------------- byte-packing witness (AIR 5, air.hpp)
-// One sequence per row.  `inputs` ([row][6]: is_read, len (0 = a padding row, else 1..32; larger values: 32), then the
-// 32 byte slots as four 64-bit words, slot i = byte i % 8 of word i / 8; slots at or beyond len are ignored) or, when
-// null, drawn from the seed like the oracle: is_read = h(0xC0) & 1, len = h(0xC1) % 33, word w = h(0xC2 + w),
-// h(c) = splitmix64(seed ^ (c << 32) ^ row).
+// One sequence per row.  `inputs` ([row][6]: word 0 = is_read (bit 0) | timestamp << 8, word 1 = len (low byte: 0 = a
+// padding row, else 1..32; larger values: 32) | address << 8 -- address and timestamp (32 bits each) of the memory
+// operation that moves the word, zero for callers that do not care --, then the 32 byte slots as four 64-bit words,
+// slot i = byte i % 8 of word i / 8; slots at or beyond len are ignored) or, when null, drawn from the seed like the
+// oracle: is_read = h(0xC0) & 1, len = h(0xC1) % 33, word w = h(0xC2 + w), h(c) = splitmix64(seed ^ (c << 32) ^ row),
+// address = row, timestamp = 2 + row.
 __global__ void __launch_bounds__(256)
 byte_packing_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs, uint32_t log_n, uint64_t seed) {
   if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
@@ -264,9 +266,11 @@ byte_packing_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   auto h = [&](uint64_t c) { return splitmix64(seed ^ (c << 32) ^ i); };
-  const uint64_t rd = (inputs ? inputs[(uint64_t)i * 6] : h(0xC0)) & 1;
-  uint64_t len = inputs ? inputs[(uint64_t)i * 6 + 1] : h(0xC1) % 33;
+  const uint64_t w0 = inputs ? inputs[(uint64_t)i * 6] : 0, w1 = inputs ? inputs[(uint64_t)i * 6 + 1] : 0;
+  const uint64_t rd = (inputs ? w0 : h(0xC0)) & 1;
+  uint64_t len = inputs ? (w1 & 0xFF) : h(0xC1) % 33;
   if (len > 32) len = 32;
+  const uint64_t addr = inputs ? (w1 >> 8) & 0xFFFFFFFFull : i, ts = inputs ? (w0 >> 8) & 0xFFFFFFFFull : 2ull + i;
   uint64_t w[4];
   for (uint32_t k = 0; k < 4; k++) w[k] = inputs ? inputs[(uint64_t)i * 6 + 2 + k] : h(0xC2 + k);
   auto put = [&](uint32_t col, uint64_t v) { t[(uint64_t)col * n + i] = v; };
@@ -282,6 +286,27 @@ byte_packing_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__
     }
   }
   for (uint32_t k = 0; k < 8; k++) put(bp::COL_VAL + k, limb[k]);
+  put(bp::COL_ADDR, addr);
+  put(bp::COL_TS, ts);
+}
+// The memory log that goes with a byte-packing table (lookup byte_packing -> memory, air::ctl), as input for
+// memory_trace_kernel: packing row r is two operations on its address, the write that put the word there (timestamp 1)
+// and the operation the row looks up -- (is_read, address, timestamp, word) --; the rows of the memory table beyond
+// those re-read the last address.  Addresses must ascend with the packing rows (seeded tables: address = row).
+__global__ void __launch_bounds__(256)
+memory_inputs_from_byte_packing_kernel(const uint64_t* __restrict__ pack, uint32_t pack_log_n, uint64_t* __restrict__ log,
+                                       uint32_t n_mem) {
+  namespace bp = bpg::air::byte_packing;
+  const uint32_t P = 1u << pack_log_n, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_mem) return;
+  const uint32_t r = (i >> 1) < P ? (i >> 1) : P - 1;
+  const bool pad = (i >> 1) >= P, second = pad || (i & 1);
+  uint64_t* o = log + (uint64_t)i * 11;
+  const uint64_t ts = pack[(uint64_t)bp::COL_TS * P + r];
+  o[0] = pad ? 1 : (second ? pack[(uint64_t)bp::COL_READ * P + r] : 0);
+  o[1] = pack[(uint64_t)bp::COL_ADDR * P + r];
+  o[2] = pad ? ts + (i - 2 * P + 1) : (second ? ts : 1);
+  for (uint32_t k = 0; k < 8; k++) o[3 + k] = pack[(uint64_t)(bp::COL_VAL + k) * P + r];
 }
 
 // ---------------------------------------------------------------- Keccak sponge witness (AIR 6, air.hpp)
@@ -512,6 +537,34 @@ keccak_ctl_helpers_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
     for (uint32_t j = ct::TUPLE_LIMBS - 1; j-- > 0;) acc = gl::addc(gl::mulc(acc, beta), a.trace[(uint64_t)(kk::COL_A + j) * n + first]);
     a.aux[(uint64_t)(ct::KECCAK_H + c) * n + i] = acc;
   }
+}
+
+// The filter column of the memory table's lookup (air::ctl): g = 1 on the operations the byte-packing table looks up.
+// A lane owns a packing row that moves a word and finds its operation -- (address, timestamp) -- in the memory trace,
+// which is sorted by (address, timestamp), by bisection.  flag_a = the packing table's trace, n_flags = its rows.
+__global__ void __launch_bounds__(256) memory_ctl_clear_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
+  const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) batch.a[blockIdx.z].aux[(uint64_t)bpg::air::ctl::MEM_G * n + i] = 0;
+}
+__global__ void __launch_bounds__(256) memory_ctl_flags_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
+  namespace bp = bpg::air::byte_packing;
+  namespace mm = bpg::air::memory;
+  const bpg::AuxArgs& a = batch.a[blockIdx.z];
+  const uint32_t n = 1u << log_n, P = a.n_flags, r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (!a.flag_a || r >= P) return;
+  const uint64_t* pack = a.flag_a;
+  uint64_t has = 0;
+  for (uint32_t j = 0; j < 32; j++) has += pack[(uint64_t)(bp::COL_LEN + j) * P + r];
+  if (!has) return;
+  const uint64_t addr = pack[(uint64_t)bp::COL_ADDR * P + r], ts = pack[(uint64_t)bp::COL_TS * P + r];
+  const uint64_t *ma = a.trace + (uint64_t)mm::COL_ADDR * n, *mt = a.trace + (uint64_t)mm::COL_TS * n;
+  uint32_t lo = 0, hi = n;  // first row with (address, timestamp) >= (addr, ts)
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    const uint64_t x = ma[mid], y = mt[mid];
+    if (x < addr || (x == addr && y < ts)) lo = mid + 1; else hi = mid;
+  }
+  if (lo < n && ma[lo] == addr && mt[lo] == ts) a.aux[(uint64_t)bpg::air::ctl::MEM_G * n + lo] = 1;
 }
 
 // ---------------------------------------------------------------- AIR 8 (plonk, air.hpp): constants, witness, copy products
@@ -1367,6 +1420,12 @@ int launch_keccak_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sp
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_memory_inputs_from_byte_packing(const uint64_t* d_pack_trace, uint32_t pack_log_n, uint64_t* d_log, uint32_t n_mem,
+                                           hipStream_t st) {
+  memory_inputs_from_byte_packing_kernel<<<ceil_div(n_mem, 256), 256, 0, st>>>(d_pack_trace, pack_log_n, d_log, n_mem);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
   arithmetic_mul_trace_kernel<<<ceil_div((uint64_t)1 << log_n, 256), 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
   BPG_LAUNCH_CHECK();
@@ -1395,6 +1454,16 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
     keccak_ctl_helpers_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), 1, batch), 256, 0, st>>>(ab, log_n);
     BPG_LAUNCH_CHECK();
   }
+  if (air_id == air::MEMORY) {  // the filter column: which operations the byte-packing table looks up
+    uint32_t rows = 0;
+    for (uint32_t b = 0; b < batch; b++) rows = std::max(rows, a[b].flag_a ? a[b].n_flags : 0u);
+    memory_ctl_clear_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), 1, batch), 256, 0, st>>>(ab, log_n);
+    BPG_LAUNCH_CHECK();
+    if (rows) {
+      memory_ctl_flags_kernel<<<dim3(ceil_div(rows, 256), 1, batch), 256, 0, st>>>(ab, log_n);
+      BPG_LAUNCH_CHECK();
+    }
+  }
   uint32_t threads = (1u << log_n) < 1024 ? (1u << log_n) : 1024;
   if (threads < 64) threads = 64;
   if (air_id == air::PLONK) {  // chunk ratios per row, suffix products of the row totals, partial products
@@ -1414,12 +1483,15 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
   const dim3 grid(n_aux - p0, 1, batch);
   // algorithmic bytes: every column a product reads, once, and the product column written (SURVEY.md section 8(d):
   // 24 n per column of a synthetic table)
-  const double reads = air_id == air::SYNTHETIC ? 2 : air_id == air::KECCAK_F ? 52 : air_id == air::KECCAK_SPONGE ? 102 : 0;
+  const double reads = air_id == air::SYNTHETIC ? 2 : air_id == air::KECCAK_F ? 52 : air_id == air::KECCAK_SPONGE ? 102
+                       : air_id == air::BYTE_PACKING ? 43 : air_id == air::MEMORY ? 12 : 0;
   KernelTimer kt(PROF_AUX, st, 8.0 * (double)((uint64_t)1 << log_n) * (reads + 1) * (n_aux - p0) * batch);
   switch (air_id) {
     case air::SYNTHETIC: aux_suffix_product_kernel<air::SYNTHETIC><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
     case air::KECCAK_F: aux_suffix_product_kernel<air::KECCAK_F><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
     case air::KECCAK_SPONGE: aux_suffix_product_kernel<air::KECCAK_SPONGE><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
+    case air::BYTE_PACKING: aux_suffix_product_kernel<air::BYTE_PACKING><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
+    case air::MEMORY: aux_suffix_product_kernel<air::MEMORY><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
     default: aux_suffix_product_kernel<air::LOGIC><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;  // no lookup: z = 1
   }
   BPG_LAUNCH_CHECK();

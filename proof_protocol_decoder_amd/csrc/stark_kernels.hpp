@@ -179,6 +179,9 @@ int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint
 // [n_perms][25] input lanes for a seeded Keccak-f table whose sponge table (trace on the device) is real
 int launch_keccak_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sponge_log_n, uint64_t* d_inputs, uint32_t n_perms,
                                      uint64_t seed, hipStream_t st);
+// the memory log ([n_mem][11], for launch_memory_trace) that goes with a byte-packing trace: two operations per packing row
+int launch_memory_inputs_from_byte_packing(const uint64_t* d_pack_trace, uint32_t pack_log_n, uint64_t* d_log, uint32_t n_mem,
+                                           hipStream_t st);
 int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_cols, uint32_t log_n, hipStream_t st);
 // AIR 8 (plonk): the constants (selectors, gate constants, sigmas of the fixed circuit) and the witness

@@ -77,7 +77,7 @@ KECCAK_COLS = 2430
 LOGIC_COLS = 523
 MEMORY_COLS = 44
 ARITHMETIC_COLS = 309
-BYTE_PACKING_COLS = 297
+BYTE_PACKING_COLS = 299
 KECCAK_SPONGE_COLS = 2414
 ARITHMETIC_MUL_COLS = 1217
 
@@ -124,7 +124,7 @@ def arithmetic_trace(log_n, seed=0, inputs=None, device="cuda"):
 
 
 def byte_packing_trace(log_n, seed=0, inputs=None, device="cuda"):
-    """bp_byte_packing_trace: the AIR-5 witness [297, 2^log_n]; inputs [2^log_n, 6] int64 on the device (is_read, len,
+    """bp_byte_packing_trace: the AIR-5 witness [299, 2^log_n]; inputs [2^log_n, 6] int64 on the device (is_read, len,
     the 32 byte slots as four words), or drawn from `seed`."""
     out = torch.empty((BYTE_PACKING_COLS, 1 << log_n), dtype=torch.int64, device=device)
     if inputs is not None:

@@ -133,7 +133,7 @@ class TxnProofGenIR:
     logic_air: bool = False    # the logic table (index 5) is proven with the logic AIR (AIR 2, 523 columns)
     memory_air: bool = False   # the memory table (index 6) with the memory AIR (AIR 3, 44 columns)
     arithmetic_air: bool = False   # the arithmetic table (index 0) with the arithmetic AIR (AIR 4, 309 columns)
-    byte_packing_air: bool = False   # the byte-packing table (index 1) with the byte-packing AIR (AIR 5, 297 columns)
+    byte_packing_air: bool = False   # the byte-packing table (index 1) with the byte-packing AIR (AIR 5, 299 columns)
     keccak_sponge_air: bool = False  # the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6, 2414 columns)
     witness: tuple = None   # ((table index, ((words of an item), ...)), ...): data for tables with an AIR instead of a
                             # seeded witness (bp_generate_txn_proof_witness); like keccak_inputs not part of the 25-word IR

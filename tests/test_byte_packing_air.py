@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 P = 0xFFFFFFFF00000001
-COL_READ, COL_LEN, COL_BITS, COL_VAL, N_COLS = 0, 1, 33, 289, 297
+COL_READ, COL_LEN, COL_BITS, COL_VAL, N_COLS = 0, 1, 33, 289, 299
 
 
 def slots_of(t, r):
@@ -130,7 +130,7 @@ def test_air_registry_describes_the_byte_packing_air():
     L = pkg.lib()
     assert L.bp_air_count() == 9
     d = pkg.ops.air_describe(5)
-    assert d.name == b"byte_packing" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (297, 297, 1, 2)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (330, 2, 9)
+    assert d.name == b"byte_packing" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (299, 299, 2, 2)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (330, 4, 9)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:6]) == 330 and fams[5] == (322, 8, 0, 2)

@@ -553,8 +553,9 @@ def test_keccak_work_includes_the_hashing_of_the_partial_tries():
 
 def test_memory_and_byte_packing_work_of_a_decoded_transaction():
     """irs_from_generation_inputs(..., memory_air=True, byte_packing_air=True): the memory log and the byte-packing
-    sequences of an entry are the traffic of exactly the bytes its Keccak table hashes -- the log replays as a memory
-    whose reads return those bytes in order, the sequences spell the 32-byte chunks big-endian, and the oracle's
+    sequences of an entry are the traffic of exactly the bytes its Keccak table hashes -- the sequences spell the
+    32-byte chunks big-endian, the log replays as a memory whose reads return the words those chunks spell, each read
+    being the operation (address, timestamp) its sequence names (the lookup byte_packing -> memory), and the oracle's
     witnesses of both (padded to the table heights the IR asks for) satisfy what tests/test_memory_air.py and
     tests/test_byte_packing_air.py check (host only)."""
     import numpy as np
@@ -571,24 +572,28 @@ def test_memory_and_byte_packing_work_of_a_decoded_transaction():
                                      keccak_trie_nodes=True, memory_air=True, byte_packing_air=True)
     busy = 0
     for g, ir in zip(gis, irs):
-        assert ir.memory_air and ir.byte_packing_air and ir.table_width[6] == 44 and ir.table_width[1] == 297
+        assert ir.memory_air and ir.byte_packing_air and ir.table_width[6] == 44 and ir.table_width[1] == 299
         pre = hashed_preimages_of_generation_inputs(g, trie_nodes=True)
         blob = b"".join(pre)
         wit = dict(ir.witness)
         log, seqs = np.array(wit[6], dtype=np.uint64).reshape(-1, 11), np.array(wit[1], dtype=np.uint64).reshape(-1, 6)
-        assert len(log) == 2 * len(blob) <= (1 << ir.table_log_n[6]) and len(seqs) <= (1 << ir.table_log_n[1])
+        chunks = [p[o:o + 32] for p in pre for o in range(0, len(p), 32)]
+        assert len(log) == 2 * len(chunks) <= (1 << ir.table_log_n[6]) and len(seqs) <= (1 << ir.table_log_n[1])
         if not len(blob):
             continue
         busy += 1
-        # sorted by (address, timestamp); the reads, in address order, are the hashed bytes
+        # sorted by (address, timestamp); the reads, in address order, return the words the chunks spell
         keys = [(int(r[1]), int(r[2])) for r in log]
         assert keys == sorted(keys) and len(set(keys)) == len(keys)
-        assert bytes(int(r[3]) for r in log if r[0] == 1) == blob
-        # the sequences are the strings cut into 32-byte chunks
-        chunks = [p[o:o + 32] for p in pre for o in range(0, len(p), 32)]
+        words = [sum(int(r[3 + k]) << (32 * k) for k in range(8)) for r in log if r[0] == 1]
+        assert words == [int.from_bytes(c, "big") for c in chunks]
+        assert b"".join(w.to_bytes(len(c), "big") for w, c in zip(words, chunks)) == blob
+        # the sequences are the strings cut into 32-byte chunks, and each names its read: (is_read, address, timestamp)
         assert len(seqs) == len(chunks)
+        reads = {(int(r[1]), int(r[2])) for r in log if r[0] == 1}
         for s, c in zip(seqs, chunks):
-            assert int(s[0]) == 1 and int(s[1]) == len(c)
+            assert int(s[0]) & 1 == 1 and int(s[1]) & 0xFF == len(c)
+            assert (int(s[1]) >> 8, int(s[0]) >> 8) in reads
             assert b"".join(int(w).to_bytes(8, "little") for w in s[2:])[:len(c)] == c
         # the oracle's witnesses of the padded inputs are a memory / spell the chunks
         n_rows = 1 << ir.table_log_n[6]
@@ -606,4 +611,5 @@ def test_memory_and_byte_packing_work_of_a_decoded_transaction():
         t = pyoracle.byte_packing_trace(ir.table_log_n[1], inputs=bp)
         for r, c in enumerate(chunks):
             assert sum(int(t[289 + k, r]) << (32 * k) for k in range(8)) == int.from_bytes(c, "big")
+            assert (int(t[297, r]), int(t[298, r])) == (r, r + 2)
     assert busy >= 2

@@ -29,7 +29,7 @@ def test_quotient_eval_matches_oracle(bpg, oracle, log_n):
     rng = np.random.default_rng(1100 + log_n)
     rows = (1 << log_n) << 1
     trace = rand_field(rng, (44, rows))
-    aux = rand_field(rng, (1, rows))
+    aux = rand_field(rng, (3, rows))
     ctl, alphas = rand_field(rng, (4,)), rand_field(rng, (2,))
     want = oracle.quotient_values(oracle.make_cfg(log_n, 44, air_id=3), None, trace, aux, ctl, alphas[0], alphas[1])
     idx = coset_major_to_natural(log_n, 1)

@@ -405,8 +405,8 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
     """memory_air / byte_packing_air / keccak_sponge_air with keccak_air: four tables of a decoded entry hold data of the
     entry, not a seed -- the Keccak table the hashing of its signed transaction, code and partial tries, the Keccak
     sponge table the absorption of those strings block by block (its xored states are, row for row, the Keccak table's
-    permutation inputs), the memory table the log of those bytes (written once, read once), the byte-packing table the
-    same bytes taken 32 at a time (bp_generate_txn_proof_witness).  The device witnesses contain the bytes; proofs equal the oracle's byte for byte
+    permutation inputs), the byte-packing table those bytes taken 32 at a time, the memory table the log of the words
+    the chunks spell (written once, read once: the operations the packing rows look up; bp_generate_txn_proof_witness).  The device witnesses contain the bytes; proofs equal the oracle's byte for byte
     (orc_pg_txn_witness); the block verifies."""
     import test_decoding as td
     from proof_protocol_decoder_amd import decoding
@@ -431,7 +431,7 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
         pre = hashed_preimages_of_generation_inputs(g, trie_nodes=True)
         blob = b"".join(pre)
         wit = dict(ir.witness)
-        # the device's memory witness of the entry's log holds the hashed bytes (value limb 0 of the reads) ...
+        # the device's memory witness of the entry's log holds the hashed bytes (the words its reads return) ...
         import torch
         log_n = ir.table_log_n[6]
         log = np.array(wit[6], dtype=np.uint64).reshape(-1, 11)
@@ -443,8 +443,10 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
             last[2] += np.uint64(1)
             padded[i] = last
         tr = bpg.ops.memory_trace(log_n, inputs=torch.from_numpy(padded.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
-        reads = tr[0, :len(log)] == 1
-        assert bytes(int(x) for x in tr[3, :len(log)][reads]) == blob
+        chunks = [p[o:o + 32] for p in pre for o in range(0, len(p), 32)]
+        rd = [i for i in range(len(log)) if tr[0, i] == 1]
+        assert len(rd) == len(chunks)
+        assert b"".join(sum(int(tr[3 + k, i]) << (32 * k) for k in range(8)).to_bytes(len(c), "big") for i, c in zip(rd, chunks)) == blob
         # ... and the byte-packing witness spells the first chunk of the first string (the signed transaction)
         seqs = np.array(wit[1], dtype=np.uint64).reshape(-1, 6)
         bp = np.zeros((1 << ir.table_log_n[1], 6), dtype=np.uint64)
@@ -522,7 +524,7 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
     Keccak sponge (4), logic (5) and memory (6) tables of the transaction are proven with AIR 4, 5, 1, 6, 2 and 3; only
     the CPU table (2) stays synthetic.  Byte parity with the oracle; the block verifies."""
     width = list(WIDTH)
-    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 297, 2430, 2414, 523, 44
+    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2430, 2414, 523, 44
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
                            memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
     t0 = pg.generate_txn_proof(p_state, ir0)
@@ -543,7 +545,7 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), memory_air=True).to_bytes()
     with pytest.raises(pg.ProofGenError, match="309"):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), arithmetic_air=True).to_bytes()
-    with pytest.raises(pg.ProofGenError, match="297"):
+    with pytest.raises(pg.ProofGenError, match="299"):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), byte_packing_air=True).to_bytes()
     with pytest.raises(pg.ProofGenError, match="2414"):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), keccak_sponge_air=True).to_bytes()
@@ -555,7 +557,7 @@ def test_table_proofs_and_their_lookups_match_the_oracle(pg, p_state, o_state, o
     (csrc/air.hpp namespace ctl): bytes equal the oracle's (oracle/ctl.c states the lookup columns independently), both
     verifiers accept both provers' output, and the prover refuses tables that are valid alone but not one statement."""
     width = list(WIDTH)
-    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 297, 2430, 2414, 523, 44
+    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2430, 2414, 523, 44
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0C71, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
                            memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))

@@ -16,8 +16,8 @@ CASES = [  # name, air_id, columns, log_n (the S1 height of the table), in the c
     ("synthetic 128 cols (S1 arithmetic width)", 0, 128, 16, False),
     ("synthetic 2432 cols (S1 keccak width)", 0, 2432, 14, True),
     ("arithmetic (AIR 4)", 4, 309, 16, True),
-    ("byte packing (AIR 5)", 5, 297, 9, False),
-    ("byte packing (AIR 5) at 2^14", 5, 297, 14, True),
+    ("byte packing (AIR 5)", 5, 299, 9, False),
+    ("byte packing (AIR 5) at 2^14", 5, 299, 14, True),
     ("keccak_f (AIR 1)", 1, 2430, 14, True),
     ("logic (AIR 2)", 2, 523, 12, False),
     ("logic (AIR 2) at 2^16", 2, 523, 16, True),
