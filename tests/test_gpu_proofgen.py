@@ -529,7 +529,7 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
                            memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
     t0 = pg.generate_txn_proof(p_state, ir0)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))
-    assert iw[1] == 0x3F01 and iw[18 + 0] == 309 and iw[18 + 1] == 297 and iw[18 + 4] == 2414 and iw[18 + 5] == 523 and iw[18 + 6] == 44
+    assert iw[1] == 0x3F01 and iw[18 + 0] == 309 and iw[18 + 1] == 299 and iw[18 + 4] == 2414 and iw[18 + 5] == 523 and iw[18 + 6] == 44
     assert (words(t0.intern) == o_state.txn(iw)).all()
     only_logic = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), (*WIDTH[:5], 523, WIDTH[6]), logic_air=True)
     t_l = pg.generate_txn_proof(p_state, only_logic)
@@ -553,8 +553,8 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
 
 def test_table_proofs_and_their_lookups_match_the_oracle(pg, p_state, o_state, oracle):
     """bp_generate_txn_table_proofs = upstream's `prove` before the recursion (AllProof): the seven table proofs on one
-    transcript.  With six real tables the sponge table's rows look their permutations up in the Keccak-f table
-    (csrc/air.hpp namespace ctl): bytes equal the oracle's (oracle/ctl.c states the lookup columns independently), both
+    transcript.  With six real tables the sponge table's rows look their permutations up in the Keccak-f table and the
+    byte-packing table's words are operations of the memory table (csrc/air.hpp namespace ctl): bytes equal the oracle's (oracle/ctl.c states the lookup columns independently), both
     verifiers accept both provers' output, and the prover refuses tables that are valid alone but not one statement."""
     width = list(WIDTH)
     width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2430, 2414, 523, 44
@@ -597,6 +597,26 @@ def test_table_proofs_and_their_lookups_match_the_oracle(pg, p_state, o_state, o
         oracle.lib().orc_pg_set_prover_lookup_check(1)
     with pytest.raises(pg.ProofGenError, match="cross-table lookup"):
         pg.verify_txn_table_proofs(p_state.cfg, bad_tp.tobytes())
+    # the second lookup, byte_packing -> memory: in the six-table transaction above the packing rows' words are the
+    # operations the (seeded) memory table exposes ...
+    packing, memory = first_row_openings(oracle, words(got), 1), first_row_openings(oracle, words(got), 6)
+    assert (packing[0] == memory[1]).all() and (packing[1] == memory[2]).all() and tuple(packing[0]) != (1, 0)
+    # ... and with caller-given tables: the strings' chunks and the log of the words they spell
+    from proof_protocol_decoder_amd.block_driver import memory_and_byte_packing_work_of_preimages
+    log, seqs = memory_and_byte_packing_work_of_preimages([b"hello, memory", bytes(range(70)), b"x" * 32])
+    w3 = list(WIDTH)
+    w3[1], w3[6] = 299, 44
+    ir2 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0C73, tuple(LOG_N), tuple(w3), byte_packing_air=True, memory_air=True)
+    iw2 = list(struct.unpack("<25Q", ir2.to_bytes()))
+    got2 = pg.generate_txn_table_proofs(p_state, ir2, witness={1: seqs, 6: log})
+    assert (words(got2) == o_state.txn_tables(iw2, witness={1: seqs, 6: log})).all()
+    assert o_state.verify_tables(words(got2)) == 0
+    bad_seqs = [list(x) for x in seqs]
+    bad_seqs[1][2] ^= 0x40   # one byte of one chunk: still a sequence, still a memory -- of another word
+    for call in (pg.generate_txn_table_proofs, pg.generate_txn_proof):
+        with pytest.raises(pg.ProofGenError, match="cross-table lookup byte_packing -> memory does not hold") as e:
+            call(p_state, ir2, witness={1: bad_seqs, 6: log})
+        assert e.value.code == -5
 
 
 S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
