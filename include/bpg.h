@@ -216,6 +216,7 @@ struct bp_stark_cfg;
  * of the table's auxiliary columns, its cross-table lookups (csrc/air.hpp, namespace ctl): n_cols / 8 unfiltered running
  * products for the synthetic AIR (a load placeholder), filter + carried input + two filtered running products for
  * keccak_f (the looked side of keccak_sponge -> keccak_f), two filtered running products for keccak_sponge (the looking
+ * side), two for byte_packing (the looking side of byte_packing -> memory), a filter and two for memory (the looked
  * side), one constant product for the tables no lookup is built for. */
 typedef struct bp_air_family {
   uint32_t first_index, count;
@@ -432,7 +433,8 @@ int bp_generate_txn_proof_keccak(const bp_state* s, const uint8_t* ir, size_t ir
  * has_* field is non-zero (n may be 0: a table of padding only) and its IR flag is set (bp_ir_set_*_air).  Items beyond
  * n are padding: Keccak permutations of the all-zero state, rows without an operation, and for the memory log reads of
  * the last address at later and later times.  Layouts as for the bp_*_trace entry points: keccak_inputs [n][25],
- * logic_ops / arithmetic_ops [n][9], memory_log [n][11] sorted by (address, timestamp), byte_sequences [n][6].
+ * logic_ops / arithmetic_ops [n][9], memory_log [n][11] sorted by (address, timestamp), byte_sequences [n][6] (with the address and timestamp of the
+ * memory operation each names when the memory table is real too: bp_byte_packing_trace).
  * Given data is CHECKED: the prover does not validate a witness and nothing downstream verifies the table proofs (upstream's
  * root circuit would), so the table proof made from caller-given data is verified on the host before the call goes on;
  * data that does not satisfy the table's AIR (a log that is not a memory, sponge rows that do not chain, ...) returns
@@ -451,11 +453,11 @@ int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t i
  * table proofs of the transaction on their ONE transcript, with the public values and the lookup challenges -- the part of
  * bp_generate_txn_proof that the recursion-shaped proofs then digest.  data: nullable, as for
  * bp_generate_txn_proof_witness.  Bytes (little-endian u64 words): "BPGTABLS", 7, the 13 public values, the four lookup
- * challenges, then per table: air_id, log_n, n_cols, n_words and the table's STARK proof (DESIGN.md section 6).
+ * challenges, then per table: air_id, log_n, n_cols, n_words and the table's STARK proof (DESIGN.md section 4).
  * bp_verify_txn_table_proofs is upstream's verify_proof(all_stark, all_proof, config) on the CPU: every table proof against
  * the shared transcript AND the cross-table lookups between the tables that are proven with their AIRs (csrc/air.hpp,
- * namespace ctl: keccak_sponge -> keccak_f -- what the sponge table hashes is what the Keccak-f table permutes): for both
- * challenge sets the looking and the looked running products agree at the first row.  cfg: the STARK parameters only.
+ * namespace ctl: keccak_sponge -> keccak_f -- what the sponge table hashes is what the Keccak-f table permutes --,
+ * byte_packing -> memory -- the word a sequence spells is the memory operation it names): for both challenge sets the looking and the looked running products agree at the first row.  cfg: the STARK parameters only.
  * The same lookup check runs inside every bp_generate_txn_proof* call (upstream's root circuit does it in-circuit): tables
  * that do not form one statement end the call with BP_ERR_VERIFY. */
 int bp_generate_txn_table_proofs(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
