@@ -106,6 +106,38 @@ def hash_summary():
     print(open(os.path.join(O, "r4_hash_sq_counters.txt")).read())
 
 
+def leg_trace_summary():
+    """r4_kernel_stats_leg_between_markers.csv: per kernel, the launches of bench.py's roofline leg ALONE -- the kernel
+    trace of `bench.py --leg-only --leg-skip-extras` restricted to the dispatches between the leg's two marker copies
+    (the whole-process stats beside it also hold the state build and the warm-up transaction) -- and, last line, the
+    coset-LDE family bench.py's `roofline` is quoted on."""
+    files = glob.glob(os.path.join(O, "r4_leg", "**", "*kernel_trace.csv"), recursive=True)
+    if not files:
+        return
+    trace = list(csv.DictReader(open(files[0])))
+    marks = sorted(int(r["Dispatch_Id"]) for r in trace if "calib_copy_u64_kernel" in r["Kernel_Name"])
+    if len(marks) != 2:
+        print("leg trace: expected two marker dispatches, found", len(marks))
+        return
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in trace:
+        if marks[0] < int(r["Dispatch_Id"]) < marks[1]:
+            a = acc[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    fam = ("ntt16_dit_kernel", "ntt_mx_dit_kernel", "ntt_lds_kernel<false>")
+    fn = sum(v[0] for k, v in acc.items() if any(f in k for f in fam))
+    ft = sum(v[1] for k, v in acc.items() if any(f in k for f in fam))
+    with open(os.path.join(O, "r4_kernel_stats_leg_between_markers.csv"), "w") as out:
+        out.write("# HEAD %s.  rocprofv3 --kernel-trace -- python bench.py --leg-only --leg-skip-extras, dispatches between the leg's marker copies only (2 txn proofs, one prover stream)\n" % HEAD)
+        out.write("Name,Calls,TotalDurationNs,AverageNs\n")
+        for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            out.write('"%s",%d,%d,%.1f\n' % (k, v[0], v[1], v[1] / v[0]))
+        out.write('"coset-LDE family (ntt16_dit_kernel<12|13|14> + ntt_mx_dit_kernel + ntt_lds_kernel<DIT>)",%d,%d,%.1f\n' % (fn, ft, ft / max(fn, 1)))
+    print("leg between markers: LDE family %d launches, average %.2f us" % (fn, ft / max(fn, 1) / 1e3))
+
+
 k5_summary()
 loaded_summary()
 hash_summary()
+leg_trace_summary()
