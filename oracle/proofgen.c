@@ -267,6 +267,7 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
    * per packing row the write that put the word at its address (timestamp 1) and the operation the row looks up --,
    * then re-reads of the last address up to the table's height */
   const int lookup_bm = byte_packing_air && memory_air;
+  if (lookup_bm && wit && wit->items[1] && !wit->items[6]) return -2; /* given sequences need their log */
   if (lookup_bm && !(wit && wit->items[6]) && tcfg[6].log_n < tcfg[1].log_n + 1) return -2;
   static const int order[NUM_TABLES] = {4, 0, 1, 2, 3, 5, 6}; /* the sponge table first: the Keccak-f table reads it */
   for (int oi = 0; oi < NUM_TABLES; oi++) {

@@ -627,6 +627,9 @@ static int prove_tables(Worker& w, const uint64_t* I, const TxnWitness* wit, Tab
   // byte_packing -> memory: the memory table that is not given by the caller is the log of the byte-packing table's
   // words (two operations per packing row); it must be tall enough to hold them
   const bool lookup_bm = tcfg[1].air_id == air::BYTE_PACKING && tcfg[6].air_id == air::MEMORY;
+  if (lookup_bm && given(1) && !given(6))
+    return fail(BP_ERR_INVALID_INPUT, "byte-packing sequences are given but the memory log is not: the memory table is looked up by them "
+                "(byte_packing -> memory) and cannot be drawn from the seed");
   if (lookup_bm && !given(6) && tcfg[6].log_n < tcfg[1].log_n + 1)
     return fail(BP_ERR_INVALID_INPUT, "the memory table (2^%u rows) cannot hold the operations of the byte-packing table (2^%u rows): "
                 "two per row", tcfg[6].log_n, tcfg[1].log_n);
