@@ -62,6 +62,7 @@ TUNE_KNOBS = (
     ("--quad-threshold-log2", "bp_tune_quad_threshold",
      "hash launches with fewer rows than 2^k take the low-latency Poseidon forms"),
     ("--rec-batch", "bp_tune_rec_batch", "recursion-shaped proofs proved in lock-step per batch (1 = one at a time)"),
+    ("--side-lanes", "bp_tune_side_lanes", "trace commitments on idle workers' streams while the device is not loaded (1) or never (0)"),
     ("--host-wait", "bp_tune_host_wait", "0 auto, 1 the runtime's wait, 2 the library's poll-and-sleep wait"),
 )
 

@@ -103,6 +103,27 @@ struct WorkerLease {
   }
 };
 
+// An idle worker borrowed as a LANE -- its stream and its cap mailbox, nothing else -- by a prover that finds the
+// device not loaded: work that does not depend on each other (the seven trace commitments of a transaction) then
+// overlaps instead of running one medium launch after the other.  Never waits for a worker, is not counted as a prover.
+struct SideLane {
+  const bp_state* s;
+  Worker* w;
+  static std::unique_ptr<SideLane> try_acquire(const bp_state* st) {
+    std::lock_guard<std::mutex> lk(st->mu);
+    if (st->idle.empty()) return nullptr;
+    std::unique_ptr<SideLane> l(new SideLane{st, st->idle.back()});
+    st->idle.pop_back();
+    return l;
+  }
+  ~SideLane() {
+    (void)hipStreamSynchronize(w->stream);  // nothing of ours is left on the lane when its owner gets it back
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->idle.push_back(w);
+    s->cv.notify_one();
+  }
+};
+
 StarkCfg rec_cfg_of(const bp_config& c) {
   return StarkCfg{c.rec_log_n, c.rec_n_cols, c.rec_n_const, 3, c.rec_rate_bits, c.stark_cap_height,
                   c.rec_num_queries, c.rec_pow_bits, c.arity_bits, c.final_poly_bits, c.rec_air_id};
@@ -161,6 +182,7 @@ int emit_box(uint64_t kind, uint64_t circuit, const std::vector<uint64_t>& pi, c
 // the state's one recursion shape are proved in lock-step, up to g_rec_batch at a time (stark_prove_batch: every
 // launch and every host wait is shared; circuits, public inputs and transcripts are each proof's own).
 std::atomic<uint32_t> g_rec_batch{MAX_BATCH};  // bp_tune_rec_batch: 1 = one proof at a time
+std::atomic<int> g_side_lanes{1};               // bp_tune_side_lanes: 0 = a prover never borrows idle workers' streams
 int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* const* circ, const std::vector<uint64_t>* pi,
                     std::vector<uint64_t>* proofs) {
   const uint32_t cap = std::min<uint32_t>(std::min<uint32_t>(MAX_BATCH, std::max<uint32_t>(1, g_rec_batch.load(std::memory_order_relaxed))),
@@ -275,6 +297,7 @@ void root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_numbe
 extern "C" {
 
 void bp_tune_rec_batch(int n) { g_rec_batch.store(n < 1 ? 1 : (n > (int)MAX_BATCH ? MAX_BATCH : (uint32_t)n)); }
+void bp_tune_side_lanes(int on) { g_side_lanes.store(on ? 1 : 0); }
 
 void bp_config_default(bp_config* c) {
   // constants.rs:6-18, positional order of prover_state.rs:85-93
@@ -611,7 +634,7 @@ static int check_lookups(const StarkCfg tcfg[BP_NUM_TABLES], const std::vector<u
 }
 
 // generate_traces + the seven table proofs on one transcript (plonky2_evm `prove`), on the leased worker
-static int prove_tables(Worker& w, const uint64_t* I, const TxnWitness* wit, TableProofs* tp) {
+static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const TxnWitness* wit, TableProofs* tp) {
   StarkCfg* tcfg = tp->tcfg;
   int r;
   // generate_traces + trace commitments for all tables, then the shared transcript prologue
@@ -679,10 +702,48 @@ static int prove_tables(Worker& w, const uint64_t* I, const TxnWitness* wit, Tab
       w.arena.release(mark);
     }
   }
-  for (int t = 0; t < BP_NUM_TABLES; t++) {
-    if ((r = commit(w, d_trace[t], tcfg[t].n_cols, tcfg[t].log_n, tcfg[t].rate_bits, tcfg[t].cap_height, false, &trace[t]))) return r;
-    ch.observe(trace[t].cap.data(), trace[t].cap.size());
+  // The seven trace commitments do not depend on each other.  Under load they queue on this prover's stream like
+  // everything else (the chip is full); on a device that is not loaded -- a lone transaction, the end of a shard --
+  // up to three idle workers lend their streams and the commitments overlap: the wide Keccak table's long sponge chains
+  // no longer have the chip to themselves (largest first, each to the lane with the least work so far).
+  std::vector<std::unique_ptr<SideLane>> sides;
+  if (s && !device_loaded() && g_side_lanes.load(std::memory_order_relaxed))
+    for (int k = 0; k < 3; k++) {
+      std::unique_ptr<SideLane> l = SideLane::try_acquire(s);
+      if (!l) break;
+      sides.push_back(std::move(l));
+    }
+  if (sides.empty()) {
+    for (int t = 0; t < BP_NUM_TABLES; t++)
+      if ((r = commit(w, d_trace[t], tcfg[t].n_cols, tcfg[t].log_n, tcfg[t].rate_bits, tcfg[t].cap_height, false, &trace[t]))) return r;
+  } else {
+    BPG_HIP(hipEventRecord(w.sync_event, w.stream));  // the witnesses are made on this prover's stream
+    std::vector<Worker*> lane = {&w};
+    for (auto& l : sides) {
+      BPG_HIP(hipStreamWaitEvent(l->w->stream, w.sync_event, 0));
+      lane.push_back(l->w);
+    }
+    std::vector<uint64_t> load(lane.size(), 0);
+    std::vector<size_t> slots(lane.size(), 0);
+    int order[BP_NUM_TABLES];
+    for (int t = 0; t < BP_NUM_TABLES; t++) order[t] = t;
+    auto cells = [&](int t) { return (uint64_t)tcfg[t].n_cols << tcfg[t].log_n; };
+    std::sort(order, order + BP_NUM_TABLES, [&](int a, int b) { return cells(a) != cells(b) ? cells(a) > cells(b) : a < b; });
+    PendingCommit pc[BP_NUM_TABLES];
+    for (int oi = 0; oi < BP_NUM_TABLES; oi++) {
+      const int t = order[oi];
+      const size_t k = std::min_element(load.begin(), load.end()) - load.begin();
+      if ((r = commit_launch(w, *lane[k], slots[k], d_trace[t], tcfg[t].n_cols, 1, tcfg[t].log_n, tcfg[t].rate_bits,
+                             tcfg[t].cap_height, false, &pc[t])))
+        return r;
+      load[k] += cells(t);
+      slots[k] += (size_t)4 << tcfg[t].cap_height;
+    }
+    for (int t = 0; t < BP_NUM_TABLES; t++)
+      if ((r = commit_finish(pc[t], &trace[t]))) return r;
+    sides.clear();  // the lanes are drained (commit_finish waited for each): back to their owners
   }
+  for (int t = 0; t < BP_NUM_TABLES; t++) ch.observe(trace[t].cap.data(), trace[t].cap.size());
   ch.observe(tp->pv.data(), tp->pv.size());
   Ctl& ctl = tp->ctl;
   for (int i = 0; i < 4; i++) ctl.v[i] = ch.challenge();
@@ -737,7 +798,7 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   w.abort_flag = abort_flag;
   w.abort_flag_u8 = abort_flag_u8;
   if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before start");
-  if ((r = prove_tables(w, I, wit, &tp))) return r;
+  if ((r = prove_tables(s, w, I, wit, &tp))) return r;
   if (tables_only) {
     // "BPGTABLS" | n_tables | public values | lookup challenges | per table: air_id, log_n, n_cols, n_words, proof words
     std::vector<uint64_t> o = {TABLES_MAGIC, BP_NUM_TABLES};

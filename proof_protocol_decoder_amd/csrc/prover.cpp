@@ -253,6 +253,17 @@ extern "C" uint64_t bp_merkle_digest_words(uint32_t, uint32_t);
 // index from grid.z).  out[b] are views into the shared buffers.  One host wait for all caps.
 int commit_batch(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t batch, uint32_t log_n, uint32_t rate_bits,
                  uint32_t cap_height, bool from_coeffs, Committed* out) {
+  PendingCommit pc;
+  TRY(commit_launch(w, w, 0, d_in, n_cols, batch, log_n, rate_bits, cap_height, from_coeffs, &pc));
+  return commit_finish(pc, out);
+}
+// The two halves of a commitment.  commit_launch allocates in `mem`'s arena and queues every launch on `lane`'s
+// stream, the caps landing in lane's pinned mailbox from word `mailbox_word` on; commit_finish waits for the lane and
+// reads them.  With mem == lane this is commit_batch; with another worker's stream as the lane, commitments that do not
+// depend on each other (the seven trace commitments of a transaction) overlap on a device that is not loaded.
+int commit_launch(Worker& mem, Worker& lane, size_t mailbox_word, const uint64_t* d_in, uint32_t n_cols, uint32_t batch,
+                  uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, bool from_coeffs, PendingCommit* pc) {
+  Worker& w = mem;
   if (batch == 0 || batch > MAX_BATCH) return fail(BP_ERR_INVALID_INPUT, "commit: batch of %u", batch);
   const uint64_t n = (uint64_t)1 << log_n, m = n << rate_bits;
   const size_t all_cols = (size_t)n_cols * batch;
@@ -265,28 +276,33 @@ int commit_batch(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t batc
     coeffs = c;
   }
   TRY(bp_lde_batch(d_in, n, from_coeffs ? nullptr : coeffs, n, lde, m, log_n, rate_bits, (uint32_t)all_cols, from_coeffs,
-                   w.stream));
+                   lane.stream));
   // the kernel that makes the cap level writes it into the pinned mailbox as well: no copy launch
   const size_t cw = (size_t)4 << cap_height;
-  if (cw * batch > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "caps do not fit the mailbox");
+  if (mailbox_word + cw * batch > lane.pinned_words) return fail(BP_ERR_UNSUPPORTED, "caps do not fit the mailbox");
   bool mirrored = false;
-  TRY(merkle_commit_cols(lde, m, n_cols, log_n, rate_bits, cap_height, digests, w.stream, w.pinned_dev, &mirrored, batch,
-                         (uint64_t)n_cols * m, dw));
-  if (mirrored) {
-    TRY(w.wait());
-  } else {  // the cap is the leaf level: no kernel above it that could have mirrored it
+  TRY(merkle_commit_cols(lde, m, n_cols, log_n, rate_bits, cap_height, digests, lane.stream, lane.pinned_dev + mailbox_word,
+                         &mirrored, batch, (uint64_t)n_cols * m, dw));
+  if (!mirrored) {  // the cap is the leaf level: no kernel above it that could have mirrored it
     for (uint32_t b = 0; b < batch; b++)
-      BPG_HIP(hipMemcpyAsync(w.pinned + b * cw, digests + (b + 1) * dw - cw, cw * 8, hipMemcpyDeviceToHost, w.stream));
-    TRY(w.wait());
+      BPG_HIP(hipMemcpyAsync(lane.pinned + mailbox_word + b * cw, digests + (b + 1) * dw - cw, cw * 8, hipMemcpyDeviceToHost,
+                             lane.stream));
   }
-  for (uint32_t b = 0; b < batch; b++) {
+  *pc = PendingCommit{&lane, mailbox_word, d_in, coeffs, lde, digests, dw, cw, n_cols, batch, log_n, rate_bits, cap_height, from_coeffs};
+  return BP_OK;
+}
+int commit_finish(const PendingCommit& pc, Committed* out) {
+  TRY(pc.lane->wait());
+  const uint64_t n = (uint64_t)1 << pc.log_n, m = n << pc.rate_bits;
+  for (uint32_t b = 0; b < pc.batch; b++) {
     Committed& o = out[b];
-    o.log_n = log_n; o.n_cols = n_cols; o.rate_bits = rate_bits; o.cap_height = cap_height;
-    o.coeffs = coeffs + (size_t)b * n_cols * n;
-    o.lde = lde + (size_t)b * n_cols * m;
-    o.digests = digests + (size_t)b * dw;
-    o.values = from_coeffs ? nullptr : d_in + (size_t)b * n_cols * n;
-    o.cap.assign(w.pinned + b * cw, w.pinned + (b + 1) * cw);
+    o.log_n = pc.log_n; o.n_cols = pc.n_cols; o.rate_bits = pc.rate_bits; o.cap_height = pc.cap_height;
+    o.coeffs = pc.coeffs + (size_t)b * pc.n_cols * n;
+    o.lde = pc.lde + (size_t)b * pc.n_cols * m;
+    o.digests = pc.digests + (size_t)b * pc.dw;
+    o.values = pc.from_coeffs ? nullptr : pc.d_in + (size_t)b * pc.n_cols * n;
+    const uint64_t* cap = pc.lane->pinned + pc.mailbox_word + b * pc.cw;
+    o.cap.assign(cap, cap + pc.cw);
   }
   return BP_OK;
 }

@@ -128,6 +128,22 @@ int commit(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t log_n, uin
 int commit_batch(Worker& w, const uint64_t* d_in, uint32_t n_cols, uint32_t batch, uint32_t log_n, uint32_t rate_bits,
                  uint32_t cap_height, bool from_coeffs, Committed* out);
 
+// The two halves of commit_batch: the launches (arena of `mem`, stream and cap mailbox of `lane`, caps from word
+// `mailbox_word` of the mailbox on) and the wait for the caps.  Commitments that do not depend on each other can be
+// launched on different lanes and finished afterwards (proofgen.cpp: the trace commitments of a lone transaction).
+struct PendingCommit {
+  Worker* lane = nullptr;
+  size_t mailbox_word = 0;
+  const uint64_t* d_in = nullptr;
+  uint64_t *coeffs = nullptr, *lde = nullptr, *digests = nullptr;
+  size_t dw = 0, cw = 0;
+  uint32_t n_cols = 0, batch = 0, log_n = 0, rate_bits = 0, cap_height = 0;
+  bool from_coeffs = false;
+};
+int commit_launch(Worker& mem, Worker& lane, size_t mailbox_word, const uint64_t* d_in, uint32_t n_cols, uint32_t batch,
+                  uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, bool from_coeffs, PendingCommit* pc);
+int commit_finish(const PendingCommit& pc, Committed* out);
+
 // prove_single_table on the synthetic AIR.  The caller has already observed the trace cap(s) and
 // drawn ctl (plonky2_evm prover order).  Fills `proof` (proof_layout(cfg).total words).
 // hint (nullable): what the prover of a LOOKED table needs to know about its looking tables (air::ctl) -- for the

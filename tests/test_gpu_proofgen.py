@@ -90,6 +90,35 @@ def test_lock_step_batches_do_not_change_a_byte(pg, p_state, bpg, chain):
         L.bp_tune_host_wait(0)
 
 
+def test_side_lanes_do_not_change_a_byte(pg, bpg, oracle):
+    """While the device is not loaded a transaction's seven trace commitments are spread over the streams of idle
+    workers (bp_tune_side_lanes, csrc/proofgen.cpp SideLane): with three lanes to borrow, with none, and with the
+    borrowing switched off the txn proof is the same bytes, and they are the oracle's; two transactions at once share
+    the idle workers between them."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = bpg.lib()
+    want = oracle.PgState(**SMALL).txn(ir_words(7, 0, 0x5EED0001))
+    proofs = []
+    for n_workers, lanes in ((4, 1), (1, 1), (4, 0)):
+        b = pg.ProverStateBuilder()
+        for t, name in enumerate(pg.TABLES):
+            getattr(b, "set_%s_circuit_size" % name)(range(SMALL["table_log_lo"][t], SMALL["table_log_hi"][t]))
+        b.set(**{k: v for k, v in SMALL.items() if not k.startswith("table_")}, n_workers=n_workers, arena_bytes=256 << 20)
+        st = b.build()
+        L.bp_tune_side_lanes(lanes)
+        try:
+            proofs.append(pg.generate_txn_proof(st, make_ir(pg, 7, 0, 0x5EED0001)).intern)
+            if n_workers == 4 and lanes:
+                with ThreadPoolExecutor(2) as pool:
+                    both = list(pool.map(lambda _: pg.generate_txn_proof(st, make_ir(pg, 7, 0, 0x5EED0001)).intern, range(2)))
+                assert both[0] == both[1] == proofs[-1]
+        finally:
+            L.bp_tune_side_lanes(1)
+            st.close()
+    assert proofs[0] == proofs[1] == proofs[2]
+    assert (words(proofs[0]) == want).all()
+
+
 def test_public_values_chain(chain):
     t0, t1, t2, a01, a012, blk = chain
     assert (t0.p_vals.txn_number_before, t0.p_vals.txn_number_after) == (0, 1)
