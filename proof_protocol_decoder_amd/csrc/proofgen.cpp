@@ -64,6 +64,11 @@ struct bp_state {
   mutable std::condition_variable cv;
   mutable std::vector<std::unique_ptr<Worker>> workers;
   mutable std::vector<Worker*> idle;
+  // three more streams (+ cap mailboxes, no arena to speak of) that belong to no prover: a prover that finds the device
+  // not loaded spreads work that does not depend on each other over them (SideLane).  Not taken from the workers: a lone
+  // prover holding idle WORKERS would keep the next transactions of a starting shard waiting for one.
+  mutable std::vector<std::unique_ptr<Worker>> lanes;
+  mutable std::vector<Worker*> idle_lanes;
   // Keccak-256 of every proof container this state has produced (bounded): aggregation verifies its children on the
   // host (verify_child), which costs 10 ms of CPU per recursion-shaped proof against 5 ms of GPU to make one -- a child
   // that this very state has just produced, byte for byte, is recognised instead of being verified again
@@ -103,24 +108,23 @@ struct WorkerLease {
   }
 };
 
-// An idle worker borrowed as a LANE -- its stream and its cap mailbox, nothing else -- by a prover that finds the
-// device not loaded: work that does not depend on each other (the seven trace commitments of a transaction) then
-// overlaps instead of running one medium launch after the other.  Never waits for a worker, is not counted as a prover.
+// One of the state's side lanes -- a stream and a cap mailbox, nothing else -- taken by a prover that finds the device
+// not loaded: work that does not depend on each other (the seven trace commitments of a transaction) then overlaps
+// instead of running one medium launch after the other.  Never waits for a lane, is not counted as a prover.
 struct SideLane {
   const bp_state* s;
   Worker* w;
   static std::unique_ptr<SideLane> try_acquire(const bp_state* st) {
     std::lock_guard<std::mutex> lk(st->mu);
-    if (st->idle.empty()) return nullptr;
-    std::unique_ptr<SideLane> l(new SideLane{st, st->idle.back()});
-    st->idle.pop_back();
+    if (st->idle_lanes.empty()) return nullptr;
+    std::unique_ptr<SideLane> l(new SideLane{st, st->idle_lanes.back()});
+    st->idle_lanes.pop_back();
     return l;
   }
   ~SideLane() {
-    (void)hipStreamSynchronize(w->stream);  // nothing of ours is left on the lane when its owner gets it back
+    (void)hipStreamSynchronize(w->stream);  // nothing of ours is left on the lane when the next prover takes it
     std::lock_guard<std::mutex> lk(s->mu);
-    s->idle.push_back(w);
-    s->cv.notify_one();
+    s->idle_lanes.push_back(w);
   }
 };
 
@@ -362,6 +366,7 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
     ~Unbuild() {
       if (!s) return;
       for (auto& w : s->workers) w->destroy();
+      for (auto& w : s->lanes) w->destroy();
       s->builder.destroy();
     }
   } unbuild{s};
@@ -381,6 +386,12 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
     if ((r = w->init(cfg->device, cfg->arena_bytes))) { w->destroy(); return r; }
     s->idle.push_back(w.get());
     s->workers.push_back(std::move(w));
+  }
+  for (uint32_t i = 0; i < 3 && cfg->n_workers > 1; i++) {  // side lanes (a state of one worker is the single-stream reference)
+    std::unique_ptr<Worker> w(new Worker());
+    if ((r = w->init(cfg->device, (size_t)1 << 20))) { w->destroy(); return r; }
+    s->idle_lanes.push_back(w.get());
+    s->lanes.push_back(std::move(w));
   }
   {
     // One prover = one HIP stream, and ROCm multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues
@@ -417,6 +428,7 @@ void bp_state_free(bp_state* s) {
   if (!s) return;
   (void)hipSetDevice(s->cfg.device);
   for (auto& w : s->workers) w->destroy();
+  for (auto& w : s->lanes) w->destroy();
   s->builder.destroy();
   delete s;
 }
@@ -704,7 +716,7 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
   }
   // The seven trace commitments do not depend on each other.  Under load they queue on this prover's stream like
   // everything else (the chip is full); on a device that is not loaded -- a lone transaction, the end of a shard --
-  // up to three idle workers lend their streams and the commitments overlap: the wide Keccak table's long sponge chains
+  // the state's three side lanes take a share and the commitments overlap: the wide Keccak table's long sponge chains
   // no longer have the chip to themselves (largest first, each to the lane with the least work so far).
   std::vector<std::unique_ptr<SideLane>> sides;
   if (s && !device_loaded() && g_side_lanes.load(std::memory_order_relaxed))
