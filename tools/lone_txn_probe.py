@@ -1,5 +1,7 @@
-"""A transaction alone on the chip: wall time of generate_txn_proof on a state with one prover stream (what the last
-txn of a shard, or a shard of one, costs).  python tools/lone_txn_probe.py [reps] [--real-airs]
+"""A transaction alone on the chip: wall time of generate_txn_proof, nothing else running (what the last txn of a
+shard, or a shard of one, costs).  python tools/lone_txn_probe.py [reps] [--real-airs] [--one-worker]
+By default the state has two workers, so it has its side lanes (the seven trace commitments overlap on them);
+--one-worker: a state of one prover stream and no lanes, the single-stream reference.
 Under `rocprofv3 --kernel-trace --stats -- python tools/lone_txn_probe.py 3` the kernel stats are the lone txn's own."""
 import os
 import sys
@@ -16,7 +18,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 real = "--real-airs" in sys.argv
 L = pkg.lib()
 L.bp_use_blocking_sync(0)
-st = pg.ProverStateBuilder().set(device=0, n_workers=1, arena_bytes=6 << 30).build()
+one = "--one-worker" in sys.argv
+st = pg.ProverStateBuilder().set(device=0, n_workers=1 if one else 2, arena_bytes=6 << 30).build()
 irs = synthetic_block_irs(2000, reps + 1, S1_LOG_N, S1_WIDTH, keccak_air=real, logic_air=real, memory_air=real,
                           arithmetic_air=real, byte_packing_air=real, keccak_sponge_air=real)
 pg.generate_txn_proof(st, irs[0])
@@ -25,5 +28,5 @@ for ir in irs[1:]:
     t0 = time.perf_counter()
     pg.generate_txn_proof(st, ir)
     ms.append((time.perf_counter() - t0) * 1e3)
-print("lone txn%s: %s ms; median %.1f ms" % (" (six real tables)" if real else "", [round(x, 1) for x in ms], sorted(ms)[len(ms) // 2]))
+print("lone txn%s%s: %s ms; median %.1f ms" % (" (six real tables)" if real else "", " (one worker, no side lanes)" if one else "", [round(x, 1) for x in ms], sorted(ms)[len(ms) // 2]))
 st.close()
