@@ -151,9 +151,9 @@ void bp_tune_assume_loaded(int mode);
  * lock-step, up to n (1..8, default 8) proofs per batch: seven transcripts stepped together, every kernel launch and every
  * host wait shared.  1 = one proof at a time (round 3's behaviour, for A/B runs).  Results are identical. */
 void bp_tune_rec_batch(int n);
-/* While fewer than six provers are at work on the device, a transaction's seven trace commitments -- which do not
- * depend on each other -- are spread over the state's three side lanes (streams that belong to no prover; a state of more
- * than one worker has them) (1, default); 0 = always on the prover's own stream.  Results are identical. */
+/* A prover that is alone on the device (a lone transaction, the last one of a shard) spreads its transaction's seven
+ * trace commitments -- which do not depend on each other -- over the streams of up to three idle workers of the state
+ * (1, default); 0 = always on the prover's own stream.  Results are identical. */
 void bp_tune_side_lanes(int on);
 /* How the library's prover threads wait for the device: 0 (default) = the runtime's wait where it sleeps
  * (bp_host_wait_mode 1), the library's own poll-and-sleep wait where the runtime's would spin (mode 2: a device the

@@ -562,6 +562,7 @@ static std::atomic<uint64_t> g_quad_threshold{0};
 static bool g_poseidon_mx_on();
 static std::atomic<int> g_active_provers{0};
 void prover_active(int delta) { g_active_provers.fetch_add(delta, std::memory_order_relaxed); }
+int provers_active() { return g_active_provers.load(std::memory_order_relaxed); }
 static std::atomic<int> g_assume_loaded{-1};  // -1: by the count of provers at work; 0 / 1: stated by the caller
 bool device_loaded() {  // several provers share the chip
   const int a = g_assume_loaded.load(std::memory_order_relaxed);

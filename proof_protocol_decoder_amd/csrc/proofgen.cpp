@@ -64,11 +64,6 @@ struct bp_state {
   mutable std::condition_variable cv;
   mutable std::vector<std::unique_ptr<Worker>> workers;
   mutable std::vector<Worker*> idle;
-  // three more streams (+ cap mailboxes, no arena to speak of) that belong to no prover: a prover that finds the device
-  // not loaded spreads work that does not depend on each other over them (SideLane).  Not taken from the workers: a lone
-  // prover holding idle WORKERS would keep the next transactions of a starting shard waiting for one.
-  mutable std::vector<std::unique_ptr<Worker>> lanes;
-  mutable std::vector<Worker*> idle_lanes;
   // Keccak-256 of every proof container this state has produced (bounded): aggregation verifies its children on the
   // host (verify_child), which costs 10 ms of CPU per recursion-shaped proof against 5 ms of GPU to make one -- a child
   // that this very state has just produced, byte for byte, is recognised instead of being verified again
@@ -108,23 +103,27 @@ struct WorkerLease {
   }
 };
 
-// One of the state's side lanes -- a stream and a cap mailbox, nothing else -- taken by a prover that finds the device
-// not loaded: work that does not depend on each other (the seven trace commitments of a transaction) then overlaps
-// instead of running one medium launch after the other.  Never waits for a lane, is not counted as a prover.
+// An idle worker borrowed as a LANE -- its stream and its cap mailbox, nothing else -- by a prover that finds itself
+// ALONE on the device (a lone transaction, the last one of a shard): work that does not depend on each other (the seven
+// trace commitments of a transaction) then overlaps instead of running one medium launch after the other.  Never waits
+// for a worker, is not counted as a prover.  (Streams of their own for this were measured and dropped: three more streams
+// in the process cost the loaded 256-txn block 2.6 % whether they were used or not -- 24 streams instead of 21, the same
+// step the stream sweep shows between 20 and 24 prover streams.)
 struct SideLane {
   const bp_state* s;
   Worker* w;
   static std::unique_ptr<SideLane> try_acquire(const bp_state* st) {
     std::lock_guard<std::mutex> lk(st->mu);
-    if (st->idle_lanes.empty()) return nullptr;
-    std::unique_ptr<SideLane> l(new SideLane{st, st->idle_lanes.back()});
-    st->idle_lanes.pop_back();
+    if (st->idle.empty()) return nullptr;
+    std::unique_ptr<SideLane> l(new SideLane{st, st->idle.back()});
+    st->idle.pop_back();
     return l;
   }
   ~SideLane() {
-    (void)hipStreamSynchronize(w->stream);  // nothing of ours is left on the lane when the next prover takes it
+    (void)hipStreamSynchronize(w->stream);  // nothing of ours is left on the lane when its owner gets it back
     std::lock_guard<std::mutex> lk(s->mu);
-    s->idle_lanes.push_back(w);
+    s->idle.push_back(w);
+    s->cv.notify_one();
   }
 };
 
@@ -186,7 +185,7 @@ int emit_box(uint64_t kind, uint64_t circuit, const std::vector<uint64_t>& pi, c
 // the state's one recursion shape are proved in lock-step, up to g_rec_batch at a time (stark_prove_batch: every
 // launch and every host wait is shared; circuits, public inputs and transcripts are each proof's own).
 std::atomic<uint32_t> g_rec_batch{MAX_BATCH};  // bp_tune_rec_batch: 1 = one proof at a time
-std::atomic<int> g_side_lanes{1};               // bp_tune_side_lanes: 0 = a prover never borrows idle workers' streams
+std::atomic<int> g_side_lanes{1};               // bp_tune_side_lanes: 0 = no side lanes
 int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* const* circ, const std::vector<uint64_t>* pi,
                     std::vector<uint64_t>* proofs) {
   const uint32_t cap = std::min<uint32_t>(std::min<uint32_t>(MAX_BATCH, std::max<uint32_t>(1, g_rec_batch.load(std::memory_order_relaxed))),
@@ -366,7 +365,6 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
     ~Unbuild() {
       if (!s) return;
       for (auto& w : s->workers) w->destroy();
-      for (auto& w : s->lanes) w->destroy();
       s->builder.destroy();
     }
   } unbuild{s};
@@ -386,12 +384,6 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
     if ((r = w->init(cfg->device, cfg->arena_bytes))) { w->destroy(); return r; }
     s->idle.push_back(w.get());
     s->workers.push_back(std::move(w));
-  }
-  for (uint32_t i = 0; i < 3 && cfg->n_workers > 1; i++) {  // side lanes (a state of one worker is the single-stream reference)
-    std::unique_ptr<Worker> w(new Worker());
-    if ((r = w->init(cfg->device, (size_t)1 << 20))) { w->destroy(); return r; }
-    s->idle_lanes.push_back(w.get());
-    s->lanes.push_back(std::move(w));
   }
   {
     // One prover = one HIP stream, and ROCm multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues
@@ -428,7 +420,6 @@ void bp_state_free(bp_state* s) {
   if (!s) return;
   (void)hipSetDevice(s->cfg.device);
   for (auto& w : s->workers) w->destroy();
-  for (auto& w : s->lanes) w->destroy();
   s->builder.destroy();
   delete s;
 }
@@ -715,11 +706,11 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
     }
   }
   // The seven trace commitments do not depend on each other.  Under load they queue on this prover's stream like
-  // everything else (the chip is full); on a device that is not loaded -- a lone transaction, the end of a shard --
-  // the state's three side lanes take a share and the commitments overlap: the wide Keccak table's long sponge chains
-  // no longer have the chip to themselves (largest first, each to the lane with the least work so far).
+  // everything else (the chip is full); a prover that is ALONE on the device -- a lone transaction, the last one of a
+  // shard -- borrows the streams of up to three idle workers and the commitments overlap: the wide Keccak table's long
+  // sponge chains no longer have the chip to themselves (largest first, each to the lane with the least work so far).
   std::vector<std::unique_ptr<SideLane>> sides;
-  if (s && !device_loaded() && g_side_lanes.load(std::memory_order_relaxed))
+  if (s && provers_active() <= 1 && g_side_lanes.load(std::memory_order_relaxed))
     for (int k = 0; k < 3; k++) {
       std::unique_ptr<SideLane> l = SideLane::try_acquire(s);
       if (!l) break;

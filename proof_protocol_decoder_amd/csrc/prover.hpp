@@ -169,6 +169,7 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t batch, const Comm
 void tune_host_wait(int mode);  // bp_tune_host_wait
 // hash_kernels.hip: +1 / -1 as a prover starts / finishes (the Poseidon kernel choice follows the load)
 void prover_active(int delta);
+int provers_active();  // how many are at work right now
 bool device_loaded();  // six or more provers at work on the device
 
 // launch-argument builders shared by the prover and the L0 entry points (stark_api.cpp)

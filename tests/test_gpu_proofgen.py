@@ -91,10 +91,10 @@ def test_lock_step_batches_do_not_change_a_byte(pg, p_state, bpg, chain):
 
 
 def test_side_lanes_do_not_change_a_byte(pg, bpg, oracle):
-    """While the device is not loaded a transaction's seven trace commitments are spread over the state's side lanes
-    (bp_tune_side_lanes, csrc/proofgen.cpp SideLane): with the three lanes, in a state that has none (one worker), and
-    with the lanes switched off the txn proof is the same bytes, and they are the oracle's; two transactions at once
-    share the lanes between them."""
+    """A prover that is alone on the device spreads its transaction's seven trace commitments over the streams of idle
+    workers (bp_tune_side_lanes, csrc/proofgen.cpp SideLane): with three workers to borrow, with none (a state of one
+    worker), and with the borrowing switched off the txn proof is the same bytes, and they are the oracle's; two
+    transactions at once (at most one of them finds itself alone) agree as well."""
     from concurrent.futures import ThreadPoolExecutor
     L = bpg.lib()
     want = oracle.PgState(**SMALL).txn(ir_words(7, 0, 0x5EED0001))

@@ -1,7 +1,7 @@
 """A transaction alone on the chip: wall time of generate_txn_proof, nothing else running (what the last txn of a
 shard, or a shard of one, costs).  python tools/lone_txn_probe.py [reps] [--real-airs] [--one-worker]
-By default the state has two workers, so it has its side lanes (the seven trace commitments overlap on them);
---one-worker: a state of one prover stream and no lanes, the single-stream reference.
+By default the state has four workers: the lone prover borrows the three idle ones' streams as side lanes (the
+seven trace commitments overlap on them); --one-worker: a state of one prover stream, the single-stream reference.
 Under `rocprofv3 --kernel-trace --stats -- python tools/lone_txn_probe.py 3` the kernel stats are the lone txn's own."""
 import os
 import sys
@@ -19,7 +19,7 @@ real = "--real-airs" in sys.argv
 L = pkg.lib()
 L.bp_use_blocking_sync(0)
 one = "--one-worker" in sys.argv
-st = pg.ProverStateBuilder().set(device=0, n_workers=1 if one else 2, arena_bytes=6 << 30).build()
+st = pg.ProverStateBuilder().set(device=0, n_workers=1 if one else 4, arena_bytes=6 << 30).build()
 irs = synthetic_block_irs(2000, reps + 1, S1_LOG_N, S1_WIDTH, keccak_air=real, logic_air=real, memory_air=real,
                           arithmetic_air=real, byte_packing_air=real, keccak_sponge_air=real)
 pg.generate_txn_proof(st, irs[0])
