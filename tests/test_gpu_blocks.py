@@ -101,6 +101,36 @@ def test_block256_at_default_config(pg, default_state, oracle):
     assert ost.verify(words(kept[200].intern)) == 0
 
 
+def test_txn_with_six_real_tables_at_baseline_sizes_matches_the_oracle(pg, default_state, oracle):
+    """One transaction of the `--real-airs` workload at bp_config_default parameters and the S1 table heights: the
+    arithmetic, byte-packing, Keccak-f, Keccak-sponge, logic and memory tables proven with their AIRs, both cross-table
+    lookups active (keccak_sponge -> keccak_f over 2^14 / 2^9 rows, byte_packing -> memory over 2^9 / 2^17 rows), the
+    recursion layer on the PLONK-shaped circuit.  The oracle proves the same transaction on the box's host cores (about
+    half a minute); the containers are equal byte for byte."""
+    import ctypes as C
+    from proof_protocol_decoder_amd.block_driver import synthetic_block_irs
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    try:  # OpenMP would otherwise start one thread per host core, not per core this process may run on
+        C.CDLL("libgomp.so.1").omp_set_num_threads(min(n, 64))
+    except OSError:
+        pass
+    ir = synthetic_block_irs(4100, 2, S1_LOG_N, S1_WIDTH, keccak_air=True, logic_air=True, memory_air=True, arithmetic_air=True,
+                             byte_packing_air=True, keccak_sponge_air=True)[1]
+    assert ir.table_width == (309, 299, 192, 2430, 2414, 523, 44)
+    got = pg.generate_txn_proof(default_state, ir)
+    want = oracle.PgState(**DEFAULT_ORACLE_CFG).txn(list(struct.unpack("<25Q", ir.to_bytes())))
+    assert words(got.intern).shape == want.shape and (words(got.intern) == want).all()
+    tables = pg.generate_txn_table_proofs(default_state, ir)
+    pg.verify_txn_table_proofs(default_state.cfg, tables)
+    assert oracle.PgState(**DEFAULT_ORACLE_CFG).verify_tables(words(tables)) == 0
+
+
 def test_block1024_properties(pg, default_state, oracle):
     """BASELINE configs[4]: 1024 transactions, 1023 aggregations (depth 10), one block proof.  No oracle run of this
     size exists (about six CPU hours); checked by properties: acceptance by both verifiers, rejection after a bit
