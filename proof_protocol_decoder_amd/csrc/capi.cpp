@@ -79,19 +79,19 @@ ThreadProf& thread_prof() {
 }
 }  // namespace
 bool profile_on() { return g_prof_on.load(std::memory_order_relaxed); }
-KernelTimer::KernelTimer(int f, hipStream_t s, double b) : family(f), st(s), bytes(b) {
+KernelTimer::KernelTimer(int f, hipStream_t s, double b, bool att) : attached(att), family(f), st(s), bytes(b) {
   if (!profile_on()) return;
   ThreadProf& tp = thread_prof();
   std::lock_guard<std::mutex> lk(tp.mu);
   e0 = tp.get();
   e1 = tp.get();
   if (!e0 || !e1) { e0 = e1 = nullptr; return; }
-  (void)hipEventRecord(e0, st);
+  if (!attached) (void)hipEventRecord(e0, st);
 }
 KernelTimer::~KernelTimer() { stop(); }
 void KernelTimer::stop() {
   if (!e0) return;
-  (void)hipEventRecord(e1, st);
+  if (!attached) (void)hipEventRecord(e1, st);
   ThreadProf& tp = thread_prof();
   std::lock_guard<std::mutex> lk(tp.mu);
   tp.pending.push_back(Pending{e0, e1, family, bytes});

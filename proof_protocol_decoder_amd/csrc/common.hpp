@@ -2,6 +2,7 @@
 #pragma once
 #include <exception>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -34,15 +35,27 @@ bool profile_on();
   catch (const std::exception& e) { return ::bpg::fail(BP_ERR_DEVICE, name ": %s", e.what()); }      \
   catch (...) { return ::bpg::fail(BP_ERR_DEVICE, name ": unknown exception"); }
 
+// attached = false: the interval between two hipEventRecord calls around whatever is launched in its scope (the
+// kernel plus the dispatch gap, ~3 us).  attached = true: the scope holds ONE launch made with BPG_LAUNCH_TIMED, which
+// hands e0 / e1 to hipExtLaunchKernelGGL as the kernel's own start / stop events: the interval is the kernel's alone,
+// which is what rocprofv3 reports for it.
 struct KernelTimer {
-  KernelTimer(int family, hipStream_t st, double alg_bytes);
+  KernelTimer(int family, hipStream_t st, double alg_bytes, bool attached = false);
   ~KernelTimer();
   void stop();  // record the end now (the destructor then does nothing more)
+  bool attached = false;
   int family;
   hipStream_t st;
   double bytes;
   hipEvent_t e0 = nullptr, e1 = nullptr;
 };
+
+// one kernel launch inside an attached KernelTimer's scope (KERNEL with template arguments: HIP_KERNEL_NAME(k<a, b>))
+#define BPG_LAUNCH_TIMED(kt, KERNEL, grid, block, lds, st, ...)                                                          \
+  do {                                                                                                                  \
+    if ((kt).e0) hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), (uint32_t)(lds), st, (kt).e0, (kt).e1, 0, __VA_ARGS__); \
+    else KERNEL<<<grid, block, lds, st>>>(__VA_ARGS__);                                                                 \
+  } while (0)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline unsigned ceil_div(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }

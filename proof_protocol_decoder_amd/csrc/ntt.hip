@@ -1030,25 +1030,26 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
     b.tw = tw_b; b.scale = scale; b.out_scalar = 1; b.log_n_total = log_n; b.n_cosets = n_cosets;
     b.n_units = n_cols << (log_n - log_blk);
     {
-      KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
+      // (attached: the kernel's own start / stop events -- this family is bench.py's `roofline`)
+      KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets), true);
       if (use_ntt_mx(log_blk, true)) {
         const mxn::Tables* tab = nullptr;
         if ((rc = get_mx_tables(1, inverse, &tab))) return rc;
         const uint32_t g = mx_grid((b.n_units + 7) / 8 * 8 * n_cosets, log_blk);
-        if (log_blk == 12) mxn::ntt_mx_dit_kernel<0><<<g, 256, (8u << 12) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
-        else if (log_blk == 13) mxn::ntt_mx_dit_kernel<1><<<g, 512, (8u << 13) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
-        else mxn::ntt_mx_dit_kernel<2><<<g, 512, (8u << 14) + 4 * mxn::C_LDS_WORDS, st>>>(b, tab);
+        if (log_blk == 12) BPG_LAUNCH_TIMED(kt, mxn::ntt_mx_dit_kernel<0>, g, 256, (8u << 12) + 4 * mxn::C_LDS_WORDS, st, b, tab);
+        else if (log_blk == 13) BPG_LAUNCH_TIMED(kt, mxn::ntt_mx_dit_kernel<1>, g, 512, (8u << 13) + 4 * mxn::C_LDS_WORDS, st, b, tab);
+        else BPG_LAUNCH_TIMED(kt, mxn::ntt_mx_dit_kernel<2>, g, 512, (8u << 14) + 4 * mxn::C_LDS_WORDS, st, b, tab);
       } else if (use_split(log_blk, (uint64_t)b.n_units * n_cosets, in, out, true)) {
         if ((rc = get_table(inverse ? 1 : 0, log_blk - 1, 0, &b.tw))) return rc;
         b.tw_top = tw_b;
         const dim3 grid1((b.n_units + 7) / 8 * 8 * n_cosets * 2);
-        if (log_blk == 14) ntt16_dit_kernel<13, 1><<<grid1, 512, 8u << 13, st>>>(b);
-        else ntt16_dit_kernel<12, 1><<<grid1, 256, 8u << 12, st>>>(b);
+        if (log_blk == 14) BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<13, 1>), grid1, 512, 8u << 13, st, b);
+        else BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<12, 1>), grid1, 256, 8u << 12, st, b);
       } else {
         const dim3 grid16((b.n_units + 7) / 8 * 8 * n_cosets);
-        if (log_blk == 12) ntt16_dit_kernel<12, 0><<<grid16, 256, 8u << 12, st>>>(b);
-        else if (log_blk == 13) ntt16_dit_kernel<13, 0><<<grid16, 512, 8u << 13, st>>>(b);
-        else ntt16_dit_kernel<14, 0><<<grid16, 1024, 8u << 14, st>>>(b);
+        if (log_blk == 12) BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<12, 0>), grid16, 256, 8u << 12, st, b);
+        else if (log_blk == 13) BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<13, 0>), grid16, 512, 8u << 13, st, b);
+        else BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<14, 0>), grid16, 1024, 8u << 14, st, b);
       }
     }
     BPG_LAUNCH_CHECK();
@@ -1060,8 +1061,8 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
   size_t lds = (size_t)8 << log_blk;
   {
     // algorithmic bytes: coefficients read once, every coset written once
-    KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets));
-    ntt_lds_kernel<false><<<grid, lds_threads(log_blk), lds, st>>>(a);
+    KernelTimer kt(PROF_LDE_DIT, st, 8.0 * (double)n_cols * (double)((uint64_t)1 << log_n) * (1.0 + n_cosets), true);
+    BPG_LAUNCH_TIMED(kt, ntt_lds_kernel<false>, grid, lds_threads(log_blk), lds, st, a);
   }
   BPG_LAUNCH_CHECK();
   }
