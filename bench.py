@@ -270,7 +270,7 @@ def main():
         L.bp_profile_enable(0)
         L.bp_debug_copy_u64(mark.data_ptr(), mark.data_ptr() + 8, 1, None)
         torch.cuda.synchronize()
-        roof = read_family("HIP events on the prover stream, 2 txn proofs of the same block proved with one stream (no "
+        roof = read_family("HIP events on the prover stream (each launch carries its own start / stop events: hipExtLaunchKernelGGL), 2 txn proofs of the same block proved with one stream (no "
                            "co-running kernels); per txn 7 table proofs, 3 lock-step batches of 7 recursion-shaped proofs, a root proof")
         alu = read_leaf_hash()
         # the other HBM-class kernels SURVEY.md section 8(d) names, over the same leg, and K5 on the synthetic tables
