@@ -1485,14 +1485,14 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
   // 24 n per column of a synthetic table)
   const double reads = air_id == air::SYNTHETIC ? 2 : air_id == air::KECCAK_F ? 52 : air_id == air::KECCAK_SPONGE ? 102
                        : air_id == air::BYTE_PACKING ? 43 : air_id == air::MEMORY ? 12 : 0;
-  KernelTimer kt(PROF_AUX, st, 8.0 * (double)((uint64_t)1 << log_n) * (reads + 1) * (n_aux - p0) * batch);
+  KernelTimer kt(PROF_AUX, st, 8.0 * (double)((uint64_t)1 << log_n) * (reads + 1) * (n_aux - p0) * batch, true);
   switch (air_id) {
-    case air::SYNTHETIC: aux_suffix_product_kernel<air::SYNTHETIC><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
-    case air::KECCAK_F: aux_suffix_product_kernel<air::KECCAK_F><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
-    case air::KECCAK_SPONGE: aux_suffix_product_kernel<air::KECCAK_SPONGE><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
-    case air::BYTE_PACKING: aux_suffix_product_kernel<air::BYTE_PACKING><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
-    case air::MEMORY: aux_suffix_product_kernel<air::MEMORY><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;
-    default: aux_suffix_product_kernel<air::LOGIC><<<grid, threads, 0, st>>>(ab, log_n, n_cols); break;  // no lookup: z = 1
+    case air::SYNTHETIC: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::SYNTHETIC>, grid, threads, 0, st, ab, log_n, n_cols); break;
+    case air::KECCAK_F: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::KECCAK_F>, grid, threads, 0, st, ab, log_n, n_cols); break;
+    case air::KECCAK_SPONGE: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::KECCAK_SPONGE>, grid, threads, 0, st, ab, log_n, n_cols); break;
+    case air::BYTE_PACKING: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::BYTE_PACKING>, grid, threads, 0, st, ab, log_n, n_cols); break;
+    case air::MEMORY: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::MEMORY>, grid, threads, 0, st, ab, log_n, n_cols); break;
+    default: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::LOGIC>, grid, threads, 0, st, ab, log_n, n_cols); break;  // no lookup: z = 1
   }
   BPG_LAUNCH_CHECK();
   return BP_OK;
@@ -1513,16 +1513,16 @@ int launch_quotient(const QuotArgs* qs, uint32_t batch, const QuotCoset& coset, 
   dim3 g1(ceil_div(rows, 256), wg_rows, batch);
   // algorithmic bytes: every element of the three LDE matrices read once, the two quotient columns written
   // (AIR 8 is counted with the synthetic recursion-shaped proofs it replaces)
-  KernelTimer kt(PROF_K5 + (q.air_id < air::COUNT ? q.air_id : 0), st, 8.0 * (double)rows * ((double)q.n_cols + q.n_aux + q.n_const + 2) * batch);
-  if (q.air_id == bpg::air::KECCAK_F) quotient_air_kernel<bpg::air::KECCAK_F><<<g1, 256, 0, st>>>(qb);
-  else if (q.air_id == bpg::air::LOGIC) quotient_air_kernel<bpg::air::LOGIC><<<g1, 256, 0, st>>>(qb);
-  else if (q.air_id == bpg::air::MEMORY) quotient_air_kernel<bpg::air::MEMORY><<<g1, 256, 0, st>>>(qb);
-  else if (q.air_id == bpg::air::ARITHMETIC) quotient_air_kernel<bpg::air::ARITHMETIC><<<g1, 256, 0, st>>>(qb);
-  else if (q.air_id == bpg::air::BYTE_PACKING) quotient_air_kernel<bpg::air::BYTE_PACKING><<<g1, 256, 0, st>>>(qb);
-  else if (q.air_id == bpg::air::KECCAK_SPONGE) quotient_air_kernel<bpg::air::KECCAK_SPONGE><<<g1, 256, 0, st>>>(qb);
-  else if (q.air_id == bpg::air::ARITHMETIC_MUL) quotient_air_kernel<bpg::air::ARITHMETIC_MUL><<<g1, 256, 0, st>>>(qb);
-  else if (q.air_id == bpg::air::PLONK) quotient_air_kernel<bpg::air::PLONK><<<g1, 256, 0, st>>>(qb);
-  else quotient_air_kernel<bpg::air::SYNTHETIC><<<g1, 256, 0, st>>>(qb);
+  KernelTimer kt(PROF_K5 + (q.air_id < air::COUNT ? q.air_id : 0), st, 8.0 * (double)rows * ((double)q.n_cols + q.n_aux + q.n_const + 2) * batch, true);
+  if (q.air_id == bpg::air::KECCAK_F) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::KECCAK_F>, g1, 256, 0, st, qb);
+  else if (q.air_id == bpg::air::LOGIC) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::LOGIC>, g1, 256, 0, st, qb);
+  else if (q.air_id == bpg::air::MEMORY) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::MEMORY>, g1, 256, 0, st, qb);
+  else if (q.air_id == bpg::air::ARITHMETIC) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::ARITHMETIC>, g1, 256, 0, st, qb);
+  else if (q.air_id == bpg::air::BYTE_PACKING) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::BYTE_PACKING>, g1, 256, 0, st, qb);
+  else if (q.air_id == bpg::air::KECCAK_SPONGE) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::KECCAK_SPONGE>, g1, 256, 0, st, qb);
+  else if (q.air_id == bpg::air::ARITHMETIC_MUL) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::ARITHMETIC_MUL>, g1, 256, 0, st, qb);
+  else if (q.air_id == bpg::air::PLONK) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::PLONK>, g1, 256, 0, st, qb);
+  else BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::SYNTHETIC>, g1, 256, 0, st, qb);
   kt.stop();
   BPG_LAUNCH_CHECK();
   if (wg_rows > 1) {
@@ -1563,8 +1563,8 @@ int launch_openings_multi(const OpenMulti* m, uint32_t batch, hipStream_t st) {
   if (int rc = check_batch(batch)) return rc;
   const uint32_t total = m[0].first_col[m[0].n_segs];  // the proofs of a batch have one shape
   if (!total) return BP_OK;
-  KernelTimer kt(PROF_OPENINGS, st, 8.0 * (double)((uint64_t)1 << m[0].log_n) * total * batch);  // every coefficient column once
-  openings_multi_kernel<<<dim3(total, 1, batch), 256, 0, st>>>(batch_of(m, batch));
+  KernelTimer kt(PROF_OPENINGS, st, 8.0 * (double)((uint64_t)1 << m[0].log_n) * total * batch, true);  // every coefficient column once
+  BPG_LAUNCH_TIMED(kt, openings_multi_kernel, dim3(total, 1, batch), 256, 0, st, batch_of(m, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -1578,8 +1578,8 @@ int launch_combine_partial_multi(const CombineMulti* m, uint32_t batch, uint32_t
   if (!total_chunks) return BP_OK;
   if (int rc = check_batch(batch)) return rc;
   dim3 grid(ceil_div((uint64_t)1 << m[0].a[0].log_n, 256), total_chunks, batch);
-  KernelTimer kt(PROF_FRI_COMBINE, st, combine_bytes(m[0]) * batch);
-  fri_combine_partial_multi_kernel<<<grid, 256, 0, st>>>(batch_of(m, batch));
+  KernelTimer kt(PROF_FRI_COMBINE, st, combine_bytes(m[0]) * batch, true);
+  BPG_LAUNCH_TIMED(kt, fri_combine_partial_multi_kernel, grid, 256, 0, st, batch_of(m, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -1587,8 +1587,8 @@ int launch_combine_all(const CombineMulti* m, uint32_t batch, uint64_t* const* d
   if (int rc = check_batch(batch)) return rc;
   GPtrs gp{};
   for (uint32_t b = 0; b < batch; b++) gp.g[b] = d_g[b];
-  KernelTimer kt(PROF_FRI_COMBINE, st, combine_bytes(m[0]) * batch);
-  fri_combine_all_kernel<<<dim3(ceil_div((uint64_t)1 << m[0].a[0].log_n, 256), 1, batch), 256, 0, st>>>(batch_of(m, batch), gp);
+  KernelTimer kt(PROF_FRI_COMBINE, st, combine_bytes(m[0]) * batch, true);
+  BPG_LAUNCH_TIMED(kt, fri_combine_all_kernel, dim3(ceil_div((uint64_t)1 << m[0].a[0].log_n, 256), 1, batch), 256, 0, st, batch_of(m, batch), gp);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -1628,8 +1628,8 @@ int launch_fri_fold(const FriLayerArgs* a, uint32_t batch, hipStream_t st) {
   if (int rc = check_batch(batch)) return rc;
   uint64_t n = (uint64_t)1 << (a[0].log_nl - a[0].arity_bits + a[0].rate_bits);
   // 16 M (1 + 1/arity): the layer's M extension values read, M / arity written
-  KernelTimer kt(PROF_FRI_FOLD, st, 16.0 * (double)n * ((1 << a[0].arity_bits) + 1) * batch);
-  fri_fold_kernel<<<dim3(ceil_div(n, 256), 1, batch), 256, 0, st>>>(batch_of(a, batch));
+  KernelTimer kt(PROF_FRI_FOLD, st, 16.0 * (double)n * ((1 << a[0].arity_bits) + 1) * batch, true);
+  BPG_LAUNCH_TIMED(kt, fri_fold_kernel, dim3(ceil_div(n, 256), 1, batch), 256, 0, st, batch_of(a, batch));
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
