@@ -159,6 +159,11 @@ void bp_tune_side_lanes(int on);
  * (bp_host_wait_mode 1), the library's own poll-and-sleep wait where the runtime's would spin (mode 2: a device the
  * process had already used when the library came to it); 1 = always the runtime's wait; 2 = always poll and sleep. */
 void bp_tune_host_wait(int mode);
+/* The CPU permutation of the Fiat-Shamir transcript (K7 stays on the host): 0 (default) = the AVX2 form of the MDS
+ * layer where the CPU has it, 1 = always the scalar form.  Same values either way (tests). */
+void bp_tune_host_poseidon(int mode);
+/* Host only: that permutation over n states of 12 words (any u64 in, canonical out), in place. */
+int bp_debug_poseidon_host(uint64_t* states, size_t n);
 /* Measurement knob: 1 = while the device is loaded the quotient kernel spreads the units of the SYNTHETIC AIR over
  * workgroup rows until the launch has 256 workgroups, as it does for the AIRs of the real tables; 0 (default): one pass. */
 void bp_tune_k5_spread(int on);

@@ -16,13 +16,9 @@ u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("core.c", "stark.c", "proofgen.c", "keccak_air.c", "keccak_air_body.inc",
-                                              "logic_air.c", "logic_air_body.inc", "memory_air.c", "memory_air_body.inc", "arithmetic_air.c", "arithmetic_air_body.inc", "byte_packing_air.c", "byte_packing_air_body.inc", "keccak_sponge_air.c", "keccak_sponge_air_body.inc", "arithmetic_mul_air.c", "arithmetic_mul_air_body.inc", "gl.h", "oracle.h",
-                                              "poseidon_rc.inc", "Makefile")]
-    if (not force and os.path.exists(_LIB_PATH)
-            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs if os.path.exists(s))):
-        return _LIB_PATH
-    subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    """make decides what is stale (the Makefile lists every source and include of liboracle.so): no second list here
+    that an added file could be missing from."""
+    subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []) + ["liboracle.so"], check=True, capture_output=True)
     return _LIB_PATH
 
 

@@ -94,6 +94,14 @@ void KernelTimer::stop() {
   if (!attached) (void)hipEventRecord(e1, st);
   ThreadProf& tp = thread_prof();
   std::lock_guard<std::mutex> lk(tp.mu);
+  if (attached && !launched) {
+    // the scope left before its launch (an early return): the recycled events still hold an EARLIER interval, which
+    // retire() would add to this family -- hand them back unrecorded
+    tp.free_events.push_back(e0);
+    tp.free_events.push_back(e1);
+    e0 = e1 = nullptr;
+    return;
+  }
   tp.pending.push_back(Pending{e0, e1, family, bytes});
   if (tp.pending.size() >= 64) tp.retire(false);
   e0 = e1 = nullptr;

@@ -44,6 +44,7 @@ struct KernelTimer {
   ~KernelTimer();
   void stop();  // record the end now (the destructor then does nothing more)
   bool attached = false;
+  bool launched = false;  // attached: BPG_LAUNCH_TIMED ran (a scope left early has recorded nothing into e0 / e1)
   int family;
   hipStream_t st;
   double bytes;
@@ -53,7 +54,10 @@ struct KernelTimer {
 // one kernel launch inside an attached KernelTimer's scope (KERNEL with template arguments: HIP_KERNEL_NAME(k<a, b>))
 #define BPG_LAUNCH_TIMED(kt, KERNEL, grid, block, lds, st, ...)                                                          \
   do {                                                                                                                  \
-    if ((kt).e0) hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), (uint32_t)(lds), st, (kt).e0, (kt).e1, 0, __VA_ARGS__); \
+    if ((kt).e0) {                                                                                                      \
+      (kt).launched = true;                                                                                             \
+      hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), (uint32_t)(lds), st, (kt).e0, (kt).e1, 0, __VA_ARGS__);    \
+    }                                                                                                                   \
     else KERNEL<<<grid, block, lds, st>>>(__VA_ARGS__);                                                                 \
   } while (0)
 

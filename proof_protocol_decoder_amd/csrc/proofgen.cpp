@@ -656,6 +656,16 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
   if (lookup_bm && given(1) && !given(6))
     return fail(BP_ERR_INVALID_INPUT, "byte-packing sequences are given but the memory log is not: the memory table is looked up by them "
                 "(byte_packing -> memory) and cannot be drawn from the seed");
+  // the mirror cases: a LOOKED table given by the caller while its looking table is drawn from the seed cannot be one
+  // statement with it either (the seeded sponge rows ask for permutations of their own; the seeded packing rows move
+  // words of their own) -- refused here, before seven table proofs are made and check_lookups blames the tables
+  if (lookup_kf && given(3) && !given(4))
+    return fail(BP_ERR_INVALID_INPUT, "Keccak-f permutations are given but the sponge rows are not: with both tables proven by their "
+                "AIRs the sponge table looks the permutations up (keccak_sponge -> keccak_f); give the sponge rows too "
+                "(bp_txn_witness.sponge_rows, bp_keccak256_sponge_rows) or clear the sponge table's AIR flag");
+  if (lookup_bm && given(6) && !given(1))
+    return fail(BP_ERR_INVALID_INPUT, "the memory log is given but the byte-packing sequences are not: the seeded byte-packing table "
+                "looks up operations of its own (byte_packing -> memory); give the sequences too or clear one of the two AIR flags");
   if (lookup_bm && !given(6) && tcfg[6].log_n < tcfg[1].log_n + 1)
     return fail(BP_ERR_INVALID_INPUT, "the memory table (2^%u rows) cannot hold the operations of the byte-packing table (2^%u rows): "
                 "two per row", tcfg[6].log_n, tcfg[1].log_n);

@@ -10,6 +10,9 @@
 #include "prover.hpp"
 #include <algorithm>
 #include <chrono>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <memory>
 #include <thread>
 
@@ -23,25 +26,97 @@ static inline uint64_t sbox_host(uint64_t x) {
   uint64_t x2 = gl::mulc(x, x), x4 = gl::mulc(x2, x2), x3 = gl::mulc(x2, x);
   return gl::mulc(x3, x4);
 }
-void poseidon_host(uint64_t s[12]) {
-  static const uint64_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+// The MDS layer over the 32-bit halves of the state words: the circulant's entries are below 2^6, so the twelve
+// products of a row sum to less than 2^42 per half and the row is  lo_sum + 2^32 hi_sum  reduced once.  (The first
+// version multiplied in 128 bits with a modulo in the index: 8..15 us per permutation, and a transaction's transcripts
+// are ~5,800 sequential permutations on the proving thread.)  The sums vectorise four rows at a time where the CPU
+// has AVX2 (vpmuludq takes the low halves as they lie in the 64-bit lanes); the scalar form is the fallback.
+static const uint32_t MDS_C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+static inline void mds_finish_host(const uint64_t al[12], const uint64_t ah[12], uint64_t s[12]) {
+  for (int r = 0; r < 12; r++) {
+    const uint64_t l = al[r] + (ah[r] << 32);
+    const uint64_t h = (ah[r] >> 32) + (l < al[r]);
+    s[r] = gl::canon(gl::reduce128(l, h));
+  }
+}
+static inline void mds_host_scalar(uint64_t s[12]) {
+  uint32_t lo[24], hi[24];
+  for (int i = 0; i < 12; i++) {
+    lo[i] = lo[i + 12] = (uint32_t)s[i];
+    hi[i] = hi[i + 12] = (uint32_t)(s[i] >> 32);
+  }
+  uint64_t al[12], ah[12];
+  for (int r = 0; r < 12; r++) {
+    uint64_t a = 0, b = 0;
+    for (int i = 0; i < 12; i++) {
+      a += (uint64_t)lo[i + r] * MDS_C[i];
+      b += (uint64_t)hi[i + r] * MDS_C[i];
+    }
+    al[r] = a;
+    ah[r] = b;
+  }
+  al[0] += (uint64_t)lo[0] * 8;
+  ah[0] += (uint64_t)hi[0] * 8;
+  mds_finish_host(al, ah, s);
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static inline void mds_host_avx2(uint64_t s[12]) {
+  alignas(32) uint64_t w[24], h[24];
+  for (int i = 0; i < 12; i++) {
+    w[i] = w[i + 12] = s[i];
+    h[i] = h[i + 12] = s[i] >> 32;
+  }
+  __m256i al[3], ah[3];
+  for (int v = 0; v < 3; v++) al[v] = ah[v] = _mm256_setzero_si256();
+  for (int i = 0; i < 12; i++) {
+    const __m256i c = _mm256_set1_epi64x(MDS_C[i]);
+    for (int v = 0; v < 3; v++) {
+      al[v] = _mm256_add_epi64(al[v], _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(w + i + 4 * v)), c));
+      ah[v] = _mm256_add_epi64(ah[v], _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(h + i + 4 * v)), c));
+    }
+  }
+  alignas(32) uint64_t a[12], b[12];
+  for (int v = 0; v < 3; v++) {
+    _mm256_store_si256((__m256i*)(a + 4 * v), al[v]);
+    _mm256_store_si256((__m256i*)(b + 4 * v), ah[v]);
+  }
+  a[0] += (uint64_t)(uint32_t)s[0] * 8;
+  b[0] += (s[0] >> 32) * 8;
+  mds_finish_host(a, b, s);
+}
+#endif
+template <bool AVX2>
+__attribute__((always_inline)) static inline void poseidon_host_body(uint64_t s[12]) {
+  auto mds = [](uint64_t* st) {
+#if defined(__x86_64__)
+    if (AVX2) return mds_host_avx2(st);
+#endif
+    mds_host_scalar(st);
+  };
   int rnd = 0;
+  for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
   for (int phase = 0; phase < 3; phase++) {
     const int n_rounds = phase == 1 ? 22 : 4;
     for (int k = 0; k < n_rounds; k++, rnd++) {
-      for (int i = 0; i < 12; i++) s[i] = gl::addc(gl::canon(s[i]), RC_HOST[rnd * 12 + i]);
+      for (int i = 0; i < 12; i++) s[i] = gl::addc(s[i], RC_HOST[rnd * 12 + i]);
       if (phase == 1) s[0] = sbox_host(s[0]);
       else for (int i = 0; i < 12; i++) s[i] = sbox_host(s[i]);
-      uint64_t o[12];
-      for (int r = 0; r < 12; r++) {
-        unsigned __int128 acc = 0;
-        for (int i = 0; i < 12; i++) acc += (unsigned __int128)s[(i + r) % 12] * C[i];
-        if (r == 0) acc += (unsigned __int128)s[0] * 8;
-        o[r] = gl::canon(gl::reduce128((uint64_t)acc, (uint64_t)(acc >> 64)));
-      }
-      std::memcpy(s, o, sizeof(o));
+      mds(s);
     }
   }
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void poseidon_host_avx2(uint64_t s[12]) { poseidon_host_body<true>(s); }
+#endif
+static void poseidon_host_scalar(uint64_t s[12]) { poseidon_host_body<false>(s); }
+static std::atomic<int> g_host_poseidon{0};  // bp_tune_host_poseidon: 0 = by the CPU, 1 = scalar form (tests)
+void tune_host_poseidon(int mode) { g_host_poseidon.store(mode == 1 ? 1 : 0); }
+void poseidon_host(uint64_t s[12]) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2 && g_host_poseidon.load(std::memory_order_relaxed) == 0) return poseidon_host_avx2(s);
+#endif
+  poseidon_host_scalar(s);
 }
 void hash_no_pad_host(const uint64_t* in, size_t len, uint64_t out[4]) {
   uint64_t s[12] = {0};

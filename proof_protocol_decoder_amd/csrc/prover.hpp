@@ -167,6 +167,7 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t batch, const Comm
                       std::vector<uint64_t>* proofs, const LookupHint* hints = nullptr);
 
 void tune_host_wait(int mode);  // bp_tune_host_wait
+void tune_host_poseidon(int mode);  // bp_tune_host_poseidon
 // hash_kernels.hip: +1 / -1 as a prover starts / finishes (the Poseidon kernel choice follows the load)
 void prover_active(int delta);
 int provers_active();  // how many are at work right now

@@ -72,6 +72,14 @@ extern "C" {
 void bp_free_buffer(uint8_t* buf) { std::free(buf); }
 void bp_tune_k5_spread(int on) { bpg::g_k5_spread_all.store(on != 0); }
 void bp_tune_host_wait(int mode) { bpg::tune_host_wait(mode); }
+void bp_tune_host_poseidon(int mode) { bpg::tune_host_poseidon(mode); }
+// Host only: the transcript's CPU permutation (prover.cpp, poseidon_host) over n states of 12 words, in place.
+int bp_debug_poseidon_host(uint64_t* states, size_t n) try {
+  if (!states && n) return bpg::fail(BP_ERR_INVALID_INPUT, "bp_debug_poseidon_host: null states");
+  for (size_t i = 0; i < n; i++) bpg::poseidon_host(states + 12 * i);
+  return BP_OK;
+}
+BPG_ABI_CATCH("bp_debug_poseidon_host")
 
 void bp_release_cached_memory(void) {
   std::vector<Worker*> all;

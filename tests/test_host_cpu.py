@@ -96,6 +96,34 @@ def test_product_cpu_verifier_accepts_oracle_proofs_and_rejects_corruption(cpu_c
     assert kind == 2 and pv.block_number == 7 and pv.txn_number_after == 2
 
 
+def test_host_transcript_permutation_matches_the_oracle_in_both_forms(oracle):
+    """poseidon_host (prover.cpp: the challenger's CPU permutation, MDS over 32-bit halves, AVX2 where the CPU has it)
+    against the oracle's permutation on random, edge and non-canonical states, in the automatic and the scalar form."""
+    import ctypes as C
+    import proof_protocol_decoder_amd as pkg
+    L = pkg.lib()
+    L.bp_debug_poseidon_host.argtypes = [C.c_void_p, C.c_size_t]
+    L.bp_tune_host_poseidon.argtypes = [C.c_int]
+    P = 0xFFFFFFFF00000001
+    rng = np.random.default_rng(5)
+    states = rng.integers(0, 2**64, size=(257, 12), dtype=np.uint64)
+    edge = np.array([0, 1, P - 1, P, P + 1, 2**32 - 1, 2**32, 2**64 - 1, 2**63, 0xFFFFFFFF, 0xFFFFFFFF00000000, 7], dtype=np.uint64)
+    states[0] = 0
+    states[1] = edge
+    states[2] = np.uint64(2**64 - 1)
+    states[3] = np.uint64(P - 1)
+    want = oracle.poseidon(states % np.uint64(P))
+    try:
+        for mode in (0, 1):
+            L.bp_tune_host_poseidon(mode)
+            got = states.copy()
+            assert L.bp_debug_poseidon_host(got.ctypes.data, got.shape[0]) == 0
+            assert (got == want).all(), "host permutation differs from the oracle (form %d)" % mode
+    finally:
+        L.bp_tune_host_poseidon(0)
+    assert [hex(int(x)) for x in want[0][:2]] == ["0x3c18a9786cb0b359", "0xc4055e3364a246c3"]   # SURVEY.md appendix A, recalled KAT
+
+
 def test_shard_bounds_are_contiguous_and_balanced():
     from proof_protocol_decoder_amd.block_driver import shard_bounds
     for n, w in [(256, 8), (256, 1), (10, 4), (7, 7), (1024, 8), (5, 2)]:
