@@ -426,6 +426,8 @@ uint64_t bp_state_device_bytes(const bp_state* s);
  * serialise; export GPU_MAX_HW_QUEUES >= n_workers (bench.py: 32) before the process's first HIP call.  (2) The
  * host-wait mode the device was left in (bp_host_wait_mode 2: the library's own poll-and-sleep wait is in use). */
 const char* bp_state_warnings(const bp_state* s);
+/* the configuration the state was built with */
+int bp_state_config(const bp_state* s, bp_config* out);
 
 /* abort_flag: nullable; polled between kernel stages (Option<Arc<AtomicBool>>, proof_gen.rs:42). */
 int bp_generate_txn_proof(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile int32_t* abort_flag,
@@ -472,6 +474,13 @@ int bp_generate_txn_proof_witness(const bp_state* s, const uint8_t* ir, size_t i
 int bp_generate_txn_table_proofs(const bp_state* s, const uint8_t* ir, size_t ir_len, const bp_txn_witness* data,
                                  const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len);
 int bp_verify_txn_table_proofs(const bp_config* cfg, const uint8_t* table_proofs, size_t len);
+/* The same with the STATEMENT fixed by the verifier, as upstream's verify_proof has it (all_stark is the verifier's): ir
+ * = the transaction's IR; a table whose header names another AIR, height or width than the IR does (e.g. a Keccak-f
+ * table relabelled as synthetic, which would drop its constraints and both of its lookups), or public values other than
+ * the IR's, is BP_ERR_VERIFY.  bp_verify_txn_table_proofs alone takes air_id / log_n / n_cols and the public values
+ * from the blob, i.e. from the prover: its caller must compare that header with what it expects. */
+int bp_verify_txn_table_proofs_for(const bp_config* cfg, const uint8_t* ir, size_t ir_len, const uint8_t* table_proofs,
+                                   size_t len);
 /* the same call taking the reference's own flag: Arc<AtomicBool> is ONE byte, `flag.as_ptr()` binds here directly */
 int bp_generate_txn_proof_u8(const bp_state* s, const uint8_t* ir, size_t ir_len, const volatile uint8_t* abort_flag,
                              uint8_t** out, size_t* out_len);
@@ -581,6 +590,79 @@ int bp_keccak256_sponge_rows(const uint8_t* data, size_t len, uint8_t digest_out
  * Release with bp_free_buffer.
  * ------------------------------------------------------------------------------------------ */
 int bp_decode_block_trace(const uint8_t* trace, size_t len, uint8_t** out, size_t* out_len);
+
+/* ------------------------------------------------------------------------------------------
+ * GenerationInputs as the prover's input (csrc/gi.cpp).  The reference's generate_txn_proof consumes
+ * TxnProofGenIR = GenerationInputs (plonky_block_proof_gen/src/proof_gen.rs:39-43, protocol_decoder/src/types.rs:48,
+ * fields as populated at decoding.rs:131-145): ONE entry of what BlockTrace::into_txn_proof_gen_ir emits.  Here: one
+ * entry of a "BPGGENI1" buffer (bp_decode_block_trace; a host holding a single GenerationInputs wraps it as a
+ * one-entry buffer).  The library derives the 25-word IR -- txn number, gas and the state-root public
+ * value threaded entry to entry (bp_gi_chain: what the entries before left; decoding.rs:106-154 threads the same
+ * three), the witness seed = Keccak-256(signed_txn | trie roots after | withdrawals) -- and, for the tables proven
+ * with their AIRs, the witness of the entry's OWN hashing work: Keccak-256 of signed_txn and of every contract_code
+ * entry (and of the hash-referenced nodes of its partial tries) as Keccak-f permutations, sponge rows, and the
+ * memory log / byte-packing sequences of the same bytes (AIRS.md section 3).  Table heights grow to hold that work.
+ * ------------------------------------------------------------------------------------------ */
+#define BP_GI_KECCAK_AIR 1u         /* table 3 proven with the Keccak-f AIR over the entry's hashing work */
+#define BP_GI_KECCAK_TRIE_NODES 2u  /* ... which includes the hashing of the entry's partial tries */
+#define BP_GI_MEMORY_AIR 4u         /* table 6: the memory log of the hashed bytes */
+#define BP_GI_BYTE_PACKING_AIR 8u   /* table 1: the byte-packing sequences of the hashed bytes */
+#define BP_GI_KECCAK_SPONGE_AIR 16u /* table 4: the sponge rows absorbing the same strings */
+typedef struct bp_gi_options {
+  uint64_t block_number;
+  uint32_t table_log_n[BP_NUM_TABLES];  /* base heights (the tables that hold given work grow beyond them as needed) */
+  uint32_t table_width[BP_NUM_TABLES];  /* widths of the tables that stay synthetic */
+  uint32_t flags;                       /* BP_GI_* */
+} bp_gi_options;
+typedef struct bp_gi_chain {            /* where an entry starts: what the entries before it left */
+  uint64_t txn_number, gas_used, state_root[4];
+} bp_gi_chain;
+int bp_gi_count(const uint8_t* geni, size_t len, uint32_t* n_entries);
+/* chain before entry 0: counters 0, state root = the first entry's state-trie root folded into four field elements */
+int bp_gi_chain_start(const uint8_t* geni, size_t len, bp_gi_chain* chain);
+/* the IR of entry `entry` given the chain before it (heights as the prover will use them); *chain moves past the entry */
+int bp_gi_entry_ir(const uint8_t* geni, size_t len, uint32_t entry, const bp_gi_options* opt, bp_gi_chain* chain,
+                   uint64_t ir_out[BP_IR_WORDS]);
+/* generate_txn_proof(&ProverState, GenerationInputs, Option<Arc<AtomicBool>>): entry `entry`, the chain before it in
+ * *chain (moved past the entry on success).  abort_flag as in bp_generate_txn_proof_u8. */
+int bp_generate_txn_proof_gi(const bp_state* s, const uint8_t* geni, size_t len, uint32_t entry, const bp_gi_options* opt,
+                             bp_gi_chain* chain, const volatile uint8_t* abort_flag, uint8_t** out, size_t* out_len);
+
+/* ------------------------------------------------------------------------------------------
+ * The shard scheduler (csrc/gi.cpp): all txn proofs of a CONTIGUOUS slice (aggregation needs contiguous ranges,
+ * proof_types.rs:23-24) and its aggregation tree on a pool of threads; every aggregation starts the moment both of its
+ * children exist and goes AHEAD of the transactions still waiting for a thread.  The reference leaves this to its
+ * scheduler (docs/usage_seq_diagrams.md:8-20); bench.py's headline rate is measured through bp_prove_shard.
+ * bp_aggregation_plan: entry k = node n + k = (left, right) node ids, leaves are 0..n-1, the last entry is the root;
+ *   shape 0 = balanced (adjacent pairs level by level, an odd tail carried up), 1 = pairs then a left-to-right chain.
+ *   pairs: room for 2 (n - 1) ids or NULL; returns n - 1, or UINT32_MAX for n = 0 / an unknown shape.
+ * bp_run_shard: the scheduler over caller-supplied work (how the CPU tests drive it, and how a host with another
+ *   prover behind the same tree would): leaf(ctx, i) makes leaf i, agg(ctx, ...) merges two children; buffers are
+ *   malloc()ed by the callee and owned by the scheduler.  root_out: the slice's one proof (the leaf itself when
+ *   n = 1).  leaf_out / leaf_len: NULL, or room for n pointers / lengths -- the leaves are then handed to the caller
+ *   too (each released with bp_free_buffer).  The first failing node ends the call with its status and message.
+ * n_threads = 0: the state's n_workers (bp_run_shard: 1). */
+typedef struct bp_shard_options {
+  uint32_t n_threads;
+  uint32_t tree_shape;
+} bp_shard_options;
+typedef int (*bp_shard_leaf_fn)(void* ctx, uint32_t index, uint8_t** out, size_t* out_len);
+typedef int (*bp_shard_agg_fn)(void* ctx, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg, const uint8_t* rhs, size_t rhs_len,
+                               int rhs_is_agg, uint8_t** out, size_t* out_len);
+uint32_t bp_aggregation_plan(uint32_t n, uint32_t shape, uint32_t* pairs);
+int bp_run_shard(uint32_t n, const bp_shard_options* opt, bp_shard_leaf_fn leaf, bp_shard_agg_fn agg, void* ctx,
+                 const volatile uint8_t* abort_flag, uint8_t** root_out, size_t* root_len, uint8_t** leaf_out, size_t* leaf_len);
+/* irs: n IRs, ir_stride bytes apart (>= BP_IR_WORDS * 8) */
+int bp_prove_shard(const bp_state* s, const uint8_t* irs, size_t ir_stride, uint32_t n, const bp_shard_options* opt,
+                   const volatile uint8_t* abort_flag, uint8_t** root_out, size_t* root_len, uint8_t** txn_out, size_t* txn_len);
+/* n proofs made elsewhere (txn or aggregation proofs, contiguous in this order: the sub-block proofs gathered from the
+ * other ranks) folded into one along the same plan */
+int bp_aggregate_proofs(const bp_state* s, const uint8_t* const* proofs, const size_t* lens, uint32_t n, const bp_shard_options* opt,
+                        uint8_t** out, size_t* out_len);
+/* entries [first, first + n) of a decoded block */
+int bp_prove_shard_gi(const bp_state* s, const uint8_t* geni, size_t len, uint32_t first, uint32_t n, const bp_gi_options* gi,
+                      const bp_shard_options* opt, const volatile uint8_t* abort_flag, uint8_t** root_out, size_t* root_len,
+                      uint8_t** txn_out, size_t* txn_len);
 
 /* state root after one synthetic txn (host-side helper for building a chain of IRs) */
 int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_number, uint64_t out[4]);

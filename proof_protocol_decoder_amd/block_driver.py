@@ -20,10 +20,14 @@ def shard_bounds(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+TREE_SHAPES = {"balanced": 0, "pairs_then_chain": 1}
+
+
 def aggregation_plan(n, shape="balanced"):
     """The aggregation tree over n contiguous leaves (nodes 0 .. n-1): a list of (left, right) node ids, entry k being
-    node n + k; the last entry is the root.  Aggregation needs contiguous ranges (proof_types.rs:23-24) and nothing
-    else, the reference leaves the order to its scheduler (docs/usage_seq_diagrams.md:8-20).
+    node n + k; the last entry is the root (bp_aggregation_plan, csrc/gi.cpp).  Aggregation needs contiguous ranges
+    (proof_types.rs:23-24) and nothing else, the reference leaves the order to its scheduler
+    (docs/usage_seq_diagrams.md:8-20).
 
     "balanced" (the default): adjacent pairs level by level, an odd tail carried up.
     "pairs_then_chain": adjacent leaves are paired and the pair results folded left to right, ((p0 p1) p2) p3 ...
@@ -34,31 +38,78 @@ def aggregation_plan(n, shape="balanced"):
     (bench.py --tree-shape)."""
     if n < 1:
         raise ValueError("nothing to aggregate")
-    plan = []
-    if shape == "balanced":
-        level = list(range(n))
-        while len(level) > 1:
-            nxt = []
-            for k in range(0, len(level) - 1, 2):
-                plan.append((level[k], level[k + 1]))
-                nxt.append(n + len(plan) - 1)
-            if len(level) % 2:
-                nxt.append(level[-1])
-            level = nxt
-        return plan
-    if shape != "pairs_then_chain":
+    if shape not in TREE_SHAPES:
         raise ValueError("unknown tree shape %r" % (shape,))
-    heads = []
-    for k in range(0, n - 1, 2):
-        plan.append((k, k + 1))
-        heads.append(n + len(plan) - 1)
-    if n % 2:
-        heads.append(n - 1)
-    acc = heads[0]
-    for h in heads[1:]:
-        plan.append((acc, h))
-        acc = n + len(plan) - 1
-    return plan
+    import ctypes as C
+    L = pg._bind()
+    L.bp_aggregation_plan.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.bp_aggregation_plan.restype = C.c_uint32
+    pairs = (C.c_uint32 * max(2 * (n - 1), 1))()
+    k = L.bp_aggregation_plan(n, TREE_SHAPES[shape], pairs)
+    if k != n - 1:
+        raise ValueError("bp_aggregation_plan refused n = %d, shape %r" % (n, shape))
+    return [(pairs[2 * i], pairs[2 * i + 1]) for i in range(k)]
+
+
+def run_shard(n, n_threads, shape, leaf_fn, agg_fn):
+    """bp_run_shard (csrc/gi.cpp) over Python callables: the library's scheduler decides what runs when -- every
+    aggregation the moment both of its children exist, AHEAD of the leaves still waiting for a thread -- and the
+    callables do the work (leaf_fn(i) -> proof, agg_fn(lhs, rhs) -> proof; any Python objects: the buffers that travel
+    through the scheduler carry node ids).  Returns (root, [leaves]).  The first exception raised by a callable ends
+    the run and is re-raised."""
+    import ctypes as C
+    import itertools
+    import threading
+    L = pg._bind()
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+    u8pp, szp = C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)
+    LEAF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, u8pp, szp)
+    AGG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, u8pp, szp)
+    results, errors, lock, ids = {}, [], threading.Lock(), itertools.count(n)
+
+    def emit(nid, value, out, out_len):
+        with lock:
+            results[nid] = value
+        buf = libc.malloc(8)
+        C.memmove(buf, nid.to_bytes(8, "little"), 8)
+        out[0] = C.cast(buf, C.POINTER(C.c_uint8))
+        out_len[0] = 8
+
+    def guarded(f):
+        def g(*a):
+            try:
+                return f(*a)
+            except BaseException as e:   # surface the first failure to the caller
+                with lock:
+                    errors.append(e)
+                return -4
+        return g
+
+    @guarded
+    def leaf(_ctx, i, out, out_len):
+        emit(i, leaf_fn(i), out, out_len)
+        return 0
+
+    @guarded
+    def agg(_ctx, l, _ln, _la, r, _rn, _ra, out, out_len):
+        li, ri = int.from_bytes(C.string_at(l, 8), "little"), int.from_bytes(C.string_at(r, 8), "little")
+        with lock:
+            a, b = results[li], results[ri]
+        emit(next(ids), agg_fn(a, b), out, out_len)
+        return 0
+
+    class Opt(C.Structure):
+        _fields_ = [("n_threads", C.c_uint32), ("tree_shape", C.c_uint32)]
+    L.bp_run_shard.argtypes = [C.c_uint32, C.POINTER(Opt), LEAF, AGG, C.c_void_p, C.c_void_p, u8pp, szp, C.c_void_p, C.c_void_p]
+    root, root_len = C.POINTER(C.c_uint8)(), C.c_size_t()
+    opt = Opt(max(1, n_threads), TREE_SHAPES[shape])
+    rc = L.bp_run_shard(n, C.byref(opt), LEAF(leaf), AGG(agg), None, None, C.byref(root), C.byref(root_len), None, None)
+    if errors:
+        raise errors[0]
+    pg.check(rc)
+    top = results[int.from_bytes(pg.take_buffer(root, root_len), "little")]
+    return top, [results[i] for i in range(n)]
 
 
 def tree_reduce(proofs, agg_fn, pool=None, shape="balanced"):
@@ -129,6 +180,8 @@ class BlockDriver:
         self.n_threads = n_threads
         self.tree_shape = tree_shape   # of a shard's local tree (aggregation_plan)
         self.pool = ThreadPoolExecutor(n_threads) if n_threads > 1 else None
+        # the HIP prover state when no callable overrides it: prove_shard then runs inside the library (bp_prove_shard)
+        self._native = p_state if (p_state is not None and prove_txn is None and prove_agg is None) else None
         self.prove_txn = prove_txn or (lambda ir: pg.generate_txn_proof(p_state, ir))
         self.prove_agg = prove_agg or (lambda a, b: pg.generate_agg_proof(p_state, a, b))
         self.prove_block = prove_block or (lambda parent, agg: pg.generate_block_proof(p_state, parent, agg))
@@ -142,63 +195,77 @@ class BlockDriver:
     def prove_shard(self, irs, shape=None):
         """All txn proofs of a contiguous slice and its local aggregation tree (aggregation_plan).  Every aggregation
         starts the moment both of its children exist and goes AHEAD of the transactions still waiting for a thread,
-        so the tree advances with the proving instead of piling up behind it."""
+        so the tree advances with the proving instead of piling up behind it.  The policy is the library's
+        (csrc/gi.cpp): bp_prove_shard when this driver binds the HIP prover and the IRs carry no witness data of their
+        own, else bp_run_shard over this driver's callables."""
         n = len(irs)
         shape = shape or self.tree_shape
-        if self.pool is None or n < 2:
-            txn_proofs = [self.prove_txn(ir) for ir in irs]
-            return tree_reduce(txn_proofs, self.prove_agg, None, shape), txn_proofs
-        import heapq
-        import threading
-        plan = aggregation_plan(n, shape)
-        parent_of = {}
-        for k, (l, r) in enumerate(plan):
-            parent_of[l] = parent_of[r] = n + k
-        root = n + len(plan) - 1
-        results, errors = {}, []
-        cond = threading.Condition()
-        # (priority, node id): aggregations (0) before transactions (1), each kind in index order
-        queue = [(1, i) for i in range(n)]
-        heapq.heapify(queue)
-        state = {"stop": False}
+        if n < 1:
+            raise ValueError("nothing to aggregate")
+        if self._native is not None and all(isinstance(ir, (bytes, pg.TxnProofGenIR)) and getattr(ir, "witness", None) is None
+                                            and getattr(ir, "keccak_inputs", None) is None for ir in irs):
+            return self._prove_shard_native(irs, shape)
+        return run_shard(n, self.n_threads if n > 1 else 1, shape, lambda i: self.prove_txn(irs[i]), self.prove_agg)
 
-        def finish(nid, value):
-            with cond:
-                results[nid] = value
-                par = parent_of.get(nid)
-                if par is not None and plan[par - n][0] in results and plan[par - n][1] in results:
-                    heapq.heappush(queue, (0, par))
-                if nid == root:
-                    state["stop"] = True
-                cond.notify_all()
+    def _prove_shard_native(self, irs, shape):
+        import ctypes as C
+        L = pg._bind()
+        raw = b"".join(ir.to_bytes() if isinstance(ir, pg.TxnProofGenIR) else bytes(ir) for ir in irs)
+        n = len(irs)
 
-        def worker():
-            while True:
-                with cond:
-                    while not queue and not state["stop"]:
-                        cond.wait()
-                    if state["stop"]:
-                        return
-                    _, nid = heapq.heappop(queue)
-                try:
-                    if nid < n:
-                        finish(nid, self.prove_txn(irs[nid]))
-                    else:
-                        l, r = plan[nid - n]
-                        finish(nid, self.prove_agg(results[l], results[r]))
-                except BaseException as e:  # surface the first failure to the caller
-                    with cond:
-                        errors.append(e)
-                        state["stop"] = True
-                        cond.notify_all()
-                    return
+        class Opt(C.Structure):
+            _fields_ = [("n_threads", C.c_uint32), ("tree_shape", C.c_uint32)]
+        u8p = C.POINTER(C.c_uint8)
+        L.bp_prove_shard.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(Opt), C.c_void_p,
+                                     C.POINTER(u8p), C.POINTER(C.c_size_t), C.POINTER(u8p), C.POINTER(C.c_size_t)]
+        root, root_len = u8p(), C.c_size_t()
+        leaves, lens = (u8p * n)(), (C.c_size_t * n)()
+        opt = Opt(self.n_threads, TREE_SHAPES[shape])
+        pg.check(L.bp_prove_shard(self._native._h, raw, len(raw) // n, n, C.byref(opt), None, C.byref(root), C.byref(root_len),
+                                  leaves, lens))
+        txns = [self._decode(pg.take_buffer(leaves[i], C.c_size_t(lens[i]))) for i in range(n)]
+        return self._decode(pg.take_buffer(root, root_len)), txns
 
-        futures = [self.pool.submit(worker) for _ in range(min(self.n_threads, n))]
-        for f in futures:
-            f.result()
-        if errors:
-            raise errors[0]
-        return results[root], [results[i] for i in range(n)]
+    def _aggregate_native(self, subs):
+        """the top of the block's tree over proofs made elsewhere (bp_aggregate_proofs)"""
+        import ctypes as C
+        if len(subs) == 1:
+            return subs[0]
+        L = pg._bind()
+
+        class Opt(C.Structure):
+            _fields_ = [("n_threads", C.c_uint32), ("tree_shape", C.c_uint32)]
+        n = len(subs)
+        raws = [bytes(p.intern) for p in subs]
+        ptrs = (C.c_char_p * n)(*raws)
+        lens = (C.c_size_t * n)(*[len(r) for r in raws])
+        L.bp_aggregate_proofs.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_uint32, C.POINTER(Opt),
+                                          C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        out, out_len = C.POINTER(C.c_uint8)(), C.c_size_t()
+        opt = Opt(self.n_threads, 0)
+        pg.check(L.bp_aggregate_proofs(self._native._h, ptrs, lens, n, C.byref(opt), C.byref(out), C.byref(out_len)))
+        return self._decode(pg.take_buffer(out, out_len))
+
+    def prove_shard_gi(self, geni, first, n, gi_options, shape=None):
+        """The same for entries [first, first + n) of a decoded block ("BPGGENI1" bytes, decoding.into_txn_proof_gen_ir
+        raw form): bp_prove_shard_gi derives every entry's IR and witness in the library (csrc/gi.cpp).
+        gi_options: a GiOptions."""
+        import ctypes as C
+        L = pg._bind()
+
+        class Opt(C.Structure):
+            _fields_ = [("n_threads", C.c_uint32), ("tree_shape", C.c_uint32)]
+        u8p = C.POINTER(C.c_uint8)
+        L.bp_prove_shard_gi.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(GiOptions),
+                                        C.POINTER(Opt), C.c_void_p, C.POINTER(u8p), C.POINTER(C.c_size_t), C.POINTER(u8p),
+                                        C.POINTER(C.c_size_t)]
+        root, root_len = u8p(), C.c_size_t()
+        leaves, lens = (u8p * max(n, 1))(), (C.c_size_t * max(n, 1))()
+        opt = Opt(self.n_threads, TREE_SHAPES[shape or self.tree_shape])
+        pg.check(L.bp_prove_shard_gi(self._native._h, geni, len(geni), first, n, C.byref(gi_options), C.byref(opt), None,
+                                     C.byref(root), C.byref(root_len), leaves, lens))
+        txns = [self._decode(pg.take_buffer(leaves[i], C.c_size_t(lens[i]))) for i in range(n)]
+        return self._decode(pg.take_buffer(root, root_len)), txns
 
     def prove_block_distributed(self, irs, rank=0, world_size=1, gather=None, parent=None):
         """Returns the GeneratedBlockProof on rank 0, None elsewhere.
@@ -230,7 +297,7 @@ class BlockDriver:
             subs = [sub] if sub is not None else []
         if not subs:
             raise ValueError("a block needs at least two transactions (decoding.rs:304-347 pads to >= 2)")
-        top = tree_reduce(subs, self.prove_agg, self.pool)
+        top = self._aggregate_native(subs) if self._native is not None else tree_reduce(subs, self.prove_agg, self.pool)
         if not isinstance(top, pg.GeneratedAggProof):
             raise ValueError("a block needs at least two transactions (decoding.rs:304-347 pads to >= 2)")
         return self.prove_block(parent, top)
@@ -397,6 +464,71 @@ def memory_and_byte_packing_work_of_preimages(preimages):
                         + [int.from_bytes(padded[8 * w:8 * w + 8], "little") for w in range(4)])
             addr += 1
     return log, seqs
+
+
+import ctypes as _C
+
+
+class GiOptions(_C.Structure):
+    """bp_gi_options (include/bpg.h)"""
+    _fields_ = [("block_number", _C.c_uint64), ("table_log_n", _C.c_uint32 * 7), ("table_width", _C.c_uint32 * 7),
+                ("flags", _C.c_uint32)]
+    KECCAK_AIR, KECCAK_TRIE_NODES, MEMORY_AIR, BYTE_PACKING_AIR, KECCAK_SPONGE_AIR = 1, 2, 4, 8, 16
+
+    @staticmethod
+    def make(block_number, table_log_n, table_width, keccak_air=False, keccak_trie_nodes=False, memory_air=False,
+             byte_packing_air=False, keccak_sponge_air=False):
+        return GiOptions(block_number, (_C.c_uint32 * 7)(*table_log_n), (_C.c_uint32 * 7)(*table_width),
+                         (1 if keccak_air else 0) | (2 if keccak_trie_nodes else 0) | (4 if memory_air else 0)
+                         | (8 if byte_packing_air else 0) | (16 if keccak_sponge_air else 0))
+
+
+class GiChain(_C.Structure):
+    """bp_gi_chain (include/bpg.h): txn number, gas and state root where an entry starts"""
+    _fields_ = [("txn_number", _C.c_uint64), ("gas_used", _C.c_uint64), ("state_root", _C.c_uint64 * 4)]
+
+
+def gi_irs(geni, gi_options):
+    """The 25-word IRs of every entry of a decoded block as the library derives them (bp_gi_chain_start, bp_gi_entry_ir):
+    what irs_from_generation_inputs computes in Python, as bytes."""
+    L = pg._bind()
+    n = _C.c_uint32()
+    L.bp_gi_count.argtypes = [_C.c_char_p, _C.c_size_t, _C.POINTER(_C.c_uint32)]
+    L.bp_gi_chain_start.argtypes = [_C.c_char_p, _C.c_size_t, _C.POINTER(GiChain)]
+    L.bp_gi_entry_ir.argtypes = [_C.c_char_p, _C.c_size_t, _C.c_uint32, _C.POINTER(GiOptions), _C.POINTER(GiChain),
+                                 _C.POINTER(_C.c_uint64)]
+    pg.check(L.bp_gi_count(geni, len(geni), _C.byref(n)))
+    chain = GiChain()
+    pg.check(L.bp_gi_chain_start(geni, len(geni), _C.byref(chain)))
+    out = []
+    for k in range(n.value):
+        ir = (_C.c_uint64 * 25)()
+        pg.check(L.bp_gi_entry_ir(geni, len(geni), k, _C.byref(gi_options), _C.byref(chain), ir))
+        out.append(bytes(ir))
+    return out
+
+
+def generate_txn_proof_gi(p_state, geni, entry, gi_options, chain, abort_signal=None):
+    """generate_txn_proof(&ProverState, GenerationInputs, abort) (proof_gen.rs:39-43) for entry `entry` of a decoded
+    block: bp_generate_txn_proof_gi.  chain: a GiChain holding what the entries before left (gi_chain_start for entry
+    0); moved past the entry."""
+    L = pg._bind()
+    out, n = pg._out()
+    L.bp_generate_txn_proof_gi.argtypes = [_C.c_void_p, _C.c_char_p, _C.c_size_t, _C.c_uint32, _C.POINTER(GiOptions),
+                                           _C.POINTER(GiChain), _C.c_void_p, _C.POINTER(_C.POINTER(_C.c_uint8)),
+                                           _C.POINTER(_C.c_size_t)]
+    pg.check(L.bp_generate_txn_proof_gi(p_state._h, geni, len(geni), entry, _C.byref(gi_options), _C.byref(chain),
+                                        _C.byref(abort_signal) if abort_signal is not None else None, _C.byref(out), _C.byref(n)))
+    intern = pg.take_buffer(out, n)
+    return pg.GeneratedTxnProof(pg.public_values_of(intern)[0], intern)
+
+
+def gi_chain_start(geni):
+    L = pg._bind()
+    L.bp_gi_chain_start.argtypes = [_C.c_char_p, _C.c_size_t, _C.POINTER(GiChain)]
+    chain = GiChain()
+    pg.check(L.bp_gi_chain_start(geni, len(geni), _C.byref(chain)))
+    return chain
 
 
 def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width, keccak_air=False,

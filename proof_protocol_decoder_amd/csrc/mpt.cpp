@@ -301,6 +301,20 @@ static const Bytes& encode(const Node& n) {
   return n.enc;
 }
 
+// The RLP encodings a hasher of the (partial) trie runs Keccak-256 over: every node its parent references by hash (an
+// encoding of 32 bytes or more) and the root whatever its length, children before parents; hashed-out subtrees
+// contribute nothing.  (What a zkEVM's Keccak table holds for this trie; gi.cpp.)
+static void preimages_rec(const NodeP& n, bool is_root, std::vector<Bytes>* out) {
+  if (!n || n->kind == Kind::Empty || n->kind == Kind::Hash) return;
+  if (n->kind == Kind::Branch)
+    for (int i = 0; i < 16; i++) preimages_rec(n->children[i], false, out);
+  else if (n->kind == Kind::Extension)
+    preimages_rec(n->child, false, out);
+  const Bytes& enc = encode(*n);
+  if (is_root || enc.size() >= 32) out->push_back(enc);
+}
+void hashed_node_preimages(const Trie& t, std::vector<Bytes>* out) { preimages_rec(t.root(), true, out); }
+
 Trie::Trie() : root_(make_empty()) {}
 Trie Trie::of_hash(const H256& h) { return Trie(make_hash(h)); }
 

@@ -120,6 +120,8 @@ class Trie {
   NodeP root_;
 };
 
+// every node encoding the trie's hasher runs Keccak-256 over (referenced by hash, or the root), children before parents
+void hashed_node_preimages(const Trie& t, std::vector<Bytes>* out);
 // hex-prefix encoding of a nibble path
 Bytes hex_prefix(const Nibbles& k, bool leaf);
 // node builders (shared with the compact-witness decoder, which builds tries structurally)

@@ -415,6 +415,11 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
 BPG_ABI_CATCH("bp_state_build")
 
 const char* bp_state_warnings(const bp_state* s) { return s ? s->warnings.c_str() : ""; }
+int bp_state_config(const bp_state* s, bp_config* out) {
+  if (!s || !out) return fail(BP_ERR_INVALID_INPUT, "bp_state_config: null argument");
+  *out = s->cfg;
+  return BP_OK;
+}
 
 void bp_state_free(bp_state* s) {
   if (!s) return;
@@ -561,7 +566,7 @@ struct TableProofs {
   Ctl ctl;
   std::vector<uint64_t> proof[BP_NUM_TABLES];
 };
-static int parse_ir(const bp_state* s, const uint64_t* I, const TxnWitness* wit, StarkCfg tcfg[BP_NUM_TABLES],
+static int parse_ir(const bp_config& cfg, const uint64_t* I, const TxnWitness* wit, StarkCfg tcfg[BP_NUM_TABLES],
                     std::vector<uint64_t>* pv_out) {
   // version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520): txn number, gas and state
   // root do not advance, the same tables are proven
@@ -590,7 +595,6 @@ static int parse_ir(const bp_state* s, const uint64_t* I, const TxnWitness* wit,
   }
   if (I[5] < I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: gas_used_after < gas_used_before");
   if (dummy && I[5] != I[4]) return fail(BP_ERR_INVALID_INPUT, "IR: a dummy entry must not use gas (decoding.rs:503-506)");
-  const bp_config& cfg = s->cfg;
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     const uint64_t ln = I[11 + t], wd = I[18 + t];
     if (ln < cfg.table_log_lo[t] || ln >= cfg.table_log_hi[t])
@@ -800,7 +804,7 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   const uint64_t* I = reinterpret_cast<const uint64_t*>(ir);
   const bp_config& cfg = s->cfg;
   TableProofs tp;
-  int r = parse_ir(s, I, wit, tp.tcfg, &tp.pv);
+  int r = parse_ir(s->cfg, I, wit, tp.tcfg, &tp.pv);
   if (r) return r;
   const StarkCfg* tcfg = tp.tcfg;
   const std::vector<uint64_t>& pv = tp.pv;
@@ -931,7 +935,9 @@ BPG_ABI_CATCH("bp_generate_txn_table_proofs")
 // verify_proof(all_stark, all_proof, config) of upstream, on the CPU: every table proof against the shared transcript
 // (trace caps and public values observed, four lookup challenges drawn, then table after table), and the cross-table
 // lookups between the tables that are proven with their AIRs (air::ctl).  cfg supplies the STARK parameters only.
-int bp_verify_txn_table_proofs(const bp_config* cfg, const uint8_t* bytes, size_t len) try {
+// expect (nullable): the statement the caller wants proven -- per table the AIR, height and width, and the public values --
+// as parse_ir derives it from the transaction's IR.  Without it the header of the blob is the PROVER's claim.
+static int verify_table_proofs(const bp_config* cfg, const StarkCfg* expect, const uint64_t* expect_pv, const uint8_t* bytes, size_t len) {
   if (!cfg || !bytes) return fail(BP_ERR_INVALID_INPUT, "bp_verify_txn_table_proofs: null argument");
   if (len % 8 || len < (2 + BP_PV_WORDS + 4) * 8) return fail(BP_ERR_INVALID_INPUT, "table proofs: truncated");
   const uint64_t* W = reinterpret_cast<const uint64_t*>(bytes);
@@ -952,6 +958,10 @@ int bp_verify_txn_table_proofs(const bp_config* cfg, const uint8_t* bytes, size_
       return fail(BP_ERR_VERIFY, "table %s is proven with AIR %llu, which is not that table's", TABLE_NAMES[t], (unsigned long long)air_id);
     tcfg[t] = table_cfg_of(*cfg, (uint32_t)log_n, (uint32_t)n_cols);
     tcfg[t].air_id = (uint32_t)air_id;
+    if (expect && (expect[t].air_id != air_id || expect[t].log_n != log_n || expect[t].n_cols != n_cols))
+      return fail(BP_ERR_VERIFY, "table %s is proven as AIR %llu, 2^%llu rows x %llu columns; the transaction's statement is AIR %u, 2^%u x %u "
+                  "(a relabelled table would drop its constraints and its lookups)", TABLE_NAMES[t], (unsigned long long)air_id,
+                  (unsigned long long)log_n, (unsigned long long)n_cols, expect[t].air_id, expect[t].log_n, expect[t].n_cols);
     int r = check_cfg(tcfg[t]);
     if (r) return r;
     if (pw != proof_layout(tcfg[t]).total || off + pw > n_words) return fail(BP_ERR_INVALID_INPUT, "table proofs: wrong length of table %s", TABLE_NAMES[t]);
@@ -959,6 +969,8 @@ int bp_verify_txn_table_proofs(const bp_config* cfg, const uint8_t* bytes, size_
     off += pw;
   }
   if (off != n_words) return fail(BP_ERR_INVALID_INPUT, "table proofs: trailing words");
+  if (expect_pv && std::memcmp(pv, expect_pv, BP_PV_WORDS * 8) != 0)
+    return fail(BP_ERR_VERIFY, "the public values of the table proofs are not those of the transaction's IR");
   Challenger ch;
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     const ProofLayout L = proof_layout(tcfg[t]);
@@ -979,7 +991,22 @@ int bp_verify_txn_table_proofs(const bp_config* cfg, const uint8_t* bytes, size_
   }
   return check_lookups(tcfg, proof);
 }
+int bp_verify_txn_table_proofs(const bp_config* cfg, const uint8_t* bytes, size_t len) try {
+  return verify_table_proofs(cfg, nullptr, nullptr, bytes, len);
+}
 BPG_ABI_CATCH("bp_verify_txn_table_proofs")
+// verify_proof(all_stark, ...) where the VERIFIER fixes the statement, as upstream's does: which AIR proves each table,
+// the table shapes and the public values come from the transaction's IR, not from the blob.
+int bp_verify_txn_table_proofs_for(const bp_config* cfg, const uint8_t* ir, size_t ir_len, const uint8_t* bytes, size_t len) try {
+  if (!cfg || !ir) return fail(BP_ERR_INVALID_INPUT, "bp_verify_txn_table_proofs_for: null argument");
+  if (ir_len != BP_IR_WORDS * 8) return fail(BP_ERR_INVALID_INPUT, "IR must be %d bytes", BP_IR_WORDS * 8);
+  StarkCfg expect[BP_NUM_TABLES];
+  std::vector<uint64_t> pv;
+  int r = parse_ir(*cfg, reinterpret_cast<const uint64_t*>(ir), nullptr, expect, &pv);
+  if (r) return r;
+  return verify_table_proofs(cfg, expect, pv.data(), bytes, len);
+}
+BPG_ABI_CATCH("bp_verify_txn_table_proofs_for")
 
 int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len, int lhs_is_agg,
                           const uint8_t* rhs, size_t rhs_len, int rhs_is_agg, uint8_t** out, size_t* out_len) try {

@@ -133,6 +133,27 @@ def _parse_ir(r: Reader) -> GenerationInputs:
                             TrieInputs(state, txn, rec, storage), roots, checkpoint, code, meta, hashes)
 
 
+def generation_inputs_bytes(bt: "tp.BlockTrace", other: OtherBlockData, code_table=None) -> bytes:
+    """`BlockTrace::into_txn_proof_gen_ir` as the library emits it: the "BPGGENI1" buffer (include/bpg.h) that
+    bp_generate_txn_proof_gi / bp_prove_shard_gi take as it is."""
+    L = lib()
+    L.bp_decode_block_trace.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    raw = trace_to_binary(bt, other, code_table)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    check(L.bp_decode_block_trace(raw, len(raw), C.byref(out), C.byref(n)))
+    return take_buffer(out, n)
+
+
+def parse_generation_inputs(geni: bytes, with_final_root=False):
+    r = Reader(geni)
+    if r.take(8) != b"BPGGENI1":
+        raise ValueError("bad magic")
+    irs = [_parse_ir(r) for _ in range(r.u32())]
+    final_root = r.take(32)
+    assert r.done()
+    return (irs, final_root) if with_final_root else irs
+
+
 def into_txn_proof_gen_ir(bt: "tp.BlockTrace", other: OtherBlockData, code_table=None, with_final_root=False):
     """`BlockTrace::into_txn_proof_gen_ir(p_meta, other_data)` -> Vec<TxnProofGenIR>.  Raises BpgError
     (code -2) where the reference returns a TraceParsingError or panics on a malformed payload."""

@@ -405,14 +405,21 @@ def generate_txn_table_proofs(p_state, gen_inputs, keccak_inputs=None, witness=N
     return take_buffer(out, n)
 
 
-def verify_txn_table_proofs(cfg, table_proofs):
-    """upstream's verify_proof(all_stark, all_proof, config) on the CPU (bp_verify_txn_table_proofs): every table proof
-    against the shared transcript and the cross-table lookups between the tables proven with their AIRs.  cfg: a
-    BpConfig (ProverState.cfg).  Raises ProofGenError when rejected."""
+def verify_txn_table_proofs(cfg, table_proofs, gen_inputs=None):
+    """upstream's verify_proof(all_stark, all_proof, config) on the CPU: every table proof against the shared transcript
+    and the cross-table lookups between the tables proven with their AIRs.  cfg: a BpConfig (ProverState.cfg).
+    gen_inputs (a TxnProofGenIR or its bytes): the statement -- which AIR proves each table, the shapes, the public
+    values -- is then the verifier's (bp_verify_txn_table_proofs_for); without it the blob's header is taken at its
+    word and the caller must check it.  Raises ProofGenError when rejected."""
     L = _bind()
-    L.bp_verify_txn_table_proofs.argtypes = [C.POINTER(BpConfig), C.c_char_p, C.c_size_t]
     b = bytes(table_proofs)
-    check(L.bp_verify_txn_table_proofs(C.byref(cfg), b, len(b)))
+    if gen_inputs is None:
+        L.bp_verify_txn_table_proofs.argtypes = [C.POINTER(BpConfig), C.c_char_p, C.c_size_t]
+        check(L.bp_verify_txn_table_proofs(C.byref(cfg), b, len(b)))
+        return
+    ir = gen_inputs.to_bytes() if hasattr(gen_inputs, "to_bytes") else bytes(gen_inputs)
+    L.bp_verify_txn_table_proofs_for.argtypes = [C.POINTER(BpConfig), C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    check(L.bp_verify_txn_table_proofs_for(C.byref(cfg), ir, len(ir), b, len(b)))
 
 
 def generate_agg_proof(p_state, lhs_child, rhs_child):

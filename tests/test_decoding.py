@@ -421,6 +421,40 @@ def test_generation_inputs_map_to_prover_irs():
     assert irs2[0].state_root_before == irs[0].state_root_before and all(a.seed != b.seed for a, b in zip(irs, irs2))
 
 
+def test_the_library_derives_the_same_irs_from_generation_inputs_as_the_python_mirror():
+    """csrc/gi.cpp (bp_gi_chain_start / bp_gi_entry_ir, the host half of bp_generate_txn_proof_gi): counters, state-root
+    chain, seeds, grown table heights and AIR flags of every entry of a decoded block, for every combination of options,
+    against block_driver.irs_from_generation_inputs (host only)."""
+    from proof_protocol_decoder_amd.block_driver import GiOptions, gi_irs, irs_from_generation_inputs
+    base_log, base_w = (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8)
+    for wd in ([], [(B, 100)]):
+        m = fresh_model()
+        infos = [t for t, _ in block(m)]
+        other = decoding.OtherBlockData(decoding.BlockLevelData(b"meta", b"hashes", wd), b"\x22" * 32)
+        trace = make_trace(m, infos, hash_out_storage_of=(E,))
+        geni = decoding.generation_inputs_bytes(trace, other)
+        gis = decoding.parse_generation_inputs(geni)
+        for kw in ({}, dict(keccak_air=True), dict(keccak_air=True, keccak_trie_nodes=True),
+                   dict(keccak_air=True, memory_air=True), dict(keccak_air=True, byte_packing_air=True, keccak_sponge_air=True),
+                   dict(keccak_air=True, keccak_trie_nodes=True, memory_air=True, byte_packing_air=True, keccak_sponge_air=True)):
+            want = [ir.to_bytes() for ir in irs_from_generation_inputs(gis, 17, base_log, base_w, **kw)]
+            assert gi_irs(geni, GiOptions.make(17, base_log, base_w, **kw)) == want, kw
+    # a block of one transaction: the prepended dummy carries the counters of its position
+    m = fresh_model()
+    infos = [t for t, _ in block(m)][:1]
+    geni = decoding.generation_inputs_bytes(make_trace(m, infos), decoding.OtherBlockData(decoding.BlockLevelData()))
+    gis = decoding.parse_generation_inputs(geni)
+    assert gis[0].signed_txn is None and gis[1].signed_txn is not None
+    assert gi_irs(geni, GiOptions.make(3, base_log, base_w)) == [ir.to_bytes() for ir in irs_from_generation_inputs(gis, 3, base_log, base_w)]
+    # options that make no sense, and buffers that are not generation inputs, are statuses
+    import ctypes as C
+    with pytest.raises(BpgError, match="needs BP_GI_KECCAK_AIR"):
+        gi_irs(geni, GiOptions.make(3, base_log, base_w, memory_air=True))
+    for bad in (geni[:-1], geni + b"\0", b"BPGGENI2" + geni[8:], geni[:40]):
+        with pytest.raises(BpgError):
+            gi_irs(bad, GiOptions.make(3, base_log, base_w))
+
+
 def test_mutated_payloads_never_crash():
     """Client-supplied bytes: every mutation of a valid "BPGTRAC1" payload must come back as BP_OK or
     BP_ERR_INVALID_INPUT (bpg.h: nothing aborts across the ABI) -- 3000 random byte flips, truncations and

@@ -189,3 +189,30 @@ def test_table_proof_containers_are_bound_to_their_transcript(oracle, o_state, p
     air, log_n, n_cols, first, pw = table_slices(tp)[4]
     with pytest.raises(pg.ProofGenError):
         pg.verify_txn_table_proofs(cfg, tp[:-1].tobytes())
+
+
+def test_a_relabelled_table_is_refused_once_the_verifier_fixes_the_statement(oracle, o_state, product_cfg):
+    """bp_verify_txn_table_proofs reads air_id / log_n / n_cols of every table from the blob -- the prover's
+    word.  A prover that proves the Keccak-f table of a transaction as a SYNTHETIC table drops that table's constraints and
+    the lookup that ties it to the sponge table, and the blob still verifies.  bp_verify_txn_table_proofs_for takes the
+    statement from the transaction's IR (upstream's verifier owns all_stark) and refuses it; so is a blob whose public
+    values are another transaction's."""
+    pg, cfg = product_cfg
+    irb = lambda words: np.array(words, dtype=np.uint64).tobytes()
+    wanted = real_ir({3, 4})                      # the statement: Keccak-f and sponge tables proven with their AIRs
+    honest = o_state.txn_tables(wanted)
+    pg.verify_txn_table_proofs(cfg, honest.tobytes(), gen_inputs=irb(wanted))
+    cheat_ir = real_ir({4})                       # the same transaction with table 3 "proven" as a synthetic table ...
+    cheat_ir[18 + 3] = 2430                       # ... of the Keccak-f table's own width
+    cheat = o_state.txn_tables(cheat_ir)
+    pg.verify_txn_table_proofs(cfg, cheat.tobytes())          # the header is taken at its word: accepted
+    with pytest.raises(pg.ProofGenError, match="table keccak is proven as AIR 0") as e:
+        pg.verify_txn_table_proofs(cfg, cheat.tobytes(), gen_inputs=irb(wanted))
+    assert e.value.code == -5
+    other = real_ir({3, 4})
+    other[3] += 1                                 # another transaction number: other public values
+    with pytest.raises(pg.ProofGenError, match="public values"):
+        pg.verify_txn_table_proofs(cfg, honest.tobytes(), gen_inputs=irb(other))
+    shorter = real_ir({3, 4}, log_n=tuple(x + (1 if t == 3 else 0) for t, x in enumerate(LOG_N)))
+    with pytest.raises(pg.ProofGenError):
+        pg.verify_txn_table_proofs(cfg, honest.tobytes(), gen_inputs=irb(shorter))
