@@ -101,11 +101,11 @@ def main():
     for flag, _, help_ in TUNE_KNOBS:
         ap.add_argument(flag, type=int, default=None, help=help_)
     ap.add_argument("--keccak-air", action="store_true",
-                    help="every transaction's Keccak table is a real Keccak-f[1600] trace (AIR 1, 2430 columns) instead "
+                    help="every transaction's Keccak table is a real Keccak-f[1600] trace (AIR 1, 2431 columns) instead "
                          "of the 2432-column synthetic table BASELINE's metric is quoted on")
     ap.add_argument("--real-airs", action="store_true",
                     help="the arithmetic, byte-packing, Keccak, Keccak-sponge, logic and memory tables of every transaction are "
-                         "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 299 / 2430 / "
+                         "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 299 / 2431 / "
                          "2414 / 523 / 44 columns) instead of synthetic tables of "
                          "BASELINE's widths -- another workload than the metric's, reported as such")
     ap.add_argument("--synthetic-rec", action="store_true",
@@ -312,7 +312,7 @@ def main():
         st.close()
         what = []
         if real_airs:
-            what.append("the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 299 / 2430 / 2414 / 523 / 44 "
+            what.append("the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 299 / 2431 / 2414 / 523 / 44 "
                         "columns), the CPU table synthetic; cross-table lookup keccak_sponge -> keccak_f checked in every txn")
         if synthetic_rec:
             what.append("every recursion-shaped proof a proof of the synthetic AIR (135 x 82 columns, 16 auxiliary columns) "
@@ -426,7 +426,7 @@ def main():
         "config": {"workload": "%d-txn synthetic block, S1 transfer-txn tables logN=%s widths=%s, 7 table STARKs "
                                "+ 22 recursion-shaped proofs per txn, %d agg proofs + 1 block proof per block"
                                % (args.txns, list(S1_LOG_N), list(S1_WIDTH), args.txns - 1),
-                   "keccak_table": "Keccak-f[1600] AIR, 2430 columns" if (args.keccak_air or args.real_airs)
+                   "keccak_table": "Keccak-f[1600] AIR, 2431 columns" if (args.keccak_air or args.real_airs)
                                    else "synthetic AIR, 2432 columns",
                    "recursion_proofs": "synthetic AIR, 135 columns, 82 constants" if args.synthetic_rec
                                        else "PLONK-shaped circuit (AIR 8), 135 wires, 84 constants, 20 auxiliary columns",

@@ -211,7 +211,7 @@ struct bp_stark_cfg;
  * (eval_packed_generic / eval_ext, evaluated by plonky2_evm's compute_quotient_polys, reached from
  * proof_gen.rs:44-52; the seven zkEVM tables of prover_state.rs:85-93, Keccak range constants.rs:12) is here an
  * air_id: 0 = the synthetic AIR of DESIGN.md section 4 (any width), 1 = keccak_f, one round of Keccak-f[1600] per
- * row on 2430 columns, written from FIPS 202 (not upstream's column layout), 2 = logic, one AND / OR / XOR of two
+ * row on 2431 columns, written from FIPS 202 (not upstream's column layout), 2 = logic, one AND / OR / XOR of two
  * 256-bit words per row on 523 columns, 3 = memory, a log of reads and writes sorted by (address, timestamp) on 44
  * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns, 5 = byte_packing,
  * a big-endian byte sequence and the word it spells on 299 columns, 6 = keccak_sponge, the absorbing side of
@@ -261,8 +261,8 @@ int bp_quotient_eval(uint32_t air_id, const struct bp_stark_cfg* shape, const ui
                      const uint64_t* d_aux_lde, const uint64_t* d_const_lde, const uint64_t ctl[4],
                      const uint64_t alphas[2], uint64_t* d_scratch, uint64_t* d_qvals_out, void* stream);
 
-/* Witness of AIR 1 (generate_traces is inside the reference's call too, proof_gen.rs:44-52): n = 2^log_n rows x 2430
- * columns, column-major, row r = round r % 24 of permutation r / 24.  d_inputs: [ceil(n / 24)][25] input lanes
+/* Witness of AIR 1 (generate_traces is inside the reference's call too, proof_gen.rs:44-52): n = 2^log_n rows x 2431
+ * columns (the last one, the lookup's filter, zero), column-major, row r = round r % 24 of permutation r / 24.  d_inputs: [ceil(n / 24)][25] input lanes
  * (any u64; lane x + 5y), or NULL to draw them from `seed` (splitmix64(seed ^ (lane << 32) ^ permutation)). */
 int bp_keccak_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 /* Witness of AIR 2 (the logic table: one AND / OR / XOR of two 256-bit words per row): n = 2^log_n rows x 523 columns,
@@ -271,7 +271,7 @@ int bp_keccak_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uin
  * (code = splitmix64(seed ^ (0xFF << 32) ^ row) & 3, word w of operand j = splitmix64(seed ^ ((1 + 4 j + w) << 32) ^ row)). */
 int bp_logic_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 /* Witness of AIR 3 (the memory table: a log of reads and writes sorted by address, then timestamp): n = 2^log_n rows x
- * 44 columns, column-major.  d_inputs: [n][11] = is_read, address (< 2^32), timestamp (< 2^32), eight 32-bit value
+ * 45 columns (the last one, the lookup's filter, zero), column-major.  d_inputs: [n][11] = is_read, address (< 2^32), timestamp (< 2^32), eight 32-bit value
  * limbs, ALREADY SORTED (the kernel derives the address_changed flag and the gap bits from neighbouring rows; a log
  * that is out of order, or whose reads do not return the previous value, gives a witness the verifier rejects); or NULL
  * for a log drawn from `seed` (four operations per address; csrc/stark_kernels.hip, memory_trace_kernel). */
@@ -342,7 +342,7 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
-/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 .. 7: n_cols = 2430 / 523 / 44 / 309 / 299 / 2414 / 1217,
+/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 .. 7: n_cols = 2431 / 523 / 45 / 309 / 299 / 2414 / 1217,
  * n_const = 0, deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
 int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                        uint8_t** out, size_t* out_len);
@@ -514,13 +514,13 @@ int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_
                        uint64_t seed, const uint32_t table_log_n[BP_NUM_TABLES],
                        const uint32_t table_width[BP_NUM_TABLES], uint64_t ir_out[BP_IR_WORDS]);
 /* Marks an encoded IR (flag 0x100 of the version word) so that its Keccak table -- table index 3 in the positional
- * order of prover_state.rs:85-93 -- is proven with the Keccak-f[1600] AIR (air_id 1: 2430 columns, the witness is
- * ceil(2^log_n / 24) permutations drawn from the seed) instead of the synthetic AIR.  The table's width must be 2430. */
+ * order of prover_state.rs:85-93 -- is proven with the Keccak-f[1600] AIR (air_id 1: 2431 columns, the witness is
+ * ceil(2^log_n / 24) permutations drawn from the seed) instead of the synthetic AIR.  The table's width must be 2431. */
 int bp_ir_set_keccak_air(uint64_t ir[BP_IR_WORDS], int on);
 /* The same for the logic table (flag 0x200; table index 5): proven with the logic AIR (air_id 2: 523 columns, one
  * operation per row drawn from the seed).  The table's width must be 523. */
 int bp_ir_set_logic_air(uint64_t ir[BP_IR_WORDS], int on);
-/* ... and for the memory table (flag 0x400; table index 6): the memory AIR (air_id 3: 44 columns, a sorted log drawn
+/* ... and for the memory table (flag 0x400; table index 6): the memory AIR (air_id 3: 45 columns, a sorted log drawn
  * from the seed).  The table's width must be 44. */
 int bp_ir_set_memory_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the arithmetic table (flag 0x800; table index 0): the arithmetic AIR (air_id 4: 309 columns). */

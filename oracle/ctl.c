@@ -14,11 +14,15 @@
  * tuple_j) on the rows that take part and 1 on the others; the statement holds when the first-row values agree, for
  * both challenge sets (beta_0, gamma_0), (beta_1, gamma_1).  Auxiliary columns per table:
  *   synthetic  n_cols / 8   unfiltered products over trace columns 8k, 8k + 1 (a load placeholder; stark.c)
- *   keccak_f   5            g (row takes part: last round of an exposed permutation), h_0, h_1 (the permutation's 50
- *                           input limbs compressed by beta_c, the same value on all its rows), z_0, z_1
+ *   keccak_f   4            h_0, h_1 (the permutation's 50 input limbs compressed by beta_c, the same value on all its
+ *                           rows), z_0, z_1
  *   sponge     2            z_0, z_1
  *   byte_packing 2          z_0, z_1
- *   memory     3            g (the operation is exposed), z_0, z_1
+ *   memory     2            z_0, z_1
+ * The FILTERS of the two looked tables -- g = 1 on the last-round row of an exposed permutation (Keccak-f, trace column
+ * 2430), on an exposed operation (memory, trace column 44) -- are columns of the TRACE: set by orc_ctl_set_filter before
+ * the trace is committed, i.e. before the challenges are drawn (as auxiliary columns, committed after the challenges,
+ * they left the prover free to pick the exposed subset knowing beta and gamma: ADVICE r4).
  *   others     1            the constant 1
  * This file computes the columns by their meaning (if / else per row, explicit powers) and states the constraints as
  * polynomials; the product (csrc/air.hpp, namespace ctl) evaluates the same polynomials by Horner's rule. */
@@ -26,30 +30,38 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { KCOL_STEP = 0, KCOL_A = 24, KCOL_APP = 2314, KCOL_APPP = 2428 };
+enum { KCOL_STEP = 0, KCOL_A = 24, KCOL_APP = 2314, KCOL_APPP = 2428, KCOL_G = 2430 };
 enum { SCOL_FULL = 0, SCOL_FINAL = 1, SCOL_CAP = 2314, SCOL_XORED = 2330, SCOL_UPDATED = 2364 };
 enum { PCOL_READ = 0, PCOL_LEN = 1, PCOL_VAL = 289, PCOL_ADDR = 297, PCOL_TS = 298 };
-enum { MCOL_READ = 0, MCOL_ADDR = 1, MCOL_TS = 2, MCOL_VAL = 3 };
+enum { MCOL_READ = 0, MCOL_ADDR = 1, MCOL_TS = 2, MCOL_VAL = 3, MCOL_G = 44 };
 
 uint32_t orc_ctl_n_aux(uint32_t air_id, uint32_t n_cols) {
   return air_id == ORC_AIR_SYNTHETIC ? n_cols / 8
-         : air_id == ORC_AIR_KECCAK_F ? 5
+         : air_id == ORC_AIR_KECCAK_F ? 4
          : air_id == ORC_AIR_KECCAK_SPONGE ? 2
          : air_id == ORC_AIR_BYTE_PACKING ? 2
-         : air_id == ORC_AIR_MEMORY ? 3
+         : air_id == ORC_AIR_MEMORY ? 2
          : air_id == ORC_AIR_PLONK ? 20 /* Z + nine partial products per challenge set (plonk_air.c) */
                                    : 1;
 }
 
-/* The auxiliary columns of a table with a real AIR, from its trace values tv ([n_cols][N], column-major).
- * exposed (nullable): Keccak-f table: exposed[p] != 0 when permutation p is asked for; memory table: exposed[i] != 0 when
- * the operation in row i is asked for; n_exposed entries. */
-void orc_ctl_aux_columns(uint32_t air_id, const gl_t* tv, unsigned log_n, const gl_t ctl[4], const uint8_t* exposed,
-                         size_t n_exposed, gl_t* aux) {
+/* The filter column of a LOOKED table's trace tv ([n_cols][N], column-major), before the trace is committed.
+ * Keccak-f table: exposed[p] != 0 when permutation p is asked for; memory table: exposed[i] != 0 when the operation in
+ * row i is asked for; n_exposed entries, NULL: nothing is exposed. */
+void orc_ctl_set_filter(uint32_t air_id, gl_t* tv, unsigned log_n, const uint8_t* exposed, size_t n_exposed) {
+  const size_t N = (size_t)1 << log_n;
+  if (air_id == ORC_AIR_KECCAK_F)
+    for (size_t i = 0; i < N; i++) tv[(size_t)KCOL_G * N + i] = (i % 24 == 23 && exposed && i / 24 < n_exposed && exposed[i / 24]) ? 1 : 0;
+  else if (air_id == ORC_AIR_MEMORY)
+    for (size_t i = 0; i < N; i++) tv[(size_t)MCOL_G * N + i] = (exposed && i < n_exposed && exposed[i]) ? 1 : 0;
+}
+
+/* The auxiliary columns of a table with a real AIR, from its trace values tv ([n_cols][N], column-major). */
+void orc_ctl_aux_columns(uint32_t air_id, const gl_t* tv, unsigned log_n, const gl_t ctl[4], gl_t* aux) {
   const size_t N = (size_t)1 << log_n;
   if (air_id == ORC_AIR_KECCAK_F) {
-    gl_t *g = aux, *h[2] = {aux + N, aux + 2 * N}, *z[2] = {aux + 3 * N, aux + 4 * N};
-    for (size_t i = 0; i < N; i++) g[i] = (i % 24 == 23 && exposed && i / 24 < n_exposed && exposed[i / 24]) ? 1 : 0;
+    const gl_t* g = tv + (size_t)KCOL_G * N;
+    gl_t *h[2] = {aux, aux + N}, *z[2] = {aux + 2 * N, aux + 3 * N};
     for (int c = 0; c < 2; c++) {
       const gl_t beta = ctl[2 * c], gamma = ctl[2 * c + 1];
       gl_t pw[100];
@@ -115,11 +127,10 @@ void orc_ctl_aux_columns(uint32_t air_id, const gl_t* tv, unsigned log_n, const 
     return;
   }
   if (air_id == ORC_AIR_MEMORY) { /* an exposed row offers (is_read, address, timestamp, value limbs) */
-    gl_t* g = aux;
-    for (size_t i = 0; i < N; i++) g[i] = (exposed && i < n_exposed && exposed[i]) ? 1 : 0;
+    const gl_t* g = tv + (size_t)MCOL_G * N;
     for (int c = 0; c < 2; c++) {
       const gl_t beta = ctl[2 * c], gamma = ctl[2 * c + 1];
-      gl_t *z = aux + (size_t)(1 + c) * N, run = 1;
+      gl_t *z = aux + (size_t)c * N, run = 1;
       for (size_t i = N; i-- > 0;) {
         if (g[i]) {
           gl_t tuple = tv[(size_t)MCOL_READ * N + i], pw = beta;

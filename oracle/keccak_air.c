@@ -1,4 +1,4 @@
-/* oracle/keccak_air.c -- AIR 1: one round of Keccak-f[1600] per trace row (24 rows per permutation), 2430 columns.
+/* oracle/keccak_air.c -- AIR 1: one round of Keccak-f[1600] per trace row (24 rows per permutation), 2430 columns + the lookup's filter column (2430: g, ctl.c).
  * TEST INFRASTRUCTURE ONLY; "parity unpinned" by the reference (see gl.h): the reference proves its Keccak table
  * through the out-of-tree plonky2_evm (call site plonky_block_proof_gen/src/proof_gen.rs:44-52, table list
  * prover_state.rs:85-93, size range constants.rs:12); nothing under /root/reference shows its columns.  This AIR is
@@ -61,7 +61,7 @@ void orc_keccak_f(uint64_t lanes[25]) { /* lanes[x + 5y]; the permutation alone,
     for (int y = 0; y < 5; y++) lanes[x + 5 * y] = A[x][y];
 }
 
-/* Witness: n = 2^log_n rows x 2430 columns, column-major.  inputs: [ceil(n/24)][25] lanes (x + 5y) or NULL, then
+/* Witness: n = 2^log_n rows x 2431 columns (the last one, g, zero), column-major.  inputs: [ceil(n/24)][25] lanes (x + 5y) or NULL, then
  * lane l of permutation p is splitmix64(seed ^ (l << 32) ^ p). */
 void orc_keccak_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* t) {
   const size_t n = (size_t)1 << log_n, n_perm = (n + 23) / 24;
@@ -97,6 +97,7 @@ void orc_keccak_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_
       for (int z = 0; z < 64; z++) PUT(KC_APP0 + z, (o.App[0][0] >> z) & 1);
       PUT(KC_APPP, o.Appp00 & 0xFFFFFFFFULL);
       PUT(KC_APPP + 1, o.Appp00 >> 32);
+      PUT(2430, 0); /* g: nothing exposed to the lookup (orc_ctl_set_filter marks the exposed rows, ctl.c) */
 #undef PUT
     }
   }

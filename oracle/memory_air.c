@@ -54,6 +54,7 @@ void orc_memory_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_
     for (int k = 0; k < 8; k++) PUT(MM_VAL + k, r[3 + k]);
     PUT(MM_CHG, chg);
     for (int z = 0; z < 32; z++) PUT(MM_GAP + z, (gap >> z) & 1);
+    PUT(44, 0); /* g: nothing exposed to the lookup (orc_ctl_set_filter marks the exposed rows, ctl.c) */
 #undef PUT
   }
   free(log);

@@ -74,13 +74,13 @@ typedef struct {
 } orc_stark_cfg;
 #define ORC_AIR_SYNTHETIC 0u
 #define ORC_AIR_KECCAK_F 1u
-#define ORC_KECCAK_COLS 2430u
+#define ORC_KECCAK_COLS 2431u /* 2430 of the round + the lookup's filter column g (ctl.c), committed with the trace */
 #define ORC_KECCAK_CONSTRAINTS 2826u
 #define ORC_AIR_LOGIC 2u
 #define ORC_LOGIC_COLS 523u
 #define ORC_LOGIC_CONSTRAINTS 524u
 #define ORC_AIR_MEMORY 3u
-#define ORC_MEMORY_COLS 44u
+#define ORC_MEMORY_COLS 45u /* 44 of the log + the lookup's filter column g (ctl.c) */
 #define ORC_MEMORY_CONSTRAINTS 60u
 #define ORC_AIR_ARITHMETIC 4u
 #define ORC_ARITHMETIC_COLS 309u
@@ -161,8 +161,10 @@ void orc_arithmetic_mul_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_
 
 /* ctl.c: the cross-table lookups (auxiliary columns) of the tables with a real AIR */
 uint32_t orc_ctl_n_aux(uint32_t air_id, uint32_t n_cols);
-void orc_ctl_aux_columns(uint32_t air_id, const gl_t* trace_values, unsigned log_n, const gl_t ctl[4], const uint8_t* exposed,
-                         size_t n_exposed, gl_t* aux);
+void orc_ctl_aux_columns(uint32_t air_id, const gl_t* trace_values, unsigned log_n, const gl_t ctl[4], gl_t* aux);
+/* the filter column of a LOOKED table's trace (Keccak-f: column 2430, exposed[p] per permutation; memory: column 44,
+ * exposed[i] per row), set before the trace is committed; NULL: nothing is exposed */
+void orc_ctl_set_filter(uint32_t air_id, gl_t* trace_values, unsigned log_n, const uint8_t* exposed, size_t n_exposed);
 void orc_ctl_constraints_base(uint32_t air_id, const gl_t* loc, const gl_t* aux, const gl_t* aux_nxt, const gl_t ctl[4],
                               orc_consumer* k);
 void orc_ctl_constraints_ext(uint32_t air_id, const gl2_t* loc, const gl2_t* aux, const gl2_t* aux_nxt, const gl_t ctl[4],
@@ -200,11 +202,6 @@ void orc_committed_free(orc_committed* c);
  * Returns 0 on success. proof_out has orc_proof_words(cfg) words. */
 int orc_stark_prove(const orc_stark_cfg* cfg, const orc_committed* consts, const orc_committed* trace,
                     const gl_t* trace_values, const gl_t ctl[4], orc_challenger* ch, gl_t* proof_out);
-/* The same for a LOOKED table: exposed[p] != 0 when permutation p of a Keccak-f table is asked for by the transaction's
- * sponge table (ctl.c); n_exposed entries, NULL: nothing is exposed. */
-int orc_stark_prove_lookup(const orc_stark_cfg* cfg, const orc_committed* consts, const orc_committed* trace,
-                           const gl_t* trace_values, const gl_t ctl[4], orc_challenger* ch, gl_t* proof_out,
-                           const uint8_t* exposed, size_t n_exposed);
 /* Verify; the caller must have driven `ch` identically (caps observed etc.). 0 = accept. */
 int orc_stark_verify(const orc_stark_cfg* cfg, const gl_t* const_cap, const gl_t ctl[4],
                      orc_challenger* ch, const gl_t* proof);

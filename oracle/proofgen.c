@@ -325,6 +325,28 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
       orc_keccak_sponge_trace_limit(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, lookup_kf ? kf_full_perms : (size_t)-1, trace[t]);
     else orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
   }
+  /* the filter columns of the two looked tables are part of their traces: set BEFORE the traces are committed */
+  if (lookup_kf) { /* the Keccak-f table exposes the permutations the sponge rows ask for, row p <-> permutation p */
+    const size_t ns = (size_t)1 << tcfg[4].log_n;
+    uint8_t* exposed = (uint8_t*)malloc(ns);
+    for (size_t p = 0; p < ns; p++) exposed[p] = trace[4][p] || trace[4][ns + p];
+    orc_ctl_set_filter(ORC_AIR_KECCAK_F, trace[3], tcfg[3].log_n, exposed, ns);
+    free(exposed);
+  }
+  if (lookup_bm) { /* the memory table exposes the operations the byte-packing rows name */
+    const size_t np = (size_t)1 << tcfg[1].log_n, nm = (size_t)1 << tcfg[6].log_n;
+    uint8_t* exposed = (uint8_t*)calloc(nm, 1);
+    for (size_t r = 0; r < np; r++) {
+      int moves = 0;
+      for (int j = 0; j < 32; j++) moves |= trace[1][(size_t)(1 + j) * np + r] != 0;
+      if (!moves) continue;
+      const gl_t a = trace[1][297 * np + r], ts = trace[1][298 * np + r];
+      for (size_t i = 0; i < nm; i++)
+        if (trace[6][1 * nm + i] == a && trace[6][2 * nm + i] == ts) { exposed[i] = 1; break; }
+    }
+    orc_ctl_set_filter(ORC_AIR_MEMORY, trace[6], tcfg[6].log_n, exposed, nm);
+    free(exposed);
+  }
   for (int t = 0; t < NUM_TABLES; t++) {
     tc[t] = orc_commit_values(trace[t], tcfg[t].log_n, tcfg[t].n_cols, tcfg[t].rate_bits, tcfg[t].cap_height);
     orc_ch_observe_many(&ch, orc_committed_cap(tc[t]), (size_t)4 << tcfg[t].cap_height);
@@ -335,28 +357,7 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
   for (int t = 0; t < NUM_TABLES; t++) proofs[t] = NULL;
   for (int t = 0; t < NUM_TABLES && !rc; t++) {
     proofs[t] = (gl_t*)malloc(orc_proof_words(&tcfg[t]) * sizeof(gl_t));
-    if (t == 3 && lookup_kf) { /* the Keccak-f table exposes the permutations the sponge rows ask for, row p <-> permutation p */
-      const size_t ns = (size_t)1 << tcfg[4].log_n;
-      uint8_t* exposed = (uint8_t*)malloc(ns);
-      for (size_t p = 0; p < ns; p++) exposed[p] = trace[4][p] || trace[4][ns + p];
-      rc = orc_stark_prove_lookup(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t], exposed, ns);
-      free(exposed);
-    } else if (t == 6 && lookup_bm) { /* the memory table exposes the operations the byte-packing rows name */
-      const size_t np = (size_t)1 << tcfg[1].log_n, nm = (size_t)1 << tcfg[6].log_n;
-      uint8_t* exposed = (uint8_t*)calloc(nm, 1);
-      for (size_t r = 0; r < np; r++) {
-        int moves = 0;
-        for (int j = 0; j < 32; j++) moves |= trace[1][(size_t)(1 + j) * np + r] != 0;
-        if (!moves) continue;
-        const gl_t a = trace[1][297 * np + r], ts = trace[1][298 * np + r];
-        for (size_t i = 0; i < nm; i++)
-          if (trace[6][1 * nm + i] == a && trace[6][2 * nm + i] == ts) { exposed[i] = 1; break; }
-      }
-      rc = orc_stark_prove_lookup(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t], exposed, nm);
-      free(exposed);
-    } else {
-      rc = orc_stark_prove(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t]);
-    }
+    rc = orc_stark_prove(&tcfg[t], NULL, tc[t], trace[t], ctl, &ch, proofs[t]);
   }
   for (int t = 0; t < NUM_TABLES; t++) { orc_committed_free(tc[t]); free(trace[t]); }
   if (!rc && g_prover_checks_lookups) rc = orc_pg_check_lookups(tcfg, (const gl_t* const*)proofs);
@@ -375,15 +376,15 @@ static size_t open_first_offset(const orc_stark_cfg* c) {
 int orc_pg_check_lookups(const orc_stark_cfg tcfg[NUM_TABLES], const gl_t* const proofs[NUM_TABLES]) {
   if (tcfg[3].air_id == ORC_AIR_KECCAK_F && tcfg[4].air_id == ORC_AIR_KECCAK_SPONGE) {
     const gl_t* looking = proofs[4] + open_first_offset(&tcfg[4]); /* z_0, z_1 are its aux columns 0, 1 */
-    const gl_t* looked = proofs[3] + open_first_offset(&tcfg[3]);  /* ... and columns 3, 4 here */
+    const gl_t* looked = proofs[3] + open_first_offset(&tcfg[3]);  /* ... and columns 2, 3 here (after h_0, h_1) */
     for (int c = 0; c < 2; c++)
-      if (looking[2 * c] != looked[2 * (3 + c)] || looking[2 * c + 1] != looked[2 * (3 + c) + 1]) return -11;
+      if (looking[2 * c] != looked[2 * (2 + c)] || looking[2 * c + 1] != looked[2 * (2 + c) + 1]) return -11;
   }
   if (tcfg[1].air_id == ORC_AIR_BYTE_PACKING && tcfg[6].air_id == ORC_AIR_MEMORY) {
     const gl_t* looking = proofs[1] + open_first_offset(&tcfg[1]); /* z_0, z_1 are its aux columns 0, 1 */
-    const gl_t* looked = proofs[6] + open_first_offset(&tcfg[6]);  /* ... and columns 1, 2 here (column 0 is the filter) */
+    const gl_t* looked = proofs[6] + open_first_offset(&tcfg[6]);  /* ... and columns 0, 1 here too (the filter is a trace column) */
     for (int c = 0; c < 2; c++)
-      if (looking[2 * c] != looked[2 * (1 + c)] || looking[2 * c + 1] != looked[2 * (1 + c) + 1]) return -12;
+      if (looking[2 * c] != looked[2 * c] || looking[2 * c + 1] != looked[2 * c + 1]) return -12;
   }
   return 0;
 }

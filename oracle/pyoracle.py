@@ -241,9 +241,9 @@ class PyChallenger:
 AIR_SYNTHETIC, AIR_KECCAK_F, AIR_LOGIC, AIR_MEMORY, AIR_ARITHMETIC, AIR_BYTE_PACKING = 0, 1, 2, 3, 4, 5
 AIR_KECCAK_SPONGE = 6
 AIR_ARITHMETIC_MUL = 7
-KECCAK_COLS = 2430
+KECCAK_COLS = 2431
 LOGIC_COLS = 523
-MEMORY_COLS = 44
+MEMORY_COLS = 45
 ARITHMETIC_COLS = 309
 BYTE_PACKING_COLS = 299
 KECCAK_SPONGE_COLS = 2414
@@ -290,7 +290,7 @@ def keccak_f(lanes):
 
 
 def keccak_trace(log_n, seed=0, inputs=None):
-    """orc_keccak_trace: the AIR-1 witness [2430, 2^log_n]."""
+    """orc_keccak_trace: the AIR-1 witness [2431, 2^log_n] (the last column, the lookup's filter, zero)."""
     out = np.zeros((KECCAK_COLS, 1 << log_n), dtype=np.uint64)
     inp = np.ascontiguousarray(inputs, dtype=np.uint64) if inputs is not None else None
     if inp is not None:
@@ -310,7 +310,7 @@ def logic_trace(log_n, seed=0, inputs=None):
 
 
 def memory_trace(log_n, seed=0, inputs=None):
-    """orc_memory_trace: the AIR-3 witness [44, 2^log_n]; inputs [2^log_n, 11] (is_read, address, timestamp, value[8],
+    """orc_memory_trace: the AIR-3 witness [45, 2^log_n] (the last column, the lookup's filter, zero); inputs [2^log_n, 11] (is_read, address, timestamp, value[8],
     sorted by address then timestamp) or a log drawn from the seed."""
     out = np.zeros((MEMORY_COLS, 1 << log_n), dtype=np.uint64)
     inp = np.ascontiguousarray(inputs, dtype=np.uint64) if inputs is not None else None

@@ -345,12 +345,6 @@ void orc_quotient_values(const orc_stark_cfg* cf, const gl_t* const_lde, const g
 
 int orc_stark_prove(const orc_stark_cfg* cf, const orc_committed* consts, const orc_committed* trace,
                     const gl_t* tv, const gl_t ctl[4], orc_challenger* ch, gl_t* proof) {
-  return orc_stark_prove_lookup(cf, consts, trace, tv, ctl, ch, proof, NULL, 0);
-}
-/* exposed (nullable; Keccak-f table only): which permutations a looking table asks for (ctl.c) */
-int orc_stark_prove_lookup(const orc_stark_cfg* cf, const orc_committed* consts, const orc_committed* trace,
-                           const gl_t* tv, const gl_t ctl[4], orc_challenger* ch, gl_t* proof, const uint8_t* exposed,
-                           size_t n_exposed) {
   layout_t L = layout(cf);
   const unsigned log_n = cf->log_n, r = cf->rate_bits, h = cf->cap_height, log_m = log_n + r;
   const size_t N = (size_t)1 << log_n, M = N << r, C = cf->n_cols, K = cf->n_const, A = L.n_aux,
@@ -383,7 +377,7 @@ int orc_stark_prove_lookup(const orc_stark_cfg* cf, const orc_committed* consts,
     orc_plonk_aux_columns(tv, cv, log_n, ctl, auxv);
     free(cv);
   } else if (cf->air_id != ORC_AIR_SYNTHETIC) {
-    orc_ctl_aux_columns(cf->air_id, tv, log_n, ctl, exposed, n_exposed, auxv);
+    orc_ctl_aux_columns(cf->air_id, tv, log_n, ctl, auxv);
   } else {
 #pragma omp parallel for
     for (size_t k = 0; k < A; k++) {

@@ -313,16 +313,16 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
     """The synthetic block of SURVEY.md section 8(d): n_txns txns with distinct seeds whose public
     values chain (state root, txn number, gas) like decoding.rs:106-154 chains GenerationInputs.
     keccak_air: every transaction's Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1; the table's width
-    becomes 2430).  logic_air / memory_air: likewise the logic table (index 5) with the logic AIR (AIR 2; width 523) and
-    the memory table (index 6) with the memory AIR (AIR 3; width 44); arithmetic_air: the arithmetic table (index 0)
+    becomes 2431).  logic_air / memory_air: likewise the logic table (index 5) with the logic AIR (AIR 2; width 523) and
+    the memory table (index 6) with the memory AIR (AIR 3; width 45); arithmetic_air: the arithmetic table (index 0)
     with the arithmetic AIR (AIR 4; width 309); byte_packing_air: the byte-packing table (index 1) with AIR 5 (width 299);
     keccak_sponge_air: the Keccak sponge table (index 4) with AIR 6 (width 2414)."""
     if keccak_air:
-        table_width = tuple(2430 if t == 3 else w for t, w in enumerate(table_width))
+        table_width = tuple(2431 if t == 3 else w for t, w in enumerate(table_width))
     if logic_air:
         table_width = tuple(523 if t == 5 else w for t, w in enumerate(table_width))
     if memory_air:
-        table_width = tuple(44 if t == 6 else w for t, w in enumerate(table_width))
+        table_width = tuple(45 if t == 6 else w for t, w in enumerate(table_width))
     if arithmetic_air:
         table_width = tuple(309 if t == 0 else w for t, w in enumerate(table_width))
     if byte_packing_air:
@@ -542,7 +542,7 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     root (folded into four field elements) and chains entry to entry.  Entries without a transaction (dummy
     padding, the withdrawal carrier) become dummy IRs: proven, counters do not advance (decoding.rs:484-520) --
     a prepended dummy is renumbered to its position, as pad_with_dummy_irs documents.
-    keccak_air: every entry's Keccak table (index 3) becomes a real Keccak-f[1600] trace (AIR 1, 2430 columns) whose
+    keccak_air: every entry's Keccak table (index 3) becomes a real Keccak-f[1600] trace (AIR 1, 2431 columns) whose
     permutations are the entry's OWN hashing work (keccak_inputs_of_generation_inputs): the table then attests data of
     the decoded transaction, not only a seed; its height grows to hold them (24 rows per permutation).
     keccak_trie_nodes: the hashing of the entry's partial tries is part of that work (the prover state's Keccak range
@@ -559,13 +559,13 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     root = tuple(int.from_bytes(first[8 * i:8 * i + 8], "little") % P for i in range(4))
     irs, txn_no, gas = [], 0, 0
     if keccak_air:
-        table_width = tuple(2430 if t == 3 else w for t, w in enumerate(table_width))
+        table_width = tuple(2431 if t == 3 else w for t, w in enumerate(table_width))
     if (memory_air or byte_packing_air or keccak_sponge_air) and not keccak_air:
         raise ValueError("the memory / byte-packing / sponge work is that of the hashed bytes: it needs keccak_air")
     if keccak_sponge_air:
         table_width = tuple(2414 if t == 4 else w for t, w in enumerate(table_width))
     if memory_air:
-        table_width = tuple(44 if t == 6 else w for t, w in enumerate(table_width))
+        table_width = tuple(45 if t == 6 else w for t, w in enumerate(table_width))
     if byte_packing_air:
         table_width = tuple(299 if t == 1 else w for t, w in enumerate(table_width))
     base_log_n = tuple(table_log_n)

@@ -16,14 +16,14 @@
 // constraints in whatever order keeps its operands in registers and the partial sums of units simply add.
 //
 // AIR 0  synthetic     DESIGN.md section 4 (any width; groups of four columns; degree 3 * deg_pow)
-// AIR 1  keccak_f      one round of Keccak-f[1600] per row, 24 rows per permutation, 2430 columns, degree 3;
+// AIR 1  keccak_f      one round of Keccak-f[1600] per row, 24 rows per permutation, 2431 columns, degree 3;
 //                      written from the public specification (FIPS 202 / the Keccak reference), in the style of
 //                      upstream's keccak table (~2.4 k columns, constants.rs:12) but NOT upstream's column layout,
 //                      which nothing under /root/reference shows [UPSTREAM-UNVERIFIED].
 // AIR 2  logic         bitwise AND / OR / XOR of two 256-bit words per row (the zkEVM's logic table, prover_state.rs:85-93
 //                      "logic"), 523 columns, degree 3; written from the definition of the three operations, NOT
 //                      upstream's column layout [UPSTREAM-UNVERIFIED].
-// AIR 3  memory        a memory log sorted by (address, timestamp), one operation per row, 44 columns, degree 3: a read
+// AIR 3  memory        a memory log sorted by (address, timestamp), one operation per row, 45 columns (44 + the lookup filter), degree 3: a read
 //                      returns what the previous operation on the address left there (zero for a first access);
 //                      the ordering is enforced by a 32-bit decomposition of the gap to the next row.  In the style
 //                      of the zkEVM's memory table (prover_state.rs:85-93 "memory"), its own layout
@@ -165,6 +165,9 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
 //   2314 .. 2363   A''        limbs: 2314 + 2 l + h
 //   2364 .. 2427   A''[0][0]  bits
 //   2428 .. 2429   A'''[0][0] limbs
+//   2430           g          1 on the last-round row of a permutation the table exposes to the lookup keccak_sponge ->
+//                             keccak_f (namespace ctl, which constrains it); committed with the trace, i.e. BEFORE the lookup
+//                             challenges are drawn
 // Constraints (index ranges; degree; kind):
 //   F0  0    .. 23    first row   s_0 - 1, s_i                                                   deg 1
 //   F1  24   .. 47    transition  s'_((i+1) mod 24) - s_i                                        deg 1
@@ -181,9 +184,9 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
 // Units: 0 = F0, F1, F7, F8, F9 and the A''[0][0] bits of F2; 1 + x = the column-x slices of F2 .. F5 (theta); 6 + y = the
 // plane-y slice of F6 (chi).
 namespace keccak {
-constexpr uint32_t N_COLS = 2430, N_CONSTRAINTS = 2826, N_UNITS = 11;
+constexpr uint32_t N_COLS = 2431, N_CONSTRAINTS = 2826, N_UNITS = 11;
 constexpr uint32_t COL_STEP = 0, COL_A = 24, COL_C = 74, COL_CP = 394, COL_AP = 714, COL_APP = 2314, COL_APP0_BITS = 2364,
-                   COL_APPP = 2428;
+                   COL_APPP = 2428, COL_G = 2430;  // COL_G: the lookup's filter (namespace ctl), a TRACE column
 constexpr uint32_t F0 = 0, F1 = 24, F2 = 48, F3 = 2032, F4 = 2352, F5 = 2672, F6 = 2722, F7 = 2772, F8 = 2774, F9 = 2776;
 GL_HD uint64_t round_constant(uint32_t i) {
   constexpr uint64_t RC[24] = {
@@ -486,6 +489,8 @@ GL_HD void eval_unit(uint32_t k, const Row& row, Emit& out) {
 //   3 .. 10    value, eight 32-bit limbs (their range is the business of the table that looks the value up)
 //   11         address_changed: the NEXT row is on another address
 //   12 .. 43   bits of the gap to the next row: address' - address - 1 if address_changed, else timestamp' - timestamp - 1
+//   44         g: 1 on the operations the table exposes to the lookup byte_packing -> memory (namespace ctl, which
+//              constrains it); committed with the trace, i.e. before the lookup challenges are drawn
 // Constraints:
 //   M0  0          all rows    is_read (is_read - 1)                                             deg 2
 //   M1  1          all rows    address_changed (address_changed - 1)                             deg 2
@@ -499,10 +504,10 @@ GL_HD void eval_unit(uint32_t k, const Row& row, Emit& out) {
 //   M7  52 .. 59   first row   is_read value_k                                                   deg 2
 // One unit.
 namespace memory {
-constexpr uint32_t N_COLS = 44, N_CONSTRAINTS = 60, N_UNITS = 1;
-constexpr uint32_t COL_READ = 0, COL_ADDR = 1, COL_TS = 2, COL_VAL = 3, COL_CHG = 11, COL_GAP = 12;
+constexpr uint32_t N_COLS = 45, N_CONSTRAINTS = 60, N_UNITS = 1;
+constexpr uint32_t COL_READ = 0, COL_ADDR = 1, COL_TS = 2, COL_VAL = 3, COL_CHG = 11, COL_GAP = 12, COL_G = 44;
 constexpr uint32_t M0 = 0, M1 = 1, M2 = 2, M3 = 34, M4 = 35, M5 = 36, M6 = 44, M7 = 52;
-// (Sixty constraints on 44 columns: the plain multiply is used outside the bit loop -- the carry-chain groups of four
+// (Sixty constraints on 45 columns: the plain multiply is used outside the bit loop -- the carry-chain groups of four
 // would hold three sets of masks next to the column offsets and spill scalars for nothing.)
 template <class T, class Row, class Emit>
 GL_HD void eval_unit(const Row& row, Emit& out) {
@@ -872,7 +877,7 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 //   row 4g + 3  arithmetic, a_i := d_i(4g + 2) for i < 11, the rest free               (2-cycles)
 // and c_j(4) := pub_j (row 0), j < 4, ties the computation to the public inputs.
 namespace plonk {
-constexpr uint32_t N_COLS = 135, N_CONST = 84, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 90, N_UNITS = 1;
+constexpr uint32_t N_COLS = 135, N_CONST = 84, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 90, N_UNITS = 10;
 constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_SIGMA = 4;
 constexpr uint32_t COL_SBOX = 80;
 constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86;
@@ -903,52 +908,132 @@ GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t& col_out, u
     if (s < N_SBOX && w == 0) { col_out = 4 * s + 3; row_out = base + 2; }      // a_i(4g+3) -> d_i(4g+2)
   }
 }
+// 7^(8u): the coset shift k_j = 7^j of the first routed wire of chunk u
+GL_HD uint64_t chunk_shift(uint32_t u) {
+  constexpr uint64_t K8[10] = {0x1ULL, 0x57f6c1ULL, 0x1e39a5057d81ULL, 0x62b942f056949437ULL, 0x33cdc3006affab59ULL,
+                               0xcb893e19494e73dULL, 0x36f01f6fb02d9400ULL, 0xd844c68aea81b372ULL, 0x9c232dfb69ab851eULL,
+                               0x255bd1d3b936892aULL};
+  return K8[u];
+}
+// Unit u (0..9) = everything that reads routed wires 8u .. 8u+7 (slots 2u, 2u+1), each wire and each sigma read ONCE:
+//   * the arithmetic gates of the two slots (G0);
+//   * chunk u + 1 of the copy constraints for BOTH challenge sets (the statement above ctl::eval, index ctl_base + 11 c + u:
+//     cur den - prev num with prev = Z(next row) for the first chunk, cur = Z(this row) for the last), and for u = 9 the
+//     first-row constraints Z_c - 1;
+//   * the S-box units whose wires lie in the chunk (2u and 2u + 1 for u < 5, unit 10 for u = 5) (G1, G2);
+//   * for u = 0 the public-input row (G3).
+// (Round 4 had ONE gate unit and the copy constraints as a second pass per challenge set: every routed wire was read
+// three times and every sigma twice -- 2.05 x the algorithmic bytes by PMC --, and a lone proof's 2^16 rows were 256
+// workgroups with nothing to spread.)  Every constraint keeps its index, so the quotient is the same polynomial.
 template <class T, class Row, class Emit>
-GL_HD void eval_unit(const Row& row, Emit& out) {
+GL_HD void eval_unit(uint32_t u, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
   typedef Ops<T> F;
+  T w[8], sg[8];
+#pragma unroll
+  for (uint32_t i = 0; i < 8; i++) w[i] = row.loc(8 * u + i);
+#pragma unroll
+  for (uint32_t i = 0; i < 8; i++) sg[i] = row.cst(CST_SIGMA + 8 * u + i);
   const T qa = row.cst(CST_ARITH), qs = row.cst(CST_SBOX), c0 = row.cst(CST_C0), c1 = row.cst(CST_C1);
-  const T qa4[4] = {qa, qa, qa, qa}, qs4[4] = {qs, qs, qs, qs}, c04[4] = {c0, c0, c0, c0}, c14[4] = {c1, c1, c1, c1};
-  // four slots at a time; only what meets an addition or the consumer is made canonical
-#pragma unroll 1
-  for (uint32_t s = 0; s < N_SLOTS; s += 4) {
-    T a[4], b[4], c[4], ab[4], cab[4], cc[4], t[4], g[4];
-    for (uint32_t i = 0; i < 4; i++) { a[i] = row.loc(4 * (s + i)); b[i] = row.loc(4 * (s + i) + 1); c[i] = row.loc(4 * (s + i) + 2); }
-    F::mul4_lazy(a, b, ab);
-    F::mul4_lazy(c04, ab, cab);
-    F::mul4(c14, c, cc);
-    for (uint32_t i = 0; i < 4; i++) t[i] = F::sub_lazy(F::add_lazy(cab[i], cc[i]), row.loc(4 * (s + i) + 3));
-    F::mul4(qa4, t, g);
-    for (uint32_t i = 0; i < 4; i++) out.all(G0 + s + i, g[i]);
+  const T x = row.x(), kp = F::k(chunk_shift(u));
+  const T beta[2] = {F::k(ctl[0]), F::k(ctl[2])}, gamma[2] = {F::k(ctl[1]), F::k(ctl[3])};
+  // ---- gates: d - c0 a b - c1 c, times the selector; the spare slots of the groups start the two beta x k chains
+  T bkx[2];
+  {
+    const T l1[4] = {w[0], w[4], c1, c1}, r1[4] = {w[1], w[5], w[2], w[6]};
+    T p1[4];
+    F::mul4(l1, r1, p1);  // a b of the two slots, c1 c of the two slots
+    const T l2[4] = {c0, c0, beta[0], beta[1]}, r2[4] = {p1[0], p1[1], x, x};
+    T p2[4];
+    F::mul4(l2, r2, p2);  // c0 a b; beta_c x
+    const T t0 = F::sub(F::add(p2[0], p1[2]), w[3]), t1 = F::sub(F::add(p2[1], p1[3]), w[7]);
+    const T l3[4] = {qa, qa, p2[2], p2[3]}, r3[4] = {t0, t1, kp, kp};
+    T p3[4];
+    F::mul4(l3, r3, p3);
+    out.all(G0 + 2 * u, p3[0]);
+    out.all(G0 + 2 * u + 1, p3[1]);
+    bkx[0] = p3[2];
+    bkx[1] = p3[3];
   }
-  // an S-box unit: its four products in one group, the selector times its four power relations in another; the
-  // selector times the two wire relations of two units share a third
-  T pend[4] = {F::k(0), F::k(0), F::k(0), F::k(0)};
-#pragma unroll 1
-  for (uint32_t i = 0; i < N_SBOX; i++) {
-    const uint32_t u = COL_SBOX + 5 * i;
-    const T x = row.loc(u), x2 = row.loc(u + 1), x4 = row.loc(u + 2), x6 = row.loc(u + 3), x7 = row.loc(u + 4);
-    const T l4[4] = {x, x2, x4, x6}, r4[4] = {x, x2, x2, x};
-    T p4[4], d4[4], g4[4];
-    F::mul4(l4, r4, p4);
-    d4[0] = F::sub(x2, p4[0]); d4[1] = F::sub(x4, p4[1]); d4[2] = F::sub(x6, p4[2]); d4[3] = F::sub(x7, p4[3]);
-    F::mul4(qs4, d4, g4);
-    for (uint32_t k = 0; k < 4; k++) out.all(G1 + 4 * i + k, g4[k]);
-    pend[2 * (i & 1)] = F::sub(x, row.loc(4 * i));
-    pend[2 * (i & 1) + 1] = F::sub(x7, row.loc(4 * i + 3));
-    if ((i & 1) || i + 1 == N_SBOX) {
-      T w4[4];
-      F::mul4(qs4, pend, w4);
-      const uint32_t i0 = i & ~1u;
-      out.all(G2 + 2 * i0, w4[0]);
-      out.all(G2 + 2 * i0 + 1, w4[1]);
-      if (i & 1) {
-        out.all(G2 + 2 * i0 + 2, w4[2]);
-        out.all(G2 + 2 * i0 + 3, w4[3]);
+  // ---- copy constraints of chunk k = u + 1, both challenge sets from the same wires and sigmas
+  T half[2][4];  // per set: numerator halves A, B, denominator halves A, B
+#pragma unroll
+  for (uint32_t c = 0; c < 2; c++) {
+    const T b4[4] = {beta[c], beta[c], beta[c], beta[c]};
+    T pn[4], pd[4];
+#pragma unroll
+    for (uint32_t h = 0; h < 2; h++) {
+      const T s4[4] = {sg[4 * h], sg[4 * h + 1], sg[4 * h + 2], sg[4 * h + 3]};
+      T bs[4], tn[4], td[4];
+      F::mul4_lazy(b4, s4, bs);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        const T wg = F::add(w[4 * h + i], gamma[c]);
+        tn[i] = F::add_lazy(bkx[c], wg);
+        td[i] = F::add_lazy(bs[i], wg);
+        bkx[c] = F::mul7(bkx[c]);
       }
+      const T l4[4] = {tn[0], tn[2], td[0], td[2]}, r4[4] = {tn[1], tn[3], td[1], td[3]};
+      T q4[4];
+      F::mul4_lazy(l4, r4, q4);
+      pn[2 * h] = q4[0]; pn[2 * h + 1] = q4[1]; pd[2 * h] = q4[2]; pd[2 * h + 1] = q4[3];
+    }
+    const T l4[4] = {pn[0], pn[2], pd[0], pd[2]}, r4[4] = {pn[1], pn[3], pd[1], pd[3]};
+    F::mul4_lazy(l4, r4, half[c]);
+  }
+  {
+    const T l4[4] = {half[0][0], half[0][2], half[1][0], half[1][2]}, r4[4] = {half[0][1], half[0][3], half[1][1], half[1][3]};
+    T nd[4];  // num_0, den_0, num_1, den_1
+    F::mul4_lazy(l4, r4, nd);
+    const uint32_t k = u + 1;
+    T cur[2], prev[2];
+#pragma unroll
+    for (uint32_t c = 0; c < 2; c++) {
+      cur[c] = row.aux(10 * c + (k < 10 ? k : 0));
+      prev[c] = k == 1 ? row.aux_nxt(10 * c) : row.aux(10 * c + k - 1);
+    }
+    const T m4[4] = {cur[0], prev[0], cur[1], prev[1]}, n4[4] = {nd[1], nd[0], nd[3], nd[2]};
+    T g4[4];
+    F::mul4(m4, n4, g4);
+    out.all(ctl_base + u, F::sub(g4[0], g4[1]));
+    out.all(ctl_base + 11 + u, F::sub(g4[2], g4[3]));
+    if (u == 9) {
+      out.first(ctl_base + 10, F::sub(cur[0], F::k(1)));
+      out.first(ctl_base + 21, F::sub(cur[1], F::k(1)));
     }
   }
-#pragma unroll 1
-  for (uint32_t j = 0; j < 4; j++) out.first(G3 + j, F::sub(row.loc(j), F::k(row.pub(j))));
+  // ---- the S-box units of the chunk: x^2, x^4, x^6, x^7 relations and the two wire relations, times the selector
+  if (u < 6) {
+    const uint32_t n_here = u < 5 ? 2 : 1;
+    const T qs4[4] = {qs, qs, qs, qs};
+    T pend[4] = {F::k(0), F::k(0), F::k(0), F::k(0)};
+#pragma unroll
+    for (uint32_t e = 0; e < 2; e++) {
+      if (e >= n_here) break;
+      const uint32_t i = 2 * u + e, col = COL_SBOX + 5 * i;
+      const T xs = row.loc(col), x2 = row.loc(col + 1), x4 = row.loc(col + 2), x6 = row.loc(col + 3), x7 = row.loc(col + 4);
+      const T l4[4] = {xs, x2, x4, x6}, r4[4] = {xs, x2, x2, xs};
+      T p4[4], d4[4], g4[4];
+      F::mul4(l4, r4, p4);
+      d4[0] = F::sub(x2, p4[0]); d4[1] = F::sub(x4, p4[1]); d4[2] = F::sub(x6, p4[2]); d4[3] = F::sub(x7, p4[3]);
+      F::mul4(qs4, d4, g4);
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) out.all(G1 + 4 * i + q, g4[q]);
+      pend[2 * e] = F::sub(xs, w[4 * e]);          // wire a of slot i = 8u + 4e
+      pend[2 * e + 1] = F::sub(x7, w[4 * e + 3]);  // wire d of slot i
+    }
+    T w4[4];
+    F::mul4(qs4, pend, w4);
+    out.all(G2 + 4 * u, w4[0]);
+    out.all(G2 + 4 * u + 1, w4[1]);
+    if (n_here == 2) {
+      out.all(G2 + 4 * u + 2, w4[2]);
+      out.all(G2 + 4 * u + 3, w4[3]);
+    }
+  }
+  if (u == 0) {
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) out.first(G3 + j, F::sub(w[j], F::k(row.pub(j))));
+  }
 }
 }  // namespace plonk
 
@@ -975,8 +1060,10 @@ GL_HD uint32_t n_units(const Shape& s) {
          : s.air_id == PLONK ? plonk::N_UNITS
                               : synthetic::n_units(s);
 }
+// ctl_base / ctl: the index of the table's first lookup constraint and the lookup challenges -- AIR 8's units carry its
+// copy constraints (the other tables' lookup constraints are ctl::eval's)
 template <class T, class Row, class Emit>
-GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
+GL_HD void eval_unit(const Shape& s, uint32_t unit, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
   if (s.air_id == KECCAK_F) keccak::eval_unit<T>(unit, row, out);
   else if (s.air_id == LOGIC) logic::eval_unit<T>(unit, row, out);
   else if (s.air_id == MEMORY) memory::eval_unit<T>(row, out);
@@ -984,7 +1071,7 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
   else if (s.air_id == BYTE_PACKING) byte_packing::eval_unit<T>(unit, row, out);
   else if (s.air_id == KECCAK_SPONGE) keccak_sponge::eval_unit<T>(unit, row, out);
   else if (s.air_id == ARITHMETIC_MUL) arithmetic_mul::eval_unit<T>(unit, row, out);
-  else if (s.air_id == PLONK) plonk::eval_unit<T>(row, out);
+  else if (s.air_id == PLONK) plonk::eval_unit<T>(unit, ctl_base, ctl, row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
 }
 
@@ -1007,30 +1094,35 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, const Row& row, Emit& out) {
 // AIR 0  synthetic   n_cols / 8 columns: the running product over trace columns 8k, 8k+1 with challenge set k mod 2,
 //                    no filter.  A load placeholder from before the real tables existed:
 //                    nothing looks these products up.
-// AIR 1  keccak_f    5 columns: g | h_0 h_1 | z_0 z_1.  LOOKED table of "keccak_sponge -> keccak_f": the tuple is a
+// AIR 1  keccak_f    4 columns: h_0 h_1 | z_0 z_1.  LOOKED table of "keccak_sponge -> keccak_f": the tuple is a
 //                    whole permutation (50 input limbs, 50 output limbs).  Input and output live 23 rows apart, so
 //                    h_c carries the compressed input along the permutation's rows -- s_0 (h_c - sum_j beta_c^j A_j) = 0
 //                    on every row, (1 - s_23)(h_c' - h_c) = 0 on transitions -- and the tuple is read on the last
 //                    round's row: v_c = h_c + beta_c^50 sum_j beta_c^j out_j, out = the iota output for lane 0, else
 //                    the chi output.  g is the filter: which permutations the table exposes (g (g - 1) = 0,
 //                    g (1 - s_23) = 0: only last-round rows).  A table holds padding permutations nobody asks for;
-//                    exposing a subset is sound because every row of the table is a valid permutation by the AIR.
+//                    exposing a subset is sound because every row of the table is a valid permutation by the AIR and
+//                    g is a TRACE column (2430), committed before the challenges.
 // AIR 6  keccak_sponge  2 columns: z_0 z_1.  LOOKING side of the same lookup: filter is_full + is_final (every row
 //                    that absorbs a block), tuple = (xored rate limbs, capacity limbs | updated state limbs).
 // AIR 5  byte_packing  2 columns: z_0 z_1.  LOOKING side of "byte_packing -> memory": filter = the row has a length,
 //                    tuple = (is_read, address, timestamp, the eight value limbs): the word the sequence spells is ONE
 //                    operation of the memory table, whose rows hold 256-bit values.  (Upstream looks every BYTE of the
 //                    sequence up, at consecutive addresses; here the word is the unit, as in this memory table.)
-// AIR 3  memory      3 columns: g | z_0 z_1.  LOOKED side: g is the filter, which operations the table exposes
-//                    (g (g - 1) = 0); tuple = (is_read, address, timestamp, value limbs) of the row.
+// AIR 3  memory      2 columns: z_0 z_1.  LOOKED side: g (TRACE column 44) is the filter, which operations the table
+//                    exposes (g (g - 1) = 0); tuple = (is_read, address, timestamp, value limbs) of the row.
 // AIR 2, 4, 7        1 column: no lookup is built for these tables (upstream's go through the CPU table, which needs
 //                    the EVM interpreter): a constant running product z = 1 keeps the oracle set of every table the same.
 namespace ctl {
-constexpr uint32_t KECCAK_G = 0, KECCAK_H = 1, KECCAK_Z = 3, KECCAK_N_AUX = 5, KECCAK_N_CONSTRAINTS = 10;
+// The FILTER columns of the two looked tables (which rows are exposed) are TRACE columns (keccak::COL_G, memory::COL_G):
+// they are committed before the lookup challenges (beta, gamma) are drawn.  (Round 4 kept them among the auxiliary
+// columns, committed AFTER the challenges: a prover could then pick the exposed subset knowing the challenges -- a
+// subset-product search over a smooth multiplicative group)  Upstream keeps its filters in the trace too.
+constexpr uint32_t KECCAK_H = 0, KECCAK_Z = 2, KECCAK_N_AUX = 4, KECCAK_N_CONSTRAINTS = 10;
 constexpr uint32_t SPONGE_Z = 0, SPONGE_N_AUX = 2, SPONGE_N_CONSTRAINTS = 4;
 constexpr uint32_t TUPLE_LIMBS = 50;  // a Keccak state as 32-bit limbs
 constexpr uint32_t PACK_Z = 0, PACK_N_AUX = 2, PACK_N_CONSTRAINTS = 4;
-constexpr uint32_t MEM_G = 0, MEM_Z = 1, MEM_N_AUX = 3, MEM_N_CONSTRAINTS = 5;
+constexpr uint32_t MEM_Z = 0, MEM_N_AUX = 2, MEM_N_CONSTRAINTS = 5;
 constexpr uint32_t WORD_TUPLE = 11;  // is_read, address, timestamp, eight value limbs
 // AIR 8 (plonk): per challenge set c, column 10 c = Z_c and 10 c + k = the k-th partial product, k = 1..9
 constexpr uint32_t PLONK_N_AUX = 20, PLONK_N_CONSTRAINTS = 22, PLONK_CHUNK = 8, PLONK_CHUNKS = 10;
@@ -1082,7 +1174,7 @@ GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const 
     const T out = compress<T>([&](uint32_t j) { return j < 2 ? row.loc(keccak::COL_APPP + j) : row.loc(keccak::COL_APP + j); },
                               TUPLE_LIMBS, beta);
     const T v = F::add(row.aux(KECCAK_H + c), F::mul(b50, out));
-    return F::add(F::k(1), F::mul(row.aux(KECCAK_G), F::sub(F::add(gamma, v), F::k(1))));
+    return F::add(F::k(1), F::mul(row.loc(keccak::COL_G), F::sub(F::add(gamma, v), F::k(1))));
   }
   if (s.air_id == KECCAK_SPONGE) {
     const uint32_t c = col - SPONGE_Z;
@@ -1119,7 +1211,7 @@ GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const 
              : j == 2 ? row.loc(memory::COL_TS)
                       : row.loc(memory::COL_VAL + j - 3);
     }, WORD_TUPLE, beta);
-    return F::add(F::k(1), F::mul(row.aux(MEM_G), F::sub(F::add(gamma, v), F::k(1))));
+    return F::add(F::k(1), F::mul(row.loc(memory::COL_G), F::sub(F::add(gamma, v), F::k(1))));
   }
   return F::k(1);
 }
@@ -1137,66 +1229,14 @@ GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const 
 // The products are taken in groups of four independent multiplications (Ops::mul4 / mul4_lazy: only the last level
 // needs canonical results): beta sigma_j for four wires (beta x k_j is a chain of multiplications by 7), then the pair products of numerator and denominator terms, then the halves; the chunk's last two levels
 // last level (cur den, prev num) rides in the next chunk's last group, so every group is full.
-template <class T, class Row, class Emit>
-GL_HD void eval_plonk(uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ctl[4], const Row& row, Emit& out) {
-  typedef Ops<T> F;
-  const T x = row.x();
-#pragma unroll 1
-  for (uint32_t c = k0 / 10; c < (k1 + 9) / 10; c++) {
-    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
-    const T bx = F::mul(beta, x);
-    const T b4[4] = {beta, beta, beta, beta};
-    T bkx = bx;  // beta x k_j, k_j = 7^j: a chain of multiplications by 7 (lazy: any representative)
-    T prev = row.aux_nxt(10 * c);
-    // the chunk before this one, one level from done: its numerator, denominator and the two running-product values
-    T num_ = F::k(0), den_ = F::k(0), cur_ = F::k(0), prev_ = F::k(0);
-#pragma unroll 1
-    for (uint32_t k = 1; k <= PLONK_CHUNKS; k++) {
-      T pn[4], pd[4];  // pair products of the chunk's eight numerator / denominator terms
-#pragma unroll 1
-      for (uint32_t h = 0; h < 2; h++) {
-        const uint32_t j0 = PLONK_CHUNK * (k - 1) + 4 * h;
-        T sg[4], bs[4];
-        for (uint32_t i = 0; i < 4; i++) sg[i] = row.cst(plonk::CST_SIGMA + j0 + i);
-        F::mul4_lazy(b4, sg, bs);
-        T tn[4], td[4];
-        for (uint32_t i = 0; i < 4; i++) {
-          const T w = F::add(row.loc(j0 + i), gamma);
-          tn[i] = F::add_lazy(bkx, w);
-          td[i] = F::add_lazy(bs[i], w);
-          bkx = F::mul7(bkx);
-        }
-        const T l4[4] = {tn[0], tn[2], td[0], td[2]}, r4[4] = {tn[1], tn[3], td[1], td[3]};
-        T q4[4];
-        F::mul4_lazy(l4, r4, q4);
-        pn[2 * h] = q4[0]; pn[2 * h + 1] = q4[1]; pd[2 * h] = q4[2]; pd[2 * h + 1] = q4[3];
-      }
-      const T cur = row.aux(10 * c + (k < PLONK_CHUNKS ? k : 0));
-      const T l4[4] = {pn[0], pn[2], pd[0], pd[2]}, r4[4] = {pn[1], pn[3], pd[1], pd[3]};
-      T hv[4];  // the halves: numerator A, B, denominator A, B
-      F::mul4_lazy(l4, r4, hv);
-      // this chunk's numerator and denominator; the previous chunk's cur den and prev num
-      const T m4[4] = {hv[0], hv[2], cur_, prev_}, n4[4] = {hv[1], hv[3], den_, num_};
-      T g4[4];
-      F::mul4(m4, n4, g4);
-      if (k > 1) out.all(base + 11 * c + k - 2, F::sub(g4[2], g4[3]));
-      num_ = g4[0]; den_ = g4[1]; cur_ = cur; prev_ = prev;
-      prev = cur;
-    }
-    out.all(base + 11 * c + PLONK_CHUNKS - 1, F::sub(F::mul(cur_, den_), F::mul(prev_, num_)));
-    out.first(base + 11 * c + 10, F::sub(row.aux(10 * c), F::k(1)));
-  }
-}
+// (Evaluated by plonk::eval_unit, chunk by chunk next to the gates that read the same wires.)
 
 // The lookup part of the constraint list.  Synthetic tables: products [k0, k1) (their unit slicing); every other
 // table: everything (one unit).
 template <class T, class Row, class Emit>
 GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const uint64_t ctl[4], const Row& row, Emit& out) {
   typedef Ops<T> F;
-  if (s.air_id == PLONK) {
-    eval_plonk<T>(base, k0, k1, ctl, row, out);
-    return;
-  }
+  if (s.air_id == PLONK) return;  // the copy constraints ride in the AIR's own units (plonk::eval_unit)
   if (s.air_id == SYNTHETIC) {
 #pragma unroll 1
     for (uint32_t k = k0; k < k1; k++) {
@@ -1208,7 +1248,7 @@ GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const u
   }
   uint32_t idx = base;
   if (s.air_id == KECCAK_F) {
-    const T g = row.aux(KECCAK_G), s0 = row.loc(keccak::COL_STEP), s23 = row.loc(keccak::COL_STEP + 23);
+    const T g = row.loc(keccak::COL_G), s0 = row.loc(keccak::COL_STEP), s23 = row.loc(keccak::COL_STEP + 23);
     out.all(idx++, F::sub(F::mul(g, g), g));
     out.all(idx++, F::mul(g, F::sub(F::k(1), s23)));
 #pragma unroll 1
@@ -1220,7 +1260,7 @@ GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const u
     }
   }
   if (s.air_id == MEMORY) {
-    const T g = row.aux(MEM_G);
+    const T g = row.loc(memory::COL_G);
     out.all(idx++, F::sub(F::mul(g, g), g));
   }
   const uint32_t p0 = first_product(s.air_id), p1 = n_aux(s);

@@ -215,9 +215,9 @@ int entry_work(const Entry& e, const bp_gi_options& o, bp_gi_chain* chain, bool 
   uint32_t log_n[BP_NUM_TABLES], width[BP_NUM_TABLES];
   std::memcpy(log_n, o.table_log_n, sizeof(log_n));
   std::memcpy(width, o.table_width, sizeof(width));
-  if (f & BP_GI_KECCAK_AIR) width[3] = 2430;
+  if (f & BP_GI_KECCAK_AIR) width[3] = 2431;
   if (f & BP_GI_KECCAK_SPONGE_AIR) width[4] = 2414;
-  if (f & BP_GI_MEMORY_AIR) width[6] = 44;
+  if (f & BP_GI_MEMORY_AIR) width[6] = 45;
   if (f & BP_GI_BYTE_PACKING_AIR) width[1] = 299;
   if (f & BP_GI_KECCAK_AIR) {
     // the heights grow to hold the work (24 rows per permutation); the witness itself only when it is asked for

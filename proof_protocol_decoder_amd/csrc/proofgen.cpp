@@ -571,9 +571,9 @@ static int parse_ir(const bp_config& cfg, const uint64_t* I, const TxnWitness* w
   // version 1: a transaction; version 2: a dummy entry (decoding.rs:484-520): txn number, gas and state
   // root do not advance, the same tables are proven
   // flags above the version byte: 0x100 = the Keccak table (index 3, prover_state.rs:85-93) is proven with the
-  // Keccak-f AIR (air.hpp, AIR 1) instead of the synthetic one: 2430 columns, witness drawn from the seed;
+  // Keccak-f AIR (air.hpp, AIR 1) instead of the synthetic one: 2431 columns, witness drawn from the seed;
   // 0x200 = the logic table (index 5) is proven with the logic AIR (AIR 2): 523 columns, operations drawn from the seed;
-  // 0x400 = the memory table (index 6) with the memory AIR (AIR 3): 44 columns, a sorted log drawn from the seed;
+  // 0x400 = the memory table (index 6) with the memory AIR (AIR 3): 45 columns, a sorted log drawn from the seed;
   // 0x800 = the arithmetic table (index 0) with the arithmetic AIR (AIR 4): 309 columns;
   // 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (AIR 5): 299 columns;
   // 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6): 2414 columns
@@ -673,7 +673,7 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
   if (lookup_bm && !given(6) && tcfg[6].log_n < tcfg[1].log_n + 1)
     return fail(BP_ERR_INVALID_INPUT, "the memory table (2^%u rows) cannot hold the operations of the byte-packing table (2^%u rows): "
                 "two per row", tcfg[6].log_n, tcfg[1].log_n);
-  static const int GEN_ORDER[BP_NUM_TABLES] = {4, 0, 1, 2, 3, 5, 6};  // the sponge table before the Keccak-f table that reads it
+  static const int GEN_ORDER[BP_NUM_TABLES] = {4, 0, 1, 2, 3, 5, 6};  // a looking table before the table it looks up (sponge before Keccak-f, byte packing before memory)
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     const uint64_t N = (uint64_t)1 << tcfg[t].log_n;
     d_trace[t] = w.arena.alloc_words((size_t)tcfg[t].n_cols * N);
@@ -712,6 +712,16 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
         r = launch_keccak_sponge_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream, sponge_row_limit);
         break;
       default: r = launch_synth_trace(d_trace[t], nullptr, tcfg[t].log_n, tcfg[t].n_cols, 0, 1, seed, w.stream); break;
+    }
+    if (r) return r;
+    // the filter column of a looked table (air::ctl) is part of its TRACE: written here, committed with the trace, i.e.
+    // before the lookup challenges are drawn.  The looking table's trace is there already (GEN_ORDER).
+    if (t == 3 && lookup_kf) {  // the permutations the sponge table asks for: its flag columns, row p <-> permutation p
+      const uint64_t N4 = (uint64_t)1 << tcfg[4].log_n;
+      r = launch_lookup_filter(air::KECCAK_F, d_trace[3], tcfg[3].log_n, d_trace[4] + (size_t)air::keccak_sponge::COL_FULL * N4,
+                               d_trace[4] + (size_t)air::keccak_sponge::COL_FINAL * N4, (uint32_t)N4, w.stream);
+    } else if (t == 6 && lookup_bm) {  // the operations the byte-packing table looks up: its trace (address, timestamp per row)
+      r = launch_lookup_filter(air::MEMORY, d_trace[6], tcfg[6].log_n, d_trace[1], nullptr, (uint32_t)1 << tcfg[1].log_n, w.stream);
     }
     if (r) return r;
     if (d_in) {  // the staging buffer and the input words are reused by the next table
@@ -769,18 +779,7 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
     if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before table %s", TABLE_NAMES[t]);
     const size_t mark = w.arena.mark();
     Challenger before = ch;  // the transcript as the verifier of this table proof starts from it
-    LookupHint hint;
-    if (t == 3 && lookup_kf) {  // the permutations the sponge table asks for: its flag columns, row p <-> permutation p
-      const uint64_t N4 = (uint64_t)1 << tcfg[4].log_n;
-      hint.flag_a = d_trace[4] + (size_t)air::keccak_sponge::COL_FULL * N4;
-      hint.flag_b = d_trace[4] + (size_t)air::keccak_sponge::COL_FINAL * N4;
-      hint.n_flags = (uint32_t)N4;
-    }
-    if (t == 6 && lookup_bm) {  // the operations the byte-packing table looks up: its trace (address, timestamp per row)
-      hint.flag_a = d_trace[1];
-      hint.n_flags = (uint32_t)1 << tcfg[1].log_n;
-    }
-    if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, tp->proof[t], &hint))) return r;
+    if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, tp->proof[t]))) return r;
     if (given(t)) {
       // The prover does not check a witness, and nothing downstream of this call verifies the table proofs (upstream's
       // root circuit would): data that came from the caller is therefore checked here, by the CPU verifier on the

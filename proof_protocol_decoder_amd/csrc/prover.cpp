@@ -406,7 +406,8 @@ int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t
   qa.n_constraints = qa.n_air_constraints + air::ctl::n_constraints(shape);
   qa.n_air_units = air::n_units(shape);
   qa.aux_per_unit = cfg.air_id == air::SYNTHETIC ? std::max<uint32_t>(16, (A + 15) / 16) : A;
-  qa.n_ctl_units = (A + qa.aux_per_unit - 1) / qa.aux_per_unit;
+  // (AIR 8's copy constraints ride in its own ten units, next to the gates that read the same wires: no lookup unit)
+  qa.n_ctl_units = cfg.air_id == air::PLONK ? 0 : (A + qa.aux_per_unit - 1) / qa.aux_per_unit;
   // One pass (the alpha fold never leaves the registers) once the rows alone fill the chip: 2048 workgroups of
   // 256 lanes = 2 per SIMD.  Shorter tables spread their units over grid.y until the launch has that many.
   // While several provers share the device nothing needs filling: one pass, one launch fewer on the proof's
@@ -454,13 +455,13 @@ int fri_layer_args(uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uin
 
 // ------------------------------------------------------------------ one table, or a batch of equally shaped ones
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
-                const uint64_t* d_tv, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof, const LookupHint* hint) {
-  return stark_prove_batch(w, cfg, 1, &consts, &trace, &d_tv, &ctl, &ch, &proof, hint);
+                const uint64_t* d_tv, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof) {
+  return stark_prove_batch(w, cfg, 1, &consts, &trace, &d_tv, &ctl, &ch, &proof);
 }
 
 int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committed* const* consts,
                       const Committed* trace, const uint64_t* const* d_tv, const Ctl* ctl, Challenger* ch,
-                      std::vector<uint64_t>* proofs, const LookupHint* hints) {
+                      std::vector<uint64_t>* proofs) {
   TRY(check_cfg(cfg));
   if (B == 0 || B > MAX_BATCH || (size_t)B * cfg.num_queries > MAX_BATCH_QUERIES)
     return fail(BP_ERR_INVALID_INPUT, "stark_prove_batch: %u proofs x %u queries (at most %u proofs, %u queries in all)", B,
@@ -495,7 +496,6 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committe
     AuxArgs aa[MAX_BATCH];
     for (uint32_t b = 0; b < B; b++) {
       aa[b] = AuxArgs{d_tv[b], d_auxv + (size_t)b * A * N, ctl[b]};
-      if (hints) { aa[b].flag_a = hints[b].flag_a; aa[b].flag_b = hints[b].flag_b; aa[b].n_flags = hints[b].n_flags; }
       if (K) aa[b].consts = consts[b]->values;
     }
     TRY(launch_aux(aa, B, cfg.air_id, C, log_n, st));

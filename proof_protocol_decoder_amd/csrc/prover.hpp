@@ -146,25 +146,15 @@ int commit_finish(const PendingCommit& pc, Committed* out);
 
 // prove_single_table on the synthetic AIR.  The caller has already observed the trace cap(s) and
 // drawn ctl (plonky2_evm prover order).  Fills `proof` (proof_layout(cfg).total words).
-// hint (nullable): what the prover of a LOOKED table needs to know about its looking tables (air::ctl) -- for the
-// Keccak-f table, which permutations the sponge table asks for: permutation p when flag_a[p] + flag_b[p] != 0 (the two
-// flag columns of the sponge table's trace on the device); for the memory table, which operations the byte-packing
-// table looks up: flag_a = that table's trace on the device (its address and timestamp columns name the operation),
-// n_flags = its rows.  Without a hint the table exposes nothing.
-struct LookupHint {
-  const uint64_t *flag_a = nullptr, *flag_b = nullptr;
-  uint32_t n_flags = 0;
-};
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
-                const uint64_t* d_trace_values, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof,
-                const LookupHint* hint = nullptr);
+                const uint64_t* d_trace_values, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof);
 // The same for `batch` (<= MAX_BATCH, batch * num_queries <= MAX_BATCH_QUERIES) proofs of ONE shape in lock-step:
 // independent transcripts, every kernel launch and every host wait shared (the seven per-table recursion chains of
 // a transaction, proofgen.cpp).  Proof b's bytes are those stark_prove would give for (consts[b], trace[b], ...).
 // consts: per proof, may be null when the shape has no constant columns.
 int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t batch, const Committed* const* consts,
                       const Committed* trace, const uint64_t* const* d_trace_values, const Ctl* ctl, Challenger* ch,
-                      std::vector<uint64_t>* proofs, const LookupHint* hints = nullptr);
+                      std::vector<uint64_t>* proofs);
 
 void tune_host_wait(int mode);  // bp_tune_host_wait
 void tune_host_poseidon(int mode);  // bp_tune_host_poseidon

@@ -117,6 +117,7 @@ keccak_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ input
     for (uint32_t z = 0; z < 64; z++) put(kk::COL_APP0_BITS + z, (R.app[0] >> z) & 1);
     put(kk::COL_APPP, (uint32_t)R.appp0);
     put(kk::COL_APPP + 1, R.appp0 >> 32);
+    put(kk::COL_G, 0);  // nothing exposed to the lookup until lookup_filter_kernel says otherwise
   } else {
     const uint32_t y = blockIdx.y - 1;
     for (uint32_t x = 0; x < 5; x++) {
@@ -201,6 +202,7 @@ memory_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ input
   for (uint32_t k = 0; k < 8; k++) put(mm::COL_VAL + k, gl::canon(v[k]));
   put(mm::COL_CHG, chg);
   for (uint32_t z = 0; z < 32; z++) put(mm::COL_GAP + z, (gap >> z) & 1);
+  put(mm::COL_G, 0);  // nothing exposed to the lookup until launch_lookup_filter says otherwise
 }
 
 // ---------------------------------------------------------------- arithmetic witness (AIR 4, air.hpp)
@@ -514,10 +516,8 @@ aux_suffix_product_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n, uint
     done = gl::mulc(done, whole);
   }
 }
-// The helper columns of the Keccak-f table's lookup (air::ctl): g, the filter -- 1 on the last-round row of every
-// permutation the table exposes, i.e. permutation p when the looking table's row p absorbs a block (flag_a + flag_b of
-// the sponge table's trace, null: none) --, and h_0 / h_1, the permutation's input compressed by beta_0 / beta_1 and
-// carried along its rows.  A lane owns a row; it reads the 50 input limbs of its permutation's first row.
+// The helper columns of the Keccak-f table's lookup (air::ctl): h_0 / h_1, the permutation's input compressed by beta_0 /
+// beta_1 and carried along its rows.  A lane owns a row; it reads the 50 input limbs of its permutation's first row.
 __global__ void __launch_bounds__(256)
 keccak_ctl_helpers_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
   if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);
@@ -526,9 +526,7 @@ keccak_ctl_helpers_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
   const bpg::AuxArgs& a = batch.a[blockIdx.z];
   const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t perm = i / 24, first = perm * 24;
-  const bool used = i % 24 == 23 && a.flag_a && perm < a.n_flags && (a.flag_a[perm] + a.flag_b[perm]) != 0;
-  a.aux[(uint64_t)ct::KECCAK_G * n + i] = used;
+  const uint32_t first = (i / 24) * 24;
 #pragma unroll 1
   for (uint32_t c = 0; c < 2; c++) {
     const uint64_t beta = a.ctl.v[2 * c];
@@ -539,32 +537,39 @@ keccak_ctl_helpers_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
   }
 }
 
-// The filter column of the memory table's lookup (air::ctl): g = 1 on the operations the byte-packing table looks up.
-// A lane owns a packing row that moves a word and finds its operation -- (address, timestamp) -- in the memory trace,
-// which is sorted by (address, timestamp), by bisection.  flag_a = the packing table's trace, n_flags = its rows.
-__global__ void __launch_bounds__(256) memory_ctl_clear_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
+// The FILTER columns of the two looked tables -- which rows a table exposes to its lookup (air::ctl) -- are columns of the
+// TRACE, written when the witness is generated and committed with it, i.e. before the lookup challenges exist.
+// Keccak-f table: g = 1 on the last-round row of permutation p when the looking (sponge) table's row p absorbs a block
+// (flag_a + flag_b: the two flag columns of the sponge table's trace, n_flags rows).
+__global__ void __launch_bounds__(256)
+keccak_lookup_filter_kernel(uint64_t* __restrict__ trace, uint32_t log_n, const uint64_t* __restrict__ flag_a,
+                            const uint64_t* __restrict__ flag_b, uint32_t n_flags) {
   const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) batch.a[blockIdx.z].aux[(uint64_t)bpg::air::ctl::MEM_G * n + i] = 0;
+  if (i >= n) return;
+  const uint32_t perm = i / 24;
+  trace[(uint64_t)bpg::air::keccak::COL_G * n + i] = i % 24 == 23 && perm < n_flags && (flag_a[perm] + flag_b[perm]) != 0;
 }
-__global__ void __launch_bounds__(256) memory_ctl_flags_kernel(bpg::BatchOf<bpg::AuxArgs> batch, uint32_t log_n) {
+// Memory table: g = 1 on the operations the byte-packing table looks up.  A lane owns a packing row that moves a word and
+// finds its operation -- (address, timestamp) -- in the memory trace, which is sorted by (address, timestamp), by
+// bisection.  pack = the packing table's trace of P rows.  (The column was zeroed by memory_trace_kernel.)
+__global__ void __launch_bounds__(256)
+memory_lookup_filter_kernel(uint64_t* __restrict__ trace, uint32_t log_n, const uint64_t* __restrict__ pack, uint32_t P) {
   namespace bp = bpg::air::byte_packing;
   namespace mm = bpg::air::memory;
-  const bpg::AuxArgs& a = batch.a[blockIdx.z];
-  const uint32_t n = 1u << log_n, P = a.n_flags, r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (!a.flag_a || r >= P) return;
-  const uint64_t* pack = a.flag_a;
+  const uint32_t n = 1u << log_n, r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P) return;
   uint64_t has = 0;
   for (uint32_t j = 0; j < 32; j++) has += pack[(uint64_t)(bp::COL_LEN + j) * P + r];
   if (!has) return;
   const uint64_t addr = pack[(uint64_t)bp::COL_ADDR * P + r], ts = pack[(uint64_t)bp::COL_TS * P + r];
-  const uint64_t *ma = a.trace + (uint64_t)mm::COL_ADDR * n, *mt = a.trace + (uint64_t)mm::COL_TS * n;
+  const uint64_t *ma = trace + (uint64_t)mm::COL_ADDR * n, *mt = trace + (uint64_t)mm::COL_TS * n;
   uint32_t lo = 0, hi = n;  // first row with (address, timestamp) >= (addr, ts)
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
     const uint64_t x = ma[mid], y = mt[mid];
     if (x < addr || (x == addr && y < ts)) lo = mid + 1; else hi = mid;
   }
-  if (lo < n && ma[lo] == addr && mt[lo] == ts) a.aux[(uint64_t)bpg::air::ctl::MEM_G * n + lo] = 1;
+  if (lo < n && ma[lo] == addr && mt[lo] == ts) trace[(uint64_t)mm::COL_G * n + lo] = 1;
 }
 
 // ---------------------------------------------------------------- AIR 8 (plonk, air.hpp): constants, witness, copy products
@@ -814,7 +819,7 @@ quotient_air_kernel(bpg::BatchOf<bpg::QuotArgs> batch) {
       else if constexpr (AIR == bpg::air::BYTE_PACKING) bpg::air::byte_packing::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::KECCAK_SPONGE) bpg::air::keccak_sponge::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::ARITHMETIC_MUL) bpg::air::arithmetic_mul::eval_unit<uint64_t>(u, row, out);
-      else if constexpr (AIR == bpg::air::PLONK) bpg::air::plonk::eval_unit<uint64_t>(row, out);
+      else if constexpr (AIR == bpg::air::PLONK) bpg::air::plonk::eval_unit<uint64_t>(u, q.n_air_constraints, q.ctl.v, row, out);
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -1426,6 +1431,20 @@ int launch_memory_inputs_from_byte_packing(const uint64_t* d_pack_trace, uint32_
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_lookup_filter(uint32_t air_id, uint64_t* d_trace, uint32_t log_n, const uint64_t* flag_a, const uint64_t* flag_b,
+                         uint32_t n_flags, hipStream_t st) {
+  if (!flag_a || !n_flags) return BP_OK;  // nothing is exposed: the trace kernels left the column zero
+  if (air_id == air::KECCAK_F) {
+    if (!flag_b) return fail(BP_ERR_INVALID_INPUT, "launch_lookup_filter: the Keccak-f table's filter needs both flag columns of the sponge table");
+    keccak_lookup_filter_kernel<<<ceil_div((uint64_t)1 << log_n, 256), 256, 0, st>>>(d_trace, log_n, flag_a, flag_b, n_flags);
+  } else if (air_id == air::MEMORY) {
+    memory_lookup_filter_kernel<<<ceil_div(n_flags, 256), 256, 0, st>>>(d_trace, log_n, flag_a, n_flags);
+  } else {
+    return fail(BP_ERR_INVALID_INPUT, "launch_lookup_filter: AIR %u is not a looked table", air_id);
+  }
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st) {
   arithmetic_mul_trace_kernel<<<ceil_div((uint64_t)1 << log_n, 256), 256, 0, st>>>(d_trace, d_inputs, log_n, seed);
   BPG_LAUNCH_CHECK();
@@ -1454,16 +1473,6 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
     keccak_ctl_helpers_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), 1, batch), 256, 0, st>>>(ab, log_n);
     BPG_LAUNCH_CHECK();
   }
-  if (air_id == air::MEMORY) {  // the filter column: which operations the byte-packing table looks up
-    uint32_t rows = 0;
-    for (uint32_t b = 0; b < batch; b++) rows = std::max(rows, a[b].flag_a ? a[b].n_flags : 0u);
-    memory_ctl_clear_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), 1, batch), 256, 0, st>>>(ab, log_n);
-    BPG_LAUNCH_CHECK();
-    if (rows) {
-      memory_ctl_flags_kernel<<<dim3(ceil_div(rows, 256), 1, batch), 256, 0, st>>>(ab, log_n);
-      BPG_LAUNCH_CHECK();
-    }
-  }
   uint32_t threads = (1u << log_n) < 1024 ? (1u << log_n) : 1024;
   if (threads < 64) threads = 64;
   if (air_id == air::PLONK) {  // chunk ratios per row, suffix products of the row totals, partial products
@@ -1483,7 +1492,7 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
   const dim3 grid(n_aux - p0, 1, batch);
   // algorithmic bytes: every column a product reads, once, and the product column written (SURVEY.md section 8(d):
   // 24 n per column of a synthetic table)
-  const double reads = air_id == air::SYNTHETIC ? 2 : air_id == air::KECCAK_F ? 52 : air_id == air::KECCAK_SPONGE ? 102
+  const double reads = air_id == air::SYNTHETIC ? 2 : air_id == air::KECCAK_F ? 53 : air_id == air::KECCAK_SPONGE ? 102
                        : air_id == air::BYTE_PACKING ? 43 : air_id == air::MEMORY ? 12 : 0;
   KernelTimer kt(PROF_AUX, st, 8.0 * (double)((uint64_t)1 << log_n) * (reads + 1) * (n_aux - p0) * batch, true);
   switch (air_id) {

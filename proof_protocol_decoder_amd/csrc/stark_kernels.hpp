@@ -54,10 +54,6 @@ struct AuxArgs {
   const uint64_t* trace;
   uint64_t* aux;
   Ctl ctl;
-  // Keccak-f table only (air::ctl): permutation p is exposed to the lookup when flag_a[p] + flag_b[p] != 0 -- the two
-  // flag columns of the looking (sponge) table's trace, n_flags rows of it; null: nothing is exposed
-  const uint64_t *flag_a = nullptr, *flag_b = nullptr;
-  uint32_t n_flags = 0;
   const uint64_t* consts = nullptr;  // AIR 8: the preprocessed constant columns on the trace domain ([K][n]: the sigmas)
 };
 struct PowerVecArgs {
@@ -182,6 +178,12 @@ int launch_keccak_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sp
 // the memory log ([n_mem][11], for launch_memory_trace) that goes with a byte-packing trace: two operations per packing row
 int launch_memory_inputs_from_byte_packing(const uint64_t* d_pack_trace, uint32_t pack_log_n, uint64_t* d_log, uint32_t n_mem,
                                            hipStream_t st);
+// The filter column of a LOOKED table's trace (air::ctl; keccak::COL_G, memory::COL_G), written after its witness and
+// before its commitment: Keccak-f table: permutation p is exposed when flag_a[p] + flag_b[p] != 0 (the two flag columns of
+// the sponge table's trace, n_flags rows of it); memory table: flag_a = the byte-packing table's trace of n_flags rows
+// (its address and timestamp columns name the operations it looks up), flag_b unused.  flag_a null: nothing is exposed.
+int launch_lookup_filter(uint32_t air_id, uint64_t* d_trace, uint32_t log_n, const uint64_t* flag_a, const uint64_t* flag_b,
+                         uint32_t n_flags, hipStream_t st);
 int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_cols, uint32_t log_n, hipStream_t st);
 // AIR 8 (plonk): the constants (selectors, gate constants, sigmas of the fixed circuit) and the witness

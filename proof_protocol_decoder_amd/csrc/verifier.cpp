@@ -137,7 +137,7 @@ int stark_verify(const StarkCfg& cfg, const uint64_t* const_cap, const Ctl& ctl,
     k.l_first = gl::mul(zhn, gl::inv(gl::sub(zeta, gl::ext(1))));
     k.l_last = gl::mul(zhn, gl::inv(gl::sub(gl::scale(zeta, g), gl::ext(1))));
     const OpenedRow row{oz, oz + 2 * (size_t)K, on, oz + 2 * (size_t)(K + C), on + 2 * (size_t)C, zeta, ctl.pub};
-    for (uint32_t u = 0; u < air::n_units(shape); u++) air::eval_unit<Ext>(shape, u, row, k);
+    for (uint32_t u = 0; u < air::n_units(shape); u++) air::eval_unit<Ext>(shape, u, n_air, ctl.v, row, k);
     air::ctl::eval<Ext>(shape, n_air, 0, A, ctl.v, row, k);
     const uint64_t* oq = oz + 2 * (size_t)(K + C + A);
     for (int j = 0; j < 2; j++) {

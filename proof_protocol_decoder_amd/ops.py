@@ -73,9 +73,9 @@ def field_ops(a, b):
 
 
 AIR_SYNTHETIC, AIR_KECCAK_F = 0, 1
-KECCAK_COLS = 2430
+KECCAK_COLS = 2431
 LOGIC_COLS = 523
-MEMORY_COLS = 44
+MEMORY_COLS = 45
 ARITHMETIC_COLS = 309
 BYTE_PACKING_COLS = 299
 KECCAK_SPONGE_COLS = 2414
@@ -102,7 +102,7 @@ def logic_trace(log_n, seed=0, inputs=None, device="cuda"):
 
 
 def memory_trace(log_n, seed=0, inputs=None, device="cuda"):
-    """bp_memory_trace: the AIR-3 witness [44, 2^log_n]; inputs [2^log_n, 11] int64 on the device (is_read, address,
+    """bp_memory_trace: the AIR-3 witness [45, 2^log_n]; inputs [2^log_n, 11] int64 on the device (is_read, address,
     timestamp, eight value limbs; sorted by address then timestamp), or a log drawn from `seed`."""
     out = torch.empty((MEMORY_COLS, 1 << log_n), dtype=torch.int64, device=device)
     if inputs is not None:
@@ -157,7 +157,7 @@ def arithmetic_mul_trace(log_n, seed=0, inputs=None, device="cuda"):
 
 
 def keccak_trace(log_n, seed=0, inputs=None, device="cuda"):
-    """bp_keccak_trace: the AIR-1 witness [2430, 2^log_n]; inputs [n_perm, 25] int64 lanes on the device, or drawn
+    """bp_keccak_trace: the AIR-1 witness [2431, 2^log_n]; inputs [n_perm, 25] int64 lanes on the device, or drawn
     from `seed`."""
     out = torch.empty((KECCAK_COLS, 1 << log_n), dtype=torch.int64, device=device)
     if inputs is not None:

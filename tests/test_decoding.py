@@ -541,7 +541,7 @@ def test_keccak_work_of_a_decoded_transaction():
             assert out[:4].astype("<u8").tobytes() == compact.keccak256(msg)
             k += n
     irs = irs_from_generation_inputs(gis, 17, (6, 5, 7, 7, 5, 6, 9), (16, 8, 24, 40, 16, 24, 8), keccak_air=True)
-    assert all(ir.keccak_air and ir.table_width[3] == 2430 and ir.table_log_n[3] >= 7 for ir in irs)
+    assert all(ir.keccak_air and ir.table_width[3] == 2431 and ir.table_log_n[3] >= 7 for ir in irs)
     assert all(24 * len(ir.keccak_inputs) <= (1 << ir.table_log_n[3]) for ir in irs)
 
 
@@ -606,7 +606,7 @@ def test_memory_and_byte_packing_work_of_a_decoded_transaction():
                                      keccak_trie_nodes=True, memory_air=True, byte_packing_air=True)
     busy = 0
     for g, ir in zip(gis, irs):
-        assert ir.memory_air and ir.byte_packing_air and ir.table_width[6] == 44 and ir.table_width[1] == 299
+        assert ir.memory_air and ir.byte_packing_air and ir.table_width[6] == 45 and ir.table_width[1] == 299
         pre = hashed_preimages_of_generation_inputs(g, trie_nodes=True)
         blob = b"".join(pre)
         wit = dict(ir.witness)

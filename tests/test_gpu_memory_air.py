@@ -17,7 +17,7 @@ SEED = 0x5EED000000000007
 def test_witness_matches_oracle(bpg, oracle, log_n):
     want = oracle.memory_trace(log_n, seed=SEED + log_n)
     got = to_host(bpg.ops.memory_trace(log_n, seed=SEED + log_n))
-    assert got.shape == want.shape == (44, 1 << log_n) and (got == want).all()
+    assert got.shape == want.shape == (45, 1 << log_n) and (got == want).all()
     if log_n <= 10:
         log = random_log(1 << log_n, log_n)
         assert (to_host(bpg.ops.memory_trace(log_n, inputs=to_dev(log))) == oracle.memory_trace(log_n, inputs=log)).all()
@@ -28,22 +28,22 @@ def test_quotient_eval_matches_oracle(bpg, oracle, log_n):
     """K5 alone on AIR 3: random LDE matrices, fixed challenges (2^17 rows is the S1 memory table's height)."""
     rng = np.random.default_rng(1100 + log_n)
     rows = (1 << log_n) << 1
-    trace = rand_field(rng, (44, rows))
-    aux = rand_field(rng, (3, rows))
+    trace = rand_field(rng, (45, rows))
+    aux = rand_field(rng, (2, rows))
     ctl, alphas = rand_field(rng, (4,)), rand_field(rng, (2,))
-    want = oracle.quotient_values(oracle.make_cfg(log_n, 44, air_id=3), None, trace, aux, ctl, alphas[0], alphas[1])
+    want = oracle.quotient_values(oracle.make_cfg(log_n, 45, air_id=3), None, trace, aux, ctl, alphas[0], alphas[1])
     idx = coset_major_to_natural(log_n, 1)
 
     def to_cm(mat):
         cm = np.empty_like(mat)
         cm[:, idx] = mat
         return to_dev(cm)
-    got = bpg.ops.quotient_eval(bpg.ops.stark_cfg(log_n, 44), to_cm(trace), to_cm(aux), None, ctl, alphas, air_id=3)
+    got = bpg.ops.quotient_eval(bpg.ops.stark_cfg(log_n, 45), to_cm(trace), to_cm(aux), None, ctl, alphas, air_id=3)
     assert (to_host(got)[:, idx] == want).all()
 
 
 def oracle_proof(oracle, log_n, nq, pb, seed):
-    cfg = oracle.make_cfg(log_n, 44, num_queries=nq, pow_bits=pb, air_id=3)
+    cfg = oracle.make_cfg(log_n, 45, num_queries=nq, pow_bits=pb, air_id=3)
     tr = oracle.memory_trace(log_n, seed=seed)
     tc = oracle.Committed.from_values(tr, 1, 4)
     ch = oracle.PyChallenger()
@@ -63,7 +63,7 @@ def test_table_proof_bit_exact(bpg, oracle, log_n, nq, pb, loaded):
     """prove -> verify, bit-flip rejection, HIP bytes == oracle bytes; 2^17 rows = the S1 memory table (constants.rs:15:
     the reference's range starts at 17)."""
     cfg, want, ctl, chv = oracle_proof(oracle, log_n, nq, pb, SEED)
-    pc = bpg.ops.stark_cfg(log_n, 44, num_queries=nq, pow_bits=pb)
+    pc = bpg.ops.stark_cfg(log_n, 45, num_queries=nq, pow_bits=pb)
     bpg.lib().bp_tune_assume_loaded(loaded)
     try:
         got = bpg.ops.stark_prove_air(3, pc, SEED)
@@ -81,7 +81,7 @@ def test_table_proof_bit_exact(bpg, oracle, log_n, nq, pb, loaded):
 
 def test_wrong_shapes_for_the_air_are_refused(bpg):
     from proof_protocol_decoder_amd._lib import BpgError
-    for kw in (dict(n_cols=48), dict(n_cols=44, n_const=2), dict(n_cols=44, deg_pow=3, rate_bits=3)):
+    for kw in (dict(n_cols=48), dict(n_cols=45, n_const=2), dict(n_cols=45, deg_pow=3, rate_bits=3)):
         cfg = bpg.ops.stark_cfg(6, kw.pop("n_cols"), num_queries=6, pow_bits=6, **kw)
         with pytest.raises(BpgError, match="memory"):
             bpg.ops.stark_prove_air(3, cfg, 1)

@@ -276,7 +276,7 @@ def test_decoded_transactions_prove_their_own_keccak_work(bpg, pg, p_state, o_st
     gis = decoding.into_txn_proof_gen_ir(td.make_trace(m, infos, hash_out_storage_of=(td.E,)), other)
     irs = irs_from_generation_inputs(gis, 22, LOG_N, WIDTH, keccak_air=True)
     real = [(g, ir) for g, ir in zip(gis, irs) if g.signed_txn]
-    assert real and all(ir.keccak_air and ir.table_width[3] == 2430 for ir in irs)
+    assert real and all(ir.keccak_air and ir.table_width[3] == 2431 for ir in irs)
     g, ir = real[0]
     states = keccak_inputs_of_generation_inputs(g)
     assert [list(x) for x in ir.keccak_inputs] == states and len(states) >= 1
@@ -551,14 +551,14 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
 
 def test_txn_with_a_real_keccak_table_matches_the_oracle(pg, p_state, o_state):
     """IR flag 0x100: the Keccak table of the transaction (index 3, prover_state.rs:85-93) is a real Keccak-f[1600]
-    trace proven with AIR 1 (2430 columns, witness drawn from the seed) next to six synthetic tables.  Byte parity of
+    trace proven with AIR 1 (2431 columns, witness drawn from the seed) next to six synthetic tables.  Byte parity of
     the txn proof with the oracle, aggregation with an ordinary txn, block proof accepted by both verifiers."""
     width = list(WIDTH)
-    width[3] = 2430
+    width[3] = 2431
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0010, tuple(LOG_N), tuple(width), keccak_air=True)
     t0 = pg.generate_txn_proof(p_state, ir0)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))
-    assert iw[1] == 0x101 and iw[18 + 3] == 2430
+    assert iw[1] == 0x101 and iw[18 + 3] == 2431
     want = o_state.txn(iw)
     assert (words(t0.intern) == want).all()
     plain = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0010, tuple(LOG_N), tuple(width))
@@ -567,7 +567,7 @@ def test_txn_with_a_real_keccak_table_matches_the_oracle(pg, p_state, o_state):
     blk = pg.generate_block_proof(p_state, None, pg.generate_agg_proof(p_state, t0, t1))
     pg.VerifierState.from_prover_state(p_state).verify(blk)
     assert o_state.verify(words(blk.intern)) == 0
-    with pytest.raises(pg.ProofGenError, match="2430"):                        # the AIR's width is not negotiable
+    with pytest.raises(pg.ProofGenError, match="2431"):                        # the AIR's width is not negotiable
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), keccak_air=True).to_bytes()
 
 
@@ -576,12 +576,12 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
     Keccak sponge (4), logic (5) and memory (6) tables of the transaction are proven with AIR 4, 5, 1, 6, 2 and 3; only
     the CPU table (2) stays synthetic.  Byte parity with the oracle; the block verifies."""
     width = list(WIDTH)
-    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2430, 2414, 523, 44
+    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2431, 2414, 523, 45
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
                            memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
     t0 = pg.generate_txn_proof(p_state, ir0)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))
-    assert iw[1] == 0x3F01 and iw[18 + 0] == 309 and iw[18 + 1] == 299 and iw[18 + 4] == 2414 and iw[18 + 5] == 523 and iw[18 + 6] == 44
+    assert iw[1] == 0x3F01 and iw[18 + 0] == 309 and iw[18 + 1] == 299 and iw[18 + 4] == 2414 and iw[18 + 5] == 523 and iw[18 + 6] == 45
     assert (words(t0.intern) == o_state.txn(iw)).all()
     only_logic = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), (*WIDTH[:5], 523, WIDTH[6]), logic_air=True)
     t_l = pg.generate_txn_proof(p_state, only_logic)
@@ -593,7 +593,7 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
     assert o_state.verify(words(blk.intern)) == 0
     with pytest.raises(pg.ProofGenError, match="523"):                         # the AIR's width is not negotiable
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), logic_air=True).to_bytes()
-    with pytest.raises(pg.ProofGenError, match="44"):
+    with pytest.raises(pg.ProofGenError, match="45"):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), memory_air=True).to_bytes()
     with pytest.raises(pg.ProofGenError, match="309"):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), arithmetic_air=True).to_bytes()
@@ -609,7 +609,7 @@ def test_table_proofs_and_their_lookups_match_the_oracle(pg, p_state, o_state, o
     byte-packing table's words are operations of the memory table (csrc/air.hpp namespace ctl): bytes equal the oracle's (oracle/ctl.c states the lookup columns independently), both
     verifiers accept both provers' output, and the prover refuses tables that are valid alone but not one statement."""
     width = list(WIDTH)
-    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2430, 2414, 523, 44
+    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2431, 2414, 523, 45
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0C71, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
                            memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))
@@ -621,12 +621,12 @@ def test_table_proofs_and_their_lookups_match_the_oracle(pg, p_state, o_state, o
     # the lookup is not vacuous (see tests/test_lookups.py for the layout): the sponge table's product is not 1
     from test_lookups import first_row_openings
     looking, looked = first_row_openings(oracle, words(got), 4), first_row_openings(oracle, words(got), 3)
-    assert (looking[0] == looked[3]).all() and (looking[1] == looked[4]).all() and tuple(looking[0]) != (1, 0)
+    assert (looking[0] == looked[2]).all() and (looking[1] == looked[3]).all() and tuple(looking[0]) != (1, 0)
     # caller-given tables: three messages absorbed by the sponge table, their permutations in the Keccak-f table
     from test_lookups import sponge_and_keccak_work
     rows, perms = sponge_and_keccak_work(oracle, [b"abc", bytes(range(200)), b""])
     w2 = list(WIDTH)
-    w2[3], w2[4] = 2430, 2414
+    w2[3], w2[4] = 2431, 2414
     ir1 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0C72, tuple(LOG_N), tuple(w2), keccak_air=True, keccak_sponge_air=True)
     iw1 = list(struct.unpack("<25Q", ir1.to_bytes()))
     got1 = pg.generate_txn_table_proofs(p_state, ir1, witness={3: perms, 4: rows})
@@ -652,12 +652,12 @@ def test_table_proofs_and_their_lookups_match_the_oracle(pg, p_state, o_state, o
     # the second lookup, byte_packing -> memory: in the six-table transaction above the packing rows' words are the
     # operations the (seeded) memory table exposes ...
     packing, memory = first_row_openings(oracle, words(got), 1), first_row_openings(oracle, words(got), 6)
-    assert (packing[0] == memory[1]).all() and (packing[1] == memory[2]).all() and tuple(packing[0]) != (1, 0)
+    assert (packing[0] == memory[0]).all() and (packing[1] == memory[1]).all() and tuple(packing[0]) != (1, 0)
     # ... and with caller-given tables: the strings' chunks and the log of the words they spell
     from proof_protocol_decoder_amd.block_driver import memory_and_byte_packing_work_of_preimages
     log, seqs = memory_and_byte_packing_work_of_preimages([b"hello, memory", bytes(range(70)), b"x" * 32])
     w3 = list(WIDTH)
-    w3[1], w3[6] = 299, 44
+    w3[1], w3[6] = 299, 45
     ir2 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0C73, tuple(LOG_N), tuple(w3), byte_packing_air=True, memory_air=True)
     iw2 = list(struct.unpack("<25Q", ir2.to_bytes()))
     got2 = pg.generate_txn_table_proofs(p_state, ir2, witness={1: seqs, 6: log})

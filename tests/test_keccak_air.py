@@ -53,7 +53,7 @@ def test_trace_rows_are_the_rounds_of_the_permutation(oracle):
     inputs = np.zeros((3, 25), dtype=np.uint64)
     inputs[0], inputs[1] = blocks[0], blocks[1]
     t = oracle.keccak_trace(log_n, inputs=inputs)
-    assert t.shape == (2430, 64) and (t < np.uint64(P)).all()
+    assert t.shape == (2431, 64) and (t < np.uint64(P)).all()
     for p, blk in enumerate(blocks):
         assert (lanes_of(t, 24 * p, COL_A) == blk).all()
         out = lanes_of(t, 24 * p + 23, COL_APP)
@@ -121,7 +121,8 @@ def test_oracle_proof_is_accepted_by_both_verifiers_and_tampering_is_not(oracle,
 # one wrong cell per constraint family: (column, row, what it breaks)
 BREAKS = [(COL_STEP + 3, 3, "F1 flags rotate"), (COL_C + 64 * 2 + 17, 9, "F3/F5 theta"), (COL_CP + 64 * 4 + 63, 30, "F3/F4"),
           (COL_AP + 64 * 13 + 5, 12, "F4/F5/F6"), (COL_A + 2 * 7 + 1, 25, "F5/F9 input limb"),
-          (COL_APP + 2 * 11, 40, "F6/F9 chi limb"), (COL_APP0 + 31, 2, "F7/F8"), (COL_APPP + 1, 7, "F8/F9 iota")]
+          (COL_APP + 2 * 11, 40, "F6/F9 chi limb"), (COL_APP0 + 31, 2, "F7/F8"), (COL_APPP + 1, 7, "F8/F9 iota"),
+          (2430, 23, "lookup filter is a bit"), (2430, 5, "lookup filter only on last-round rows")]
 
 
 @pytest.mark.parametrize("col,row,what", BREAKS, ids=[b[2] for b in BREAKS])
@@ -133,6 +134,8 @@ def test_a_witness_that_breaks_one_family_yields_a_rejected_proof(oracle, col, r
     trace = oracle.keccak_trace(log_n, seed=0x5EED)
     v = int(trace[col, row])
     trace[col, row] = (1 - v) if v <= 1 and COL_C <= col < COL_APP or COL_APP0 <= col < COL_APPP or col < 24 else (v ^ 0x40)
+    if col == 2430 and row % 24 != 23:
+        trace[col, row] = 1     # a well-formed bit, on a row that is not a permutation's last round
     proof, ctl, chv = prove(oracle, cfg, trace)
     assert oracle.stark_verify(cfg, proof, ctl, chv, None) != 0
     assert product_verify(cfg, proof) != 0
@@ -143,7 +146,7 @@ def test_air_registry_describes_both_airs():
     L = pkg.lib()
     assert L.bp_air_count() == 9
     d = pkg.ops.air_describe(1)
-    assert d.name == b"keccak_f" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (2430, 2430, 5, 3)
+    assert d.name == b"keccak_f" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (2431, 2431, 4, 3)
     assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (2826, 10, 11)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:10]) == 2826 and fams[0] == (0, 24, 2, 1) and fams[9] == (2776, 50, 1, 2)
@@ -161,11 +164,11 @@ def test_air_registry_describes_both_airs():
 
 def test_oracle_txn_with_the_keccak_flag_differs_only_through_table_3(oracle):
     """The IR flag 0x100 (Keccak table = AIR 1) in the oracle's generate_txn_proof: accepted, different from the
-    all-synthetic proof of the same IR, refused when table 3 is not 2430 columns wide."""
+    all-synthetic proof of the same IR, refused when table 3 is not 2431 columns wide."""
     from pg_common import LOG_N, SMALL, WIDTH, ir_words
     st = oracle.PgState(**SMALL)
     width = list(WIDTH)
-    width[3] = 2430
+    width[3] = 2431
     iw = ir_words(5, 0, 0x5EED0042, width=tuple(width))
     plain = st.txn(iw)
     iw[1] = 0x101

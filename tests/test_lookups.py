@@ -8,7 +8,7 @@ import pytest
 
 from pg_common import LOG_N, SMALL, WIDTH, ir_words
 
-REAL_WIDTH = {0: 309, 1: 299, 3: 2430, 4: 2414, 5: 523, 6: 44}
+REAL_WIDTH = {0: 309, 1: 299, 3: 2431, 4: 2414, 5: 523, 6: 45}
 REAL_FLAG = {3: 0x100, 5: 0x200, 6: 0x400, 0: 0x800, 1: 0x1000, 4: 0x2000}
 
 
@@ -63,11 +63,11 @@ def test_seeded_tables_of_a_transaction_are_one_statement(oracle, o_state, produ
     # the lookup is not vacuous: the sponge table asks for permutations (its product is not 1) and the Keccak-f table's
     # exposed product is the same value, for both challenge sets
     looking, looked = first_row_openings(oracle, tp, 4), first_row_openings(oracle, tp, 3)
-    assert (looking[0] == looked[3]).all() and (looking[1] == looked[4]).all()
+    assert (looking[0] == looked[2]).all() and (looking[1] == looked[3]).all()
     assert tuple(looking[0]) != (1, 0) and tuple(looking[0]) != tuple(looking[1])
     # the same for byte_packing -> memory: the packing rows that move a word name operations the memory table exposes
     packing, memory = first_row_openings(oracle, tp, 1), first_row_openings(oracle, tp, 6)
-    assert (packing[0] == memory[1]).all() and (packing[1] == memory[2]).all()
+    assert (packing[0] == memory[0]).all() and (packing[1] == memory[1]).all()
     assert tuple(packing[0]) != (1, 0) and tuple(packing[0]) != tuple(packing[1])
     # a table no lookup is built for carries the constant product
     assert (first_row_openings(oracle, tp, 5) == [[1, 0]]).all()
@@ -75,12 +75,12 @@ def test_seeded_tables_of_a_transaction_are_one_statement(oracle, o_state, produ
     tp3 = o_state.txn_tables(real_ir({6}))
     assert o_state.verify_tables(tp3) == 0
     pg.verify_txn_table_proofs(cfg, tp3.tobytes())
-    assert (first_row_openings(oracle, tp3, 6)[1:] == [[1, 0], [1, 0]]).all()
+    assert (first_row_openings(oracle, tp3, 6) == [[1, 0], [1, 0]]).all()
     # without a real sponge table the Keccak-f table exposes nothing, and nothing is compared
     tp2 = o_state.txn_tables(real_ir({3}))
     assert o_state.verify_tables(tp2) == 0
     pg.verify_txn_table_proofs(cfg, tp2.tobytes())
-    assert (first_row_openings(oracle, tp2, 3)[3:] == [[1, 0], [1, 0]]).all()
+    assert (first_row_openings(oracle, tp2, 3)[2:] == [[1, 0], [1, 0]]).all()
 
 
 def sponge_and_keccak_work(oracle, messages):
@@ -129,6 +129,31 @@ def test_given_tables_that_disagree_are_rejected_by_both_verifiers(oracle, o_sta
         pg.verify_txn_table_proofs(cfg, bad2.tobytes())
 
 
+def test_the_filter_of_a_looked_table_is_committed_before_the_lookup_challenges(oracle, o_state, product_cfg):
+    """which rows a looked table exposes (its filter g) was an AUXILIARY column, committed after the lookup
+    challenges were drawn -- a prover could pick the exposed subset knowing beta and gamma.  It is a TRACE column now
+    (Keccak-f: column 2430, memory: column 44): two provers whose Keccak-f tables hold the SAME permutations but expose
+    different subsets commit to different trace caps, hence draw different challenges; and the auxiliary columns no
+    longer hold a filter."""
+    pg, cfg = product_cfg
+    L = oracle.lib()
+    assert L.orc_ctl_n_aux(1, 2431) == 4 and L.orc_ctl_n_aux(3, 45) == 2      # h_0 h_1 z_0 z_1 / z_0 z_1
+    msgs = [b"abc", bytes(range(200))]
+    rows, perms = sponge_and_keccak_work(oracle, msgs)
+    rows_fewer, _ = sponge_and_keccak_work(oracle, msgs[:1])                   # the sponge table asks for one permutation only
+    ir = real_ir({3, 4})
+    a = o_state.txn_tables(ir, witness={3: perms, 4: rows})
+    b = o_state.txn_tables(ir, witness={3: perms, 4: rows_fewer})              # same Keccak-f permutations, a smaller exposed subset
+    cap = 4 << SMALL["stark_cap_height"]
+    first = table_slices(a)[3][3]
+    trace_cap = lambda tp: tp[first + 16:first + 16 + cap]
+    assert not (trace_cap(a) == trace_cap(b)).all()                            # the subset is in the trace commitment ...
+    assert not (a[2 + 13:2 + 13 + 4] == b[2 + 13:2 + 13 + 4]).all()            # ... that the lookup challenges are drawn from
+    for tp in (a, b):
+        assert o_state.verify_tables(tp) == 0
+        pg.verify_txn_table_proofs(cfg, tp.tobytes(), gen_inputs=np.array(ir, dtype=np.uint64).tobytes())
+
+
 def test_words_the_byte_packing_table_moves_are_memory_operations(oracle, o_state, product_cfg):
     """byte_packing -> memory with tables given by the caller: the packing rows and the memory log of the same strings
     (block_driver.memory_and_byte_packing_work_of_preimages) agree; a sequence that spells another word, or names an
@@ -142,7 +167,7 @@ def test_words_the_byte_packing_table_moves_are_memory_operations(oracle, o_stat
     assert o_state.verify_tables(good) == 0
     pg.verify_txn_table_proofs(cfg, good.tobytes())
     packing, memory = first_row_openings(oracle, good, 1), first_row_openings(oracle, good, 6)
-    assert (packing[0] == memory[1]).all() and tuple(packing[0]) != (1, 0)
+    assert (packing[0] == memory[0]).all() and tuple(packing[0]) != (1, 0)
 
     def rejected(bad_seqs, bad_log):
         with pytest.raises(RuntimeError, match="-12"):      # the prover refuses to go on
@@ -203,7 +228,7 @@ def test_a_relabelled_table_is_refused_once_the_verifier_fixes_the_statement(ora
     honest = o_state.txn_tables(wanted)
     pg.verify_txn_table_proofs(cfg, honest.tobytes(), gen_inputs=irb(wanted))
     cheat_ir = real_ir({4})                       # the same transaction with table 3 "proven" as a synthetic table ...
-    cheat_ir[18 + 3] = 2430                       # ... of the Keccak-f table's own width
+    cheat_ir[18 + 3] = 2431                       # ... of the Keccak-f table's own width
     cheat = o_state.txn_tables(cheat_ir)
     pg.verify_txn_table_proofs(cfg, cheat.tobytes())          # the header is taken at its word: accepted
     with pytest.raises(pg.ProofGenError, match="table keccak is proven as AIR 0") as e:

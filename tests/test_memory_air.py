@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 P = 0xFFFFFFFF00000001
-COL_READ, COL_ADDR, COL_TS, COL_VAL, COL_CHG, COL_GAP, N_COLS = 0, 1, 2, 3, 11, 12, 44
+COL_READ, COL_ADDR, COL_TS, COL_VAL, COL_CHG, COL_GAP, N_COLS = 0, 1, 2, 3, 11, 12, 45
 
 
 def random_log(n, seed, n_addr=None):
@@ -154,7 +154,7 @@ def test_air_registry_describes_the_memory_air():
     L = pkg.lib()
     assert L.bp_air_count() == 9
     d = pkg.ops.air_describe(3)
-    assert d.name == b"memory" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (44, 44, 3, 3)
+    assert d.name == b"memory" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (45, 45, 2, 3)
     assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (60, 5, 1)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:8]) == 60 and fams[5] == (36, 8, 1, 3) and fams[7] == (52, 8, 2, 2)

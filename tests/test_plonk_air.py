@@ -133,7 +133,7 @@ def test_air_registry_describes_the_plonk_air():
     assert pkg.lib().bp_air_count() == 9
     d = pkg.ops.air_describe(8)
     assert d.name == b"plonk" and (d.fixed_n_cols, d.n_cols, d.n_const_max, d.n_aux, d.degree) == (135, 135, 84, 20, 9)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (90, 22, 1)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (90, 22, 10)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert fams == [(0, 20, 0, 4), (20, 44, 0, 3), (64, 22, 0, 2), (86, 4, 2, 1), (90, 10, 0, 9), (100, 1, 2, 1), (101, 10, 0, 9), (111, 1, 2, 1)]
 

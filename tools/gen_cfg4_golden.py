@@ -19,10 +19,10 @@ import numpy as np  # noqa: E402
 from oracle import pyoracle as orc  # noqa: E402
 
 log_n = int(sys.argv[1])
-# second argument "keccak_f": the same configuration as a REAL Keccak-f[1600] trace (AIR 1, 2430 columns, witness
+# second argument "keccak_f": the same configuration as a REAL Keccak-f[1600] trace (AIR 1, 2431 columns, witness
 # drawn from the seed); merge under "tables" as logn<k>_keccak_f
 AIR = 1 if len(sys.argv) > 2 and sys.argv[2] == "keccak_f" else 0
-C = 2430 if AIR else 2432
+C = 2431 if AIR else 2432
 try:  # OpenMP would otherwise start one thread per host core, not per core of this process's share
     import ctypes
     _n = len(os.sched_getaffinity(0))
