@@ -22,22 +22,25 @@ def rows(dirs):
             yield from csv.DictReader(open(f))
 
 
+K5 = os.environ.get("K5_PREFIX", "r4")   # r5: tools/prof_round5_k5.sh
+
+
 def k5_summary():
     cases = {}
-    log = os.path.join(O, "r4_k5_sq.log")
+    log = os.path.join(O, K5 + "_k5_sq.log")
     for line in open(log) if os.path.exists(log) else []:
         m = re.match(r"counters case: air (\d+) (\w+) rows (\d+) cols (\d+) aux (\d+) constraints (\d+) alg_bytes (\d+)", line)
         if m:
             cases[int(m.group(1))] = dict(name=m.group(2), rows=int(m.group(3)), cols=int(m.group(4)), aux=int(m.group(5)),
                                           constraints=int(m.group(6)), alg=int(m.group(7)))
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in rows(("r4_k5_sq", "r4_k5_fetch", "r4_k5_write")):
+    for r in rows((K5 + "_k5_sq", K5 + "_k5_fetch", K5 + "_k5_write")):
         m = re.search(r"quotient_air_kernel<(\d+)u?>", r["Kernel_Name"])
         if m:
             acc[int(m.group(1))][r["Counter_Name"]] += float(r["Counter_Value"])
     if not acc:
         return
-    with open(os.path.join(O, "r4_k5_counters.txt"), "w") as out:
+    with open(os.path.join(O, K5 + "_k5_counters.txt"), "w") as out:
         out.write("# HEAD %s.  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES / FETCH_SIZE / WRITE_SIZE (three passes) -- python "
                   "tools/k5_air_probe.py --counters: ONE quotient_air_kernel<AIR> launch per AIR on random LDE matrices (spread form, "
                   "rate 2; rate 8 for AIR 8).  valu_per_constraint = SQ_INSTS_VALU x 64 lanes / (rows x constraints); fetch_over_algorithmic = "
@@ -51,7 +54,7 @@ def k5_summary():
                       % (c["name"], c["rows"], c["cols"], c["aux"], c["constraints"], v.get("SQ_INSTS_VALU", 0),
                          64.0 * v.get("SQ_INSTS_VALU", 0) / (c["rows"] * c["constraints"]), fetch / 1e6, read_alg / 1e6,
                          fetch / read_alg if read_alg else 0, 1024 * v.get("WRITE_SIZE", 0) / 1e6))
-    print(open(os.path.join(O, "r4_k5_counters.txt")).read())
+    print(open(os.path.join(O, K5 + "_k5_counters.txt")).read())
 
 
 def family(k):
@@ -137,7 +140,9 @@ def leg_trace_summary():
     print("leg between markers: LDE family %d launches, average %.2f us" % (fn, ft / max(fn, 1) / 1e3))
 
 
+import sys
 k5_summary()
-loaded_summary()
-hash_summary()
-leg_trace_summary()
+if "k5" not in sys.argv[1:]:
+    loaded_summary()
+    hash_summary()
+    leg_trace_summary()
