@@ -167,6 +167,41 @@ class TorchGather:
         return [bytes(out[r][:lens[r]].cpu().numpy().tobytes()) for r in range(world)]
 
 
+    # ---- the pieces of the pairwise top tree (prove_block_distributed, top_tree="pairwise")
+    def exchange_status(self, n_bytes, failed=False):
+        """all_gather of every rank's payload length (-1 = its shard failed): every rank raises ShardFailed when any
+        failed, before anybody waits for a payload that will never come.  Returns the lengths."""
+        torch, dist = self.torch, self.dist
+        n = torch.tensor([-1 if failed else n_bytes], dtype=torch.int64, device=self.device)
+        lens = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
+        dist.all_gather(lens, n)
+        lens = [int(x.item()) for x in lens]
+        bad = [r for r, l in enumerate(lens) if l < 0]
+        if bad:
+            raise ShardFailed("shard proving failed on rank(s) %s" % bad)
+        return lens
+
+    def send_bytes(self, dst, payload, failed=False):
+        """length (-1 = this rank failed inside the tree), then the bytes"""
+        torch, dist = self.torch, self.dist
+        dist.send(torch.tensor([-1 if failed else len(payload)], dtype=torch.int64, device=self.device), dst)
+        if not failed and payload:
+            dist.send(torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self.device), dst)
+
+    def recv_bytes(self, src):
+        torch, dist = self.torch, self.dist
+        n = torch.zeros(1, dtype=torch.int64, device=self.device)
+        dist.recv(n, src)
+        n = int(n.item())
+        if n < 0:
+            raise ShardFailed("aggregation failed on rank %d" % src)
+        if n == 0:
+            return b""
+        buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        dist.recv(buf, src)
+        return bytes(buf.cpu().numpy().tobytes())
+
+
 class ShardFailed(RuntimeError):
     """Raised on every rank when any rank's shard failed (see TorchGather.gather_bytes)."""
 
@@ -267,13 +302,19 @@ class BlockDriver:
         txns = [self._decode(pg.take_buffer(leaves[i], C.c_size_t(lens[i]))) for i in range(n)]
         return self._decode(pg.take_buffer(root, root_len)), txns
 
-    def prove_block_distributed(self, irs, rank=0, world_size=1, gather=None, parent=None):
+    def prove_block_distributed(self, irs, rank=0, world_size=1, gather=None, parent=None, top_tree="pairwise"):
         """Returns the GeneratedBlockProof on rank 0, None elsewhere.
 
         A block with fewer entries than ranks (decoding.rs:304-347 pads to two, so any block of 0 or 1
-        transactions on an 8-GPU node) leaves the high ranks without a slice: they join the gather with an
-        empty payload that rank 0 skips.  A rank whose shard raises reports it through the gather's length
-        exchange, and every rank raises instead of waiting for a payload that will never come."""
+        transactions on an 8-GPU node) leaves the high ranks without a slice: they take part with an empty payload
+        that is skipped.  A rank whose shard raises reports it through the length exchange, and every rank raises
+        instead of waiting for a payload that will never come.
+
+        top_tree: how the N sub-block proofs become one (the same balanced tree over ranks either way, so the same bytes):
+          "pairwise" (default): level by level, rank 2k+1 sends its proof to rank 2k, which aggregates (then 4k+2 -> 4k,
+            ...): every rank verifies ONE foreign child per level and rank 0 makes log2 N aggregation proofs one after
+            the other (SURVEY.md section 8(e));
+          "gather": all N proofs to rank 0, which makes the N - 1 aggregations alone (rounds 1-4)."""
         lo, hi = shard_bounds(len(irs), rank, world_size)
         sub, err = None, None
         try:
@@ -281,7 +322,11 @@ class BlockDriver:
                 sub, _ = self.prove_shard(irs[lo:hi])
         except Exception as e:  # held until the other ranks know
             err = e
-        if world_size > 1:
+        if world_size > 1 and top_tree == "pairwise":
+            top = self._pairwise_top_tree(sub, err, rank, world_size, gather)
+            if rank != 0:
+                return None
+        elif world_size > 1:
             try:
                 raws = gather.gather_bytes(sub.intern if sub is not None else b"", failed=err is not None)
             except ShardFailed:
@@ -291,16 +336,49 @@ class BlockDriver:
             if rank != 0:
                 return None
             subs = [self.decode_proof(r) for r in raws if r]
+            if not subs:
+                raise ValueError("a block needs at least two transactions (decoding.rs:304-347 pads to >= 2)")
+            top = self._aggregate_native(subs) if self._native is not None else tree_reduce(subs, self.prove_agg, self.pool)
         else:
             if err is not None:
                 raise err
-            subs = [sub] if sub is not None else []
-        if not subs:
-            raise ValueError("a block needs at least two transactions (decoding.rs:304-347 pads to >= 2)")
-        top = self._aggregate_native(subs) if self._native is not None else tree_reduce(subs, self.prove_agg, self.pool)
+            top = sub
         if not isinstance(top, pg.GeneratedAggProof):
             raise ValueError("a block needs at least two transactions (decoding.rs:304-347 pads to >= 2)")
         return self.prove_block(parent, top)
+
+    def _pairwise_top_tree(self, sub, err, rank, world_size, gather):
+        """Level l: rank r with r % 2^(l+1) == 2^l sends what it holds to rank r - 2^l and is done; the receiver
+        aggregates (its own range is the left child: rank order is transaction order).  The balanced tree over ranks,
+        odd tails carried up -- aggregation_plan(N)'s shape.  A failure inside the tree travels up as a length of -1, so
+        no parent waits for a payload that will never come; the failing rank raises its own error, the ranks above it
+        ShardFailed."""
+        try:
+            gather.exchange_status(len(sub.intern) if sub is not None else 0, failed=err is not None)
+        except ShardFailed:
+            if err is not None:
+                raise err
+            raise
+        cur, step = sub, 1
+        while step < world_size:
+            if rank % (2 * step) == step:
+                gather.send_bytes(rank - step, cur.intern if (cur is not None and err is None) else b"", failed=err is not None)
+                if err is not None:
+                    raise err
+                return None
+            src = rank + step
+            if src < world_size:
+                try:
+                    raw = gather.recv_bytes(src)
+                    if err is None and raw:
+                        other = self.decode_proof(raw)
+                        cur = other if cur is None else self.prove_agg(cur, other)
+                except Exception as e:   # keep walking the levels: the ranks above must hear of it
+                    err = err or e
+            step *= 2
+        if err is not None:
+            raise err
+        return cur
 
     def close(self):
         if self.pool is not None:

@@ -228,22 +228,41 @@ def prove_block(parent, agg):
 L = pg._bind()
 L.bp_state_root_after.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
 irs, root, gas = [], (1, 2, 3, 4), 0
-N_TXNS, FAIL_RANK = {n_txns}, {fail_rank}
+N_TXNS, FAIL_RANK, TOP_TREE = {n_txns}, {fail_rank}, {top_tree!r}
 for i in range(N_TXNS):
     seed = 0x5EED1000 + i
     irs.append(ir_words(11, i, seed, root_before=root, gas=(gas, gas + 7)))
     out = (C.c_uint64 * 4)()
     assert L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out) == 0
     root, gas = tuple(out), gas + 7
+FAIL_AGG = {fail_agg}
 if rank == FAIL_RANK:
     def prove_txn(ir): raise RuntimeError("injected failure on rank %d" % rank)
+if rank == FAIL_AGG:
+    def prove_agg(a, b): raise RuntimeError("injected aggregation failure on rank %d" % rank)
 drv = BlockDriver(n_threads=2, prove_txn=prove_txn, prove_agg=prove_agg, prove_block=prove_block)
+if FAIL_AGG >= 0:
+    # a failure INSIDE the pairwise tree (one transaction per rank: every aggregation is a tree step): the failing rank
+    # raises its own error, the ranks above it on the way to rank 0 raise ShardFailed, the ranks that had already handed
+    # their proof over return None -- and nobody is left waiting in a recv
+    from proof_protocol_decoder_amd.block_driver import ShardFailed
+    try:
+        got = drv.prove_block_distributed(irs, rank, world, TorchGather(torch.device("cpu")), top_tree="pairwise")
+    except ShardFailed as e:
+        assert rank == 0 and rank != FAIL_AGG, (rank, str(e))
+    except RuntimeError as e:
+        assert rank == FAIL_AGG and "injected aggregation" in str(e)
+    else:
+        assert got is None and rank not in (0, FAIL_AGG)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
 if FAIL_RANK >= 0:
     from proof_protocol_decoder_amd.block_driver import ShardFailed
     try:
-        drv.prove_block_distributed(irs, rank, world, TorchGather(torch.device("cpu")))
+        drv.prove_block_distributed(irs, rank, world, TorchGather(torch.device("cpu")), top_tree=TOP_TREE)
     except ShardFailed as e:
-        assert rank != FAIL_RANK and str(FAIL_RANK) in str(e)
+        assert rank != FAIL_RANK and "failed on rank" in str(e)
     except RuntimeError as e:
         assert rank == FAIL_RANK and "injected" in str(e)
     else:
@@ -251,7 +270,7 @@ if FAIL_RANK >= 0:
     dist.barrier()                     # every rank got here: nobody is stuck in the gather
     dist.destroy_process_group()
     sys.exit(0)
-blk = drv.prove_block_distributed(irs, rank, world, TorchGather(torch.device("cpu")))
+blk = drv.prove_block_distributed(irs, rank, world, TorchGather(torch.device("cpu")), top_tree=TOP_TREE)
 if rank == 0:
     w = np.frombuffer(blk.intern, dtype=np.uint64)
     assert st.verify(w) == 0
@@ -271,7 +290,7 @@ def test_block_driver_world_size_2_over_gloo(tmp_path, oracle):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     script = tmp_path / "drv.py"
     for world, out, port in ((2, out2, 29611), (1, out1, 29612)):
-        script.write_text(DRIVER_SCRIPT.format(root=ROOT, out=out, n_txns=5, fail_rank=-1))
+        script.write_text(DRIVER_SCRIPT.format(root=ROOT, out=out, n_txns=5, fail_rank=-1, top_tree="pairwise", fail_agg=-1))
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                             "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                            env=env, capture_output=True, text=True, timeout=600)
@@ -281,10 +300,10 @@ def test_block_driver_world_size_2_over_gloo(tmp_path, oracle):
     assert a.shape == b.shape and (a[4 + 9:4 + 22] == b[4 + 9:4 + 22]).all()
 
 
-def _run_driver(tmp_path, world, n_txns, port, fail_rank=-1, omp="1"):
-    out = str(tmp_path / ("w%d_%d.npy" % (world, n_txns)))
-    script = tmp_path / ("drv_%d_%d_%d.py" % (world, n_txns, fail_rank))
-    script.write_text(DRIVER_SCRIPT.format(root=ROOT, out=out, n_txns=n_txns, fail_rank=fail_rank))
+def _run_driver(tmp_path, world, n_txns, port, fail_rank=-1, omp="1", top_tree="pairwise", fail_agg=-1):
+    out = str(tmp_path / ("w%d_%d_%s.npy" % (world, n_txns, top_tree)))
+    script = tmp_path / ("drv_%d_%d_%d_%s_%d.py" % (world, n_txns, fail_rank, top_tree, fail_agg))
+    script.write_text(DRIVER_SCRIPT.format(root=ROOT, out=out, n_txns=n_txns, fail_rank=fail_rank, top_tree=top_tree, fail_agg=fail_agg))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=omp)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
@@ -300,6 +319,10 @@ def test_block_driver_world_size_8_uneven_split(tmp_path, oracle):
     a = np.load(_run_driver(tmp_path, 8, 21, 29621))
     b = np.load(_run_driver(tmp_path, 1, 21, 29622, omp="8"))
     assert a.shape == b.shape and (a[4 + 9:4 + 22] == b[4 + 9:4 + 22]).all()
+    # the pairwise top tree (rank 2k+1 -> 2k, 4k+2 -> 4k, 4 -> 0: rank 0 makes three aggregations, not seven) is the
+    # balanced tree over ranks the gather form builds on rank 0: the same block proof, byte for byte
+    c = np.load(_run_driver(tmp_path, 8, 21, 29626, top_tree="gather"))
+    assert (a == c).all()
 
 
 def test_block_driver_fewer_entries_than_ranks(tmp_path, oracle):
@@ -309,12 +332,23 @@ def test_block_driver_fewer_entries_than_ranks(tmp_path, oracle):
     a = np.load(_run_driver(tmp_path, 4, 2, 29623))
     b = np.load(_run_driver(tmp_path, 1, 2, 29624, omp="4"))
     assert (a == b).all()          # two ranks with one txn each = the same tree as one rank with two
+    c = np.load(_run_driver(tmp_path, 4, 2, 29627, top_tree="gather"))
+    assert (a == c).all()
+    # five ranks, three entries: ranks 3 and 4 are empty, rank 4's nothing travels 4 -> 0 at the last level
+    d = np.load(_run_driver(tmp_path, 5, 3, 29628))
+    e = np.load(_run_driver(tmp_path, 5, 3, 29629, top_tree="gather"))
+    assert (d == e).all()
 
 
 def test_block_driver_failure_on_one_rank_raises_everywhere(tmp_path, oracle):
     """A rank whose shard raises reports it through the gather's length exchange; every rank raises (ShardFailed on
     the healthy ones, the original error on the failed one) and all of them reach the next barrier."""
     _run_driver(tmp_path, 3, 6, 29625, fail_rank=1)
+    _run_driver(tmp_path, 3, 6, 29630, fail_rank=1, top_tree="gather")
+    _run_driver(tmp_path, 5, 10, 29631, fail_rank=4)      # the rank that only joins the tree at its last level
+    _run_driver(tmp_path, 4, 8, 29632, fail_rank=0)
+    _run_driver(tmp_path, 4, 4, 29633, fail_agg=2)        # rank 2 fails merging rank 3's proof: 0 hears of it, 1 and 3 are done
+    _run_driver(tmp_path, 4, 4, 29634, fail_agg=0)
 
 
 def test_config_bounds_are_checked_before_any_device_work():
