@@ -178,6 +178,10 @@ int bp_debug_poseidon_group_tables(uint32_t K, uint32_t r0, uint8_t* out_ops, in
  * block with TWO workgroups that each do half of the stage coupling its halves while loading (csrc/ntt.hip).
  * Results are identical either way. */
 void bp_tune_ntt_split(int mode);
+/* 2^14-point coset-LDE blocks as persistent workgroups that prefetch the next block's coefficients while the last pass
+ * of the current one computes and stores (csrc/ntt.hip, ntt16_dit_persist_kernel): on = 1 / 0 = the one-shot grid (the
+ * default: the persistent form measured 8 % slower, profiles/r5_ntt_stalls.txt); resident_workgroups > 0 sets the grid (default 256 = one per CU).  Same values either way (tests). */
+void bp_tune_ntt_persist(int on, int resident_workgroups);
 /* NTT blocks as three radix-16 passes whose 16-point DFTs are int8 MFMAs on the bytes of the elements
  * (csrc/ntt_mx.cuh): 0 = never (the VALU butterfly kernels everywhere), 1 = 2^12- and 2^13-point blocks, 2 = 2^14-point
  * blocks too, 3 (default) = 2^13-point blocks while fewer than 6 provers are at work on the device, 4 / 5 = like 1 for

@@ -615,6 +615,113 @@ __global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per
   }
 }
 
+// The 2^14-point form of ntt16_dit_kernel<L, 0> as a PERSISTENT workgroup.  A 2^14-point block is 128 KiB of LDS: one
+// workgroup per CU, so nothing overlaps its memory phases -- SQ counters (profiles/r5_ntt_stalls.txt): VALU busy
+// 58..74 % of the launch, the rest is the coefficient load at the head of every block, the drain of its stores and the
+// next workgroup's start.  Here the workgroup walks over its share of the (block, coset) items itself and loads the NEXT
+// item's coefficients into registers while the last pass of the current one computes and stores (16 words per lane: the
+// kernel has the registers, 48 of the 128 a four-wave SIMD allows).  The walk keeps id mod 8 (the XCD) and the
+// coset-adjacent dispatch order of the one-shot grid: gridDim.x is a multiple of 8 * n_cosets.  No barrier between items:
+// a lane's first LDS stores of an item go to the addresses its own last loads of the previous item read.
+template <int L>
+__global__ void __launch_bounds__((1 << L) / 16) __attribute__((amdgpu_waves_per_eu(4, 4)))
+ntt16_dit_persist_kernel(Ntt16Args a, uint32_t n_items) {
+  extern __shared__ uint64_t buf[];
+  constexpr uint32_t T = (1u << L) / 16;
+  constexpr int RT = (L % 4 == 0) ? 4 : (L % 4);
+  const uint32_t t = threadIdx.x;
+  const uint32_t log_bpc = a.log_n_total - L;
+  const uint64_t* tw = a.tw;
+  auto source_of = [&](uint32_t id) -> const uint64_t* {  // null: a padding id of the last group of eight
+    const uint32_t k = id >> 3, unit = (k / a.n_cosets) * 8 + (id & 7);
+    if (id >= n_items || unit >= a.n_units) return nullptr;
+    const uint32_t col = unit >> log_bpc, blk = unit & ((1u << log_bpc) - 1);
+    return a.in + col * a.in_stride + ((uint64_t)blk << L);
+  };
+  uint64_t xn[16];
+  {
+    const uint64_t* s0 = source_of(blockIdx.x);
+    if (s0) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) xn[m] = s0[m * T + t];
+    }
+  }
+  for (uint32_t id = blockIdx.x; id < n_items; id += gridDim.x) {
+    const uint32_t k = id >> 3, coset = k % a.n_cosets, unit = (k / a.n_cosets) * 8 + (id & 7);
+    const uint64_t* next_src = source_of(id + gridDim.x);
+    // opaque copies of the lane id, one per phase: every LDS and global address below is recomputed in the item it is
+    // used in (hoisted out of the item loop they are ~100 registers: the kernel then spills, as its one-shot form would
+    // without its own opaque copy)
+    uint32_t ta = t, tb = t, tc = t;
+    asm volatile("" : "+v"(ta));
+    if (unit >= a.n_units) {  // padding (the whole workgroup agrees): nothing was prefetched for it; fetch for the next one
+      if (next_src) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) xn[m] = next_src[m * T + t];
+      }
+      continue;
+    }
+    const uint32_t col = unit >> log_bpc, blk = unit & ((1u << log_bpc) - 1);
+    const uint64_t off = (uint64_t)blk << L;
+    if (a.scale) {
+      const uint64_t* sc = a.scale + ((uint64_t)coset << a.log_n_total) + off;
+#pragma unroll
+      for (int m0 = 0; m0 < 16; m0 += 4) {
+        uint64_t v[4], w[4], r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          v[i] = xn[m0 + i];
+          w[i] = sc[(m0 + i) * T + ta];
+        }
+        gl::mul_n<4>(v, w, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++) buf[swz<L>((m0 + i) * T + ta)] = r[i];
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; m++) buf[swz<L>(m * T + ta)] = xn[m];
+    }
+    __syncthreads();
+    asm volatile("" : "+v"(tb));
+    const uint32_t base = gl::bitrev(tb, L - 4) << 4;
+    uint64_t x[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(base | m)];
+    dit_butterflies<4, true>(x, tw, 0, 0, L - 4);
+#pragma unroll
+    for (int m = 0; m < 16; m++) buf[swz<L>(base | m)] = x[m];
+    __syncthreads();
+#pragma unroll
+    for (int b = 4; b + 4 <= L - RT; b += 4) {
+      asm volatile("" : "+v"(tc));
+#pragma unroll
+      for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(insert4(tc, m, b))];
+      dit_butterflies<4>(x, tw, tc & ((1u << b) - 1), b, L - (b + 4));
+#pragma unroll
+      for (int m = 0; m < 16; m++) buf[swz<L>(insert4(tc, m, b))] = x[m];
+      __syncthreads();
+    }
+    // the next item's coefficients start their way now: they fly while the last pass computes and stores
+    uint32_t t2 = t;
+    asm volatile("" : "+v"(t2));
+    if (next_src) {
+#pragma unroll
+      for (int m = 0; m < 16; m++) xn[m] = next_src[m * T + t2];
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) x[m] = buf[swz<L>(m * T + t2)];
+    sub_butterflies<RT, 4 - RT, false, false>(x, tw, t2, L - 4, L - RT, 0);
+    uint64_t* dst = a.out + col * a.out_stride + coset * a.out_coset_stride + off;
+#pragma unroll
+    for (int m0 = 0; m0 < 16; m0 += 4) {
+      uint64_t v[4] = {x[m0], x[m0 + 1], x[m0 + 2], x[m0 + 3]};
+      gl::canon_n<4>(v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[(m0 + i) * T + t2] = v[i];
+    }
+  }
+}
+
 #include "ntt_mx.cuh"  // the same blocks with the 16-point DFTs on the matrix cores
 
 // Strided global pass for columns taller than one LDS block: the top LOGR stages (DIF) or the
@@ -894,6 +1001,13 @@ static NttPlan plan_ntt(uint32_t log_n) {
 }
 static uint32_t pick_log_blk(uint32_t log_n) { return plan_ntt(log_n).log_blk; }
 
+// Persistent 2^14-point DIT workgroups (ntt16_dit_persist_kernel): 0 = the one-shot grid (default), 1 = on; resident
+// workgroups: one per CU.  Measured and NOT adopted (profiles/r5_ntt_stalls.txt): 2^14 x 2432 at rate 2 takes 893..919 us
+// persistent against 795..857 us one-shot on the same box -- the prefetched words push the kernel to the 128-VGPR edge
+// of four waves per SIMD (140 bytes of scratch per lane), and a one-shot grid already overlaps a finishing workgroup's
+// store drain with its successor's start on the same CU.
+static std::atomic<int> g_ntt_persist{0};
+static std::atomic<int> g_ntt_persist_wgs{256};
 // Split form (Ntt16Args), out of place only.
 static std::atomic<int> g_ntt_split{0};  // 0 = automatic, 1 = never, 2 = wherever possible, 3 = automatic + small DIT launches (measurement knobs)
 static bool use_split(uint32_t log_blk, uint64_t workgroups, const void* src, const void* dst, bool dit) {
@@ -1049,7 +1163,16 @@ int ntt_br2nat(const uint64_t* in, uint64_t in_stride, uint64_t* out, uint64_t o
         const dim3 grid16((b.n_units + 7) / 8 * 8 * n_cosets);
         if (log_blk == 12) BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<12, 0>), grid16, 256, 8u << 12, st, b);
         else if (log_blk == 13) BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<13, 0>), grid16, 512, 8u << 13, st, b);
-        else BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<14, 0>), grid16, 1024, 8u << 14, st, b);
+        else {
+          // 2^14-point blocks: one workgroup per CU either way; with more items than CUs the workgroups are persistent and
+          // prefetch (ntt16_dit_persist_kernel).  Grid: a multiple of 8 * n_cosets, at most one workgroup per CU.
+          const uint32_t items = grid16.x, group = 8 * n_cosets;
+          const uint32_t resident = std::max<uint32_t>(group, (uint32_t)g_ntt_persist_wgs.load(std::memory_order_relaxed) / group * group);
+          if (g_ntt_persist.load(std::memory_order_relaxed) && items > resident && in != out)
+            BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_persist_kernel<14>), dim3(resident), 1024, 8u << 14, st, b, items);
+          else
+            BPG_LAUNCH_TIMED(kt, HIP_KERNEL_NAME(ntt16_dit_kernel<14, 0>), grid16, 1024, 8u << 14, st, b);
+        }
       }
     }
     BPG_LAUNCH_CHECK();
@@ -1092,6 +1215,8 @@ static int init_ntt_kernels_once() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<14, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
+  BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_persist_kernel<14>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 14));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dif_kernel<13, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 << 13));
   BPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt16_dit_kernel<13, 0>),
@@ -1122,6 +1247,10 @@ int init_ntt_kernels() {
 extern "C" {
 
 void bp_tune_ntt_split(int mode) { bpg::g_ntt_split.store(mode); }
+void bp_tune_ntt_persist(int on, int resident_workgroups) {
+  bpg::g_ntt_persist.store(on != 0);
+  if (resident_workgroups > 0) bpg::g_ntt_persist_wgs.store(resident_workgroups);
+}
 void bp_tune_ntt_mx(int mode) { bpg::g_ntt_mx.store(mode < 0 || mode > 5 ? 3 : mode); }
 void bp_tune_ntt_mx_wg_per_cu(int n) { bpg::g_mx_wg_per_cu.store(n); }
 

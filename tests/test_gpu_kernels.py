@@ -100,6 +100,35 @@ def test_lde_matches_oracle(bpg, oracle, log_n, rate_bits, n_cols, ntt_form):
     assert (to_host(lde2) == to_host(lde)).all() and (to_host(c2) == to_host(coeffs)).all()
 
 
+def test_persistent_lde_workgroups_give_the_one_shot_grid_s_values(bpg, oracle):
+    """2^14-point coset-LDE blocks run as persistent workgroups that prefetch the next block's coefficients
+    (ntt16_dit_persist_kernel) once a launch has more (block, coset) items than resident workgroups: with 8 / 16 / 32
+    resident workgroups -- every workgroup walks over several items, padding ids included (37 columns: the last group of
+    eight is padded) -- the values are those of the one-shot grid and of the oracle; inputs may be any u64."""
+    import ctypes as C
+    L = bpg.lib()
+    L.bp_tune_ntt_persist.argtypes = [C.c_int, C.c_int]
+    L.bp_tune_ntt_persist.restype = None
+    rng = np.random.default_rng(77)
+    log_n, n_cols = 14, 37
+    vals = rng.integers(0, 1 << 64, size=(n_cols, 1 << log_n), dtype=np.uint64)
+    vals[:, ::5] = np.uint64(2**64 - 1)
+    try:
+        L.bp_tune_ntt_mx(0)
+        for r in (1, 3):
+            outs = []
+            for on, wgs in ((0, 256), (1, 8), (1, 16), (1, 32)):
+                L.bp_tune_ntt_persist(on, wgs)
+                outs.append(to_host(bpg.ops.lde_batch(to_dev(vals), r)[1]))
+            for k in range(1, len(outs)):
+                assert (outs[k] == outs[0]).all(), "persistent form %d differs from the one-shot grid (rate bits %d)" % (k, r)
+            _, want = oracle.lde_batch(vals[:2] % np.uint64(P), r)
+            assert (outs[1][:2][:, coset_major_to_natural(log_n, r)] == want).all()
+    finally:
+        L.bp_tune_ntt_persist(0, 256)
+        L.bp_tune_ntt_mx(3)
+
+
 def test_field_ops_against_big_integers(bpg):
     """K1 (SURVEY.md section 8(c) self-consistency item 2): every device form of the modular multiply
     (one-element carry chain, groups of three and four, the compiler form), lazy add/sub, the

@@ -35,6 +35,16 @@ def run(time_it):
 
 
 if __name__ == "__main__":
+    if "--persist" in sys.argv:   # the 2^14-point LDE blocks as one-shot grid / persistent prefetching workgroups
+        import ctypes as C
+        L = bpg.lib()
+        L.bp_tune_ntt_persist.argtypes = [C.c_int, C.c_int]
+        L.bp_tune_ntt_mx(0)
+        for on, wgs in ((0, 256), (1, 256), (1, 512), (0, 256), (1, 256)):
+            L.bp_tune_ntt_persist(on, wgs)
+            print("bp_tune_ntt_persist(%d, %d)" % (on, wgs), flush=True)
+            run(True)
+        sys.exit(0)
     for knob in ([0, 3] if "--both" in sys.argv else [None]):
         if knob is not None:
             bpg.lib().bp_tune_ntt_mx(knob)
