@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--real-airs", action="store_true",
                     help="the arithmetic, byte-packing, Keccak, Keccak-sponge, logic and memory tables of every transaction are "
                          "proven with the AIRs written from their public definitions (AIR 4, 5, 1, 6, 2, 3: 309 / 299 / 2431 / "
-                         "2414 / 523 / 44 columns) instead of synthetic tables of "
+                         "2414 / 523 / 45 columns) instead of synthetic tables of "
                          "BASELINE's widths -- another workload than the metric's, reported as such")
     ap.add_argument("--synthetic-rec", action="store_true",
                     help="the recursion-shaped proofs (22 of a txn's 29 proofs, every aggregation and block proof) are proofs of "
@@ -379,6 +379,7 @@ def main():
         L.bp_profile_enable(1)
     barrier()
     step_ms = []
+    clock = ClockSampler(torch, local_rank) if rank == 0 else None   # engine clock actually held in the timed region
     t0 = time.perf_counter()
     for b in range(args.warmup, args.warmup + args.steps):
         phase("timed step %d" % (b - args.warmup))
@@ -387,6 +388,7 @@ def main():
         step_ms.append(round((time.perf_counter() - t_s) * 1e3, 1))
     barrier()
     dt = time.perf_counter() - t0
+    clock_held = clock.stop() if clock else None
     phase("after the timed region")
     L.bp_profile_enable(0)
     if world > 1:
@@ -430,14 +432,19 @@ def main():
                                    else "synthetic AIR, 2432 columns",
                    "recursion_proofs": "synthetic AIR, 135 columns, 82 constants" if args.synthetic_rec
                                        else "PLONK-shaped circuit (AIR 8), 135 wires, 84 constants, 20 auxiliary columns",
-                   **({"logic_table": "logic AIR, 523 columns", "memory_table": "memory AIR, 44 columns",
+                   **({"logic_table": "logic AIR, 523 columns", "memory_table": "memory AIR, 45 columns",
                        "arithmetic_table": "arithmetic AIR, 309 columns",
                        "byte_packing_table": "byte-packing AIR, 299 columns",
                        "keccak_sponge_table": "Keccak sponge AIR, 2414 columns"} if args.real_airs else {}),
                    "txns_per_block": args.txns, "prover_streams_per_gpu": args.threads,
-                   "sharding": "contiguous txn slices, RCCL gather of %d sub-block proofs" % world,
+                   "sharding": "contiguous txn slices; the %d sub-block proofs meet in a pairwise tree over ranks (RCCL send / recv: "
+                               "rank 2k+1 -> 2k, 4k+2 -> 4k, ...)" % world,
+                   "scheduler": "bp_prove_shard (csrc/gi.cpp): the slice's txn proofs and its aggregation tree on the library's own "
+                                "thread pool, aggregations ahead of waiting transactions",
                    "ms_of_each_step_rank0": step_ms, "host_waits": host_waits, **t_build_info},
     }
+    out["engine_clock"] = clock_held
+    out["valu_issue"] = block_valu_issue(out["value"], clock_held, synthetic_rec=args.synthetic_rec, real_airs=args.real_airs or args.keccak_air)
     alone = {}
     if not args.no_profile:
         if args.leg_first:
@@ -483,6 +490,85 @@ def main():
 # 4 cycles (a SIMD has 16 lanes), at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md).
 N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
 VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * PEAK_CLOCK_HZ / 4
+class ClockSampler:
+    """The engine clock (sclk) of this rank's card, read from sysfs (hwmon freq1_input of the card with the device's PCI
+    address) every 50 ms by a thread while the timed region runs: the clock the chip actually HELD under this load --
+    the VALU-issue ceiling is SIMDs x that clock / cycles per instruction, not x the 2.4 GHz of the data sheet."""
+
+    def __init__(self, torch, device):
+        import threading
+        self.samples, self._stop, self.path = [], threading.Event(), None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from smi_sampler import find_sources
+            p = torch.cuda.get_device_properties(device)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            self.path = find_sources(bdf).get("sclk_Hz")
+        except Exception:
+            self.path = None
+        if not self.path:
+            self.thread = None
+            return
+
+        def run():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append(int(open(self.path).read().strip()))
+                except (OSError, ValueError):
+                    pass
+                self._stop.wait(0.05)
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        if not self.thread:
+            return None
+        self._stop.set()
+        self.thread.join()
+        hz = [x for x in self.samples if x > 0]
+        if not hz:
+            return None
+        return {"sclk_mhz_mean": round(sum(hz) / len(hz) / 1e6, 1), "sclk_mhz_min": round(min(hz) / 1e6, 1),
+                "sclk_mhz_max": round(max(hz) / 1e6, 1), "samples": len(hz), "source": "hwmon freq1_input, every 50 ms over the timed region"}
+
+
+LOADED_SQ_FILE = os.path.join("profiles", "r4_sq_loaded_by_kernel.txt")
+CLASS_MIX_FILE = os.path.join("profiles", "r5_valu_class_mix.txt")
+
+
+def block_valu_issue(rate, clock_held, synthetic_rec=False, real_airs=False):
+    """How close the block rate is to the chip's VALU-issue ceiling: (wave-instructions per txn proof, SQ counters of the
+    loaded run) x rate against 1024 SIMDs x clock / cycles per instruction -- once the data-sheet way (2.4 GHz, a flat
+    4 cycles), once with the clock held in this run's timed region and the cycle cost weighted by the instruction
+    classes of the kernels that issue them (tools/valu_class_mix.py: the cheap 32-bit class at 2.45 cycles, the carry /
+    multiply / 64-bit class at 4.5: profiles/r2_issue_rates.txt)."""
+    import re
+    if synthetic_rec or real_airs:
+        return None   # the tracked counters are those of the default workload
+    try:
+        txt = open(os.path.join(ROOT, LOADED_SQ_FILE)).read()
+        n_txn = int(re.search(r"--txns (\d+)", txt).group(1))
+        per_txn = sum(float(m.group(1)) for m in re.finditer(r"VALU ([0-9.]+e[+0-9]+) \(", txt)) / n_txn
+    except (OSError, AttributeError, ValueError):
+        return None
+    if not per_txn:
+        return None
+    out = {"valu_wave_insts_per_txn": per_txn, "counters_source": LOADED_SQ_FILE,
+           "frac_of_peak_clock_flat_4_cycles": round(per_txn * rate / VALU_PEAK_WAVE_INSTS_PER_S, 3)}
+    try:
+        mix = open(os.path.join(ROOT, CLASS_MIX_FILE)).read()
+        cyc = float(re.search(r"weighted cycles per VALU instruction \(block mix\): ([0-9.]+)", mix).group(1))
+        out["weighted_cycles_per_inst"] = cyc
+        out["class_mix_source"] = CLASS_MIX_FILE
+        if clock_held:
+            hz = clock_held["sclk_mhz_mean"] * 1e6
+            out["frac_at_held_clock_weighted"] = round(per_txn * rate / (N_SIMD * hz / cyc), 3)
+            out["frac_at_held_clock_flat_4_cycles"] = round(per_txn * rate / (N_SIMD * hz / 4), 3)
+    except (OSError, AttributeError, ValueError):
+        pass
+    return out
+
+
 SQ_FILE = os.path.join("profiles", "r4_hash_sq_counters.txt")
 
 
