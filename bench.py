@@ -47,7 +47,16 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md
 # (two rocprofv3 --pmc passes of this same command, tools/pmc_family_traffic.py).  bench.py cannot collect
 # counters itself, so it reads the tracked summary and names it (and the commit it was taken at) beside the
 # number; no file, no number.
-TRAFFIC_FILE = os.path.join("profiles", "r4_pmc_lde_family.txt")
+def tracked(name):
+    """the newest tracked counter summary of that name: profiles/r5_<name> when this round's passes were taken, else round 4's"""
+    for rnd in ("r5", "r4"):
+        p = os.path.join("profiles", "%s_%s" % (rnd, name))
+        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), p)):
+            return p
+    return os.path.join("profiles", "r4_" + name)
+
+
+TRAFFIC_FILE = tracked("pmc_lde_family.txt")
 
 
 # (flag, bp_tune_* entry, help): every run-time knob of the library that bench.py can set
@@ -112,7 +121,7 @@ def main():
                     help="the recursion-shaped proofs (22 of a txn's 29 proofs, every aggregation and block proof) are proofs of "
                          "the synthetic AIR on 135 x 82 columns, as in rounds 1-3 (bp_config.rec_air_id = 0), instead of the "
                          "PLONK-shaped circuit that is the default since round 4 (AIR 8: gates by constants, public inputs "
-                         "in-circuit, the copy-constraint permutation argument; 84 constant columns, 20 instead of 16 "
+                         "in-circuit, the copy-constraint permutation argument; 85 constant columns, 20 instead of 16 "
                          "auxiliary columns)")
     ap.add_argument("--tree-shape", default="balanced", choices=("balanced", "pairs_then_chain"),
                     help="shape of a shard's aggregation tree (block_driver.aggregation_plan)")
@@ -431,7 +440,7 @@ def main():
                    "keccak_table": "Keccak-f[1600] AIR, 2431 columns" if (args.keccak_air or args.real_airs)
                                    else "synthetic AIR, 2432 columns",
                    "recursion_proofs": "synthetic AIR, 135 columns, 82 constants" if args.synthetic_rec
-                                       else "PLONK-shaped circuit (AIR 8), 135 wires, 84 constants, 20 auxiliary columns",
+                                       else "PLONK-shaped circuit (AIR 8), 135 wires, 85 constants, 20 auxiliary columns; the public-input list is hashed in-circuit by Poseidon-gate rows",
                    **({"logic_table": "logic AIR, 523 columns", "memory_table": "memory AIR, 45 columns",
                        "arithmetic_table": "arithmetic AIR, 309 columns",
                        "byte_packing_table": "byte-packing AIR, 299 columns",
@@ -532,7 +541,7 @@ class ClockSampler:
                 "sclk_mhz_max": round(max(hz) / 1e6, 1), "samples": len(hz), "source": "hwmon freq1_input, every 50 ms over the timed region"}
 
 
-LOADED_SQ_FILE = os.path.join("profiles", "r4_sq_loaded_by_kernel.txt")
+LOADED_SQ_FILE = tracked("sq_loaded_by_kernel.txt")
 CLASS_MIX_FILE = os.path.join("profiles", "r5_valu_class_mix.txt")
 
 
@@ -569,7 +578,7 @@ def block_valu_issue(rate, clock_held, synthetic_rec=False, real_airs=False):
     return out
 
 
-SQ_FILE = os.path.join("profiles", "r4_hash_sq_counters.txt")
+SQ_FILE = tracked("hash_sq_counters.txt")
 
 
 def valu_insts_per_perm():
@@ -589,7 +598,7 @@ def valu_insts_per_perm():
         return None, None
 
 
-K5_FILE = os.path.join("profiles", "r4_k5_counters.txt")
+K5_FILE = tracked("k5_counters.txt")
 REAL_AIRS = dict(keccak_air=True, logic_air=True, memory_air=True, arithmetic_air=True, byte_packing_air=True,
                  keccak_sponge_air=True)
 
@@ -727,7 +736,7 @@ def cpu_baseline(ir, synthetic_rec=False):
     lo, hi = list(S1_LOG_N), [x + 1 for x in S1_LOG_N]
     st = pyoracle.PgState(table_log_lo=lo, table_log_hi=hi, stark_rate_bits=1, stark_cap_height=4,
                           stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5, rec_log_n=13,
-                          rec_n_cols=135, rec_n_const=82 if synthetic_rec else 84, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
+                          rec_n_cols=135, rec_n_const=82 if synthetic_rec else 85, rec_rate_bits=3, rec_num_queries=28, rec_pow_bits=16,
                           shrink_depth=3, rec_air_id=0 if synthetic_rec else 8)
     import struct
     words = list(struct.unpack("<25Q", ir.to_bytes()))

@@ -304,11 +304,13 @@ int bp_keccak_sponge_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log
  * d_inputs: [n][9] = is_mul (0 = a padding row), the four 64-bit words of x and of y; or NULL to draw them from `seed`. */
 int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
-/* AIR 8 (plonk): the 84 preprocessed constant columns of the fixed circuit (selectors, gate constants drawn from `seed`,
- * the 80 sigmas of its copy permutation), n = 2^log_n rows, column-major; and the circuit's witness, 135 wires: free wires
- * drawn from `seed`, the four public inputs in row 0 and, through a copy constraint, in the first arithmetic row. */
-int bp_plonk_constants(uint64_t seed, uint32_t log_n, uint64_t* d_consts_out, void* stream);
-int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t pub[4], uint32_t log_n, uint64_t* d_trace_out,
+/* AIR 8 (plonk): the 85 preprocessed constant columns of the fixed circuit (selectors, gate constants drawn from `seed`,
+ * the hash-row selector, the 80 sigmas of its copy permutation) for a circuit that hashes a public-input list of pi_len
+ * words (1..64) in its Poseidon-gate rows, n = 2^log_n rows (>= 16), column-major; and the circuit's witness, 135 wires:
+ * free wires drawn from `seed`, the list pi hashed in rows 4.., its hash in row 0 (the four public inputs) and, through
+ * copy constraints, in the first arithmetic row.  bp_plonk_trace returns after the stream has run it. */
+int bp_plonk_constants(uint64_t seed, uint32_t log_n, uint32_t pi_len, uint64_t* d_consts_out, void* stream);
+int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t* pi, uint32_t pi_len, uint32_t log_n, uint64_t* d_trace_out,
                    void* stream);
 
 /* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
@@ -355,9 +357,12 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
  * constants commitment when n_const > 0, else NULL.  Host only; BP_ERR_VERIFY + bp_last_error() on rejection. */
 int bp_stark_verify_air(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint8_t* proof,
                         size_t len);
-/* AIR 8 (plonk) binds four public inputs to its first row.  A lone table proof (bp_stark_prove_air(8, ...)) takes them from
- * its seed by bp_stark_public_inputs; its verifier is given them (pub = NULL: four zeros, what every other AIR has). */
+/* AIR 8 (plonk) binds four public inputs to its first row: the hash of the proof's public-input list, which the circuit
+ * computes in its hash rows.  A lone table proof (bp_stark_prove_air(8, ...)) has the four-word list
+ * bp_stark_public_input_list(seed); bp_stark_public_inputs = its hash, what the verifier is given (pub = NULL: four zeros,
+ * what every other AIR has). */
 void bp_stark_public_inputs(uint64_t seed, uint64_t out[4]);
+void bp_stark_public_input_list(uint64_t seed, uint64_t out[4]);
 int bp_stark_verify_air_pub(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint64_t* pub,
                             const uint8_t* proof, size_t len);
 /* bp_stark_prove_synthetic keeps one worker (stream + device arena, up to ~100 GB for a 2^20 x 2432

@@ -96,7 +96,7 @@ typedef struct {
 #define ORC_ARITHMETIC_MUL_CONSTRAINTS 1218u
 #define ORC_AIR_PLONK 8u
 #define ORC_PLONK_COLS 135u
-#define ORC_PLONK_CONSTS 84u
+#define ORC_PLONK_CONSTS 85u
 
 /* starky ConstraintConsumer: acc_j = acc_j * alpha_j + constraint, in list order; base field (the LDE coset)
  * and extension field (the verifier at zeta; the alphas stay in the base field). */
@@ -146,9 +146,10 @@ void orc_keccak_sponge_trace_limit(uint64_t seed, const uint64_t* inputs, unsign
 void orc_keccak_sponge_constraints_base(const gl_t* loc, const gl_t* nxt, orc_consumer* k);
 void orc_keccak_sponge_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_consumer2* k);
 /* plonk_air.c */
-void orc_stark_public_inputs(uint64_t seed, gl_t out[4]);
-void orc_plonk_constants(uint64_t seed, unsigned log_n, gl_t* consts);
-void orc_plonk_trace(uint64_t seed, const gl_t pub[4], const gl_t* consts, unsigned log_n, gl_t* trace);
+void orc_stark_public_inputs(uint64_t seed, gl_t out[4]);      /* hash of the list below */
+void orc_stark_public_input_list(uint64_t seed, gl_t out[4]);
+void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, gl_t* consts);
+void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, const gl_t* consts, unsigned log_n, gl_t* trace);
 void orc_plonk_aux_columns(const gl_t* trace_values, const gl_t* consts, unsigned log_n, const gl_t ctl[4], gl_t* aux);
 void orc_plonk_constraints_base(const gl_t* cst, const gl_t* loc, const gl_t* aux, const gl_t* aux_nxt, const gl_t ctl[4],
                                 const gl_t pub[4], gl_t x, orc_consumer* k);

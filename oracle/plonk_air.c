@@ -8,17 +8,32 @@
  * constraints.  NOT upstream's gate set, NOT a verifier circuit.
  *
  * Wires: 20 slots (a, b, c, d) = columns 4s..4s+3 (routed), 11 S-box units (x, x^2, x^4, x^6, x^7) = columns 80+5i...
- * Constants (84): 0 q_arith, 1 q_sbox, 2 c0, 3 c1, 4 + j sigma_j.  Copy permutation: wire (j, i) is the field element
+ * Constants (85): 0 q_arith, 1 q_sbox, 2 c0, 3 c1, 4 q_hash, 5 + j sigma_j.  Copy permutation: wire (j, i) is the field element
  * 7^j w^i; sigma maps every wire to the next one of its equivalence class.  The circuit: rows in groups of four,
  *   4g   arith, free inputs     4g+1  arith on the outputs of 4g     4g+2  S-box of the first 11 outputs of 4g+1
  *   4g+3 arith whose first 11 `a` inputs are the S-box outputs;  group 0 = the public-input row and three no-ops;
- * c_j of row 4 (j < 4) is the public input w_j of row 0.  Equivalence classes are listed below as explicit sets; the
+ * c_j of row 12 (j < 4) is the public input w_j of row 0, which is word j of the in-circuit hash (see below).  Equivalence classes are listed below as explicit sets; the
  * product (csrc/air.hpp, plonk::sigma_of) computes "the next member" in closed form. */
 #include "oracle.h"
 #include <stdlib.h>
 #include <string.h>
 
-enum { PW = 135, PK = 84, ROUTED = 80, SLOTS = 20, SBOX = 11, SB0 = 80 };
+enum { PW = 135, PK = 85, ROUTED = 80, SLOTS = 20, SBOX = 11, SB0 = 80, SIG0 = 5 /* first sigma column */ };
+/* Round 5: the circuit hashes its public-input list in-circuit.  Rows 4 .. 4 + H - 1 (H = ceil(len / 8)) are Poseidon
+ * rows (constant column 4 = q_hash): one permutation per row, wires 0..11 state in, 12..23 state out, 24..59 the S-box
+ * inputs of rounds 1..3, 60..81 word 0 going into the S-box of rounds 4..25, 82..129 the S-box inputs of rounds 26..29.
+ * Chunk h of the list sits in wires 0..7 of row 4 + h; the rest of the incoming state is copied from the previous row's
+ * output, or (row 4) from the d wires of row 1, an arithmetic row whose gate constants are zero.  The first four output
+ * words of the last hash row are the public-input wires of row 0.  Arithmetic groups start at row 12. */
+enum { HROW0 = 4, AROW0 = 12, ZROW = 1, HIN = 0, HOUT = 12, HF1 = 24, HPART = 60, HF2 = 82, HWIRES = 130 };
+static const gl_t PRC[360] = {
+#include "poseidon_rc.inc"
+};
+static gl_t mds_at(int r, int c) { /* out[r] = sum_c M[r][c] in[c]: the circulant with first ROW (17, 15, 41, ...), plus 8 at [0][0] */
+  static const gl_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  return CIRC[((c - r) % 12 + 12) % 12] + (r == 0 && c == 0 ? 8 : 0);
+}
+static unsigned hash_rows_of(unsigned pi_len) { return (pi_len + 7) / 8; }
 
 static inline uint64_t smix(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ULL;
@@ -28,8 +43,13 @@ static inline uint64_t smix(uint64_t x) {
 }
 static inline gl_t rnd(uint64_t seed, uint64_t col, uint64_t row) { return gl_canon(smix(seed ^ (col << 32) ^ row)); }
 
-void orc_stark_public_inputs(uint64_t seed, gl_t out[4]) { /* of a lone table proof: from its seed */
+void orc_stark_public_input_list(uint64_t seed, gl_t out[4]) { /* of a lone table proof: four words from its seed */
   for (uint64_t j = 0; j < 4; j++) out[j] = gl_canon(smix(seed ^ ((0x50 + j) << 32)));
+}
+void orc_stark_public_inputs(uint64_t seed, gl_t out[4]) { /* ... and what its first row is bound to: the hash of that list */
+  gl_t pi[4];
+  orc_stark_public_input_list(seed, pi);
+  orc_hash_no_pad(pi, 4, out);
 }
 
 typedef struct { uint32_t col, row; } wire_t;
@@ -37,33 +57,52 @@ typedef struct { uint32_t col, row; } wire_t;
 static void tie(gl_t* consts, size_t N, const gl_t* kpow, const gl_t* wpow, const wire_t* m, int n) {
   for (int i = 0; i < n; i++) {
     const wire_t to = m[(i + 1) % n];
-    consts[(size_t)(4 + m[i].col) * N + m[i].row] = gl_mul(kpow[to.col], wpow[to.row]);
+    consts[(size_t)(SIG0 + m[i].col) * N + m[i].row] = gl_mul(kpow[to.col], wpow[to.row]);
   }
 }
-void orc_plonk_constants(uint64_t seed, unsigned log_n, gl_t* consts) {
+void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, gl_t* consts) {
   const size_t N = (size_t)1 << log_n;
+  const unsigned H = hash_rows_of(pi_len), last_len = pi_len - 8 * (H - 1);
   gl_t *kpow = (gl_t*)malloc(ROUTED * sizeof(gl_t)), *wpow = (gl_t*)malloc(N * sizeof(gl_t));
   kpow[0] = 1;
   for (int j = 1; j < ROUTED; j++) kpow[j] = gl_mul(kpow[j - 1], 7);
   wpow[0] = 1;
   for (size_t i = 1; i < N; i++) wpow[i] = gl_mul(wpow[i - 1], gl_root(log_n));
   for (size_t i = 0; i < N; i++) {
-    const int gate_row = i >= 4;
-    consts[0 * N + i] = gate_row && (i % 4 != 2);
+    const int gate_row = i >= AROW0;
+    consts[0 * N + i] = (gate_row && (i % 4 != 2)) || i == ZROW; /* row 1: an arithmetic gate with zero constants: d = 0 */
     consts[1 * N + i] = gate_row && (i % 4 == 2);
-    consts[2 * N + i] = rnd(seed ^ 0xC0115700C0115700ULL, 2, i);
-    consts[3 * N + i] = rnd(seed ^ 0xC0115700C0115700ULL, 3, i);
-    for (int j = 0; j < ROUTED; j++) consts[(size_t)(4 + j) * N + i] = gl_mul(kpow[j], wpow[i]); /* untied: itself */
+    consts[2 * N + i] = i == ZROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, 2, i);
+    consts[3 * N + i] = i == ZROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, 3, i);
+    consts[4 * N + i] = i >= HROW0 && i < HROW0 + H;
+    for (int j = 0; j < ROUTED; j++) consts[(size_t)(SIG0 + j) * N + i] = gl_mul(kpow[j], wpow[i]); /* untied: itself */
   }
-  for (size_t g = 1; g < N / 4; g++) {
+  /* the sponge: which incoming state words of hash row h are NOT words of the list */
+  {
+    unsigned zero_wire = 0;
+    for (unsigned h = 0; h < H; h++)
+      for (unsigned k = 0; k < 12; k++) {
+        const int carried = k >= 8 || (h == H - 1 && k >= last_len);
+        if (!carried) continue;
+        if (h == 0) { /* nothing before the first chunk: the word is zero -- a copy of one of row 1's d wires */
+          const wire_t z[2] = {{HIN + k, HROW0}, {4 * zero_wire + 3, ZROW}};
+          tie(consts, N, kpow, wpow, z, 2);
+          zero_wire++;
+        } else { /* what the previous permutation left there */
+          const wire_t c[2] = {{HIN + k, HROW0 + h}, {HOUT + k, HROW0 + h - 1}};
+          tie(consts, N, kpow, wpow, c, 2);
+        }
+      }
+  }
+  for (size_t g = AROW0 / 4; g < N / 4; g++) {
     const uint32_t r = (uint32_t)(4 * g);
     for (uint32_t s = 0; s < SLOTS; s++) {
       /* d_s(4g) is the `a` input of slot s and the `b` input of slot s - 1 in the next row */
       const wire_t dab[3] = {{4 * s + 3, r}, {4 * s, r + 1}, {4 * ((s + SLOTS - 1) % SLOTS) + 1, r + 1}};
       tie(consts, N, kpow, wpow, dab, 3);
-      if (g == 1 && s < 4) { /* c_s of the first computing rows is public input s */
-        const wire_t cc[3] = {{4 * s + 2, r}, {4 * s + 2, r + 1}, {s, 0}};
-        tie(consts, N, kpow, wpow, cc, 3);
+      if (r == AROW0 && s < 4) { /* c_s of the first computing rows is public input s, which is word s of the hash */
+        const wire_t cc[4] = {{s, 0}, {4 * s + 2, r}, {4 * s + 2, r + 1}, {HOUT + s, HROW0 + H - 1}};
+        tie(consts, N, kpow, wpow, cc, 4);
       } else {
         const wire_t cc[2] = {{4 * s + 2, r}, {4 * s + 2, r + 1}};
         tie(consts, N, kpow, wpow, cc, 2);
@@ -79,14 +118,47 @@ void orc_plonk_constants(uint64_t seed, unsigned log_n, gl_t* consts) {
   free(kpow); free(wpow);
 }
 
-/* Witness: row by row.  consts: the circuit's constants (c0, c1 are read). */
-void orc_plonk_trace(uint64_t seed, const gl_t pub[4], const gl_t* consts, unsigned log_n, gl_t* t) {
+/* Witness: row by row.  consts: the circuit's constants (c0, c1 are read).  pi: the public-input list the hash rows
+ * absorb; the four public inputs of row 0 are its hash, computed here the way the circuit computes it. */
+static gl_t pow7(gl_t x) { const gl_t x2 = gl_mul(x, x), x3 = gl_mul(x2, x), x6 = gl_mul(x3, x3); return gl_mul(x6, x); }
+static void mds_layer(gl_t st[12]) {
+  gl_t o[12];
+  for (int r = 0; r < 12; r++) {
+    gl_t acc = 0;
+    for (int c = 0; c < 12; c++) acc = gl_add(acc, gl_mul(mds_at(r, c), st[c]));
+    o[r] = acc;
+  }
+  memcpy(st, o, sizeof(o));
+}
+void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, const gl_t* consts, unsigned log_n, gl_t* t) {
   const size_t N = (size_t)1 << log_n;
+  const unsigned H = hash_rows_of(pi_len);
 #define W(col, row) t[(size_t)(col) * N + (row)]
   for (size_t i = 0; i < N; i++) /* every wire starts free; the rows below overwrite what the circuit computes */
     for (int c = 0; c < PW; c++) W(c, i) = rnd(seed, c, i);
+  for (int s = 0; s < SLOTS; s++) W(4 * s + 3, ZROW) = 0; /* 0 a b + 0 c */
+  /* the hash rows: absorb eight words, permute, keep every S-box input on the way */
+  gl_t st[12] = {0};
+  for (unsigned h = 0; h < H; h++) {
+    const size_t row = HROW0 + h;
+    const unsigned take = pi_len - 8 * h < 8 ? pi_len - 8 * h : 8;
+    for (unsigned k = 0; k < take; k++) st[k] = pi[8 * h + k];
+    for (int k = 0; k < 12; k++) W(HIN + k, row) = st[k];
+    for (int rnd_no = 0; rnd_no < 30; rnd_no++) {
+      for (int k = 0; k < 12; k++) st[k] = gl_add(st[k], PRC[12 * rnd_no + k]);
+      const int full = rnd_no < 4 || rnd_no >= 26;
+      if (rnd_no >= 1 && rnd_no <= 3) for (int k = 0; k < 12; k++) W(HF1 + 12 * (rnd_no - 1) + k, row) = st[k];
+      if (rnd_no >= 4 && rnd_no <= 25) W(HPART + rnd_no - 4, row) = st[0];
+      if (rnd_no >= 26) for (int k = 0; k < 12; k++) W(HF2 + 12 * (rnd_no - 26) + k, row) = st[k];
+      if (full) for (int k = 0; k < 12; k++) st[k] = pow7(st[k]);
+      else st[0] = pow7(st[0]);
+      mds_layer(st);
+    }
+    for (int k = 0; k < 12; k++) W(HOUT + k, row) = st[k];
+  }
+  gl_t pub[4] = {st[0], st[1], st[2], st[3]};
   for (int j = 0; j < 4; j++) W(j, 0) = pub[j];
-  for (size_t i = 4; i < N; i++) {
+  for (size_t i = AROW0; i < N; i++) {
     const gl_t c0 = consts[2 * N + i], c1 = consts[3 * N + i];
     const int p = (int)(i % 4);
     if (p == 1)
@@ -95,7 +167,7 @@ void orc_plonk_trace(uint64_t seed, const gl_t pub[4], const gl_t* consts, unsig
         W(4 * s + 1, i) = W(4 * ((s + 1) % SLOTS) + 3, i - 1);
         W(4 * s + 2, i) = W(4 * s + 2, i - 1);
       }
-    if (p == 0 && i == 4)
+    if (p == 0 && i == AROW0)
       for (int s = 0; s < 4; s++) W(4 * s + 2, i) = pub[s];
     if (p == 3)
       for (int s = 0; s < SBOX; s++) W(4 * s, i) = W(4 * s + 3, i - 1);
@@ -132,7 +204,7 @@ void orc_plonk_aux_columns(const gl_t* tv, const gl_t* consts, unsigned log_n, c
         for (int j = 8 * k; j < 8 * k + 8; j++) {
           const gl_t w = tv[(size_t)j * N + i];
           num = gl_mul(num, gl_add(gl_add(w, gl_mul(beta, gl_mul(kj, x))), gamma));
-          den = gl_mul(den, gl_add(gl_add(w, gl_mul(beta, consts[(size_t)(4 + j) * N + i])), gamma));
+          den = gl_mul(den, gl_add(gl_add(w, gl_mul(beta, consts[(size_t)(SIG0 + j) * N + i])), gamma));
           kj = gl_mul(kj, 7);
         }
         ratio[(size_t)k * N + i] = gl_mul(num, gl_inv(den));

@@ -74,11 +74,11 @@ void orc_pg_state_free(orc_pg_state* s) {
   free(s);
 }
 /* circuits are preprocessed lazily (same data as libbpg's eager bp_state_build) */
-static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed) {
+static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len) {
   if (!c->built) {
     size_t n = (size_t)1 << s->rec.log_n;
     c->const_values = (gl_t*)malloc(s->rec.n_const * n * sizeof(gl_t));
-    if (s->rec.air_id == ORC_AIR_PLONK) orc_plonk_constants(seed, s->rec.log_n, c->const_values);
+    if (s->rec.air_id == ORC_AIR_PLONK) orc_plonk_constants(seed, s->rec.log_n, pi_len, c->const_values);
     else orc_synth_constants(seed, s->rec.log_n, s->rec.n_const, c->const_values);
     c->consts = orc_commit_values(c->const_values, s->rec.log_n, s->rec.n_const, s->rec.rate_bits, s->rec.cap_height);
     orc_hash_no_pad(orc_committed_cap(c->consts), (size_t)4 << s->rec.cap_height, c->digest);
@@ -86,8 +86,13 @@ static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed) {
   }
   return c;
 }
-static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) { return get_circuit(s, &s->table[t][d], circuit_seed(t, d)); }
-static circuit_t* special_circuit(orc_pg_state* s, int k) { return get_circuit(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0)); }
+/* the length of the public-input list each circuit hashes in-circuit: a table's chain circuits (digest, table, depth) 6;
+ * root 7 digests + the public values; aggregation two digests, two flags + the public values; block two digests, a flag + them */
+static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) { return get_circuit(s, &s->table[t][d], circuit_seed(t, d), 6); }
+static circuit_t* special_circuit(orc_pg_state* s, int k) {
+  static const unsigned PI_LEN[3] = {4 * NUM_TABLES + PV_WORDS, 10 + PV_WORDS, 9 + PV_WORDS};
+  return get_circuit(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0), PI_LEN[k]);
+}
 
 static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_pi, gl_t* proof) {
   gl_t pi_hash[4];
@@ -101,7 +106,7 @@ static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_
   orc_stark_cfg rcfg = s->rec; /* the PLONK-shaped circuit binds the hash of the public inputs to its first row */
   if (rcfg.air_id == ORC_AIR_PLONK) {
     memcpy(rcfg.pub, pi_hash, sizeof(rcfg.pub));
-    orc_plonk_trace(pi_hash[0], pi_hash, circ->const_values, rcfg.log_n, trace);
+    orc_plonk_trace(pi_hash[0], pi, (unsigned)n_pi, circ->const_values, rcfg.log_n, trace);
   } else {
     orc_synth_trace(pi_hash[0], &s->rec, circ->const_values, trace);
   }

@@ -117,8 +117,9 @@ def lib():
     L.orc_pg_txn_witness.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                      C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_stark_public_inputs.argtypes = [u6, u64p]
-    L.orc_plonk_constants.argtypes = [u6, u, u64p]
-    L.orc_plonk_trace.argtypes = [u6, u64p, u64p, u, u64p]
+    L.orc_plonk_constants.argtypes = [u6, u, u, u64p]
+    L.orc_plonk_trace.argtypes = [u6, u64p, u, u64p, u, u64p]
+    L.orc_stark_public_input_list.argtypes = [u6, u64p]
     L.orc_pg_txn_tables.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                     C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_pg_verify_tables.argtypes = [C.POINTER(PgConfig), u64p, sz]
@@ -256,11 +257,11 @@ def make_cfg(log_n, n_cols, n_const=0, deg_pow=1, rate_bits=1, cap_height=4, num
                     final_poly_bits, air_id, (C.c_uint64 * 4)(*[int(x) for x in pub]))
 
 
-AIR_PLONK, PLONK_COLS, PLONK_CONSTS = 8, 135, 84
+AIR_PLONK, PLONK_COLS, PLONK_CONSTS = 8, 135, 85
 
 
 def plonk_cfg(log_n, pub=(0, 0, 0, 0), **kw):
-    """AIR 8 (plonk_air.c): 135 wires, 84 constant columns, degree 9 -> deg_pow 3, rate_bits 3."""
+    """AIR 8 (plonk_air.c): 135 wires, 85 constant columns, degree 9 -> deg_pow 3, rate_bits 3."""
     return make_cfg(log_n, PLONK_COLS, n_const=PLONK_CONSTS, deg_pow=3, rate_bits=3, air_id=AIR_PLONK, pub=pub, **kw)
 
 
@@ -270,15 +271,25 @@ def stark_public_inputs(seed):
     return out
 
 
-def plonk_constants(log_n, seed):
-    out = np.zeros((PLONK_CONSTS, 1 << log_n), dtype=np.uint64)
-    lib().orc_plonk_constants(C.c_uint64(seed), log_n, out)
+def stark_public_input_list(seed):
+    """the four-word public-input list of a lone AIR-8 table proof; stark_public_inputs(seed) is its hash"""
+    out = np.empty(4, dtype=np.uint64)
+    lib().orc_stark_public_input_list(C.c_uint64(seed), out)
     return out
 
 
-def plonk_trace(log_n, seed, pub, consts):
+def plonk_constants(log_n, seed, pi_len=4):
+    """the 85 constant columns of a circuit that hashes a public-input list of pi_len words"""
+    out = np.zeros((PLONK_CONSTS, 1 << log_n), dtype=np.uint64)
+    lib().orc_plonk_constants(C.c_uint64(seed), log_n, pi_len, out)
+    return out
+
+
+def plonk_trace(log_n, seed, pi, consts):
+    """the witness; pi: the public-input list the hash rows absorb (its hash lands in row 0)"""
     out = np.zeros((PLONK_COLS, 1 << log_n), dtype=np.uint64)
-    lib().orc_plonk_trace(C.c_uint64(seed), arr(pub), arr(consts), log_n, out)
+    pi = arr(pi)
+    lib().orc_plonk_trace(C.c_uint64(seed), pi, pi.size, arr(consts), log_n, out)
     return out
 
 

@@ -47,6 +47,9 @@
 #pragma once
 #include <cstdint>
 #include "gl.hpp"
+#if defined(__HIP__)
+#include "poseidon.cuh"  // the device form of the Poseidon gate's round function (PoseidonOps<uint64_t>)
+#endif
 
 namespace bpg {
 namespace air {
@@ -109,6 +112,58 @@ struct Ops<gl::Ext> {
   static T sub_lazy(T a, T b) { return gl::sub(a, b); }
   static T mul7(T a) { return gl::scale(a, 7); }
 };
+
+// ------------------------------------------------------------------------------------------ Poseidon, as constraints
+// The round function of Poseidon-Goldilocks (width 12, x^7, MDS = circulant(17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20)
+// + diag(8, 0, ...), constants poseidon_rc.inc: the permutation the Merkle trees and the transcript use) over a field
+// policy T, for AIR 8's Poseidon gate: sbox_all = x^7 on the twelve words, mds_rc = the MDS layer followed by the
+// constants of round `next` (none for next < 0).  Generic form (the host verifier's extension field); the device's
+// base-field form is the hash kernels' own code (poseidon.cuh: grouped carry-chain S-boxes, MDS over 32-bit halves).
+GL_HD uint64_t poseidon_rc(uint32_t i) {
+  constexpr uint64_t RC[360] = {
+#include "poseidon_rc.inc"
+  };
+  return RC[i];
+}
+GL_HD uint32_t poseidon_mds_entry(uint32_t r, uint32_t c) {  // out[r] = sum_c M[r][c] in[c]
+  constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  return C[(c + 12 - r) % 12] + ((r | c) == 0 ? 8u : 0u);
+}
+template <class T>
+struct PoseidonOps {
+  typedef Ops<T> F;
+  static GL_HD T sbox(T x) {
+    const T x2 = F::mul(x, x), x4 = F::mul(x2, x2), x3 = F::mul(x2, x);
+    return F::mul(x3, x4);
+  }
+  static GL_HD void sbox_all(T (&s)[12]) {
+    for (uint32_t i = 0; i < 12; i++) s[i] = sbox(s[i]);
+  }
+  static GL_HD void mds_rc(T (&s)[12], int next) {
+    T o[12];
+    for (uint32_t r = 0; r < 12; r++) {
+      T acc = F::k(next >= 0 ? poseidon_rc(12 * (uint32_t)next + r) : 0);
+      for (uint32_t c = 0; c < 12; c++) acc = F::add(acc, F::mul(F::k(poseidon_mds_entry(r, c)), s[c]));
+      o[r] = acc;
+    }
+    for (uint32_t r = 0; r < 12; r++) s[r] = o[r];
+  }
+  static GL_HD T add_rc0(T x, uint32_t i) { return F::add(x, F::k(poseidon_rc(i))); }
+};
+#if defined(__HIP__)
+template <>
+struct PoseidonOps<uint64_t> {  // canonical words in, canonical words out (Ops<uint64_t>'s convention)
+  static __device__ __forceinline__ uint64_t sbox(uint64_t x) { return gl::canon(poseidon::sbox(x)); }
+  static __device__ __forceinline__ void sbox_all(uint64_t (&s)[12]) { poseidon::sbox_all(s); }  // reduced: mds_rc takes any u64
+  static __device__ __forceinline__ void mds_rc(uint64_t (&s)[12], int next) {
+    if (next >= 0) poseidon::mds<true>(s, poseidon::RC + 12 * next);
+    else poseidon::mds<false>(s, nullptr);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+  }
+  static __device__ __forceinline__ uint64_t add_rc0(uint64_t x, uint32_t i) { return gl::addc(x, poseidon::RC[i]); }
+};
+#endif
 
 // ------------------------------------------------------------------------------------------ AIR 0: synthetic
 // Per group g of four columns (a, b, c, d), q = constant column g mod K (or 1):
@@ -875,18 +930,79 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 //   row 4g + 1  arithmetic, a_s := d_s(4g), b_s := d_(s+1)(4g), c_s := c_s(4g)          (3- and 2-cycles)
 //   row 4g + 2  S-box, x_i := d_i(4g + 1) through a_i, d_i = x_i^7                       (2-cycles)
 //   row 4g + 3  arithmetic, a_i := d_i(4g + 2) for i < 11, the rest free               (2-cycles)
-// and c_j(4) := pub_j (row 0), j < 4, ties the computation to the public inputs.
+// and c_j(12) := pub_j (row 0), j < 4, ties the computation to the public inputs.
+//
+// Round 5: the circuit HASHES its public-input list itself (upstream: the public inputs of a recursion circuit are hashed
+// in-circuit by PoseidonGates and the four hash words routed to the PublicInputGate; round 4 bound the first row to a hash
+// the HOST computed).  A **Poseidon gate** -- one whole permutation per row across the wires, as upstream's PoseidonGate
+// lays it out, which is why a row has 135 wires -- selected by a fifth constant column q_hash:
+//   wires of a hash row: 0..11 the state in, 12..23 the state out, 24..59 the S-box inputs of full rounds 1..3 (round 0's
+//   are in + rc_0), 60..81 the S-box input (word 0) of the 22 partial rounds, 82..129 those of full rounds 26..29
+//   G4  90 .. 207  all rows   q_hash (wire - what the round function makes of the previous wires)   118 constraints,  degree 8
+//        90 + 12 (r - 1) + i   s_r[i] - (M (s_(r-1))^7 + rc_r)[i],  r = 1..3          (s_0 = in + rc_0)
+//        126 + (r - 4)         p_r - state[0] through the partial rounds r = 4..25        (state: M applied to (p^7, the other
+//                                                                                        eleven words), + rc_(r+1))
+//        148 + 12 (r - 26) + i s_r[i] - state[i],  r = 26..29;    196 + i   out[i] - (M (s_29)^7)[i]
+// with the permutation's own round constants and MDS matrix (poseidon_rc.inc): hash rows compute hash_no_pad.
+// Rows 4 .. 4 + H - 1 (H = ceil(len / 8) <= 8) absorb the list eight words at a time: the words are free wires 0..7 of
+// their row, the other state words are copies -- of the previous row's output (the sponge's carry: words 8..11, and the
+// words a short last chunk leaves alone), or, in the first row, of ZERO wires: row 1 is an arithmetic row with
+// c0 = c1 = 0, so its twenty d wires are zero.  The first four output words of the last hash row ARE the public-input
+// wires of row 0 (one copy cycle with c_j(12), c_j(13)), which G3 binds to the four words the verifier computed from
+// the list it was given.  Rows 4..11 are the hash region (no-ops beyond H); arithmetic groups start at row 12.
 namespace plonk {
-constexpr uint32_t N_COLS = 135, N_CONST = 84, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 90, N_UNITS = 10;
-constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_SIGMA = 4;
+constexpr uint32_t N_COLS = 135, N_CONST = 85, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 208, N_UNITS = 11;
+constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_HASH = 4, CST_SIGMA = 5;
 constexpr uint32_t COL_SBOX = 80;
-constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86;
-// where wire (col, row) points in the copy permutation (the next position of its cycle), n rows
-GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t& col_out, uint32_t& row_out) {
+constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86, G4 = 90;
+constexpr uint32_t HASH_ROW0 = 4, HASH_ROWS_MAX = 8, ARITH_ROW0 = 12, ZERO_ROW = 1, MAX_PI = 8 * HASH_ROWS_MAX;
+constexpr uint32_t H_IN = 0, H_OUT = 12, H_FULL1 = 24, H_PART = 60, H_FULL2 = 82, H_WIRES = 130;
+GL_HD uint32_t hash_rows(uint32_t pi_len) { return (pi_len + 7) / 8; }
+// is state word k of hash row h (0-based) a carried word -- a copy of the previous row's output (h > 0) or of a zero wire
+// (h = 0) -- rather than a word of the list?
+GL_HD bool hash_word_is_carried(uint32_t pi_len, uint32_t h, uint32_t k) {
+  const uint32_t H = hash_rows(pi_len), last = pi_len - 8 * (H - 1);  // words in the last chunk: 1..8
+  return k >= 8 || (h + 1 == H && k >= last);
+}
+// where wire (col, row) points in the copy permutation (the next position of its cycle), n rows; pi_len: the length of
+// the public-input list the circuit hashes (1 .. MAX_PI)
+GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t pi_len, uint32_t& col_out, uint32_t& row_out) {
   col_out = col; row_out = row;
-  if (col >= N_ROUTED || row < 4) {
-    // the public-input row: w_j(0) -> c_j(4) -> c_j(5) -> w_j(0), j < 4 (needs a second group to exist)
-    if (row == 0 && col < 4 && n >= 8) { col_out = 4 * col + 2; row_out = 4; }
+  if (col >= N_ROUTED) return;
+  const uint32_t H = hash_rows(pi_len), last_hash_row = HASH_ROW0 + H - 1;
+  if (row < ARITH_ROW0) {
+    if (row == 0) {  // the public-input row: w_j(0) -> c_j(12) -> c_j(13) -> out_j(last hash row) -> w_j(0)
+      if (col < 4) { col_out = 4 * col + 2; row_out = ARITH_ROW0; }
+    } else if (row == ZERO_ROW) {  // zero wire z = d_z(1) <-> the z-th carried word of the first hash row
+      if ((col & 3) == 3) {
+        uint32_t z = col >> 2, seen = 0;
+        for (uint32_t k = 0; k < 12; k++)
+          if (hash_word_is_carried(pi_len, 0, k)) {
+            if (seen == z) { col_out = H_IN + k; row_out = HASH_ROW0; }
+            seen++;
+          }
+      }
+    } else if (row >= HASH_ROW0 && row <= last_hash_row) {
+      const uint32_t h = row - HASH_ROW0;
+      if (col < 12) {  // a state word coming in
+        if (hash_word_is_carried(pi_len, h, col)) {
+          if (h == 0) {
+            uint32_t z = 0;
+            for (uint32_t k = 0; k < col; k++) z += hash_word_is_carried(pi_len, 0, k);
+            col_out = 4 * z + 3; row_out = ZERO_ROW;
+          } else {
+            col_out = H_OUT + col; row_out = row - 1;
+          }
+        }
+      } else if (col < 24) {  // a state word going out
+        const uint32_t k = col - H_OUT;
+        if (row == last_hash_row) {
+          if (k < 4) { col_out = k; row_out = 0; }
+        } else if (hash_word_is_carried(pi_len, h + 1, k)) {
+          col_out = H_IN + k; row_out = row + 1;
+        }
+      }
+    }
     return;
   }
   const uint32_t g = row >> 2, p = row & 3, s = col >> 2, w = col & 3;
@@ -897,8 +1013,8 @@ GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t& col_out, u
   } else if (p == 1) {
     if (w == 0) { col_out = 4 * ((s + N_SLOTS - 1) % N_SLOTS) + 1; row_out = base + 1; }  // a_s -> b_(s-1) of the same row
     else if (w == 1) { col_out = 4 * ((s + 1) % N_SLOTS) + 3; row_out = base; }           // b_s(4g+1) -> d_(s+1)(4g)
-    else if (w == 2) {                                                                   // c_s(4g+1) -> c_s(4g), or the public input
-      if (g == 1 && s < 4) { col_out = s; row_out = 0; }
+    else if (w == 2) {                                                                   // c_s(4g+1) -> c_s(4g), or on to the hash output
+      if (base == ARITH_ROW0 && s < 4) { col_out = H_OUT + s; row_out = last_hash_row; }
       else { col_out = col; row_out = base; }
     } else if (s < N_SBOX) { col_out = 4 * s; row_out = base + 2; }             // d_i(4g+1) -> a_i(4g+2)
   } else if (p == 2) {
@@ -925,9 +1041,63 @@ GL_HD uint64_t chunk_shift(uint32_t u) {
 // (Round 4 had ONE gate unit and the copy constraints as a second pass per challenge set: every routed wire was read
 // three times and every sigma twice -- 2.05 x the algorithmic bytes by PMC --, and a lone proof's 2^16 rows were 256
 // workgroups with nothing to spread.)  Every constraint keeps its index, so the quotient is the same polynomial.
+// Unit 10: the Poseidon gate (G4).  The wires of the row are taken at their word: every constraint compares a wire with
+// what the round function makes of the wires before it, so a hash row is a chain of 118 local checks.
+template <class T, class Row, class Emit>
+GL_HD void eval_hash_unit(const Row& row, Emit& out) {
+  typedef Ops<T> F;
+  typedef PoseidonOps<T> H;
+  const T qh = row.cst(CST_HASH);
+  const T q4[4] = {qh, qh, qh, qh};
+  T st[12];
+#pragma unroll
+  for (uint32_t i = 0; i < 12; i++) st[i] = H::add_rc0(row.loc(H_IN + i), i);
+  // a block of twelve wires against the state, selector applied four at a time; the wires become the state
+  auto check12 = [&](uint32_t col0, uint32_t idx0) {
+#pragma unroll
+    for (uint32_t i0 = 0; i0 < 12; i0 += 4) {
+      T d[4], g[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) {
+        const T wv = row.loc(col0 + i0 + i);
+        d[i] = F::sub(wv, st[i0 + i]);
+        st[i0 + i] = wv;
+      }
+      F::mul4(q4, d, g);
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++) out.all(idx0 + i0 + i, g[i]);
+    }
+  };
+#pragma unroll 1
+  for (uint32_t r = 1; r <= 3; r++) {
+    H::sbox_all(st);
+    H::mds_rc(st, (int)r);
+    check12(H_FULL1 + 12 * (r - 1), G4 + 12 * (r - 1));
+  }
+  H::sbox_all(st);
+  H::mds_rc(st, 4);
+#pragma unroll 1
+  for (uint32_t r = 4; r <= 25; r++) {
+    const T pv = row.loc(H_PART + r - 4);
+    out.all(G4 + 36 + (r - 4), F::mul(qh, F::sub(pv, st[0])));
+    st[0] = H::sbox(pv);
+    H::mds_rc(st, (int)r + 1);
+  }
+#pragma unroll 1
+  for (uint32_t r = 26; r <= 29; r++) {
+    check12(H_FULL2 + 12 * (r - 26), G4 + 58 + 12 * (r - 26));
+    H::sbox_all(st);
+    H::mds_rc(st, r < 29 ? (int)r + 1 : -1);
+  }
+  check12(H_OUT, G4 + 106);
+}
 template <class T, class Row, class Emit>
 GL_HD void eval_unit(uint32_t u, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
   typedef Ops<T> F;
+  if (u == 10) {
+    eval_hash_unit<T>(row, out);
+    return;
+  }
   T w[8], sg[8];
 #pragma unroll
   for (uint32_t i = 0; i < 8; i++) w[i] = row.loc(8 * u + i);

@@ -136,11 +136,13 @@ StarkCfg table_cfg_of(const bp_config& c, uint32_t log_n, uint32_t width) {
                   c.stark_pow_bits, c.arity_bits, c.final_poly_bits};
 }
 
-int build_circuit(Worker& w, const StarkCfg& rc, uint64_t seed, Circuit* out) {
+// pi_len: the length of the public-input list the circuit's hash rows absorb (AIR 8): 6 for a table's chain circuits
+// (digest, table, depth), 7 x 4 + 13 for the root circuit, 10 + 13 / 9 + 13 for the aggregation / block circuit
+int build_circuit(Worker& w, const StarkCfg& rc, uint64_t seed, uint32_t pi_len, Circuit* out) {
   const uint64_t N = (uint64_t)1 << rc.log_n;
   out->d_const_values = w.arena.alloc_words((size_t)rc.n_const * N);
   if (!out->d_const_values) return fail(BP_ERR_DEVICE, "state arena exhausted");
-  int rc2 = rc.air_id == air::PLONK ? launch_plonk_constants(out->d_const_values, rc.log_n, seed, w.stream)
+  int rc2 = rc.air_id == air::PLONK ? launch_plonk_constants(out->d_const_values, rc.log_n, seed, pi_len, w.stream)
                                     : launch_synth_constants(out->d_const_values, rc.log_n, rc.n_const, seed, w.stream);
   if (rc2) return rc2;
   if ((rc2 = commit(w, out->d_const_values, rc.n_const, rc.log_n, rc.rate_bits, rc.cap_height, false, &out->consts)))
@@ -202,15 +204,25 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
     Ctl ctl[MAX_BATCH];
     const uint64_t* d_tv[MAX_BATCH];
     const Committed* consts[MAX_BATCH];
+    std::vector<uint64_t> rows;
     for (uint32_t b = 0; b < B; b++) {
       const Circuit& c = *circ[first + b];
+      // the hash of the public-input list, with the witness of the circuit's own computation of it (its hash rows)
       uint64_t pi_hash[4];
-      hash_no_pad_host(pi[first + b].data(), pi[first + b].size(), pi_hash);
+      const size_t n_pi = pi[first + b].size();
+      if (rc.air_id == air::PLONK) {
+        if (n_pi < 1 || n_pi > air::plonk::MAX_PI) return fail(BP_ERR_INVALID_INPUT, "a recursion circuit hashes 1..%u public inputs: got %zu", air::plonk::MAX_PI, n_pi);
+        poseidon_hash_rows(pi[first + b].data(), n_pi, &rows, pi_hash);
+        std::memcpy(w.hash_rows + (size_t)b * HASH_ROWS_WORDS, rows.data(), rows.size() * 8);
+      } else {
+        hash_no_pad_host(pi[first + b].data(), n_pi, pi_hash);
+      }
       ch[b].observe(c.digest, 4);
       ch[b].observe(pi_hash, 4);
       d_tv[b] = d_trace + (size_t)b * rc.n_cols * N;
       sa[b] = SynthTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0]};
-      pa[b] = PlonkTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0], {pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]}};
+      pa[b] = PlonkTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0], {pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]},
+                             w.hash_rows_dev + (size_t)b * HASH_ROWS_WORDS, (uint32_t)((n_pi + 7) / 8)};
       if (rc.air_id == air::PLONK) std::memcpy(ctl[b].pub, pi_hash, sizeof(pi_hash));  // bound to the circuit's first row
       consts[b] = &c.consts;
     }
@@ -309,8 +321,8 @@ void bp_config_default(bp_config* c) {
   for (int t = 0; t < BP_NUM_TABLES; t++) { c->table_log_lo[t] = lo[t]; c->table_log_hi[t] = hi[t]; }
   c->stark_rate_bits = 1; c->stark_cap_height = 4; c->stark_num_queries = 84; c->stark_pow_bits = 16;
   c->arity_bits = 4; c->final_poly_bits = 5;
-  // recursion-shaped proofs: proofs of the PLONK-shaped circuit (AIR 8), 135 wires, 84 preprocessed constant columns
-  c->rec_log_n = 13; c->rec_n_cols = 135; c->rec_n_const = 84; c->rec_rate_bits = 3; c->rec_num_queries = 28;
+  // recursion-shaped proofs: proofs of the PLONK-shaped circuit (AIR 8), 135 wires, 85 preprocessed constant columns
+  c->rec_log_n = 13; c->rec_n_cols = 135; c->rec_n_const = 85; c->rec_rate_bits = 3; c->rec_num_queries = 28;
   c->rec_pow_bits = 16;
   c->shrink_depth = 3;
   c->rec_air_id = 8;
@@ -374,10 +386,11 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     s->table_offset[t] = idx;
     for (uint32_t d = cfg->table_log_lo[t]; d < cfg->table_log_hi[t]; d++, idx++)
-      if ((r = build_circuit(s->builder, rc, circuit_seed(t, d), &s->table_circuits[idx]))) return r;
+      if ((r = build_circuit(s->builder, rc, circuit_seed(t, d), 6, &s->table_circuits[idx]))) return r;
   }
+  static const uint32_t SPECIAL_PI_LEN[3] = {4 * BP_NUM_TABLES + BP_PV_WORDS, 10 + BP_PV_WORDS, 9 + BP_PV_WORDS};  // root, agg, block
   for (uint32_t k = 0; k < 3; k++)
-    if ((r = build_circuit(s->builder, rc, circuit_seed(CIRCUIT_ROOT + k, 0), &s->special[k]))) return r;
+    if ((r = build_circuit(s->builder, rc, circuit_seed(CIRCUIT_ROOT + k, 0), SPECIAL_PI_LEN[k], &s->special[k]))) return r;
   BPG_HIP(hipStreamSynchronize(s->builder.stream));
   for (uint32_t i = 0; i < cfg->n_workers; i++) {
     std::unique_ptr<Worker> w(new Worker());

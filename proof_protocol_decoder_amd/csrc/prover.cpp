@@ -118,6 +118,34 @@ void poseidon_host(uint64_t s[12]) {
 #endif
   poseidon_host_scalar(s);
 }
+// hash_no_pad of a recursion circuit's public-input list together with the WITNESS of its in-circuit computation (AIR
+// 8's Poseidon gate, air.hpp): per absorbed chunk one row of air::plonk::H_WIRES wires -- the state in, the state out and
+// the S-box inputs of every round in between.  rows: ceil(n / 8) x H_WIRES words; digest = the hash (the first four
+// output words of the last row).
+void poseidon_hash_rows(const uint64_t* in, size_t n, std::vector<uint64_t>* rows, uint64_t digest[4]) {
+  namespace pk = air::plonk;
+  const size_t H = (n + 7) / 8;
+  rows->assign(H * pk::H_WIRES, 0);
+  uint64_t s[12] = {0};
+  for (size_t h = 0; h < H; h++) {
+    uint64_t* w = rows->data() + h * pk::H_WIRES;
+    const size_t k = std::min<size_t>(8, n - 8 * h);
+    for (size_t i = 0; i < k; i++) s[i] = gl::canon(in[8 * h + i]);
+    std::memcpy(w + pk::H_IN, s, sizeof(s));
+    for (int rnd = 0; rnd < 30; rnd++) {
+      for (int i = 0; i < 12; i++) s[i] = gl::addc(s[i], RC_HOST[rnd * 12 + i]);   // s = the S-box input of this round
+      const bool full = rnd < 4 || rnd >= 26;
+      if (rnd >= 1 && rnd <= 3) std::memcpy(w + pk::H_FULL1 + 12 * (rnd - 1), s, sizeof(s));
+      else if (rnd >= 4 && rnd <= 25) w[pk::H_PART + rnd - 4] = s[0];
+      else if (rnd >= 26) std::memcpy(w + pk::H_FULL2 + 12 * (rnd - 26), s, sizeof(s));
+      if (full) for (int i = 0; i < 12; i++) s[i] = sbox_host(s[i]);
+      else s[0] = sbox_host(s[0]);
+      mds_host_scalar(s);
+    }
+    std::memcpy(w + pk::H_OUT, s, sizeof(s));
+  }
+  std::memcpy(digest, s, 32);
+}
 void hash_no_pad_host(const uint64_t* in, size_t len, uint64_t out[4]) {
   uint64_t s[12] = {0};
   for (size_t off = 0; off < len; off += 8) {
@@ -241,6 +269,8 @@ int Worker::init(int dev, size_t arena_bytes) {
   pinned_words = (size_t)1 << 22;  // 32 MiB staging
   BPG_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), pinned_words * 8, hipHostMallocDefault));
   BPG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&pinned_dev), pinned, 0));
+  BPG_HIP(hipHostMalloc(reinterpret_cast<void**>(&hash_rows), MAX_BATCH * HASH_ROWS_WORDS * 8, hipHostMallocDefault));
+  BPG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hash_rows_dev), hash_rows, 0));
   BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_pow_result), 8 * MAX_BATCH));
   // many prover threads share few host cores: wait on a blocking event (the thread sleeps) rather
   // than spin in hipStreamSynchronize
@@ -251,6 +281,8 @@ void Worker::destroy() {
   if (stream) (void)hipStreamSynchronize(stream);
   arena.destroy();
   if (pinned) (void)hipHostFree(pinned);
+  if (hash_rows) (void)hipHostFree(hash_rows);
+  hash_rows = hash_rows_dev = nullptr;
   if (d_pow_result) (void)hipFree(d_pow_result);
   if (sync_event) (void)hipEventDestroy(sync_event);
   if (stream) (void)hipStreamDestroy(stream);

@@ -13,6 +13,8 @@ namespace bpg {
 // ---- host Poseidon (transcript only: K7 stays on the host) ----
 void poseidon_host(uint64_t s[12]);
 void hash_no_pad_host(const uint64_t* in, size_t len, uint64_t out[4]);
+// the same hash with the witness of its in-circuit computation: ceil(n / 8) rows of air::plonk::H_WIRES wires (AIR 8)
+void poseidon_hash_rows(const uint64_t* in, size_t n, std::vector<uint64_t>* rows, uint64_t digest[4]);
 
 // plonky2::iop::challenger::Challenger: overwrite-mode duplex sponge, outputs popped from the back.
 class Challenger {
@@ -92,6 +94,8 @@ class DeviceArena {
   size_t cap_ = 0, off_ = 0, high_ = 0;
 };
 
+constexpr size_t HASH_ROWS_WORDS = (size_t)air::plonk::HASH_ROWS_MAX * air::plonk::H_WIRES;  // per proof
+
 struct Committed {
   uint64_t *coeffs = nullptr, *lde = nullptr, *digests = nullptr;
   const uint64_t* values = nullptr;  // the committed values on the trace domain, while the caller keeps them (else null)
@@ -106,6 +110,9 @@ struct Worker {
   uint64_t* pinned = nullptr;      // host staging / mailbox (kernels may write it directly)
   uint64_t* pinned_dev = nullptr;  // the same memory as seen from the device
   size_t pinned_words = 0;
+  // the hash-row witnesses of a batch of recursion-shaped proofs (AIR 8), made on the host, read by the witness kernel:
+  // pinned memory of its own (the mailbox above belongs to the kernels that mirror caps and openings into it)
+  uint64_t *hash_rows = nullptr, *hash_rows_dev = nullptr;
   unsigned long long* d_pow_result = nullptr;  // MAX_BATCH words: one witness per proof of a batch
   hipEvent_t sync_event = nullptr;  // blocking-sync event: waiting threads sleep instead of spinning
   const volatile int32_t* abort_flag = nullptr;

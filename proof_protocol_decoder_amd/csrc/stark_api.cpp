@@ -9,6 +9,17 @@
 using namespace bpg;
 
 namespace {
+constexpr uint32_t LONE_PI_LEN = 4;
+void lone_public_input_list(uint64_t seed, uint64_t out[LONE_PI_LEN]) {
+  for (uint64_t j = 0; j < LONE_PI_LEN; j++) {
+    uint64_t z = (seed ^ ((0x50 + j) << 32)) + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    out[j] = gl::canon(z ^ (z >> 31));
+  }
+}
+}  // namespace
+namespace {
 // One parked worker (stream + arena) per device: a 2^20 x 2432 table needs a ~100 GB arena, and
 // hipFree + hipMalloc of that much costs seconds -- several times the proof itself.  A call takes
 // the parked worker if its arena is large enough (concurrent calls simply make their own), and parks
@@ -120,7 +131,7 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
     if (c.n_const) {
       d_consts = w.arena.alloc_words((size_t)c.n_const * N);
       if (!d_consts) return fail(BP_ERR_DEVICE, "arena exhausted");
-      int r2 = c.air_id == air::PLONK ? launch_plonk_constants(d_consts, c.log_n, const_seed, w.stream)
+      int r2 = c.air_id == air::PLONK ? launch_plonk_constants(d_consts, c.log_n, const_seed, LONE_PI_LEN, w.stream)
                                       : launch_synth_constants(d_consts, c.log_n, c.n_const, const_seed, w.stream);
       if (r2) return r2;
       if ((r2 = commit(w, d_consts, c.n_const, c.log_n, c.rate_bits, c.cap_height, false, &consts))) return r2;
@@ -138,10 +149,13 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
              : c.air_id == air::PLONK ? BP_OK
                                        : launch_synth_trace(d_trace, d_consts, c.log_n, c.n_cols, c.n_const, c.deg_pow, seed, w.stream);
     Ctl ctl;
-    if (c.air_id == air::PLONK) {  // the public inputs of a lone table proof follow from the seed (bp_stark_public_inputs)
-      PlonkTraceArgs pa{d_trace, d_consts, seed, {0, 0, 0, 0}};
-      bp_stark_public_inputs(seed, ctl.pub);
-      std::memcpy(pa.pub, ctl.pub, sizeof(pa.pub));
+    if (c.air_id == air::PLONK) {  // the public-input list of a lone table proof follows from the seed (lone_public_input_list)
+      uint64_t pi[LONE_PI_LEN];
+      lone_public_input_list(seed, pi);
+      std::vector<uint64_t> rows;
+      poseidon_hash_rows(pi, LONE_PI_LEN, &rows, ctl.pub);   // the circuit hashes the list in its hash rows: pub = that hash
+      std::memcpy(w.hash_rows, rows.data(), rows.size() * 8);
+      PlonkTraceArgs pa{d_trace, d_consts, seed, {ctl.pub[0], ctl.pub[1], ctl.pub[2], ctl.pub[3]}, w.hash_rows_dev, 1};
       r2 = launch_plonk_trace(&pa, 1, c.log_n, w.stream);
     }
     if (r2) return r2;
@@ -171,15 +185,14 @@ int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t co
 
 // The CPU verifier for one table proof of bp_stark_prove_air (same transcript prologue: constants cap if any, trace
 // cap, four CTL challenges).  Host only: runs without a GPU.
-// The four public inputs of a lone AIR-8 table proof made from `seed` (in a transaction they are the hash of the proof's
-// public-input list): splitmix64(seed ^ ((0x50 + j) << 32)) reduced mod p.
+// A lone AIR-8 table proof made from `seed` has the public-input LIST splitmix64(seed ^ ((0x50 + j) << 32)) mod p, j < 4
+// (in a transaction the list is child digests and public values); the four public inputs bound to its first row are the
+// hash of that list, which the circuit computes in its hash rows and the verifier computes for itself.
+void bp_stark_public_input_list(uint64_t seed, uint64_t out[4]) { lone_public_input_list(seed, out); }
 void bp_stark_public_inputs(uint64_t seed, uint64_t out[4]) {
-  for (uint64_t j = 0; j < 4; j++) {
-    uint64_t z = (seed ^ ((0x50 + j) << 32)) + 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    out[j] = gl::canon(z ^ (z >> 31));
-  }
+  uint64_t pi[LONE_PI_LEN];
+  lone_public_input_list(seed, pi);
+  hash_no_pad_host(pi, LONE_PI_LEN, out);
 }
 
 int bp_stark_verify_air(uint32_t air_id, const bp_stark_cfg* cfg, const uint64_t* const_cap, const uint8_t* proof,
@@ -263,7 +276,7 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
     fam(sp::K10, 1, 1, 2);
   } else if (air_id == air::PLONK) {
     namespace pk = air::plonk;
-    fam(pk::G0, 20, 0, 4); fam(pk::G1, 44, 0, 3); fam(pk::G2, 22, 0, 2); fam(pk::G3, 4, 2, 1);
+    fam(pk::G0, 20, 0, 4); fam(pk::G1, 44, 0, 3); fam(pk::G2, 22, 0, 2); fam(pk::G3, 4, 2, 1); fam(pk::G4, 118, 0, 8);
   } else if (air_id == air::ARITHMETIC_MUL) {
     namespace am = air::arithmetic_mul;
     fam(am::U0, 1, 0, 2); fam(am::U1, 256, 0, 2); fam(am::U2, 256, 0, 2); fam(am::U3, 672, 0, 2); fam(am::U4, 32, 0, 3);
@@ -345,23 +358,36 @@ int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t lo
 }
 BPG_ABI_CATCH("bp_arithmetic_mul_trace")
 
-// AIR 8: the preprocessed constants of the fixed PLONK-shaped circuit (84 columns: selectors, gate constants drawn from
-// `seed`, sigmas) and its witness (135 wires; free wires drawn from `seed`, public inputs pub[4] in row 0).
-int bp_plonk_constants(uint64_t seed, uint32_t log_n, uint64_t* d_consts_out, void* stream) try {
+// AIR 8: the preprocessed constants of the fixed PLONK-shaped circuit (85 columns: selectors, gate constants drawn from
+// `seed`, the hash-row selector, sigmas) for a circuit that hashes a public-input list of pi_len words, and its witness
+// (135 wires; free wires drawn from `seed`; the list pi is hashed in the hash rows, the hash lands in row 0).
+int bp_plonk_constants(uint64_t seed, uint32_t log_n, uint32_t pi_len, uint64_t* d_consts_out, void* stream) try {
   if (!d_consts_out) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_constants: null output");
   if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_constants: log_n out of range");
   int rc = init_ntt_kernels();
   if (rc) return rc;
-  return launch_plonk_constants(d_consts_out, log_n, seed, as_stream(stream));
+  return launch_plonk_constants(d_consts_out, log_n, seed, pi_len, as_stream(stream));
 }
 BPG_ABI_CATCH("bp_plonk_constants")
-int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t pub[4], uint32_t log_n, uint64_t* d_trace_out,
-                   void* stream) try {
-  if (!d_consts || !pub || !d_trace_out) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: null argument");
+int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t* pi, uint32_t pi_len, uint32_t log_n,
+                   uint64_t* d_trace_out, void* stream) try {
+  if (!d_consts || !pi || !d_trace_out) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: null argument");
   if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: log_n out of range");
-  PlonkTraceArgs a{d_trace_out, d_consts, seed, {pub[0], pub[1], pub[2], pub[3]}};
-  for (int j = 0; j < 4; j++) if (pub[j] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: non-canonical public input");
-  return launch_plonk_trace(&a, 1, log_n, as_stream(stream));
+  if (pi_len < 1 || pi_len > air::plonk::MAX_PI) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: 1..%u public inputs", air::plonk::MAX_PI);
+  for (uint32_t j = 0; j < pi_len; j++) if (pi[j] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: non-canonical public input");
+  std::vector<uint64_t> rows;
+  uint64_t pub[4];
+  poseidon_hash_rows(pi, pi_len, &rows, pub);
+  // (a test / integration entry: the hash rows go up with a blocking copy into a buffer of their own)
+  uint64_t* d_rows = nullptr;
+  BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_rows), rows.size() * 8));
+  struct Free { uint64_t* p; ~Free() { (void)hipFree(p); } } guard{d_rows};
+  BPG_HIP(hipMemcpy(d_rows, rows.data(), rows.size() * 8, hipMemcpyHostToDevice));
+  PlonkTraceArgs a{d_trace_out, d_consts, seed, {pub[0], pub[1], pub[2], pub[3]}, d_rows, (uint32_t)(rows.size() / air::plonk::H_WIRES)};
+  int rc = launch_plonk_trace(&a, 1, log_n, as_stream(stream));
+  if (rc) return rc;
+  BPG_HIP(hipStreamSynchronize(as_stream(stream)));
+  return BP_OK;
 }
 BPG_ABI_CATCH("bp_plonk_trace")
 

@@ -574,20 +574,22 @@ memory_lookup_filter_kernel(uint64_t* __restrict__ trace, uint32_t log_n, const 
 
 // ---------------------------------------------------------------- AIR 8 (plonk, air.hpp): constants, witness, copy products
 // The preprocessed columns of the fixed circuit: selectors by the row's place in its group of four, gate constants
-// drawn from the circuit's seed, and the sigmas sigma_j(w^i) = k_j' w^i' by air::plonk::sigma_of.  grid = (rows/256, 84).
+// drawn from the circuit's seed, the hash-row selector, and the sigmas sigma_j(w^i) = k_j' w^i' by air::plonk::sigma_of
+// for a circuit that hashes a public-input list of pi_len words.  grid = (rows/256, 85).
 __global__ void __launch_bounds__(256)
-plonk_constants_kernel(uint64_t* __restrict__ out, uint32_t log_n, uint64_t seed, const uint64_t* __restrict__ tw_n) {
+plonk_constants_kernel(uint64_t* __restrict__ out, uint32_t log_n, uint64_t seed, const uint64_t* __restrict__ tw_n, uint32_t pi_len) {
   namespace pk = bpg::air::plonk;
   const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
   if (i >= n) return;
   const uint32_t p = i & 3;
   uint64_t v;
-  if (k == pk::CST_ARITH) v = i >= 4 && p != 2;
-  else if (k == pk::CST_SBOX) v = i >= 4 && p == 2;
-  else if (k < pk::CST_SIGMA) v = rnd(seed ^ 0xC0115700C0115700ULL, k, i);
+  if (k == pk::CST_ARITH) v = (i >= pk::ARITH_ROW0 && p != 2) || i == pk::ZERO_ROW;   // row 1: the gate that makes the zero wires
+  else if (k == pk::CST_SBOX) v = i >= pk::ARITH_ROW0 && p == 2;
+  else if (k == pk::CST_HASH) v = i >= pk::HASH_ROW0 && i < pk::HASH_ROW0 + pk::hash_rows(pi_len);
+  else if (k < pk::CST_SIGMA) v = i == pk::ZERO_ROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, k, i);
   else {
     uint32_t c2, r2;
-    pk::sigma_of(k - pk::CST_SIGMA, i, n, c2, r2);
+    pk::sigma_of(k - pk::CST_SIGMA, i, n, pi_len, c2, r2);
     v = gl::mulc(gl::pow((uint64_t)7, c2), root_pow(tw_n, log_n, r2));
   }
   out[(uint64_t)k * n + i] = v;
@@ -613,9 +615,9 @@ plonk_trace_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
   const uint32_t u = pk::COL_SBOX + 5 * s;  // the slot's S-box unit (slots 0..10)
 #define PUT(col, row, v) t[(uint64_t)(col) * n + (row)] = (v)
 #define CST(k, row) cs[(uint64_t)(k) * n + (row)]
-  if (g == 0) {  // the public-input row and three no-op rows: every wire free
+  if (g == 0) {  // the public-input row, the zero row (its d wires are 0: an arithmetic gate with c0 = c1 = 0) and two no-op rows
     for (uint32_t r = 0; r < 4; r++) {
-      for (uint32_t w = 0; w < 4; w++) PUT(4 * s + w, r, rnd(seed, 4 * s + w, r));
+      for (uint32_t w = 0; w < 4; w++) PUT(4 * s + w, r, r == pk::ZERO_ROW && w == 3 ? 0 : rnd(seed, 4 * s + w, r));
       if (unit)
         for (uint32_t w = 0; w < 5; w++) PUT(u + w, r, rnd(seed, u + w, r));
     }
@@ -623,6 +625,8 @@ plonk_trace_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
       for (uint32_t j = 0; j < 4; j++) PUT(j, 0, batch.a[blockIdx.z].pub[j]);
     return;
   }
+  if (r0 < pk::ARITH_ROW0) return;  // rows 4..11: the hash region, written by plonk_hash_rows_kernel
+  const bool first_group = r0 == pk::ARITH_ROW0;  // its c inputs are the public inputs
   if (unit)  // the advice wires of the three arithmetic rows are free
     for (uint32_t p = 0; p < 4; p++)
       if (p != 2)
@@ -630,9 +634,9 @@ plonk_trace_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
   // row 4g: inputs free (c_j of the first computing row = public input j)
   const uint64_t c0 = CST(pk::CST_C0, r0), c1 = CST(pk::CST_C1, r0);
   const uint64_t av = rnd(seed, 4 * s, r0), bv = rnd(seed, 4 * s + 1, r0);
-  const uint64_t cv = g == 1 && s < 4 ? pub_s : rnd(seed, 4 * s + 2, r0);
+  const uint64_t cv = first_group && s < 4 ? pub_s : rnd(seed, 4 * s + 2, r0);
   const uint64_t d0 = gl::addc(gl::mulc(c0, gl::mulc(av, bv)), gl::mulc(c1, cv));
-  const uint64_t cn = g == 1 && sn < 4 ? pub_n : rnd(seed, 4 * sn + 2, r0);
+  const uint64_t cn = first_group && sn < 4 ? pub_n : rnd(seed, 4 * sn + 2, r0);
   const uint64_t d0n = gl::addc(gl::mulc(c0, gl::mulc(rnd(seed, 4 * sn, r0), rnd(seed, 4 * sn + 1, r0))), gl::mulc(c1, cn));
   PUT(4 * s, r0, av); PUT(4 * s + 1, r0, bv); PUT(4 * s + 2, r0, cv); PUT(4 * s + 3, r0, d0);
   // row 4g + 1: a_s = d_s, b_s = d_(s+1), c_s = c_s of the row above
@@ -655,6 +659,20 @@ plonk_trace_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
   PUT(4 * s, r0 + 3, a3); PUT(4 * s + 1, r0 + 3, b3); PUT(4 * s + 2, r0 + 3, c3); PUT(4 * s + 3, r0 + 3, d3);
 #undef PUT
 #undef CST
+}
+// The hash region (rows 4..11) of the witness: row 4 + h, h < n_hash_rows, takes its first H_WIRES wires from the rows the
+// host made while it hashed the public-input list (bpg::poseidon_hash_rows: the list is a few dozen words and the host
+// has just hashed it anyway -- one lane chaining six permutations would cost 0.3 ms of a proof's critical path,
+// profiles/r5_transcript_latency.txt); every other wire of the region is free.  grid = (1, 8 rows, proofs) x 135 lanes.
+__global__ void __launch_bounds__(256)
+plonk_hash_rows_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
+  namespace pk = bpg::air::plonk;
+  __builtin_amdgcn_s_setprio(3);
+  const bpg::PlonkTraceArgs& a = batch.a[blockIdx.z];
+  const uint32_t n = 1u << log_n, c = threadIdx.x, h = blockIdx.y, row = pk::HASH_ROW0 + h;
+  if (c >= pk::N_COLS || row >= n) return;
+  const bool given = h < a.n_hash_rows && c < pk::H_WIRES;
+  a.trace[(uint64_t)c * n + row] = given ? a.hash_rows[(uint64_t)h * pk::H_WIRES + c] : rnd(a.seed, c, row);
 }
 // Copy products, step 1 of 3: per row and challenge set the ten chunk ratios num_k / den_k (one inversion per row:
 // the denominators are inverted together) as cumulative products P_k = prod_{k' <= k} num / den: P_1..P_9 into the
@@ -1450,16 +1468,24 @@ int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uin
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, hipStream_t st) {
+int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, uint32_t pi_len, hipStream_t st) {
+  if (pi_len < 1 || pi_len > air::plonk::MAX_PI)
+    return fail(BP_ERR_INVALID_INPUT, "a recursion circuit hashes a public-input list of 1..%u words: got %u", air::plonk::MAX_PI, pi_len);
+  if (log_n < 4) return fail(BP_ERR_INVALID_INPUT, "the plonk circuit needs 16 rows: the hash region and one arithmetic group");
   const uint64_t* tw_n = nullptr;
   if (int rc = get_table(0, log_n, 0, &tw_n)) return rc;
-  plonk_constants_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), air::plonk::N_CONST), 256, 0, st>>>(d_out, log_n, seed, tw_n);
+  plonk_constants_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), air::plonk::N_CONST), 256, 0, st>>>(d_out, log_n, seed, tw_n, pi_len);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
 int launch_plonk_trace(const PlonkTraceArgs* a, uint32_t batch, uint32_t log_n, hipStream_t st) {
   if (int rc = check_batch(batch)) return rc;
+  for (uint32_t b = 0; b < batch; b++)
+    if (!a[b].hash_rows || a[b].n_hash_rows < 1 || a[b].n_hash_rows > air::plonk::HASH_ROWS_MAX)
+      return fail(BP_ERR_INVALID_INPUT, "launch_plonk_trace: the witness of the hash rows is missing (poseidon_hash_rows)");
   plonk_trace_kernel<<<dim3(ceil_div((((uint64_t)1 << log_n) / 4) * air::plonk::N_SLOTS, 256), 1, batch), 256, 0, st>>>(batch_of(a, batch), log_n);
+  BPG_LAUNCH_CHECK();
+  plonk_hash_rows_kernel<<<dim3(1, air::plonk::HASH_ROWS_MAX, batch), 256, 0, st>>>(batch_of(a, batch), log_n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }

@@ -12,5 +12,5 @@ IR_MAGIC = 0x52494E5854475042
 def ir_words(block_number, txn_before, seed, root_before=(1, 2, 3, 4), gas=(100, 121), log_n=LOG_N, width=WIDTH):
     return [IR_MAGIC, 1, block_number, txn_before, gas[0], gas[1], *root_before, seed, *log_n, *width]
 
-# the same with the recursion-shaped proofs made on the PLONK-shaped circuit (AIR 8: 135 wires, 84 preprocessed constants)
-SMALL_PLONK = dict(SMALL, rec_n_cols=135, rec_n_const=84, rec_air_id=8)
+# the same with the recursion-shaped proofs made on the PLONK-shaped circuit (AIR 8: 135 wires, 85 preprocessed constants)
+SMALL_PLONK = dict(SMALL, rec_n_cols=135, rec_n_const=85, rec_air_id=8)

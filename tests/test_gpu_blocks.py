@@ -24,7 +24,7 @@ S1_LOG_N = (16, 9, 12, 14, 9, 12, 17)
 S1_WIDTH = (128, 128, 192, 2432, 512, 320, 16)
 DEFAULT_ORACLE_CFG = dict(table_log_lo=list(S1_LOG_N), table_log_hi=[x + 1 for x in S1_LOG_N], stark_rate_bits=1,
                           stark_cap_height=4, stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5,
-                          rec_log_n=13, rec_n_cols=135, rec_n_const=84, rec_rate_bits=3, rec_num_queries=28,
+                          rec_log_n=13, rec_n_cols=135, rec_n_const=85, rec_rate_bits=3, rec_num_queries=28,
                           rec_pow_bits=16, shrink_depth=3, rec_air_id=8)
 
 

@@ -720,7 +720,7 @@ def test_block16_at_default_config_matches_golden(bpg, pg, oracle):
         pg.VerifierState.from_prover_state(st).verify(blk)
         ost = oracle.PgState(table_log_lo=list(S1_LOG_N), table_log_hi=[x + 1 for x in S1_LOG_N], stark_rate_bits=1,
                              stark_cap_height=4, stark_num_queries=84, stark_pow_bits=16, arity_bits=4, final_poly_bits=5,
-                             rec_log_n=13, rec_n_cols=135, rec_n_const=84, rec_rate_bits=3, rec_num_queries=28,
+                             rec_log_n=13, rec_n_cols=135, rec_n_const=85, rec_rate_bits=3, rec_num_queries=28,
                              rec_pow_bits=16, shrink_depth=3, rec_air_id=8)
         assert ost.verify(words(blk.intern)) == 0
         assert ost.verify(words(txns[7].intern)) == 0

@@ -28,12 +28,12 @@ CASES = [  # name, air_id, columns, log_n (the S1 height of the table), in the c
     ("plonk (AIR 8), one recursion-shaped proof", 8, 135, 13, True),
     ("synthetic 135 x 82 at the recursion shape", 0, 135, 13, False),
 ]
-REC = dict(n_const=82, deg_pow=3, rate_bits=3)   # the recursion shape: rate 8; AIR 8 has 84 constant columns
+REC = dict(n_const=82, deg_pow=3, rate_bits=3)   # the recursion shape: rate 8; AIR 8 has 85 constant columns
 g = torch.Generator(device="cuda").manual_seed(1)
 for name, air, C_, log_n, in_counters in CASES:
     if COUNTERS and not in_counters:
         continue
-    rec = dict(REC, n_const=84 if air == 8 else 82) if log_n == 13 and C_ == 135 else None
+    rec = dict(REC, n_const=85 if air == 8 else 82) if log_n == 13 and C_ == 135 else None
     rows = (1 << log_n) << (3 if rec else 1)
     d = (bpg.ops.air_describe(air, n_cols=C_, **({k: rec[k] for k in ("n_const", "deg_pow")} if rec else {})) if air == 0
          else bpg.ops.air_describe(air))

@@ -22,7 +22,8 @@ def rows(dirs):
             yield from csv.DictReader(open(f))
 
 
-K5 = os.environ.get("K5_PREFIX", "r4")   # r5: tools/prof_round5_k5.sh
+K5 = os.environ.get("K5_PREFIX", os.environ.get("PROF_ROUND", "r4"))   # r5: tools/prof_round5_k5.sh
+RND = os.environ.get("PROF_ROUND", "r4")   # the prefix of every other pass (tools/prof_round.sh)
 
 
 def k5_summary():
@@ -68,11 +69,11 @@ def family(k):
 
 def loaded_summary():
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in rows(("r4_sq_loaded1", "r4_sq_loaded2")):
+    for r in rows((RND + "_sq_loaded1", RND + "_sq_loaded2")):
         acc[family(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
     if not acc:
         return
-    with open(os.path.join(O, "r4_sq_loaded_by_kernel.txt"), "w") as out:
+    with open(os.path.join(O, RND + "_sq_loaded_by_kernel.txt"), "w") as out:
         out.write("# HEAD %s.  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES (pass 1), "
                   "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES (pass 2) -- python bench.py --txns 64 --steps 1 --warmup 0 "
                   "--no-cpu-baseline --no-profile   (64 txns on 16 prover streams: the loaded chip; counters are summed over the "
@@ -85,12 +86,12 @@ def loaded_summary():
                 v.get("SQ_WAVES", 0), v.get("SQ_ACTIVE_INST_VALU", 0), v.get("SQ_BUSY_CYCLES", 0)))
         out.write("total VALU wave-instructions %.5e for 64 txn proofs + 63 aggregations + 1 block proof + bp_state_build\n" % tot)
         out.write("total MFMA %.5e\n" % sum(v.get("SQ_INSTS_MFMA", 0) for v in acc.values()))
-    print(open(os.path.join(O, "r4_sq_loaded_by_kernel.txt")).read())
+    print(open(os.path.join(O, RND + "_sq_loaded_by_kernel.txt")).read())
 
 
 def hash_summary():
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in rows(("r4_hash_sq1", "r4_hash_sq2")):
+    for r in rows((RND + "_hash_sq1", RND + "_hash_sq2")):
         k = r["Kernel_Name"]
         if "leaf_hash" in k:
             m = re.search(r"leaf_hash_mx_kernel<(\d+), (\d+)>", k) or re.search(r"leaf_hash_mx_kernelILi(\d+)ELi(\d+)E", k)
@@ -99,14 +100,14 @@ def hash_summary():
             acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
     if not acc:
         return
-    with open(os.path.join(O, "r4_hash_sq_counters.txt"), "w") as out:
+    with open(os.path.join(O, RND + "_hash_sq_counters.txt"), "w") as out:
         out.write("# HEAD %s.  rocprofv3 --kernel-trace --pmc <SQ counters, two passes> -- python tools/pmc_probe_hash.py: leaf hashing "
                   "of 2^21 rows x 8 permutations = 16777216 permutations per kernel form\n" % HEAD)
         for k, v in acc.items():
             out.write(k + "\n")
             for n, x in sorted(v.items()):
                 out.write("    %-28s %.4e\n" % (n, x))
-    print(open(os.path.join(O, "r4_hash_sq_counters.txt")).read())
+    print(open(os.path.join(O, RND + "_hash_sq_counters.txt")).read())
 
 
 def leg_trace_summary():
@@ -114,7 +115,7 @@ def leg_trace_summary():
     trace of `bench.py --leg-only --leg-skip-extras` restricted to the dispatches between the leg's two marker copies
     (the whole-process stats beside it also hold the state build and the warm-up transaction) -- and, last line, the
     coset-LDE family bench.py's `roofline` is quoted on."""
-    files = glob.glob(os.path.join(O, "r4_leg", "**", "*kernel_trace.csv"), recursive=True)
+    files = glob.glob(os.path.join(O, RND + "_leg", "**", "*kernel_trace.csv"), recursive=True)
     if not files:
         return
     trace = list(csv.DictReader(open(files[0])))
@@ -131,7 +132,7 @@ def leg_trace_summary():
     fam = ("ntt16_dit_kernel", "ntt_mx_dit_kernel", "ntt_lds_kernel<false>")
     fn = sum(v[0] for k, v in acc.items() if any(f in k for f in fam))
     ft = sum(v[1] for k, v in acc.items() if any(f in k for f in fam))
-    with open(os.path.join(O, "r4_kernel_stats_leg_between_markers.csv"), "w") as out:
+    with open(os.path.join(O, RND + "_kernel_stats_leg_between_markers.csv"), "w") as out:
         out.write("# HEAD %s.  rocprofv3 --kernel-trace -- python bench.py --leg-only --leg-skip-extras, dispatches between the leg's marker copies only (2 txn proofs, one prover stream)\n" % HEAD)
         out.write("Name,Calls,TotalDurationNs,AverageNs\n")
         for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):

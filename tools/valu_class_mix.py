@@ -52,7 +52,8 @@ def kernel_bodies(src, tmp):
 
 def main():
     shares = {}
-    txt = open(os.path.join(ROOT, "profiles", "r4_sq_loaded_by_kernel.txt")).read()
+    sq = next(f for f in ("r5_sq_loaded_by_kernel.txt", "r4_sq_loaded_by_kernel.txt") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+    txt = open(os.path.join(ROOT, "profiles", sq)).read()
     for m in re.finditer(r"^(\S*)\s+VALU ([0-9.e+]+)", txt, re.M):
         shares[m.group(1)] = float(m.group(2))
     total = sum(shares.values())
