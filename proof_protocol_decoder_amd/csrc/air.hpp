@@ -148,6 +148,7 @@ struct PoseidonOps {
     }
     for (uint32_t r = 0; r < 12; r++) s[r] = o[r];
   }
+  static GL_HD void mds_rc_word0(T (&s)[12], int next) { mds_rc(s, next); }  // (the device form: only s[0] canonical after it)
   static GL_HD T add_rc0(T x, uint32_t i) { return F::add(x, F::k(poseidon_rc(i))); }
 };
 #if defined(__HIP__)
@@ -160,6 +161,11 @@ struct PoseidonOps<uint64_t> {  // canonical words in, canonical words out (Ops<
     else poseidon::mds<false>(s, nullptr);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+  }
+  // partial rounds: only word 0 meets a wire before the next layer, and the layer takes any u64
+  static __device__ __forceinline__ void mds_rc_word0(uint64_t (&s)[12], int next) {
+    poseidon::mds<true>(s, poseidon::RC + 12 * next);
+    s[0] = gl::canon(s[0]);
   }
   static __device__ __forceinline__ uint64_t add_rc0(uint64_t x, uint32_t i) { return gl::addc(x, poseidon::RC[i]); }
 };
@@ -1043,8 +1049,10 @@ GL_HD uint64_t chunk_shift(uint32_t u) {
 // workgroups with nothing to spread.)  Every constraint keeps its index, so the quotient is the same polynomial.
 // Unit 10: the Poseidon gate (G4).  The wires of the row are taken at their word: every constraint compares a wire with
 // what the round function makes of the wires before it, so a hash row is a chain of 118 local checks.
-template <class T, class Row, class Emit>
+template <class T, class Row, class Emit, bool SELECTOR = true>
 GL_HD void eval_hash_unit(const Row& row, Emit& out) {
+  // SELECTOR = false: the differences go out bare and the caller multiplies the folded sum by q_hash once
+  // (sum_i alpha^e_i q d_i = q sum_i alpha^e_i d_i: the device's hash pass, which folds nothing else)
   typedef Ops<T> F;
   typedef PoseidonOps<T> H;
   const T qh = row.cst(CST_HASH);
@@ -1063,9 +1071,9 @@ GL_HD void eval_hash_unit(const Row& row, Emit& out) {
         d[i] = F::sub(wv, st[i0 + i]);
         st[i0 + i] = wv;
       }
-      F::mul4(q4, d, g);
+      if (SELECTOR) F::mul4(q4, d, g);
 #pragma unroll
-      for (uint32_t i = 0; i < 4; i++) out.all(idx0 + i0 + i, g[i]);
+      for (uint32_t i = 0; i < 4; i++) out.all(idx0 + i0 + i, SELECTOR ? g[i] : d[i]);
     }
   };
 #pragma unroll 1
@@ -1075,13 +1083,15 @@ GL_HD void eval_hash_unit(const Row& row, Emit& out) {
     check12(H_FULL1 + 12 * (r - 1), G4 + 12 * (r - 1));
   }
   H::sbox_all(st);
-  H::mds_rc(st, 4);
+  H::mds_rc_word0(st, 4);
 #pragma unroll 1
   for (uint32_t r = 4; r <= 25; r++) {
     const T pv = row.loc(H_PART + r - 4);
-    out.all(G4 + 36 + (r - 4), F::mul(qh, F::sub(pv, st[0])));
+    const T d = F::sub(pv, st[0]);
+    out.all(G4 + 36 + (r - 4), SELECTOR ? F::mul(qh, d) : d);
     st[0] = H::sbox(pv);
-    H::mds_rc(st, (int)r + 1);
+    if (r < 25) H::mds_rc_word0(st, (int)r + 1);
+    else H::mds_rc(st, (int)r + 1);
   }
 #pragma unroll 1
   for (uint32_t r = 26; r <= 29; r++) {
@@ -1091,13 +1101,10 @@ GL_HD void eval_hash_unit(const Row& row, Emit& out) {
   }
   check12(H_OUT, G4 + 106);
 }
+// Units 0 .. 9: the gates of slots 2u, 2u + 1, the copy constraints of chunk u + 1, the S-box units and the public row.
 template <class T, class Row, class Emit>
-GL_HD void eval_unit(uint32_t u, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
+GL_HD void eval_chunk_unit(uint32_t u, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
   typedef Ops<T> F;
-  if (u == 10) {
-    eval_hash_unit<T>(row, out);
-    return;
-  }
   T w[8], sg[8];
 #pragma unroll
   for (uint32_t i = 0; i < 8; i++) w[i] = row.loc(8 * u + i);
@@ -1204,6 +1211,11 @@ GL_HD void eval_unit(uint32_t u, uint32_t ctl_base, const uint64_t ctl[4], const
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) out.first(G3 + j, F::sub(w[j], F::k(row.pub(j))));
   }
+}
+template <class T, class Row, class Emit>
+GL_HD void eval_unit(uint32_t u, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
+  if (u == 10) eval_hash_unit<T>(row, out);
+  else eval_chunk_unit<T>(u, ctl_base, ctl, row, out);
 }
 }  // namespace plonk
 

@@ -436,7 +436,8 @@ int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t
   // table's many product columns are sliced into units; a real table's few lookup columns are one unit.
   qa.n_air_constraints = air::n_constraints(shape);
   qa.n_constraints = qa.n_air_constraints + air::ctl::n_constraints(shape);
-  qa.n_air_units = air::n_units(shape);
+  qa.side_rows = cfg.air_id == air::PLONK ? 1 : 0;
+  qa.n_air_units = air::n_units(shape) - qa.side_rows;
   qa.aux_per_unit = cfg.air_id == air::SYNTHETIC ? std::max<uint32_t>(16, (A + 15) / 16) : A;
   // (AIR 8's copy constraints ride in its own ten units, next to the gates that read the same wires: no lookup unit)
   qa.n_ctl_units = cfg.air_id == air::PLONK ? 0 : (A + qa.aux_per_unit - 1) / qa.aux_per_unit;
@@ -466,7 +467,7 @@ int quotient_args(const StarkCfg& cfg, const Ctl& ctl, uint64_t alpha0, uint64_t
   return BP_OK;
 }
 size_t quotient_partial_words(const QuotArgs& qa) {
-  const uint32_t n_units = qa.n_air_units + qa.n_ctl_units, wg_rows = (n_units + qa.units_per_wg - 1) / qa.units_per_wg;
+  const uint32_t n_units = qa.n_air_units + qa.n_ctl_units, wg_rows = (n_units + qa.units_per_wg - 1) / qa.units_per_wg + qa.side_rows;
   return wg_rows > 1 ? (size_t)wg_rows * 2 * (((size_t)1 << qa.log_n) << qa.rate_bits) : 0;
 }
 

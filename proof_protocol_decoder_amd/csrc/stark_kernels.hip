@@ -810,6 +810,9 @@ struct DevEmit {  // the constraint consumer: two constraints (x two challenges)
 // "AIR units, then CTL units".
 // The Keccak-f evaluator wants 193 VGPRs (two waves per SIMD); held to 168 (three waves, 26 registers in scratch) it is
 // 10 % faster alone on the chip (700 -> 628 us at 2^14 rows; four waves at 128 VGPRs: 795 us).
+#ifndef BPG_PLONK_HASH_WAVES
+#define BPG_PLONK_HASH_WAVES 2
+#endif
 template <uint32_t AIR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AIR == bpg::air::KECCAK_F ? 3 : 1)))
 quotient_air_kernel(bpg::BatchOf<bpg::QuotArgs> batch) {
@@ -837,7 +840,7 @@ quotient_air_kernel(bpg::BatchOf<bpg::QuotArgs> batch) {
       else if constexpr (AIR == bpg::air::BYTE_PACKING) bpg::air::byte_packing::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::KECCAK_SPONGE) bpg::air::keccak_sponge::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::ARITHMETIC_MUL) bpg::air::arithmetic_mul::eval_unit<uint64_t>(u, row, out);
-      else if constexpr (AIR == bpg::air::PLONK) bpg::air::plonk::eval_unit<uint64_t>(u, q.n_air_constraints, q.ctl.v, row, out);
+      else if constexpr (AIR == bpg::air::PLONK) bpg::air::plonk::eval_chunk_unit<uint64_t>(u, q.n_air_constraints, q.ctl.v, row, out);  // (unit 10: quotient_plonk_hash_kernel)
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
     } else {
       const uint32_t k0 = (u - q.n_air_units) * q.aux_per_unit, k1 = min(k0 + q.aux_per_unit, q.n_aux);
@@ -846,7 +849,7 @@ quotient_air_kernel(bpg::BatchOf<bpg::QuotArgs> batch) {
     }
   }
   const uint64_t r0 = out.result(0), r1 = out.result(1);
-  if (gridDim.y == 1) {
+  if (gridDim.y == 1 && q.side_rows == 0) {
     const uint64_t zh_inv = q.apow[2 * (size_t)q.n_constraints + 32 + t];
     q.qvals[pos] = gl::mulc(r0, zh_inv);
     q.qvals[rows + pos] = gl::mulc(r1, zh_inv);
@@ -854,6 +857,28 @@ quotient_air_kernel(bpg::BatchOf<bpg::QuotArgs> batch) {
     q.partial[((uint64_t)blockIdx.y * 2) * rows + pos] = r0;
     q.partial[((uint64_t)blockIdx.y * 2 + 1) * rows + pos] = r1;
   }
+}
+// AIR 8's Poseidon gate: 118 local checks of one permutation's wires per row, folded bare and multiplied by the
+// selector once; its sums are row `wg_row` of `partial`.  About ten times the instructions of a chunk unit and another
+// register budget (the twelve-word state and the layer's accumulators), hence its own kernel: the chunk units keep three
+// waves per SIMD.   grid = (rows / 256, 1, batch)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BPG_PLONK_HASH_WAVES)))
+quotient_plonk_hash_kernel(bpg::BatchOf<bpg::QuotArgs> batch, uint32_t wg_row) {
+  if (gridDim.x * gridDim.y * gridDim.z <= 64) __builtin_amdgcn_s_setprio(3);  // small launch = latency-critical: issue first
+  const bpg::QuotArgs& q = batch.a[blockIdx.z];
+  const uint64_t rows = (uint64_t)1 << (q.log_n + q.rate_bits);
+  const uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (pos >= rows) return;
+  const uint32_t n = 1u << q.log_n;
+  const uint32_t t = (uint32_t)(pos >> q.log_n), m = (uint32_t)(pos & (n - 1));
+  DevEmit out{q.apow, q.n_constraints, row_point(q, t, m),
+              {gl::dot_zero(), gl::dot_zero(), gl::dot_zero(), gl::dot_zero()}, 0, 0, false};
+  DevRow row{q.trace_lde, q.aux_lde, q.const_lde, q.trace_stride, q.aux_stride, q.const_stride, pos,
+             ((uint64_t)t << q.log_n) | ((m + 1) & (n - 1)), out.rp.x, q.ctl.pub};
+  bpg::air::plonk::eval_hash_unit<uint64_t, DevRow, DevEmit, false>(row, out);
+  const uint64_t qh = row.cst(bpg::air::plonk::CST_HASH);
+  q.partial[((uint64_t)wg_row * 2) * rows + pos] = gl::mulc(out.result(0), qh);
+  q.partial[((uint64_t)wg_row * 2 + 1) * rows + pos] = gl::mulc(out.result(1), qh);
 }
 // qvals = (sum of the workgroup rows' partial sums) / Z_H.   grid = (rows / 256, 2 challenges)
 __global__ void __launch_bounds__(256) quotient_sum_kernel(bpg::BatchOf<bpg::QuotArgs> batch, uint32_t n_wg_rows) {
@@ -1559,9 +1584,15 @@ int launch_quotient(const QuotArgs* qs, uint32_t batch, const QuotCoset& coset, 
   else if (q.air_id == bpg::air::PLONK) BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::PLONK>, g1, 256, 0, st, qb);
   else BPG_LAUNCH_TIMED(kt, quotient_air_kernel<bpg::air::SYNTHETIC>, g1, 256, 0, st, qb);
   kt.stop();
+  if (q.side_rows) {
+    BPG_LAUNCH_CHECK();
+    // same family, no algorithmic bytes of its own: the wires it reads are the ones the chunk units have just read
+    KernelTimer kh(PROF_K5 + q.air_id, st, 0.0, true);
+    BPG_LAUNCH_TIMED(kh, quotient_plonk_hash_kernel, dim3(ceil_div(rows, 256), 1, batch), 256, 0, st, qb, wg_rows);
+  }
   BPG_LAUNCH_CHECK();
-  if (wg_rows > 1) {
-    quotient_sum_kernel<<<dim3(ceil_div(rows, 256), 2, batch), 256, 0, st>>>(qb, wg_rows);
+  if (wg_rows + q.side_rows > 1) {
+    quotient_sum_kernel<<<dim3(ceil_div(rows, 256), 2, batch), 256, 0, st>>>(qb, wg_rows + q.side_rows);
     BPG_LAUNCH_CHECK();
   }
   return BP_OK;

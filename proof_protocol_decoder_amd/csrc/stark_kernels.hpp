@@ -39,6 +39,9 @@ struct QuotArgs {
   uint32_t air_id, log_n, rate_bits, n_cols, n_const, n_aux, deg_pow;
   // the constraint list (air.hpp): AIR constraints, then two per aux column; units = AIR units, then CTL units
   uint32_t n_air_constraints, n_constraints, n_air_units, n_ctl_units, aux_per_unit, units_per_wg;
+  // AIR 8: its Poseidon gate (unit 10) is a pass of its own (quotient_plonk_hash_kernel: another register budget), whose
+  // sums are one more row of `partial`; n_air_units then counts the ten chunk units only
+  uint32_t side_rows;
   uint64_t alpha0, alpha1, g, g_inv, n_inv;
   Ctl ctl;
 };

@@ -28,7 +28,8 @@ def test_no_throughput_kernel_spills_sgprs(tmp_path):
     test_no_valu_reads_a_fresh_asm_carry_mask (which also sees v_writelane / v_readlane); on top of it the
     throughput kernels (Poseidon, NTT) are kept free of SGPR spills altogether, which is also what their speed
     wants.  The AIR-generic quotient kernel of stark_kernels.hip holds ~50 SGPRs of kernel arguments next to the
-    masks and spills a handful of those arguments (never a mask: the scan proves it), so it is exempt here."""
+    masks and spills a handful of those arguments (never a mask: the scan proves it), so it is exempt here, and so is
+    AIR 8's Poseidon-gate pass (the same arguments next to 24 round-constant SGPRs: 4 spills)."""
     import re
     csrc = os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc")
     bad, scratch = [], []
@@ -54,10 +55,10 @@ def test_no_throughput_kernel_spills_sgprs(tmp_path):
                 if int(m.group(1)) > cap:
                     scratch.append((src, name, int(m.group(1)), "allowed %d" % cap))
             m = re.match(r"\s+\.sgpr_spill_count:\s+(\d+)", line)
-            if m and int(m.group(1)) and "quotient_air_kernel" not in name:
+            if m and int(m.group(1)) and "quotient_air_kernel" not in name and "quotient_plonk_hash_kernel" not in name:
                 bad.append((src, name, int(m.group(1))))
             m = re.match(r"\s+\.sgpr_spill_count:\s+(\d+)", line)
-            if m and "quotient_air_kernel" in name:
+            if m and ("quotient_air_kernel" in name or "quotient_plonk_hash_kernel" in name):
                 # 4 .. 15 for most AIRs, 22 for the Keccak sponge (2414 columns, three nested rolled loops)
                 assert int(m.group(1)) <= 40, (name, "spills far more than kernel arguments and wave-uniform column offsets: look at it")
     assert not bad, bad
