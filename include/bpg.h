@@ -305,13 +305,24 @@ int bp_keccak_sponge_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log
 int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
 /* AIR 8 (plonk): the 85 preprocessed constant columns of the fixed circuit (selectors, gate constants drawn from `seed`,
- * the hash-row selector, the 80 sigmas of its copy permutation) for a circuit that hashes a public-input list of pi_len
- * words (1..64) in its Poseidon-gate rows, n = 2^log_n rows (>= 16), column-major; and the circuit's witness, 135 wires:
- * free wires drawn from `seed`, the list pi hashed in rows 4.., its hash in row 0 (the four public inputs) and, through
- * copy constraints, in the first arithmetic row.  bp_plonk_trace returns after the stream has run it. */
-int bp_plonk_constants(uint64_t seed, uint32_t log_n, uint32_t pi_len, uint64_t* d_consts_out, void* stream);
-int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t* pi, uint32_t pi_len, uint32_t log_n, uint64_t* d_trace_out,
-                   void* stream);
+ * the Poseidon-row selector, the 80 sigmas of its copy permutation), n = 2^log_n rows, column-major, for a circuit that
+ *   - hashes a public-input list of pi_len words (1..64) in Poseidon-gate rows 4.. (one permutation per row), and
+ *   - walks n_paths Merkle paths of path_depth levels each in Poseidon-gate rows 12.. (n_paths x path_depth <= 64): path p
+ *     starts at list words path_pi0 + 8p .. + 3 (a leaf digest) and must arrive at list words path_pi0 + 8p + 4 .. + 7 (a
+ *     cap entry); the aggregation circuit walks one path per child proof (merkle_proofs::verify_merkle_proof_to_cap of the
+ *     child's first query into its trace oracle), the block circuit its aggregation child's.  Arithmetic rows start at
+ *     the first multiple of four past the Merkle rows (12 without paths) and one group of four must fit;
+ * and the circuit's witness, 135 wires: free wires drawn from `seed`, the list pi hashed in rows 4.., its hash in row 0
+ * (the four public inputs) and, through copy constraints, in the first arithmetic row; `paths` (NULL when n_paths = 0):
+ * per path 1 + 4 path_depth words -- the leaf's position (bit l = "the node of level l is a right child"), then the
+ * sibling digests from the leaf upward.  A witness whose path does not arrive at the list's cap entry is written as it
+ * is: its proof is what a verifier rejects.  bp_plonk_trace returns after the stream has run it. */
+typedef struct bp_plonk_layout {
+  uint32_t pi_len, n_paths, path_depth, path_pi0;
+} bp_plonk_layout;
+int bp_plonk_constants(uint64_t seed, uint32_t log_n, const bp_plonk_layout* layout, uint64_t* d_consts_out, void* stream);
+int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t* pi, const bp_plonk_layout* layout, const uint64_t* paths,
+                   uint32_t log_n, uint64_t* d_trace_out, void* stream);
 
 /* K6.  One FRI fold (plonky2 fri::prover::fri_committed_trees: reduce_with_powers(beta) + coset_fft on the
  * folded domain), done in the evaluation domain.  d_values: the layer's n_l << rate_bits extension values

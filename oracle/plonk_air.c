@@ -25,7 +25,14 @@ enum { PW = 135, PK = 85, ROUTED = 80, SLOTS = 20, SBOX = 11, SB0 = 80, SIG0 = 5
  * Chunk h of the list sits in wires 0..7 of row 4 + h; the rest of the incoming state is copied from the previous row's
  * output, or (row 4) from the d wires of row 1, an arithmetic row whose gate constants are zero.  The first four output
  * words of the last hash row are the public-input wires of row 0.  Arithmetic groups start at row 12. */
-enum { HROW0 = 4, AROW0 = 12, ZROW = 1, HIN = 0, HOUT = 12, HF1 = 24, HPART = 60, HF2 = 82, HWIRES = 130 };
+/* Round 5, second step: the Poseidon gate has upstream's swap (wire 130 = a bit s, wires 131..134 = delta_i = s (in[4+i] -
+ * in[i]); the permutation runs on (in[i] + delta_i, in[4+i] - delta_i, in[8..11])), and a circuit may walk Merkle paths with
+ * it: rows 12 .. 12 + n_paths * depth - 1, one level per row -- node in 0..3, sibling in 4..7, zeros in 8..11, position bit
+ * on the swap wire, the node above in out 0..3.  Path p's leaf digest is words path_pi0 + 8p .. + 3 of the public-input
+ * list, the cap entry it arrives at words path_pi0 + 8p + 4 .. + 7.  Arithmetic groups start at the first multiple of four
+ * past the Merkle rows. */
+enum { HROW0 = 4, MROW0 = 12, ZROW = 1, HIN = 0, HOUT = 12, HF1 = 24, HPART = 60, HF2 = 82, HSWAP = 130, HDELTA = 131, HWIRES = 135 };
+static unsigned arith_row0_of(unsigned n_paths, unsigned depth) { return (MROW0 + n_paths * depth + 3) / 4 * 4; }
 static const gl_t PRC[360] = {
 #include "poseidon_rc.inc"
 };
@@ -60,9 +67,11 @@ static void tie(gl_t* consts, size_t N, const gl_t* kpow, const gl_t* wpow, cons
     consts[(size_t)(SIG0 + m[i].col) * N + m[i].row] = gl_mul(kpow[to.col], wpow[to.row]);
   }
 }
-void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, gl_t* consts) {
+void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0,
+                         gl_t* consts) {
   const size_t N = (size_t)1 << log_n;
   const unsigned H = hash_rows_of(pi_len), last_len = pi_len - 8 * (H - 1);
+  const unsigned AROW0 = arith_row0_of(n_paths, depth), MROWS = n_paths * depth;
   gl_t *kpow = (gl_t*)malloc(ROUTED * sizeof(gl_t)), *wpow = (gl_t*)malloc(N * sizeof(gl_t));
   kpow[0] = 1;
   for (int j = 1; j < ROUTED; j++) kpow[j] = gl_mul(kpow[j - 1], 7);
@@ -74,7 +83,7 @@ void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, gl_t* c
     consts[1 * N + i] = gate_row && (i % 4 == 2);
     consts[2 * N + i] = i == ZROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, 2, i);
     consts[3 * N + i] = i == ZROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, 3, i);
-    consts[4 * N + i] = i >= HROW0 && i < HROW0 + H;
+    consts[4 * N + i] = (i >= HROW0 && i < HROW0 + H) || (i >= MROW0 && i < MROW0 + MROWS);
     for (int j = 0; j < ROUTED; j++) consts[(size_t)(SIG0 + j) * N + i] = gl_mul(kpow[j], wpow[i]); /* untied: itself */
   }
   /* the sponge: which incoming state words of hash row h are NOT words of the list */
@@ -93,6 +102,34 @@ void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, gl_t* c
           tie(consts, N, kpow, wpow, c, 2);
         }
       }
+  }
+  /* the Merkle paths: level by level the node climbs; the ends are words of the list; every capacity word is zero */
+  if (MROWS) {
+    wire_t* zeros = (wire_t*)malloc((4 * MROWS + 1) * sizeof(wire_t));
+    int nz = 0;
+    zeros[nz++] = (wire_t){4 * 19 + 3, ZROW}; /* the last zero wire of row 1 */
+    for (unsigned p = 0; p < n_paths; p++)
+      for (unsigned l = 0; l < depth; l++) {
+        const uint32_t row = MROW0 + p * depth + l;
+        for (uint32_t j = 0; j < 4; j++) {
+          zeros[nz++] = (wire_t){HIN + 8 + j, row};
+          if (l == 0) { /* the leaf digest: word path_pi0 + 8p + j of the list, wherever the sponge absorbs it */
+            const unsigned i = path_pi0 + 8 * p + j;
+            const wire_t leaf[2] = {{HIN + j, row}, {HIN + i % 8, HROW0 + i / 8}};
+            tie(consts, N, kpow, wpow, leaf, 2);
+          } else {
+            const wire_t up[2] = {{HIN + j, row}, {HOUT + j, row - 1}};
+            tie(consts, N, kpow, wpow, up, 2);
+          }
+          if (l == depth - 1) { /* the cap entry */
+            const unsigned i = path_pi0 + 8 * p + 4 + j;
+            const wire_t top[2] = {{HOUT + j, row}, {HIN + i % 8, HROW0 + i / 8}};
+            tie(consts, N, kpow, wpow, top, 2);
+          }
+        }
+      }
+    tie(consts, N, kpow, wpow, zeros, nz);
+    free(zeros);
   }
   for (size_t g = AROW0 / 4; g < N / 4; g++) {
     const uint32_t r = (uint32_t)(4 * g);
@@ -130,9 +167,28 @@ static void mds_layer(gl_t st[12]) {
   }
   memcpy(st, o, sizeof(o));
 }
-void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, const gl_t* consts, unsigned log_n, gl_t* t) {
+/* one permutation, every S-box input kept in the row's wires */
+static void permute_into_row(gl_t st[12], gl_t* t, size_t N, size_t row) {
+#define W(col, row) t[(size_t)(col) * N + (row)]
+  for (int rnd_no = 0; rnd_no < 30; rnd_no++) {
+    for (int k = 0; k < 12; k++) st[k] = gl_add(st[k], PRC[12 * rnd_no + k]);
+    const int full = rnd_no < 4 || rnd_no >= 26;
+    if (rnd_no >= 1 && rnd_no <= 3) for (int k = 0; k < 12; k++) W(HF1 + 12 * (rnd_no - 1) + k, row) = st[k];
+    if (rnd_no >= 4 && rnd_no <= 25) W(HPART + rnd_no - 4, row) = st[0];
+    if (rnd_no >= 26) for (int k = 0; k < 12; k++) W(HF2 + 12 * (rnd_no - 26) + k, row) = st[k];
+    if (full) for (int k = 0; k < 12; k++) st[k] = pow7(st[k]);
+    else st[0] = pow7(st[0]);
+    mds_layer(st);
+  }
+  for (int k = 0; k < 12; k++) W(HOUT + k, row) = st[k];
+#undef W
+}
+/* paths (n_paths > 0): per path 1 + 4 depth words: the leaf's position, then the siblings from the leaf upward */
+void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0,
+                     const gl_t* paths, const gl_t* consts, unsigned log_n, gl_t* t) {
   const size_t N = (size_t)1 << log_n;
   const unsigned H = hash_rows_of(pi_len);
+  const unsigned AROW0 = arith_row0_of(n_paths, depth);
 #define W(col, row) t[(size_t)(col) * N + (row)]
   for (size_t i = 0; i < N; i++) /* every wire starts free; the rows below overwrite what the circuit computes */
     for (int c = 0; c < PW; c++) W(c, i) = rnd(seed, c, i);
@@ -144,19 +200,34 @@ void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, const gl_t*
     const unsigned take = pi_len - 8 * h < 8 ? pi_len - 8 * h : 8;
     for (unsigned k = 0; k < take; k++) st[k] = pi[8 * h + k];
     for (int k = 0; k < 12; k++) W(HIN + k, row) = st[k];
-    for (int rnd_no = 0; rnd_no < 30; rnd_no++) {
-      for (int k = 0; k < 12; k++) st[k] = gl_add(st[k], PRC[12 * rnd_no + k]);
-      const int full = rnd_no < 4 || rnd_no >= 26;
-      if (rnd_no >= 1 && rnd_no <= 3) for (int k = 0; k < 12; k++) W(HF1 + 12 * (rnd_no - 1) + k, row) = st[k];
-      if (rnd_no >= 4 && rnd_no <= 25) W(HPART + rnd_no - 4, row) = st[0];
-      if (rnd_no >= 26) for (int k = 0; k < 12; k++) W(HF2 + 12 * (rnd_no - 26) + k, row) = st[k];
-      if (full) for (int k = 0; k < 12; k++) st[k] = pow7(st[k]);
-      else st[0] = pow7(st[0]);
-      mds_layer(st);
-    }
-    for (int k = 0; k < 12; k++) W(HOUT + k, row) = st[k];
+    for (int k = 0; k < 5; k++) W(HSWAP + k, row) = 0; /* no swap in a sponge row */
+    permute_into_row(st, t, N, row);
   }
   gl_t pub[4] = {st[0], st[1], st[2], st[3]};
+  /* the Merkle rows: the two-to-one compression of (left, right), the node on the side its position bit says */
+  for (unsigned p = 0; p < n_paths; p++) {
+    const gl_t* pw = paths + (size_t)p * (1 + 4 * depth);
+    uint64_t index = pw[0];
+    gl_t node[4];
+    for (int j = 0; j < 4; j++) node[j] = pi[path_pi0 + 8 * p + j];
+    for (unsigned l = 0; l < depth; l++, index >>= 1) {
+      const size_t row = MROW0 + p * depth + l;
+      const gl_t* sib = pw + 1 + 4 * l;
+      const int right = (int)(index & 1);
+      gl_t m[12] = {0};
+      for (int j = 0; j < 4; j++) {
+        W(HIN + j, row) = node[j];
+        W(HIN + 4 + j, row) = sib[j];
+        W(HIN + 8 + j, row) = 0;
+        W(HDELTA + j, row) = right ? gl_sub(sib[j], node[j]) : 0;
+        m[j] = right ? sib[j] : node[j];
+        m[4 + j] = right ? node[j] : sib[j];
+      }
+      W(HSWAP, row) = (gl_t)right;
+      permute_into_row(m, t, N, row);
+      for (int j = 0; j < 4; j++) node[j] = m[j];
+    }
+  }
   for (int j = 0; j < 4; j++) W(j, 0) = pub[j];
   for (size_t i = AROW0; i < N; i++) {
     const gl_t c0 = consts[2 * N + i], c1 = consts[3 * N + i];

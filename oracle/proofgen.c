@@ -29,6 +29,7 @@ typedef struct {
   gl_t* const_values;
   orc_committed* consts;
   gl_t digest[4];
+  unsigned n_paths, path_pi0; /* the Merkle paths the circuit walks (plonk_air.c) */
 } circuit_t;
 
 typedef struct orc_pg_state {
@@ -74,11 +75,13 @@ void orc_pg_state_free(orc_pg_state* s) {
   free(s);
 }
 /* circuits are preprocessed lazily (same data as libbpg's eager bp_state_build) */
-static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len) {
+static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned path_pi0) {
   if (!c->built) {
     size_t n = (size_t)1 << s->rec.log_n;
     c->const_values = (gl_t*)malloc(s->rec.n_const * n * sizeof(gl_t));
-    if (s->rec.air_id == ORC_AIR_PLONK) orc_plonk_constants(seed, s->rec.log_n, pi_len, c->const_values);
+    c->n_paths = n_paths; c->path_pi0 = path_pi0;
+    if (s->rec.air_id == ORC_AIR_PLONK)
+      orc_plonk_constants(seed, s->rec.log_n, pi_len, n_paths, s->rec.log_n + s->rec.rate_bits - s->rec.cap_height, path_pi0, c->const_values);
     else orc_synth_constants(seed, s->rec.log_n, s->rec.n_const, c->const_values);
     c->consts = orc_commit_values(c->const_values, s->rec.log_n, s->rec.n_const, s->rec.rate_bits, s->rec.cap_height);
     orc_hash_no_pad(orc_committed_cap(c->consts), (size_t)4 << s->rec.cap_height, c->digest);
@@ -88,13 +91,18 @@ static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed, unsi
 }
 /* the length of the public-input list each circuit hashes in-circuit: a table's chain circuits (digest, table, depth) 6;
  * root 7 digests + the public values; aggregation two digests, two flags + the public values; block two digests, a flag + them */
-static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) { return get_circuit(s, &s->table[t][d], circuit_seed(t, d), 6); }
+static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) { return get_circuit(s, &s->table[t][d], circuit_seed(t, d), 6, 0, 0); }
+/* The aggregation circuit also walks, per child, the Merkle path of the child's first trace opening (its leaf digest and
+ * the cap entry above it: eight more words of the list per child, after the digests and flags); the block circuit walks
+ * its aggregation child's. */
+enum { AGG_PATHS_AT = 10, BLOCK_PATH_AT = 9, AGG_PI = 10 + 16 + PV_WORDS, BLOCK_PI = 9 + 8 + PV_WORDS };
 static circuit_t* special_circuit(orc_pg_state* s, int k) {
-  static const unsigned PI_LEN[3] = {4 * NUM_TABLES + PV_WORDS, 10 + PV_WORDS, 9 + PV_WORDS};
-  return get_circuit(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0), PI_LEN[k]);
+  static const unsigned PI_LEN[3] = {4 * NUM_TABLES + PV_WORDS, AGG_PI, BLOCK_PI}, PATHS[3] = {0, 2, 1}, AT[3] = {0, AGG_PATHS_AT, BLOCK_PATH_AT};
+  return get_circuit(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0), PI_LEN[k], PATHS[k], AT[k]);
 }
 
-static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_pi, gl_t* proof) {
+/* paths: the witness of the circuit's Merkle paths (circ->n_paths of them, 1 + 4 depth words each), or NULL */
+static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_pi, const gl_t* paths, gl_t* proof) {
   gl_t pi_hash[4];
   orc_hash_no_pad(pi, n_pi, pi_hash);
   orc_challenger ch;
@@ -106,7 +114,8 @@ static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_
   orc_stark_cfg rcfg = s->rec; /* the PLONK-shaped circuit binds the hash of the public inputs to its first row */
   if (rcfg.air_id == ORC_AIR_PLONK) {
     memcpy(rcfg.pub, pi_hash, sizeof(rcfg.pub));
-    orc_plonk_trace(pi_hash[0], pi, (unsigned)n_pi, circ->const_values, rcfg.log_n, trace);
+    orc_plonk_trace(pi_hash[0], pi, (unsigned)n_pi, circ->n_paths, rcfg.log_n + rcfg.rate_bits - rcfg.cap_height, circ->path_pi0,
+                    paths, circ->const_values, rcfg.log_n, trace);
   } else {
     orc_synth_trace(pi_hash[0], &s->rec, circ->const_values, trace);
   }
@@ -485,7 +494,7 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
     circuit_t* circ = table_circuit(s, t, tcfg[t].log_n);
     for (uint32_t depth = 0; depth < cfg->shrink_depth && !rc; depth++) {
       gl_t pi[6] = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (gl_t)t, depth};
-      rc = rec_prove(s, circ, pi, 6, proof);
+      rc = rec_prove(s, circ, pi, 6, NULL, proof);
       if (!rc) orc_proof_digest(&s->rec, proof, digest[t]);
     }
   }
@@ -493,7 +502,7 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
     gl_t pi[4 * NUM_TABLES + PV_WORDS];
     for (int t = 0; t < NUM_TABLES; t++) memcpy(pi + 4 * t, digest[t], 32);
     memcpy(pi + 4 * NUM_TABLES, pv, sizeof(pv));
-    rc = rec_prove(s, special_circuit(s, 0), pi, 4 * NUM_TABLES + PV_WORDS, proof);
+    rc = rec_prove(s, special_circuit(s, 0), pi, 4 * NUM_TABLES + PV_WORDS, NULL, proof);
     if (!rc) *out = emit_box(0, pi, 4 * NUM_TABLES + PV_WORDS, proof, sw, out_words);
   }
   free(proof);
@@ -516,19 +525,24 @@ int orc_pg_agg(orc_pg_state* s, const gl_t* lhs, size_t lw, int lhs_is_agg, cons
   if (parse_box(s, lhs, lw, &L) || parse_box(s, rhs, rw, &R)) return -2;
   if ((L.kind == 1) != (lhs_is_agg != 0) || (R.kind == 1) != (rhs_is_agg != 0) || L.kind > 1 || R.kind > 1) return -2;
   if (L.pv[1] != R.pv[0] || L.pv[3] != R.pv[2] || memcmp(L.pv + 8, R.pv + 4, 32) || L.pv[12] != R.pv[12]) return -2;
-  gl_t pi[10 + PV_WORDS];
+  gl_t pi[AGG_PI];
   orc_proof_digest(&s->rec, L.stark, pi);
   orc_proof_digest(&s->rec, R.stark, pi + 4);
   pi[8] = lhs_is_agg != 0; pi[9] = rhs_is_agg != 0;
-  gl_t* pv = pi + 10;
+  const size_t path_words = 1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height);
+  gl_t* paths = (gl_t*)malloc(2 * path_words * sizeof(gl_t));
+  orc_proof_first_query_path(&s->rec, L.stark, pi + AGG_PATHS_AT, pi + AGG_PATHS_AT + 4, paths);
+  orc_proof_first_query_path(&s->rec, R.stark, pi + AGG_PATHS_AT + 8, pi + AGG_PATHS_AT + 12, paths + path_words);
+  gl_t* pv = pi + AGG_PATHS_AT + 16;
   pv[0] = L.pv[0]; pv[1] = R.pv[1]; pv[2] = L.pv[2]; pv[3] = R.pv[3];
   memcpy(pv + 4, L.pv + 4, 32); memcpy(pv + 8, R.pv + 8, 32);
   pv[12] = L.pv[12];
   size_t sw = orc_proof_words(&s->rec);
   gl_t* proof = (gl_t*)malloc(sw * sizeof(gl_t));
-  int rc = rec_prove(s, special_circuit(s, 1), pi, 10 + PV_WORDS, proof);
-  if (!rc) *out = emit_box(1, pi, 10 + PV_WORDS, proof, sw, out_words);
+  int rc = rec_prove(s, special_circuit(s, 1), pi, AGG_PI, paths, proof);
+  if (!rc) *out = emit_box(1, pi, AGG_PI, proof, sw, out_words);
   free(proof);
+  free(paths);
   return rc;
 }
 
@@ -537,7 +551,7 @@ int orc_pg_block(orc_pg_state* s, const gl_t* parent, size_t pw, const gl_t* agg
                  size_t* out_words) {
   box_t A, Pb;
   if (parse_box(s, agg, aw, &A) || A.kind != 1) return -2;
-  gl_t pi[9 + PV_WORDS];
+  gl_t pi[BLOCK_PI];
   memset(pi, 0, sizeof(pi));
   if (parent) {
     if (parse_box(s, parent, pw, &Pb) || Pb.kind != 2 || Pb.pv[12] + 1 != A.pv[12]) return -2;
@@ -545,12 +559,15 @@ int orc_pg_block(orc_pg_state* s, const gl_t* parent, size_t pw, const gl_t* agg
     pi[8] = 1;
   }
   orc_proof_digest(&s->rec, A.stark, pi + 4);
-  memcpy(pi + 9, A.pv, PV_WORDS * 8);
+  gl_t* path = (gl_t*)malloc((1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height)) * sizeof(gl_t));
+  orc_proof_first_query_path(&s->rec, A.stark, pi + BLOCK_PATH_AT, pi + BLOCK_PATH_AT + 4, path);
+  memcpy(pi + BLOCK_PATH_AT + 8, A.pv, PV_WORDS * 8);
   size_t sw = orc_proof_words(&s->rec);
   gl_t* proof = (gl_t*)malloc(sw * sizeof(gl_t));
-  int rc = rec_prove(s, special_circuit(s, 2), pi, 9 + PV_WORDS, proof);
-  if (!rc) *out = emit_box(2, pi, 9 + PV_WORDS, proof, sw, out_words);
+  int rc = rec_prove(s, special_circuit(s, 2), pi, BLOCK_PI, path, proof);
+  if (!rc) *out = emit_box(2, pi, BLOCK_PI, proof, sw, out_words);
   free(proof);
+  free(path);
   return rc;
 }
 

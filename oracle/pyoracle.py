@@ -117,8 +117,8 @@ def lib():
     L.orc_pg_txn_witness.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                      C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_stark_public_inputs.argtypes = [u6, u64p]
-    L.orc_plonk_constants.argtypes = [u6, u, u, u64p]
-    L.orc_plonk_trace.argtypes = [u6, u64p, u, u64p, u, u64p]
+    L.orc_plonk_constants.argtypes = [u6, u, u, u, u, u, u64p]
+    L.orc_plonk_trace.argtypes = [u6, u64p, u, u, u, u, u64p, u64p, u, u64p]
     L.orc_stark_public_input_list.argtypes = [u6, u64p]
     L.orc_pg_txn_tables.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                     C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
@@ -278,19 +278,35 @@ def stark_public_input_list(seed):
     return out
 
 
-def plonk_constants(log_n, seed, pi_len=4):
-    """the 85 constant columns of a circuit that hashes a public-input list of pi_len words"""
+def plonk_constants(log_n, seed, pi_len=4, n_paths=0, depth=0, path_pi0=0):
+    """the 85 constant columns of a circuit that hashes a public-input list of pi_len words and walks n_paths Merkle
+    paths of `depth` levels (leaf digest / cap entry = list words path_pi0 + 8 p .. + 7)"""
     out = np.zeros((PLONK_CONSTS, 1 << log_n), dtype=np.uint64)
-    lib().orc_plonk_constants(C.c_uint64(seed), log_n, pi_len, out)
+    lib().orc_plonk_constants(C.c_uint64(seed), log_n, pi_len, n_paths, depth, path_pi0, out)
     return out
 
 
-def plonk_trace(log_n, seed, pi, consts):
-    """the witness; pi: the public-input list the hash rows absorb (its hash lands in row 0)"""
+def plonk_trace(log_n, seed, pi, consts, n_paths=0, depth=0, path_pi0=0, paths=None):
+    """the witness; pi: the public-input list the hash rows absorb (its hash lands in row 0); paths: per Merkle path
+    1 + 4 depth words (the leaf's position, the siblings upward)"""
     out = np.zeros((PLONK_COLS, 1 << log_n), dtype=np.uint64)
     pi = arr(pi)
-    lib().orc_plonk_trace(C.c_uint64(seed), pi, pi.size, arr(consts), log_n, out)
+    pw = arr(paths) if n_paths else np.zeros(1, dtype=np.uint64)
+    assert not n_paths or pw.size == n_paths * (1 + 4 * depth)
+    lib().orc_plonk_trace(C.c_uint64(seed), pi, pi.size, n_paths, depth, path_pi0, pw, arr(consts), log_n, out)
     return out
+
+
+def merkle_path(leaf_digests, index, cap_height=0):
+    """Sibling digests of leaf `index` in the tree over leaf_digests ([n][4], n a power of two), leaf upward, down to
+    2^cap_height cap entries; and the cap entry the path arrives at.  Built with hash_no_pad over (left, right)."""
+    level = [np.array(d, dtype=np.uint64) for d in leaf_digests]
+    sibs, i = [], index
+    while len(level) > (1 << cap_height):
+        sibs.append(level[i ^ 1])
+        level = [hash_no_pad(np.concatenate([level[2 * k], level[2 * k + 1]])) for k in range(len(level) // 2)]
+        i >>= 1
+    return np.concatenate(sibs) if sibs else np.zeros(0, dtype=np.uint64), level[i]
 
 
 def keccak_f(lanes):

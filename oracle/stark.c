@@ -708,6 +708,25 @@ int orc_stark_verify(const orc_stark_cfg* cf, const gl_t* const_cap, const gl_t 
   return 0;
 }
 
+/* What an aggregating circuit walks for a child proof: the first query's opening of the trace oracle.  leaf = the digest
+ * of the opened row (hash_or_noop), cap_entry = the entry of the trace cap above it, path = the leaf's position below that
+ * entry followed by the 4 * depth0 sibling words (1 + 4 * depth0 words). */
+void orc_proof_first_query_path(const orc_stark_cfg* cf, const gl_t* proof, gl_t leaf[4], gl_t cap_entry[4], gl_t* path) {
+  layout_t L = layout(cf);
+  const gl_t* q = proof + L.queries;
+  const uint64_t x = q[0];
+  const gl_t* row = q + 1 + (cf->n_const ? cf->n_const + (size_t)L.depth0 * 4 : 0); /* past the constants' row and path */
+  if (cf->n_cols <= 4) {
+    memset(leaf, 0, 32);
+    memcpy(leaf, row, cf->n_cols * 8);
+  } else {
+    orc_hash_no_pad(row, cf->n_cols, leaf);
+  }
+  path[0] = x % ((uint64_t)1 << L.depth0);
+  memcpy(path + 1, row + cf->n_cols, (size_t)L.depth0 * 32);
+  memcpy(cap_entry, proof + L.trace_cap + 4 * (x >> L.depth0), 32);
+}
+
 void orc_proof_digest(const orc_stark_cfg* cf, const gl_t* proof, gl_t out[4]) {
   layout_t L = layout(cf);
   size_t n = 3 * L.cap_words + 2 * (size_t)L.final_len + 1;

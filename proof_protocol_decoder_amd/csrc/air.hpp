@@ -949,38 +949,66 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 //        126 + (r - 4)         p_r - state[0] through the partial rounds r = 4..25        (state: M applied to (p^7, the other
 //                                                                                        eleven words), + rc_(r+1))
 //        148 + 12 (r - 26) + i s_r[i] - state[i],  r = 26..29;    196 + i   out[i] - (M (s_29)^7)[i]
-// with the permutation's own round constants and MDS matrix (poseidon_rc.inc): hash rows compute hash_no_pad.
+//   G5  208 .. 212 all rows   q_hash s (s - 1),  q_hash (delta_i - s (in[4 + i] - in[i])), i < 4:  the gate's swap -- wire 130
+//        = s, wires 131..134 = delta; the permutation runs on (in[i] + delta_i, in[4 + i] - delta_i, in[8..11]), i.e. on
+//        (left, right, capacity) of a Merkle step whose node arrives in in[0..3] and whose sibling in in[4..7]       degree 3
+// with the permutation's own round constants and MDS matrix (poseidon_rc.inc): hash rows compute hash_no_pad (s = 0).
+// All 135 wires of a Poseidon row are now spoken for, as in upstream's PoseidonGate (12 + 12 + 1 + 4 + 36 + 22 + 48).
 // Rows 4 .. 4 + H - 1 (H = ceil(len / 8) <= 8) absorb the list eight words at a time: the words are free wires 0..7 of
 // their row, the other state words are copies -- of the previous row's output (the sponge's carry: words 8..11, and the
 // words a short last chunk leaves alone), or, in the first row, of ZERO wires: row 1 is an arithmetic row with
 // c0 = c1 = 0, so its twenty d wires are zero.  The first four output words of the last hash row ARE the public-input
 // wires of row 0 (one copy cycle with c_j(12), c_j(13)), which G3 binds to the four words the verifier computed from
-// the list it was given.  Rows 4..11 are the hash region (no-ops beyond H); arithmetic groups start at row 12.
+// the list it was given.  Rows 4..11 are the hash region (no-ops beyond H).
+// **Merkle rows** (rows 12 .. 12 + n_paths x depth - 1, also selected by q_hash): the aggregation / block circuit walks,
+// per child proof, the Merkle path of the child's first query into its trace oracle (merkle_proofs::
+// verify_merkle_proof_to_cap in-circuit): level l's row takes the node of level l in in[0..3] -- a copy of the row
+// below's out[0..3]; at l = 0 a copy of the leaf-digest words of the public-input list -- the sibling in in[4..7] (free
+// witness, like the position bit on the swap wire) and zeros in in[8..11] (one copy cycle through all of them and zero
+// wire 19 of row 1); out[0..3] of the path's last row is a copy of the list's cap-entry words.  So the hash the verifier
+// is given commits to (leaf digest, cap entry) pairs between which the circuit has checked a path; which leaf and which
+// cap the words are is the aggregating host's statement, as the child digests in the same list are.  Arithmetic groups
+// start at the first multiple of four past the Merkle rows (row 12 for a circuit that walks no path).
 namespace plonk {
-constexpr uint32_t N_COLS = 135, N_CONST = 85, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 208, N_UNITS = 11;
+constexpr uint32_t N_COLS = 135, N_CONST = 85, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 213, N_UNITS = 11;
 constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_HASH = 4, CST_SIGMA = 5;
 constexpr uint32_t COL_SBOX = 80;
-constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86, G4 = 90;
-constexpr uint32_t HASH_ROW0 = 4, HASH_ROWS_MAX = 8, ARITH_ROW0 = 12, ZERO_ROW = 1, MAX_PI = 8 * HASH_ROWS_MAX;
-constexpr uint32_t H_IN = 0, H_OUT = 12, H_FULL1 = 24, H_PART = 60, H_FULL2 = 82, H_WIRES = 130;
+constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86, G4 = 90, G5 = 208;
+constexpr uint32_t HASH_ROW0 = 4, HASH_ROWS_MAX = 8, ZERO_ROW = 1, MAX_PI = 8 * HASH_ROWS_MAX;
+constexpr uint32_t MERKLE_ROW0 = HASH_ROW0 + HASH_ROWS_MAX, MERKLE_ROWS_MAX = 64, MERKLE_ZERO_COL = 79;
+constexpr uint32_t H_IN = 0, H_OUT = 12, H_FULL1 = 24, H_PART = 60, H_FULL2 = 82, H_SWAP = 130, H_DELTA = 131, H_WIRES = 135;
+// What a circuit of this family does besides its arithmetic groups: it hashes a public-input list of pi_len words
+// (rows 4 ..), and it walks n_paths Merkle paths of `depth` levels each (rows 12 ..): path p's leaf digest is list words
+// path_pi0 + 8p .. + 3, the cap entry it must arrive at is list words path_pi0 + 8p + 4 .. + 7.
+struct Layout {
+  uint32_t pi_len, n_paths, depth, path_pi0;
+};
 GL_HD uint32_t hash_rows(uint32_t pi_len) { return (pi_len + 7) / 8; }
+GL_HD uint32_t merkle_rows(const Layout& L) { return L.n_paths * L.depth; }
+GL_HD uint32_t arith_row0(const Layout& L) { return (MERKLE_ROW0 + merkle_rows(L) + 3) & ~3u; }  // 12 without paths
+GL_HD bool layout_ok(const Layout& L, uint32_t n) {
+  return L.pi_len >= 1 && L.pi_len <= MAX_PI && merkle_rows(L) <= MERKLE_ROWS_MAX && (L.n_paths == 0 || L.depth >= 1) &&
+         L.path_pi0 + 8 * L.n_paths <= L.pi_len && arith_row0(L) + 4 <= n;
+}
 // is state word k of hash row h (0-based) a carried word -- a copy of the previous row's output (h > 0) or of a zero wire
 // (h = 0) -- rather than a word of the list?
 GL_HD bool hash_word_is_carried(uint32_t pi_len, uint32_t h, uint32_t k) {
   const uint32_t H = hash_rows(pi_len), last = pi_len - 8 * (H - 1);  // words in the last chunk: 1..8
   return k >= 8 || (h + 1 == H && k >= last);
 }
-// where wire (col, row) points in the copy permutation (the next position of its cycle), n rows; pi_len: the length of
-// the public-input list the circuit hashes (1 .. MAX_PI)
-GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t pi_len, uint32_t& col_out, uint32_t& row_out) {
+// where wire (col, row) points in the copy permutation (the next position of its cycle), n rows
+GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, const Layout& L, uint32_t& col_out, uint32_t& row_out) {
   col_out = col; row_out = row;
   if (col >= N_ROUTED) return;
-  const uint32_t H = hash_rows(pi_len), last_hash_row = HASH_ROW0 + H - 1;
-  if (row < ARITH_ROW0) {
-    if (row == 0) {  // the public-input row: w_j(0) -> c_j(12) -> c_j(13) -> out_j(last hash row) -> w_j(0)
-      if (col < 4) { col_out = 4 * col + 2; row_out = ARITH_ROW0; }
+  const uint32_t pi_len = L.pi_len, H = hash_rows(pi_len), last_hash_row = HASH_ROW0 + H - 1;
+  const uint32_t A0 = arith_row0(L), T = merkle_rows(L);
+  if (row < A0) {
+    if (row == 0) {  // the public-input row: w_j(0) -> c_j(A0) -> c_j(A0 + 1) -> out_j(last hash row) -> w_j(0)
+      if (col < 4) { col_out = 4 * col + 2; row_out = A0; }
     } else if (row == ZERO_ROW) {  // zero wire z = d_z(1) <-> the z-th carried word of the first hash row
-      if ((col & 3) == 3) {
+      if (T && col == MERKLE_ZERO_COL) {  // the last zero wire heads the chain of the Merkle rows' capacity words
+        col_out = H_IN + 8; row_out = MERKLE_ROW0;
+      } else if ((col & 3) == 3) {
         uint32_t z = col >> 2, seen = 0;
         for (uint32_t k = 0; k < 12; k++)
           if (hash_word_is_carried(pi_len, 0, k)) {
@@ -999,6 +1027,13 @@ GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t pi_len, uin
           } else {
             col_out = H_OUT + col; row_out = row - 1;
           }
+        } else {  // a word of the list: a path's leaf digest / cap entry is the same wire as the path's first input / last output
+          const uint32_t i = 8 * h + col;
+          if (i >= L.path_pi0 && i < L.path_pi0 + 8 * L.n_paths) {
+            const uint32_t q = i - L.path_pi0, p = q >> 3, r = q & 7;
+            if (r < 4) { col_out = H_IN + r; row_out = MERKLE_ROW0 + p * L.depth; }
+            else { col_out = H_OUT + r - 4; row_out = MERKLE_ROW0 + p * L.depth + L.depth - 1; }
+          }
         }
       } else if (col < 24) {  // a state word going out
         const uint32_t k = col - H_OUT;
@@ -1007,6 +1042,22 @@ GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t pi_len, uin
         } else if (hash_word_is_carried(pi_len, h + 1, k)) {
           col_out = H_IN + k; row_out = row + 1;
         }
+      }
+    } else if (row >= MERKLE_ROW0 && row < MERKLE_ROW0 + T) {
+      // level l of path p: in 0..3 the node below (the leaf digest at l = 0), 4..7 its sibling (free), 8..11 zero;
+      // out 0..3 the node above (the cap entry at the last level)
+      const uint32_t t = row - MERKLE_ROW0, p = t / L.depth, l = t % L.depth;
+      if (col < 4) {
+        if (l == 0) { const uint32_t i = L.path_pi0 + 8 * p + col; col_out = i & 7; row_out = HASH_ROW0 + (i >> 3); }
+        else { col_out = H_OUT + col; row_out = row - 1; }
+      } else if (col >= 8 && col < 12) {  // one cycle through every capacity word of every Merkle row and a zero wire
+        if (col < 11) col_out = col + 1;
+        else if (t + 1 < T) { col_out = 8; row_out = row + 1; }
+        else { col_out = MERKLE_ZERO_COL; row_out = ZERO_ROW; }
+      } else if (col >= H_OUT && col < H_OUT + 4) {
+        const uint32_t j = col - H_OUT;
+        if (l + 1 == L.depth) { const uint32_t i = L.path_pi0 + 8 * p + 4 + j; col_out = i & 7; row_out = HASH_ROW0 + (i >> 3); }
+        else { col_out = H_IN + j; row_out = row + 1; }
       }
     }
     return;
@@ -1020,7 +1071,7 @@ GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, uint32_t pi_len, uin
     if (w == 0) { col_out = 4 * ((s + N_SLOTS - 1) % N_SLOTS) + 1; row_out = base + 1; }  // a_s -> b_(s-1) of the same row
     else if (w == 1) { col_out = 4 * ((s + 1) % N_SLOTS) + 3; row_out = base; }           // b_s(4g+1) -> d_(s+1)(4g)
     else if (w == 2) {                                                                   // c_s(4g+1) -> c_s(4g), or on to the hash output
-      if (base == ARITH_ROW0 && s < 4) { col_out = H_OUT + s; row_out = last_hash_row; }
+      if (base == A0 && s < 4) { col_out = H_OUT + s; row_out = last_hash_row; }
       else { col_out = col; row_out = base; }
     } else if (s < N_SBOX) { col_out = 4 * s; row_out = base + 2; }             // d_i(4g+1) -> a_i(4g+2)
   } else if (p == 2) {
@@ -1048,7 +1099,7 @@ GL_HD uint64_t chunk_shift(uint32_t u) {
 // three times and every sigma twice -- 2.05 x the algorithmic bytes by PMC --, and a lone proof's 2^16 rows were 256
 // workgroups with nothing to spread.)  Every constraint keeps its index, so the quotient is the same polynomial.
 // Unit 10: the Poseidon gate (G4).  The wires of the row are taken at their word: every constraint compares a wire with
-// what the round function makes of the wires before it, so a hash row is a chain of 118 local checks.
+// what the round function makes of the wires before it, so a hash row is a chain of 118 local checks (+ 5 for the swap).
 template <class T, class Row, class Emit, bool SELECTOR = true>
 GL_HD void eval_hash_unit(const Row& row, Emit& out) {
   // SELECTOR = false: the differences go out bare and the caller multiplies the folded sum by q_hash once
@@ -1058,8 +1109,31 @@ GL_HD void eval_hash_unit(const Row& row, Emit& out) {
   const T qh = row.cst(CST_HASH);
   const T q4[4] = {qh, qh, qh, qh};
   T st[12];
+  {
+    // the swap: with s = wire 130 (a bit) and delta_i = s (in[4 + i] - in[i]) (wires 131..134), the permutation takes
+    // (in[i] + delta_i, in[4 + i] - delta_i, in[8..11]): the two digests of a Merkle step in the order the path bit says
+    const T sw = row.loc(H_SWAP);
+    T lhs[4], rhs[4], dl[4], pr[4], g[4];
 #pragma unroll
-  for (uint32_t i = 0; i < 12; i++) st[i] = H::add_rc0(row.loc(H_IN + i), i);
+    for (uint32_t i = 0; i < 4; i++) {
+      lhs[i] = row.loc(H_IN + i);
+      rhs[i] = row.loc(H_IN + 4 + i);
+      dl[i] = row.loc(H_DELTA + i);
+      pr[i] = F::sub(rhs[i], lhs[i]);
+    }
+    const T s4[4] = {sw, sw, sw, sw};
+    F::mul4(s4, pr, g);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      const T d = F::sub(dl[i], g[i]);
+      out.all(G5 + 1 + i, SELECTOR ? F::mul(qh, d) : d);
+      st[i] = H::add_rc0(F::add(lhs[i], dl[i]), i);
+      st[4 + i] = H::add_rc0(F::sub(rhs[i], dl[i]), 4 + i);
+      st[8 + i] = H::add_rc0(row.loc(H_IN + 8 + i), 8 + i);
+    }
+    const T bit = F::mul(sw, F::sub(sw, F::k(1)));
+    out.all(G5, SELECTOR ? F::mul(qh, bit) : bit);
+  }
   // a block of twelve wires against the state, selector applied four at a time; the wires become the state
   auto check12 = [&](uint32_t col0, uint32_t idx0) {
 #pragma unroll

@@ -27,6 +27,7 @@ constexpr uint64_t IR_MAGIC = 0x52494E5854475042ULL;     // "BPGTXNIR"
 constexpr uint64_t PROOF_BOX_MAGIC = 0x464F4F5250475042ULL;  // "BPGPROOF"
 constexpr uint64_t TABLES_MAGIC = 0x534C424154475042ULL;     // "BPGTABLS"
 constexpr uint32_t CIRCUIT_ROOT = 7, CIRCUIT_AGG = 8, CIRCUIT_BLOCK = 9;
+constexpr uint32_t AGG_PATH_PI0 = 10, BLOCK_PATH_PI0 = 9;  // where the children's (leaf digest, cap entry) words sit in the list
 constexpr size_t BOX_HDR = 4;
 const char* TABLE_NAMES[BP_NUM_TABLES] = {"arithmetic", "byte_packing", "cpu", "keccak", "keccak_sponge", "logic", "memory"};
 
@@ -44,6 +45,13 @@ struct Circuit {  // one preprocessed recursion circuit: constants commitment + 
   uint64_t* d_const_values = nullptr;
   Committed consts;
   uint64_t digest[4];
+  air::plonk::Layout lay{};  // AIR 8: the list the circuit hashes and the Merkle paths it walks
+};
+// One Merkle path a recursion circuit walks in its Poseidon rows: the leaf digest and the cap entry are words of the
+// proof's public-input list (Layout::path_pi0), the position and the siblings are witness.
+struct PathWitness {
+  uint64_t index = 0;
+  std::vector<uint64_t> siblings;  // 4 words per level, leaf upward
 };
 struct LightCircuit {
   std::vector<uint64_t> cap;
@@ -136,13 +144,15 @@ StarkCfg table_cfg_of(const bp_config& c, uint32_t log_n, uint32_t width) {
                   c.stark_pow_bits, c.arity_bits, c.final_poly_bits};
 }
 
-// pi_len: the length of the public-input list the circuit's hash rows absorb (AIR 8): 6 for a table's chain circuits
-// (digest, table, depth), 7 x 4 + 13 for the root circuit, 10 + 13 / 9 + 13 for the aggregation / block circuit
-int build_circuit(Worker& w, const StarkCfg& rc, uint64_t seed, uint32_t pi_len, Circuit* out) {
+// lay (AIR 8): the public-input list the circuit's hash rows absorb -- 6 words for a table's chain circuits (digest,
+// table, depth), 7 x 4 + 13 for the root circuit, 10 + 2 x 8 + 13 / 9 + 8 + 13 for the aggregation / block circuit -- and
+// the Merkle paths it walks: one per child proof of the aggregation circuit, the aggregation child's of the block circuit
+int build_circuit(Worker& w, const StarkCfg& rc, uint64_t seed, const air::plonk::Layout& lay, Circuit* out) {
   const uint64_t N = (uint64_t)1 << rc.log_n;
+  out->lay = lay;
   out->d_const_values = w.arena.alloc_words((size_t)rc.n_const * N);
   if (!out->d_const_values) return fail(BP_ERR_DEVICE, "state arena exhausted");
-  int rc2 = rc.air_id == air::PLONK ? launch_plonk_constants(out->d_const_values, rc.log_n, seed, pi_len, w.stream)
+  int rc2 = rc.air_id == air::PLONK ? launch_plonk_constants(out->d_const_values, rc.log_n, seed, lay, w.stream)
                                     : launch_synth_constants(out->d_const_values, rc.log_n, rc.n_const, seed, w.stream);
   if (rc2) return rc2;
   if ((rc2 = commit(w, out->d_const_values, rc.n_const, rc.log_n, rc.rate_bits, rc.cap_height, false, &out->consts)))
@@ -188,8 +198,9 @@ int emit_box(uint64_t kind, uint64_t circuit, const std::vector<uint64_t>& pi, c
 // launch and every host wait is shared; circuits, public inputs and transcripts are each proof's own).
 std::atomic<uint32_t> g_rec_batch{MAX_BATCH};  // bp_tune_rec_batch: 1 = one proof at a time
 std::atomic<int> g_side_lanes{1};               // bp_tune_side_lanes: 0 = no side lanes
+// paths (nullable): per proof the witness of the Merkle paths its circuit walks (Circuit::lay.n_paths of them)
 int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* const* circ, const std::vector<uint64_t>* pi,
-                    std::vector<uint64_t>* proofs) {
+                    std::vector<uint64_t>* proofs, const std::vector<PathWitness>* paths = nullptr) {
   const uint32_t cap = std::min<uint32_t>(std::min<uint32_t>(MAX_BATCH, std::max<uint32_t>(1, g_rec_batch.load(std::memory_order_relaxed))),
                                           std::max<uint32_t>(1, MAX_BATCH_QUERIES / std::max<uint32_t>(1, rc.num_queries)));
   const uint64_t N = (uint64_t)1 << rc.log_n;
@@ -212,8 +223,20 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
       const size_t n_pi = pi[first + b].size();
       if (rc.air_id == air::PLONK) {
         if (n_pi < 1 || n_pi > air::plonk::MAX_PI) return fail(BP_ERR_INVALID_INPUT, "a recursion circuit hashes 1..%u public inputs: got %zu", air::plonk::MAX_PI, n_pi);
+        if (n_pi != c.lay.pi_len) return fail(BP_ERR_INVALID_INPUT, "this circuit hashes a list of %u public inputs: got %zu", c.lay.pi_len, n_pi);
         poseidon_hash_rows(pi[first + b].data(), n_pi, &rows, pi_hash);
-        std::memcpy(w.hash_rows + (size_t)b * HASH_ROWS_WORDS, rows.data(), rows.size() * 8);
+        uint64_t* hr = w.hash_rows + (size_t)b * HASH_ROWS_WORDS;
+        std::memcpy(hr, rows.data(), rows.size() * 8);
+        if (c.lay.n_paths) {  // the children's Merkle paths, walked on the host the way the circuit's rows walk them
+          if (!paths || paths[first + b].size() != c.lay.n_paths) return fail(BP_ERR_INVALID_INPUT, "this circuit walks %u Merkle paths: their witness is missing", c.lay.n_paths);
+          for (uint32_t p = 0; p < c.lay.n_paths; p++) {
+            const PathWitness& pw = paths[first + b][p];
+            if (pw.siblings.size() != 4 * (size_t)c.lay.depth) return fail(BP_ERR_INVALID_INPUT, "Merkle path %u: %zu sibling words for %u levels", p, pw.siblings.size(), c.lay.depth);
+            uint64_t root[4];  // (not compared with the list's cap entry here: the copy constraints do that, and the verifier)
+            poseidon_merkle_rows(&pi[first + b][c.lay.path_pi0 + 8 * p], pw.index, pw.siblings.data(), c.lay.depth,
+                                 hr + (size_t)(air::plonk::HASH_ROWS_MAX + p * c.lay.depth) * air::plonk::H_WIRES, root);
+          }
+        }
       } else {
         hash_no_pad_host(pi[first + b].data(), n_pi, pi_hash);
       }
@@ -222,7 +245,8 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
       d_tv[b] = d_trace + (size_t)b * rc.n_cols * N;
       sa[b] = SynthTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0]};
       pa[b] = PlonkTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0], {pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]},
-                             w.hash_rows_dev + (size_t)b * HASH_ROWS_WORDS, (uint32_t)((n_pi + 7) / 8)};
+                             w.hash_rows_dev + (size_t)b * HASH_ROWS_WORDS, (uint32_t)((n_pi + 7) / 8),
+                             air::plonk::merkle_rows(c.lay), air::plonk::arith_row0(c.lay)};
       if (rc.air_id == air::PLONK) std::memcpy(ctl[b].pub, pi_hash, sizeof(pi_hash));  // bound to the circuit's first row
       consts[b] = &c.consts;
     }
@@ -242,9 +266,30 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
   return BP_OK;
 }
 int rec_prove(Worker& w, const StarkCfg& rc, const Circuit& circ, const std::vector<uint64_t>& pi,
-              std::vector<uint64_t>& proof) {
+              std::vector<uint64_t>& proof, const std::vector<PathWitness>* paths = nullptr) {
   const Circuit* c = &circ;
-  return rec_prove_batch(w, rc, 1, &c, &pi, &proof);
+  return rec_prove_batch(w, rc, 1, &c, &pi, &proof, paths);
+}
+// What the aggregation / block circuit walks for a child: the Merkle path of the child's FIRST query into its trace
+// oracle.  leaf = the digest of the opened trace row, cap_entry = the entry of the child's trace cap the path ends in
+// (both become words of the parent's public-input list), pw = position and siblings.  `child` has been parsed
+// (parse_box: its length is the layout's).
+void first_query_trace_path(const StarkCfg& c, const uint64_t* child, uint64_t leaf[4], uint64_t cap_entry[4], PathWitness* pw) {
+  const ProofLayout L = proof_layout(c);
+  const uint64_t* w = child + L.queries;
+  const uint64_t x = *w++;
+  if (c.n_const) w += c.n_const + (size_t)L.depth0 * 4;
+  if (c.n_cols <= 4) {  // Hasher::hash_or_noop
+    std::memset(leaf, 0, 32);
+    std::memcpy(leaf, w, c.n_cols * 8);
+  } else {
+    hash_no_pad_host(w, c.n_cols, leaf);
+  }
+  w += c.n_cols;
+  pw->index = x & (((uint64_t)1 << L.depth0) - 1);
+  pw->siblings.assign(w, w + 4 * (size_t)L.depth0);
+  const uint64_t top = (x >> L.depth0) & (((uint64_t)1 << c.cap_height) - 1);
+  std::memcpy(cap_entry, child + L.trace_cap + 4 * top, 32);
 }
 int rec_verify(const StarkCfg& rc, const LightCircuit& circ, const Box& b) {
   uint64_t pi_hash[4];
@@ -386,11 +431,15 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     s->table_offset[t] = idx;
     for (uint32_t d = cfg->table_log_lo[t]; d < cfg->table_log_hi[t]; d++, idx++)
-      if ((r = build_circuit(s->builder, rc, circuit_seed(t, d), 6, &s->table_circuits[idx]))) return r;
+      if ((r = build_circuit(s->builder, rc, circuit_seed(t, d), air::plonk::Layout{6, 0, 0, 0}, &s->table_circuits[idx]))) return r;
   }
-  static const uint32_t SPECIAL_PI_LEN[3] = {4 * BP_NUM_TABLES + BP_PV_WORDS, 10 + BP_PV_WORDS, 9 + BP_PV_WORDS};  // root, agg, block
+  // root, aggregation (two children: their paths' words follow the digests and flags), block (the aggregation child's)
+  const uint32_t depth = rc.log_n + rc.rate_bits - rc.cap_height;
+  const air::plonk::Layout special[3] = {{4 * BP_NUM_TABLES + BP_PV_WORDS, 0, 0, 0},
+                                         {AGG_PATH_PI0 + 2 * 8 + BP_PV_WORDS, 2, depth, AGG_PATH_PI0},
+                                         {BLOCK_PATH_PI0 + 8 + BP_PV_WORDS, 1, depth, BLOCK_PATH_PI0}};
   for (uint32_t k = 0; k < 3; k++)
-    if ((r = build_circuit(s->builder, rc, circuit_seed(CIRCUIT_ROOT + k, 0), SPECIAL_PI_LEN[k], &s->special[k]))) return r;
+    if ((r = build_circuit(s->builder, rc, circuit_seed(CIRCUIT_ROOT + k, 0), special[k], &s->special[k]))) return r;
   BPG_HIP(hipStreamSynchronize(s->builder.stream));
   for (uint32_t i = 0; i < cfg->n_workers; i++) {
     std::unique_ptr<Worker> w(new Worker());
@@ -1069,18 +1118,22 @@ int bp_generate_agg_proof(const bp_state* s, const uint8_t* lhs, size_t lhs_len,
     if (r) return fail(r, "%s", lhs_err.c_str());
     if (r_rhs) return fail(r_rhs, "%s", rhs_err.c_str());
   }
-  std::vector<uint64_t> pi(10 + BP_PV_WORDS);
+  std::vector<uint64_t> pi(AGG_PATH_PI0 + 16 + BP_PV_WORDS);
   proof_digest(s->rec_cfg, L.stark, &pi[0]);
   proof_digest(s->rec_cfg, R.stark, &pi[4]);
   pi[8] = lhs_is_agg != 0; pi[9] = rhs_is_agg != 0;
-  uint64_t* pv = &pi[10];
+  // per child the opened trace row of its first query and the cap entry above it: the circuit walks the path between them
+  std::vector<PathWitness> paths(2);
+  first_query_trace_path(s->rec_cfg, L.stark, &pi[AGG_PATH_PI0], &pi[AGG_PATH_PI0 + 4], &paths[0]);
+  first_query_trace_path(s->rec_cfg, R.stark, &pi[AGG_PATH_PI0 + 8], &pi[AGG_PATH_PI0 + 12], &paths[1]);
+  uint64_t* pv = &pi[AGG_PATH_PI0 + 16];
   pv[0] = L.pv[0]; pv[1] = R.pv[1]; pv[2] = L.pv[2]; pv[3] = R.pv[3];
   std::memcpy(pv + 4, L.pv + 4, 32); std::memcpy(pv + 8, R.pv + 8, 32);
   pv[12] = L.pv[12];
   (void)hipSetDevice(s->cfg.device);
   WorkerLease lease(s);
   std::vector<uint64_t> proof;
-  if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[1], pi, proof))) return r;
+  if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[1], pi, proof, &paths))) return r;
   if ((r = emit_box(1, CIRCUIT_AGG, pi, proof, out, out_len))) return r;
   remember_proof(s, *out, *out_len);
   return BP_OK;
@@ -1094,7 +1147,7 @@ int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t par
   int r;
   if ((r = parse_box(agg, agg_len, s->rec_cfg, &A))) return r;
   if (A.kind != 1) return fail(BP_ERR_INVALID_INPUT, "curr_block_agg_proof is not an aggregation proof");
-  std::vector<uint64_t> pi(9 + BP_PV_WORDS, 0);
+  std::vector<uint64_t> pi(BLOCK_PATH_PI0 + 8 + BP_PV_WORDS, 0);
   if (parent) {
     if ((r = parse_box(parent, parent_len, s->rec_cfg, &Pb))) return r;
     if (Pb.kind != 2) return fail(BP_ERR_INVALID_INPUT, "parent is not a block proof");
@@ -1106,11 +1159,13 @@ int bp_generate_block_proof(const bp_state* s, const uint8_t* parent, size_t par
   }
   if ((r = verify_child(s, A, "curr_block_agg_proof", agg, agg_len))) return r;
   proof_digest(s->rec_cfg, A.stark, &pi[4]);
-  std::memcpy(&pi[9], A.pv, BP_PV_WORDS * 8);
+  std::vector<PathWitness> paths(1);
+  first_query_trace_path(s->rec_cfg, A.stark, &pi[BLOCK_PATH_PI0], &pi[BLOCK_PATH_PI0 + 4], &paths[0]);
+  std::memcpy(&pi[BLOCK_PATH_PI0 + 8], A.pv, BP_PV_WORDS * 8);
   (void)hipSetDevice(s->cfg.device);
   WorkerLease lease(s);
   std::vector<uint64_t> proof;
-  if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[2], pi, proof))) return r;
+  if ((r = rec_prove(*lease.w, s->rec_cfg, s->special[2], pi, proof, &paths))) return r;
   if (b_height) *b_height = A.pv[12];  // block_metadata.block_number.low_u64(), proof_gen.rs:90-94
   if ((r = emit_box(2, CIRCUIT_BLOCK, pi, proof, out, out_len))) return r;
   remember_proof(s, *out, *out_len);

@@ -122,29 +122,65 @@ void poseidon_host(uint64_t s[12]) {
 // 8's Poseidon gate, air.hpp): per absorbed chunk one row of air::plonk::H_WIRES wires -- the state in, the state out and
 // the S-box inputs of every round in between.  rows: ceil(n / 8) x H_WIRES words; digest = the hash (the first four
 // output words of the last row).
+// one permutation with every S-box input kept: s in / out, w = the row's wires (H_FULL1, H_PART, H_FULL2; not in / out)
+static void permutation_wires(uint64_t (&s)[12], uint64_t* w) {
+  namespace pk = air::plonk;
+  for (int rnd = 0; rnd < 30; rnd++) {
+    for (int i = 0; i < 12; i++) s[i] = gl::addc(s[i], RC_HOST[rnd * 12 + i]);   // s = the S-box input of this round
+    const bool full = rnd < 4 || rnd >= 26;
+    if (rnd >= 1 && rnd <= 3) std::memcpy(w + pk::H_FULL1 + 12 * (rnd - 1), s, sizeof(s));
+    else if (rnd >= 4 && rnd <= 25) w[pk::H_PART + rnd - 4] = s[0];
+    else if (rnd >= 26) std::memcpy(w + pk::H_FULL2 + 12 * (rnd - 26), s, sizeof(s));
+    if (full) for (int i = 0; i < 12; i++) s[i] = sbox_host(s[i]);
+    else s[0] = sbox_host(s[0]);
+    mds_host_scalar(s);
+  }
+}
 void poseidon_hash_rows(const uint64_t* in, size_t n, std::vector<uint64_t>* rows, uint64_t digest[4]) {
   namespace pk = air::plonk;
   const size_t H = (n + 7) / 8;
-  rows->assign(H * pk::H_WIRES, 0);
+  rows->assign(H * pk::H_WIRES, 0);   // (swap and delta wires stay 0: a sponge row permutes what comes in)
   uint64_t s[12] = {0};
   for (size_t h = 0; h < H; h++) {
     uint64_t* w = rows->data() + h * pk::H_WIRES;
     const size_t k = std::min<size_t>(8, n - 8 * h);
     for (size_t i = 0; i < k; i++) s[i] = gl::canon(in[8 * h + i]);
     std::memcpy(w + pk::H_IN, s, sizeof(s));
-    for (int rnd = 0; rnd < 30; rnd++) {
-      for (int i = 0; i < 12; i++) s[i] = gl::addc(s[i], RC_HOST[rnd * 12 + i]);   // s = the S-box input of this round
-      const bool full = rnd < 4 || rnd >= 26;
-      if (rnd >= 1 && rnd <= 3) std::memcpy(w + pk::H_FULL1 + 12 * (rnd - 1), s, sizeof(s));
-      else if (rnd >= 4 && rnd <= 25) w[pk::H_PART + rnd - 4] = s[0];
-      else if (rnd >= 26) std::memcpy(w + pk::H_FULL2 + 12 * (rnd - 26), s, sizeof(s));
-      if (full) for (int i = 0; i < 12; i++) s[i] = sbox_host(s[i]);
-      else s[0] = sbox_host(s[0]);
-      mds_host_scalar(s);
-    }
+    permutation_wires(s, w);
     std::memcpy(w + pk::H_OUT, s, sizeof(s));
   }
   std::memcpy(digest, s, 32);
+}
+// The witness of one Merkle path walked by Poseidon-gate rows (merkle_proofs::verify_merkle_proof_to_cap as a circuit):
+// level l's row holds (node, sibling, 0) coming in, bit l of `index` on the swap wire, delta = bit (sibling - node), the
+// permutation of (left, right, 0) and its output, whose first four words are the next level's node.  rows: depth x
+// H_WIRES words; root = the last output (the cap entry the path arrives at).
+void poseidon_merkle_rows(const uint64_t leaf[4], uint64_t index, const uint64_t* siblings, uint32_t depth, uint64_t* rows,
+                          uint64_t root[4]) {
+  namespace pk = air::plonk;
+  uint64_t cur[4];
+  for (int i = 0; i < 4; i++) cur[i] = gl::canon(leaf[i]);
+  for (uint32_t l = 0; l < depth; l++, index >>= 1) {
+    uint64_t* w = rows + (size_t)l * pk::H_WIRES;
+    std::memset(w, 0, pk::H_WIRES * 8);
+    const uint64_t* sib = siblings + 4 * (size_t)l;
+    const uint64_t bit = index & 1;
+    uint64_t s[12] = {0};
+    for (int i = 0; i < 4; i++) {
+      const uint64_t sv = gl::canon(sib[i]);
+      w[pk::H_IN + i] = cur[i];
+      w[pk::H_IN + 4 + i] = sv;
+      const uint64_t d = bit ? gl::subc(sv, cur[i]) : 0;
+      w[pk::H_DELTA + i] = d;
+      s[i] = gl::addc(cur[i], d);
+      s[4 + i] = gl::subc(sv, d);
+    }
+    w[pk::H_SWAP] = bit;
+    permutation_wires(s, w);
+    std::memcpy(w + pk::H_OUT, s, sizeof(s));
+    std::memcpy(cur, s, 32);
+  }
+  std::memcpy(root, cur, 32);
 }
 void hash_no_pad_host(const uint64_t* in, size_t len, uint64_t out[4]) {
   uint64_t s[12] = {0};

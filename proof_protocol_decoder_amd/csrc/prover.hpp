@@ -15,6 +15,8 @@ void poseidon_host(uint64_t s[12]);
 void hash_no_pad_host(const uint64_t* in, size_t len, uint64_t out[4]);
 // the same hash with the witness of its in-circuit computation: ceil(n / 8) rows of air::plonk::H_WIRES wires (AIR 8)
 void poseidon_hash_rows(const uint64_t* in, size_t n, std::vector<uint64_t>* rows, uint64_t digest[4]);
+void poseidon_merkle_rows(const uint64_t leaf[4], uint64_t index, const uint64_t* siblings, uint32_t depth, uint64_t* rows,
+                          uint64_t root[4]);
 
 // plonky2::iop::challenger::Challenger: overwrite-mode duplex sponge, outputs popped from the back.
 class Challenger {
@@ -94,7 +96,7 @@ class DeviceArena {
   size_t cap_ = 0, off_ = 0, high_ = 0;
 };
 
-constexpr size_t HASH_ROWS_WORDS = (size_t)air::plonk::HASH_ROWS_MAX * air::plonk::H_WIRES;  // per proof
+constexpr size_t HASH_ROWS_WORDS = (size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::MERKLE_ROWS_MAX) * air::plonk::H_WIRES;  // per proof: list rows, then Merkle rows
 
 struct Committed {
   uint64_t *coeffs = nullptr, *lde = nullptr, *digests = nullptr;

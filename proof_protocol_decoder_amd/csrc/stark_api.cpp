@@ -131,7 +131,7 @@ int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, 
     if (c.n_const) {
       d_consts = w.arena.alloc_words((size_t)c.n_const * N);
       if (!d_consts) return fail(BP_ERR_DEVICE, "arena exhausted");
-      int r2 = c.air_id == air::PLONK ? launch_plonk_constants(d_consts, c.log_n, const_seed, LONE_PI_LEN, w.stream)
+      int r2 = c.air_id == air::PLONK ? launch_plonk_constants(d_consts, c.log_n, const_seed, air::plonk::Layout{LONE_PI_LEN, 0, 0, 0}, w.stream)
                                       : launch_synth_constants(d_consts, c.log_n, c.n_const, const_seed, w.stream);
       if (r2) return r2;
       if ((r2 = commit(w, d_consts, c.n_const, c.log_n, c.rate_bits, c.cap_height, false, &consts))) return r2;
@@ -276,7 +276,7 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
     fam(sp::K10, 1, 1, 2);
   } else if (air_id == air::PLONK) {
     namespace pk = air::plonk;
-    fam(pk::G0, 20, 0, 4); fam(pk::G1, 44, 0, 3); fam(pk::G2, 22, 0, 2); fam(pk::G3, 4, 2, 1); fam(pk::G4, 118, 0, 8);
+    fam(pk::G0, 20, 0, 4); fam(pk::G1, 44, 0, 3); fam(pk::G2, 22, 0, 2); fam(pk::G3, 4, 2, 1); fam(pk::G4, 118, 0, 8); fam(pk::G5, 5, 0, 3);
   } else if (air_id == air::ARITHMETIC_MUL) {
     namespace am = air::arithmetic_mul;
     fam(am::U0, 1, 0, 2); fam(am::U1, 256, 0, 2); fam(am::U2, 256, 0, 2); fam(am::U3, 672, 0, 2); fam(am::U4, 32, 0, 3);
@@ -361,30 +361,54 @@ BPG_ABI_CATCH("bp_arithmetic_mul_trace")
 // AIR 8: the preprocessed constants of the fixed PLONK-shaped circuit (85 columns: selectors, gate constants drawn from
 // `seed`, the hash-row selector, sigmas) for a circuit that hashes a public-input list of pi_len words, and its witness
 // (135 wires; free wires drawn from `seed`; the list pi is hashed in the hash rows, the hash lands in row 0).
-int bp_plonk_constants(uint64_t seed, uint32_t log_n, uint32_t pi_len, uint64_t* d_consts_out, void* stream) try {
+static int plonk_layout_of(const bp_plonk_layout* l, uint32_t log_n, air::plonk::Layout* out) {
+  if (!l) return fail(BP_ERR_INVALID_INPUT, "null plonk layout");
+  *out = air::plonk::Layout{l->pi_len, l->n_paths, l->path_depth, l->path_pi0};
+  if (!air::plonk::layout_ok(*out, 1u << log_n))
+    return fail(BP_ERR_INVALID_INPUT, "plonk layout: a list of 1..%u words, at most %u Merkle rows (n_paths x path_depth), the paths' words "
+                "(8 per path from path_pi0) inside the list, and room for one arithmetic group in 2^%u rows", air::plonk::MAX_PI,
+                air::plonk::MERKLE_ROWS_MAX, log_n);
+  return BP_OK;
+}
+int bp_plonk_constants(uint64_t seed, uint32_t log_n, const bp_plonk_layout* layout, uint64_t* d_consts_out, void* stream) try {
   if (!d_consts_out) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_constants: null output");
   if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_constants: log_n out of range");
-  int rc = init_ntt_kernels();
+  air::plonk::Layout lay;
+  int rc = plonk_layout_of(layout, log_n, &lay);
   if (rc) return rc;
-  return launch_plonk_constants(d_consts_out, log_n, seed, pi_len, as_stream(stream));
+  if ((rc = init_ntt_kernels())) return rc;
+  return launch_plonk_constants(d_consts_out, log_n, seed, lay, as_stream(stream));
 }
 BPG_ABI_CATCH("bp_plonk_constants")
-int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t* pi, uint32_t pi_len, uint32_t log_n,
-                   uint64_t* d_trace_out, void* stream) try {
+int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t* pi, const bp_plonk_layout* layout, const uint64_t* paths,
+                   uint32_t log_n, uint64_t* d_trace_out, void* stream) try {
   if (!d_consts || !pi || !d_trace_out) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: null argument");
   if (log_n < 4 || log_n > 26) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: log_n out of range");
-  if (pi_len < 1 || pi_len > air::plonk::MAX_PI) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: 1..%u public inputs", air::plonk::MAX_PI);
-  for (uint32_t j = 0; j < pi_len; j++) if (pi[j] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: non-canonical public input");
-  std::vector<uint64_t> rows;
+  air::plonk::Layout lay;
+  int rc = plonk_layout_of(layout, log_n, &lay);
+  if (rc) return rc;
+  if (lay.n_paths && !paths) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: the layout walks %u Merkle paths: their witness is missing", lay.n_paths);
+  for (uint32_t j = 0; j < lay.pi_len; j++) if (pi[j] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: non-canonical public input");
+  std::vector<uint64_t> rows, all((size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::merkle_rows(lay)) * air::plonk::H_WIRES, 0);
   uint64_t pub[4];
-  poseidon_hash_rows(pi, pi_len, &rows, pub);
-  // (a test / integration entry: the hash rows go up with a blocking copy into a buffer of their own)
+  poseidon_hash_rows(pi, lay.pi_len, &rows, pub);
+  std::memcpy(all.data(), rows.data(), rows.size() * 8);
+  const size_t path_words = 1 + 4 * (size_t)lay.depth;
+  for (uint32_t p = 0; p < lay.n_paths; p++) {
+    const uint64_t* pw = paths + p * path_words;
+    for (size_t j = 1; j < path_words; j++) if (pw[j] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: non-canonical sibling word");
+    uint64_t root[4];
+    poseidon_merkle_rows(pi + lay.path_pi0 + 8 * p, pw[0], pw + 1, lay.depth,
+                         all.data() + (size_t)(air::plonk::HASH_ROWS_MAX + p * lay.depth) * air::plonk::H_WIRES, root);
+  }
+  // (a test / integration entry: the rows go up with a blocking copy into a buffer of their own)
   uint64_t* d_rows = nullptr;
-  BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_rows), rows.size() * 8));
+  BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_rows), all.size() * 8));
   struct Free { uint64_t* p; ~Free() { (void)hipFree(p); } } guard{d_rows};
-  BPG_HIP(hipMemcpy(d_rows, rows.data(), rows.size() * 8, hipMemcpyHostToDevice));
-  PlonkTraceArgs a{d_trace_out, d_consts, seed, {pub[0], pub[1], pub[2], pub[3]}, d_rows, (uint32_t)(rows.size() / air::plonk::H_WIRES)};
-  int rc = launch_plonk_trace(&a, 1, log_n, as_stream(stream));
+  BPG_HIP(hipMemcpy(d_rows, all.data(), all.size() * 8, hipMemcpyHostToDevice));
+  PlonkTraceArgs a{d_trace_out, d_consts, seed, {pub[0], pub[1], pub[2], pub[3]}, d_rows, (uint32_t)(rows.size() / air::plonk::H_WIRES),
+                   air::plonk::merkle_rows(lay), air::plonk::arith_row0(lay)};
+  rc = launch_plonk_trace(&a, 1, log_n, as_stream(stream));
   if (rc) return rc;
   BPG_HIP(hipStreamSynchronize(as_stream(stream)));
   return BP_OK;

@@ -575,21 +575,22 @@ memory_lookup_filter_kernel(uint64_t* __restrict__ trace, uint32_t log_n, const 
 // ---------------------------------------------------------------- AIR 8 (plonk, air.hpp): constants, witness, copy products
 // The preprocessed columns of the fixed circuit: selectors by the row's place in its group of four, gate constants
 // drawn from the circuit's seed, the hash-row selector, and the sigmas sigma_j(w^i) = k_j' w^i' by air::plonk::sigma_of
-// for a circuit that hashes a public-input list of pi_len words.  grid = (rows/256, 85).
+// for a circuit of the given layout (the list it hashes, the Merkle paths it walks).  grid = (rows/256, 85).
 __global__ void __launch_bounds__(256)
-plonk_constants_kernel(uint64_t* __restrict__ out, uint32_t log_n, uint64_t seed, const uint64_t* __restrict__ tw_n, uint32_t pi_len) {
+plonk_constants_kernel(uint64_t* __restrict__ out, uint32_t log_n, uint64_t seed, const uint64_t* __restrict__ tw_n, bpg::air::plonk::Layout lay) {
   namespace pk = bpg::air::plonk;
   const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
   if (i >= n) return;
-  const uint32_t p = i & 3;
+  const uint32_t p = i & 3, a0 = pk::arith_row0(lay);
   uint64_t v;
-  if (k == pk::CST_ARITH) v = (i >= pk::ARITH_ROW0 && p != 2) || i == pk::ZERO_ROW;   // row 1: the gate that makes the zero wires
-  else if (k == pk::CST_SBOX) v = i >= pk::ARITH_ROW0 && p == 2;
-  else if (k == pk::CST_HASH) v = i >= pk::HASH_ROW0 && i < pk::HASH_ROW0 + pk::hash_rows(pi_len);
+  if (k == pk::CST_ARITH) v = (i >= a0 && p != 2) || i == pk::ZERO_ROW;   // row 1: the gate that makes the zero wires
+  else if (k == pk::CST_SBOX) v = i >= a0 && p == 2;
+  else if (k == pk::CST_HASH) v = (i >= pk::HASH_ROW0 && i < pk::HASH_ROW0 + pk::hash_rows(lay.pi_len)) ||
+                                  (i >= pk::MERKLE_ROW0 && i < pk::MERKLE_ROW0 + pk::merkle_rows(lay));
   else if (k < pk::CST_SIGMA) v = i == pk::ZERO_ROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, k, i);
   else {
     uint32_t c2, r2;
-    pk::sigma_of(k - pk::CST_SIGMA, i, n, pi_len, c2, r2);
+    pk::sigma_of(k - pk::CST_SIGMA, i, n, lay, c2, r2);
     v = gl::mulc(gl::pow((uint64_t)7, c2), root_pow(tw_n, log_n, r2));
   }
   out[(uint64_t)k * n + i] = v;
@@ -625,8 +626,9 @@ plonk_trace_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
       for (uint32_t j = 0; j < 4; j++) PUT(j, 0, batch.a[blockIdx.z].pub[j]);
     return;
   }
-  if (r0 < pk::ARITH_ROW0) return;  // rows 4..11: the hash region, written by plonk_hash_rows_kernel
-  const bool first_group = r0 == pk::ARITH_ROW0;  // its c inputs are the public inputs
+  const uint32_t a0 = batch.a[blockIdx.z].arith_row0;
+  if (r0 < a0) return;  // rows 4 .. a0 - 1: the hash rows and the Merkle rows, written by plonk_hash_rows_kernel
+  const bool first_group = r0 == a0;  // its c inputs are the public inputs
   if (unit)  // the advice wires of the three arithmetic rows are free
     for (uint32_t p = 0; p < 4; p++)
       if (p != 2)
@@ -660,18 +662,19 @@ plonk_trace_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
 #undef PUT
 #undef CST
 }
-// The hash region (rows 4..11) of the witness: row 4 + h, h < n_hash_rows, takes its first H_WIRES wires from the rows the
-// host made while it hashed the public-input list (bpg::poseidon_hash_rows: the list is a few dozen words and the host
+// The Poseidon rows (4 .. arith_row0 - 1) of the witness: row 4 + h takes its wires from the rows the host made -- h <
+// n_hash_rows while it hashed the public-input list (bpg::poseidon_hash_rows: the list is a few dozen words and the host
 // has just hashed it anyway -- one lane chaining six permutations would cost 0.3 ms of a proof's critical path,
-// profiles/r5_transcript_latency.txt); every other wire of the region is free.  grid = (1, 8 rows, proofs) x 135 lanes.
+// profiles/r5_transcript_latency.txt), 8 <= h < 8 + n_merkle_rows while it walked the children's Merkle paths
+// (bpg::poseidon_merkle_rows); every other row of the region is free.  grid = (1, rows of the region, proofs) x 135 lanes.
 __global__ void __launch_bounds__(256)
 plonk_hash_rows_kernel(bpg::BatchOf<bpg::PlonkTraceArgs> batch, uint32_t log_n) {
   namespace pk = bpg::air::plonk;
   __builtin_amdgcn_s_setprio(3);
   const bpg::PlonkTraceArgs& a = batch.a[blockIdx.z];
   const uint32_t n = 1u << log_n, c = threadIdx.x, h = blockIdx.y, row = pk::HASH_ROW0 + h;
-  if (c >= pk::N_COLS || row >= n) return;
-  const bool given = h < a.n_hash_rows && c < pk::H_WIRES;
+  if (c >= pk::N_COLS || row >= a.arith_row0) return;
+  const bool given = h < a.n_hash_rows || (h >= pk::HASH_ROWS_MAX && h < pk::HASH_ROWS_MAX + a.n_merkle_rows);
   a.trace[(uint64_t)c * n + row] = given ? a.hash_rows[(uint64_t)h * pk::H_WIRES + c] : rnd(a.seed, c, row);
 }
 // Copy products, step 1 of 3: per row and challenge set the ten chunk ratios num_k / den_k (one inversion per row:
@@ -1493,13 +1496,17 @@ int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uin
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
-int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, uint32_t pi_len, hipStream_t st) {
-  if (pi_len < 1 || pi_len > air::plonk::MAX_PI)
-    return fail(BP_ERR_INVALID_INPUT, "a recursion circuit hashes a public-input list of 1..%u words: got %u", air::plonk::MAX_PI, pi_len);
+int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, const air::plonk::Layout& lay, hipStream_t st) {
+  if (lay.pi_len < 1 || lay.pi_len > air::plonk::MAX_PI)
+    return fail(BP_ERR_INVALID_INPUT, "a recursion circuit hashes a public-input list of 1..%u words: got %u", air::plonk::MAX_PI, lay.pi_len);
+  if (log_n >= 4 && log_n < 31 && !air::plonk::layout_ok(lay, 1u << log_n))
+    return fail(BP_ERR_INVALID_INPUT, "plonk circuit layout: %u paths of %u levels (at most %u Merkle rows), their words at %u.. of a "
+                "list of %u, and one arithmetic group must fit 2^%u rows", lay.n_paths, lay.depth, air::plonk::MERKLE_ROWS_MAX,
+                lay.path_pi0, lay.pi_len, log_n);
   if (log_n < 4) return fail(BP_ERR_INVALID_INPUT, "the plonk circuit needs 16 rows: the hash region and one arithmetic group");
   const uint64_t* tw_n = nullptr;
   if (int rc = get_table(0, log_n, 0, &tw_n)) return rc;
-  plonk_constants_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), air::plonk::N_CONST), 256, 0, st>>>(d_out, log_n, seed, tw_n, pi_len);
+  plonk_constants_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), air::plonk::N_CONST), 256, 0, st>>>(d_out, log_n, seed, tw_n, lay);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
@@ -1508,9 +1515,16 @@ int launch_plonk_trace(const PlonkTraceArgs* a, uint32_t batch, uint32_t log_n, 
   for (uint32_t b = 0; b < batch; b++)
     if (!a[b].hash_rows || a[b].n_hash_rows < 1 || a[b].n_hash_rows > air::plonk::HASH_ROWS_MAX)
       return fail(BP_ERR_INVALID_INPUT, "launch_plonk_trace: the witness of the hash rows is missing (poseidon_hash_rows)");
+  uint32_t region = 0;
+  for (uint32_t b = 0; b < batch; b++) {
+    if (a[b].arith_row0 < air::plonk::MERKLE_ROW0 || (a[b].arith_row0 & 3) || a[b].arith_row0 + 4 > (1ull << log_n) ||
+        air::plonk::MERKLE_ROW0 + a[b].n_merkle_rows > a[b].arith_row0 || a[b].n_merkle_rows > air::plonk::MERKLE_ROWS_MAX)
+      return fail(BP_ERR_INVALID_INPUT, "launch_plonk_trace: %u Merkle rows and first arithmetic row %u do not fit 2^%u rows", a[b].n_merkle_rows, a[b].arith_row0, log_n);
+    region = std::max(region, a[b].arith_row0 - air::plonk::HASH_ROW0);
+  }
   plonk_trace_kernel<<<dim3(ceil_div((((uint64_t)1 << log_n) / 4) * air::plonk::N_SLOTS, 256), 1, batch), 256, 0, st>>>(batch_of(a, batch), log_n);
   BPG_LAUNCH_CHECK();
-  plonk_hash_rows_kernel<<<dim3(1, air::plonk::HASH_ROWS_MAX, batch), 256, 0, st>>>(batch_of(a, batch), log_n);
+  plonk_hash_rows_kernel<<<dim3(1, region, batch), 256, 0, st>>>(batch_of(a, batch), log_n);
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }

@@ -190,14 +190,17 @@ int launch_lookup_filter(uint32_t air_id, uint64_t* d_trace, uint32_t log_n, con
 int launch_arithmetic_mul_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint32_t log_n, uint64_t seed, hipStream_t st);
 int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_cols, uint32_t log_n, hipStream_t st);
 // AIR 8 (plonk): the constants (selectors, gate constants, sigmas of the fixed circuit) and the witness
-// pi_len: the length of the public-input list the circuit hashes in its hash rows (air::plonk)
-int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, uint32_t pi_len, hipStream_t st);
+// lay: the public-input list the circuit hashes in its hash rows and the Merkle paths it walks (air::plonk::Layout)
+int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, const air::plonk::Layout& lay, hipStream_t st);
 struct PlonkTraceArgs {
   uint64_t* trace;
   const uint64_t* consts;
   uint64_t seed, pub[4];        // pub = hash_no_pad(the public-input list) = the first output words of the last hash row
-  const uint64_t* hash_rows;    // device-visible [n_hash_rows][air::plonk::H_WIRES]: the witness of that hash (poseidon_hash_rows)
+  // device-visible [HASH_ROWS_MAX + n_merkle_rows][air::plonk::H_WIRES]: the witness of that hash in the first
+  // n_hash_rows rows (poseidon_hash_rows), of the Merkle paths from row HASH_ROWS_MAX on (poseidon_merkle_rows)
+  const uint64_t* hash_rows;
   uint32_t n_hash_rows;
+  uint32_t n_merkle_rows = 0, arith_row0 = air::plonk::MERKLE_ROW0;  // air::plonk::arith_row0(the circuit's layout)
 };
 int launch_plonk_trace(const PlonkTraceArgs* a, uint32_t batch, uint32_t log_n, hipStream_t st);
 // every proof of the batch has the shape and the unit spreading of q[0]

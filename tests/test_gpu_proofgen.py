@@ -148,7 +148,7 @@ def test_verifier_rejects_corruption(pg, p_state, chain):
     v = pg.VerifierState.from_prover_state(p_state)
     w = words(blk.intern).copy()
     rng = np.random.default_rng(5)
-    for i in list(rng.integers(4, w.size, size=10)) + [4 + 9, 4 + 22 + 16]:  # a public value, the trace cap
+    for i in list(rng.integers(4, w.size, size=10)) + [4 + 17, 4 + 30 + 16]:  # a public value, the trace cap
         bad = w.copy()
         bad[i] ^= np.uint64(1 << int(rng.integers(0, 60)))
         with pytest.raises(pg.ProofGenError) as e:

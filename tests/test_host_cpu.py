@@ -86,7 +86,7 @@ def test_product_cpu_verifier_accepts_oracle_proofs_and_rejects_corruption(cpu_c
     with pytest.raises(pg.ProofGenError):
         v.verify(agg.tobytes())            # not a block proof
     rng = np.random.default_rng(11)
-    for i in list(rng.integers(4, blk.size, size=16)) + [4 + 9, 4 + 22 + 16, blk.size - 1]:
+    for i in list(rng.integers(4, blk.size, size=16)) + [4 + 17, 4 + 30 + 16, blk.size - 1]:
         bad = blk.copy()
         bad[i] ^= np.uint64(1 << int(rng.integers(0, 60)))
         with pytest.raises(pg.ProofGenError) as e:
@@ -297,7 +297,7 @@ def test_block_driver_world_size_2_over_gloo(tmp_path, oracle):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     a, b = np.load(out2), np.load(out1)
     # the tree shape differs (2 slices vs 1) so the proofs differ, but the public values must not
-    assert a.shape == b.shape and (a[4 + 9:4 + 22] == b[4 + 9:4 + 22]).all()
+    assert a.shape == b.shape and (a[4 + 17:4 + 30] == b[4 + 17:4 + 30]).all()
 
 
 def _run_driver(tmp_path, world, n_txns, port, fail_rank=-1, omp="1", top_tree="pairwise", fail_agg=-1):
@@ -318,7 +318,7 @@ def test_block_driver_world_size_8_uneven_split(tmp_path, oracle):
     equal the single-process run's."""
     a = np.load(_run_driver(tmp_path, 8, 21, 29621))
     b = np.load(_run_driver(tmp_path, 1, 21, 29622, omp="8"))
-    assert a.shape == b.shape and (a[4 + 9:4 + 22] == b[4 + 9:4 + 22]).all()
+    assert a.shape == b.shape and (a[4 + 17:4 + 30] == b[4 + 17:4 + 30]).all()
     # the pairwise top tree (rank 2k+1 -> 2k, 4k+2 -> 4k, 4 -> 0: rank 0 makes three aggregations, not seven) is the
     # balanced tree over ranks the gather form builds on rank 0: the same block proof, byte for byte
     c = np.load(_run_driver(tmp_path, 8, 21, 29626, top_tree="gather"))

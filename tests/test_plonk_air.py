@@ -57,17 +57,42 @@ def hash_no_pad_py(oracle, words):
     return [int(x) for x in st[:4]]
 
 
-@pytest.mark.parametrize("pi_len", [4, 6, 8, 9, 23, 41, 64])
-def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len):
-    """The circuit for a public-input list of pi_len words: gates hold row by row, the hash rows are the permutations of
-    hash_no_pad(list) -- checked against the oracle's plain permutation, S-box input by S-box input --, their output is
-    what row 0 carries, sigma is a permutation of the routed wires that only ties equal values."""
+def merkle_fixture(oracle, rng, depth, n_paths, cap_height=1):
+    """n_paths trees of 2^(depth + cap_height) random leaf digests each, one leaf picked in each: per path its
+    (leaf digest, cap entry) -- the eight words the public-input list carries -- and the witness words
+    (position below the cap entry, siblings upward)."""
+    words, wit = [], []
+    for _ in range(n_paths):
+        leaves = rng.integers(0, P, size=(1 << (depth + cap_height), 4), dtype=np.uint64)
+        index = int(rng.integers(0, 1 << (depth + cap_height)))
+        sibs, top = oracle.merkle_path(leaves, index, cap_height)
+        assert sibs.size == 4 * depth
+        words += [int(x) for x in leaves[index]] + [int(x) for x in top]
+        wit += [index & ((1 << depth) - 1)] + [int(x) for x in sibs]
+    return words, wit
+
+
+# (pi_len, n_paths, depth, path_pi0): lists of every chunking; the aggregation / block circuits' layouts at a small depth
+LAYOUTS = [(4, 0, 0, 0), (6, 0, 0, 0), (8, 0, 0, 0), (9, 0, 0, 0), (23, 0, 0, 0), (41, 0, 0, 0), (64, 0, 0, 0),
+           (39, 2, 5, 10), (30, 1, 7, 9), (17, 1, 1, 3), (64, 2, 6, 40)]
+
+
+@pytest.mark.parametrize("pi_len,n_paths,depth,path_pi0", LAYOUTS)
+def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_paths, depth, path_pi0):
+    """The circuit for a public-input list of pi_len words that walks n_paths Merkle paths: gates hold row by row, the
+    hash rows are the permutations of hash_no_pad(list) -- checked against the oracle's plain permutation, S-box input by
+    S-box input --, their output is what row 0 carries, the Merkle rows climb from the list's leaf digest to the list's
+    cap entry, sigma is a permutation of the routed wires that only ties equal values."""
     log_n, n = 6, 64
-    rng = np.random.default_rng(pi_len)
+    rng = np.random.default_rng(pi_len + 100 * n_paths)
     pi = rng.integers(0, P, size=pi_len, dtype=np.uint64)
-    k = oracle.plonk_constants(log_n, CSEED, pi_len)
-    t = oracle.plonk_trace(log_n, SEED, pi, k)
+    words, wit = merkle_fixture(oracle, rng, depth, n_paths)
+    pi[path_pi0:path_pi0 + 8 * n_paths] = words
+    k = oracle.plonk_constants(log_n, CSEED, pi_len, n_paths, depth, path_pi0)
+    t = oracle.plonk_trace(log_n, SEED, pi, k, n_paths, depth, path_pi0, wit)
     H = (pi_len + 7) // 8
+    T = n_paths * depth
+    A0 = (12 + T + 3) // 4 * 4
     want_hash = hash_no_pad_py(oracle, pi)
     assert [int(t[j, 0]) for j in range(4)] == want_hash
     assert [int(x) for x in oracle.hash_no_pad(pi)] == want_hash
@@ -78,7 +103,8 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len):
     CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
     for i in range(n):
         qa, qs, qh = int(k[0, i]), int(k[1, i]), int(k[4, i])
-        want = (1, 0, 0) if i == 1 else (0, 0, 1) if 4 <= i < 4 + H else (0, 0, 0) if i < 12 else ((0, 1, 0) if i % 4 == 2 else (1, 0, 0))
+        want = ((1, 0, 0) if i == 1 else (0, 0, 1) if 4 <= i < 4 + H or 12 <= i < 12 + T else (0, 0, 0) if i < A0
+                else ((0, 1, 0) if i % 4 == 2 else (1, 0, 0)))
         assert (qa, qs, qh) == want, i
         if qa:
             for s in range(20):
@@ -92,6 +118,11 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len):
                 assert int(t[4 * u, i]) == x and int(t[4 * u + 3, i]) == pow(x, 7, P)
         if qh:   # one permutation: replay it in Python integers from the row's own wires
             st = [int(t[c, i]) for c in range(12)]
+            sw, delta = int(t[130, i]), [int(t[131 + j, i]) for j in range(4)]
+            assert sw in (0, 1) and delta == [sw * (st[4 + j] - st[j]) % P for j in range(4)]
+            assert sw == 0 or i >= 12                        # a sponge row does not swap
+            if sw:
+                st = st[4:8] + st[0:4] + st[8:]
             assert [int(x) for x in oracle.poseidon(np.array(st, dtype=np.uint64))[0]] == [int(t[12 + c, i]) for c in range(12)]
             for rnd in range(30):
                 st = [(x + RC[12 * rnd + c]) % P for c, x in enumerate(st)]
@@ -104,8 +135,20 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len):
                 st = [pow(x, 7, P) if (rnd < 4 or rnd >= 26 or c == 0) else x for c, x in enumerate(st)]
                 st = [(sum(CIRC[(c - r) % 12] * st[c] for c in range(12)) + (8 * st[0] if r == 0 else 0)) % P for r in range(12)]
             assert st == [int(t[12 + c, i]) for c in range(12)]
-            h = i - 4
-            assert [int(t[c, i]) for c in range(min(8, pi_len - 8 * h))] == [int(x) for x in pi[8 * h:8 * h + 8]]
+            if i < 12:
+                h = i - 4
+                assert [int(t[c, i]) for c in range(min(8, pi_len - 8 * h))] == [int(x) for x in pi[8 * h:8 * h + 8]]
+    # the Merkle rows: from the list's leaf digest, level by level (the position bit on the swap wire), to the list's cap entry
+    for p in range(n_paths):
+        node, index = words[8 * p:8 * p + 4], wit[p * (1 + 4 * depth)]
+        for l in range(depth):
+            row = 12 + p * depth + l
+            sib = wit[p * (1 + 4 * depth) + 1 + 4 * l:][:4]
+            assert [int(t[c, row]) for c in range(12)] == node + sib + [0, 0, 0, 0] and int(t[130, row]) == (index >> l) & 1
+            pair = sib + node if (index >> l) & 1 else node + sib
+            node = [int(x) for x in oracle.hash_no_pad(np.array(pair, dtype=np.uint64))]
+            assert [int(t[12 + c, row]) for c in range(4)] == node
+        assert node == words[8 * p + 4:8 * p + 8]
     # sigma is a permutation of the routed wires that only ties equal values; the classes the circuit needs exist
     w = pow(7, (P - 1) >> log_n, P)
     ident = {(mul(pow(7, j, P), pow(w, i, P))): (j, i) for j in range(80) for i in range(n)}
@@ -116,9 +159,10 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len):
         assert int(t[j, i]) == int(t[j2, i2])
     last = 4 + H - 1
     # public input 0 = word 0 of the hash = c_0 of the first arithmetic rows: one cycle
-    assert nxt[(0, 0)] == (2, 12) and nxt[(2, 12)] == (2, 13) and nxt[(2, 13)] == (12, last) and nxt[(12, last)] == (0, 0)
-    assert nxt[(3, 16)] == (0, 17) and nxt[(0, 17)] == (4 * 19 + 1, 17) and nxt[(4 * 19 + 1, 17)] == (3, 16)
-    assert nxt[(3, 17)] == (0, 18) and nxt[(3, 18)] == (0, 19)
+    assert nxt[(0, 0)] == (2, A0) and nxt[(2, A0)] == (2, A0 + 1) and nxt[(2, A0 + 1)] == (12, last) and nxt[(12, last)] == (0, 0)
+    g = A0 + 4
+    assert nxt[(3, g)] == (0, g + 1) and nxt[(0, g + 1)] == (4 * 19 + 1, g + 1) and nxt[(4 * 19 + 1, g + 1)] == (3, g)
+    assert nxt[(3, g + 1)] == (0, g + 2) and nxt[(3, g + 2)] == (0, g + 3)
     # the sponge: the capacity words of the first hash row are zero wires of row 1, later rows carry the previous output
     assert nxt[(8, 4)] == (4 * [c for c in range(12) if c >= 8 or (H == 1 and c >= pi_len)].index(8) + 3, 1) and int(t[8, 4]) == 0
     if H > 1:
@@ -127,7 +171,23 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len):
         k_free = pi_len % 8          # the first state word the short last chunk leaves alone
         assert nxt[(k_free, last)] == ((12 + k_free, last - 1) if H > 1 else nxt[(k_free, last)])
         assert nxt[(k_free, last)] != (k_free, last)
-    assert sum(1 for a, b in nxt.items() if a != b) > 80 * n // 3
+    assert sum(1 for a, b in nxt.items() if a != b) > 80 * (n - A0) // 3
+    # the paths' ends are wires of the list, their levels are chained, all their capacity words hang on one zero wire
+    for p in range(n_paths):
+        r0, r1 = 12 + p * depth, 12 + p * depth + depth - 1
+        for j in range(4):
+            i_leaf, i_top = path_pi0 + 8 * p + j, path_pi0 + 8 * p + 4 + j
+            assert nxt[(j, r0)] == (i_leaf % 8, 4 + i_leaf // 8) and nxt[(i_leaf % 8, 4 + i_leaf // 8)] == (j, r0)
+            assert nxt[(12 + j, r1)] == (i_top % 8, 4 + i_top // 8) and nxt[(i_top % 8, 4 + i_top // 8)] == (12 + j, r1)
+            for l in range(depth - 1):
+                assert nxt[(12 + j, r0 + l)] == (j, r0 + l + 1) and nxt[(j, r0 + l + 1)] == (12 + j, r0 + l)
+    if T:
+        cyc, at = [], (79, 1)
+        while at not in cyc:
+            cyc.append(at)
+            at = nxt[at]
+        assert sorted(cyc) == sorted([(79, 1)] + [(8 + j, 12 + r) for r in range(T) for j in range(4)])
+        assert all(int(t[c, r]) == 0 for c, r in cyc)
 
 
 @pytest.mark.parametrize("log_n", [5, 8])
@@ -186,14 +246,57 @@ def test_a_witness_that_breaks_one_rule_yields_a_rejected_proof(oracle, col, row
     assert product_verify(cfg, proof, cap, pub) != 0
 
 
+# a circuit that walks two paths of five levels (rows 12..21; the list's path words at 10..25): one wrong cell each
+MERKLE_BREAKS = [(4 + 2, 12 + 3, "a sibling of path 0 (level 3)"), (130, 12 + 1, "the position bit of a level is not a bit"),
+                 (131 + 2, 12 + 7, "a delta word without its swap"), (1, 12 + 5, "the leaf digest of path 1 is not the list's"),
+                 (12 + 3, 12 + 4, "path 0 does not arrive at the list's cap entry"), (2, 12 + 2, "a level does not take the node below"),
+                 (8 + 1, 12 + 6, "a capacity word of a Merkle row is not zero"), (10 % 8 + 2, 4 + 10 // 8, "the list names another leaf digest"),
+                 (60 + 4, 12 + 9, "a partial-round wire of a Merkle row")]
+
+
+@pytest.mark.parametrize("col,row,what", MERKLE_BREAKS, ids=[b[2][:44] for b in MERKLE_BREAKS])
+def test_a_wrong_merkle_path_yields_a_rejected_proof(oracle, col, row, what):
+    """merkle_proofs::verify_merkle_proof_to_cap in-circuit: the valid witness is accepted by both verifiers; with one cell
+    changed -- a sibling, a position bit, the leaf digest the list names, the node a level takes over -- the proof is
+    rejected by both.  A flipped position bit with its delta words recomputed is another path: it must not arrive."""
+    log_n, layout = 6, (39, 2, 5, 10)
+    rng = np.random.default_rng(5)
+    pi = rng.integers(0, P, size=layout[0], dtype=np.uint64)
+    words, wit = merkle_fixture(oracle, rng, layout[2], layout[1])
+    pi[10:26] = words
+    pub = oracle.hash_no_pad(pi)
+    cfg = small_cfg(oracle, log_n, pub)
+    k = oracle.plonk_constants(log_n, CSEED, *layout)
+    t = oracle.plonk_trace(log_n, 78, pi, k, *layout[1:], wit)
+    if col == 130 and what.startswith("the position bit"):
+        proof, ctl, chv, cap = prove(oracle, cfg, k, t)          # the untouched witness first
+        assert oracle.stark_verify(cfg, proof, ctl, chv, cap) == 0 and product_verify(cfg, proof, cap, pub) == 0
+        # the other side of the same level, consistently (bit and deltas): every gate of the row holds, the path does not arrive
+        wit2 = list(wit)
+        wit2[0] ^= 1 << 1
+        t2 = oracle.plonk_trace(log_n, 78, pi, k, *layout[1:], wit2)
+        assert int(t2[130, 13]) == 1 - int(t[130, 13])
+        proof, ctl, chv, cap = prove(oracle, cfg, k, t2)
+        assert oracle.stark_verify(cfg, proof, ctl, chv, cap) != 0 and product_verify(cfg, proof, cap, pub) != 0
+        t[col, row] = np.uint64(2)
+    else:
+        t[col, row] = np.uint64((int(t[col, row]) + 1) % P)
+    try:
+        proof, ctl, chv, cap = prove(oracle, cfg, k, t)
+    except RuntimeError:
+        return
+    assert oracle.stark_verify(cfg, proof, ctl, chv, cap) != 0
+    assert product_verify(cfg, proof, cap, pub) != 0
+
+
 def test_air_registry_describes_the_plonk_air():
     import proof_protocol_decoder_amd as pkg
     assert pkg.lib().bp_air_count() == 9
     d = pkg.ops.air_describe(8)
     assert d.name == b"plonk" and (d.fixed_n_cols, d.n_cols, d.n_const_max, d.n_aux, d.degree) == (135, 135, 85, 20, 9)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (208, 22, 11)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (213, 22, 11)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
-    assert fams == [(0, 20, 0, 4), (20, 44, 0, 3), (64, 22, 0, 2), (86, 4, 2, 1), (90, 118, 0, 8), (208, 10, 0, 9), (218, 1, 2, 1), (219, 10, 0, 9), (229, 1, 2, 1)]
+    assert fams == [(0, 20, 0, 4), (20, 44, 0, 3), (64, 22, 0, 2), (86, 4, 2, 1), (90, 118, 0, 8), (208, 5, 0, 3), (213, 10, 0, 9), (223, 1, 2, 1), (224, 10, 0, 9), (234, 1, 2, 1)]
 
 
 def test_recursion_layer_on_the_plonk_circuit_chain_of_proofs(oracle):
@@ -212,7 +315,7 @@ def test_recursion_layer_on_the_plonk_circuit_chain_of_proofs(oracle):
     blk = st.block(None, agg)
     for p in (t0, agg, blk):
         assert st.verify(p) == 0
-    assert int(blk[4 + 22 + 14]) == 8 and int(blk[4 + 22 + 4]) == 20        # header of the block proof's STARK: AIR 8, 20 aux columns
+    assert int(blk[4 + 30 + 14]) == 8 and int(blk[4 + 30 + 4]) == 20        # header of the block proof's STARK: AIR 8, 20 aux columns
     b = pg.ProverStateBuilder()
     for t, name in enumerate(pg.TABLES):
         getattr(b, "set_%s_circuit_size" % name)(range(SMALL_PLONK["table_log_lo"][t], SMALL_PLONK["table_log_hi"][t]))
@@ -222,7 +325,7 @@ def test_recursion_layer_on_the_plonk_circuit_chain_of_proofs(oracle):
     v.verify_any(t0.tobytes())
     v.verify_any(agg.tobytes())
     rng = np.random.default_rng(12)
-    for i in list(rng.integers(4, blk.size, size=10)) + [4 + 9 + 3, 4 + 22 + 16]:   # a public value; the trace cap
+    for i in list(rng.integers(4, blk.size, size=10)) + [4 + 17 + 3, 4 + 30 + 16, 4 + 9 + 1, 4 + 9 + 6]:   # a public value; the trace cap; the aggregation child's leaf digest, its cap entry
         bad = blk.copy()
         bad[i] ^= np.uint64(1 << int(rng.integers(0, 60)))
         with pytest.raises(pg.ProofGenError):
