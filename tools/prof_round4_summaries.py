@@ -39,6 +39,9 @@ def k5_summary():
         m = re.search(r"quotient_air_kernel<(\d+)u?>", r["Kernel_Name"])
         if m:
             acc[int(m.group(1))][r["Counter_Name"]] += float(r["Counter_Value"])
+        elif "quotient_plonk_hash_kernel" in r["Kernel_Name"]:   # AIR 8's Poseidon-gate pass: part of the same quotient
+            acc[8][r["Counter_Name"]] += float(r["Counter_Value"])
+            acc[108][r["Counter_Name"]] += float(r["Counter_Value"])
     if not acc:
         return
     with open(os.path.join(O, K5 + "_k5_counters.txt"), "w") as out:
@@ -55,6 +58,11 @@ def k5_summary():
                       % (c["name"], c["rows"], c["cols"], c["aux"], c["constraints"], v.get("SQ_INSTS_VALU", 0),
                          64.0 * v.get("SQ_INSTS_VALU", 0) / (c["rows"] * c["constraints"]), fetch / 1e6, read_alg / 1e6,
                          fetch / read_alg if read_alg else 0, 1024 * v.get("WRITE_SIZE", 0) / 1e6))
+        if 108 in acc:
+            c, v = cases[8], acc[108]
+            out.write("# of plonk's figures, the Poseidon-gate pass (quotient_plonk_hash_kernel, 123 of the constraints) alone: valu_wave_insts=%.4e "
+                      "fetched_MB=%.1f (it re-reads the 135 wires and one constant column: 131/240 of the algorithmic read again)\n"
+                      % (v.get("SQ_INSTS_VALU", 0), 2 * 1024 * v.get("FETCH_SIZE", 0) / 1e6))
     print(open(os.path.join(O, K5 + "_k5_counters.txt")).read())
 
 
