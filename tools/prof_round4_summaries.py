@@ -68,7 +68,7 @@ def k5_summary():
 
 def family(k):
     for name in ("leaf_hash_mx_kernel", "leaf_hash_rows", "leaf_hash", "merkle_level_mx_kernel", "merkle_level", "merkle_subtree",
-                 "pow_grind", "perm_batch", "fri_layer_leaf", "ntt", "quotient_air_kernel", "quotient", "fri_", "openings",
+                 "pow_grind", "perm_batch", "fri_layer_leaf", "ntt", "quotient_air_kernel", "quotient_plonk_hash_kernel", "quotient", "fri_", "openings",
                  "aux_suffix", "keccak_ctl", "synth_", "keccak_trace", "query", "combine", "power_vector", "alpha"):
         if name in k:
             return name

@@ -5,7 +5,7 @@ no DPP / SDWA -- issues every 2.2..2.7 cycles (2.45 used), everything with a car
 64-bit operands every 4.1..4.8 (4.5 used).  A STATIC count: the kernels' hot code is straight-line, unrolled rounds /
 butterflies executed the same number of times, so the static mix of a kernel's body is its dynamic mix to a few percent.
 Families are weighted by their share of a txn proof's VALU instructions in the LOADED run (SQ counters,
-profiles/r4_sq_loaded_by_kernel.txt).  Writes profiles/r5_valu_class_mix.txt; bench.py reads its last line.
+profiles/r5_sq_loaded_by_kernel.txt).  Writes profiles/r5_valu_class_mix.txt; bench.py reads its last line.
 
     python tools/valu_class_mix.py"""
 import os
@@ -24,6 +24,7 @@ FAMILIES = [  # (family in the SQ summary, source, mangled-name fragments of the
     ("merkle_level_mx_kernel", "hash_kernels.hip", ["merkle_level_mx_kernel"]),
     ("quotient_air_kernel", "stark_kernels.hip", ["quotient_air_kernelILj8E", "quotient_air_kernelILj0E"]),
     ("pow_grind", "stark_kernels.hip", ["pow_grind_mx_kernelILi3E"]),
+    ("quotient", "stark_kernels.hip", ["quotient_plonk_hash_kernel"]),   # AIR 8's Poseidon-gate pass (+ the small sum / chunk kernels)
 ]
 
 
