@@ -27,11 +27,11 @@ enum { PW = 135, PK = 85, ROUTED = 80, SLOTS = 20, SBOX = 11, SB0 = 80, SIG0 = 5
  * words of the last hash row are the public-input wires of row 0.  Arithmetic groups start at row 12. */
 /* Round 5, second step: the Poseidon gate has upstream's swap (wire 130 = a bit s, wires 131..134 = delta_i = s (in[4+i] -
  * in[i]); the permutation runs on (in[i] + delta_i, in[4+i] - delta_i, in[8..11])), and a circuit may walk Merkle paths with
- * it: rows 12 .. 12 + n_paths * depth - 1, one level per row -- node in 0..3, sibling in 4..7, zeros in 8..11, position bit
+ * it: rows 17 .. 17 + n_paths * depth - 1, one level per row -- node in 0..3, sibling in 4..7, zeros in 8..11, position bit
  * on the swap wire, the node above in out 0..3.  Path p's leaf digest is words path_pi0 + 8p .. + 3 of the public-input
  * list, the cap entry it arrives at words path_pi0 + 8p + 4 .. + 7.  Arithmetic groups start at the first multiple of four
  * past the Merkle rows. */
-enum { HROW0 = 4, MROW0 = 12, ZROW = 1, HIN = 0, HOUT = 12, HF1 = 24, HPART = 60, HF2 = 82, HSWAP = 130, HDELTA = 131, HWIRES = 135 };
+enum { HROW0 = 4, MROW0 = 17 /* after at most 13 rows of list */, ZROW = 1, HIN = 0, HOUT = 12, HF1 = 24, HPART = 60, HF2 = 82, HSWAP = 130, HDELTA = 131, HWIRES = 135 };
 static unsigned arith_row0_of(unsigned n_paths, unsigned depth) { return (MROW0 + n_paths * depth + 3) / 4 * 4; }
 static const gl_t PRC[360] = {
 #include "poseidon_rc.inc"

@@ -29,13 +29,14 @@ typedef struct {
   gl_t* const_values;
   orc_committed* consts;
   gl_t digest[4];
-  unsigned n_paths, path_pi0; /* the Merkle paths the circuit walks (plonk_air.c) */
+  unsigned n_paths, path_pi0, depth; /* the Merkle paths the circuit walks (plonk_air.c) */
 } circuit_t;
 
 typedef struct orc_pg_state {
   orc_pg_config cfg;
   orc_stark_cfg rec;
   circuit_t table[NUM_TABLES][32];
+  circuit_t shrink[NUM_TABLES];
   circuit_t special[3];
 } orc_pg_state;
 
@@ -72,16 +73,17 @@ void orc_pg_state_free(orc_pg_state* s) {
   if (!s) return;
   for (int t = 0; t < NUM_TABLES; t++) for (int d = 0; d < 32; d++) circuit_free(&s->table[t][d]);
   for (int k = 0; k < 3; k++) circuit_free(&s->special[k]);
+  for (int t = 0; t < NUM_TABLES; t++) circuit_free(&s->shrink[t]);
   free(s);
 }
 /* circuits are preprocessed lazily (same data as libbpg's eager bp_state_build) */
-static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned path_pi0) {
+static circuit_t* get_circuit_depth(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0) {
   if (!c->built) {
     size_t n = (size_t)1 << s->rec.log_n;
     c->const_values = (gl_t*)malloc(s->rec.n_const * n * sizeof(gl_t));
-    c->n_paths = n_paths; c->path_pi0 = path_pi0;
+    c->n_paths = n_paths; c->path_pi0 = path_pi0; c->depth = depth;
     if (s->rec.air_id == ORC_AIR_PLONK)
-      orc_plonk_constants(seed, s->rec.log_n, pi_len, n_paths, s->rec.log_n + s->rec.rate_bits - s->rec.cap_height, path_pi0, c->const_values);
+      orc_plonk_constants(seed, s->rec.log_n, pi_len, n_paths, depth, path_pi0, c->const_values);
     else orc_synth_constants(seed, s->rec.log_n, s->rec.n_const, c->const_values);
     c->consts = orc_commit_values(c->const_values, s->rec.log_n, s->rec.n_const, s->rec.rate_bits, s->rec.cap_height);
     orc_hash_no_pad(orc_committed_cap(c->consts), (size_t)4 << s->rec.cap_height, c->digest);
@@ -91,14 +93,25 @@ static circuit_t* get_circuit(orc_pg_state* s, circuit_t* c, uint64_t seed, unsi
 }
 /* the length of the public-input list each circuit hashes in-circuit: a table's chain circuits (digest, table, depth) 6;
  * root 7 digests + the public values; aggregation two digests, two flags + the public values; block two digests, a flag + them */
-static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) { return get_circuit(s, &s->table[t][d], circuit_seed(t, d), 6, 0, 0); }
+/* Every recursion circuit walks one Merkle path per child (the child's first trace opening: leaf digest and cap entry are
+ * eight more words of the list).  A table's chain: level 0 by the circuit of the table's height (its child is the table's
+ * STARK proof: d + rate - cap levels), the levels above by the table's shrink circuit (a recursion-shaped child). */
+enum { CHAIN_PATH_AT = 6, CHAIN_PI = 6 + 8, ROOT_PATHS_AT = 4 * NUM_TABLES, ROOT_PI = 4 * NUM_TABLES + 8 * NUM_TABLES + PV_WORDS };
+static circuit_t* get_circuit_depth(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0);
+static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) {
+  return get_circuit_depth(s, &s->table[t][d], circuit_seed(t, d), CHAIN_PI, 1, d + s->cfg.stark_rate_bits - s->cfg.stark_cap_height, CHAIN_PATH_AT);
+}
+static circuit_t* shrink_circuit(orc_pg_state* s, int t) {
+  return get_circuit_depth(s, &s->shrink[t], circuit_seed(t, 255), CHAIN_PI, 1, s->rec.log_n + s->rec.rate_bits - s->rec.cap_height, CHAIN_PATH_AT);
+}
 /* The aggregation circuit also walks, per child, the Merkle path of the child's first trace opening (its leaf digest and
  * the cap entry above it: eight more words of the list per child, after the digests and flags); the block circuit walks
  * its aggregation child's. */
 enum { AGG_PATHS_AT = 10, BLOCK_PATH_AT = 9, AGG_PI = 10 + 16 + PV_WORDS, BLOCK_PI = 9 + 8 + PV_WORDS };
 static circuit_t* special_circuit(orc_pg_state* s, int k) {
-  static const unsigned PI_LEN[3] = {4 * NUM_TABLES + PV_WORDS, AGG_PI, BLOCK_PI}, PATHS[3] = {0, 2, 1}, AT[3] = {0, AGG_PATHS_AT, BLOCK_PATH_AT};
-  return get_circuit(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0), PI_LEN[k], PATHS[k], AT[k]);
+  static const unsigned PI_LEN[3] = {ROOT_PI, AGG_PI, BLOCK_PI}, PATHS[3] = {NUM_TABLES, 2, 1}, AT[3] = {ROOT_PATHS_AT, AGG_PATHS_AT, BLOCK_PATH_AT};
+  return get_circuit_depth(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0), PI_LEN[k], PATHS[k],
+                           s->rec.log_n + s->rec.rate_bits - s->rec.cap_height, AT[k]);
 }
 
 /* paths: the witness of the circuit's Merkle paths (circ->n_paths of them, 1 + 4 depth words each), or NULL */
@@ -114,8 +127,7 @@ static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_
   orc_stark_cfg rcfg = s->rec; /* the PLONK-shaped circuit binds the hash of the public inputs to its first row */
   if (rcfg.air_id == ORC_AIR_PLONK) {
     memcpy(rcfg.pub, pi_hash, sizeof(rcfg.pub));
-    orc_plonk_trace(pi_hash[0], pi, (unsigned)n_pi, circ->n_paths, rcfg.log_n + rcfg.rate_bits - rcfg.cap_height, circ->path_pi0,
-                    paths, circ->const_values, rcfg.log_n, trace);
+    orc_plonk_trace(pi_hash[0], pi, (unsigned)n_pi, circ->n_paths, circ->depth, circ->path_pi0, paths, circ->const_values, rcfg.log_n, trace);
   } else {
     orc_synth_trace(pi_hash[0], &s->rec, circ->const_values, trace);
   }
@@ -483,35 +495,50 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
   gl_t pv[PV_WORDS], ctl[4], *tproofs[NUM_TABLES];
   int rc = pg_tables(s, I, wit, tcfg, pv, ctl, tproofs);
   if (rc) return rc;
-  gl_t digest[NUM_TABLES][4];
+  /* per chain: the digest of its newest proof and that proof's first trace opening (leaf digest, cap entry, path) */
+  gl_t digest[NUM_TABLES][4], leaf_cap[NUM_TABLES][8], *path[NUM_TABLES];
+  const size_t rec_path_words = 1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height);
   for (int t = 0; t < NUM_TABLES; t++) {
+    const size_t table_path_words = 1 + 4 * (size_t)(tcfg[t].log_n + tcfg[t].rate_bits - tcfg[t].cap_height);
+    path[t] = (gl_t*)malloc((table_path_words > rec_path_words ? table_path_words : rec_path_words) * sizeof(gl_t));
     orc_proof_digest(&tcfg[t], tproofs[t], digest[t]);
+    orc_proof_first_query_path(&tcfg[t], tproofs[t], leaf_cap[t], leaf_cap[t] + 4, path[t]);
     free(tproofs[t]);
   }
   size_t sw = orc_proof_words(&s->rec);
   gl_t* proof = (gl_t*)malloc(sw * sizeof(gl_t));
   for (int t = 0; t < NUM_TABLES && !rc; t++) {
-    circuit_t* circ = table_circuit(s, t, tcfg[t].log_n);
     for (uint32_t depth = 0; depth < cfg->shrink_depth && !rc; depth++) {
-      gl_t pi[6] = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (gl_t)t, depth};
-      rc = rec_prove(s, circ, pi, 6, NULL, proof);
-      if (!rc) orc_proof_digest(&s->rec, proof, digest[t]);
+      circuit_t* circ = depth == 0 ? table_circuit(s, t, tcfg[t].log_n) : shrink_circuit(s, t);
+      gl_t pi[CHAIN_PI] = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (gl_t)t, depth};
+      memcpy(pi + CHAIN_PATH_AT, leaf_cap[t], sizeof(leaf_cap[t]));
+      rc = rec_prove(s, circ, pi, CHAIN_PI, path[t], proof);
+      if (!rc) {
+        orc_proof_digest(&s->rec, proof, digest[t]);
+        orc_proof_first_query_path(&s->rec, proof, leaf_cap[t], leaf_cap[t] + 4, path[t]);
+      }
     }
   }
   if (!rc) {
-    gl_t pi[4 * NUM_TABLES + PV_WORDS];
-    for (int t = 0; t < NUM_TABLES; t++) memcpy(pi + 4 * t, digest[t], 32);
-    memcpy(pi + 4 * NUM_TABLES, pv, sizeof(pv));
-    rc = rec_prove(s, special_circuit(s, 0), pi, 4 * NUM_TABLES + PV_WORDS, NULL, proof);
-    if (!rc) *out = emit_box(0, pi, 4 * NUM_TABLES + PV_WORDS, proof, sw, out_words);
+    gl_t pi[ROOT_PI], *paths = (gl_t*)malloc(NUM_TABLES * rec_path_words * sizeof(gl_t));
+    for (int t = 0; t < NUM_TABLES; t++) {
+      memcpy(pi + 4 * t, digest[t], 32);
+      memcpy(pi + ROOT_PATHS_AT + 8 * t, leaf_cap[t], sizeof(leaf_cap[t]));
+      memcpy(paths + t * rec_path_words, path[t], rec_path_words * sizeof(gl_t));
+    }
+    memcpy(pi + ROOT_PATHS_AT + 8 * NUM_TABLES, pv, sizeof(pv));
+    rc = rec_prove(s, special_circuit(s, 0), pi, ROOT_PI, paths, proof);
+    if (!rc) *out = emit_box(0, pi, ROOT_PI, proof, sw, out_words);
+    free(paths);
   }
+  for (int t = 0; t < NUM_TABLES; t++) free(path[t]);
   free(proof);
   return rc;
 }
 
 typedef struct { uint64_t kind, n_pi; const gl_t *pi, *pv, *stark; } box_t;
 static int parse_box(orc_pg_state* s, const gl_t* w, size_t words, box_t* b) {
-  if (words < BOX_HDR + PV_WORDS || w[0] != BOX_MAGIC || w[1] > 2 || w[2] < PV_WORDS || w[2] > 64) return -2;
+  if (words < BOX_HDR + PV_WORDS || w[0] != BOX_MAGIC || w[1] > 2 || w[2] < PV_WORDS || w[2] > 104) return -2;
   b->kind = w[1]; b->n_pi = w[2];
   if (words != BOX_HDR + b->n_pi + orc_proof_words(&s->rec)) return -2;
   b->pi = w + BOX_HDR; b->pv = b->pi + b->n_pi - PV_WORDS; b->stark = b->pi + b->n_pi;

@@ -974,8 +974,8 @@ constexpr uint32_t N_COLS = 135, N_CONST = 85, N_ROUTED = 80, N_SLOTS = 20, N_SB
 constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_HASH = 4, CST_SIGMA = 5;
 constexpr uint32_t COL_SBOX = 80;
 constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86, G4 = 90, G5 = 208;
-constexpr uint32_t HASH_ROW0 = 4, HASH_ROWS_MAX = 8, ZERO_ROW = 1, MAX_PI = 8 * HASH_ROWS_MAX;
-constexpr uint32_t MERKLE_ROW0 = HASH_ROW0 + HASH_ROWS_MAX, MERKLE_ROWS_MAX = 64, MERKLE_ZERO_COL = 79;
+constexpr uint32_t HASH_ROW0 = 4, HASH_ROWS_MAX = 13, ZERO_ROW = 1, MAX_PI = 8 * HASH_ROWS_MAX;
+constexpr uint32_t MERKLE_ROW0 = HASH_ROW0 + HASH_ROWS_MAX, MERKLE_ROWS_MAX = 96, MERKLE_ZERO_COL = 79;
 constexpr uint32_t H_IN = 0, H_OUT = 12, H_FULL1 = 24, H_PART = 60, H_FULL2 = 82, H_SWAP = 130, H_DELTA = 131, H_WIRES = 135;
 // What a circuit of this family does besides its arithmetic groups: it hashes a public-input list of pi_len words
 // (rows 4 ..), and it walks n_paths Merkle paths of `depth` levels each (rows 12 ..): path p's leaf digest is list words
@@ -985,7 +985,7 @@ struct Layout {
 };
 GL_HD uint32_t hash_rows(uint32_t pi_len) { return (pi_len + 7) / 8; }
 GL_HD uint32_t merkle_rows(const Layout& L) { return L.n_paths * L.depth; }
-GL_HD uint32_t arith_row0(const Layout& L) { return (MERKLE_ROW0 + merkle_rows(L) + 3) & ~3u; }  // 12 without paths
+GL_HD uint32_t arith_row0(const Layout& L) { return (MERKLE_ROW0 + merkle_rows(L) + 3) & ~3u; }  // 20 without paths
 GL_HD bool layout_ok(const Layout& L, uint32_t n) {
   return L.pi_len >= 1 && L.pi_len <= MAX_PI && merkle_rows(L) <= MERKLE_ROWS_MAX && (L.n_paths == 0 || L.depth >= 1) &&
          L.path_pi0 + 8 * L.n_paths <= L.pi_len && arith_row0(L) + 4 <= n;

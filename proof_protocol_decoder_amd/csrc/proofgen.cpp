@@ -28,6 +28,8 @@ constexpr uint64_t PROOF_BOX_MAGIC = 0x464F4F5250475042ULL;  // "BPGPROOF"
 constexpr uint64_t TABLES_MAGIC = 0x534C424154475042ULL;     // "BPGTABLS"
 constexpr uint32_t CIRCUIT_ROOT = 7, CIRCUIT_AGG = 8, CIRCUIT_BLOCK = 9;
 constexpr uint32_t AGG_PATH_PI0 = 10, BLOCK_PATH_PI0 = 9;  // where the children's (leaf digest, cap entry) words sit in the list
+constexpr uint32_t CHAIN_PATH_PI0 = 6, ROOT_PATH_PI0 = 4 * BP_NUM_TABLES;  // ... of a chain circuit's one child, of the root circuit's seven
+constexpr uint32_t SHRINK_SEED_DEGREE = 255;  // circuit_seed(table, 255): the table's shrink circuit (levels >= 1 of its chain)
 constexpr size_t BOX_HDR = 4;
 const char* TABLE_NAMES[BP_NUM_TABLES] = {"arithmetic", "byte_packing", "cpu", "keccak", "keccak_sponge", "logic", "memory"};
 
@@ -64,7 +66,8 @@ struct bp_state {
   bp_config cfg;
   StarkCfg rec_cfg;
   Worker builder;                       // owns the persistent (preprocessed) device memory
-  std::vector<Circuit> table_circuits;  // [table][degree - lo] flattened
+  std::vector<Circuit> table_circuits;  // [table][degree - lo] flattened: level 0 of a table's chain (its child is the table's STARK proof)
+  Circuit shrink_circuits[BP_NUM_TABLES];  // levels >= 1 of a table's chain (their child is a recursion-shaped proof)
   uint32_t table_offset[BP_NUM_TABLES];
   Circuit special[3];                   // root, agg, block
   // worker pool: `&ProverState` is shared by many threads in the reference (proof_gen.rs:40)
@@ -171,7 +174,7 @@ int parse_box(const uint8_t* bytes, size_t len, const StarkCfg& rc, Box* b) {
   const uint64_t* wds = reinterpret_cast<const uint64_t*>(bytes);
   if (wds[0] != PROOF_BOX_MAGIC) return fail(BP_ERR_INVALID_INPUT, "proof: bad magic");
   b->kind = wds[1]; b->n_pi = wds[2]; b->circuit = wds[3];
-  if (b->kind > 2 || b->n_pi < BP_PV_WORDS || b->n_pi > 64) return fail(BP_ERR_INVALID_INPUT, "proof: bad header");
+  if (b->kind > 2 || b->n_pi < BP_PV_WORDS || b->n_pi > air::plonk::MAX_PI) return fail(BP_ERR_INVALID_INPUT, "proof: bad header");
   const size_t sw = proof_layout(rc).total;
   if (len / 8 != BOX_HDR + b->n_pi + sw) return fail(BP_ERR_INVALID_INPUT, "proof: wrong length for this circuit");
   b->pi = wds + BOX_HDR;
@@ -380,6 +383,9 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
   const StarkCfg rc = rec_cfg_of(*cfg);
   int r = check_cfg(rc);
   if (r) return r;
+  if (cfg->shrink_depth < 1)
+    return fail(BP_ERR_INVALID_INPUT, "shrink_depth must be at least 1: the root circuit walks Merkle paths of the recursion shape's depth, "
+                "so its children are recursion-shaped proofs, not the tables' STARK proofs");
   uint32_t n_circ = 0;
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     if (cfg->table_log_lo[t] >= cfg->table_log_hi[t] || cfg->table_log_hi[t] > 31)
@@ -401,7 +407,7 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
   // persistent memory: per circuit K*n values + K*n coeffs + K*m LDE + digests
   const uint64_t N = (uint64_t)1 << rc.log_n, M = N << rc.rate_bits;
   const size_t per = ((size_t)rc.n_const * (2 * N + M) + 2 * M * 4 + 4096) * 8;
-  const size_t circuits_bytes = per * (n_circ + 3) + (64u << 20);
+  const size_t circuits_bytes = per * (n_circ + 3 + BP_NUM_TABLES) + (64u << 20);
   {
     // size the whole state against the device BEFORE the first allocation: a late hipMalloc failure would name one
     // arena, not the configuration that does not fit
@@ -413,7 +419,7 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
       return fail(BP_ERR_DEVICE,
                   "prover state does not fit device %d: %u preprocessed circuits %.1f GiB + %u prover arenas x %.1f GiB = "
                   "%.1f GiB, %.1f GiB free of %.1f GiB (lower n_workers or arena_bytes, or narrow the table ranges)",
-                  cfg->device, n_circ + 3, circuits_bytes / 1073741824.0, cfg->n_workers,
+                  cfg->device, n_circ + 3 + BP_NUM_TABLES, circuits_bytes / 1073741824.0, cfg->n_workers,
                   cfg->arena_bytes / 1073741824.0, need / 1073741824.0, free_b / 1073741824.0, total_b / 1073741824.0);
   }
   // from here on device memory is owned by *s: release it on every early return
@@ -431,11 +437,19 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     s->table_offset[t] = idx;
     for (uint32_t d = cfg->table_log_lo[t]; d < cfg->table_log_hi[t]; d++, idx++)
-      if ((r = build_circuit(s->builder, rc, circuit_seed(t, d), air::plonk::Layout{6, 0, 0, 0}, &s->table_circuits[idx]))) return r;
+      // (digest, table, level) and the child's (leaf digest, cap entry): the child of level 0 is the table's STARK proof,
+      // whose trace tree has d + rate - cap levels below its cap
+      if ((r = build_circuit(s->builder, rc, circuit_seed(t, d),
+                             air::plonk::Layout{CHAIN_PATH_PI0 + 8, 1, d + cfg->stark_rate_bits - cfg->stark_cap_height, CHAIN_PATH_PI0},
+                             &s->table_circuits[idx]))) return r;
   }
-  // root, aggregation (two children: their paths' words follow the digests and flags), block (the aggregation child's)
+  // Every recursion circuit walks one Merkle path per child: root (seven chains), aggregation (two children: their
+  // paths' words follow the digests and flags), block (the aggregation child's), a table's shrink circuit (the level below)
   const uint32_t depth = rc.log_n + rc.rate_bits - rc.cap_height;
-  const air::plonk::Layout special[3] = {{4 * BP_NUM_TABLES + BP_PV_WORDS, 0, 0, 0},
+  for (int t = 0; t < BP_NUM_TABLES; t++)
+    if ((r = build_circuit(s->builder, rc, circuit_seed(t, SHRINK_SEED_DEGREE), air::plonk::Layout{CHAIN_PATH_PI0 + 8, 1, depth, CHAIN_PATH_PI0},
+                           &s->shrink_circuits[t]))) return r;
+  const air::plonk::Layout special[3] = {{ROOT_PATH_PI0 + 8 * BP_NUM_TABLES + BP_PV_WORDS, BP_NUM_TABLES, depth, ROOT_PATH_PI0},
                                          {AGG_PATH_PI0 + 2 * 8 + BP_PV_WORDS, 2, depth, AGG_PATH_PI0},
                                          {BLOCK_PATH_PI0 + 8 + BP_PV_WORDS, 1, depth, BLOCK_PATH_PI0}};
   for (uint32_t k = 0; k < 3; k++)
@@ -585,7 +599,7 @@ int bp_state_root_after(const uint64_t root_before[4], uint64_t seed, uint64_t t
 int bp_proof_public_values(const uint8_t* proof, size_t len, uint64_t pv_out[BP_PV_WORDS], int* kind_out) try {
   if (!proof || len % 8 || len < (BOX_HDR + BP_PV_WORDS) * 8) return fail(BP_ERR_INVALID_INPUT, "proof: truncated");
   const uint64_t* w = reinterpret_cast<const uint64_t*>(proof);
-  if (w[0] != PROOF_BOX_MAGIC || w[1] > 2 || w[2] < BP_PV_WORDS || w[2] > 64 || len / 8 < BOX_HDR + w[2])
+  if (w[0] != PROOF_BOX_MAGIC || w[1] > 2 || w[2] < BP_PV_WORDS || w[2] > air::plonk::MAX_PI || len / 8 < BOX_HDR + w[2])
     return fail(BP_ERR_INVALID_INPUT, "proof: bad header");
   if (pv_out) std::memcpy(pv_out, w + BOX_HDR + w[2] - BP_PV_WORDS, BP_PV_WORDS * 8);
   if (kind_out) *kind_out = (int)w[1];
@@ -894,9 +908,14 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
     *out_len = o.size() * 8;
     return BP_OK;
   }
-  uint64_t digest[BP_NUM_TABLES][4];
+  // per child of a recursion circuit: its digest, and the Merkle path of its first trace opening (leaf digest, cap entry:
+  // words of the parent's public-input list; position and siblings: witness of the parent's Merkle rows)
+  uint64_t digest[BP_NUM_TABLES][4], leaf_cap[BP_NUM_TABLES][8];
+  std::vector<PathWitness> child_path[BP_NUM_TABLES];
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     proof_digest(tcfg[t], tp.proof[t].data(), digest[t]);
+    child_path[t].resize(1);
+    first_query_trace_path(tcfg[t], tp.proof[t].data(), leaf_cap[t], leaf_cap[t] + 4, &child_path[t][0]);
     std::vector<uint64_t>().swap(tp.proof[t]);
   }
   std::vector<uint64_t> proof;
@@ -906,25 +925,35 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   // proofs have one shape: level k of all seven is ONE batch proved in lock-step (rec_prove_batch) -- seven
   // transcripts stepped together, every kernel launch and host wait shared --, then level k + 1.  (Until round 4 each
   // chain was its own sequence of 6..16-column launches: 88 of a transaction's 118 LDE launches and most of its
-  // 1,620 kernel launches.)
+  // 1,620 kernel launches.)  Level 0 is proved by the circuit of the table's height (its child is the table's STARK
+  // proof), the levels above by the table's shrink circuit.
   {
     const Circuit* circ[BP_NUM_TABLES];
-    for (int t = 0; t < BP_NUM_TABLES; t++)
-      circ[t] = &s->table_circuits[s->table_offset[t] + (tcfg[t].log_n - cfg.table_log_lo[t])];
     std::vector<uint64_t> pis[BP_NUM_TABLES], chain_proof[BP_NUM_TABLES];
     for (uint32_t depth = 0; depth < cfg.shrink_depth; depth++) {
       if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted in the recursion chains (level %u)", depth);
-      for (int t = 0; t < BP_NUM_TABLES; t++)
+      for (int t = 0; t < BP_NUM_TABLES; t++) {
+        circ[t] = depth == 0 ? &s->table_circuits[s->table_offset[t] + (tcfg[t].log_n - cfg.table_log_lo[t])] : &s->shrink_circuits[t];
         pis[t] = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (uint64_t)t, depth};
-      if ((r = rec_prove_batch(w, s->rec_cfg, BP_NUM_TABLES, circ, pis, chain_proof))) return r;
-      for (int t = 0; t < BP_NUM_TABLES; t++) proof_digest(s->rec_cfg, chain_proof[t].data(), digest[t]);
+        pis[t].insert(pis[t].end(), leaf_cap[t], leaf_cap[t] + 8);
+      }
+      if ((r = rec_prove_batch(w, s->rec_cfg, BP_NUM_TABLES, circ, pis, chain_proof, child_path))) return r;
+      for (int t = 0; t < BP_NUM_TABLES; t++) {
+        proof_digest(s->rec_cfg, chain_proof[t].data(), digest[t]);
+        first_query_trace_path(s->rec_cfg, chain_proof[t].data(), leaf_cap[t], leaf_cap[t] + 4, &child_path[t][0]);
+      }
     }
   }
-  // root proof
+  // root proof: the seven chains' digests, their seven (leaf digest, cap entry) pairs, the public values
   std::vector<uint64_t> pi;
+  std::vector<PathWitness> root_paths(BP_NUM_TABLES);
   for (int t = 0; t < BP_NUM_TABLES; t++) pi.insert(pi.end(), digest[t], digest[t] + 4);
+  for (int t = 0; t < BP_NUM_TABLES; t++) {
+    pi.insert(pi.end(), leaf_cap[t], leaf_cap[t] + 8);
+    root_paths[t] = std::move(child_path[t][0]);
+  }
   pi.insert(pi.end(), pv.begin(), pv.end());
-  if ((r = rec_prove(w, s->rec_cfg, s->special[0], pi, proof))) return r;
+  if ((r = rec_prove(w, s->rec_cfg, s->special[0], pi, proof, &root_paths))) return r;
   if ((r = emit_box(0, CIRCUIT_ROOT, pi, proof, out, out_len))) return r;
   remember_proof(s, *out, *out_len);
   return BP_OK;

@@ -1503,7 +1503,7 @@ int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, const
     return fail(BP_ERR_INVALID_INPUT, "plonk circuit layout: %u paths of %u levels (at most %u Merkle rows), their words at %u.. of a "
                 "list of %u, and one arithmetic group must fit 2^%u rows", lay.n_paths, lay.depth, air::plonk::MERKLE_ROWS_MAX,
                 lay.path_pi0, lay.pi_len, log_n);
-  if (log_n < 4) return fail(BP_ERR_INVALID_INPUT, "the plonk circuit needs 16 rows: the hash region and one arithmetic group");
+  if (log_n < 5) return fail(BP_ERR_INVALID_INPUT, "the plonk circuit needs 32 rows: the Poseidon rows (4..19) and one arithmetic group");
   const uint64_t* tw_n = nullptr;
   if (int rc = get_table(0, log_n, 0, &tw_n)) return rc;
   plonk_constants_kernel<<<dim3(ceil_div((uint64_t)1 << log_n, 256), air::plonk::N_CONST), 256, 0, st>>>(d_out, log_n, seed, tw_n, lay);

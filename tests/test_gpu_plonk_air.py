@@ -27,9 +27,10 @@ def dev_constants(bpg, log_n, seed, pi_len=4, n_paths=0, depth=0, path_pi0=0):
     return out
 
 
-# (log_n, pi_len, n_paths, depth, path_pi0): lists of every chunking; the aggregation / block layouts at default depth 12
-CIRCUITS = [(4, 4, 0, 0, 0), (8, 6, 0, 0, 0), (13, 41, 0, 0, 0), (6, 23, 0, 0, 0), (5, 64, 0, 0, 0), (5, 8, 0, 0, 0), (5, 1, 0, 0, 0),
-            (13, 39, 2, 12, 10), (13, 30, 1, 12, 9), (6, 39, 2, 5, 10), (7, 64, 2, 32, 40), (5, 17, 1, 1, 3)]
+# (log_n, pi_len, n_paths, depth, path_pi0): lists of every chunking; the aggregation / block / root / chain layouts at default depth 12
+CIRCUITS = [(5, 4, 0, 0, 0), (8, 6, 0, 0, 0), (13, 41, 0, 0, 0), (6, 23, 0, 0, 0), (5, 64, 0, 0, 0), (5, 8, 0, 0, 0), (5, 1, 0, 0, 0), (5, 104, 0, 0, 0),
+            (13, 39, 2, 12, 10), (13, 30, 1, 12, 9), (13, 97, 7, 12, 28), (13, 14, 1, 14, 6), (13, 14, 1, 27, 6), (6, 39, 2, 5, 10),
+            (7, 64, 2, 32, 40), (7, 104, 3, 32, 80), (5, 17, 1, 1, 3)]
 
 
 @pytest.mark.parametrize("log_n,pi_len,n_paths,depth,path_pi0", CIRCUITS)
@@ -73,7 +74,7 @@ def test_constants_and_witness_match_oracle(bpg, oracle, log_n, pi_len, n_paths,
 
 def test_layouts_that_do_not_fit_are_refused(bpg):
     from proof_protocol_decoder_amd._lib import BpgError
-    for log_n, lay in ((5, (39, 2, 12, 10)), (13, (39, 2, 12, 32)), (13, (65, 0, 0, 0)), (13, (39, 3, 30, 0)), (13, (0, 0, 0, 0))):
+    for log_n, lay in ((5, (39, 2, 12, 10)), (13, (39, 2, 12, 32)), (13, (105, 0, 0, 0)), (13, (39, 4, 30, 0)), (13, (0, 0, 0, 0)), (4, (4, 0, 0, 0))):
         with pytest.raises(BpgError):
             dev_constants(bpg, log_n, 1, *lay)
 

@@ -59,7 +59,7 @@ def test_ir_encoding_and_public_values_roundtrip():
 def cpu_chain(oracle):
     st = oracle.PgState(**SMALL)
     t0 = st.txn(ir_words(7, 0, 0x5EED0001))
-    root1 = tuple(int(x) for x in t0[4 + 28 + 8:4 + 28 + 12])
+    root1 = tuple(int(x) for x in t0[4 + 84 + 8:4 + 84 + 12])
     t1 = st.txn(ir_words(7, 1, 0x5EED0002, root_before=root1, gas=(121, 150)))
     agg = st.agg(t0, False, t1, False)
     blk = st.block(None, agg)

@@ -183,7 +183,7 @@ def test_stark_accepts_and_rejects_single_bit_flips(oracle, case):
 def test_txn_agg_block_chain_on_cpu(oracle):
     st = oracle.PgState(**SMALL)
     t0 = st.txn(ir_words(7, 0, 0x5EED0001))
-    pv0 = t0[4 + 28:4 + 41]
+    pv0 = t0[4 + 84:4 + 97]
     t1 = st.txn(ir_words(7, 1, 0x5EED0002, root_before=tuple(int(x) for x in pv0[8:12]), gas=(121, 150)))
     assert st.verify(t0) == 0 and st.verify(t1) == 0
     agg = st.agg(t0, False, t1, False)
@@ -205,7 +205,7 @@ def test_dummy_entry_does_not_advance_public_values(oracle):
     dummy = ir_words(7, 0, 0x44554D4D59000000, gas=(100, 100))
     dummy[1] = 2
     d, t = st.txn(dummy), st.txn(real)
-    pv_d, pv_t = d[4 + 28:4 + 41], t[4 + 28:4 + 41]
+    pv_d, pv_t = d[4 + 84:4 + 97], t[4 + 84:4 + 97]
     assert int(pv_d[0]) == int(pv_d[1]) == 0 and int(pv_d[2]) == int(pv_d[3]) == 100
     assert (pv_d[4:8] == pv_d[8:12]).all() and int(pv_t[1]) == 1 and (pv_t[4:8] != pv_t[8:12]).any()
     assert st.verify(d) == 0

@@ -73,8 +73,9 @@ def merkle_fixture(oracle, rng, depth, n_paths, cap_height=1):
 
 
 # (pi_len, n_paths, depth, path_pi0): lists of every chunking; the aggregation / block circuits' layouts at a small depth
-LAYOUTS = [(4, 0, 0, 0), (6, 0, 0, 0), (8, 0, 0, 0), (9, 0, 0, 0), (23, 0, 0, 0), (41, 0, 0, 0), (64, 0, 0, 0),
-           (39, 2, 5, 10), (30, 1, 7, 9), (17, 1, 1, 3), (64, 2, 6, 40)]
+LAYOUTS = [(4, 0, 0, 0), (6, 0, 0, 0), (8, 0, 0, 0), (9, 0, 0, 0), (23, 0, 0, 0), (41, 0, 0, 0), (64, 0, 0, 0), (104, 0, 0, 0),
+           (39, 2, 5, 10), (30, 1, 7, 9), (17, 1, 1, 3), (64, 2, 6, 40), (14, 1, 6, 6), (97, 7, 5, 28)]
+MROW0 = 17   # the Merkle rows start after the thirteen rows a list can take (rows 4..16)
 
 
 @pytest.mark.parametrize("pi_len,n_paths,depth,path_pi0", LAYOUTS)
@@ -92,7 +93,7 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
     t = oracle.plonk_trace(log_n, SEED, pi, k, n_paths, depth, path_pi0, wit)
     H = (pi_len + 7) // 8
     T = n_paths * depth
-    A0 = (12 + T + 3) // 4 * 4
+    A0 = (MROW0 + T + 3) // 4 * 4
     want_hash = hash_no_pad_py(oracle, pi)
     assert [int(t[j, 0]) for j in range(4)] == want_hash
     assert [int(x) for x in oracle.hash_no_pad(pi)] == want_hash
@@ -103,7 +104,7 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
     CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
     for i in range(n):
         qa, qs, qh = int(k[0, i]), int(k[1, i]), int(k[4, i])
-        want = ((1, 0, 0) if i == 1 else (0, 0, 1) if 4 <= i < 4 + H or 12 <= i < 12 + T else (0, 0, 0) if i < A0
+        want = ((1, 0, 0) if i == 1 else (0, 0, 1) if 4 <= i < 4 + H or MROW0 <= i < MROW0 + T else (0, 0, 0) if i < A0
                 else ((0, 1, 0) if i % 4 == 2 else (1, 0, 0)))
         assert (qa, qs, qh) == want, i
         if qa:
@@ -120,7 +121,7 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
             st = [int(t[c, i]) for c in range(12)]
             sw, delta = int(t[130, i]), [int(t[131 + j, i]) for j in range(4)]
             assert sw in (0, 1) and delta == [sw * (st[4 + j] - st[j]) % P for j in range(4)]
-            assert sw == 0 or i >= 12                        # a sponge row does not swap
+            assert sw == 0 or i >= MROW0                     # a sponge row does not swap
             if sw:
                 st = st[4:8] + st[0:4] + st[8:]
             assert [int(x) for x in oracle.poseidon(np.array(st, dtype=np.uint64))[0]] == [int(t[12 + c, i]) for c in range(12)]
@@ -135,14 +136,14 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
                 st = [pow(x, 7, P) if (rnd < 4 or rnd >= 26 or c == 0) else x for c, x in enumerate(st)]
                 st = [(sum(CIRC[(c - r) % 12] * st[c] for c in range(12)) + (8 * st[0] if r == 0 else 0)) % P for r in range(12)]
             assert st == [int(t[12 + c, i]) for c in range(12)]
-            if i < 12:
+            if i < MROW0:
                 h = i - 4
                 assert [int(t[c, i]) for c in range(min(8, pi_len - 8 * h))] == [int(x) for x in pi[8 * h:8 * h + 8]]
     # the Merkle rows: from the list's leaf digest, level by level (the position bit on the swap wire), to the list's cap entry
     for p in range(n_paths):
         node, index = words[8 * p:8 * p + 4], wit[p * (1 + 4 * depth)]
         for l in range(depth):
-            row = 12 + p * depth + l
+            row = MROW0 + p * depth + l
             sib = wit[p * (1 + 4 * depth) + 1 + 4 * l:][:4]
             assert [int(t[c, row]) for c in range(12)] == node + sib + [0, 0, 0, 0] and int(t[130, row]) == (index >> l) & 1
             pair = sib + node if (index >> l) & 1 else node + sib
@@ -174,7 +175,7 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
     assert sum(1 for a, b in nxt.items() if a != b) > 80 * (n - A0) // 3
     # the paths' ends are wires of the list, their levels are chained, all their capacity words hang on one zero wire
     for p in range(n_paths):
-        r0, r1 = 12 + p * depth, 12 + p * depth + depth - 1
+        r0, r1 = MROW0 + p * depth, MROW0 + p * depth + depth - 1
         for j in range(4):
             i_leaf, i_top = path_pi0 + 8 * p + j, path_pi0 + 8 * p + 4 + j
             assert nxt[(j, r0)] == (i_leaf % 8, 4 + i_leaf // 8) and nxt[(i_leaf % 8, 4 + i_leaf // 8)] == (j, r0)
@@ -186,7 +187,7 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
         while at not in cyc:
             cyc.append(at)
             at = nxt[at]
-        assert sorted(cyc) == sorted([(79, 1)] + [(8 + j, 12 + r) for r in range(T) for j in range(4)])
+        assert sorted(cyc) == sorted([(79, 1)] + [(8 + j, MROW0 + r) for r in range(T) for j in range(4)])
         assert all(int(t[c, r]) == 0 for c, r in cyc)
 
 
@@ -211,11 +212,11 @@ def test_oracle_proof_is_accepted_by_both_verifiers_and_tampering_is_not(oracle,
     assert oracle.stark_verify(small_cfg(oracle, log_n, wrong), proof, ctl, chv.clone(), cap) != 0
 
 
-# one wrong cell: (column, row, what it breaks).  Row 17 is a consuming arithmetic row, row 18 an S-box row, row 4 the
+# one wrong cell: (column, row, what it breaks).  Row 25 is a consuming arithmetic row, row 26 an S-box row, row 4 the
 # hash row of the four-word list of a lone proof, row 1 the zero row.
-BREAKS = [(0, 17, "copy constraint: a_0 of row 17 is no longer d_0 of row 16 (the gate still holds: d recomputed)"),
-          (3, 21, "arithmetic gate of slot 0"), (80 + 5 * 3 + 2, 18, "S-box unit 3: x^4"),
-          (4 * 5, 18, "S-box unit 5 is no longer fed by its routed wire"), (1, 0, "public input 1"),
+BREAKS = [(0, 25, "copy constraint: a_0 of row 25 is no longer d_0 of row 24 (the gate still holds: d recomputed)"),
+          (3, 29, "arithmetic gate of slot 0"), (80 + 5 * 3 + 2, 26, "S-box unit 3: x^4"),
+          (4 * 5, 26, "S-box unit 5 is no longer fed by its routed wire"), (1, 0, "public input 1"),
           (2, 4, "hash row: a word of the list changes, the first S-box inputs no longer follow"),
           (24 + 12 + 5, 4, "hash row: an S-box input of full round 2"), (60 + 9, 4, "hash row: the S-box input of partial round 13"),
           (82 + 47, 4, "hash row: the last S-box input of round 29"), (12 + 7, 4, "hash row: an output word nobody copies"),
@@ -246,12 +247,12 @@ def test_a_witness_that_breaks_one_rule_yields_a_rejected_proof(oracle, col, row
     assert product_verify(cfg, proof, cap, pub) != 0
 
 
-# a circuit that walks two paths of five levels (rows 12..21; the list's path words at 10..25): one wrong cell each
-MERKLE_BREAKS = [(4 + 2, 12 + 3, "a sibling of path 0 (level 3)"), (130, 12 + 1, "the position bit of a level is not a bit"),
-                 (131 + 2, 12 + 7, "a delta word without its swap"), (1, 12 + 5, "the leaf digest of path 1 is not the list's"),
-                 (12 + 3, 12 + 4, "path 0 does not arrive at the list's cap entry"), (2, 12 + 2, "a level does not take the node below"),
-                 (8 + 1, 12 + 6, "a capacity word of a Merkle row is not zero"), (10 % 8 + 2, 4 + 10 // 8, "the list names another leaf digest"),
-                 (60 + 4, 12 + 9, "a partial-round wire of a Merkle row")]
+# a circuit that walks two paths of five levels (rows 17..26; the list's path words at 10..25): one wrong cell each
+MERKLE_BREAKS = [(4 + 2, 17 + 3, "a sibling of path 0 (level 3)"), (130, 17 + 1, "the position bit of a level is not a bit"),
+                 (131 + 2, 17 + 7, "a delta word without its swap"), (1, 17 + 5, "the leaf digest of path 1 is not the list's"),
+                 (12 + 3, 17 + 4, "path 0 does not arrive at the list's cap entry"), (2, 17 + 2, "a level does not take the node below"),
+                 (8 + 1, 17 + 6, "a capacity word of a Merkle row is not zero"), (10 % 8 + 2, 4 + 10 // 8, "the list names another leaf digest"),
+                 (60 + 4, 17 + 9, "a partial-round wire of a Merkle row")]
 
 
 @pytest.mark.parametrize("col,row,what", MERKLE_BREAKS, ids=[b[2][:44] for b in MERKLE_BREAKS])
@@ -275,7 +276,7 @@ def test_a_wrong_merkle_path_yields_a_rejected_proof(oracle, col, row, what):
         wit2 = list(wit)
         wit2[0] ^= 1 << 1
         t2 = oracle.plonk_trace(log_n, 78, pi, k, *layout[1:], wit2)
-        assert int(t2[130, 13]) == 1 - int(t[130, 13])
+        assert int(t2[130, 18]) == 1 - int(t[130, 18])
         proof, ctl, chv, cap = prove(oracle, cfg, k, t2)
         assert oracle.stark_verify(cfg, proof, ctl, chv, cap) != 0 and product_verify(cfg, proof, cap, pub) != 0
         t[col, row] = np.uint64(2)
@@ -309,7 +310,7 @@ def test_recursion_layer_on_the_plonk_circuit_chain_of_proofs(oracle):
     from proof_protocol_decoder_amd import proof_gen as pg
     st = oracle.PgState(**SMALL_PLONK)
     t0 = st.txn(ir_words(7, 0, 0x5EED0001))
-    root1 = tuple(int(x) for x in t0[4 + 28 + 8:4 + 28 + 12])
+    root1 = tuple(int(x) for x in t0[4 + 84 + 8:4 + 84 + 12])
     t1 = st.txn(ir_words(7, 1, 0x5EED0002, root_before=root1, gas=(121, 150)))
     agg = st.agg(t0, False, t1, False)
     blk = st.block(None, agg)
