@@ -200,7 +200,7 @@ struct PlonkTraceArgs {
   // n_hash_rows rows (poseidon_hash_rows), of the Merkle paths from row HASH_ROWS_MAX on (poseidon_merkle_rows)
   const uint64_t* hash_rows;
   uint32_t n_hash_rows;
-  uint32_t n_merkle_rows = 0, arith_row0 = air::plonk::MERKLE_ROW0;  // air::plonk::arith_row0(the circuit's layout)
+  uint32_t n_merkle_rows = 0, arith_row0 = (air::plonk::MERKLE_ROW0 + 3) & ~3u;  // air::plonk::arith_row0(the circuit's layout); default: no paths
 };
 int launch_plonk_trace(const PlonkTraceArgs* a, uint32_t batch, uint32_t log_n, hipStream_t st);
 // every proof of the batch has the shape and the unit spreading of q[0]
