@@ -202,8 +202,9 @@ int emit_box(uint64_t kind, uint64_t circuit, const std::vector<uint64_t>& pi, c
 std::atomic<uint32_t> g_rec_batch{MAX_BATCH};  // bp_tune_rec_batch: 1 = one proof at a time
 std::atomic<int> g_side_lanes{1};               // bp_tune_side_lanes: 0 = no side lanes
 // paths (nullable): per proof the witness of the Merkle paths its circuit walks (Circuit::lay.n_paths of them)
+// first_leaf (nullable, 4 words per proof): the digest of the trace leaf each proof's first query opens
 int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* const* circ, const std::vector<uint64_t>* pi,
-                    std::vector<uint64_t>* proofs, const std::vector<PathWitness>* paths = nullptr) {
+                    std::vector<uint64_t>* proofs, const std::vector<PathWitness>* paths = nullptr, uint64_t* first_leaf = nullptr) {
   const uint32_t cap = std::min<uint32_t>(std::min<uint32_t>(MAX_BATCH, std::max<uint32_t>(1, g_rec_batch.load(std::memory_order_relaxed))),
                                           std::max<uint32_t>(1, MAX_BATCH_QUERIES / std::max<uint32_t>(1, rc.num_queries)));
   const uint64_t N = (uint64_t)1 << rc.log_n;
@@ -262,7 +263,7 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
       ch[b].observe(trace[b].cap.data(), trace[b].cap.size());
       for (int i = 0; i < 4; i++) ctl[b].v[i] = ch[b].challenge();
     }
-    r = stark_prove_batch(w, rc, B, consts, trace, d_tv, ctl, ch, proofs + first);
+    r = stark_prove_batch(w, rc, B, consts, trace, d_tv, ctl, ch, proofs + first, first_leaf ? first_leaf + 4 * first : nullptr);
     w.arena.release(mark);
     if (r) return r;
   }
@@ -277,12 +278,17 @@ int rec_prove(Worker& w, const StarkCfg& rc, const Circuit& circ, const std::vec
 // oracle.  leaf = the digest of the opened trace row, cap_entry = the entry of the child's trace cap the path ends in
 // (both become words of the parent's public-input list), pw = position and siblings.  `child` has been parsed
 // (parse_box: its length is the layout's).
-void first_query_trace_path(const StarkCfg& c, const uint64_t* child, uint64_t leaf[4], uint64_t cap_entry[4], PathWitness* pw) {
+// known_leaf (nullable): the leaf digest as the prover's device gave it (stark_prove's first_trace_leaf) -- a child made
+// elsewhere has its opened row hashed here.
+void first_query_trace_path(const StarkCfg& c, const uint64_t* child, uint64_t leaf[4], uint64_t cap_entry[4], PathWitness* pw,
+                            const uint64_t* known_leaf = nullptr) {
   const ProofLayout L = proof_layout(c);
   const uint64_t* w = child + L.queries;
   const uint64_t x = *w++;
   if (c.n_const) w += c.n_const + (size_t)L.depth0 * 4;
-  if (c.n_cols <= 4) {  // Hasher::hash_or_noop
+  if (known_leaf) {
+    std::memcpy(leaf, known_leaf, 32);
+  } else if (c.n_cols <= 4) {  // Hasher::hash_or_noop
     std::memset(leaf, 0, 32);
     std::memcpy(leaf, w, c.n_cols * 8);
   } else {
@@ -641,6 +647,7 @@ struct TableProofs {
   std::vector<uint64_t> pv;
   Ctl ctl;
   std::vector<uint64_t> proof[BP_NUM_TABLES];
+  uint64_t first_leaf[BP_NUM_TABLES][4];  // per table proof: the digest of the trace leaf its first query opens (stark_prove)
 };
 static int parse_ir(const bp_config& cfg, const uint64_t* I, const TxnWitness* wit, StarkCfg tcfg[BP_NUM_TABLES],
                     std::vector<uint64_t>* pv_out) {
@@ -855,7 +862,7 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
     if (w.aborted()) return fail(BP_ERR_ABORTED, "aborted before table %s", TABLE_NAMES[t]);
     const size_t mark = w.arena.mark();
     Challenger before = ch;  // the transcript as the verifier of this table proof starts from it
-    if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, tp->proof[t]))) return r;
+    if ((r = stark_prove(w, tcfg[t], nullptr, trace[t], d_trace[t], ctl, ch, tp->proof[t], tp->first_leaf[t]))) return r;
     if (given(t)) {
       // The prover does not check a witness, and nothing downstream of this call verifies the table proofs (upstream's
       // root circuit would): data that came from the caller is therefore checked here, by the CPU verifier on the
@@ -915,7 +922,7 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
   for (int t = 0; t < BP_NUM_TABLES; t++) {
     proof_digest(tcfg[t], tp.proof[t].data(), digest[t]);
     child_path[t].resize(1);
-    first_query_trace_path(tcfg[t], tp.proof[t].data(), leaf_cap[t], leaf_cap[t] + 4, &child_path[t][0]);
+    first_query_trace_path(tcfg[t], tp.proof[t].data(), leaf_cap[t], leaf_cap[t] + 4, &child_path[t][0], tp.first_leaf[t]);
     std::vector<uint64_t>().swap(tp.proof[t]);
   }
   std::vector<uint64_t> proof;
@@ -937,10 +944,11 @@ static int txn_proof_impl(const bp_state* s, const uint8_t* ir, size_t ir_len, c
         pis[t] = {digest[t][0], digest[t][1], digest[t][2], digest[t][3], (uint64_t)t, depth};
         pis[t].insert(pis[t].end(), leaf_cap[t], leaf_cap[t] + 8);
       }
-      if ((r = rec_prove_batch(w, s->rec_cfg, BP_NUM_TABLES, circ, pis, chain_proof, child_path))) return r;
+      uint64_t first_leaf[BP_NUM_TABLES][4];
+      if ((r = rec_prove_batch(w, s->rec_cfg, BP_NUM_TABLES, circ, pis, chain_proof, child_path, &first_leaf[0][0]))) return r;
       for (int t = 0; t < BP_NUM_TABLES; t++) {
         proof_digest(s->rec_cfg, chain_proof[t].data(), digest[t]);
-        first_query_trace_path(s->rec_cfg, chain_proof[t].data(), leaf_cap[t], leaf_cap[t] + 4, &child_path[t][0]);
+        first_query_trace_path(s->rec_cfg, chain_proof[t].data(), leaf_cap[t], leaf_cap[t] + 4, &child_path[t][0], first_leaf[t]);
       }
     }
   }

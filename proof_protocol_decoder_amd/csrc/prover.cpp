@@ -123,7 +123,8 @@ void poseidon_host(uint64_t s[12]) {
 // the S-box inputs of every round in between.  rows: ceil(n / 8) x H_WIRES words; digest = the hash (the first four
 // output words of the last row).
 // one permutation with every S-box input kept: s in / out, w = the row's wires (H_FULL1, H_PART, H_FULL2; not in / out)
-static void permutation_wires(uint64_t (&s)[12], uint64_t* w) {
+template <bool AVX2>
+__attribute__((always_inline)) static inline void permutation_wires_body(uint64_t (&s)[12], uint64_t* w) {
   namespace pk = air::plonk;
   for (int rnd = 0; rnd < 30; rnd++) {
     for (int i = 0; i < 12; i++) s[i] = gl::addc(s[i], RC_HOST[rnd * 12 + i]);   // s = the S-box input of this round
@@ -133,8 +134,22 @@ static void permutation_wires(uint64_t (&s)[12], uint64_t* w) {
     else if (rnd >= 26) std::memcpy(w + pk::H_FULL2 + 12 * (rnd - 26), s, sizeof(s));
     if (full) for (int i = 0; i < 12; i++) s[i] = sbox_host(s[i]);
     else s[0] = sbox_host(s[0]);
-    mds_host_scalar(s);
+#if defined(__x86_64__)
+    if (AVX2) mds_host_avx2(s);
+    else
+#endif
+      mds_host_scalar(s);
   }
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void permutation_wires_avx2(uint64_t (&s)[12], uint64_t* w) { permutation_wires_body<true>(s, w); }
+#endif
+static void permutation_wires(uint64_t (&s)[12], uint64_t* w) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2 && g_host_poseidon.load(std::memory_order_relaxed) == 0) return permutation_wires_avx2(s, w);
+#endif
+  permutation_wires_body<false>(s, w);
 }
 void poseidon_hash_rows(const uint64_t* in, size_t n, std::vector<uint64_t>* rows, uint64_t digest[4]) {
   namespace pk = air::plonk;
@@ -524,13 +539,13 @@ int fri_layer_args(uint32_t log_nl, uint32_t rate_bits, uint32_t arity_bits, uin
 
 // ------------------------------------------------------------------ one table, or a batch of equally shaped ones
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
-                const uint64_t* d_tv, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof) {
-  return stark_prove_batch(w, cfg, 1, &consts, &trace, &d_tv, &ctl, &ch, &proof);
+                const uint64_t* d_tv, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof, uint64_t* first_trace_leaf) {
+  return stark_prove_batch(w, cfg, 1, &consts, &trace, &d_tv, &ctl, &ch, &proof, first_trace_leaf);
 }
 
 int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committed* const* consts,
                       const Committed* trace, const uint64_t* const* d_tv, const Ctl* ctl, Challenger* ch,
-                      std::vector<uint64_t>* proofs) {
+                      std::vector<uint64_t>* proofs, uint64_t* first_trace_leaf) {
   TRY(check_cfg(cfg));
   if (B == 0 || B > MAX_BATCH || (size_t)B * cfg.num_queries > MAX_BATCH_QUERIES)
     return fail(BP_ERR_INVALID_INPUT, "stark_prove_batch: %u proofs x %u queries (at most %u proofs, %u queries in all)", B,
@@ -895,8 +910,8 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committe
     std::unique_ptr<QueryArgs> qa2(new QueryArgs());
     std::unique_ptr<QueryLayerArgs> ql(new QueryLayerArgs());
     const size_t q_words = (size_t)cfg.num_queries * L.query_words;
-    const bool q_direct = q_words * B <= w.pinned_words;  // gather straight into host-visible memory when it fits
-    uint64_t* d_q = q_direct ? w.pinned_dev : w.arena.alloc_words(q_words * B);
+    const bool q_direct = q_words * B + 4 * B <= w.pinned_words;  // gather straight into host-visible memory when it fits
+    uint64_t* d_q = q_direct ? w.pinned_dev : w.arena.alloc_words(q_words * B + 4 * B);  // (+ the first leaf digests, at the end)
     if (!d_q) return fail(BP_ERR_DEVICE, "device arena exhausted (%zu MiB) allocating the query buffer", w.arena.capacity() >> 20);
     qa2->query_words = ql->query_words = L.query_words;
     qa2->n_queries = ql->n_queries = cfg.num_queries;
@@ -906,6 +921,7 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committe
       for (uint32_t q = 0; q < cfg.num_queries; q++)
         qa2->x_index[b * cfg.num_queries + q] = ql->x_index[b * cfg.num_queries + q] = ch[b].challenge() & (M - 1);
       qa2->proof[b].out = ql->proof[b].out = d_q + b * q_words;
+      qa2->proof[b].first_leaf = first_trace_leaf ? d_q + B * q_words + 4 * b : nullptr;
       uint32_t off = 1;
       for (int o = 0; o < n_or; o++) {
         const Committed* c = refs[b][o].c;
@@ -918,13 +934,16 @@ int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t B, const Committe
         off += 2 * arity + (layer_log_nl[l] - ab + r - h) * 4;
       }
     }
+    qa2->leaf_oracle = K ? 1 : 0;  // the trace follows the constants
     TRY(launch_query_initial(*qa2, B, n_or, st));
     TRY(launch_query_layers(*ql, B, L.n_layers, st));
     if (q_direct) {
       TRY(w.wait());
       for (uint32_t b = 0; b < B; b++) std::memcpy(P[b] + L.queries, w.pinned + b * q_words, q_words * 8);
+      if (first_trace_leaf) std::memcpy(first_trace_leaf, w.pinned + B * q_words, 4 * B * 8);
     } else {
       for (uint32_t b = 0; b < B; b++) TRY(w.d2h(P[b] + L.queries, d_q + b * q_words, q_words));
+      if (first_trace_leaf) TRY(w.d2h(first_trace_leaf, d_q + B * q_words, 4 * B));
     }
   }
   return BP_OK;

@@ -155,15 +155,18 @@ int commit_finish(const PendingCommit& pc, Committed* out);
 
 // prove_single_table on the synthetic AIR.  The caller has already observed the trace cap(s) and
 // drawn ctl (plonky2_evm prover order).  Fills `proof` (proof_layout(cfg).total words).
+// first_trace_leaf (nullable, 4 words per proof): the digest of the trace-oracle leaf the proof's first query opens -- what
+// a parent recursion circuit's Merkle path starts from; gathered on the device with the query openings.
 int stark_prove(Worker& w, const StarkCfg& cfg, const Committed* consts, const Committed& trace,
-                const uint64_t* d_trace_values, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof);
+                const uint64_t* d_trace_values, const Ctl& ctl, Challenger& ch, std::vector<uint64_t>& proof,
+                uint64_t* first_trace_leaf = nullptr);
 // The same for `batch` (<= MAX_BATCH, batch * num_queries <= MAX_BATCH_QUERIES) proofs of ONE shape in lock-step:
 // independent transcripts, every kernel launch and every host wait shared (the seven per-table recursion chains of
 // a transaction, proofgen.cpp).  Proof b's bytes are those stark_prove would give for (consts[b], trace[b], ...).
 // consts: per proof, may be null when the shape has no constant columns.
 int stark_prove_batch(Worker& w, const StarkCfg& cfg, uint32_t batch, const Committed* const* consts,
                       const Committed* trace, const uint64_t* const* d_trace_values, const Ctl* ctl, Challenger* ch,
-                      std::vector<uint64_t>* proofs);
+                      std::vector<uint64_t>* proofs, uint64_t* first_trace_leaf = nullptr);
 
 void tune_host_wait(int mode);  // bp_tune_host_wait
 void tune_host_poseidon(int mode);  // bp_tune_host_poseidon

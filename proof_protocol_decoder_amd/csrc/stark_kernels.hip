@@ -1381,6 +1381,9 @@ __global__ void __launch_bounds__(256) query_initial_kernel(bpg::QueryArgs a) {
     const uint64_t off = ((uint64_t)2 << log_rows) - ((uint64_t)2 << (log_rows - lvl));
     w[k] = orc.digests[(off + ((x >> lvl) ^ 1)) * 4 + (k & 3)];
   }
+  // what a parent circuit walks from (proofgen.cpp: first_query_trace_path): the digest of the leaf itself, which the
+  // proof does not carry and the host would otherwise re-hash from the opened row (304 permutations for 2432 columns)
+  if (q == 0 && o == a.leaf_oracle && a.proof[b].first_leaf && threadIdx.x < 4) a.proof[b].first_leaf[threadIdx.x] = orc.digests[x * 4 + threadIdx.x];
 }
 // grid = (num_queries x proofs, n_layers)
 __global__ void __launch_bounds__(64) query_layers_kernel(bpg::QueryLayerArgs a) {

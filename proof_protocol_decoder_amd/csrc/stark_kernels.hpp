@@ -134,11 +134,13 @@ constexpr uint32_t MAX_BATCH_QUERIES = 256;
 struct QueryProof {
   uint64_t* out;
   QueryOracle oracle[4];
+  uint64_t* first_leaf = nullptr;  // (nullable) 4 words: the digest of the leaf query 0 opens in oracle `leaf_oracle` (the trace)
 };
 struct QueryArgs {
   uint64_t x_index[MAX_BATCH_QUERIES];
   uint64_t query_words;
   uint32_t log_n, rate_bits, cap_height, n_queries;  // n_queries: per proof
+  uint32_t leaf_oracle = 0;
   QueryProof proof[MAX_BATCH];
 };
 struct QueryLayer {
