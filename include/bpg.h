@@ -306,12 +306,12 @@ int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t lo
 
 /* AIR 8 (plonk): the 85 preprocessed constant columns of the fixed circuit (selectors, gate constants drawn from `seed`,
  * the Poseidon-row selector, the 80 sigmas of its copy permutation), n = 2^log_n rows, column-major, for a circuit that
- *   - hashes a public-input list of pi_len words (1..64) in Poseidon-gate rows 4.. (one permutation per row), and
- *   - walks n_paths Merkle paths of path_depth levels each in Poseidon-gate rows 12.. (n_paths x path_depth <= 64): path p
+ *   - hashes a public-input list of pi_len words (1..104) in Poseidon-gate rows 4.. (one permutation per row), and
+ *   - walks n_paths Merkle paths of path_depth levels each in Poseidon-gate rows 17.. (n_paths x path_depth <= 96): path p
  *     starts at list words path_pi0 + 8p .. + 3 (a leaf digest) and must arrive at list words path_pi0 + 8p + 4 .. + 7 (a
- *     cap entry); the aggregation circuit walks one path per child proof (merkle_proofs::verify_merkle_proof_to_cap of the
- *     child's first query into its trace oracle), the block circuit its aggregation child's.  Arithmetic rows start at
- *     the first multiple of four past the Merkle rows (12 without paths) and one group of four must fit;
+ *     cap entry); every recursion circuit of the prover state walks one path per child proof (merkle_proofs::
+ *     verify_merkle_proof_to_cap of the child's first query into its trace oracle).  Arithmetic rows start at
+ *     the first multiple of four past the Merkle rows (20 without paths) and one group of four must fit (2^log_n >= 32);
  * and the circuit's witness, 135 wires: free wires drawn from `seed`, the list pi hashed in rows 4.., its hash in row 0
  * (the four public inputs) and, through copy constraints, in the first arithmetic row; `paths` (NULL when n_paths = 0):
  * per path 1 + 4 path_depth words -- the leaf's position (bit l = "the node of level l is a right child"), then the

@@ -936,7 +936,7 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 //   row 4g + 1  arithmetic, a_s := d_s(4g), b_s := d_(s+1)(4g), c_s := c_s(4g)          (3- and 2-cycles)
 //   row 4g + 2  S-box, x_i := d_i(4g + 1) through a_i, d_i = x_i^7                       (2-cycles)
 //   row 4g + 3  arithmetic, a_i := d_i(4g + 2) for i < 11, the rest free               (2-cycles)
-// and c_j(12) := pub_j (row 0), j < 4, ties the computation to the public inputs.
+// and c_j(first arithmetic row) := pub_j (row 0), j < 4, ties the computation to the public inputs.
 //
 // Round 5: the circuit HASHES its public-input list itself (upstream: the public inputs of a recursion circuit are hashed
 // in-circuit by PoseidonGates and the four hash words routed to the PublicInputGate; round 4 bound the first row to a hash
@@ -954,13 +954,13 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 //        (left, right, capacity) of a Merkle step whose node arrives in in[0..3] and whose sibling in in[4..7]       degree 3
 // with the permutation's own round constants and MDS matrix (poseidon_rc.inc): hash rows compute hash_no_pad (s = 0).
 // All 135 wires of a Poseidon row are now spoken for, as in upstream's PoseidonGate (12 + 12 + 1 + 4 + 36 + 22 + 48).
-// Rows 4 .. 4 + H - 1 (H = ceil(len / 8) <= 8) absorb the list eight words at a time: the words are free wires 0..7 of
+// Rows 4 .. 4 + H - 1 (H = ceil(len / 8) <= 13) absorb the list eight words at a time: the words are free wires 0..7 of
 // their row, the other state words are copies -- of the previous row's output (the sponge's carry: words 8..11, and the
 // words a short last chunk leaves alone), or, in the first row, of ZERO wires: row 1 is an arithmetic row with
 // c0 = c1 = 0, so its twenty d wires are zero.  The first four output words of the last hash row ARE the public-input
-// wires of row 0 (one copy cycle with c_j(12), c_j(13)), which G3 binds to the four words the verifier computed from
-// the list it was given.  Rows 4..11 are the hash region (no-ops beyond H).
-// **Merkle rows** (rows 12 .. 12 + n_paths x depth - 1, also selected by q_hash): the aggregation / block circuit walks,
+// wires of row 0 (one copy cycle with c_j of the first two arithmetic rows), which G3 binds to the four words the verifier computed from
+// the list it was given.  Rows 4..16 are the hash region (no-ops beyond H <= 13).
+// **Merkle rows** (rows 17 .. 17 + n_paths x depth - 1, also selected by q_hash): a recursion circuit walks,
 // per child proof, the Merkle path of the child's first query into its trace oracle (merkle_proofs::
 // verify_merkle_proof_to_cap in-circuit): level l's row takes the node of level l in in[0..3] -- a copy of the row
 // below's out[0..3]; at l = 0 a copy of the leaf-digest words of the public-input list -- the sibling in in[4..7] (free
@@ -968,7 +968,7 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 // wire 19 of row 1); out[0..3] of the path's last row is a copy of the list's cap-entry words.  So the hash the verifier
 // is given commits to (leaf digest, cap entry) pairs between which the circuit has checked a path; which leaf and which
 // cap the words are is the aggregating host's statement, as the child digests in the same list are.  Arithmetic groups
-// start at the first multiple of four past the Merkle rows (row 12 for a circuit that walks no path).
+// start at the first multiple of four past the Merkle rows (row 20 for a circuit that walks no path).
 namespace plonk {
 constexpr uint32_t N_COLS = 135, N_CONST = 85, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 213, N_UNITS = 11;
 constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_HASH = 4, CST_SIGMA = 5;
