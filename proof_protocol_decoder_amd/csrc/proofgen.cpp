@@ -300,7 +300,14 @@ void first_query_trace_path(const StarkCfg& c, const uint64_t* child, uint64_t l
   const uint64_t top = (x >> L.depth0) & (((uint64_t)1 << c.cap_height) - 1);
   std::memcpy(cap_entry, child + L.trace_cap + 4 * top, 32);
 }
+// the length of the public-input list each kind of container carries (what its circuit hashes in its thirteen rows at most)
+uint32_t box_pi_len(uint64_t kind) {
+  return kind == 0 ? ROOT_PATH_PI0 + 8 * BP_NUM_TABLES + BP_PV_WORDS : kind == 1 ? AGG_PATH_PI0 + 16 + BP_PV_WORDS : BLOCK_PATH_PI0 + 8 + BP_PV_WORDS;
+}
 int rec_verify(const StarkCfg& rc, const LightCircuit& circ, const Box& b) {
+  if (b.n_pi != box_pi_len(b.kind))
+    return fail(BP_ERR_VERIFY, "a proof of kind %llu carries %u public inputs, this one %llu", (unsigned long long)b.kind, box_pi_len(b.kind),
+                (unsigned long long)b.n_pi);
   uint64_t pi_hash[4];
   hash_no_pad_host(b.pi, b.n_pi, pi_hash);
   Challenger ch;

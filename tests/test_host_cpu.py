@@ -94,6 +94,12 @@ def test_product_cpu_verifier_accepts_oracle_proofs_and_rejects_corruption(cpu_c
         assert e.value.code in (-5, -2)
     pv, kind = pg.public_values_of(blk.tobytes())
     assert kind == 2 and pv.block_number == 7 and pv.txn_number_after == 2
+    # a container whose list has another length than its kind's circuit hashes is refused before any hashing: here the
+    # block proof's list with one more word (and the header saying so)
+    longer = np.concatenate([blk[:4 + 30], np.zeros(1, dtype=np.uint64), blk[4 + 30:]])
+    longer[2] = 31
+    with pytest.raises(pg.ProofGenError, match="public inputs"):
+        v.verify(longer.tobytes())
 
 
 def test_host_transcript_permutation_matches_the_oracle_in_both_forms(oracle):
