@@ -7,6 +7,10 @@
  *   keccak_sponge -> keccak_f: every row of the sponge table that absorbs a block claims "the permutation of (xored
  *   rate, capacity) is (updated state)"; the Keccak-f table exposes (input, output) of the permutations it is asked for.
  *
+ *   keccak_sponge -> logic: every row of the sponge table that absorbs a block claims "the XOR of limbs 8 m .. 8 m + 7 of
+ *   the rate with the block is an operation of the logic table", m < 5 (136 bytes = 34 limbs: the fifth operation has two
+ *   limbs and six zeros); the logic table exposes the operations it is asked for (filter: trace column 523).
+ *
  *   byte_packing -> memory: every row of the byte-packing table that moves a word claims "the memory operation
  *   (is_read, address, timestamp) carries this 256-bit value"; the memory table exposes the operations it is asked for.
  *
@@ -16,7 +20,8 @@
  *   synthetic  n_cols / 8   unfiltered products over trace columns 8k, 8k + 1 (a load placeholder; stark.c)
  *   keccak_f   4            h_0, h_1 (the permutation's 50 input limbs compressed by beta_c, the same value on all its
  *                           rows), z_0, z_1
- *   sponge     2            z_0, z_1
+ *   sponge     12           z_0, z_1 (-> keccak_f); then for m < 5 and challenge set c column 2 + 2 m + c (-> logic)
+ *   logic      2            z_0, z_1
  *   byte_packing 2          z_0, z_1
  *   memory     2            z_0, z_1
  * The FILTERS of the two looked tables -- g = 1 on the last-round row of an exposed permutation (Keccak-f, trace column
@@ -34,13 +39,16 @@ enum { KCOL_STEP = 0, KCOL_A = 24, KCOL_APP = 2314, KCOL_APPP = 2428, KCOL_G = 2
 enum { SCOL_FULL = 0, SCOL_FINAL = 1, SCOL_CAP = 2314, SCOL_XORED = 2330, SCOL_UPDATED = 2364 };
 enum { PCOL_READ = 0, PCOL_LEN = 1, PCOL_VAL = 289, PCOL_ADDR = 297, PCOL_TS = 298 };
 enum { MCOL_READ = 0, MCOL_ADDR = 1, MCOL_TS = 2, MCOL_VAL = 3, MCOL_G = 44 };
+enum { SCOL_BLOCK = 138, SCOL_RATE = 1226 };                       /* the sponge table's bit columns (block as absorbed, rate before) */
+enum { LCOL_OP = 0, LCOL_IN0 = 3, LCOL_IN1 = 259, LCOL_RES = 515, LCOL_G = 523 };
 
 uint32_t orc_ctl_n_aux(uint32_t air_id, uint32_t n_cols) {
   return air_id == ORC_AIR_SYNTHETIC ? n_cols / 8
          : air_id == ORC_AIR_KECCAK_F ? 4
-         : air_id == ORC_AIR_KECCAK_SPONGE ? 2
+         : air_id == ORC_AIR_KECCAK_SPONGE ? 12 /* z_0 z_1 (-> keccak_f), then five logic operations x two challenge sets */
          : air_id == ORC_AIR_BYTE_PACKING ? 2
          : air_id == ORC_AIR_MEMORY ? 2
+         : air_id == ORC_AIR_LOGIC ? 2
          : air_id == ORC_AIR_PLONK ? 20 /* Z + nine partial products per challenge set (plonk_air.c) */
                                    : 1;
 }
@@ -54,6 +62,42 @@ void orc_ctl_set_filter(uint32_t air_id, gl_t* tv, unsigned log_n, const uint8_t
     for (size_t i = 0; i < N; i++) tv[(size_t)KCOL_G * N + i] = (i % 24 == 23 && exposed && i / 24 < n_exposed && exposed[i / 24]) ? 1 : 0;
   else if (air_id == ORC_AIR_MEMORY)
     for (size_t i = 0; i < N; i++) tv[(size_t)MCOL_G * N + i] = (exposed && i < n_exposed && exposed[i]) ? 1 : 0;
+  else if (air_id == ORC_AIR_LOGIC) /* exposed[i]: the operation in row i is asked for */
+    for (size_t i = 0; i < N; i++) tv[(size_t)LCOL_G * N + i] = (exposed && i < n_exposed && exposed[i]) ? 1 : 0;
+}
+
+/* keccak_sponge -> logic.  The 27-word tuple of a logic operation: the three flags, the eight 32-bit limbs of either
+ * input, the eight of the result.  As the sponge table sends it for the m-th group of eight rate limbs of row i (an XOR
+ * of the rate with the block; limbs past the 34th do not exist: zero), and as the logic table offers it for row i. */
+static void sponge_logic_tuple(const gl_t* tv, size_t N, size_t i, int m, gl_t t[27]) {
+  t[0] = 0; t[1] = 0; t[2] = 1;
+  for (int j = 0; j < 8; j++) {
+    const int l = 8 * m + j;
+    gl_t rate = 0, block = 0;
+    if (l < 34)
+      for (int z = 0; z < 32; z++) {
+        rate += tv[(size_t)(SCOL_RATE + 32 * l + z) * N + i] << z;
+        block += tv[(size_t)(SCOL_BLOCK + 32 * l + z) * N + i] << z;
+      }
+    t[3 + j] = rate; t[11 + j] = block;
+    t[19 + j] = l < 34 ? tv[(size_t)(SCOL_XORED + l) * N + i] : 0;
+  }
+}
+static void logic_tuple(const gl_t* tv, size_t N, size_t i, gl_t t[27]) {
+  for (int j = 0; j < 3; j++) t[j] = tv[(size_t)(LCOL_OP + j) * N + i];
+  for (int j = 0; j < 8; j++) {
+    gl_t a = 0, b = 0;
+    for (int z = 0; z < 32; z++) {
+      a += tv[(size_t)(LCOL_IN0 + 32 * j + z) * N + i] << z;
+      b += tv[(size_t)(LCOL_IN1 + 32 * j + z) * N + i] << z;
+    }
+    t[3 + j] = a; t[11 + j] = b; t[19 + j] = tv[(size_t)(LCOL_RES + j) * N + i];
+  }
+}
+static gl_t compress27(const gl_t t[27], gl_t beta) {
+  gl_t acc = 0, pw = 1;
+  for (int j = 0; j < 27; j++) { acc = gl_add(acc, gl_mul(pw, gl_canon(t[j]))); pw = gl_mul(pw, beta); }
+  return acc;
 }
 
 /* The auxiliary columns of a table with a real AIR, from its trace values tv ([n_cols][N], column-major). */
@@ -101,6 +145,32 @@ void orc_ctl_aux_columns(uint32_t air_id, const gl_t* tv, unsigned log_n, const 
           for (int j = 0; j < 16; j++) tuple = gl_add(tuple, gl_mul(pw[34 + j], tv[(size_t)(SCOL_CAP + j) * N + i]));
           for (int j = 0; j < 50; j++) tuple = gl_add(tuple, gl_mul(pw[50 + j], tv[(size_t)(SCOL_UPDATED + j) * N + i]));
           run = gl_mul(run, gl_add(gamma, tuple));
+        }
+        z[i] = run;
+      }
+    }
+    for (int m = 0; m < 5; m++) /* keccak_sponge -> logic: column 2 + 2 m + c */
+      for (int c = 0; c < 2; c++) {
+        gl_t *z = aux + (size_t)(2 + 2 * m + c) * N, run = 1;
+        for (size_t i = N; i-- > 0;) {
+          if (tv[(size_t)SCOL_FULL * N + i] || tv[(size_t)SCOL_FINAL * N + i]) {
+            gl_t t[27];
+            sponge_logic_tuple(tv, N, i, m, t);
+            run = gl_mul(run, gl_add(ctl[2 * c + 1], compress27(t, ctl[2 * c])));
+          }
+          z[i] = run;
+        }
+      }
+    return;
+  }
+  if (air_id == ORC_AIR_LOGIC) { /* an exposed row offers its operation */
+    for (int c = 0; c < 2; c++) {
+      gl_t *z = aux + (size_t)c * N, run = 1;
+      for (size_t i = N; i-- > 0;) {
+        if (tv[(size_t)LCOL_G * N + i]) {
+          gl_t t[27];
+          logic_tuple(tv, N, i, t);
+          run = gl_mul(run, gl_add(ctl[2 * c + 1], compress27(t, ctl[2 * c])));
         }
         z[i] = run;
       }

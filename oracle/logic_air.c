@@ -1,4 +1,5 @@
-/* oracle/logic_air.c -- AIR 2: one bitwise operation (AND / OR / XOR) on two 256-bit words per trace row, 523 columns.
+/* oracle/logic_air.c -- AIR 2: one bitwise operation (AND / OR / XOR) on two 256-bit words per trace row, 524 columns
+ * (the last one is the filter of the lookup keccak_sponge -> logic, ctl.c).
  * TEST INFRASTRUCTURE ONLY; "parity unpinned" by the reference (see gl.h): the reference proves its logic table
  * through the out-of-tree plonky2_evm (call site plonky_block_proof_gen/src/proof_gen.rs:44-52, table list
  * prover_state.rs:85-93 "logic", size range constants.rs:14); nothing under /root/reference shows its columns.
@@ -18,7 +19,7 @@ static inline uint64_t smix(uint64_t x) {
   return z ^ (z >> 31);
 }
 
-/* Witness: n = 2^log_n rows x 523 columns, column-major.  inputs: [n][9] = operation code (0 none, 1 and, 2 or,
+/* Witness: n = 2^log_n rows x 524 columns, column-major.  inputs: [n][9] = operation code (0 none, 1 and, 2 or,
  * 3 xor), operand 0 (four u64, least significant first), operand 1; or NULL, then row r draws
  * code = smix(seed ^ (0xFF << 32) ^ r) & 3 and word w of operand j = smix(seed ^ ((1 + 4j + w) << 32) ^ r). */
 void orc_logic_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t* t) {
@@ -41,6 +42,7 @@ void orc_logic_trace(uint64_t seed, const uint64_t* inputs, unsigned log_n, gl_t
       PUT(LG_IN1 + i, (y[i / 64] >> (i % 64)) & 1);
     }
     for (int limb = 0; limb < 8; limb++) PUT(LG_RES + limb, (res[limb / 2] >> (32 * (limb % 2))) & 0xFFFFFFFFULL);
+    PUT(523, 0); /* the lookup's filter (ctl.c: keccak_sponge -> logic), set by orc_ctl_set_filter */
 #undef PUT
   }
 }

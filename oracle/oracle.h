@@ -77,7 +77,7 @@ typedef struct {
 #define ORC_KECCAK_COLS 2431u /* 2430 of the round + the lookup's filter column g (ctl.c), committed with the trace */
 #define ORC_KECCAK_CONSTRAINTS 2826u
 #define ORC_AIR_LOGIC 2u
-#define ORC_LOGIC_COLS 523u
+#define ORC_LOGIC_COLS 524u
 #define ORC_LOGIC_CONSTRAINTS 524u
 #define ORC_AIR_MEMORY 3u
 #define ORC_MEMORY_COLS 45u /* 44 of the log + the lookup's filter column g (ctl.c) */

@@ -289,6 +289,13 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
    * they are (and refused below if they disagree). */
   const int lookup_kf = keccak_air && sponge_air;
   const size_t kf_full_perms = ((size_t)1 << tcfg[3].log_n) / 24;
+  /* keccak_sponge -> logic (ctl.c): rows 5 p + m of the logic table are the five XORs of sponge row p (where it absorbs a
+   * block; a row without an operation where it does not), for the sponge rows the logic table has room for; the caller's
+   * or the seeded operations follow.  The seeded sponge table absorbs no block beyond those rows. */
+  const int lookup_sl = sponge_air && logic_air;
+  const size_t sl_covered = lookup_sl ? (((size_t)1 << tcfg[4].log_n) < ((size_t)1 << tcfg[5].log_n) / 5 ? ((size_t)1 << tcfg[4].log_n)
+                                                                                                       : ((size_t)1 << tcfg[5].log_n) / 5) : 0;
+  if (lookup_sl && wit && wit->items[5] && wit->n[5] > ((size_t)1 << tcfg[5].log_n) - 5 * sl_covered) return -2;
   /* byte_packing -> memory (ctl.c): a memory table that is not given is the log of the byte-packing table's words --
    * per packing row the write that put the word at its address (timestamp 1) and the operation the row looks up --,
    * then re-reads of the last address up to the table's height */
@@ -300,7 +307,35 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
     const int t = order[oi];
     size_t n = (size_t)1 << tcfg[t].log_n;
     trace[t] = (gl_t*)malloc(tcfg[t].n_cols * n * sizeof(gl_t));
-    if (wit && wit->items[t] && tcfg[t].air_id != ORC_AIR_SYNTHETIC) {
+    if (t == 5 && lookup_sl) {
+      const uint64_t seed = I[10] ^ splitmix64(t + 1);
+      const size_t ns = (size_t)1 << tcfg[4].log_n;
+      const int given = wit && wit->items[5];
+      uint64_t* in = (uint64_t*)calloc(n * 9, 8);
+      for (size_t i = 0; i < n; i++) {
+        uint64_t* o = in + i * 9;
+        if (i < 5 * sl_covered) {
+          const size_t p = i / 5, m = i % 5;
+          if (!(trace[4][0 * ns + p] || trace[4][1 * ns + p])) continue; /* no operation */
+          o[0] = 3;
+          for (int w = 0; w < 4; w++)
+            for (int z = 0; z < 64; z++) {
+              const size_t bit = 256 * m + 64 * (size_t)w + z;
+              if (bit >= 1088) break;
+              o[1 + w] |= (trace[4][(1226 + bit) * ns + p] & 1) << z; /* the rate before the block */
+              o[5 + w] |= (trace[4][(138 + bit) * ns + p] & 1) << z;  /* the block */
+            }
+        } else if (given) {
+          const size_t k = i - 5 * sl_covered;
+          if (k < wit->n[5]) memcpy(o, wit->items[5] + k * 9, 72);
+        } else {
+          o[0] = splitmix64(seed ^ (0xFFULL << 32) ^ i) & 3;
+          for (int w = 0; w < 8; w++) o[1 + w] = splitmix64(seed ^ ((uint64_t)(1 + w) << 32) ^ i);
+        }
+      }
+      orc_logic_trace(0, in, tcfg[t].log_n, trace[t]);
+      free(in);
+    } else if (wit && wit->items[t] && tcfg[t].air_id != ORC_AIR_SYNTHETIC) {
       uint64_t* in = padded_items(t, n, wit->items[t], wit->n[t]);
       if (t == 3) orc_keccak_trace(0, in, tcfg[t].log_n, trace[t]);
       else if (t == 5) orc_logic_trace(0, in, tcfg[t].log_n, trace[t]);
@@ -348,7 +383,9 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
     else if (tcfg[t].air_id == ORC_AIR_ARITHMETIC) orc_arithmetic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_BYTE_PACKING) orc_byte_packing_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_KECCAK_SPONGE)
-      orc_keccak_sponge_trace_limit(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, lookup_kf ? kf_full_perms : (size_t)-1, trace[t]);
+      orc_keccak_sponge_trace_limit(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n,
+                                    (lookup_kf ? kf_full_perms : (size_t)-1) < (lookup_sl ? sl_covered : (size_t)-1)
+                                        ? (lookup_kf ? kf_full_perms : (size_t)-1) : (lookup_sl ? sl_covered : (size_t)-1), trace[t]);
     else orc_synth_trace(I[10] ^ splitmix64(t + 1), &tcfg[t], NULL, trace[t]);
   }
   /* the filter columns of the two looked tables are part of their traces: set BEFORE the traces are committed */
@@ -357,6 +394,13 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
     uint8_t* exposed = (uint8_t*)malloc(ns);
     for (size_t p = 0; p < ns; p++) exposed[p] = trace[4][p] || trace[4][ns + p];
     orc_ctl_set_filter(ORC_AIR_KECCAK_F, trace[3], tcfg[3].log_n, exposed, ns);
+    free(exposed);
+  }
+  if (lookup_sl) { /* the logic table exposes rows 5 p + m of the sponge rows p that absorb a block */
+    const size_t ns = (size_t)1 << tcfg[4].log_n, nl = (size_t)1 << tcfg[5].log_n;
+    uint8_t* exposed = (uint8_t*)calloc(nl, 1);
+    for (size_t i = 0; i < 5 * sl_covered; i++) exposed[i] = trace[4][i / 5] || trace[4][ns + i / 5];
+    orc_ctl_set_filter(ORC_AIR_LOGIC, trace[5], tcfg[5].log_n, exposed, nl);
     free(exposed);
   }
   if (lookup_bm) { /* the memory table exposes the operations the byte-packing rows name */
@@ -405,6 +449,21 @@ int orc_pg_check_lookups(const orc_stark_cfg tcfg[NUM_TABLES], const gl_t* const
     const gl_t* looked = proofs[3] + open_first_offset(&tcfg[3]);  /* ... and columns 2, 3 here (after h_0, h_1) */
     for (int c = 0; c < 2; c++)
       if (looking[2 * c] != looked[2 * (2 + c)] || looking[2 * c + 1] != looked[2 * (2 + c) + 1]) return -11;
+  }
+  if (tcfg[4].air_id == ORC_AIR_KECCAK_SPONGE && tcfg[5].air_id == ORC_AIR_LOGIC) {
+    /* the sponge table's ten products into the logic table (columns 2 + 2 m + c), multiplied over m, against the logic
+     * table's z_c: first-row openings are extension elements (c0, c1) */
+    const gl_t* looking = proofs[4] + open_first_offset(&tcfg[4]);
+    const gl_t* looked = proofs[5] + open_first_offset(&tcfg[5]);
+    for (int c = 0; c < 2; c++) {
+      gl2_t prod = gl2_from(1);
+      for (int m = 0; m < 5; m++) {
+        const gl_t* v = looking + 2 * (2 + 2 * m + c);
+        gl2_t x; x.c0 = v[0]; x.c1 = v[1];
+        prod = gl2_mul(prod, x);
+      }
+      if (prod.c0 != looked[2 * c] || prod.c1 != looked[2 * c + 1]) return -13;
+    }
   }
   if (tcfg[1].air_id == ORC_AIR_BYTE_PACKING && tcfg[6].air_id == ORC_AIR_MEMORY) {
     const gl_t* looking = proofs[1] + open_first_offset(&tcfg[1]); /* z_0, z_1 are its aux columns 0, 1 */

@@ -243,7 +243,7 @@ AIR_SYNTHETIC, AIR_KECCAK_F, AIR_LOGIC, AIR_MEMORY, AIR_ARITHMETIC, AIR_BYTE_PAC
 AIR_KECCAK_SPONGE = 6
 AIR_ARITHMETIC_MUL = 7
 KECCAK_COLS = 2431
-LOGIC_COLS = 523
+LOGIC_COLS = 524
 MEMORY_COLS = 45
 ARITHMETIC_COLS = 309
 BYTE_PACKING_COLS = 299
@@ -327,7 +327,7 @@ def keccak_trace(log_n, seed=0, inputs=None):
 
 
 def logic_trace(log_n, seed=0, inputs=None):
-    """orc_logic_trace: the AIR-2 witness [523, 2^log_n]; inputs [2^log_n, 9] (code, operand 0, operand 1) or seeded."""
+    """orc_logic_trace: the AIR-2 witness [524, 2^log_n]; inputs [2^log_n, 9] (code, operand 0, operand 1) or seeded."""
     out = np.zeros((LOGIC_COLS, 1 << log_n), dtype=np.uint64)
     inp = np.ascontiguousarray(inputs, dtype=np.uint64) if inputs is not None else None
     if inp is not None:

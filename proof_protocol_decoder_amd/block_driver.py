@@ -391,14 +391,14 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
     """The synthetic block of SURVEY.md section 8(d): n_txns txns with distinct seeds whose public
     values chain (state root, txn number, gas) like decoding.rs:106-154 chains GenerationInputs.
     keccak_air: every transaction's Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1; the table's width
-    becomes 2431).  logic_air / memory_air: likewise the logic table (index 5) with the logic AIR (AIR 2; width 523) and
+    becomes 2431).  logic_air / memory_air: likewise the logic table (index 5) with the logic AIR (AIR 2; width 524) and
     the memory table (index 6) with the memory AIR (AIR 3; width 45); arithmetic_air: the arithmetic table (index 0)
     with the arithmetic AIR (AIR 4; width 309); byte_packing_air: the byte-packing table (index 1) with AIR 5 (width 299);
     keccak_sponge_air: the Keccak sponge table (index 4) with AIR 6 (width 2414)."""
     if keccak_air:
         table_width = tuple(2431 if t == 3 else w for t, w in enumerate(table_width))
     if logic_air:
-        table_width = tuple(523 if t == 5 else w for t, w in enumerate(table_width))
+        table_width = tuple(524 if t == 5 else w for t, w in enumerate(table_width))
     if memory_air:
         table_width = tuple(45 if t == 6 else w for t, w in enumerate(table_width))
     if arithmetic_air:

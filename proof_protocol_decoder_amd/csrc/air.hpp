@@ -495,8 +495,8 @@ GL_HD void round(const uint64_t a[25], uint32_t rnd, Round& o) {
 //                    q = is_and - is_or - 2 is_xor   (and: ab, or: a + b - ab, xor: a + b - 2ab)
 // Units: unit k = the bits of limb k of both inputs (L2) and L3 + k; unit 0 also takes L0 and L1.
 namespace logic {
-constexpr uint32_t N_COLS = 523, N_CONSTRAINTS = 524, N_UNITS = 8;
-constexpr uint32_t COL_OP = 0, COL_IN0 = 3, COL_IN1 = 259, COL_RES = 515;
+constexpr uint32_t N_COLS = 524, N_CONSTRAINTS = 524, N_UNITS = 8;
+constexpr uint32_t COL_OP = 0, COL_IN0 = 3, COL_IN1 = 259, COL_RES = 515, COL_G = 523;  // COL_G: the lookup's filter (namespace ctl), a TRACE column
 constexpr uint32_t L0 = 0, L1 = 3, L2 = 4, L3 = 516;
 constexpr uint32_t OP_NONE = 0, OP_AND = 1, OP_OR = 2, OP_XOR = 3;
 GL_HD uint32_t apply(uint32_t op, uint32_t a, uint32_t b) {
@@ -1375,7 +1375,10 @@ namespace ctl {
 // columns, committed AFTER the challenges: a prover could then pick the exposed subset knowing the challenges -- a
 // subset-product search over a smooth multiplicative group)  Upstream keeps its filters in the trace too.
 constexpr uint32_t KECCAK_H = 0, KECCAK_Z = 2, KECCAK_N_AUX = 4, KECCAK_N_CONSTRAINTS = 10;
-constexpr uint32_t SPONGE_Z = 0, SPONGE_N_AUX = 2, SPONGE_N_CONSTRAINTS = 4;
+// sponge: z_0 z_1 (-> keccak_f), then per block-of-eight-limbs m < 5 and challenge set c the product 2 + 2 m + c (-> logic)
+constexpr uint32_t SPONGE_Z = 0, SPONGE_LZ = 2, SPONGE_LOGIC_OPS = 5, SPONGE_N_AUX = 2 + 2 * SPONGE_LOGIC_OPS, SPONGE_N_CONSTRAINTS = 2 * SPONGE_N_AUX;
+constexpr uint32_t LOGIC_Z = 0, LOGIC_N_AUX = 2, LOGIC_N_CONSTRAINTS = 5;
+constexpr uint32_t LOGIC_TUPLE = 27;  // is_and, is_or, is_xor, eight limbs of each input, eight of the result
 constexpr uint32_t TUPLE_LIMBS = 50;  // a Keccak state as 32-bit limbs
 constexpr uint32_t PACK_Z = 0, PACK_N_AUX = 2, PACK_N_CONSTRAINTS = 4;
 constexpr uint32_t MEM_Z = 0, MEM_N_AUX = 2, MEM_N_CONSTRAINTS = 5;
@@ -1389,6 +1392,7 @@ GL_HD uint32_t n_aux(const Shape& s) {
          : s.air_id == KECCAK_SPONGE ? SPONGE_N_AUX
          : s.air_id == BYTE_PACKING ? PACK_N_AUX
          : s.air_id == MEMORY ? MEM_N_AUX
+         : s.air_id == LOGIC ? LOGIC_N_AUX
          : s.air_id == PLONK ? PLONK_N_AUX
                              : 1;
 }
@@ -1398,6 +1402,7 @@ GL_HD uint32_t n_constraints(const Shape& s) {
          : s.air_id == KECCAK_SPONGE ? SPONGE_N_CONSTRAINTS
          : s.air_id == BYTE_PACKING ? PACK_N_CONSTRAINTS
          : s.air_id == MEMORY ? MEM_N_CONSTRAINTS
+         : s.air_id == LOGIC ? LOGIC_N_CONSTRAINTS
          : s.air_id == PLONK ? PLONK_N_CONSTRAINTS
                                      : 2;
 }
@@ -1431,6 +1436,58 @@ GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const 
                               TUPLE_LIMBS, beta);
     const T v = F::add(row.aux(KECCAK_H + c), F::mul(b50, out));
     return F::add(F::k(1), F::mul(row.loc(keccak::COL_G), F::sub(F::add(gamma, v), F::k(1))));
+  }
+  if (s.air_id == KECCAK_SPONGE && col >= SPONGE_LZ) {
+    // keccak_sponge -> logic: the XOR of limbs 8m .. 8m + 7 of the rate with the block is one operation of the logic
+    // table: (0, 0, 1 | rate-before limbs | block limbs | xored limbs), limbs past the 34th zero
+    const uint32_t m = (col - SPONGE_LZ) >> 1, c = (col - SPONGE_LZ) & 1;
+    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
+    T acc = F::k(0);  // Horner from the top: result limbs, input-1 limbs, input-0 limbs, then the flags (0, 0, 1)
+#pragma unroll 1
+    for (uint32_t j = 8; j-- > 0;) {
+      const uint32_t l = 8 * m + j;
+      acc = F::mul(acc, beta);
+      if (l < 34) acc = F::add(acc, row.loc(keccak_sponge::COL_XORED + l));
+    }
+#pragma unroll 1
+    for (uint32_t part = 0; part < 2; part++) {  // part 0: the block (input 1), part 1: the rate before (input 0)
+      const uint32_t bits0 = part == 0 ? keccak_sponge::COL_BLOCK : keccak_sponge::COL_RATE;
+#pragma unroll 1
+      for (uint32_t j = 8; j-- > 0;) {
+        const uint32_t l = 8 * m + j;
+        T limb = F::k(0);
+        if (l < 34) {
+#pragma unroll 1
+          for (uint32_t z = 32; z-- > 0;) limb = F::add(F::dbl(limb), row.loc(bits0 + 32 * l + z));
+        }
+        acc = F::add(F::mul(acc, beta), limb);
+      }
+    }
+    acc = F::add(F::mul(acc, beta), F::k(1));  // is_xor
+    acc = F::mul(F::mul(acc, beta), beta);      // is_or = is_and = 0
+    const T f = F::add(row.loc(keccak_sponge::COL_FULL), row.loc(keccak_sponge::COL_FINAL));
+    return F::add(F::k(1), F::mul(f, F::sub(F::add(gamma, acc), F::k(1))));
+  }
+  if (s.air_id == LOGIC) {
+    const uint32_t c = col - LOGIC_Z;
+    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
+    T acc = F::k(0);
+#pragma unroll 1
+    for (uint32_t j = 8; j-- > 0;) acc = F::add(F::mul(acc, beta), row.loc(logic::COL_RES + j));
+#pragma unroll 1
+    for (uint32_t part = 0; part < 2; part++) {
+      const uint32_t bits0 = part == 0 ? logic::COL_IN1 : logic::COL_IN0;
+#pragma unroll 1
+      for (uint32_t j = 8; j-- > 0;) {
+        T limb = F::k(0);
+#pragma unroll 1
+        for (uint32_t z = 32; z-- > 0;) limb = F::add(F::dbl(limb), row.loc(bits0 + 32 * j + z));
+        acc = F::add(F::mul(acc, beta), limb);
+      }
+    }
+#pragma unroll 1
+    for (uint32_t j = 3; j-- > 0;) acc = F::add(F::mul(acc, beta), row.loc(logic::COL_OP + j));
+    return F::add(F::k(1), F::mul(row.loc(logic::COL_G), F::sub(F::add(gamma, acc), F::k(1))));
   }
   if (s.air_id == KECCAK_SPONGE) {
     const uint32_t c = col - SPONGE_Z;
@@ -1519,6 +1576,10 @@ GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const u
     const T g = row.loc(memory::COL_G);
     out.all(idx++, F::sub(F::mul(g, g), g));
   }
+  if (s.air_id == LOGIC) {
+    const T g = row.loc(logic::COL_G);
+    out.all(idx++, F::sub(F::mul(g, g), g));
+  }
   const uint32_t p0 = first_product(s.air_id), p1 = n_aux(s);
 #pragma unroll 1
   for (uint32_t k = p0; k < p1; k++) {
@@ -1532,14 +1593,17 @@ GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const u
 // columns, for challenge set c.  Tables by their position in a transaction (prover_state.rs:85-93).
 struct Pair {
   const char* name;
-  uint32_t looking_table, looking_air, looking_col;  // aux column of challenge set 0; set c is column + c
+  // the looking side: n_looking aux columns of challenge set 0, `stride` apart (set c is column + c): their first-row
+  // values are multiplied together
+  uint32_t looking_table, looking_air, looking_col, n_looking, stride;
   uint32_t looked_table, looked_air, looked_col;
 };
-constexpr uint32_t N_PAIRS = 2;
+constexpr uint32_t N_PAIRS = 3;
 inline const Pair* pairs() {
   static const Pair P[N_PAIRS] = {
-      {"keccak_sponge -> keccak_f", 4, KECCAK_SPONGE, SPONGE_Z, 3, KECCAK_F, KECCAK_Z},
-      {"byte_packing -> memory", 1, BYTE_PACKING, PACK_Z, 6, MEMORY, MEM_Z},
+      {"keccak_sponge -> keccak_f", 4, KECCAK_SPONGE, SPONGE_Z, 1, 2, 3, KECCAK_F, KECCAK_Z},
+      {"byte_packing -> memory", 1, BYTE_PACKING, PACK_Z, 1, 2, 6, MEMORY, MEM_Z},
+      {"keccak_sponge -> logic", 4, KECCAK_SPONGE, SPONGE_LZ, SPONGE_LOGIC_OPS, 2, 5, LOGIC, LOGIC_Z},
   };
   return P;
 }

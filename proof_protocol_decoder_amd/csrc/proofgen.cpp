@@ -720,9 +720,14 @@ static int check_lookups(const StarkCfg tcfg[BP_NUM_TABLES], const std::vector<u
     if (tcfg[p.looking_table].air_id != p.looking_air || tcfg[p.looked_table].air_id != p.looked_air) continue;
     const ProofLayout La = proof_layout(tcfg[p.looking_table]), Lb = proof_layout(tcfg[p.looked_table]);
     for (uint32_t c = 0; c < 2; c++) {
-      const uint64_t* a = proof[p.looking_table].data() + La.open_first + 2 * (p.looking_col + c);
+      // the first-row values of the looking side's product columns, multiplied together, against the looked side's
+      gl::Ext a = gl::ext(1);
+      for (uint32_t m = 0; m < p.n_looking; m++) {
+        const uint64_t* v = proof[p.looking_table].data() + La.open_first + 2 * (p.looking_col + p.stride * m + c);
+        a = gl::mul(a, gl::Ext{v[0], v[1]});
+      }
       const uint64_t* b = proof[p.looked_table].data() + Lb.open_first + 2 * (p.looked_col + c);
-      if (a[0] != b[0] || a[1] != b[1])
+      if (a.c0 != b[0] || a.c1 != b[1])
         return fail(BP_ERR_VERIFY, "cross-table lookup %s does not hold (challenge set %u): the %s table asks for tuples the %s table "
                     "does not expose", p.name, c, TABLE_NAMES[p.looking_table], TABLE_NAMES[p.looked_table]);
     }
@@ -743,7 +748,13 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
   // permutations than the Keccak-f table holds in full, and the seeded Keccak-f table's first permutations are the
   // ones the sponge rows ask for (air::ctl, keccak_sponge -> keccak_f).  Tables given by the caller are taken as they are.
   const bool lookup_kf = tcfg[3].air_id == air::KECCAK_F && tcfg[4].air_id == air::KECCAK_SPONGE;
-  const uint32_t sponge_row_limit = lookup_kf ? (uint32_t)(((uint64_t)1 << tcfg[3].log_n) / 24) : ~0u;
+  // keccak_sponge -> logic: the XOR of every absorbed block with the rate is five operations of the logic table, whose
+  // first rows are then derived from the sponge table's trace (five per covered sponge row; the caller's or seeded
+  // operations follow them); the seeded sponge table absorbs no more blocks than the logic table can hold
+  const bool lookup_sl = tcfg[4].air_id == air::KECCAK_SPONGE && tcfg[5].air_id == air::LOGIC;
+  const uint32_t logic_covered = lookup_sl ? (uint32_t)std::min<uint64_t>((uint64_t)1 << tcfg[4].log_n, ((uint64_t)1 << tcfg[5].log_n) / 5) : 0;
+  const uint32_t sponge_row_limit = std::min<uint32_t>(lookup_kf ? (uint32_t)(((uint64_t)1 << tcfg[3].log_n) / 24) : ~0u,
+                                                       lookup_sl ? logic_covered : ~0u);
   // byte_packing -> memory: the memory table that is not given by the caller is the log of the byte-packing table's
   // words (two operations per packing row); it must be tall enough to hold them
   const bool lookup_bm = tcfg[1].air_id == air::BYTE_PACKING && tcfg[6].air_id == air::MEMORY;
@@ -774,7 +785,27 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
     const uint64_t N = (uint64_t)1 << tcfg[t].log_n, seed = I[10] ^ splitmix64(t + 1);
     const size_t mark = w.arena.mark();
     uint64_t* d_in = nullptr;
-    if (given(t)) {
+    if (t == 5 && lookup_sl) {
+      // [five operations per covered sponge row][the caller's operations, or seeded ones]
+      const size_t n_given = given(5) ? wit->n[5] : 0;
+      if (n_given > N - 5ull * logic_covered)
+        return fail(BP_ERR_INVALID_INPUT, "the logic table (2^%u rows) holds the sponge table's %u XORs first: room for %llu operations, %zu given",
+                    tcfg[5].log_n, 5 * logic_covered, (unsigned long long)(N - 5ull * logic_covered), n_given);
+      d_in = w.arena.alloc_words((size_t)N * 9 + n_given * 9);
+      if (!d_in) return fail(BP_ERR_DEVICE, "device arena exhausted for the logic table's operations");
+      uint64_t* d_given = nullptr;
+      if (n_given) {
+        if (n_given * 9 > w.pinned_words) return fail(BP_ERR_UNSUPPORTED, "too many logic operations for the input staging buffer");
+        std::memcpy(w.pinned, wit->in[5], n_given * 9 * 8);
+        d_given = d_in + (size_t)N * 9;
+        BPG_HIP(hipMemcpyAsync(d_given, w.pinned, n_given * 9 * 8, hipMemcpyHostToDevice, w.stream));
+      }
+      if ((r = launch_logic_inputs_from_sponge(d_trace[4], tcfg[4].log_n, logic_covered, given(5) ? d_given : nullptr, (uint32_t)n_given,
+                                               d_in, (uint32_t)N, seed, w.stream))) return r;
+      if (given(5) && !d_given) {  // an empty list was given: padding operations, not seeded ones
+        BPG_HIP(hipMemsetAsync(d_in + (size_t)5 * logic_covered * 9, 0, ((size_t)N - 5 * logic_covered) * 9 * 8, w.stream));
+      }
+    } else if (given(t)) {
       // the caller's items, then padding up to the table's height, staged through the pinned buffer
       const size_t words = witness_capacity(t, N) * WITNESS_WORDS[t];
       d_in = w.arena.alloc_words(words);
@@ -812,6 +843,10 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
                                d_trace[4] + (size_t)air::keccak_sponge::COL_FINAL * N4, (uint32_t)N4, w.stream);
     } else if (t == 6 && lookup_bm) {  // the operations the byte-packing table looks up: its trace (address, timestamp per row)
       r = launch_lookup_filter(air::MEMORY, d_trace[6], tcfg[6].log_n, d_trace[1], nullptr, (uint32_t)1 << tcfg[1].log_n, w.stream);
+    } else if (t == 5 && lookup_sl) {  // the XORs the sponge table asks for: rows 5 p + m of the rows p that absorb a block
+      const uint64_t N4 = (uint64_t)1 << tcfg[4].log_n;
+      r = launch_lookup_filter(air::LOGIC, d_trace[5], tcfg[5].log_n, d_trace[4] + (size_t)air::keccak_sponge::COL_FULL * N4,
+                               d_trace[4] + (size_t)air::keccak_sponge::COL_FINAL * N4, logic_covered, w.stream);
     }
     if (r) return r;
     if (d_in) {  // the staging buffer and the input words are reused by the next table

@@ -299,9 +299,14 @@ int bp_air_describe(uint32_t air_id, uint32_t n_cols, uint32_t n_const, uint32_t
         fam(i, 1, 0, 2); fam(i + 1, 1, 1, 2); i += 2;
       }
     }
-    if (air_id == air::MEMORY) { fam(i, 1, 0, 2); i += 1; }  // the filter g of byte_packing -> memory: a bit
-    for (uint32_t k = air::ctl::first_product(air_id); k < out->n_aux; k++) {  // filtered running products
-      fam(i, 1, 1, 3); fam(i + 1, 1, 3, 2); i += 2;
+    if (air_id == air::MEMORY || air_id == air::LOGIC) { fam(i, 1, 0, 2); i += 1; }  // the filter g of the looked table: a bit
+    const uint32_t n_products = out->n_aux - air::ctl::first_product(air_id);
+    if (n_products > 4) {  // (the sponge table's twelve) interleaved like the synthetic tables': 2k transition, 2k + 1 last row
+      fam(i, n_products, 1, 3); fam(i + 1, n_products, 3, 2);
+    } else {
+      for (uint32_t k = 0; k < n_products; k++) {  // filtered running products
+        fam(i, 1, 1, 3); fam(i + 1, 1, 3, 2); i += 2;
+      }
     }
   }
   out->n_families = n;

@@ -154,6 +154,7 @@ logic_trace_kernel(uint64_t* __restrict__ t, const uint64_t* __restrict__ inputs
       const uint32_t a = (uint32_t)(w[0][k >> 1] >> (32 * (k & 1))), b = (uint32_t)(w[1][k >> 1] >> (32 * (k & 1)));
       put(lg::COL_RES + k, lg::apply(op, a, b));
     }
+    put(lg::COL_G, 0);  // the lookup's filter: set by logic_lookup_filter_kernel where the sponge table asks
   }
   for (uint32_t z = 0; z < 256; z++) put((j ? lg::COL_IN1 : lg::COL_IN0) + z, (w[j][z >> 6] >> (z & 63)) & 1);
 }
@@ -402,6 +403,53 @@ keccak_inputs_from_sponge_kernel(const uint64_t* __restrict__ sponge, uint32_t s
     }
     inputs[(uint64_t)p * 25 + l] = v;
   }
+}
+
+// The operations a transaction's logic table holds when its sponge table is real too (keccak_sponge -> logic, air::ctl):
+// rows 5 p + m, p < covered sponge rows, are the XOR of limbs 8 m .. 8 m + 7 of sponge row p's rate with its block where
+// row p absorbs a block (a padding operation where it does not); the rows after them are the caller's operations
+// (`given`, n_given of them, then padding) or, without any, drawn from the seed as logic_trace_kernel would draw them.
+// inputs: [n_logic][9] = code, operand 0 (rate before), operand 1 (block), as logic_trace_kernel reads them.
+__global__ void __launch_bounds__(256)
+logic_inputs_from_sponge_kernel(const uint64_t* __restrict__ sponge, uint32_t sponge_log_n, uint32_t covered,
+                                const uint64_t* __restrict__ given, uint32_t n_given, uint64_t* __restrict__ inputs, uint32_t n_logic,
+                                uint64_t seed) {
+  namespace sp = bpg::air::keccak_sponge;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << sponge_log_n;
+  if (i >= n_logic) return;
+  uint64_t* o = inputs + (uint64_t)i * 9;
+  const uint32_t region = 5 * covered;
+  if (i < region) {
+    const uint32_t p = i / 5, m = i % 5;
+    const bool asked = (sponge[(uint64_t)sp::COL_FULL * n + p] + sponge[(uint64_t)sp::COL_FINAL * n + p]) != 0;
+    o[0] = asked ? bpg::air::logic::OP_XOR : bpg::air::logic::OP_NONE;
+    for (uint32_t j = 0; j < 2; j++)
+      for (uint32_t w = 0; w < 4; w++) {
+        uint64_t v = 0;
+        if (asked)
+          for (uint32_t z = 0; z < 64; z++) {
+            const uint32_t bit = 256 * m + 64 * w + z;  // bit of the 1088-bit rate / block
+            if (bit < 1088) v |= (sponge[(uint64_t)((j ? sp::COL_BLOCK : sp::COL_RATE) + bit) * n + p] & 1) << z;
+          }
+        o[1 + 4 * j + w] = v;
+      }
+    return;
+  }
+  const uint32_t k = i - region;
+  if (given) {
+    for (uint32_t w = 0; w < 9; w++) o[w] = k < n_given ? given[(uint64_t)k * 9 + w] : 0;
+  } else {
+    o[0] = splitmix64(seed ^ (0xFFull << 32) ^ i) & 3u;
+    for (uint32_t w = 0; w < 8; w++) o[1 + w] = splitmix64(seed ^ ((uint64_t)(1 + w) << 32) ^ i);
+  }
+}
+// ... and the filter of that table: g = 1 on the rows 5 p + m whose sponge row p absorbs a block
+__global__ void __launch_bounds__(256)
+logic_lookup_filter_kernel(uint64_t* __restrict__ trace, uint32_t log_n, const uint64_t* __restrict__ full, const uint64_t* __restrict__ fin,
+                           uint32_t covered) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << log_n;
+  if (i >= 5 * covered || i >= n) return;
+  trace[(uint64_t)bpg::air::logic::COL_G * n + i] = (full[i / 5] + fin[i / 5]) != 0;
 }
 
 // ---------------------------------------------------------------- multiplication witness (AIR 7, air.hpp)
@@ -1474,6 +1522,15 @@ int launch_keccak_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sp
   BPG_LAUNCH_CHECK();
   return BP_OK;
 }
+int launch_logic_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sponge_log_n, uint32_t covered, const uint64_t* d_given,
+                                    uint32_t n_given, uint64_t* d_inputs, uint32_t n_logic, uint64_t seed, hipStream_t st) {
+  if (5ull * covered > n_logic || covered > (1u << sponge_log_n))
+    return fail(BP_ERR_INVALID_INPUT, "the logic table (%u rows) cannot hold five operations for each of %u sponge rows", n_logic, covered);
+  logic_inputs_from_sponge_kernel<<<ceil_div(n_logic, 256), 256, 0, st>>>(d_sponge_trace, sponge_log_n, covered, d_given, n_given, d_inputs,
+                                                                           n_logic, seed);
+  BPG_LAUNCH_CHECK();
+  return BP_OK;
+}
 int launch_memory_inputs_from_byte_packing(const uint64_t* d_pack_trace, uint32_t pack_log_n, uint64_t* d_log, uint32_t n_mem,
                                            hipStream_t st) {
   memory_inputs_from_byte_packing_kernel<<<ceil_div(n_mem, 256), 256, 0, st>>>(d_pack_trace, pack_log_n, d_log, n_mem);
@@ -1488,6 +1545,9 @@ int launch_lookup_filter(uint32_t air_id, uint64_t* d_trace, uint32_t log_n, con
     keccak_lookup_filter_kernel<<<ceil_div((uint64_t)1 << log_n, 256), 256, 0, st>>>(d_trace, log_n, flag_a, flag_b, n_flags);
   } else if (air_id == air::MEMORY) {
     memory_lookup_filter_kernel<<<ceil_div(n_flags, 256), 256, 0, st>>>(d_trace, log_n, flag_a, n_flags);
+  } else if (air_id == air::LOGIC) {  // flag_a / flag_b: the sponge table's is_full / is_final columns, n_flags: covered sponge rows
+    if (!flag_b) return fail(BP_ERR_INVALID_INPUT, "launch_lookup_filter: the logic table's filter needs both flag columns of the sponge table");
+    logic_lookup_filter_kernel<<<ceil_div(5ull * n_flags, 256), 256, 0, st>>>(d_trace, log_n, flag_a, flag_b, n_flags);
   } else {
     return fail(BP_ERR_INVALID_INPUT, "launch_lookup_filter: AIR %u is not a looked table", air_id);
   }
@@ -1561,7 +1621,7 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
   // algorithmic bytes: every column a product reads, once, and the product column written (SURVEY.md section 8(d):
   // 24 n per column of a synthetic table)
   const double reads = air_id == air::SYNTHETIC ? 2 : air_id == air::KECCAK_F ? 53 : air_id == air::KECCAK_SPONGE ? 102
-                       : air_id == air::BYTE_PACKING ? 43 : air_id == air::MEMORY ? 12 : 0;
+                       : air_id == air::BYTE_PACKING ? 43 : air_id == air::MEMORY ? 12 : air_id == air::LOGIC ? 524 : 0;
   KernelTimer kt(PROF_AUX, st, 8.0 * (double)((uint64_t)1 << log_n) * (reads + 1) * (n_aux - p0) * batch, true);
   switch (air_id) {
     case air::SYNTHETIC: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::SYNTHETIC>, grid, threads, 0, st, ab, log_n, n_cols); break;
@@ -1569,7 +1629,8 @@ int launch_aux(const AuxArgs* a, uint32_t batch, uint32_t air_id, uint32_t n_col
     case air::KECCAK_SPONGE: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::KECCAK_SPONGE>, grid, threads, 0, st, ab, log_n, n_cols); break;
     case air::BYTE_PACKING: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::BYTE_PACKING>, grid, threads, 0, st, ab, log_n, n_cols); break;
     case air::MEMORY: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::MEMORY>, grid, threads, 0, st, ab, log_n, n_cols); break;
-    default: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::LOGIC>, grid, threads, 0, st, ab, log_n, n_cols); break;  // no lookup: z = 1
+    case air::LOGIC: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::LOGIC>, grid, threads, 0, st, ab, log_n, n_cols); break;
+    default: BPG_LAUNCH_TIMED(kt, aux_suffix_product_kernel<air::ARITHMETIC>, grid, threads, 0, st, ab, log_n, n_cols); break;  // no lookup: z = 1
   }
   BPG_LAUNCH_CHECK();
   return BP_OK;

@@ -181,6 +181,10 @@ int launch_keccak_sponge_trace(uint64_t* d_trace, const uint64_t* d_inputs, uint
 int launch_keccak_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sponge_log_n, uint64_t* d_inputs, uint32_t n_perms,
                                      uint64_t seed, hipStream_t st);
 // the memory log ([n_mem][11], for launch_memory_trace) that goes with a byte-packing trace: two operations per packing row
+// the logic table's operations when the sponge table is proven by its AIR too (keccak_sponge -> logic): five per covered sponge row,
+// then the caller's (d_given, may be null) or seeded ones
+int launch_logic_inputs_from_sponge(const uint64_t* d_sponge_trace, uint32_t sponge_log_n, uint32_t covered, const uint64_t* d_given,
+                                    uint32_t n_given, uint64_t* d_inputs, uint32_t n_logic, uint64_t seed, hipStream_t st);
 int launch_memory_inputs_from_byte_packing(const uint64_t* d_pack_trace, uint32_t pack_log_n, uint64_t* d_log, uint32_t n_mem,
                                            hipStream_t st);
 // The filter column of a LOOKED table's trace (air::ctl; keccak::COL_G, memory::COL_G), written after its witness and

@@ -74,7 +74,7 @@ def field_ops(a, b):
 
 AIR_SYNTHETIC, AIR_KECCAK_F = 0, 1
 KECCAK_COLS = 2431
-LOGIC_COLS = 523
+LOGIC_COLS = 524
 MEMORY_COLS = 45
 ARITHMETIC_COLS = 309
 BYTE_PACKING_COLS = 299
@@ -91,7 +91,7 @@ def air_describe(air_id, n_cols=0, n_const=0, deg_pow=1):
 
 
 def logic_trace(log_n, seed=0, inputs=None, device="cuda"):
-    """bp_logic_trace: the AIR-2 witness [523, 2^log_n]; inputs [2^log_n, 9] int64 on the device (operation code, the
+    """bp_logic_trace: the AIR-2 witness [524, 2^log_n]; inputs [2^log_n, 9] int64 on the device (operation code, the
     four words of operand 0, of operand 1), or drawn from `seed`."""
     out = torch.empty((LOGIC_COLS, 1 << log_n), dtype=torch.int64, device=device)
     if inputs is not None:

@@ -130,7 +130,7 @@ class TxnProofGenIR:
     keccak_air: bool = False   # the Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1, 2431 columns)
     keccak_inputs: tuple = None   # ... attesting THESE permutations ([n][25] lanes) instead of seeded ones; not part of
                                   # the 25-word IR: handed to bp_generate_txn_proof_keccak beside it
-    logic_air: bool = False    # the logic table (index 5) is proven with the logic AIR (AIR 2, 523 columns)
+    logic_air: bool = False    # the logic table (index 5) is proven with the logic AIR (AIR 2, 524 columns)
     memory_air: bool = False   # the memory table (index 6) with the memory AIR (AIR 3, 45 columns)
     arithmetic_air: bool = False   # the arithmetic table (index 0) with the arithmetic AIR (AIR 4, 309 columns)
     byte_packing_air: bool = False   # the byte-packing table (index 1) with the byte-packing AIR (AIR 5, 299 columns)

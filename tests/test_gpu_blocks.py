@@ -122,7 +122,7 @@ def test_txn_with_six_real_tables_at_baseline_sizes_matches_the_oracle(pg, defau
         pass
     ir = synthetic_block_irs(4100, 2, S1_LOG_N, S1_WIDTH, keccak_air=True, logic_air=True, memory_air=True, arithmetic_air=True,
                              byte_packing_air=True, keccak_sponge_air=True)[1]
-    assert ir.table_width == (309, 299, 192, 2431, 2414, 523, 45)
+    assert ir.table_width == (309, 299, 192, 2431, 2414, 524, 45)
     got = pg.generate_txn_proof(default_state, ir)
     want = oracle.PgState(**DEFAULT_ORACLE_CFG).txn(list(struct.unpack("<25Q", ir.to_bytes())))
     assert words(got.intern).shape == want.shape and (words(got.intern) == want).all()

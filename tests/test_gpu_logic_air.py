@@ -15,7 +15,7 @@ SEED = 0x5EED000000000006
 def test_witness_matches_oracle(bpg, oracle, log_n):
     want = oracle.logic_trace(log_n, seed=SEED + log_n)
     got = to_host(bpg.ops.logic_trace(log_n, seed=SEED + log_n))
-    assert got.shape == want.shape == (523, 1 << log_n) and (got == want).all()
+    assert got.shape == want.shape == (524, 1 << log_n) and (got == want).all()
     rng = np.random.default_rng(log_n)
     inputs = rng.integers(0, 1 << 64, size=(1 << log_n, 9), dtype=np.uint64)   # codes: the low two bits of any word
     want = oracle.logic_trace(log_n, inputs=inputs)
@@ -34,22 +34,22 @@ def test_quotient_eval_matches_oracle(bpg, oracle, log_n):
     challenges.  2^5 / 2^10 rows spread the eight units and the CTL part over grid.y, 2^14 is closer to one pass."""
     rng = np.random.default_rng(900 + log_n)
     rows = (1 << log_n) << 1
-    trace = rand_field(rng, (523, rows))
+    trace = rand_field(rng, (524, rows))
     aux = rand_field(rng, (1, rows))
     ctl, alphas = rand_field(rng, (4,)), rand_field(rng, (2,))
-    want = oracle.quotient_values(oracle.make_cfg(log_n, 523, air_id=2), None, trace, aux, ctl, alphas[0], alphas[1])
+    want = oracle.quotient_values(oracle.make_cfg(log_n, 524, air_id=2), None, trace, aux, ctl, alphas[0], alphas[1])
     idx = coset_major_to_natural(log_n, 1)
 
     def to_cm(mat):
         cm = np.empty_like(mat)
         cm[:, idx] = mat
         return to_dev(cm)
-    got = bpg.ops.quotient_eval(bpg.ops.stark_cfg(log_n, 523), to_cm(trace), to_cm(aux), None, ctl, alphas, air_id=2)
+    got = bpg.ops.quotient_eval(bpg.ops.stark_cfg(log_n, 524), to_cm(trace), to_cm(aux), None, ctl, alphas, air_id=2)
     assert (to_host(got)[:, idx] == want).all()
 
 
 def oracle_proof(oracle, log_n, nq, pb, seed):
-    cfg = oracle.make_cfg(log_n, 523, num_queries=nq, pow_bits=pb, air_id=2)
+    cfg = oracle.make_cfg(log_n, 524, num_queries=nq, pow_bits=pb, air_id=2)
     tr = oracle.logic_trace(log_n, seed=seed)
     tc = oracle.Committed.from_values(tr, 1, 4)
     ch = oracle.PyChallenger()
@@ -69,7 +69,7 @@ def test_table_proof_bit_exact(bpg, oracle, log_n, nq, pb, loaded):
     """prove -> verify, bit-flip rejection, HIP bytes == oracle bytes.  2^12 rows is the bottom of the reference's
     logic range (constants.rs:14).  loaded: K5 in ONE pass, as the library runs it while provers share the device."""
     cfg, want, ctl, chv = oracle_proof(oracle, log_n, nq, pb, SEED)
-    pc = bpg.ops.stark_cfg(log_n, 523, num_queries=nq, pow_bits=pb)
+    pc = bpg.ops.stark_cfg(log_n, 524, num_queries=nq, pow_bits=pb)
     bpg.lib().bp_tune_assume_loaded(loaded)
     try:
         got = bpg.ops.stark_prove_air(2, pc, SEED)
@@ -87,7 +87,7 @@ def test_table_proof_bit_exact(bpg, oracle, log_n, nq, pb, loaded):
 
 def test_wrong_shapes_for_the_air_are_refused(bpg):
     from proof_protocol_decoder_amd._lib import BpgError
-    for kw in (dict(n_cols=524), dict(n_cols=523, n_const=2), dict(n_cols=523, deg_pow=3, rate_bits=3)):
+    for kw in (dict(n_cols=523), dict(n_cols=524, n_const=2), dict(n_cols=524, deg_pow=3, rate_bits=3)):
         cfg = bpg.ops.stark_cfg(6, kw.pop("n_cols"), num_queries=6, pow_bits=6, **kw)
         with pytest.raises(BpgError, match="logic"):
             bpg.ops.stark_prove_air(2, cfg, 1)

@@ -576,14 +576,14 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
     Keccak sponge (4), logic (5) and memory (6) tables of the transaction are proven with AIR 4, 5, 1, 6, 2 and 3; only
     the CPU table (2) stays synthetic.  Byte parity with the oracle; the block verifies."""
     width = list(WIDTH)
-    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2431, 2414, 523, 45
+    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2431, 2414, 524, 45
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
                            memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
     t0 = pg.generate_txn_proof(p_state, ir0)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))
-    assert iw[1] == 0x3F01 and iw[18 + 0] == 309 and iw[18 + 1] == 299 and iw[18 + 4] == 2414 and iw[18 + 5] == 523 and iw[18 + 6] == 45
+    assert iw[1] == 0x3F01 and iw[18 + 0] == 309 and iw[18 + 1] == 299 and iw[18 + 4] == 2414 and iw[18 + 5] == 524 and iw[18 + 6] == 45
     assert (words(t0.intern) == o_state.txn(iw)).all()
-    only_logic = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), (*WIDTH[:5], 523, WIDTH[6]), logic_air=True)
+    only_logic = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0020, tuple(LOG_N), (*WIDTH[:5], 524, WIDTH[6]), logic_air=True)
     t_l = pg.generate_txn_proof(p_state, only_logic)
     iw_l = list(struct.unpack("<25Q", only_logic.to_bytes()))
     assert iw_l[1] == 0x201 and (words(t_l.intern) == o_state.txn(iw_l)).all() and t_l.intern != t0.intern
@@ -591,7 +591,7 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
     blk = pg.generate_block_proof(p_state, None, pg.generate_agg_proof(p_state, t0, t1))
     pg.VerifierState.from_prover_state(p_state).verify(blk)
     assert o_state.verify(words(blk.intern)) == 0
-    with pytest.raises(pg.ProofGenError, match="523"):                         # the AIR's width is not negotiable
+    with pytest.raises(pg.ProofGenError, match="524"):                         # the AIR's width is not negotiable
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), logic_air=True).to_bytes()
     with pytest.raises(pg.ProofGenError, match="45"):
         pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 1, tuple(LOG_N), tuple(WIDTH), memory_air=True).to_bytes()
@@ -609,7 +609,7 @@ def test_table_proofs_and_their_lookups_match_the_oracle(pg, p_state, o_state, o
     byte-packing table's words are operations of the memory table (csrc/air.hpp namespace ctl): bytes equal the oracle's (oracle/ctl.c states the lookup columns independently), both
     verifiers accept both provers' output, and the prover refuses tables that are valid alone but not one statement."""
     width = list(WIDTH)
-    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2431, 2414, 523, 45
+    width[0], width[1], width[3], width[4], width[5], width[6] = 309, 299, 2431, 2414, 524, 45
     ir0 = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0C71, tuple(LOG_N), tuple(width), keccak_air=True, logic_air=True,
                            memory_air=True, arithmetic_air=True, byte_packing_air=True, keccak_sponge_air=True)
     iw = list(struct.unpack("<25Q", ir0.to_bytes()))

@@ -420,7 +420,7 @@ def test_witness_entry_points_check_their_arguments_before_any_device_work():
         assert f(None, 1, 40, C.c_void_p(8), None) == -2
     pg._bind()
     ir = (C.c_uint64 * 25)(*struct_ir())
-    for setter, width in (("bp_ir_set_keccak_air", b"2431"), ("bp_ir_set_logic_air", b"523"), ("bp_ir_set_memory_air", b"45"),
+    for setter, width in (("bp_ir_set_keccak_air", b"2431"), ("bp_ir_set_logic_air", b"524"), ("bp_ir_set_memory_air", b"45"),
                           ("bp_ir_set_arithmetic_air", b"309"), ("bp_ir_set_byte_packing_air", b"299"),
                           ("bp_ir_set_keccak_sponge_air", b"2414")):
         f = getattr(L, setter)
@@ -431,7 +431,7 @@ def test_witness_entry_points_check_their_arguments_before_any_device_work():
         assert f(junk, 1) == -2 and b"not an IR" in L.bp_last_error()
     # all four flags together, each on a table of the right width
     w = list(struct_ir())
-    w[18 + 0], w[18 + 1], w[18 + 3], w[18 + 4], w[18 + 5], w[18 + 6] = 309, 299, 2431, 2414, 523, 45
+    w[18 + 0], w[18 + 1], w[18 + 3], w[18 + 4], w[18 + 5], w[18 + 6] = 309, 299, 2431, 2414, 524, 45
     ir = (C.c_uint64 * 25)(*w)
     for setter in ("bp_ir_set_arithmetic_air", "bp_ir_set_byte_packing_air", "bp_ir_set_keccak_air", "bp_ir_set_keccak_sponge_air",
                    "bp_ir_set_logic_air", "bp_ir_set_memory_air"):

@@ -151,8 +151,9 @@ def test_air_registry_describes_the_keccak_sponge_air():
     L = pkg.lib()
     assert L.bp_air_count() == 9
     d = pkg.ops.air_describe(6)
-    assert d.name == b"keccak_sponge" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (2414, 2414, 2, 2)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (2587, 4, 36)
+    assert d.name == b"keccak_sponge" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (2414, 2414, 12, 2)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (2587, 24, 36)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:11]) == 2587 and fams[8] == (2486, 50, 1, 2) and fams[10] == (2586, 1, 1, 2)
-    assert fams[11:] == [(2587, 1, 1, 3), (2588, 1, 3, 2), (2589, 1, 1, 3), (2590, 1, 3, 2)]   # the looking products
+    # the twelve looking products (two into the Keccak-f table, ten into the logic table), interleaved transition / last row
+    assert fams[11:] == [(2587, 12, 1, 3), (2588, 12, 3, 2)]

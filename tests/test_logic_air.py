@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 P = 0xFFFFFFFF00000001
-COL_OP, COL_IN0, COL_IN1, COL_RES, N_COLS = 0, 3, 259, 515, 523
+COL_OP, COL_IN0, COL_IN1, COL_RES, N_COLS = 0, 3, 259, 515, 524
 OPS = {0: lambda a, b: 0, 1: lambda a, b: a & b, 2: lambda a, b: a | b, 3: lambda a, b: a ^ b}
 
 
@@ -97,7 +97,7 @@ def test_oracle_proof_is_accepted_by_both_verifiers_and_tampering_is_not(oracle,
 # one wrong cell per constraint family: (column, row, new value or None = flip the bit, what it breaks)
 BREAKS = [(COL_OP, 3, 2, "L0 flag not a bit"), (COL_OP + 1, 5, None, "L1 two operations / L3"),
           (COL_IN0 + 77, 9, 2, "L2 operand bit not a bit"), (COL_IN1 + 200, 11, None, "L3 result of limb 6"),
-          (COL_RES + 4, 20, None, "L3 result limb")]
+          (COL_RES + 4, 20, None, "L3 result limb"), (523, 7, 2, "lookup filter is a bit")]
 
 
 @pytest.mark.parametrize("col,row,val,what", BREAKS, ids=[b[3] for b in BREAKS])
@@ -122,10 +122,12 @@ def test_air_registry_describes_the_logic_air():
     L = pkg.lib()
     assert L.bp_air_count() == 9
     d = pkg.ops.air_describe(2)
-    assert d.name == b"logic" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (523, 523, 1, 3)
-    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (524, 2, 8)
+    assert d.name == b"logic" and (d.fixed_n_cols, d.n_cols, d.n_aux, d.degree) == (524, 524, 2, 3)
+    assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (524, 5, 8)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert fams[:4] == [(0, 3, 0, 2), (3, 1, 0, 2), (4, 512, 0, 2), (516, 8, 0, 3)]
+    # the lookup keccak_sponge -> logic: the filter is a bit, two filtered running products
+    assert fams[4:] == [(524, 1, 0, 2), (525, 1, 1, 3), (526, 1, 3, 2), (527, 1, 1, 3), (528, 1, 3, 2)]
     # a table of the wrong width is refused
-    cfg = pkg.ops.stark_cfg(6, 524)
+    cfg = pkg.ops.stark_cfg(6, 523)
     assert L.bp_stark_verify_air(2, C.byref(cfg), None, b"\0" * 8, 8) != 0

@@ -1,6 +1,6 @@
 """Cross-table lookups (CPU): the tables of a transaction that are proven with their AIRs form ONE statement
 (proof_gen.rs:44-52 proves all tables in one call; upstream ties them with plonky2_evm's cross-table lookups).  Built
-here: keccak_sponge -> keccak_f and byte_packing -> memory (csrc/air.hpp namespace ctl, oracle/ctl.c, AIRS.md section 3).  The oracle proves a
+here: keccak_sponge -> keccak_f, keccak_sponge -> logic and byte_packing -> memory (csrc/air.hpp namespace ctl, oracle/ctl.c, AIRS.md section 3).  The oracle proves a
 transaction's seven tables; its own verifier and the product's CPU verifier (independent statements of the lookup
 constraints) both accept; tables that are each valid alone but disagree with each other are rejected by both."""
 import numpy as np
@@ -8,7 +8,7 @@ import pytest
 
 from pg_common import LOG_N, SMALL, WIDTH, ir_words
 
-REAL_WIDTH = {0: 309, 1: 299, 3: 2431, 4: 2414, 5: 523, 6: 45}
+REAL_WIDTH = {0: 309, 1: 299, 3: 2431, 4: 2414, 5: 524, 6: 45}
 REAL_FLAG = {3: 0x100, 5: 0x200, 6: 0x400, 0: 0x800, 1: 0x1000, 4: 0x2000}
 
 
@@ -69,8 +69,22 @@ def test_seeded_tables_of_a_transaction_are_one_statement(oracle, o_state, produ
     packing, memory = first_row_openings(oracle, tp, 1), first_row_openings(oracle, tp, 6)
     assert (packing[0] == memory[0]).all() and (packing[1] == memory[1]).all()
     assert tuple(packing[0]) != (1, 0) and tuple(packing[0]) != tuple(packing[1])
+    # keccak_sponge -> logic: the XORs of every absorbed block are operations of the logic table -- per challenge set the
+    # product of the sponge table's five columns (limb groups m = 0..4: aux columns 2 + 2 m + c) is the logic table's z_c
+    logic = first_row_openings(oracle, tp, 5)
+    assert looking.shape == (12, 2) and logic.shape == (2, 2)
+    for c in range(2):
+        prod = (1, 0)
+        for m in range(5):
+            prod = ext_mul(prod, tuple(int(x) for x in looking[2 + 2 * m + c]))
+        assert prod == tuple(int(x) for x in logic[c]) and prod != (1, 0)
     # a table no lookup is built for carries the constant product
-    assert (first_row_openings(oracle, tp, 5) == [[1, 0]]).all()
+    assert (first_row_openings(oracle, tp, 0) == [[1, 0]]).all()
+    # a real logic table next to a synthetic sponge table exposes nothing
+    tp4 = o_state.txn_tables(real_ir({5}))
+    assert o_state.verify_tables(tp4) == 0
+    pg.verify_txn_table_proofs(cfg, tp4.tobytes())
+    assert (first_row_openings(oracle, tp4, 5) == [[1, 0], [1, 0]]).all()
     # a real memory table next to a synthetic byte-packing table exposes nothing
     tp3 = o_state.txn_tables(real_ir({6}))
     assert o_state.verify_tables(tp3) == 0
@@ -81,6 +95,48 @@ def test_seeded_tables_of_a_transaction_are_one_statement(oracle, o_state, produ
     assert o_state.verify_tables(tp2) == 0
     pg.verify_txn_table_proofs(cfg, tp2.tobytes())
     assert (first_row_openings(oracle, tp2, 3)[2:] == [[1, 0], [1, 0]]).all()
+
+
+P = 0xFFFFFFFF00000001
+
+
+def ext_mul(a, b):
+    """(a0 + a1 X)(b0 + b1 X) with X^2 = 7"""
+    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def test_sponge_rows_the_logic_table_has_no_operations_for_are_refused(oracle, o_state, product_cfg):
+    """keccak_sponge -> logic alone (sponge and logic tables by their AIRs, the Keccak-f table synthetic): the logic
+    table of the small configuration (2^6 rows) holds the XORs of twelve sponge rows; given sponge rows that absorb
+    thirteen blocks are still a valid absorption, and the logic table is still a table of valid operations -- but one block's
+    XORs are nobody's operations."""
+    pg, cfg = product_cfg
+    ir = real_ir({4, 5})
+    rows, _ = sponge_and_keccak_work(oracle, [b"a" * 130, bytes(range(250)) * 4, b"xyz"])     # 1 + 8 + 1 = 10 blocks
+    assert len(rows) == 10
+    good = o_state.txn_tables(ir, witness={4: rows})
+    assert o_state.verify_tables(good) == 0
+    pg.verify_txn_table_proofs(cfg, good.tobytes())
+    logic = first_row_openings(oracle, good, 5)
+    assert tuple(int(x) for x in logic[0]) != (1, 0)
+    # the caller's own logic operations follow the sponge table's in the logic table and do not disturb the lookup
+    ops = [[3, 1, 2, 3, 4, 5, 6, 7, 8], [1, 9, 9, 9, 9, 7, 7, 7, 7]]
+    both = o_state.txn_tables(ir, witness={4: rows, 5: ops})
+    assert o_state.verify_tables(both) == 0
+    pg.verify_txn_table_proofs(cfg, both.tobytes())
+    rows13, _ = sponge_and_keccak_work(oracle, [bytes(range(250)) * 6, b"q"])                # 12 + 1 = 13 blocks
+    assert len(rows13) == 13
+    with pytest.raises(RuntimeError, match="-13"):          # the prover refuses to go on
+        o_state.txn_tables(ir, witness={4: rows13})
+    oracle.lib().orc_pg_set_prover_lookup_check(0)
+    try:
+        bad = o_state.txn_tables(ir, witness={4: rows13})
+    finally:
+        oracle.lib().orc_pg_set_prover_lookup_check(1)
+    assert o_state.verify_tables(bad) == -13
+    with pytest.raises(pg.ProofGenError, match="cross-table lookup keccak_sponge -> logic does not hold") as e:
+        pg.verify_txn_table_proofs(cfg, bad.tobytes())
+    assert e.value.code == -5
 
 
 def sponge_and_keccak_work(oracle, messages):

@@ -19,8 +19,8 @@ CASES = [  # name, air_id, columns, log_n (the S1 height of the table), in the c
     ("byte packing (AIR 5)", 5, 299, 9, False),
     ("byte packing (AIR 5) at 2^14", 5, 299, 14, True),
     ("keccak_f (AIR 1)", 1, 2431, 14, True),
-    ("logic (AIR 2)", 2, 523, 12, False),
-    ("logic (AIR 2) at 2^16", 2, 523, 16, True),
+    ("logic (AIR 2)", 2, 524, 12, False),
+    ("logic (AIR 2) at 2^16", 2, 524, 16, True),
     ("memory (AIR 3)", 3, 45, 17, True),
     ("keccak sponge (AIR 6)", 6, 2414, 9, False),
     ("keccak sponge (AIR 6) at 2^12", 6, 2414, 12, True),
