@@ -34,7 +34,7 @@ def test_quotient_eval_matches_oracle(bpg, oracle, log_n):
     rng = np.random.default_rng(900 + log_n)
     rows = (1 << log_n) << 1
     trace = rand_field(rng, (2414, rows))
-    aux = rand_field(rng, (2, rows))
+    aux = rand_field(rng, (12, rows))   # two products into the Keccak-f table, ten into the logic table
     ctl, alphas = rand_field(rng, (4,)), rand_field(rng, (2,))
     want = oracle.quotient_values(oracle.make_cfg(log_n, 2414, air_id=6), None, trace, aux, ctl, alphas[0], alphas[1])
     idx = coset_major_to_natural(log_n, 1)
