@@ -328,7 +328,7 @@ def main():
         what = []
         if real_airs:
             what.append("the six tables that have an AIR proven with it (AIR 4, 5, 1, 6, 2, 3: 309 / 299 / 2431 / 2414 / 524 / 45 "
-                        "columns), the CPU table synthetic; cross-table lookup keccak_sponge -> keccak_f checked in every txn")
+                        "columns), the CPU table synthetic; cross-table lookups keccak_sponge -> keccak_f, keccak_sponge -> logic and byte_packing -> memory checked in every txn")
         if synthetic_rec:
             what.append("every recursion-shaped proof a proof of the synthetic AIR (135 x 82 columns, 16 auxiliary columns) "
                         "instead of the PLONK-shaped circuit: the recursion workload of rounds 1-3")

@@ -216,7 +216,7 @@ struct bp_stark_cfg;
  * proof_gen.rs:44-52; the seven zkEVM tables of prover_state.rs:85-93, Keccak range constants.rs:12) is here an
  * air_id: 0 = the synthetic AIR of DESIGN.md section 4 (any width), 1 = keccak_f, one round of Keccak-f[1600] per
  * row on 2431 columns, written from FIPS 202 (not upstream's column layout), 2 = logic, one AND / OR / XOR of two
- * 256-bit words per row on 523 columns, 3 = memory, a log of reads and writes sorted by (address, timestamp) on 44
+ * 256-bit words per row on 524 columns, 3 = memory, a log of reads and writes sorted by (address, timestamp) on 45
  * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns, 5 = byte_packing,
  * a big-endian byte sequence and the word it spells on 299 columns, 6 = keccak_sponge, the absorbing side of
  * Keccak-256 (XOR into the rate, chaining, pad10*1) on 2414 columns, 7 = arithmetic_mul, x * y = z + 2^256 w on 1217
@@ -269,8 +269,8 @@ int bp_quotient_eval(uint32_t air_id, const struct bp_stark_cfg* shape, const ui
  * columns (the last one, the lookup's filter, zero), column-major, row r = round r % 24 of permutation r / 24.  d_inputs: [ceil(n / 24)][25] input lanes
  * (any u64; lane x + 5y), or NULL to draw them from `seed` (splitmix64(seed ^ (lane << 32) ^ permutation)). */
 int bp_keccak_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
-/* Witness of AIR 2 (the logic table: one AND / OR / XOR of two 256-bit words per row): n = 2^log_n rows x 523 columns,
- * column-major.  d_inputs: [n][9] = operation code (0 none = a padding row, 1 and, 2 or, 3 xor), then the four 64-bit
+/* Witness of AIR 2 (the logic table: one AND / OR / XOR of two 256-bit words per row): n = 2^log_n rows x 524 columns
+ * (the last one, the filter of the lookup keccak_sponge -> logic, zero), column-major.  d_inputs: [n][9] = operation code (0 none = a padding row, 1 and, 2 or, 3 xor), then the four 64-bit
  * words of operand 0 and of operand 1, least significant first; or NULL to draw them from `seed`
  * (code = splitmix64(seed ^ (0xFF << 32) ^ row) & 3, word w of operand j = splitmix64(seed ^ ((1 + 4 j + w) << 32) ^ row)). */
 int bp_logic_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t log_n, uint64_t* d_trace_out, void* stream);
@@ -359,7 +359,7 @@ typedef struct bp_stark_cfg {
 } bp_stark_cfg;
 int bp_stark_prove_synthetic(const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                              uint8_t** out, size_t* out_len);
-/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 .. 7: n_cols = 2431 / 523 / 45 / 309 / 299 / 2414 / 1217,
+/* The same for any built-in AIR (bp_stark_prove_synthetic = air_id 0).  air_id 1 .. 7: n_cols = 2431 / 524 / 45 / 309 / 299 / 2414 / 1217,
  * n_const = 0, deg_pow = 1, rate_bits = 1; const_seed is ignored.  The air_id is header word 14 of the proof. */
 int bp_stark_prove_air(uint32_t air_id, const bp_stark_cfg* cfg, uint64_t seed, uint64_t const_seed, int device,
                        uint8_t** out, size_t* out_len);
@@ -465,7 +465,11 @@ int bp_generate_txn_proof_keccak(const bp_state* s, const uint8_t* ir, size_t ir
  * n are padding: Keccak permutations of the all-zero state, rows without an operation, and for the memory log reads of
  * the last address at later and later times.  Layouts as for the bp_*_trace entry points: keccak_inputs [n][25],
  * logic_ops / arithmetic_ops [n][9], memory_log [n][11] sorted by (address, timestamp), byte_sequences [n][6] (with the address and timestamp of the
- * memory operation each names when the memory table is real too: bp_byte_packing_trace).
+ * memory operation each names when the memory table is real too: bp_byte_packing_trace).  When the sponge table and the
+ * logic table are both proven by their AIRs the logic table's FIRST rows are not the caller's: rows 5 p + m are the XOR of
+ * limbs 8 m .. 8 m + 7 of sponge row p's rate with its block (the lookup keccak_sponge -> logic), for the min(sponge rows,
+ * logic rows / 5) sponge rows the table has room for; logic_ops (or seeded operations) follow them, and more operations
+ * than fit behind them are BP_ERR_INVALID_INPUT.
  * Given data is CHECKED: the prover does not validate a witness and nothing downstream verifies the table proofs (upstream's
  * root circuit would), so the table proof made from caller-given data is verified on the host before the call goes on;
  * data that does not satisfy the table's AIR (a log that is not a memory, sponge rows that do not chain, ...) returns
@@ -537,11 +541,11 @@ int bp_ir_encode_dummy(uint64_t block_number, uint64_t txn_number, uint64_t gas_
  * order of prover_state.rs:85-93 -- is proven with the Keccak-f[1600] AIR (air_id 1: 2431 columns, the witness is
  * ceil(2^log_n / 24) permutations drawn from the seed) instead of the synthetic AIR.  The table's width must be 2431. */
 int bp_ir_set_keccak_air(uint64_t ir[BP_IR_WORDS], int on);
-/* The same for the logic table (flag 0x200; table index 5): proven with the logic AIR (air_id 2: 523 columns, one
- * operation per row drawn from the seed).  The table's width must be 523. */
+/* The same for the logic table (flag 0x200; table index 5): proven with the logic AIR (air_id 2: 524 columns, one
+ * operation per row drawn from the seed).  The table's width must be 524. */
 int bp_ir_set_logic_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the memory table (flag 0x400; table index 6): the memory AIR (air_id 3: 45 columns, a sorted log drawn
- * from the seed).  The table's width must be 44. */
+ * from the seed).  The table's width must be 45. */
 int bp_ir_set_memory_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the arithmetic table (flag 0x800; table index 0): the arithmetic AIR (air_id 4: 309 columns). */
 int bp_ir_set_arithmetic_air(uint64_t ir[BP_IR_WORDS], int on);

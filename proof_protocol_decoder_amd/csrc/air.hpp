@@ -487,6 +487,7 @@ GL_HD void round(const uint64_t a[25], uint32_t rnd, Round& o) {
 //   3 .. 258     input 0 bits: 3 + 32 k + z   (limb k, bit z)
 //   259 .. 514   input 1 bits: 259 + 32 k + z
 //   515 .. 522   result limbs
+//   523          g: 1 on the operations the table exposes to the lookup keccak_sponge -> logic (namespace ctl)
 // Constraints (all rows):
 //   L0  0 .. 2       f (f - 1) for the three flags                                               deg 2
 //   L1  3            s (s - 1), s = is_and + is_or + is_xor: at most one operation               deg 2
@@ -1367,10 +1368,18 @@ GL_HD void eval_unit(const Shape& s, uint32_t unit, uint32_t ctl_base, const uin
 //                    sequence up, at consecutive addresses; here the word is the unit, as in this memory table.)
 // AIR 3  memory      2 columns: z_0 z_1.  LOOKED side: g (TRACE column 44) is the filter, which operations the table
 //                    exposes (g (g - 1) = 0); tuple = (is_read, address, timestamp, value limbs) of the row.
-// AIR 2, 4, 7        1 column: no lookup is built for these tables (upstream's go through the CPU table, which needs
+// AIR 6  keccak_sponge  ... and 10 more columns, LOOKING side of "keccak_sponge -> logic" (upstream: ctl_logic's
+//                    keccak_sponge_stark::ctl_looking_logic(i), i < 5 [UPSTREAM-UNVERIFIED]): the XOR of the rate with
+//                    the block, eight 32-bit limbs at a time (136 bytes = 34 limbs: five operations, the last one two
+//                    limbs and six zeros), is an operation of the logic table: column 2 + 2 m + c, tuple (is_and, is_or,
+//                    is_xor = 1 | rate-before limbs | block limbs | xored limbs), the inputs as sums over their bit columns.
+// AIR 2  logic       2 columns: z_0 z_1.  LOOKED side: g (TRACE column 523) is the filter, which operations the table
+//                    exposes; tuple = the row's flags, the limbs of its inputs (sums over the bit columns) and of its result.
+//                    The product of the sponge table's five first-row values equals z_c's.
+// AIR 4, 7           1 column: no lookup is built for these tables (upstream's go through the CPU table, which needs
 //                    the EVM interpreter): a constant running product z = 1 keeps the oracle set of every table the same.
 namespace ctl {
-// The FILTER columns of the two looked tables (which rows are exposed) are TRACE columns (keccak::COL_G, memory::COL_G):
+// The FILTER columns of the three looked tables (which rows are exposed) are TRACE columns (keccak::COL_G, memory::COL_G, logic::COL_G):
 // they are committed before the lookup challenges (beta, gamma) are drawn.  (Round 4 kept them among the auxiliary
 // columns, committed AFTER the challenges: a prover could then pick the exposed subset knowing the challenges -- a
 // subset-product search over a smooth multiplicative group)  Upstream keeps its filters in the trace too.
