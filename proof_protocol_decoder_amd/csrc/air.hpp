@@ -503,8 +503,13 @@ constexpr uint32_t OP_NONE = 0, OP_AND = 1, OP_OR = 2, OP_XOR = 3;
 GL_HD uint32_t apply(uint32_t op, uint32_t a, uint32_t b) {
   return op == OP_AND ? (a & b) : op == OP_OR ? (a | b) : op == OP_XOR ? (a ^ b) : 0u;
 }
+// The unit of limb k also hands the lookup keccak_sponge -> logic (namespace ctl) the limb's SHARE of the two product
+// constraints: a product's term 1 + g (gamma + v - 1) is linear in the tuple v = sum_j beta^j t_j, so the part of
+// z - z' term that carries (input-0 limb k, input-1 limb k, result limb k) is emitted here, where the limb sums exist
+// anyway, under the constraint's own index (the consumer adds the shares of one index up); the rest -- z - z' (1 + g
+// (gamma + flags - 1)) -- is ctl::eval's.  ctl_base: the index of the table's first lookup constraint (the filter bit).
 template <class T, class Row, class Emit>
-GL_HD void eval_unit(uint32_t k, const Row& row, Emit& out) {
+GL_HD void eval_unit(uint32_t k, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
   typedef Ops<T> F;
   const T f_and = row.loc(COL_OP), f_or = row.loc(COL_OP + 1), f_xor = row.loc(COL_OP + 2);
   if (k == 0) {
@@ -516,7 +521,7 @@ GL_HD void eval_unit(uint32_t k, const Row& row, Emit& out) {
     for (uint32_t i = 0; i < 3; i++) out.all(L0 + i, F::sub(xx[i], x4[i]));
     out.all(L1, F::sub(xx[3], s));
   }
-  T sum = F::k(0), prod = F::k(0);  // sum_z 2^z (a_z + b_z) and sum_z 2^z a_z b_z, Horner from the top bit down
+  T sum = F::k(0), prod = F::k(0), la = F::k(0);  // sum_z 2^z (a_z + b_z), sum_z 2^z a_z b_z and sum_z 2^z a_z, Horner from the top bit down
 #pragma unroll 1
   for (uint32_t z0 = 32; z0 > 0; z0 -= 4) {
     T a[4], b[4], aa[4], bb[4], ab[4];
@@ -535,10 +540,23 @@ GL_HD void eval_unit(uint32_t k, const Row& row, Emit& out) {
       out.all(L2 + 256 + 32 * k + z, F::sub(bb[i], b[i]));
       sum = F::add(F::dbl(sum), F::add(a[i], b[i]));
       prod = F::add(F::dbl(prod), ab[i]);
+      la = F::add(F::dbl(la), a[i]);
     }
   }
   const T p = F::add(f_or, f_xor), q = F::sub(F::sub(f_and, f_or), F::dbl(f_xor));
-  out.all(L3 + k, F::sub(row.loc(COL_RES + k), F::add(F::mul(p, sum), F::mul(q, prod))));
+  const T res = row.loc(COL_RES + k);
+  out.all(L3 + k, F::sub(res, F::add(F::mul(p, sum), F::mul(q, prod))));
+  // the limb's share of the lookup: tuple positions 3 + k (input 0), 11 + k (input 1), 19 + k (result)
+  const T g = row.loc(COL_G), lb = F::sub(sum, la);
+#pragma unroll 1
+  for (uint32_t c = 0; c < 2; c++) {
+    const T beta = F::k(ctl[2 * c]), b8 = F::k(gl::pow(ctl[2 * c], 8)), bk = F::k(gl::pow(ctl[2 * c], 3 + k));
+    (void)beta;
+    const T x = F::mul(bk, F::add(la, F::mul(b8, F::add(lb, F::mul(b8, res)))));
+    const T gx = F::mul(g, x);
+    out.transition(ctl_base + 1 + 2 * c, F::sub(F::k(0), F::mul(row.aux_nxt(c), gx)));
+    out.last(ctl_base + 2 + 2 * c, F::sub(F::k(0), gx));
+  }
 }
 }  // namespace logic
 
@@ -786,8 +804,10 @@ constexpr uint32_t N_COLS = 2414, N_CONSTRAINTS = 2587, N_UNITS = 36;
 constexpr uint32_t COL_FULL = 0, COL_FINAL = 1, COL_LEN = 2, COL_BLOCK = 138, COL_RATE = 1226, COL_CAP = 2314, COL_XORED = 2330,
                    COL_UPDATED = 2364;
 constexpr uint32_t K0 = 0, K1 = 2, K2 = 3, K3 = 139, K4 = 140, K5 = 1228, K6 = 2316, K7 = 2452, K8 = 2486, K9 = 2536, K10 = 2586;
+// (ctl_base, ctl: the limb units also emit their limb's share of the lookup keccak_sponge -> logic, as the logic table's
+// limb units do: logic::eval_unit)
 template <class T, class Row, class Emit>
-GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
+GL_HD void eval_unit(uint32_t u, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
   typedef Ops<T> F;
   const T full = row.loc(COL_FULL);
   if (u == 0) {
@@ -835,15 +855,32 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
       after = F::add(after, l_i);
     }
   }
-  T xored = F::k(0), before = F::k(0);
+  T xored = F::k(0), before = F::k(0), blk = F::k(0);
 #pragma unroll 1
   for (uint32_t z = 32; z > 0; z--) {  // limb bit z - 1 = bit (z - 1) % 8 of byte 4k + (z - 1) / 8
     const T bb = row.loc(COL_BLOCK + 32 * k + z - 1), rr = row.loc(COL_RATE + 32 * k + z - 1);
     out.all(K5 + 32 * k + z - 1, F::sub(F::mul(rr, rr), rr));
     xored = F::add(F::dbl(xored), F::sub(F::add(bb, rr), F::dbl(F::mul(bb, rr))));
     before = F::add(F::dbl(before), rr);
+    blk = F::add(F::dbl(blk), bb);
   }
-  out.all(K7 + k, F::sub(row.loc(COL_XORED + k), xored));
+  const T xcol = row.loc(COL_XORED + k);
+  out.all(K7 + k, F::sub(xcol, xored));
+  {
+    // the limb's share of the lookup keccak_sponge -> logic: limb group m = k / 8, tuple positions 3 + j (rate before),
+    // 11 + j (block), 19 + j (xored), j = k % 8; product column 2 + 2 m + c of the table's lookup constraints
+    const uint32_t m = k >> 3, j = k & 7;
+    const T f = F::add(full, row.loc(COL_FINAL));
+#pragma unroll 1
+    for (uint32_t c = 0; c < 2; c++) {
+      const T b8 = F::k(gl::pow(ctl[2 * c], 8)), bj = F::k(gl::pow(ctl[2 * c], 3 + j));
+      const T x = F::mul(bj, F::add(before, F::mul(b8, F::add(blk, F::mul(b8, xcol)))));
+      const T fx = F::mul(f, x);
+      const uint32_t col = 2 + 2 * m + c;
+      out.transition(ctl_base + 2 * col, F::sub(F::k(0), F::mul(row.aux_nxt(col), fx)));
+      out.last(ctl_base + 2 * col + 1, F::sub(F::k(0), fx));
+    }
+  }
   T before_next = F::k(0);
 #pragma unroll 1
   for (uint32_t z = 32; z > 0; z--) before_next = F::add(F::dbl(before_next), row.nxt(COL_RATE + 32 * k + z - 1));
@@ -1322,11 +1359,11 @@ GL_HD uint32_t n_units(const Shape& s) {
 template <class T, class Row, class Emit>
 GL_HD void eval_unit(const Shape& s, uint32_t unit, uint32_t ctl_base, const uint64_t ctl[4], const Row& row, Emit& out) {
   if (s.air_id == KECCAK_F) keccak::eval_unit<T>(unit, row, out);
-  else if (s.air_id == LOGIC) logic::eval_unit<T>(unit, row, out);
+  else if (s.air_id == LOGIC) logic::eval_unit<T>(unit, ctl_base, ctl, row, out);
   else if (s.air_id == MEMORY) memory::eval_unit<T>(row, out);
   else if (s.air_id == ARITHMETIC) arithmetic::eval_unit<T>(unit, row, out);
   else if (s.air_id == BYTE_PACKING) byte_packing::eval_unit<T>(unit, row, out);
-  else if (s.air_id == KECCAK_SPONGE) keccak_sponge::eval_unit<T>(unit, row, out);
+  else if (s.air_id == KECCAK_SPONGE) keccak_sponge::eval_unit<T>(unit, ctl_base, ctl, row, out);
   else if (s.air_id == ARITHMETIC_MUL) arithmetic_mul::eval_unit<T>(unit, row, out);
   else if (s.air_id == PLONK) plonk::eval_unit<T>(unit, ctl_base, ctl, row, out);
   else synthetic::eval_unit<T>(s, unit, row, out);
@@ -1537,6 +1574,28 @@ GL_HD T product_term(const Shape& s, uint32_t col, const uint64_t ctl[4], const 
   }
   return F::k(1);
 }
+// What ctl::eval keeps of a product's term when the table's AIR units emit the limb shares of the tuple themselves
+// (keccak_sponge -> logic, both sides: logic::eval_unit, keccak_sponge::eval_unit): the flags' part.  Every other
+// product: the whole term.
+template <class T, class Row>
+GL_HD T product_term_in_eval(const Shape& s, uint32_t col, const uint64_t ctl[4], const Row& row) {
+  typedef Ops<T> F;
+  if (s.air_id == KECCAK_SPONGE && col >= SPONGE_LZ) {
+    const uint32_t c = (col - SPONGE_LZ) & 1;
+    const T b2 = F::k(gl::mulc(ctl[2 * c], ctl[2 * c])), gamma = F::k(ctl[2 * c + 1]);   // is_xor = 1 sits at position 2
+    const T f = F::add(row.loc(keccak_sponge::COL_FULL), row.loc(keccak_sponge::COL_FINAL));
+    return F::add(F::k(1), F::mul(f, F::sub(F::add(gamma, b2), F::k(1))));
+  }
+  if (s.air_id == LOGIC) {
+    const uint32_t c = col - LOGIC_Z;
+    const T beta = F::k(ctl[2 * c]), gamma = F::k(ctl[2 * c + 1]);
+    T acc = F::k(0);
+#pragma unroll 1
+    for (uint32_t j = 3; j-- > 0;) acc = F::add(F::mul(acc, beta), row.loc(logic::COL_OP + j));
+    return F::add(F::k(1), F::mul(row.loc(logic::COL_G), F::sub(F::add(gamma, acc), F::k(1))));
+  }
+  return product_term<T>(s, col, ctl, row);
+}
 // AIR 8: the copy constraints of the PLONK-shaped circuit (plonky2's permutation argument: Z and partial products;
 // upstream's vanishing-polynomial terms check_partial_products + L_1 (Z - 1)).  With the routed wires w_j, j < 80, in
 // chunks of eight, per challenge set (beta, gamma):
@@ -1568,33 +1627,39 @@ GL_HD void eval(const Shape& s, uint32_t base, uint32_t k0, uint32_t k1, const u
     }
     return;
   }
+  // Real tables: the unit that starts at column 0 also holds what is not a product (filter bits, the Keccak-f table's
+  // carried input); the product columns [k0, k1) are this unit's (the sponge table's twelve products are sliced over
+  // several units: each of the ten into the logic table sums 512 bit columns).
   uint32_t idx = base;
+  const bool head = k0 == 0;
   if (s.air_id == KECCAK_F) {
-    const T g = row.loc(keccak::COL_G), s0 = row.loc(keccak::COL_STEP), s23 = row.loc(keccak::COL_STEP + 23);
-    out.all(idx++, F::sub(F::mul(g, g), g));
-    out.all(idx++, F::mul(g, F::sub(F::k(1), s23)));
+    if (head) {
+      const T g = row.loc(keccak::COL_G), s0 = row.loc(keccak::COL_STEP), s23 = row.loc(keccak::COL_STEP + 23);
+      out.all(idx, F::sub(F::mul(g, g), g));
+      out.all(idx + 1, F::mul(g, F::sub(F::k(1), s23)));
 #pragma unroll 1
-    for (uint32_t c = 0; c < 2; c++) {
-      const T beta = F::k(ctl[2 * c]), h = row.aux(KECCAK_H + c);
-      const T in = compress<T>([&](uint32_t j) { return row.loc(keccak::COL_A + j); }, TUPLE_LIMBS, beta);
-      out.all(idx++, F::mul(s0, F::sub(h, in)));
-      out.transition(idx++, F::mul(F::sub(F::k(1), s23), F::sub(row.aux_nxt(KECCAK_H + c), h)));
+      for (uint32_t c = 0; c < 2; c++) {
+        const T beta = F::k(ctl[2 * c]), h = row.aux(KECCAK_H + c);
+        const T in = compress<T>([&](uint32_t j) { return row.loc(keccak::COL_A + j); }, TUPLE_LIMBS, beta);
+        out.all(idx + 2 + 2 * c, F::mul(s0, F::sub(h, in)));
+        out.transition(idx + 3 + 2 * c, F::mul(F::sub(F::k(1), s23), F::sub(row.aux_nxt(KECCAK_H + c), h)));
+      }
     }
+    idx += 6;
   }
-  if (s.air_id == MEMORY) {
-    const T g = row.loc(memory::COL_G);
-    out.all(idx++, F::sub(F::mul(g, g), g));
-  }
-  if (s.air_id == LOGIC) {
-    const T g = row.loc(logic::COL_G);
-    out.all(idx++, F::sub(F::mul(g, g), g));
+  if (s.air_id == MEMORY || s.air_id == LOGIC) {
+    if (head) {
+      const T g = row.loc(s.air_id == MEMORY ? memory::COL_G : logic::COL_G);
+      out.all(idx, F::sub(F::mul(g, g), g));
+    }
+    idx += 1;
   }
   const uint32_t p0 = first_product(s.air_id), p1 = n_aux(s);
 #pragma unroll 1
-  for (uint32_t k = p0; k < p1; k++) {
-    const T z = row.aux(k), zn = row.aux_nxt(k), term = product_term<T>(s, k, ctl, row);
-    out.transition(idx++, F::sub(z, F::mul(zn, term)));
-    out.last(idx++, F::sub(z, term));
+  for (uint32_t k = k0 > p0 ? k0 : p0; k < (k1 < p1 ? k1 : p1); k++) {
+    const T z = row.aux(k), zn = row.aux_nxt(k), term = product_term_in_eval<T>(s, k, ctl, row);
+    out.transition(idx + 2 * (k - p0), F::sub(z, F::mul(zn, term)));
+    out.last(idx + 2 * (k - p0) + 1, F::sub(z, term));
   }
 }
 

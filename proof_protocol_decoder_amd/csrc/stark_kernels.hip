@@ -885,11 +885,11 @@ quotient_air_kernel(bpg::BatchOf<bpg::QuotArgs> batch) {
   for (uint32_t u = u0; u < u1; u++) {
     if (u < q.n_air_units) {
       if constexpr (AIR == bpg::air::KECCAK_F) bpg::air::keccak::eval_unit<uint64_t>(u, row, out);
-      else if constexpr (AIR == bpg::air::LOGIC) bpg::air::logic::eval_unit<uint64_t>(u, row, out);
+      else if constexpr (AIR == bpg::air::LOGIC) bpg::air::logic::eval_unit<uint64_t>(u, q.n_air_constraints, q.ctl.v, row, out);
       else if constexpr (AIR == bpg::air::MEMORY) bpg::air::memory::eval_unit<uint64_t>(row, out);
       else if constexpr (AIR == bpg::air::ARITHMETIC) bpg::air::arithmetic::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::BYTE_PACKING) bpg::air::byte_packing::eval_unit<uint64_t>(u, row, out);
-      else if constexpr (AIR == bpg::air::KECCAK_SPONGE) bpg::air::keccak_sponge::eval_unit<uint64_t>(u, row, out);
+      else if constexpr (AIR == bpg::air::KECCAK_SPONGE) bpg::air::keccak_sponge::eval_unit<uint64_t>(u, q.n_air_constraints, q.ctl.v, row, out);
       else if constexpr (AIR == bpg::air::ARITHMETIC_MUL) bpg::air::arithmetic_mul::eval_unit<uint64_t>(u, row, out);
       else if constexpr (AIR == bpg::air::PLONK) bpg::air::plonk::eval_chunk_unit<uint64_t>(u, q.n_air_constraints, q.ctl.v, row, out);  // (unit 10: quotient_plonk_hash_kernel)
       else bpg::air::synthetic::eval_unit<uint64_t>(shape, u, row, out);
