@@ -24,7 +24,7 @@ FAMILIES = [  # (family in the SQ summary, source, mangled-name fragments of the
     ("merkle_level_mx_kernel", "hash_kernels.hip", ["merkle_level_mx_kernel"]),
     ("quotient_air_kernel", "stark_kernels.hip", ["quotient_air_kernelILj8E", "quotient_air_kernelILj0E"]),
     ("pow_grind", "stark_kernels.hip", ["pow_grind_mx_kernelILi3E"]),
-    ("quotient", "stark_kernels.hip", ["quotient_plonk_hash_kernel"]),   # AIR 8's Poseidon-gate pass (+ the small sum / chunk kernels)
+    ("quotient_plonk_hash_kernel", "stark_kernels.hip", ["quotient_plonk_hash_kernel"]),   # AIR 8's Poseidon-gate pass
 ]
 
 
