@@ -632,6 +632,7 @@ int bp_decode_block_trace(const uint8_t* trace, size_t len, uint8_t** out, size_
 #define BP_GI_MEMORY_AIR 4u         /* table 6: the memory log of the hashed bytes */
 #define BP_GI_BYTE_PACKING_AIR 8u   /* table 1: the byte-packing sequences of the hashed bytes */
 #define BP_GI_KECCAK_SPONGE_AIR 16u /* table 4: the sponge rows absorbing the same strings */
+#define BP_GI_LOGIC_AIR 32u         /* table 5: the logic AIR, holding the sponge rows' XORs first (keccak_sponge -> logic; needs the sponge flag) */
 typedef struct bp_gi_options {
   uint64_t block_number;
   uint32_t table_log_n[BP_NUM_TABLES];  /* base heights (the tables that hold given work grow beyond them as needed) */

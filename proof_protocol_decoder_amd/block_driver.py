@@ -551,14 +551,14 @@ class GiOptions(_C.Structure):
     """bp_gi_options (include/bpg.h)"""
     _fields_ = [("block_number", _C.c_uint64), ("table_log_n", _C.c_uint32 * 7), ("table_width", _C.c_uint32 * 7),
                 ("flags", _C.c_uint32)]
-    KECCAK_AIR, KECCAK_TRIE_NODES, MEMORY_AIR, BYTE_PACKING_AIR, KECCAK_SPONGE_AIR = 1, 2, 4, 8, 16
+    KECCAK_AIR, KECCAK_TRIE_NODES, MEMORY_AIR, BYTE_PACKING_AIR, KECCAK_SPONGE_AIR, LOGIC_AIR = 1, 2, 4, 8, 16, 32
 
     @staticmethod
     def make(block_number, table_log_n, table_width, keccak_air=False, keccak_trie_nodes=False, memory_air=False,
-             byte_packing_air=False, keccak_sponge_air=False):
+             byte_packing_air=False, keccak_sponge_air=False, logic_air=False):
         return GiOptions(block_number, (_C.c_uint32 * 7)(*table_log_n), (_C.c_uint32 * 7)(*table_width),
                          (1 if keccak_air else 0) | (2 if keccak_trie_nodes else 0) | (4 if memory_air else 0)
-                         | (8 if byte_packing_air else 0) | (16 if keccak_sponge_air else 0))
+                         | (8 if byte_packing_air else 0) | (16 if keccak_sponge_air else 0) | (32 if logic_air else 0))
 
 
 class GiChain(_C.Structure):
@@ -610,7 +610,8 @@ def gi_chain_start(geni):
 
 
 def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_width, keccak_air=False,
-                               keccak_trie_nodes=False, memory_air=False, byte_packing_air=False, keccak_sponge_air=False):
+                               keccak_trie_nodes=False, memory_air=False, byte_packing_air=False, keccak_sponge_air=False,
+                               logic_air=False):
     """`Vec<TxnProofGenIR>` as produced by `decoding.into_txn_proof_gen_ir` (the reference's
     BlockTrace::into_txn_proof_gen_ir: minimal tries, delta replay, dummy padding, withdrawals) -> the IRs this
     library's prover takes.  The zkEVM that would consume the partial tries is upstream-only, so
@@ -630,7 +631,10 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
     (memory_and_byte_packing_work_of_preimages) instead of a seeded witness; their heights grow to hold it.
     keccak_sponge_air (with keccak_air): the Keccak sponge table (AIR 6) absorbs the same strings block by block
     (pg.keccak256_sponge_rows): its (xored rate, capacity) -> updated state pairs are, row for row, the inputs and
-    outputs of the Keccak table's permutations."""
+    outputs of the Keccak table's permutations.
+    logic_air (with keccak_sponge_air): the logic table (AIR 2) holds the sponge rows' XORs first -- five operations per
+    row of the sponge table (the lookup keccak_sponge -> logic derives them from the sponge table's trace inside the
+    library); its height grows to hold them."""
     from . import compact
     P = 0xFFFFFFFF00000001
     first = gen_inputs[0].tries.state_trie.hash()
@@ -642,6 +646,10 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
         raise ValueError("the memory / byte-packing / sponge work is that of the hashed bytes: it needs keccak_air")
     if keccak_sponge_air:
         table_width = tuple(2414 if t == 4 else w for t, w in enumerate(table_width))
+    if logic_air:
+        if not keccak_sponge_air:
+            raise ValueError("the logic table's work is the sponge table's XORs: logic_air needs keccak_sponge_air")
+        table_width = tuple(524 if t == 5 else w for t, w in enumerate(table_width))
     if memory_air:
         table_width = tuple(45 if t == 6 else w for t, w in enumerate(table_width))
     if byte_packing_air:
@@ -663,6 +671,8 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
                     rows = [r for m in pre for r in pg.keccak256_sponge_rows(m)[1]]
                     ln[4] = max(ln[4], (max(len(rows), 1) - 1).bit_length())
                     wit.append((4, tuple(tuple(r) for r in rows)))
+                    if logic_air:
+                        ln[5] = max(ln[5], ((5 << ln[4]) - 1).bit_length())
                 if memory_air:
                     ln[6] = max(ln[6], (max(len(log), 1) - 1).bit_length())
                     wit.append((6, tuple(tuple(r) for r in log)))
@@ -671,7 +681,7 @@ def irs_from_generation_inputs(gen_inputs, block_number, table_log_n, table_widt
                     wit.append((1, tuple(tuple(r) for r in seqs)))
                 table_log_n = tuple(ln)
                 kw.update(memory_air=memory_air, byte_packing_air=byte_packing_air, keccak_sponge_air=keccak_sponge_air,
-                          witness=tuple(wit))
+                          logic_air=logic_air, witness=tuple(wit))
         r = g.trie_roots_after
         blob = (g.signed_txn or b"") + r.state_root + r.transactions_root + r.receipts_root
         blob += b"".join(bytes(a) + int(v).to_bytes(32, "big") for a, v in g.withdrawals)

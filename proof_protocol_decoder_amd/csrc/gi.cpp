@@ -209,7 +209,9 @@ struct EntryWork {  // everything bp_generate_txn_proof_witness needs for one en
 // IR (+ witness when `with_witness`) of entry e given the chain before it; *chain moves to after the entry.
 int entry_work(const Entry& e, const bp_gi_options& o, bp_gi_chain* chain, bool with_witness, EntryWork* w) {
   const uint32_t f = o.flags;
-  if (f & ~(uint32_t)31) return fail(BP_ERR_INVALID_INPUT, "bp_gi_options.flags: unknown bits");
+  if (f & ~(uint32_t)63) return fail(BP_ERR_INVALID_INPUT, "bp_gi_options.flags: unknown bits");
+  if ((f & BP_GI_LOGIC_AIR) && !(f & BP_GI_KECCAK_SPONGE_AIR))
+    return fail(BP_ERR_INVALID_INPUT, "the logic table's work is the sponge table's XORs: BP_GI_LOGIC_AIR needs BP_GI_KECCAK_SPONGE_AIR");
   if ((f & (BP_GI_MEMORY_AIR | BP_GI_BYTE_PACKING_AIR | BP_GI_KECCAK_SPONGE_AIR | BP_GI_KECCAK_TRIE_NODES)) && !(f & BP_GI_KECCAK_AIR))
     return fail(BP_ERR_INVALID_INPUT, "the memory / byte-packing / sponge work is that of the hashed bytes: it needs BP_GI_KECCAK_AIR");
   uint32_t log_n[BP_NUM_TABLES], width[BP_NUM_TABLES];
@@ -219,6 +221,7 @@ int entry_work(const Entry& e, const bp_gi_options& o, bp_gi_chain* chain, bool 
   if (f & BP_GI_KECCAK_SPONGE_AIR) width[4] = 2414;
   if (f & BP_GI_MEMORY_AIR) width[6] = 45;
   if (f & BP_GI_BYTE_PACKING_AIR) width[1] = 299;
+  if (f & BP_GI_LOGIC_AIR) width[5] = 524;
   if (f & BP_GI_KECCAK_AIR) {
     // the heights grow to hold the work (24 rows per permutation); the witness itself only when it is asked for
     std::vector<Bytes> pre;
@@ -231,6 +234,8 @@ int entry_work(const Entry& e, const bp_gi_options& o, bp_gi_chain* chain, bool 
     }
     log_n[3] = std::max(log_n[3], ceil_log2(std::max<uint64_t>(24 * n_perms, 1)));
     if (f & BP_GI_KECCAK_SPONGE_AIR) log_n[4] = std::max(log_n[4], ceil_log2(std::max<uint64_t>(n_rows, 1)));
+    // (five XORs per absorbed block, of every row of the sponge table's final height: keccak_sponge -> logic)
+    if (f & BP_GI_LOGIC_AIR) log_n[5] = std::max(log_n[5], ceil_log2(5ull << log_n[4]));
     if (f & BP_GI_MEMORY_AIR) log_n[6] = std::max(log_n[6], ceil_log2(std::max<uint64_t>(2 * n_chunks, 1)));
     if (f & BP_GI_BYTE_PACKING_AIR) log_n[1] = std::max(log_n[1], ceil_log2(std::max<uint64_t>(n_chunks, 1)));
     if (with_witness) {
@@ -276,6 +281,7 @@ int entry_work(const Entry& e, const bp_gi_options& o, bp_gi_chain* chain, bool 
   if ((f & BP_GI_KECCAK_SPONGE_AIR) && (rc = bp_ir_set_keccak_sponge_air(w->ir, 1))) return rc;
   if ((f & BP_GI_MEMORY_AIR) && (rc = bp_ir_set_memory_air(w->ir, 1))) return rc;
   if ((f & BP_GI_BYTE_PACKING_AIR) && (rc = bp_ir_set_byte_packing_air(w->ir, 1))) return rc;
+  if ((f & BP_GI_LOGIC_AIR) && (rc = bp_ir_set_logic_air(w->ir, 1))) return rc;
   return BP_OK;
 }
 int chain_start(const std::vector<Entry>& es, bp_gi_chain* chain) {

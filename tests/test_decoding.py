@@ -436,7 +436,9 @@ def test_the_library_derives_the_same_irs_from_generation_inputs_as_the_python_m
         gis = decoding.parse_generation_inputs(geni)
         for kw in ({}, dict(keccak_air=True), dict(keccak_air=True, keccak_trie_nodes=True),
                    dict(keccak_air=True, memory_air=True), dict(keccak_air=True, byte_packing_air=True, keccak_sponge_air=True),
-                   dict(keccak_air=True, keccak_trie_nodes=True, memory_air=True, byte_packing_air=True, keccak_sponge_air=True)):
+                   dict(keccak_air=True, keccak_trie_nodes=True, memory_air=True, byte_packing_air=True, keccak_sponge_air=True),
+                   dict(keccak_air=True, keccak_sponge_air=True, logic_air=True),
+                   dict(keccak_air=True, keccak_trie_nodes=True, memory_air=True, byte_packing_air=True, keccak_sponge_air=True, logic_air=True)):
             want = [ir.to_bytes() for ir in irs_from_generation_inputs(gis, 17, base_log, base_w, **kw)]
             assert gi_irs(geni, GiOptions.make(17, base_log, base_w, **kw)) == want, kw
     # a block of one transaction: the prepended dummy carries the counters of its position
@@ -450,6 +452,8 @@ def test_the_library_derives_the_same_irs_from_generation_inputs_as_the_python_m
     import ctypes as C
     with pytest.raises(BpgError, match="needs BP_GI_KECCAK_AIR"):
         gi_irs(geni, GiOptions.make(3, base_log, base_w, memory_air=True))
+    with pytest.raises(BpgError, match="needs BP_GI_KECCAK_SPONGE_AIR"):
+        gi_irs(geni, GiOptions.make(3, base_log, base_w, keccak_air=True, logic_air=True))
     for bad in (geni[:-1], geni + b"\0", b"BPGGENI2" + geni[8:], geni[:40]):
         with pytest.raises(BpgError):
             gi_irs(bad, GiOptions.make(3, base_log, base_w))

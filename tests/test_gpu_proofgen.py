@@ -442,7 +442,7 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
     from proof_protocol_decoder_amd.block_driver import (BlockDriver, hashed_preimages_of_generation_inputs,
                                                          irs_from_generation_inputs)
     hi = list(SMALL["table_log_hi"])
-    hi[1], hi[3], hi[6] = 8, 11, 13
+    hi[1], hi[3], hi[5], hi[6] = 8, 11, 12, 13
     cfg = dict(SMALL, table_log_hi=hi)
     b = pg.ProverStateBuilder()
     for t, name in enumerate(pg.TABLES):
@@ -513,6 +513,21 @@ def test_decoded_transactions_prove_the_traffic_of_their_hashed_bytes(bpg, pg, o
         by_entry = [generate_txn_proof_gi(st, geni, k, opts, chain) for k in range(len(irs))]
         assert [p.intern for p in by_entry] == [pg.generate_txn_proof(st, x).intern for x in irs]
         assert chain.txn_number == by_entry[-1].p_vals.txn_number_after and chain.gas_used == by_entry[-1].p_vals.gas_used_after
+        # BP_GI_LOGIC_AIR: the entry's logic table by its AIR too; its first rows are the sponge rows' XORs, derived inside
+        # the library from the sponge table's trace (keccak_sponge -> logic), the table grown to hold five per sponge row
+        opts_l = GiOptions.make(24, LOG_N, WIDTH, keccak_air=True, keccak_trie_nodes=True, memory_air=True, byte_packing_air=True,
+                                keccak_sponge_air=True, logic_air=True)
+        irs_l = irs_from_generation_inputs(gis, 24, LOG_N, WIDTH, keccak_air=True, keccak_trie_nodes=True, memory_air=True,
+                                           byte_packing_air=True, keccak_sponge_air=True, logic_air=True)
+        assert gi_irs(geni, opts_l) == [x.to_bytes() for x in irs_l]
+        assert all(x.table_width[5] == 524 and (1 << x.table_log_n[5]) >= (5 << x.table_log_n[4]) for x in irs_l)
+        chain_l = gi_chain_start(geni)
+        for k, e in enumerate(irs_l[:2]):
+            got = generate_txn_proof_gi(st, geni, k, opts_l, chain_l)
+            w = {t: np.array(items, dtype=np.uint64) for t, items in e.witness}
+            want = ost.txn(list(struct.unpack("<25Q", e.to_bytes())), keccak_inputs=np.array(e.keccak_inputs, dtype=np.uint64).reshape(-1, 25),
+                           witness=w)
+            assert (words(got.intern) == want).all()
         drv2 = BlockDriver(st, n_threads=2)
         try:
             top, leaves = drv2.prove_shard_gi(geni, 0, len(irs), opts)
