@@ -220,7 +220,7 @@ struct bp_stark_cfg;
  * columns, 4 = arithmetic, ADD / SUB / LT / GT on 256-bit words with a carry chain on 309 columns, 5 = byte_packing,
  * a big-endian byte sequence and the word it spells on 299 columns, 6 = keccak_sponge, the absorbing side of
  * Keccak-256 (XOR into the rate, chaining, pad10*1) on 2414 columns, 7 = arithmetic_mul, x * y = z + 2^256 w on 1217
- * columns (likewise their own layouts; AIR 7 is not wired to a transaction's table: bp_stark_prove_air only), 8 = plonk, a
+ * columns (likewise their own layouts; a transaction's arithmetic table is proven by AIR 4 or by AIR 7: bp_ir_set_arithmetic_mul_air), 8 = plonk, a
  * PLONK-shaped circuit as a table: 135 wires (80 routed), 84 preprocessed constant columns (two gate selectors, two gate
  * constants, 80 sigmas), arithmetic and S-box gates, public inputs bound to the first row and the copy-constraint
  * permutation argument (Z + nine partial products per challenge set) as its auxiliary columns; degree 9, rate_bits 3 -- the
@@ -549,6 +549,9 @@ int bp_ir_set_logic_air(uint64_t ir[BP_IR_WORDS], int on);
 int bp_ir_set_memory_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the arithmetic table (flag 0x800; table index 0): the arithmetic AIR (air_id 4: 309 columns). */
 int bp_ir_set_arithmetic_air(uint64_t ir[BP_IR_WORDS], int on);
+/* ... or, instead (one AIR per table), with the multiplication AIR (flag 0x4000; air_id 7: 1217 columns, x * y = z + 2^256 w
+ * per row; arithmetic_ops then are [n][9] = is_mul, the words of x, the words of y).  The table's width must be 1217. */
+int bp_ir_set_arithmetic_mul_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the byte-packing table (flag 0x1000; table index 1): the byte-packing AIR (air_id 5: 299 columns). */
 int bp_ir_set_byte_packing_air(uint64_t ir[BP_IR_WORDS], int on);
 /* ... and for the Keccak sponge table (flag 0x2000; table index 4): the Keccak sponge AIR (air_id 6: 2414 columns). */

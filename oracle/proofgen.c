@@ -230,7 +230,8 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
    * 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (byte_packing_air.c): 299 columns;
    * 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (keccak_sponge_air.c): 2414 columns */
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
-  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 63) return -2;
+  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 127 || ((flags & 8) && (flags & 64))) return -2;
+  const int mul_air = (int)((flags >> 6) & 1); /* 0x4000: the arithmetic table by the multiplication AIR (arithmetic_mul_air.c): 1217 columns */
   const int dummy = ver == 2, keccak_air = (int)(flags & 1), logic_air = (int)((flags >> 1) & 1), memory_air = (int)((flags >> 2) & 1),
             arithmetic_air = (int)((flags >> 3) & 1), byte_packing_air = (int)((flags >> 4) & 1),
             sponge_air = (int)((flags >> 5) & 1);
@@ -255,6 +256,10 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
     if (tcfg[0].n_cols != ORC_ARITHMETIC_COLS) return -2;
     tcfg[0].air_id = ORC_AIR_ARITHMETIC;
   }
+  if (mul_air) {
+    if (tcfg[0].n_cols != ORC_ARITHMETIC_MUL_COLS) return -2;
+    tcfg[0].air_id = ORC_AIR_ARITHMETIC_MUL;
+  }
   if (byte_packing_air) {
     if (tcfg[1].n_cols != ORC_BYTE_PACKING_COLS) return -2;
     tcfg[1].air_id = ORC_AIR_BYTE_PACKING;
@@ -264,7 +269,7 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
     tcfg[4].air_id = ORC_AIR_KECCAK_SPONGE;
   }
   if (wit) {
-    const int has_air[NUM_TABLES] = {arithmetic_air, byte_packing_air, 0, keccak_air, sponge_air, logic_air, memory_air};
+    const int has_air[NUM_TABLES] = {arithmetic_air || mul_air, byte_packing_air, 0, keccak_air, sponge_air, logic_air, memory_air};
     for (int t = 0; t < NUM_TABLES; t++) {
       if (!wit->items[t]) continue;
       const size_t rows = (size_t)1 << tcfg[t].log_n;
@@ -340,6 +345,7 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
       if (t == 3) orc_keccak_trace(0, in, tcfg[t].log_n, trace[t]);
       else if (t == 5) orc_logic_trace(0, in, tcfg[t].log_n, trace[t]);
       else if (t == 6) orc_memory_trace(0, in, tcfg[t].log_n, trace[t]);
+      else if (t == 0 && mul_air) orc_arithmetic_mul_trace(0, in, tcfg[t].log_n, trace[t]);
       else if (t == 0) orc_arithmetic_trace(0, in, tcfg[t].log_n, trace[t]);
       else if (t == 4) orc_keccak_sponge_trace(0, in, tcfg[t].log_n, trace[t]);
       else orc_byte_packing_trace(0, in, tcfg[t].log_n, trace[t]);
@@ -381,6 +387,7 @@ static int pg_tables(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, 
     else if (tcfg[t].air_id == ORC_AIR_LOGIC) orc_logic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_MEMORY) orc_memory_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_ARITHMETIC) orc_arithmetic_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
+    else if (tcfg[t].air_id == ORC_AIR_ARITHMETIC_MUL) orc_arithmetic_mul_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_BYTE_PACKING) orc_byte_packing_trace(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n, trace[t]);
     else if (tcfg[t].air_id == ORC_AIR_KECCAK_SPONGE)
       orc_keccak_sponge_trace_limit(I[10] ^ splitmix64(t + 1), NULL, tcfg[t].log_n,
@@ -523,7 +530,7 @@ int orc_pg_verify_tables(const orc_pg_config* cfg, const gl_t* w, size_t words) 
                                                  ORC_AIR_KECCAK_SPONGE, ORC_AIR_LOGIC, ORC_AIR_MEMORY};
   for (int t = 0; t < NUM_TABLES; t++) {
     if (off + 4 > words) return -2;
-    if (w[off] != ORC_AIR_SYNTHETIC && w[off] != table_air[t]) return -5;
+    if (w[off] != ORC_AIR_SYNTHETIC && w[off] != table_air[t] && !(t == 0 && w[off] == ORC_AIR_ARITHMETIC_MUL)) return -5;
     if (w[off + 1] > 30 || w[off + 2] > 65536) return -2;
     tcfg[t] = table_cfg_of(cfg, (uint32_t)w[off + 1], (uint32_t)w[off + 2]);
     tcfg[t].air_id = (uint32_t)w[off];

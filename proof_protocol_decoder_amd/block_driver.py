@@ -387,16 +387,19 @@ class BlockDriver:
 
 def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_base=0x5EED000000000000,
                         root0=(1, 2, 3, 4), keccak_air=False, logic_air=False, memory_air=False, arithmetic_air=False,
-                        byte_packing_air=False, keccak_sponge_air=False):
+                        byte_packing_air=False, keccak_sponge_air=False, arithmetic_mul_air=False):
     """The synthetic block of SURVEY.md section 8(d): n_txns txns with distinct seeds whose public
     values chain (state root, txn number, gas) like decoding.rs:106-154 chains GenerationInputs.
     keccak_air: every transaction's Keccak table (index 3) is a real Keccak-f[1600] trace (AIR 1; the table's width
     becomes 2431).  logic_air / memory_air: likewise the logic table (index 5) with the logic AIR (AIR 2; width 524) and
     the memory table (index 6) with the memory AIR (AIR 3; width 45); arithmetic_air: the arithmetic table (index 0)
     with the arithmetic AIR (AIR 4; width 309); byte_packing_air: the byte-packing table (index 1) with AIR 5 (width 299);
-    keccak_sponge_air: the Keccak sponge table (index 4) with AIR 6 (width 2414)."""
+    keccak_sponge_air: the Keccak sponge table (index 4) with AIR 6 (width 2414); arithmetic_mul_air (instead of
+    arithmetic_air): the arithmetic table with the multiplication AIR (AIR 7; width 1217)."""
     if keccak_air:
         table_width = tuple(2431 if t == 3 else w for t, w in enumerate(table_width))
+    if arithmetic_mul_air:
+        table_width = tuple(1217 if t == 0 else w for t, w in enumerate(table_width))
     if logic_air:
         table_width = tuple(524 if t == 5 else w for t, w in enumerate(table_width))
     if memory_air:
@@ -416,7 +419,8 @@ def synthetic_block_irs(block_number, n_txns, table_log_n, table_width, seed_bas
         irs.append(pg.TxnProofGenIR(block_number, i, gas, gas + 21000, root, seed, tuple(table_log_n),
                                     tuple(table_width), keccak_air=keccak_air, logic_air=logic_air,
                                     memory_air=memory_air, arithmetic_air=arithmetic_air,
-                                    byte_packing_air=byte_packing_air, keccak_sponge_air=keccak_sponge_air))
+                                    byte_packing_air=byte_packing_air, keccak_sponge_air=keccak_sponge_air,
+                                    arithmetic_mul_air=arithmetic_mul_air))
         out = (C.c_uint64 * 4)()
         pg.check(L.bp_state_root_after((C.c_uint64 * 4)(*root), seed, i, out))
         root, gas = tuple(out), gas + 21000

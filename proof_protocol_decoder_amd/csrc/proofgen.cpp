@@ -574,6 +574,16 @@ int bp_ir_set_arithmetic_air(uint64_t ir[BP_IR_WORDS], int on) {
   return BP_OK;
 }
 
+int bp_ir_set_arithmetic_mul_air(uint64_t ir[BP_IR_WORDS], int on) {
+  if (!ir || ir[0] != IR_MAGIC) return fail(BP_ERR_INVALID_INPUT, "bp_ir_set_arithmetic_mul_air: not an IR");
+  if (on && ir[18 + 0] != air::arithmetic_mul::N_COLS)
+    return fail(BP_ERR_INVALID_INPUT, "the multiplication AIR has %u columns: the IR gives table arithmetic %llu",
+                air::arithmetic_mul::N_COLS, (unsigned long long)ir[18 + 0]);
+  if (on && (ir[1] & 0x800)) return fail(BP_ERR_INVALID_INPUT, "the arithmetic table is proven by ONE AIR: clear bp_ir_set_arithmetic_air first");
+  ir[1] = (ir[1] & ~(uint64_t)0x4000) | (on ? 0x4000 : 0);
+  return BP_OK;
+}
+
 int bp_ir_set_byte_packing_air(uint64_t ir[BP_IR_WORDS], int on) {
   if (!ir || ir[0] != IR_MAGIC) return fail(BP_ERR_INVALID_INPUT, "bp_ir_set_byte_packing_air: not an IR");
   if (on && ir[18 + 1] != air::byte_packing::N_COLS)
@@ -666,16 +676,19 @@ static int parse_ir(const bp_config& cfg, const uint64_t* I, const TxnWitness* w
   // 0x400 = the memory table (index 6) with the memory AIR (AIR 3): 45 columns, a sorted log drawn from the seed;
   // 0x800 = the arithmetic table (index 0) with the arithmetic AIR (AIR 4): 309 columns;
   // 0x1000 = the byte-packing table (index 1) with the byte-packing AIR (AIR 5): 299 columns;
-  // 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6): 2414 columns
+  // 0x2000 = the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6): 2414 columns;
+  // 0x4000 = the arithmetic table (index 0) with the MULTIPLICATION AIR (AIR 7, the multiplicative half of upstream's
+  //          arithmetic table: 1217 columns) instead of AIR 4 -- one or the other
   const uint64_t ver = I[1] & 0xFF, flags = I[1] >> 8;
-  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 63) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
+  if (I[0] != IR_MAGIC || (ver != 1 && ver != 2) || flags > 127) return fail(BP_ERR_INVALID_INPUT, "IR: bad magic/version");
+  if ((flags & 8) && (flags & 64)) return fail(BP_ERR_INVALID_INPUT, "IR: the arithmetic table is proven by ONE AIR (flags 0x800 and 0x4000 are both set)");
   const bool dummy = ver == 2;
   // table index -> the AIR its flag selects (bit t' of flags; WITNESS_AIR lists them by table)
   static const uint32_t FLAG_OF_TABLE[BP_NUM_TABLES] = {8, 16, 0, 1, 32, 2, 4};
   if (wit) {
     for (int t = 0; t < BP_NUM_TABLES; t++) {
       if (!wit->in[t]) continue;
-      if (!(flags & FLAG_OF_TABLE[t]))
+      if (!(flags & (FLAG_OF_TABLE[t] | (t == 0 ? 64u : 0u))))
         return fail(BP_ERR_INVALID_INPUT, "witness data for table %s needs an IR whose %s table is proven with its AIR (bp_ir_set_*_air)",
                     TABLE_NAMES[t], TABLE_NAMES[t]);
       if (I[11 + t] < 40 && wit->n[t] > witness_capacity(t, (uint64_t)1 << I[11 + t]))
@@ -693,6 +706,7 @@ static int parse_ir(const bp_config& cfg, const uint64_t* I, const TxnWitness* w
     if (wd > 65536) return fail(BP_ERR_INVALID_INPUT, "table %s: width out of range", TABLE_NAMES[t]);
     tcfg[t] = table_cfg_of(cfg, (uint32_t)ln, (uint32_t)wd);
     if (flags & FLAG_OF_TABLE[t]) tcfg[t].air_id = WITNESS_AIR[t];  // check_cfg insists on the AIR's own width
+    if (t == 0 && (flags & 64)) tcfg[t].air_id = air::ARITHMETIC_MUL;
     int r = check_cfg(tcfg[t]);
     if (r) return r;
   }
@@ -743,7 +757,7 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
   uint64_t* d_trace[BP_NUM_TABLES];
   Committed trace[BP_NUM_TABLES];
   Challenger ch;
-  auto given = [&](int t) { return wit && wit->in[t] && tcfg[t].air_id == WITNESS_AIR[t]; };
+  auto given = [&](int t) { return wit && wit->in[t] && (tcfg[t].air_id == WITNESS_AIR[t] || (t == 0 && tcfg[t].air_id == air::ARITHMETIC_MUL)); };
   // Two seeded tables that a lookup ties together are ONE statement: the seeded sponge table asks for no more
   // permutations than the Keccak-f table holds in full, and the seeded Keccak-f table's first permutations are the
   // ones the sponge rows ask for (air::ctl, keccak_sponge -> keccak_f).  Tables given by the caller are taken as they are.
@@ -828,6 +842,7 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
       case air::LOGIC: r = launch_logic_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
       case air::MEMORY: r = launch_memory_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
       case air::ARITHMETIC: r = launch_arithmetic_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
+      case air::ARITHMETIC_MUL: r = launch_arithmetic_mul_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
       case air::BYTE_PACKING: r = launch_byte_packing_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream); break;
       case air::KECCAK_SPONGE:
         r = launch_keccak_sponge_trace(d_trace[t], d_in, tcfg[t].log_n, d_in ? 0 : seed, w.stream, sponge_row_limit);
@@ -1094,7 +1109,7 @@ static int verify_table_proofs(const bp_config* cfg, const StarkCfg* expect, con
     const uint64_t air_id = W[off], log_n = W[off + 1], n_cols = W[off + 2], pw = W[off + 3];
     off += 4;
     if (air_id >= air::COUNT || log_n > 30 || n_cols > 65536) return fail(BP_ERR_INVALID_INPUT, "table proofs: bad header of table %s", TABLE_NAMES[t]);
-    if (air_id != air::SYNTHETIC && air_id != WITNESS_AIR[t])
+    if (air_id != air::SYNTHETIC && air_id != WITNESS_AIR[t] && !(t == 0 && air_id == air::ARITHMETIC_MUL))
       return fail(BP_ERR_VERIFY, "table %s is proven with AIR %llu, which is not that table's", TABLE_NAMES[t], (unsigned long long)air_id);
     tcfg[t] = table_cfg_of(*cfg, (uint32_t)log_n, (uint32_t)n_cols);
     tcfg[t].air_id = (uint32_t)air_id;

@@ -66,6 +66,7 @@ def _bind():
     L.bp_ir_set_logic_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_memory_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_arithmetic_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.bp_ir_set_arithmetic_mul_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_byte_packing_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_ir_set_keccak_sponge_air.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.bp_keccak256_sponge_rows.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t,
@@ -135,6 +136,7 @@ class TxnProofGenIR:
     arithmetic_air: bool = False   # the arithmetic table (index 0) with the arithmetic AIR (AIR 4, 309 columns)
     byte_packing_air: bool = False   # the byte-packing table (index 1) with the byte-packing AIR (AIR 5, 299 columns)
     keccak_sponge_air: bool = False  # the Keccak sponge table (index 4) with the Keccak sponge AIR (AIR 6, 2414 columns)
+    arithmetic_mul_air: bool = False   # the arithmetic table (index 0) with the multiplication AIR instead (AIR 7, 1217 columns)
     witness: tuple = None   # ((table index, ((words of an item), ...)), ...): data for tables with an AIR instead of a
                             # seeded witness (bp_generate_txn_proof_witness); like keccak_inputs not part of the 25-word IR
 
@@ -163,6 +165,8 @@ class TxnProofGenIR:
             check(L.bp_ir_set_byte_packing_air(out, 1))
         if self.keccak_sponge_air:
             check(L.bp_ir_set_keccak_sponge_air(out, 1))
+        if self.arithmetic_mul_air:
+            check(L.bp_ir_set_arithmetic_mul_air(out, 1))
         return struct.pack("<%dQ" % IR_WORDS, *out)
 
 

@@ -123,3 +123,34 @@ def test_air_registry_describes_the_multiplication_air():
     assert (d.n_air_constraints, d.n_ctl_constraints, d.n_units) == (1218, 2, 8)
     fams = [(f.first_index, f.count, f.kind, f.degree) for f in d.families[:d.n_families]]
     assert sum(c for _, c, _, _ in fams[:6]) == 1218 and fams[4] == (1185, 32, 0, 3)
+
+
+def test_a_transaction_s_arithmetic_table_proven_by_the_multiplication_air(oracle):
+    """IR flag 0x4000: the arithmetic table (index 0, prover_state.rs:85-93) of a transaction is proven with AIR 7 instead
+    of AIR 4 -- seeded products or the caller's.  The oracle's table proofs are accepted by its own verifier and by the
+    product's CPU verifier (which takes the statement from the IR); both AIR flags at once are refused."""
+    from pg_common import LOG_N, SMALL, WIDTH, ir_words
+    from proof_protocol_decoder_amd import proof_gen as pg
+    st = oracle.PgState(**SMALL)
+    width = list(WIDTH)
+    width[0] = 1217
+    ir = ir_words(9, 0, 0x5EED0717, width=tuple(width))
+    ir[1] |= 0x4000
+    b = pg.ProverStateBuilder()
+    for t, name in enumerate(pg.TABLES):
+        getattr(b, "set_%s_circuit_size" % name)(range(SMALL["table_log_lo"][t], SMALL["table_log_hi"][t]))
+    b.set(**{k: v for k, v in SMALL.items() if not k.startswith("table_")})
+    tp = st.txn_tables(ir)
+    assert st.verify_tables(tp) == 0
+    pg.verify_txn_table_proofs(b.cfg, tp.tobytes(), np.array(ir, dtype=np.uint64).tobytes())
+    assert int(tp[2 + 13 + 4]) == 7                            # the first table's header: AIR 7
+    ops = [[1, 3, 0, 0, 0, 5, 0, 0, 0], [1, 2**64 - 1, 2**64 - 1, 2**64 - 1, 2**64 - 1, 2**64 - 1, 2**64 - 1, 2**64 - 1, 2**64 - 1]]
+    tp2 = st.txn_tables(ir, witness={0: ops})
+    assert st.verify_tables(tp2) == 0 and (tp2 != tp).any()
+    pg.verify_txn_table_proofs(b.cfg, tp2.tobytes(), np.array(ir, dtype=np.uint64).tobytes())
+    both = list(ir)
+    both[1] |= 0x800
+    with pytest.raises(Exception):
+        st.txn_tables(both)
+    full = st.txn(ir)                                          # ... and the whole transaction proof on top of it
+    assert st.verify(full) == 0

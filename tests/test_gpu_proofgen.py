@@ -602,6 +602,14 @@ def test_txn_with_six_real_tables_matches_the_oracle(pg, p_state, o_state):
     t_l = pg.generate_txn_proof(p_state, only_logic)
     iw_l = list(struct.unpack("<25Q", only_logic.to_bytes()))
     assert iw_l[1] == 0x201 and (words(t_l.intern) == o_state.txn(iw_l)).all() and t_l.intern != t0.intern
+    # the arithmetic table by the multiplication AIR instead (AIR 7, flag 0x4000): seeded products, and the caller's
+    mul_ir = pg.TxnProofGenIR(9, 0, 0, 21000, (1, 2, 3, 4), 0x5EED0027, tuple(LOG_N), (1217, *WIDTH[1:]), arithmetic_mul_air=True)
+    iw_m = list(struct.unpack("<25Q", mul_ir.to_bytes()))
+    t_m = pg.generate_txn_proof(p_state, mul_ir)
+    assert iw_m[1] == 0x4001 and (words(t_m.intern) == o_state.txn(iw_m)).all()
+    ops = ((1, 7, 0, 0, 0, 9, 0, 0, 0), (1, 2**64 - 1, 5, 2**63, 1, 3, 2**64 - 2, 0, 2**62))
+    t_m2 = pg.generate_txn_proof(p_state, mul_ir, witness={0: ops})
+    assert (words(t_m2.intern) == o_state.txn(iw_m, witness={0: np.array(ops, dtype=np.uint64)})).all() and t_m2.intern != t_m.intern
     t1 = pg.generate_txn_proof(p_state, make_ir(pg, 9, 1, 0x5EED0021, root=t0.p_vals.state_root_after, gas=(21000, 42000)))
     blk = pg.generate_block_proof(p_state, None, pg.generate_agg_proof(p_state, t0, t1))
     pg.VerifierState.from_prover_state(p_state).verify(blk)

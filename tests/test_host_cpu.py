@@ -438,6 +438,15 @@ def test_witness_entry_points_check_their_arguments_before_any_device_work():
         assert getattr(L, setter)(ir, 1) == 0
     assert ir[1] == 0x3F01
     assert L.bp_ir_set_logic_air(ir, 0) == 0 and ir[1] == 0x3D01
+    # the arithmetic table is proven by ONE AIR: the multiplication AIR (flag 0x4000, 1217 columns) instead of AIR 4
+    f = L.bp_ir_set_arithmetic_mul_air
+    f.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    assert f(ir, 1) == -2 and b"1217" in L.bp_last_error()
+    w[18 + 0] = 1217
+    ir2 = (C.c_uint64 * 25)(*w)
+    assert f(ir2, 1) == 0 and ir2[1] == 0x4001 and f(ir2, 0) == 0 and ir2[1] == 1
+    ir2[1] |= 0x800
+    assert f(ir2, 1) == -2 and b"ONE AIR" in L.bp_last_error()
 
 
 def struct_ir():
