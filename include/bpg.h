@@ -314,11 +314,14 @@ int bp_arithmetic_mul_trace(const uint64_t* d_inputs, uint64_t seed, uint32_t lo
  *     the first multiple of four past the Merkle rows (20 without paths) and one group of four must fit (2^log_n >= 32);
  * and the circuit's witness, 135 wires: free wires drawn from `seed`, the list pi hashed in rows 4.., its hash in row 0
  * (the four public inputs) and, through copy constraints, in the first arithmetic row; `paths` (NULL when n_paths = 0):
- * per path 1 + 4 path_depth words -- the leaf's position (bit l = "the node of level l is a right child"), then the
- * sibling digests from the leaf upward.  A witness whose path does not arrive at the list's cap entry is written as it
+ * per path 1 + 4 path_depth + leaf_len words -- the leaf's position (bit l = "the node of level l is a right child"), the
+ * sibling digests from the leaf upward, then (leaf_len > 0: the aggregation and block circuits of a prover state whose
+ * recursion shape has the rows for it) the leaf_len words of the opened row, which the circuit hashes in ceil(leaf_len / 8)
+ * Poseidon rows per path right after the Merkle rows; their digest is the path's first node and the list's leaf digest.  A witness whose path does not arrive at the list's cap entry is written as it
  * is: its proof is what a verifier rejects.  bp_plonk_trace returns after the stream has run it. */
 typedef struct bp_plonk_layout {
   uint32_t pi_len, n_paths, path_depth, path_pi0;
+  uint32_t leaf_len; /* 0, or the words of the row each path's leaf digest is the hash of (> 8): the circuit then hashes it too */
 } bp_plonk_layout;
 int bp_plonk_constants(uint64_t seed, uint32_t log_n, const bp_plonk_layout* layout, uint64_t* d_consts_out, void* stream);
 int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t* pi, const bp_plonk_layout* layout, const uint64_t* paths,

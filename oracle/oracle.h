@@ -149,9 +149,9 @@ void orc_keccak_sponge_constraints_ext(const gl2_t* loc, const gl2_t* nxt, orc_c
 void orc_stark_public_inputs(uint64_t seed, gl_t out[4]);      /* hash of the list below */
 void orc_stark_public_input_list(uint64_t seed, gl_t out[4]);
 void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0,
-                         gl_t* consts);
+                         unsigned leaf_len, gl_t* consts);
 void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0,
-                     const gl_t* paths, const gl_t* consts, unsigned log_n, gl_t* trace);
+                     unsigned leaf_len, const gl_t* paths, const gl_t* consts, unsigned log_n, gl_t* trace);
 void orc_plonk_aux_columns(const gl_t* trace_values, const gl_t* consts, unsigned log_n, const gl_t ctl[4], gl_t* aux);
 void orc_plonk_constraints_base(const gl_t* cst, const gl_t* loc, const gl_t* aux, const gl_t* aux_nxt, const gl_t ctl[4],
                                 const gl_t pub[4], gl_t x, orc_consumer* k);
@@ -209,6 +209,7 @@ int orc_stark_prove(const orc_stark_cfg* cfg, const orc_committed* consts, const
 int orc_stark_verify(const orc_stark_cfg* cfg, const gl_t* const_cap, const gl_t ctl[4],
                      orc_challenger* ch, const gl_t* proof);
 void orc_proof_first_query_path(const orc_stark_cfg* cf, const gl_t* proof, gl_t leaf[4], gl_t cap_entry[4], gl_t* path);
+void orc_proof_first_query_row(const orc_stark_cfg* cf, const gl_t* proof, gl_t* row); /* the opened trace row itself (n_cols words) */
 void orc_proof_digest(const orc_stark_cfg* cfg, const gl_t* proof, gl_t out[4]);
 
 #ifdef __cplusplus

@@ -32,7 +32,11 @@ enum { PW = 135, PK = 85, ROUTED = 80, SLOTS = 20, SBOX = 11, SB0 = 80, SIG0 = 5
  * list, the cap entry it arrives at words path_pi0 + 8p + 4 .. + 7.  Arithmetic groups start at the first multiple of four
  * past the Merkle rows. */
 enum { HROW0 = 4, MROW0 = 17 /* after at most 13 rows of list */, ZROW = 1, HIN = 0, HOUT = 12, HF1 = 24, HPART = 60, HF2 = 82, HSWAP = 130, HDELTA = 131, HWIRES = 135 };
-static unsigned arith_row0_of(unsigned n_paths, unsigned depth) { return (MROW0 + n_paths * depth + 3) / 4 * 4; }
+/* leaf_len > 0: after the Merkle rows every path has ceil(leaf_len / 8) sponge rows that hash the row its leaf digest is the
+ * digest of (the child's opened trace row: free wires); their last output is the path's first node and the list's leaf words */
+static unsigned arith_row0_of(unsigned n_paths, unsigned depth, unsigned leaf_len) {
+  return (MROW0 + n_paths * depth + (leaf_len ? n_paths * ((leaf_len + 7) / 8) : 0) + 3) / 4 * 4;
+}
 static const gl_t PRC[360] = {
 #include "poseidon_rc.inc"
 };
@@ -68,10 +72,11 @@ static void tie(gl_t* consts, size_t N, const gl_t* kpow, const gl_t* wpow, cons
   }
 }
 void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0,
-                         gl_t* consts) {
+                         unsigned leaf_len, gl_t* consts) {
   const size_t N = (size_t)1 << log_n;
   const unsigned H = hash_rows_of(pi_len), last_len = pi_len - 8 * (H - 1);
-  const unsigned AROW0 = arith_row0_of(n_paths, depth), MROWS = n_paths * depth;
+  const unsigned AROW0 = arith_row0_of(n_paths, depth, leaf_len), MROWS = n_paths * depth;
+  const unsigned LH = leaf_len ? (leaf_len + 7) / 8 : 0, LROW0 = MROW0 + MROWS, LROWS = n_paths * LH;
   gl_t *kpow = (gl_t*)malloc(ROUTED * sizeof(gl_t)), *wpow = (gl_t*)malloc(N * sizeof(gl_t));
   kpow[0] = 1;
   for (int j = 1; j < ROUTED; j++) kpow[j] = gl_mul(kpow[j - 1], 7);
@@ -83,7 +88,7 @@ void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, unsigne
     consts[1 * N + i] = gate_row && (i % 4 == 2);
     consts[2 * N + i] = i == ZROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, 2, i);
     consts[3 * N + i] = i == ZROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, 3, i);
-    consts[4 * N + i] = (i >= HROW0 && i < HROW0 + H) || (i >= MROW0 && i < MROW0 + MROWS);
+    consts[4 * N + i] = (i >= HROW0 && i < HROW0 + H) || (i >= MROW0 && i < MROW0 + MROWS + LROWS);
     for (int j = 0; j < ROUTED; j++) consts[(size_t)(SIG0 + j) * N + i] = gl_mul(kpow[j], wpow[i]); /* untied: itself */
   }
   /* the sponge: which incoming state words of hash row h are NOT words of the list */
@@ -105,7 +110,7 @@ void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, unsigne
   }
   /* the Merkle paths: level by level the node climbs; the ends are words of the list; every capacity word is zero */
   if (MROWS) {
-    wire_t* zeros = (wire_t*)malloc((4 * MROWS + 1) * sizeof(wire_t));
+    wire_t* zeros = (wire_t*)malloc((4 * (MROWS + n_paths) + 1) * sizeof(wire_t));
     int nz = 0;
     zeros[nz++] = (wire_t){4 * 19 + 3, ZROW}; /* the last zero wire of row 1 */
     for (unsigned p = 0; p < n_paths; p++)
@@ -113,7 +118,11 @@ void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, unsigne
         const uint32_t row = MROW0 + p * depth + l;
         for (uint32_t j = 0; j < 4; j++) {
           zeros[nz++] = (wire_t){HIN + 8 + j, row};
-          if (l == 0) { /* the leaf digest: word path_pi0 + 8p + j of the list, wherever the sponge absorbs it */
+          if (l == 0 && leaf_len) { /* ... which the path's own sponge rows compute: list word, first node, last sponge output */
+            const unsigned i = path_pi0 + 8 * p + j;
+            const wire_t leaf[3] = {{HIN + i % 8, HROW0 + i / 8}, {HIN + j, row}, {HOUT + j, LROW0 + p * LH + LH - 1}};
+            tie(consts, N, kpow, wpow, leaf, 3);
+          } else if (l == 0) { /* the leaf digest: word path_pi0 + 8p + j of the list, wherever the sponge absorbs it */
             const unsigned i = path_pi0 + 8 * p + j;
             const wire_t leaf[2] = {{HIN + j, row}, {HIN + i % 8, HROW0 + i / 8}};
             tie(consts, N, kpow, wpow, leaf, 2);
@@ -125,6 +134,22 @@ void orc_plonk_constants(uint64_t seed, unsigned log_n, unsigned pi_len, unsigne
             const unsigned i = path_pi0 + 8 * p + 4 + j;
             const wire_t top[2] = {{HOUT + j, row}, {HIN + i % 8, HROW0 + i / 8}};
             tie(consts, N, kpow, wpow, top, 2);
+          }
+        }
+      }
+    /* the leaf sponges: row h of path p absorbs eight words of the opened row; what it does not take from the row it
+     * carries from the row before (h > 0) or, in its first row, is zero (the capacity words: more members of the zero class) */
+    for (unsigned p = 0; p < n_paths && leaf_len; p++)
+      for (unsigned h = 0; h < LH; h++) {
+        const uint32_t row = LROW0 + p * LH + h;
+        const unsigned last_len = leaf_len - 8 * (LH - 1);
+        for (uint32_t k = 0; k < 12; k++) {
+          const int carried = k >= 8 || (h == LH - 1 && k >= last_len);
+          if (!carried) continue;
+          if (h == 0) zeros[nz++] = (wire_t){HIN + k, row};
+          else {
+            const wire_t c[2] = {{HIN + k, row}, {HOUT + k, row - 1}};
+            tie(consts, N, kpow, wpow, c, 2);
           }
         }
       }
@@ -185,10 +210,12 @@ static void permute_into_row(gl_t st[12], gl_t* t, size_t N, size_t row) {
 }
 /* paths (n_paths > 0): per path 1 + 4 depth words: the leaf's position, then the siblings from the leaf upward */
 void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0,
-                     const gl_t* paths, const gl_t* consts, unsigned log_n, gl_t* t) {
+                     unsigned leaf_len, const gl_t* paths, const gl_t* consts, unsigned log_n, gl_t* t) {
   const size_t N = (size_t)1 << log_n;
   const unsigned H = hash_rows_of(pi_len);
-  const unsigned AROW0 = arith_row0_of(n_paths, depth);
+  const unsigned AROW0 = arith_row0_of(n_paths, depth, leaf_len);
+  const unsigned LH = leaf_len ? (leaf_len + 7) / 8 : 0, LROW0 = MROW0 + n_paths * depth;
+  const size_t path_words = 1 + 4 * (size_t)depth + leaf_len;
 #define W(col, row) t[(size_t)(col) * N + (row)]
   for (size_t i = 0; i < N; i++) /* every wire starts free; the rows below overwrite what the circuit computes */
     for (int c = 0; c < PW; c++) W(c, i) = rnd(seed, c, i);
@@ -206,7 +233,7 @@ void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, unsigned n_
   gl_t pub[4] = {st[0], st[1], st[2], st[3]};
   /* the Merkle rows: the two-to-one compression of (left, right), the node on the side its position bit says */
   for (unsigned p = 0; p < n_paths; p++) {
-    const gl_t* pw = paths + (size_t)p * (1 + 4 * depth);
+    const gl_t* pw = paths + (size_t)p * path_words;
     uint64_t index = pw[0];
     gl_t node[4];
     for (int j = 0; j < 4; j++) node[j] = pi[path_pi0 + 8 * p + j];
@@ -226,6 +253,19 @@ void orc_plonk_trace(uint64_t seed, const gl_t* pi, unsigned pi_len, unsigned n_
       W(HSWAP, row) = (gl_t)right;
       permute_into_row(m, t, N, row);
       for (int j = 0; j < 4; j++) node[j] = m[j];
+    }
+    /* the leaf sponge of the path: hash_no_pad of the opened row, eight words a row */
+    if (leaf_len) {
+      const gl_t* leaf = pw + 1 + 4 * depth;
+      gl_t ls[12] = {0};
+      for (unsigned h = 0; h < LH; h++) {
+        const size_t row = LROW0 + p * LH + h;
+        const unsigned take = leaf_len - 8 * h < 8 ? leaf_len - 8 * h : 8;
+        for (unsigned k = 0; k < take; k++) ls[k] = leaf[8 * h + k];
+        for (int k = 0; k < 12; k++) W(HIN + k, row) = ls[k];
+        for (int k = 0; k < 5; k++) W(HSWAP + k, row) = 0;
+        permute_into_row(ls, t, N, row);
+      }
     }
   }
   for (int j = 0; j < 4; j++) W(j, 0) = pub[j];

@@ -29,7 +29,7 @@ typedef struct {
   gl_t* const_values;
   orc_committed* consts;
   gl_t digest[4];
-  unsigned n_paths, path_pi0, depth; /* the Merkle paths the circuit walks (plonk_air.c) */
+  unsigned n_paths, path_pi0, depth, leaf_len; /* the Merkle paths the circuit walks, the leaves it hashes (plonk_air.c) */
 } circuit_t;
 
 typedef struct orc_pg_state {
@@ -77,13 +77,17 @@ void orc_pg_state_free(orc_pg_state* s) {
   free(s);
 }
 /* circuits are preprocessed lazily (same data as libbpg's eager bp_state_build) */
+static circuit_t* get_circuit_leaf(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0, unsigned leaf_len);
 static circuit_t* get_circuit_depth(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0) {
+  return get_circuit_leaf(s, c, seed, pi_len, n_paths, depth, path_pi0, 0);
+}
+static circuit_t* get_circuit_leaf(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0, unsigned leaf_len) {
   if (!c->built) {
     size_t n = (size_t)1 << s->rec.log_n;
     c->const_values = (gl_t*)malloc(s->rec.n_const * n * sizeof(gl_t));
-    c->n_paths = n_paths; c->path_pi0 = path_pi0; c->depth = depth;
+    c->n_paths = n_paths; c->path_pi0 = path_pi0; c->depth = depth; c->leaf_len = leaf_len;
     if (s->rec.air_id == ORC_AIR_PLONK)
-      orc_plonk_constants(seed, s->rec.log_n, pi_len, n_paths, depth, path_pi0, c->const_values);
+      orc_plonk_constants(seed, s->rec.log_n, pi_len, n_paths, depth, path_pi0, leaf_len, c->const_values);
     else orc_synth_constants(seed, s->rec.log_n, s->rec.n_const, c->const_values);
     c->consts = orc_commit_values(c->const_values, s->rec.log_n, s->rec.n_const, s->rec.rate_bits, s->rec.cap_height);
     orc_hash_no_pad(orc_committed_cap(c->consts), (size_t)4 << s->rec.cap_height, c->digest);
@@ -98,6 +102,7 @@ static circuit_t* get_circuit_depth(orc_pg_state* s, circuit_t* c, uint64_t seed
  * STARK proof: d + rate - cap levels), the levels above by the table's shrink circuit (a recursion-shaped child). */
 enum { CHAIN_PATH_AT = 6, CHAIN_PI = 6 + 8, ROOT_PATHS_AT = 4 * NUM_TABLES, ROOT_PI = 4 * NUM_TABLES + 8 * NUM_TABLES + PV_WORDS };
 static circuit_t* get_circuit_depth(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0);
+static circuit_t* get_circuit_leaf(orc_pg_state* s, circuit_t* c, uint64_t seed, unsigned pi_len, unsigned n_paths, unsigned depth, unsigned path_pi0, unsigned leaf_len);
 static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) {
   return get_circuit_depth(s, &s->table[t][d], circuit_seed(t, d), CHAIN_PI, 1, d + s->cfg.stark_rate_bits - s->cfg.stark_cap_height, CHAIN_PATH_AT);
 }
@@ -110,8 +115,15 @@ static circuit_t* shrink_circuit(orc_pg_state* s, int t) {
 enum { AGG_PATHS_AT = 10, BLOCK_PATH_AT = 9, AGG_PI = 10 + 16 + PV_WORDS, BLOCK_PI = 9 + 8 + PV_WORDS };
 static circuit_t* special_circuit(orc_pg_state* s, int k) {
   static const unsigned PI_LEN[3] = {ROOT_PI, AGG_PI, BLOCK_PI}, PATHS[3] = {NUM_TABLES, 2, 1}, AT[3] = {ROOT_PATHS_AT, AGG_PATHS_AT, BLOCK_PATH_AT};
-  return get_circuit_depth(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0), PI_LEN[k], PATHS[k],
-                           s->rec.log_n + s->rec.rate_bits - s->rec.cap_height, AT[k]);
+  const unsigned depth = s->rec.log_n + s->rec.rate_bits - s->rec.cap_height;
+  /* the aggregation and block circuits also hash the row each child opens, where the circuit has the rows for it: 17 list
+   * rows at most, the Merkle rows, ceil(n_cols / 8) leaf rows per path, and one arithmetic group of four must fit */
+  unsigned leaf_len = 0;
+  if (k > 0 && s->rec.air_id == ORC_AIR_PLONK && s->rec.n_cols > 8) {
+    const unsigned lh = (s->rec.n_cols + 7) / 8, rows = 17 + PATHS[k] * depth + PATHS[k] * lh;
+    if (PATHS[k] * lh <= 40 && (rows + 3) / 4 * 4 + 4 <= (1u << s->rec.log_n)) leaf_len = s->rec.n_cols;
+  }
+  return get_circuit_leaf(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0), PI_LEN[k], PATHS[k], depth, AT[k], leaf_len);
 }
 
 /* paths: the witness of the circuit's Merkle paths (circ->n_paths of them, 1 + 4 depth words each), or NULL */
@@ -127,7 +139,7 @@ static int rec_prove(orc_pg_state* s, circuit_t* circ, const gl_t* pi, size_t n_
   orc_stark_cfg rcfg = s->rec; /* the PLONK-shaped circuit binds the hash of the public inputs to its first row */
   if (rcfg.air_id == ORC_AIR_PLONK) {
     memcpy(rcfg.pub, pi_hash, sizeof(rcfg.pub));
-    orc_plonk_trace(pi_hash[0], pi, (unsigned)n_pi, circ->n_paths, circ->depth, circ->path_pi0, paths, circ->const_values, rcfg.log_n, trace);
+    orc_plonk_trace(pi_hash[0], pi, (unsigned)n_pi, circ->n_paths, circ->depth, circ->path_pi0, circ->leaf_len, paths, circ->const_values, rcfg.log_n, trace);
   } else {
     orc_synth_trace(pi_hash[0], &s->rec, circ->const_values, trace);
   }
@@ -622,10 +634,15 @@ int orc_pg_agg(orc_pg_state* s, const gl_t* lhs, size_t lw, int lhs_is_agg, cons
   orc_proof_digest(&s->rec, L.stark, pi);
   orc_proof_digest(&s->rec, R.stark, pi + 4);
   pi[8] = lhs_is_agg != 0; pi[9] = rhs_is_agg != 0;
-  const size_t path_words = 1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height);
+  const unsigned agg_leaf = special_circuit(s, 1)->leaf_len;
+  const size_t sib_words = 1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height), path_words = sib_words + agg_leaf;
   gl_t* paths = (gl_t*)malloc(2 * path_words * sizeof(gl_t));
   orc_proof_first_query_path(&s->rec, L.stark, pi + AGG_PATHS_AT, pi + AGG_PATHS_AT + 4, paths);
   orc_proof_first_query_path(&s->rec, R.stark, pi + AGG_PATHS_AT + 8, pi + AGG_PATHS_AT + 12, paths + path_words);
+  if (agg_leaf) { /* the opened rows themselves, hashed in-circuit */
+    orc_proof_first_query_row(&s->rec, L.stark, paths + sib_words);
+    orc_proof_first_query_row(&s->rec, R.stark, paths + path_words + sib_words);
+  }
   gl_t* pv = pi + AGG_PATHS_AT + 16;
   pv[0] = L.pv[0]; pv[1] = R.pv[1]; pv[2] = L.pv[2]; pv[3] = R.pv[3];
   memcpy(pv + 4, L.pv + 4, 32); memcpy(pv + 8, R.pv + 8, 32);
@@ -652,8 +669,11 @@ int orc_pg_block(orc_pg_state* s, const gl_t* parent, size_t pw, const gl_t* agg
     pi[8] = 1;
   }
   orc_proof_digest(&s->rec, A.stark, pi + 4);
-  gl_t* path = (gl_t*)malloc((1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height)) * sizeof(gl_t));
+  const unsigned blk_leaf = special_circuit(s, 2)->leaf_len;
+  const size_t blk_sib_words = 1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height);
+  gl_t* path = (gl_t*)malloc((blk_sib_words + blk_leaf) * sizeof(gl_t));
   orc_proof_first_query_path(&s->rec, A.stark, pi + BLOCK_PATH_AT, pi + BLOCK_PATH_AT + 4, path);
+  if (blk_leaf) orc_proof_first_query_row(&s->rec, A.stark, path + blk_sib_words);
   memcpy(pi + BLOCK_PATH_AT + 8, A.pv, PV_WORDS * 8);
   size_t sw = orc_proof_words(&s->rec);
   gl_t* proof = (gl_t*)malloc(sw * sizeof(gl_t));

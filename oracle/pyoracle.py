@@ -117,8 +117,8 @@ def lib():
     L.orc_pg_txn_witness.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                      C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
     L.orc_stark_public_inputs.argtypes = [u6, u64p]
-    L.orc_plonk_constants.argtypes = [u6, u, u, u, u, u, u64p]
-    L.orc_plonk_trace.argtypes = [u6, u64p, u, u, u, u, u64p, u64p, u, u64p]
+    L.orc_plonk_constants.argtypes = [u6, u, u, u, u, u, u, u64p]
+    L.orc_plonk_trace.argtypes = [u6, u64p, u, u, u, u, u, u64p, u64p, u, u64p]
     L.orc_stark_public_input_list.argtypes = [u6, u64p]
     L.orc_pg_txn_tables.argtypes = [vp, u64p, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_int),
                                     C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz)]
@@ -278,22 +278,23 @@ def stark_public_input_list(seed):
     return out
 
 
-def plonk_constants(log_n, seed, pi_len=4, n_paths=0, depth=0, path_pi0=0):
+def plonk_constants(log_n, seed, pi_len=4, n_paths=0, depth=0, path_pi0=0, leaf_len=0):
     """the 85 constant columns of a circuit that hashes a public-input list of pi_len words and walks n_paths Merkle
-    paths of `depth` levels (leaf digest / cap entry = list words path_pi0 + 8 p .. + 7)"""
+    paths of `depth` levels (leaf digest / cap entry = list words path_pi0 + 8 p .. + 7); leaf_len > 0: it also hashes the
+    leaf_len-word row each path's leaf digest is the hash of"""
     out = np.zeros((PLONK_CONSTS, 1 << log_n), dtype=np.uint64)
-    lib().orc_plonk_constants(C.c_uint64(seed), log_n, pi_len, n_paths, depth, path_pi0, out)
+    lib().orc_plonk_constants(C.c_uint64(seed), log_n, pi_len, n_paths, depth, path_pi0, leaf_len, out)
     return out
 
 
-def plonk_trace(log_n, seed, pi, consts, n_paths=0, depth=0, path_pi0=0, paths=None):
+def plonk_trace(log_n, seed, pi, consts, n_paths=0, depth=0, path_pi0=0, paths=None, leaf_len=0):
     """the witness; pi: the public-input list the hash rows absorb (its hash lands in row 0); paths: per Merkle path
-    1 + 4 depth words (the leaf's position, the siblings upward)"""
+    1 + 4 depth + leaf_len words (the leaf's position, the siblings upward, the row the leaf digest is the hash of)"""
     out = np.zeros((PLONK_COLS, 1 << log_n), dtype=np.uint64)
     pi = arr(pi)
     pw = arr(paths) if n_paths else np.zeros(1, dtype=np.uint64)
-    assert not n_paths or pw.size == n_paths * (1 + 4 * depth)
-    lib().orc_plonk_trace(C.c_uint64(seed), pi, pi.size, n_paths, depth, path_pi0, pw, arr(consts), log_n, out)
+    assert not n_paths or pw.size == n_paths * (1 + 4 * depth + leaf_len)
+    lib().orc_plonk_trace(C.c_uint64(seed), pi, pi.size, n_paths, depth, path_pi0, leaf_len, pw, arr(consts), log_n, out)
     return out
 
 

@@ -727,6 +727,12 @@ void orc_proof_first_query_path(const orc_stark_cfg* cf, const gl_t* proof, gl_t
   memcpy(cap_entry, proof + L.trace_cap + 4 * (x >> L.depth0), 32);
 }
 
+void orc_proof_first_query_row(const orc_stark_cfg* cf, const gl_t* proof, gl_t* row_out) {
+  layout_t L = layout(cf);
+  const gl_t* q = proof + L.queries;
+  memcpy(row_out, q + 1 + (cf->n_const ? cf->n_const + (size_t)L.depth0 * 4 : 0), cf->n_cols * sizeof(gl_t));
+}
+
 void orc_proof_digest(const orc_stark_cfg* cf, const gl_t* proof, gl_t out[4]) {
   layout_t L = layout(cf);
   size_t n = 3 * L.cap_words + 2 * (size_t)L.final_len + 1;

@@ -1013,20 +1013,26 @@ constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_HASH
 constexpr uint32_t COL_SBOX = 80;
 constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86, G4 = 90, G5 = 208;
 constexpr uint32_t HASH_ROW0 = 4, HASH_ROWS_MAX = 13, ZERO_ROW = 1, MAX_PI = 8 * HASH_ROWS_MAX;
-constexpr uint32_t MERKLE_ROW0 = HASH_ROW0 + HASH_ROWS_MAX, MERKLE_ROWS_MAX = 96, MERKLE_ZERO_COL = 79;
+constexpr uint32_t MERKLE_ROW0 = HASH_ROW0 + HASH_ROWS_MAX, MERKLE_ROWS_MAX = 96, MERKLE_ZERO_COL = 79, LEAF_ROWS_MAX = 40;
 constexpr uint32_t H_IN = 0, H_OUT = 12, H_FULL1 = 24, H_PART = 60, H_FULL2 = 82, H_SWAP = 130, H_DELTA = 131, H_WIRES = 135;
 // What a circuit of this family does besides its arithmetic groups: it hashes a public-input list of pi_len words
 // (rows 4 ..), and it walks n_paths Merkle paths of `depth` levels each (rows 12 ..): path p's leaf digest is list words
 // path_pi0 + 8p .. + 3, the cap entry it must arrive at is list words path_pi0 + 8p + 4 .. + 7.
+// leaf_len > 0: the circuit also HASHES, per path, the leaf the path starts from -- a row of leaf_len words (the child's
+// opened trace row: free wires, not words of the list) absorbed eight at a time in rows of its own right after the
+// Merkle rows; the digest it arrives at is the path's first node and the list's leaf-digest words (one copy cycle).
 struct Layout {
-  uint32_t pi_len, n_paths, depth, path_pi0;
+  uint32_t pi_len, n_paths, depth, path_pi0, leaf_len = 0;
 };
 GL_HD uint32_t hash_rows(uint32_t pi_len) { return (pi_len + 7) / 8; }
 GL_HD uint32_t merkle_rows(const Layout& L) { return L.n_paths * L.depth; }
-GL_HD uint32_t arith_row0(const Layout& L) { return (MERKLE_ROW0 + merkle_rows(L) + 3) & ~3u; }  // 20 without paths
+GL_HD uint32_t leaf_rows(const Layout& L) { return L.leaf_len ? L.n_paths * hash_rows(L.leaf_len) : 0; }
+GL_HD uint32_t leaf_row0(const Layout& L) { return MERKLE_ROW0 + merkle_rows(L); }
+GL_HD uint32_t arith_row0(const Layout& L) { return (MERKLE_ROW0 + merkle_rows(L) + leaf_rows(L) + 3) & ~3u; }  // 20 without paths
 GL_HD bool layout_ok(const Layout& L, uint32_t n) {
   return L.pi_len >= 1 && L.pi_len <= MAX_PI && merkle_rows(L) <= MERKLE_ROWS_MAX && (L.n_paths == 0 || L.depth >= 1) &&
-         L.path_pi0 + 8 * L.n_paths <= L.pi_len && arith_row0(L) + 4 <= n;
+         L.path_pi0 + 8 * L.n_paths <= L.pi_len && (L.leaf_len == 0 || (L.leaf_len > 8 && L.n_paths >= 1)) &&
+         leaf_rows(L) <= LEAF_ROWS_MAX && arith_row0(L) + 4 <= n;
 }
 // is state word k of hash row h (0-based) a carried word -- a copy of the previous row's output (h > 0) or of a zero wire
 // (h = 0) -- rather than a word of the list?
@@ -1086,16 +1092,38 @@ GL_HD void sigma_of(uint32_t col, uint32_t row, uint32_t n, const Layout& L, uin
       // out 0..3 the node above (the cap entry at the last level)
       const uint32_t t = row - MERKLE_ROW0, p = t / L.depth, l = t % L.depth;
       if (col < 4) {
-        if (l == 0) { const uint32_t i = L.path_pi0 + 8 * p + col; col_out = i & 7; row_out = HASH_ROW0 + (i >> 3); }
+        if (l == 0 && L.leaf_len) {  // the leaf digest: computed by the path's leaf rows (their last output), which closes the cycle
+          col_out = H_OUT + col; row_out = leaf_row0(L) + p * hash_rows(L.leaf_len) + hash_rows(L.leaf_len) - 1;
+        } else if (l == 0) { const uint32_t i = L.path_pi0 + 8 * p + col; col_out = i & 7; row_out = HASH_ROW0 + (i >> 3); }
         else { col_out = H_OUT + col; row_out = row - 1; }
       } else if (col >= 8 && col < 12) {  // one cycle through every capacity word of every Merkle row and a zero wire
         if (col < 11) col_out = col + 1;
         else if (t + 1 < T) { col_out = 8; row_out = row + 1; }
+        else if (L.leaf_len) { col_out = 8; row_out = leaf_row0(L); }  // ... and on through the leaf sponges' first rows
         else { col_out = MERKLE_ZERO_COL; row_out = ZERO_ROW; }
       } else if (col >= H_OUT && col < H_OUT + 4) {
         const uint32_t j = col - H_OUT;
         if (l + 1 == L.depth) { const uint32_t i = L.path_pi0 + 8 * p + 4 + j; col_out = i & 7; row_out = HASH_ROW0 + (i >> 3); }
         else { col_out = H_IN + j; row_out = row + 1; }
+      }
+    } else if (L.leaf_len && row >= leaf_row0(L) && row < leaf_row0(L) + leaf_rows(L)) {
+      // row h of the leaf sponge of path p: eight words of the leaf (free), the rest carried; the first row's capacity
+      // words are zeros (members of the Merkle rows' zero cycle); the last output is the path's first node
+      const uint32_t LH = hash_rows(L.leaf_len), t = row - leaf_row0(L), p = t / LH, h = t % LH;
+      if (col < 12) {
+        if (hash_word_is_carried(L.leaf_len, h, col)) {
+          if (h > 0) { col_out = H_OUT + col; row_out = row - 1; }
+          else if (col < 11) col_out = col + 1;                                  // (leaf_len > 8: the carried words of row 0 are 8..11)
+          else if (p + 1 < L.n_paths) { col_out = 8; row_out = row + LH; }
+          else { col_out = MERKLE_ZERO_COL; row_out = ZERO_ROW; }
+        }
+      } else if (col < 24) {
+        const uint32_t k = col - H_OUT;
+        if (h + 1 == LH) {
+          if (k < 4) { const uint32_t i = L.path_pi0 + 8 * p + k; col_out = i & 7; row_out = HASH_ROW0 + (i >> 3); }
+        } else if (hash_word_is_carried(L.leaf_len, h + 1, k)) {
+          col_out = H_IN + k; row_out = row + 1;
+        }
       }
     }
     return;

@@ -54,6 +54,7 @@ struct Circuit {  // one preprocessed recursion circuit: constants commitment + 
 struct PathWitness {
   uint64_t index = 0;
   std::vector<uint64_t> siblings;  // 4 words per level, leaf upward
+  std::vector<uint64_t> leaf_row;  // the opened row the leaf digest is the hash of (circuits that hash it: Layout::leaf_len)
 };
 struct LightCircuit {
   std::vector<uint64_t> cap;
@@ -239,6 +240,13 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
             uint64_t root[4];  // (not compared with the list's cap entry here: the copy constraints do that, and the verifier)
             poseidon_merkle_rows(&pi[first + b][c.lay.path_pi0 + 8 * p], pw.index, pw.siblings.data(), c.lay.depth,
                                  hr + (size_t)(air::plonk::HASH_ROWS_MAX + p * c.lay.depth) * air::plonk::H_WIRES, root);
+            if (c.lay.leaf_len) {  // ... and the sponge over the opened row that the leaf digest is the hash of
+              if (pw.leaf_row.size() != c.lay.leaf_len) return fail(BP_ERR_INVALID_INPUT, "Merkle path %u: the circuit hashes a leaf of %u words, %zu given", p, c.lay.leaf_len, pw.leaf_row.size());
+              uint64_t leaf_digest[4];
+              poseidon_hash_rows(pw.leaf_row.data(), c.lay.leaf_len, &rows, leaf_digest);
+              std::memcpy(hr + (size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::merkle_rows(c.lay) + p * air::plonk::hash_rows(c.lay.leaf_len)) * air::plonk::H_WIRES,
+                          rows.data(), rows.size() * 8);
+            }
           }
         }
       } else {
@@ -250,7 +258,7 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
       sa[b] = SynthTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0]};
       pa[b] = PlonkTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0], {pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]},
                              w.hash_rows_dev + (size_t)b * HASH_ROWS_WORDS, (uint32_t)((n_pi + 7) / 8),
-                             air::plonk::merkle_rows(c.lay), air::plonk::arith_row0(c.lay)};
+                             air::plonk::merkle_rows(c.lay) + air::plonk::leaf_rows(c.lay), air::plonk::arith_row0(c.lay)};
       if (rc.air_id == air::PLONK) std::memcpy(ctl[b].pub, pi_hash, sizeof(pi_hash));  // bound to the circuit's first row
       consts[b] = &c.consts;
     }
@@ -286,6 +294,7 @@ void first_query_trace_path(const StarkCfg& c, const uint64_t* child, uint64_t l
   const uint64_t* w = child + L.queries;
   const uint64_t x = *w++;
   if (c.n_const) w += c.n_const + (size_t)L.depth0 * 4;
+  pw->leaf_row.assign(w, w + c.n_cols);
   if (known_leaf) {
     std::memcpy(leaf, known_leaf, 32);
   } else if (c.n_cols <= 4) {  // Hasher::hash_or_noop
@@ -462,9 +471,17 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
   for (int t = 0; t < BP_NUM_TABLES; t++)
     if ((r = build_circuit(s->builder, rc, circuit_seed(t, SHRINK_SEED_DEGREE), air::plonk::Layout{CHAIN_PATH_PI0 + 8, 1, depth, CHAIN_PATH_PI0},
                            &s->shrink_circuits[t]))) return r;
-  const air::plonk::Layout special[3] = {{ROOT_PATH_PI0 + 8 * BP_NUM_TABLES + BP_PV_WORDS, BP_NUM_TABLES, depth, ROOT_PATH_PI0},
-                                         {AGG_PATH_PI0 + 2 * 8 + BP_PV_WORDS, 2, depth, AGG_PATH_PI0},
-                                         {BLOCK_PATH_PI0 + 8 + BP_PV_WORDS, 1, depth, BLOCK_PATH_PI0}};
+  // The aggregation and block circuits also HASH the row each child opens (its leaf: the child's n_cols trace values)
+  // before they walk up from it -- merkle_proofs::verify_merkle_proof_to_cap whole -- where the circuit has the rows for it
+  // (a 2^6-row test circuit has not: both sides take the same decision from the shape alone)
+  air::plonk::Layout special[3] = {{ROOT_PATH_PI0 + 8 * BP_NUM_TABLES + BP_PV_WORDS, BP_NUM_TABLES, depth, ROOT_PATH_PI0},
+                                   {AGG_PATH_PI0 + 2 * 8 + BP_PV_WORDS, 2, depth, AGG_PATH_PI0},
+                                   {BLOCK_PATH_PI0 + 8 + BP_PV_WORDS, 1, depth, BLOCK_PATH_PI0}};
+  for (uint32_t k = 1; k < 3; k++) {
+    air::plonk::Layout with_leaf = special[k];
+    with_leaf.leaf_len = rc.n_cols;
+    if (rc.air_id == air::PLONK && air::plonk::layout_ok(with_leaf, 1u << rc.log_n)) special[k] = with_leaf;
+  }
   for (uint32_t k = 0; k < 3; k++)
     if ((r = build_circuit(s->builder, rc, circuit_seed(CIRCUIT_ROOT + k, 0), special[k], &s->special[k]))) return r;
   BPG_HIP(hipStreamSynchronize(s->builder.stream));

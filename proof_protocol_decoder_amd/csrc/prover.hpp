@@ -96,7 +96,7 @@ class DeviceArena {
   size_t cap_ = 0, off_ = 0, high_ = 0;
 };
 
-constexpr size_t HASH_ROWS_WORDS = (size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::MERKLE_ROWS_MAX) * air::plonk::H_WIRES;  // per proof: list rows, then Merkle rows
+constexpr size_t HASH_ROWS_WORDS = (size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::MERKLE_ROWS_MAX + air::plonk::LEAF_ROWS_MAX) * air::plonk::H_WIRES;  // per proof: list rows, Merkle rows, leaf rows
 
 struct Committed {
   uint64_t *coeffs = nullptr, *lde = nullptr, *digests = nullptr;

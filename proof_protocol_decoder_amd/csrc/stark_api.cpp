@@ -368,7 +368,7 @@ BPG_ABI_CATCH("bp_arithmetic_mul_trace")
 // (135 wires; free wires drawn from `seed`; the list pi is hashed in the hash rows, the hash lands in row 0).
 static int plonk_layout_of(const bp_plonk_layout* l, uint32_t log_n, air::plonk::Layout* out) {
   if (!l) return fail(BP_ERR_INVALID_INPUT, "null plonk layout");
-  *out = air::plonk::Layout{l->pi_len, l->n_paths, l->path_depth, l->path_pi0};
+  *out = air::plonk::Layout{l->pi_len, l->n_paths, l->path_depth, l->path_pi0, l->leaf_len};
   if (!air::plonk::layout_ok(*out, 1u << log_n))
     return fail(BP_ERR_INVALID_INPUT, "plonk layout: a list of 1..%u words, at most %u Merkle rows (n_paths x path_depth), the paths' words "
                 "(8 per path from path_pi0) inside the list, and room for one arithmetic group in 2^%u rows", air::plonk::MAX_PI,
@@ -394,25 +394,32 @@ int bp_plonk_trace(const uint64_t* d_consts, uint64_t seed, const uint64_t* pi, 
   if (rc) return rc;
   if (lay.n_paths && !paths) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: the layout walks %u Merkle paths: their witness is missing", lay.n_paths);
   for (uint32_t j = 0; j < lay.pi_len; j++) if (pi[j] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: non-canonical public input");
-  std::vector<uint64_t> rows, all((size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::merkle_rows(lay)) * air::plonk::H_WIRES, 0);
+  std::vector<uint64_t> rows, all((size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::merkle_rows(lay) + air::plonk::leaf_rows(lay)) * air::plonk::H_WIRES, 0);
   uint64_t pub[4];
   poseidon_hash_rows(pi, lay.pi_len, &rows, pub);
   std::memcpy(all.data(), rows.data(), rows.size() * 8);
-  const size_t path_words = 1 + 4 * (size_t)lay.depth;
+  const uint32_t n_list_rows = (uint32_t)(rows.size() / air::plonk::H_WIRES);
+  const size_t path_words = 1 + 4 * (size_t)lay.depth + lay.leaf_len;
   for (uint32_t p = 0; p < lay.n_paths; p++) {
     const uint64_t* pw = paths + p * path_words;
     for (size_t j = 1; j < path_words; j++) if (pw[j] >= gl::P) return fail(BP_ERR_INVALID_INPUT, "bp_plonk_trace: non-canonical sibling word");
     uint64_t root[4];
     poseidon_merkle_rows(pi + lay.path_pi0 + 8 * p, pw[0], pw + 1, lay.depth,
                          all.data() + (size_t)(air::plonk::HASH_ROWS_MAX + p * lay.depth) * air::plonk::H_WIRES, root);
+    if (lay.leaf_len) {
+      uint64_t digest[4];
+      poseidon_hash_rows(pw + 1 + 4 * (size_t)lay.depth, lay.leaf_len, &rows, digest);
+      std::memcpy(all.data() + (size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::merkle_rows(lay) + p * air::plonk::hash_rows(lay.leaf_len)) * air::plonk::H_WIRES,
+                  rows.data(), rows.size() * 8);
+    }
   }
   // (a test / integration entry: the rows go up with a blocking copy into a buffer of their own)
   uint64_t* d_rows = nullptr;
   BPG_HIP(hipMalloc(reinterpret_cast<void**>(&d_rows), all.size() * 8));
   struct Free { uint64_t* p; ~Free() { (void)hipFree(p); } } guard{d_rows};
   BPG_HIP(hipMemcpy(d_rows, all.data(), all.size() * 8, hipMemcpyHostToDevice));
-  PlonkTraceArgs a{d_trace_out, d_consts, seed, {pub[0], pub[1], pub[2], pub[3]}, d_rows, (uint32_t)(rows.size() / air::plonk::H_WIRES),
-                   air::plonk::merkle_rows(lay), air::plonk::arith_row0(lay)};
+  PlonkTraceArgs a{d_trace_out, d_consts, seed, {pub[0], pub[1], pub[2], pub[3]}, d_rows, n_list_rows,
+                   air::plonk::merkle_rows(lay) + air::plonk::leaf_rows(lay), air::plonk::arith_row0(lay)};
   rc = launch_plonk_trace(&a, 1, log_n, as_stream(stream));
   if (rc) return rc;
   BPG_HIP(hipStreamSynchronize(as_stream(stream)));

@@ -634,7 +634,7 @@ plonk_constants_kernel(uint64_t* __restrict__ out, uint32_t log_n, uint64_t seed
   if (k == pk::CST_ARITH) v = (i >= a0 && p != 2) || i == pk::ZERO_ROW;   // row 1: the gate that makes the zero wires
   else if (k == pk::CST_SBOX) v = i >= a0 && p == 2;
   else if (k == pk::CST_HASH) v = (i >= pk::HASH_ROW0 && i < pk::HASH_ROW0 + pk::hash_rows(lay.pi_len)) ||
-                                  (i >= pk::MERKLE_ROW0 && i < pk::MERKLE_ROW0 + pk::merkle_rows(lay));
+                                  (i >= pk::MERKLE_ROW0 && i < pk::MERKLE_ROW0 + pk::merkle_rows(lay) + pk::leaf_rows(lay));
   else if (k < pk::CST_SIGMA) v = i == pk::ZERO_ROW ? 0 : rnd(seed ^ 0xC0115700C0115700ULL, k, i);
   else {
     uint32_t c2, r2;
@@ -1564,8 +1564,8 @@ int launch_plonk_constants(uint64_t* d_out, uint32_t log_n, uint64_t seed, const
     return fail(BP_ERR_INVALID_INPUT, "a recursion circuit hashes a public-input list of 1..%u words: got %u", air::plonk::MAX_PI, lay.pi_len);
   if (log_n >= 4 && log_n < 31 && !air::plonk::layout_ok(lay, 1u << log_n))
     return fail(BP_ERR_INVALID_INPUT, "plonk circuit layout: %u paths of %u levels (at most %u Merkle rows), their words at %u.. of a "
-                "list of %u, and one arithmetic group must fit 2^%u rows", lay.n_paths, lay.depth, air::plonk::MERKLE_ROWS_MAX,
-                lay.path_pi0, lay.pi_len, log_n);
+                "list of %u, leaves of %u words (0 or more than 8; at most %u leaf rows), and one arithmetic group must fit 2^%u rows",
+                lay.n_paths, lay.depth, air::plonk::MERKLE_ROWS_MAX, lay.path_pi0, lay.pi_len, lay.leaf_len, air::plonk::LEAF_ROWS_MAX, log_n);
   if (log_n < 5) return fail(BP_ERR_INVALID_INPUT, "the plonk circuit needs 32 rows: the Poseidon rows (4..19) and one arithmetic group");
   const uint64_t* tw_n = nullptr;
   if (int rc = get_table(0, log_n, 0, &tw_n)) return rc;
@@ -1581,7 +1581,7 @@ int launch_plonk_trace(const PlonkTraceArgs* a, uint32_t batch, uint32_t log_n, 
   uint32_t region = 0;
   for (uint32_t b = 0; b < batch; b++) {
     if (a[b].arith_row0 < air::plonk::MERKLE_ROW0 || (a[b].arith_row0 & 3) || a[b].arith_row0 + 4 > (1ull << log_n) ||
-        air::plonk::MERKLE_ROW0 + a[b].n_merkle_rows > a[b].arith_row0 || a[b].n_merkle_rows > air::plonk::MERKLE_ROWS_MAX)
+        air::plonk::MERKLE_ROW0 + a[b].n_merkle_rows > a[b].arith_row0 || a[b].n_merkle_rows > air::plonk::MERKLE_ROWS_MAX + air::plonk::LEAF_ROWS_MAX)
       return fail(BP_ERR_INVALID_INPUT, "launch_plonk_trace: %u Merkle rows and first arithmetic row %u do not fit 2^%u rows", a[b].n_merkle_rows, a[b].arith_row0, log_n);
     region = std::max(region, a[b].arith_row0 - air::plonk::HASH_ROW0);
   }

@@ -203,7 +203,8 @@ struct PlonkTraceArgs {
   const uint64_t* consts;
   uint64_t seed, pub[4];        // pub = hash_no_pad(the public-input list) = the first output words of the last hash row
   // device-visible [HASH_ROWS_MAX + n_merkle_rows][air::plonk::H_WIRES]: the witness of that hash in the first
-  // n_hash_rows rows (poseidon_hash_rows), of the Merkle paths from row HASH_ROWS_MAX on (poseidon_merkle_rows)
+  // n_hash_rows rows (poseidon_hash_rows), of the Merkle paths from row HASH_ROWS_MAX on (poseidon_merkle_rows), of the
+  // paths' leaf sponges right after them (poseidon_hash_rows of each opened row); n_merkle_rows counts both
   const uint64_t* hash_rows;
   uint32_t n_hash_rows;
   uint32_t n_merkle_rows = 0, arith_row0 = (air::plonk::MERKLE_ROW0 + 3) & ~3u;  // air::plonk::arith_row0(the circuit's layout); default: no paths

@@ -14,34 +14,38 @@ SEED, CSEED = 0x5EED000000000008, 0xC0DE000000000008
 
 
 class Layout(C.Structure):   # include/bpg.h: bp_plonk_layout
-    _fields_ = [("pi_len", C.c_uint32), ("n_paths", C.c_uint32), ("path_depth", C.c_uint32), ("path_pi0", C.c_uint32)]
+    _fields_ = [("pi_len", C.c_uint32), ("n_paths", C.c_uint32), ("path_depth", C.c_uint32), ("path_pi0", C.c_uint32),
+                ("leaf_len", C.c_uint32)]
 
 
-def dev_constants(bpg, log_n, seed, pi_len=4, n_paths=0, depth=0, path_pi0=0):
+def dev_constants(bpg, log_n, seed, pi_len=4, n_paths=0, depth=0, path_pi0=0, leaf_len=0):
     import torch
     out = torch.empty((85, 1 << log_n), dtype=torch.int64, device="cuda")
     L = bpg.lib()
     L.bp_plonk_constants.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(Layout), C.c_void_p, C.c_void_p]
-    lay = Layout(pi_len, n_paths, depth, path_pi0)
+    lay = Layout(pi_len, n_paths, depth, path_pi0, leaf_len)
     bpg._lib.check(L.bp_plonk_constants(C.c_uint64(seed), log_n, C.byref(lay), C.c_void_p(out.data_ptr()), None))
     return out
 
 
 # (log_n, pi_len, n_paths, depth, path_pi0): lists of every chunking; the aggregation / block / root / chain layouts at default depth 12
-CIRCUITS = [(5, 4, 0, 0, 0), (8, 6, 0, 0, 0), (13, 41, 0, 0, 0), (6, 23, 0, 0, 0), (5, 64, 0, 0, 0), (5, 8, 0, 0, 0), (5, 1, 0, 0, 0), (5, 104, 0, 0, 0),
-            (13, 39, 2, 12, 10), (13, 30, 1, 12, 9), (13, 97, 7, 12, 28), (13, 14, 1, 14, 6), (13, 14, 1, 27, 6), (6, 39, 2, 5, 10),
-            (7, 64, 2, 32, 40), (7, 104, 3, 32, 80), (5, 17, 1, 1, 3)]
+CIRCUITS = [(5, 4, 0, 0, 0, 0), (8, 6, 0, 0, 0, 0), (13, 41, 0, 0, 0, 0), (6, 23, 0, 0, 0, 0), (5, 64, 0, 0, 0, 0), (5, 8, 0, 0, 0, 0),
+            (5, 1, 0, 0, 0, 0), (5, 104, 0, 0, 0, 0), (13, 39, 2, 12, 10, 0), (13, 30, 1, 12, 9, 0), (13, 97, 7, 12, 28, 0),
+            (13, 14, 1, 14, 6, 0), (13, 14, 1, 27, 6, 0), (6, 39, 2, 5, 10, 0), (7, 64, 2, 32, 40, 0), (7, 104, 3, 32, 80, 0),
+            (5, 17, 1, 1, 3, 0),
+            # the aggregation / block circuits of the default shape: they hash the 135-word rows their paths start from
+            (13, 39, 2, 12, 10, 135), (13, 30, 1, 12, 9, 135), (7, 39, 2, 5, 10, 19), (7, 30, 1, 7, 9, 135)]
 
 
-@pytest.mark.parametrize("log_n,pi_len,n_paths,depth,path_pi0", CIRCUITS)
-def test_constants_and_witness_match_oracle(bpg, oracle, log_n, pi_len, n_paths, depth, path_pi0):
+@pytest.mark.parametrize("log_n,pi_len,n_paths,depth,path_pi0,leaf_len", CIRCUITS)
+def test_constants_and_witness_match_oracle(bpg, oracle, log_n, pi_len, n_paths, depth, path_pi0, leaf_len):
     """The circuit of a pi_len-word public-input list that walks n_paths Merkle paths (selectors, Poseidon-row selector,
     sigmas with the sponge's and the paths' copy cycles) and its witness (the Poseidon rows made on the host, the rest on
     the device) against the oracle's."""
     import torch
     from test_plonk_air import merkle_fixture
-    k = dev_constants(bpg, log_n, CSEED + log_n, pi_len, n_paths, depth, path_pi0)
-    want_k = oracle.plonk_constants(log_n, CSEED + log_n, pi_len, n_paths, depth, path_pi0)
+    k = dev_constants(bpg, log_n, CSEED + log_n, pi_len, n_paths, depth, path_pi0, leaf_len)
+    want_k = oracle.plonk_constants(log_n, CSEED + log_n, pi_len, n_paths, depth, path_pi0, leaf_len)
     assert (to_host(k) == want_k).all()
     pub, lst = oracle.stark_public_inputs(SEED + log_n), oracle.stark_public_input_list(SEED + log_n)
     got_pub, got_lst = (C.c_uint64 * 4)(), (C.c_uint64 * 4)()
@@ -51,30 +55,31 @@ def test_constants_and_witness_match_oracle(bpg, oracle, log_n, pi_len, n_paths,
     assert [int(x) for x in oracle.hash_no_pad(lst)] == [int(x) for x in pub]
     rng = np.random.default_rng(pi_len)
     pi = rng.integers(0, 0xFFFFFFFF00000001, size=pi_len, dtype=np.uint64)
-    words, wit = merkle_fixture(oracle, rng, min(depth, 8), n_paths, cap_height=0) if depth <= 8 else (None, None)
+    words, wit = merkle_fixture(oracle, rng, min(depth, 8), n_paths, cap_height=0, leaf_len=leaf_len) if depth <= 8 else (None, None)
     if n_paths and words is None:   # deep paths: any siblings will do for witness parity (the path's end is whatever it is)
         words = [int(x) for x in rng.integers(0, 0xFFFFFFFF00000001, size=8 * n_paths, dtype=np.uint64)]
         wit = []
         for _ in range(n_paths):
-            wit += [int(rng.integers(0, 1 << depth))] + [int(x) for x in rng.integers(0, 0xFFFFFFFF00000001, size=4 * depth, dtype=np.uint64)]
+            wit += [int(rng.integers(0, 1 << depth))] + [int(x) for x in rng.integers(0, 0xFFFFFFFF00000001, size=4 * depth + leaf_len, dtype=np.uint64)]
     if n_paths:
         pi[path_pi0:path_pi0 + 8 * n_paths] = words
     t = torch.empty((135, 1 << log_n), dtype=torch.int64, device="cuda")
     pi_c = (C.c_uint64 * pi_len)(*[int(x) for x in pi])
     wit_c = (C.c_uint64 * max(1, len(wit or [])))(*[int(x) for x in (wit or [])])
-    lay = Layout(pi_len, n_paths, depth, path_pi0)
+    lay = Layout(pi_len, n_paths, depth, path_pi0, leaf_len)
     bpg.lib().bp_plonk_trace.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(Layout), C.POINTER(C.c_uint64), C.c_uint32,
                                          C.c_void_p, C.c_void_p]
     bpg._lib.check(bpg.lib().bp_plonk_trace(C.c_void_p(k.data_ptr()), C.c_uint64(SEED + log_n), pi_c, C.byref(lay), wit_c if n_paths else None,
                                             log_n, C.c_void_p(t.data_ptr()), None))
     got = to_host(t)
-    assert (got == oracle.plonk_trace(log_n, SEED + log_n, pi, want_k, n_paths, depth, path_pi0, wit)).all()
+    assert (got == oracle.plonk_trace(log_n, SEED + log_n, pi, want_k, n_paths, depth, path_pi0, wit, leaf_len)).all()
     assert [int(x) for x in got[:4, 0]] == [int(x) for x in oracle.hash_no_pad(pi)]
 
 
 def test_layouts_that_do_not_fit_are_refused(bpg):
     from proof_protocol_decoder_amd._lib import BpgError
-    for log_n, lay in ((5, (39, 2, 12, 10)), (13, (39, 2, 12, 32)), (13, (105, 0, 0, 0)), (13, (39, 4, 30, 0)), (13, (0, 0, 0, 0)), (4, (4, 0, 0, 0))):
+    for log_n, lay in ((5, (39, 2, 12, 10)), (13, (39, 2, 12, 32)), (13, (105, 0, 0, 0)), (13, (39, 4, 30, 0)), (13, (0, 0, 0, 0)), (4, (4, 0, 0, 0)),
+                       (13, (39, 2, 12, 10, 8)), (13, (39, 0, 0, 0, 135)), (13, (39, 2, 12, 10, 400)), (6, (39, 2, 5, 10, 135))):
         with pytest.raises(BpgError):
             dev_constants(bpg, log_n, 1, *lay)
 

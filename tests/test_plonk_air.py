@@ -57,29 +57,34 @@ def hash_no_pad_py(oracle, words):
     return [int(x) for x in st[:4]]
 
 
-def merkle_fixture(oracle, rng, depth, n_paths, cap_height=1):
+def merkle_fixture(oracle, rng, depth, n_paths, cap_height=1, leaf_len=0):
     """n_paths trees of 2^(depth + cap_height) random leaf digests each, one leaf picked in each: per path its
     (leaf digest, cap entry) -- the eight words the public-input list carries -- and the witness words
-    (position below the cap entry, siblings upward)."""
+    (position below the cap entry, siblings upward; with leaf_len > 0 the picked leaf is the hash of a random row of
+    leaf_len words, and the row follows the siblings)."""
     words, wit = [], []
     for _ in range(n_paths):
         leaves = rng.integers(0, P, size=(1 << (depth + cap_height), 4), dtype=np.uint64)
         index = int(rng.integers(0, 1 << (depth + cap_height)))
+        row = rng.integers(0, P, size=leaf_len, dtype=np.uint64)
+        if leaf_len:
+            leaves[index] = oracle.hash_no_pad(row)
         sibs, top = oracle.merkle_path(leaves, index, cap_height)
         assert sibs.size == 4 * depth
         words += [int(x) for x in leaves[index]] + [int(x) for x in top]
-        wit += [index & ((1 << depth) - 1)] + [int(x) for x in sibs]
+        wit += [index & ((1 << depth) - 1)] + [int(x) for x in sibs] + [int(x) for x in row]
     return words, wit
 
 
 # (pi_len, n_paths, depth, path_pi0): lists of every chunking; the aggregation / block circuits' layouts at a small depth
-LAYOUTS = [(4, 0, 0, 0), (6, 0, 0, 0), (8, 0, 0, 0), (9, 0, 0, 0), (23, 0, 0, 0), (41, 0, 0, 0), (64, 0, 0, 0), (104, 0, 0, 0),
-           (39, 2, 5, 10), (30, 1, 7, 9), (17, 1, 1, 3), (64, 2, 6, 40), (14, 1, 6, 6), (97, 7, 5, 28)]
+LAYOUTS = [(4, 0, 0, 0, 0), (6, 0, 0, 0, 0), (8, 0, 0, 0, 0), (9, 0, 0, 0, 0), (23, 0, 0, 0, 0), (41, 0, 0, 0, 0), (64, 0, 0, 0, 0),
+           (104, 0, 0, 0, 0), (39, 2, 5, 10, 0), (30, 1, 7, 9, 0), (17, 1, 1, 3, 0), (64, 2, 6, 40, 0), (14, 1, 6, 6, 0), (97, 7, 5, 28, 0),
+           (39, 2, 5, 10, 19), (30, 1, 7, 9, 135), (39, 2, 3, 10, 9), (30, 1, 12, 9, 16)]   # ... and circuits that hash their paths' leaves
 MROW0 = 17   # the Merkle rows start after the thirteen rows a list can take (rows 4..16)
 
 
-@pytest.mark.parametrize("pi_len,n_paths,depth,path_pi0", LAYOUTS)
-def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_paths, depth, path_pi0):
+@pytest.mark.parametrize("pi_len,n_paths,depth,path_pi0,leaf_len", LAYOUTS)
+def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_paths, depth, path_pi0, leaf_len):
     """The circuit for a public-input list of pi_len words that walks n_paths Merkle paths: gates hold row by row, the
     hash rows are the permutations of hash_no_pad(list) -- checked against the oracle's plain permutation, S-box input by
     S-box input --, their output is what row 0 carries, the Merkle rows climb from the list's leaf digest to the list's
@@ -87,13 +92,15 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
     log_n, n = 6, 64
     rng = np.random.default_rng(pi_len + 100 * n_paths)
     pi = rng.integers(0, P, size=pi_len, dtype=np.uint64)
-    words, wit = merkle_fixture(oracle, rng, depth, n_paths)
+    words, wit = merkle_fixture(oracle, rng, depth, n_paths, leaf_len=leaf_len)
     pi[path_pi0:path_pi0 + 8 * n_paths] = words
-    k = oracle.plonk_constants(log_n, CSEED, pi_len, n_paths, depth, path_pi0)
-    t = oracle.plonk_trace(log_n, SEED, pi, k, n_paths, depth, path_pi0, wit)
+    k = oracle.plonk_constants(log_n, CSEED, pi_len, n_paths, depth, path_pi0, leaf_len)
+    t = oracle.plonk_trace(log_n, SEED, pi, k, n_paths, depth, path_pi0, wit, leaf_len)
     H = (pi_len + 7) // 8
-    T = n_paths * depth
-    A0 = (MROW0 + T + 3) // 4 * 4
+    LH = (leaf_len + 7) // 8
+    T, PW = n_paths * depth, 1 + 4 * depth + leaf_len            # Merkle rows; witness words per path
+    LROW0 = MROW0 + T
+    A0 = (MROW0 + T + n_paths * LH + 3) // 4 * 4
     want_hash = hash_no_pad_py(oracle, pi)
     assert [int(t[j, 0]) for j in range(4)] == want_hash
     assert [int(x) for x in oracle.hash_no_pad(pi)] == want_hash
@@ -104,7 +111,7 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
     CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
     for i in range(n):
         qa, qs, qh = int(k[0, i]), int(k[1, i]), int(k[4, i])
-        want = ((1, 0, 0) if i == 1 else (0, 0, 1) if 4 <= i < 4 + H or MROW0 <= i < MROW0 + T else (0, 0, 0) if i < A0
+        want = ((1, 0, 0) if i == 1 else (0, 0, 1) if 4 <= i < 4 + H or MROW0 <= i < MROW0 + T + n_paths * LH else (0, 0, 0) if i < A0
                 else ((0, 1, 0) if i % 4 == 2 else (1, 0, 0)))
         assert (qa, qs, qh) == want, i
         if qa:
@@ -141,15 +148,23 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
                 assert [int(t[c, i]) for c in range(min(8, pi_len - 8 * h))] == [int(x) for x in pi[8 * h:8 * h + 8]]
     # the Merkle rows: from the list's leaf digest, level by level (the position bit on the swap wire), to the list's cap entry
     for p in range(n_paths):
-        node, index = words[8 * p:8 * p + 4], wit[p * (1 + 4 * depth)]
+        node, index = words[8 * p:8 * p + 4], wit[p * PW]
         for l in range(depth):
             row = MROW0 + p * depth + l
-            sib = wit[p * (1 + 4 * depth) + 1 + 4 * l:][:4]
+            sib = wit[p * PW + 1 + 4 * l:][:4]
             assert [int(t[c, row]) for c in range(12)] == node + sib + [0, 0, 0, 0] and int(t[130, row]) == (index >> l) & 1
             pair = sib + node if (index >> l) & 1 else node + sib
             node = [int(x) for x in oracle.hash_no_pad(np.array(pair, dtype=np.uint64))]
             assert [int(t[12 + c, row]) for c in range(4)] == node
         assert node == words[8 * p + 4:8 * p + 8]
+        # the leaf sponge: the opened row, eight words a row; its last output is the leaf digest the path started from
+        row_words = wit[p * PW + 1 + 4 * depth:][:leaf_len]
+        for h in range(LH):
+            r = LROW0 + p * LH + h
+            assert [int(t[c, r]) for c in range(min(8, leaf_len - 8 * h))] == row_words[8 * h:8 * h + 8] and int(t[130, r]) == 0
+        if leaf_len:
+            assert [int(t[12 + c, LROW0 + p * LH + LH - 1]) for c in range(4)] == words[8 * p:8 * p + 4]
+            assert [int(x) for x in oracle.hash_no_pad(np.array(row_words, dtype=np.uint64))] == words[8 * p:8 * p + 4]
     # sigma is a permutation of the routed wires that only ties equal values; the classes the circuit needs exist
     w = pow(7, (P - 1) >> log_n, P)
     ident = {(mul(pow(7, j, P), pow(w, i, P))): (j, i) for j in range(80) for i in range(n)}
@@ -178,7 +193,12 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
         r0, r1 = MROW0 + p * depth, MROW0 + p * depth + depth - 1
         for j in range(4):
             i_leaf, i_top = path_pi0 + 8 * p + j, path_pi0 + 8 * p + 4 + j
-            assert nxt[(j, r0)] == (i_leaf % 8, 4 + i_leaf // 8) and nxt[(i_leaf % 8, 4 + i_leaf // 8)] == (j, r0)
+            if leaf_len:   # list word -> the path's first node -> the leaf sponge's last output -> the list word
+                last_leaf = LROW0 + p * LH + LH - 1
+                assert nxt[(i_leaf % 8, 4 + i_leaf // 8)] == (j, r0) and nxt[(j, r0)] == (12 + j, last_leaf)
+                assert nxt[(12 + j, last_leaf)] == (i_leaf % 8, 4 + i_leaf // 8)
+            else:
+                assert nxt[(j, r0)] == (i_leaf % 8, 4 + i_leaf // 8) and nxt[(i_leaf % 8, 4 + i_leaf // 8)] == (j, r0)
             assert nxt[(12 + j, r1)] == (i_top % 8, 4 + i_top // 8) and nxt[(i_top % 8, 4 + i_top // 8)] == (12 + j, r1)
             for l in range(depth - 1):
                 assert nxt[(12 + j, r0 + l)] == (j, r0 + l + 1) and nxt[(j, r0 + l + 1)] == (12 + j, r0 + l)
@@ -187,7 +207,11 @@ def test_the_fixed_circuit_is_satisfied_and_its_copies_hold(oracle, pi_len, n_pa
         while at not in cyc:
             cyc.append(at)
             at = nxt[at]
-        assert sorted(cyc) == sorted([(79, 1)] + [(8 + j, MROW0 + r) for r in range(T) for j in range(4)])
+        assert sorted(cyc) == sorted([(79, 1)] + [(8 + j, MROW0 + r) for r in range(T) for j in range(4)]
+                                     + [(8 + j, LROW0 + p * LH) for p in range(n_paths if leaf_len else 0) for j in range(4)])
+        for p in range(n_paths if leaf_len else 0):      # the sponge's carry between the leaf rows
+            for h in range(1, LH):
+                assert nxt[(9, LROW0 + p * LH + h)] == (12 + 9, LROW0 + p * LH + h - 1)
         assert all(int(t[c, r]) == 0 for c, r in cyc)
 
 
@@ -288,6 +312,33 @@ def test_a_wrong_merkle_path_yields_a_rejected_proof(oracle, col, row, what):
         return
     assert oracle.stark_verify(cfg, proof, ctl, chv, cap) != 0
     assert product_verify(cfg, proof, cap, pub) != 0
+
+
+def test_a_leaf_row_that_is_not_the_leaf_s_preimage_yields_a_rejected_proof(oracle):
+    """The circuits that hash their paths' leaves (the aggregation / block circuits at the default shape): the valid
+    witness is accepted by both verifiers; one changed word of the opened row changes the digest its sponge rows arrive at,
+    which is no longer the path's first node nor the list's leaf digest: rejected by both.  So is a changed carry between
+    two leaf rows."""
+    log_n, layout = 7, (30, 1, 7, 9, 135)
+    rng = np.random.default_rng(6)
+    pi = rng.integers(0, P, size=layout[0], dtype=np.uint64)
+    words, wit = merkle_fixture(oracle, rng, layout[2], layout[1], leaf_len=135)
+    pi[9:17] = words
+    pub = oracle.hash_no_pad(pi)
+    cfg = small_cfg(oracle, log_n, pub)
+    k = oracle.plonk_constants(log_n, CSEED, *layout)
+    t = oracle.plonk_trace(log_n, 79, pi, k, layout[1], layout[2], layout[3], wit, 135)
+    proof, ctl, chv, cap = prove(oracle, cfg, k, t)
+    assert oracle.stark_verify(cfg, proof, ctl, chv, cap) == 0 and product_verify(cfg, proof, cap, pub) == 0
+    wit2 = list(wit)
+    wit2[1 + 4 * 7 + 60] ^= 1                       # word 60 of the opened row
+    t2 = oracle.plonk_trace(log_n, 79, pi, k, layout[1], layout[2], layout[3], wit2, 135)
+    proof, ctl, chv, cap = prove(oracle, cfg, k, t2)
+    assert oracle.stark_verify(cfg, proof, ctl, chv, cap) != 0 and product_verify(cfg, proof, cap, pub) != 0
+    t3 = t.copy()
+    t3[9, MROW0 + 7 + 3] = np.uint64((int(t3[9, MROW0 + 7 + 3]) + 1) % P)   # a carried capacity word of leaf row 3
+    proof, ctl, chv, cap = prove(oracle, cfg, k, t3)
+    assert oracle.stark_verify(cfg, proof, ctl, chv, cap) != 0 and product_verify(cfg, proof, cap, pub) != 0
 
 
 def test_air_registry_describes_the_plonk_air():
