@@ -446,7 +446,7 @@ def main():
                    "keccak_table": "Keccak-f[1600] AIR, 2431 columns" if (args.keccak_air or args.real_airs)
                                    else "synthetic AIR, 2432 columns",
                    "recursion_proofs": "synthetic AIR, 135 columns, 82 constants" if args.synthetic_rec
-                                       else "PLONK-shaped circuit (AIR 8), 135 wires, 85 constants, 20 auxiliary columns; the public-input list is hashed in-circuit by Poseidon-gate rows, and every recursion circuit walks one Merkle path per child proof in-circuit",
+                                       else "PLONK-shaped circuit (AIR 8), 135 wires, 85 constants, 20 auxiliary columns; the public-input list is hashed in-circuit by Poseidon-gate rows, and every recursion circuit walks one Merkle path per child proof in-circuit (the aggregation / block circuits from the opened row itself)",
                    **({"logic_table": "logic AIR, 524 columns", "memory_table": "memory AIR, 45 columns",
                        "arithmetic_table": "arithmetic AIR, 309 columns",
                        "byte_packing_table": "byte-packing AIR, 299 columns",

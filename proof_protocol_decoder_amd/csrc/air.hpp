@@ -1007,6 +1007,8 @@ GL_HD void eval_unit(uint32_t u, const Row& row, Emit& out) {
 // is given commits to (leaf digest, cap entry) pairs between which the circuit has checked a path; which leaf and which
 // cap the words are is the aggregating host's statement, as the child digests in the same list are.  Arithmetic groups
 // start at the first multiple of four past the Merkle rows (row 20 for a circuit that walks no path).
+// **Leaf rows** (Layout::leaf_len > 0; right after the Merkle rows, ceil(leaf_len / 8) per path): the circuit hashes the
+// row each path starts from -- a second sponge whose words are free wires -- and its last output IS the path's first node.
 namespace plonk {
 constexpr uint32_t N_COLS = 135, N_CONST = 85, N_ROUTED = 80, N_SLOTS = 20, N_SBOX = 11, N_CONSTRAINTS = 213, N_UNITS = 11;
 constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_HASH = 4, CST_SIGMA = 5;
