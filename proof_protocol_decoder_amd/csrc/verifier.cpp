@@ -2,6 +2,10 @@
 // VerifierState::verify, plonky_block_proof_gen/src/verifier_state.rs:56-71; upstream
 // verify_stark_proof_with_challenges + fri::verifier::verify_fri_proof).  Host code only: the
 // reference's verifier is CPU too, and a light verifier must not need a GPU.
+#include <string>
+#include <thread>
+#include <system_error>
+#include <vector>
 #include "prover.hpp"
 
 namespace bpg {
@@ -181,9 +185,12 @@ int stark_verify(const StarkCfg& cfg, const uint64_t* const_cap, const Ctl& ctl,
   caps[n_init] = P + L.quot_cap; widths[n_init++] = Q;
   const uint64_t w_m = gl::root(log_m);
 
-  for (uint32_t q = 0; q < cfg.num_queries; q++) {
+  // the query indices come out of the transcript one after the other; the queries themselves are independent
+  std::vector<uint64_t> xs(cfg.num_queries);
+  for (uint32_t q = 0; q < cfg.num_queries; q++) xs[q] = ch.challenge() & (M - 1);
+  auto verify_query = [&](uint32_t q) -> int {
     const uint64_t* w = P + L.queries + (size_t)q * L.query_words;
-    uint64_t x = ch.challenge() & (M - 1);
+    uint64_t x = xs[q];
     if (*w++ != x) REJECT("query %u: index does not match the transcript", q);
     const uint64_t* rows[4];
     for (int o = 0; o < n_init; o++) {
@@ -227,7 +234,47 @@ int stark_verify(const StarkCfg& cfg, const uint64_t* const_cap, const Ctl& ctl,
     Ext fv = gl::ext(0);
     for (size_t i = L.final_len; i-- > 0;) fv = gl::add(gl::scale(fv, subgroup_x), rd(fp, i));
     if (!gl::eq(fv, old_eval)) REJECT("query %u: final polynomial evaluation", q);
+    return BP_OK;
+  };
+  // A proof of the default shape is ~3,000 host permutations of Merkle paths over its 28 / 84 queries (5 .. 10 ms): when
+  // the process is not busy proving (a verifier, the top of a multi-GPU tree checking a foreign child) the queries are
+  // checked by up to four threads; the reported failure is that of the lowest failing query either way.
+  const uint32_t hw = std::thread::hardware_concurrency();
+  const uint32_t n_threads = (cfg.num_queries >= 16 && hw >= 4 && provers_active() <= 1) ? 4 : 1;
+  if (n_threads == 1) {
+    for (uint32_t q = 0; q < cfg.num_queries; q++)
+      if (int r = verify_query(q)) return r;
+    return BP_OK;
   }
+  std::vector<int> rcs(cfg.num_queries, BP_OK);
+  std::vector<std::string> msgs(cfg.num_queries);
+  auto work = [&](uint32_t t) {
+    for (uint32_t q = t; q < cfg.num_queries; q += n_threads) {
+      try {
+        rcs[q] = verify_query(q);
+        if (rcs[q]) msgs[q] = bp_last_error();
+      } catch (...) {
+        rcs[q] = BP_ERR_DEVICE;
+        msgs[q] = "out of memory while verifying a query";
+      }
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    struct Join {
+      std::vector<std::thread>& p;
+      ~Join() { for (auto& t : p) if (t.joinable()) t.join(); }
+    } join{pool};
+    try {
+      for (uint32_t t = 1; t < n_threads; t++) pool.emplace_back(work, t);
+    } catch (const std::system_error&) {  // no threads to be had: the slices not started are done below
+    }
+    const uint32_t started = (uint32_t)pool.size() + 1;
+    work(0);
+    for (uint32_t t = started; t < n_threads; t++) work(t);
+  }
+  for (uint32_t q = 0; q < cfg.num_queries; q++)
+    if (rcs[q]) return fail(rcs[q], "%s", msgs[q].c_str());
   return BP_OK;
 }
 
