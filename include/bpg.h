@@ -153,8 +153,9 @@ void bp_tune_assume_loaded(int mode);
 void bp_tune_rec_batch(int n);
 /* A prover that is alone on the device (a lone transaction, the last one of a shard) spreads its transaction's seven
  * trace commitments -- which do not depend on each other -- over the streams of up to three idle workers of the state
- * (1, default); 0 = always on the prover's own stream.  Results are identical. */
-void bp_tune_side_lanes(int on);
+ * (1, default); 0 = always on the prover's own stream; n > 1 = also while up to n provers are at work (measured: no gain,
+ * profiles/r5_block_size_series.txt).  Results are identical. */
+void bp_tune_side_lanes(int n);
 /* How the library's prover threads wait for the device: 0 (default) = the runtime's wait where it sleeps
  * (bp_host_wait_mode 1), the library's own poll-and-sleep wait where the runtime's would spin (mode 2: a device the
  * process had already used when the library came to it); 1 = always the runtime's wait; 2 = always poll and sleep. */

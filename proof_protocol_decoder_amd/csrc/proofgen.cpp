@@ -201,7 +201,7 @@ int emit_box(uint64_t kind, uint64_t circuit, const std::vector<uint64_t>& pi, c
 // the state's one recursion shape are proved in lock-step, up to g_rec_batch at a time (stark_prove_batch: every
 // launch and every host wait is shared; circuits, public inputs and transcripts are each proof's own).
 std::atomic<uint32_t> g_rec_batch{MAX_BATCH};  // bp_tune_rec_batch: 1 = one proof at a time
-std::atomic<int> g_side_lanes{1};               // bp_tune_side_lanes: 0 = no side lanes
+std::atomic<int> g_side_lanes{1};               // bp_tune_side_lanes: 0 = no side lanes, n = while at most n provers are at work
 // paths (nullable): per proof the witness of the Merkle paths its circuit walks (Circuit::lay.n_paths of them)
 // first_leaf (nullable, 4 words per proof): the digest of the trace leaf each proof's first query opens
 int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* const* circ, const std::vector<uint64_t>* pi,
@@ -382,7 +382,7 @@ void root_after(const uint64_t root_before[4], uint64_t seed, uint64_t txn_numbe
 extern "C" {
 
 void bp_tune_rec_batch(int n) { g_rec_batch.store(n < 1 ? 1 : (n > (int)MAX_BATCH ? MAX_BATCH : (uint32_t)n)); }
-void bp_tune_side_lanes(int on) { g_side_lanes.store(on ? 1 : 0); }
+void bp_tune_side_lanes(int n) { g_side_lanes.store(n < 0 ? 0 : n); }
 
 void bp_config_default(bp_config* c) {
   // constants.rs:6-18, positional order of prover_state.rs:85-93
@@ -891,7 +891,7 @@ static int prove_tables(const bp_state* s, Worker& w, const uint64_t* I, const T
   // shard -- borrows the streams of up to three idle workers and the commitments overlap: the wide Keccak table's long
   // sponge chains no longer have the chip to themselves (largest first, each to the lane with the least work so far).
   std::vector<std::unique_ptr<SideLane>> sides;
-  if (s && provers_active() <= 1 && g_side_lanes.load(std::memory_order_relaxed))
+  if (s && provers_active() <= g_side_lanes.load(std::memory_order_relaxed))
     for (int k = 0; k < 3; k++) {
       std::unique_ptr<SideLane> l = SideLane::try_acquire(s);
       if (!l) break;
