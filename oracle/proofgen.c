@@ -106,8 +106,16 @@ static circuit_t* get_circuit_leaf(orc_pg_state* s, circuit_t* c, uint64_t seed,
 static circuit_t* table_circuit(orc_pg_state* s, int t, uint32_t d) {
   return get_circuit_depth(s, &s->table[t][d], circuit_seed(t, d), CHAIN_PI, 1, d + s->cfg.stark_rate_bits - s->cfg.stark_cap_height, CHAIN_PATH_AT);
 }
+/* A circuit whose children are recursion-shaped proofs also hashes the row each child opens, where it has the rows for it:
+ * 17 list rows at most, the Merkle rows, ceil(n_cols / 8) leaf rows per path (120 at most), and one arithmetic group of four */
+static unsigned leaf_len_of(const orc_pg_state* s, unsigned n_paths, unsigned depth) {
+  if (s->rec.air_id != ORC_AIR_PLONK || s->rec.n_cols <= 8) return 0;
+  const unsigned lh = (s->rec.n_cols + 7) / 8, rows = 17 + n_paths * depth + n_paths * lh;
+  return (n_paths * lh <= 120 && (rows + 3) / 4 * 4 + 4 <= (1u << s->rec.log_n)) ? s->rec.n_cols : 0;
+}
 static circuit_t* shrink_circuit(orc_pg_state* s, int t) {
-  return get_circuit_depth(s, &s->shrink[t], circuit_seed(t, 255), CHAIN_PI, 1, s->rec.log_n + s->rec.rate_bits - s->rec.cap_height, CHAIN_PATH_AT);
+  const unsigned depth = s->rec.log_n + s->rec.rate_bits - s->rec.cap_height;
+  return get_circuit_leaf(s, &s->shrink[t], circuit_seed(t, 255), CHAIN_PI, 1, depth, CHAIN_PATH_AT, leaf_len_of(s, 1, depth));
 }
 /* The aggregation circuit also walks, per child, the Merkle path of the child's first trace opening (its leaf digest and
  * the cap entry above it: eight more words of the list per child, after the digests and flags); the block circuit walks
@@ -116,13 +124,7 @@ enum { AGG_PATHS_AT = 10, BLOCK_PATH_AT = 9, AGG_PI = 10 + 16 + PV_WORDS, BLOCK_
 static circuit_t* special_circuit(orc_pg_state* s, int k) {
   static const unsigned PI_LEN[3] = {ROOT_PI, AGG_PI, BLOCK_PI}, PATHS[3] = {NUM_TABLES, 2, 1}, AT[3] = {ROOT_PATHS_AT, AGG_PATHS_AT, BLOCK_PATH_AT};
   const unsigned depth = s->rec.log_n + s->rec.rate_bits - s->rec.cap_height;
-  /* the aggregation and block circuits also hash the row each child opens, where the circuit has the rows for it: 17 list
-   * rows at most, the Merkle rows, ceil(n_cols / 8) leaf rows per path, and one arithmetic group of four must fit */
-  unsigned leaf_len = 0;
-  if (k > 0 && s->rec.air_id == ORC_AIR_PLONK && s->rec.n_cols > 8) {
-    const unsigned lh = (s->rec.n_cols + 7) / 8, rows = 17 + PATHS[k] * depth + PATHS[k] * lh;
-    if (PATHS[k] * lh <= 40 && (rows + 3) / 4 * 4 + 4 <= (1u << s->rec.log_n)) leaf_len = s->rec.n_cols;
-  }
+  const unsigned leaf_len = leaf_len_of(s, PATHS[k], depth);
   return get_circuit_leaf(s, &s->special[k], circuit_seed(CIRCUIT_ROOT + k, 0), PI_LEN[k], PATHS[k], depth, AT[k], leaf_len);
 }
 
@@ -575,7 +577,9 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
   if (rc) return rc;
   /* per chain: the digest of its newest proof and that proof's first trace opening (leaf digest, cap entry, path) */
   gl_t digest[NUM_TABLES][4], leaf_cap[NUM_TABLES][8], *path[NUM_TABLES];
-  const size_t rec_path_words = 1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height);
+  /* (a recursion-shaped child's path is followed by its opened row: the shrink and root circuits hash it when they have room) */
+  const size_t rec_sib_words = 1 + 4 * (size_t)(s->rec.log_n + s->rec.rate_bits - s->rec.cap_height);
+  const size_t rec_path_words = rec_sib_words + s->rec.n_cols;
   for (int t = 0; t < NUM_TABLES; t++) {
     const size_t table_path_words = 1 + 4 * (size_t)(tcfg[t].log_n + tcfg[t].rate_bits - tcfg[t].cap_height);
     path[t] = (gl_t*)malloc((table_path_words > rec_path_words ? table_path_words : rec_path_words) * sizeof(gl_t));
@@ -594,15 +598,17 @@ static int pg_txn(orc_pg_state* s, const uint64_t* I, const pg_witness* wit, gl_
       if (!rc) {
         orc_proof_digest(&s->rec, proof, digest[t]);
         orc_proof_first_query_path(&s->rec, proof, leaf_cap[t], leaf_cap[t] + 4, path[t]);
+        orc_proof_first_query_row(&s->rec, proof, path[t] + rec_sib_words);
       }
     }
   }
   if (!rc) {
-    gl_t pi[ROOT_PI], *paths = (gl_t*)malloc(NUM_TABLES * rec_path_words * sizeof(gl_t));
+    const size_t root_path_words = rec_sib_words + special_circuit(s, 0)->leaf_len;
+    gl_t pi[ROOT_PI], *paths = (gl_t*)malloc(NUM_TABLES * root_path_words * sizeof(gl_t));
     for (int t = 0; t < NUM_TABLES; t++) {
       memcpy(pi + 4 * t, digest[t], 32);
       memcpy(pi + ROOT_PATHS_AT + 8 * t, leaf_cap[t], sizeof(leaf_cap[t]));
-      memcpy(paths + t * rec_path_words, path[t], rec_path_words * sizeof(gl_t));
+      memcpy(paths + t * root_path_words, path[t], root_path_words * sizeof(gl_t));
     }
     memcpy(pi + ROOT_PATHS_AT + 8 * NUM_TABLES, pv, sizeof(pv));
     rc = rec_prove(s, special_circuit(s, 0), pi, ROOT_PI, paths, proof);

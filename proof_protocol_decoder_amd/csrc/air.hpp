@@ -1015,7 +1015,7 @@ constexpr uint32_t CST_ARITH = 0, CST_SBOX = 1, CST_C0 = 2, CST_C1 = 3, CST_HASH
 constexpr uint32_t COL_SBOX = 80;
 constexpr uint32_t G0 = 0, G1 = 20, G2 = 64, G3 = 86, G4 = 90, G5 = 208;
 constexpr uint32_t HASH_ROW0 = 4, HASH_ROWS_MAX = 13, ZERO_ROW = 1, MAX_PI = 8 * HASH_ROWS_MAX;
-constexpr uint32_t MERKLE_ROW0 = HASH_ROW0 + HASH_ROWS_MAX, MERKLE_ROWS_MAX = 96, MERKLE_ZERO_COL = 79, LEAF_ROWS_MAX = 40;
+constexpr uint32_t MERKLE_ROW0 = HASH_ROW0 + HASH_ROWS_MAX, MERKLE_ROWS_MAX = 96, MERKLE_ZERO_COL = 79, LEAF_ROWS_MAX = 120;
 constexpr uint32_t H_IN = 0, H_OUT = 12, H_FULL1 = 24, H_PART = 60, H_FULL2 = 82, H_SWAP = 130, H_DELTA = 131, H_WIRES = 135;
 // What a circuit of this family does besides its arithmetic groups: it hashes a public-input list of pi_len words
 // (rows 4 ..), and it walks n_paths Merkle paths of `depth` levels each (rows 12 ..): path p's leaf digest is list words

@@ -220,38 +220,85 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
     Ctl ctl[MAX_BATCH];
     const uint64_t* d_tv[MAX_BATCH];
     const Committed* consts[MAX_BATCH];
-    std::vector<uint64_t> rows;
+    // The witness of every proof's Poseidon rows is made on the host (prover.hpp): per proof the sponge over its list, per
+    // path the Merkle rows and -- where the circuit hashes its leaves -- the sponge over the opened row.  The pieces are
+    // independent; a prover that is alone on the device (a lone transaction: this is its critical path) makes them on up
+    // to seven threads.
+    uint64_t pi_hashes[MAX_BATCH][4];
+    struct Job {
+      uint32_t b, kind, p;  // kind 0: the list's rows, 1: path p's Merkle rows, 2: path p's leaf rows
+    };
+    std::vector<Job> jobs;
     for (uint32_t b = 0; b < B; b++) {
       const Circuit& c = *circ[first + b];
-      // the hash of the public-input list, with the witness of the circuit's own computation of it (its hash rows)
-      uint64_t pi_hash[4];
       const size_t n_pi = pi[first + b].size();
-      if (rc.air_id == air::PLONK) {
-        if (n_pi < 1 || n_pi > air::plonk::MAX_PI) return fail(BP_ERR_INVALID_INPUT, "a recursion circuit hashes 1..%u public inputs: got %zu", air::plonk::MAX_PI, n_pi);
-        if (n_pi != c.lay.pi_len) return fail(BP_ERR_INVALID_INPUT, "this circuit hashes a list of %u public inputs: got %zu", c.lay.pi_len, n_pi);
-        poseidon_hash_rows(pi[first + b].data(), n_pi, &rows, pi_hash);
-        uint64_t* hr = w.hash_rows + (size_t)b * HASH_ROWS_WORDS;
-        std::memcpy(hr, rows.data(), rows.size() * 8);
-        if (c.lay.n_paths) {  // the children's Merkle paths, walked on the host the way the circuit's rows walk them
-          if (!paths || paths[first + b].size() != c.lay.n_paths) return fail(BP_ERR_INVALID_INPUT, "this circuit walks %u Merkle paths: their witness is missing", c.lay.n_paths);
-          for (uint32_t p = 0; p < c.lay.n_paths; p++) {
-            const PathWitness& pw = paths[first + b][p];
-            if (pw.siblings.size() != 4 * (size_t)c.lay.depth) return fail(BP_ERR_INVALID_INPUT, "Merkle path %u: %zu sibling words for %u levels", p, pw.siblings.size(), c.lay.depth);
-            uint64_t root[4];  // (not compared with the list's cap entry here: the copy constraints do that, and the verifier)
-            poseidon_merkle_rows(&pi[first + b][c.lay.path_pi0 + 8 * p], pw.index, pw.siblings.data(), c.lay.depth,
-                                 hr + (size_t)(air::plonk::HASH_ROWS_MAX + p * c.lay.depth) * air::plonk::H_WIRES, root);
-            if (c.lay.leaf_len) {  // ... and the sponge over the opened row that the leaf digest is the hash of
-              if (pw.leaf_row.size() != c.lay.leaf_len) return fail(BP_ERR_INVALID_INPUT, "Merkle path %u: the circuit hashes a leaf of %u words, %zu given", p, c.lay.leaf_len, pw.leaf_row.size());
-              uint64_t leaf_digest[4];
-              poseidon_hash_rows(pw.leaf_row.data(), c.lay.leaf_len, &rows, leaf_digest);
-              std::memcpy(hr + (size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::merkle_rows(c.lay) + p * air::plonk::hash_rows(c.lay.leaf_len)) * air::plonk::H_WIRES,
-                          rows.data(), rows.size() * 8);
-            }
-          }
-        }
-      } else {
-        hash_no_pad_host(pi[first + b].data(), n_pi, pi_hash);
+      if (rc.air_id != air::PLONK) {
+        hash_no_pad_host(pi[first + b].data(), n_pi, pi_hashes[b]);
+        continue;
       }
+      if (n_pi < 1 || n_pi > air::plonk::MAX_PI) return fail(BP_ERR_INVALID_INPUT, "a recursion circuit hashes 1..%u public inputs: got %zu", air::plonk::MAX_PI, n_pi);
+      if (n_pi != c.lay.pi_len) return fail(BP_ERR_INVALID_INPUT, "this circuit hashes a list of %u public inputs: got %zu", c.lay.pi_len, n_pi);
+      jobs.push_back(Job{b, 0, 0});
+      if (c.lay.n_paths) {
+        if (!paths || paths[first + b].size() != c.lay.n_paths) return fail(BP_ERR_INVALID_INPUT, "this circuit walks %u Merkle paths: their witness is missing", c.lay.n_paths);
+        for (uint32_t p = 0; p < c.lay.n_paths; p++) {
+          const PathWitness& pw = paths[first + b][p];
+          if (pw.siblings.size() != 4 * (size_t)c.lay.depth) return fail(BP_ERR_INVALID_INPUT, "Merkle path %u: %zu sibling words for %u levels", p, pw.siblings.size(), c.lay.depth);
+          if (c.lay.leaf_len && pw.leaf_row.size() != c.lay.leaf_len) return fail(BP_ERR_INVALID_INPUT, "Merkle path %u: the circuit hashes a leaf of %u words, %zu given", p, c.lay.leaf_len, pw.leaf_row.size());
+          jobs.push_back(Job{b, 1, p});
+          if (c.lay.leaf_len) jobs.push_back(Job{b, 2, p});
+        }
+      }
+    }
+    auto run_job = [&](const Job& j) {
+      const Circuit& c = *circ[first + j.b];
+      uint64_t* hr = w.hash_rows + (size_t)j.b * HASH_ROWS_WORDS;
+      std::vector<uint64_t> rows;
+      if (j.kind == 0) {  // the hash of the public-input list, with the witness of the circuit's own computation of it
+        poseidon_hash_rows(pi[first + j.b].data(), pi[first + j.b].size(), &rows, pi_hashes[j.b]);
+        std::memcpy(hr, rows.data(), rows.size() * 8);
+      } else if (j.kind == 1) {  // a child's Merkle path, walked the way the circuit's rows walk it
+        const PathWitness& pw = paths[first + j.b][j.p];
+        uint64_t root[4];  // (not compared with the list's cap entry here: the copy constraints do that, and the verifier)
+        poseidon_merkle_rows(&pi[first + j.b][c.lay.path_pi0 + 8 * j.p], pw.index, pw.siblings.data(), c.lay.depth,
+                             hr + (size_t)(air::plonk::HASH_ROWS_MAX + j.p * c.lay.depth) * air::plonk::H_WIRES, root);
+      } else {  // the sponge over the opened row that the leaf digest is the hash of
+        const PathWitness& pw = paths[first + j.b][j.p];
+        uint64_t leaf_digest[4];
+        poseidon_hash_rows(pw.leaf_row.data(), c.lay.leaf_len, &rows, leaf_digest);
+        std::memcpy(hr + (size_t)(air::plonk::HASH_ROWS_MAX + air::plonk::merkle_rows(c.lay) + j.p * air::plonk::hash_rows(c.lay.leaf_len)) * air::plonk::H_WIRES,
+                    rows.data(), rows.size() * 8);
+      }
+    };
+    {
+      const uint32_t n_threads = (provers_active() <= 1 && jobs.size() >= 4) ? (uint32_t)std::min<size_t>(7, jobs.size()) : 1;
+      std::atomic<size_t> next{0};
+      std::atomic<bool> oom{false};
+      auto drain = [&] {
+        try {
+          for (size_t k; (k = next.fetch_add(1)) < jobs.size();) run_job(jobs[k]);
+        } catch (...) {
+          oom.store(true);
+        }
+      };
+      std::vector<std::thread> pool;
+      struct Join {
+        std::vector<std::thread>& p;
+        ~Join() { for (auto& t : p) if (t.joinable()) t.join(); }
+      } join{pool};
+      try {
+        for (uint32_t t = 1; t < n_threads; t++) pool.emplace_back(drain);
+      } catch (const std::system_error&) {  // no thread to be had: this one does the rest
+      }
+      drain();
+      for (auto& t : pool) t.join();
+      pool.clear();
+      if (oom.load()) return fail(BP_ERR_DEVICE, "out of memory while making the witness of the Poseidon rows");
+    }
+    for (uint32_t b = 0; b < B; b++) {
+      const Circuit& c = *circ[first + b];
+      const uint64_t* pi_hash = pi_hashes[b];
+      const size_t n_pi = pi[first + b].size();
       ch[b].observe(c.digest, 4);
       ch[b].observe(pi_hash, 4);
       d_tv[b] = d_trace + (size_t)b * rc.n_cols * N;
@@ -259,7 +306,7 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
       pa[b] = PlonkTraceArgs{d_trace + (size_t)b * rc.n_cols * N, c.d_const_values, pi_hash[0], {pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]},
                              w.hash_rows_dev + (size_t)b * HASH_ROWS_WORDS, (uint32_t)((n_pi + 7) / 8),
                              air::plonk::merkle_rows(c.lay) + air::plonk::leaf_rows(c.lay), air::plonk::arith_row0(c.lay)};
-      if (rc.air_id == air::PLONK) std::memcpy(ctl[b].pub, pi_hash, sizeof(pi_hash));  // bound to the circuit's first row
+      if (rc.air_id == air::PLONK) std::memcpy(ctl[b].pub, pi_hash, 32);  // bound to the circuit's first row
       consts[b] = &c.consts;
     }
     int r = rc.air_id == air::PLONK ? launch_plonk_trace(pa, B, rc.log_n, w.stream)
@@ -468,20 +515,21 @@ int bp_state_build(const bp_config* cfg, bp_state** out) try {
   // Every recursion circuit walks one Merkle path per child: root (seven chains), aggregation (two children: their
   // paths' words follow the digests and flags), block (the aggregation child's), a table's shrink circuit (the level below)
   const uint32_t depth = rc.log_n + rc.rate_bits - rc.cap_height;
+  // Every circuit whose children are recursion-shaped proofs (all but level 0 of a chain, whose child is a table's STARK
+  // proof of up to 2432 columns) also HASHES the row each child opens (its leaf: the child's n_cols trace values) before
+  // it walks up from it -- merkle_proofs::verify_merkle_proof_to_cap whole -- where the circuit has the rows for it (a
+  // 2^6-row test circuit has them for one child, not for seven: both sides take the same decision from the shape alone)
+  auto with_leaf = [&](air::plonk::Layout lay) {
+    air::plonk::Layout l = lay;
+    l.leaf_len = rc.n_cols;
+    return (rc.air_id == air::PLONK && air::plonk::layout_ok(l, 1u << rc.log_n)) ? l : lay;
+  };
   for (int t = 0; t < BP_NUM_TABLES; t++)
-    if ((r = build_circuit(s->builder, rc, circuit_seed(t, SHRINK_SEED_DEGREE), air::plonk::Layout{CHAIN_PATH_PI0 + 8, 1, depth, CHAIN_PATH_PI0},
+    if ((r = build_circuit(s->builder, rc, circuit_seed(t, SHRINK_SEED_DEGREE), with_leaf(air::plonk::Layout{CHAIN_PATH_PI0 + 8, 1, depth, CHAIN_PATH_PI0}),
                            &s->shrink_circuits[t]))) return r;
-  // The aggregation and block circuits also HASH the row each child opens (its leaf: the child's n_cols trace values)
-  // before they walk up from it -- merkle_proofs::verify_merkle_proof_to_cap whole -- where the circuit has the rows for it
-  // (a 2^6-row test circuit has not: both sides take the same decision from the shape alone)
-  air::plonk::Layout special[3] = {{ROOT_PATH_PI0 + 8 * BP_NUM_TABLES + BP_PV_WORDS, BP_NUM_TABLES, depth, ROOT_PATH_PI0},
-                                   {AGG_PATH_PI0 + 2 * 8 + BP_PV_WORDS, 2, depth, AGG_PATH_PI0},
-                                   {BLOCK_PATH_PI0 + 8 + BP_PV_WORDS, 1, depth, BLOCK_PATH_PI0}};
-  for (uint32_t k = 1; k < 3; k++) {
-    air::plonk::Layout with_leaf = special[k];
-    with_leaf.leaf_len = rc.n_cols;
-    if (rc.air_id == air::PLONK && air::plonk::layout_ok(with_leaf, 1u << rc.log_n)) special[k] = with_leaf;
-  }
+  air::plonk::Layout special[3] = {with_leaf({ROOT_PATH_PI0 + 8 * BP_NUM_TABLES + BP_PV_WORDS, BP_NUM_TABLES, depth, ROOT_PATH_PI0}),
+                                   with_leaf({AGG_PATH_PI0 + 2 * 8 + BP_PV_WORDS, 2, depth, AGG_PATH_PI0}),
+                                   with_leaf({BLOCK_PATH_PI0 + 8 + BP_PV_WORDS, 1, depth, BLOCK_PATH_PI0})};
   for (uint32_t k = 0; k < 3; k++)
     if ((r = build_circuit(s->builder, rc, circuit_seed(CIRCUIT_ROOT + k, 0), special[k], &s->special[k]))) return r;
   BPG_HIP(hipStreamSynchronize(s->builder.stream));

@@ -34,7 +34,8 @@ CIRCUITS = [(5, 4, 0, 0, 0, 0), (8, 6, 0, 0, 0, 0), (13, 41, 0, 0, 0, 0), (6, 23
             (13, 14, 1, 14, 6, 0), (13, 14, 1, 27, 6, 0), (6, 39, 2, 5, 10, 0), (7, 64, 2, 32, 40, 0), (7, 104, 3, 32, 80, 0),
             (5, 17, 1, 1, 3, 0),
             # the aggregation / block circuits of the default shape: they hash the 135-word rows their paths start from
-            (13, 39, 2, 12, 10, 135), (13, 30, 1, 12, 9, 135), (7, 39, 2, 5, 10, 19), (7, 30, 1, 7, 9, 135)]
+            (13, 39, 2, 12, 10, 135), (13, 30, 1, 12, 9, 135), (7, 39, 2, 5, 10, 19), (7, 30, 1, 7, 9, 135),
+            (13, 97, 7, 12, 28, 135), (13, 14, 1, 12, 6, 135), (6, 14, 1, 5, 6, 135)]   # ... the root and shrink circuits too
 
 
 @pytest.mark.parametrize("log_n,pi_len,n_paths,depth,path_pi0,leaf_len", CIRCUITS)
