@@ -156,6 +156,10 @@ void bp_tune_rec_batch(int n);
  * (1, default); 0 = always on the prover's own stream; n > 1 = also while up to n provers are at work (measured: no gain,
  * profiles/r5_block_size_series.txt).  Results are identical. */
 void bp_tune_side_lanes(int n);
+/* The witness of a recursion circuit's Poseidon rows (the sponge over its public-input list, its children's Merkle paths,
+ * the sponges over their opened rows: independent pieces) is made on the host; a prover that is alone on the device makes
+ * the pieces of a lock-step batch on up to n threads (default 7; 1 = on the prover's own thread).  Results are identical. */
+void bp_tune_witness_threads(int n);
 /* How the library's prover threads wait for the device: 0 (default) = the runtime's wait where it sleeps
  * (bp_host_wait_mode 1), the library's own poll-and-sleep wait where the runtime's would spin (mode 2: a device the
  * process had already used when the library came to it); 1 = always the runtime's wait; 2 = always poll and sleep. */

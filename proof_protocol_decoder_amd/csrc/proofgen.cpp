@@ -201,6 +201,7 @@ int emit_box(uint64_t kind, uint64_t circuit, const std::vector<uint64_t>& pi, c
 // the state's one recursion shape are proved in lock-step, up to g_rec_batch at a time (stark_prove_batch: every
 // launch and every host wait is shared; circuits, public inputs and transcripts are each proof's own).
 std::atomic<uint32_t> g_rec_batch{MAX_BATCH};  // bp_tune_rec_batch: 1 = one proof at a time
+std::atomic<int> g_witness_threads{7};           // bp_tune_witness_threads: host threads a lone prover makes its Poseidon-row witness on
 std::atomic<int> g_side_lanes{1};               // bp_tune_side_lanes: 0 = no side lanes, n = while at most n provers are at work
 // paths (nullable): per proof the witness of the Merkle paths its circuit walks (Circuit::lay.n_paths of them)
 // first_leaf (nullable, 4 words per proof): the digest of the trace leaf each proof's first query opens
@@ -271,7 +272,8 @@ int rec_prove_batch(Worker& w, const StarkCfg& rc, uint32_t n, const Circuit* co
       }
     };
     {
-      const uint32_t n_threads = (provers_active() <= 1 && jobs.size() >= 4) ? (uint32_t)std::min<size_t>(7, jobs.size()) : 1;
+      const uint32_t max_threads = (uint32_t)std::max(1, g_witness_threads.load(std::memory_order_relaxed));
+      const uint32_t n_threads = (provers_active() <= 1 && jobs.size() >= 4) ? (uint32_t)std::min<size_t>(max_threads, jobs.size()) : 1;
       std::atomic<size_t> next{0};
       std::atomic<bool> oom{false};
       auto drain = [&] {
@@ -430,6 +432,7 @@ extern "C" {
 
 void bp_tune_rec_batch(int n) { g_rec_batch.store(n < 1 ? 1 : (n > (int)MAX_BATCH ? MAX_BATCH : (uint32_t)n)); }
 void bp_tune_side_lanes(int n) { g_side_lanes.store(n < 0 ? 0 : n); }
+void bp_tune_witness_threads(int n) { g_witness_threads.store(n < 1 ? 1 : (n > 16 ? 16 : n)); }
 
 void bp_config_default(bp_config* c) {
   // constants.rs:6-18, positional order of prover_state.rs:85-93

@@ -80,7 +80,7 @@ def test_constants_and_witness_match_oracle(bpg, oracle, log_n, pi_len, n_paths,
 def test_layouts_that_do_not_fit_are_refused(bpg):
     from proof_protocol_decoder_amd._lib import BpgError
     for log_n, lay in ((5, (39, 2, 12, 10)), (13, (39, 2, 12, 32)), (13, (105, 0, 0, 0)), (13, (39, 4, 30, 0)), (13, (0, 0, 0, 0)), (4, (4, 0, 0, 0)),
-                       (13, (39, 2, 12, 10, 8)), (13, (39, 0, 0, 0, 135)), (13, (39, 2, 12, 10, 400)), (6, (39, 2, 5, 10, 135))):
+                       (13, (39, 2, 12, 10, 8)), (13, (39, 0, 0, 0, 135)), (13, (39, 2, 12, 10, 500)), (6, (39, 2, 5, 10, 135))):
         with pytest.raises(BpgError):
             dev_constants(bpg, log_n, 1, *lay)
 

@@ -19,6 +19,9 @@ real = "--real-airs" in sys.argv
 L = pkg.lib()
 L.bp_use_blocking_sync(0)
 one = "--one-worker" in sys.argv
+for a in sys.argv:   # --witness-threads=N: bp_tune_witness_threads (default 7; 1 = the prover's own thread)
+    if a.startswith("--witness-threads="):
+        L.bp_tune_witness_threads(int(a.split("=")[1]))
 st = pg.ProverStateBuilder().set(device=0, n_workers=1 if one else 4, arena_bytes=6 << 30).build()
 irs = synthetic_block_irs(2000, reps + 1, S1_LOG_N, S1_WIDTH, keccak_air=real, logic_air=real, memory_air=real,
                           arithmetic_air=real, byte_packing_air=real, keccak_sponge_air=real)
