@@ -11,6 +11,21 @@ HIPCC_FLAGS = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "proof_prot
                               "print-hip-flags"], check=True, capture_output=True, text=True).stdout.split()
 
 
+_ASM_CACHE = {}
+
+
+def device_assembly(src, tmp_path):
+    """The gfx950 assembly of csrc/<src> (hipcc -S, device only), compiled once per test session: three scanners read it."""
+    if src not in _ASM_CACHE:
+        csrc = os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc")
+        out = tmp_path / (src + ".s")
+        subprocess.run(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-S", "--cuda-device-only",
+                        "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(csrc, src)],
+                       check=True, capture_output=True)
+        _ASM_CACHE[src] = out.read_text()
+    return _ASM_CACHE[src]
+
+
 def test_build_entry_compiles_everything():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
@@ -34,12 +49,9 @@ def test_no_throughput_kernel_spills_sgprs(tmp_path):
     csrc = os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc")
     bad, scratch = [], []
     for src in ("hash_kernels.hip", "ntt.hip", "stark_kernels.hip"):
-        out = tmp_path / (src + ".s")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-S", "--cuda-device-only",
-                        "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(csrc, src)],
-                       check=True, capture_output=True)
+        asm_text = device_assembly(src, tmp_path)
         name = None
-        for line in out.read_text().splitlines():
+        for line in asm_text.splitlines():
             m = re.match(r"\s+\.name:\s+(\S+)", line)
             if m:
                 name = m.group(1)
@@ -87,14 +99,11 @@ def test_no_dpp_reads_a_fresh_asm_result(tmp_path):
     csrc = os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc")
     bad = []
     for src in ("hash_kernels.hip", "stark_kernels.hip"):
-        out = tmp_path / (src + ".s")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-S", "--cuda-device-only",
-                        "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(csrc, src)],
-                       check=True, capture_output=True)
+        asm_text = device_assembly(src, tmp_path)
         in_asm = False
         recent = []  # (wait states since, regs written inside asm)
         n_dpp = 0
-        for ln, line in enumerate(out.read_text().splitlines(), 1):
+        for ln, line in enumerate(asm_text.splitlines(), 1):
             t = line.strip()
             if t.startswith(";ASMSTART") or t.startswith("; ASMSTART") or "ASMSTART" in t and t.startswith(";"):
                 in_asm = True
@@ -243,11 +252,8 @@ def test_no_valu_reads_a_fresh_asm_carry_mask(tmp_path):
     csrc = os.path.join(ROOT, "proof_protocol_decoder_amd", "csrc")
     bad, n_asm_writes = [], 0
     for src in ("hash_kernels.hip", "ntt.hip", "stark_kernels.hip"):
-        out = tmp_path / (src + ".s")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-S", "--cuda-device-only",
-                        "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(csrc, src)],
-                       check=True, capture_output=True)
-        b, n = scan_carry_mask_hazards(out.read_text())
+        asm_text = device_assembly(src, tmp_path)
+        b, n = scan_carry_mask_hazards(asm_text)
         bad += [(src,) + x for x in b]
         n_asm_writes += n
     assert n_asm_writes > 1000, "scanner found only %d carry-mask writes inside asm: is it still parsing?" % n_asm_writes
