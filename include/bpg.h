@@ -424,7 +424,7 @@ typedef struct bp_config {
   /* CircuitConfig::standard_recursion_config() shaped proofs: 2^13 rows x 135 wires, rate_bits 3, 28 queries; 84
    * preprocessed constant columns (4 gate constants + 80 sigmas) for the PLONK-shaped circuit, which is the default */
   uint32_t rec_log_n, rec_n_cols, rec_n_const, rec_rate_bits, rec_num_queries, rec_pow_bits;
-  uint32_t shrink_depth; /* recursion-shaped proofs per table before the root (3) */
+  uint32_t shrink_depth; /* recursion-shaped proofs per table before the root (3; at least 1: the root circuit walks paths of the recursion shape) */
   uint32_t rec_air_id;   /* what the recursion-shaped proofs are proofs OF: 0 = the synthetic AIR on rec_n_cols x rec_n_const
                           * columns (rounds 1-3; 82 constants); 8 (default) = the PLONK-shaped circuit of AIR 8 (csrc/air.hpp: gates by constants,
                           * public inputs bound in-circuit, copy constraints by the permutation argument), which needs
